@@ -1,0 +1,191 @@
+# -*- coding: utf-8 -*-
+"""oracle/dense.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Dense-linear-algebra oracle and deterministic input recipes.  This is exactly
+the ground truth the reference's own tests use (there are no stored golden
+vectors upstream): build the dense kernel matrix from the closed-form kernel,
+then compare against numpy Cholesky / triangular products.
+
+Reference citations (paths relative to /root/reference):
+  * kernel value k(tau)             python/celerite2/terms.py:58-79, c++/test/test_to_dense.cpp:27-38
+  * celerite matrices (a,U,V,c)     python/celerite2/driver.cpp:456-474, python/celerite2/terms.py:171-173
+  * SHOTerm coefficients            python/celerite2/terms.py:658-691
+  * RealTerm / ComplexTerm          python/celerite2/terms.py:515-521, 554-569
+  * Matern32Term                    python/celerite2/terms.py:729-745
+  * python test inputs              python/celerite2/testing.py:10-49
+  * C++ test inputs and kernels     c++/test/helpers.hpp:14-62
+"""
+import numpy as np
+
+__all__ = [
+    "Coeffs", "real_term", "complex_term", "sho_term", "matern32_term", "term_sum",
+    "kernel_value", "dense_matrix", "celerite_matrices", "get_matrices", "cpp_test_data",
+    "cpp_test_kernels", "dense_loglik", "synthetic_batch", "sho_sum_coeffs",
+]
+
+
+class Coeffs:
+    """(ar, cr, ac, bc, cc, dc) coefficient lists of a celerite term."""
+
+    def __init__(self, ar=(), cr=(), ac=(), bc=(), cc=(), dc=()):
+        f = lambda x: np.atleast_1d(np.asarray(x, dtype=np.float64)).reshape(-1)
+        self.ar, self.cr, self.ac, self.bc, self.cc, self.dc = map(f, (ar, cr, ac, bc, cc, dc))
+
+    @property
+    def J(self):
+        return len(self.ar) + 2 * len(self.ac)
+
+    def __add__(self, other):  # TermSum concatenates coefficient lists (terms.py:233-235)
+        return Coeffs(*[np.concatenate([x, y]) for x, y in zip(self.tuple(), other.tuple())])
+
+    def tuple(self):
+        return (self.ar, self.cr, self.ac, self.bc, self.cc, self.dc)
+
+
+def real_term(a, c):
+    return Coeffs(ar=[a], cr=[c])
+
+
+def complex_term(a, b, c, d):
+    return Coeffs(ac=[a], bc=[b], cc=[c], dc=[d])
+
+
+def sho_term(S0, w0, Q, eps=1e-5):
+    """terms.py:658-691 (overdamped -> 2 real terms, underdamped -> 1 complex term)."""
+    if Q < 0.5:
+        f = np.sqrt(max(1.0 - 4.0 * Q**2, eps))
+        return Coeffs(
+            ar=0.5 * S0 * w0 * Q * np.array([1.0 + 1.0 / f, 1.0 - 1.0 / f]),
+            cr=0.5 * w0 / Q * np.array([1.0 - f, 1.0 + f]),
+        )
+    f = np.sqrt(max(4.0 * Q**2 - 1.0, eps))
+    a = S0 * w0 * Q
+    c = 0.5 * w0 / Q
+    return Coeffs(ac=[a], bc=[a / f], cc=[c], dc=[c * f])
+
+
+def matern32_term(sigma, rho, eps=0.01):
+    w0 = np.sqrt(3.0) / rho
+    S0 = sigma**2 / w0
+    return Coeffs(ac=[w0 * S0], bc=[w0 * w0 * S0 / eps], cc=[w0], dc=[eps])
+
+
+def term_sum(*terms):
+    out = terms[0]
+    for t in terms[1:]:
+        out = out + t
+    return out
+
+
+def kernel_value(co, tau):
+    """k(tau) = sum_r ar e^{-cr|tau|} + sum_c e^{-cc|tau|}(ac cos(dc|tau|) + bc sin(dc|tau|))."""
+    tau = np.abs(np.asarray(tau, dtype=np.float64))[..., None]
+    k = np.sum(co.ar * np.exp(-co.cr * tau), axis=-1)
+    k = k + np.sum(np.exp(-co.cc * tau) * (co.ac * np.cos(co.dc * tau) + co.bc * np.sin(co.dc * tau)), axis=-1)
+    return k
+
+
+def dense_matrix(co, x, diag):
+    K = kernel_value(co, x[:, None] - x[None, :])
+    K[np.diag_indices_from(K)] += diag
+    return K
+
+
+def celerite_matrices(co, x, diag):
+    """numpy restatement of driver.cpp:456-474 + the c layout of terms.py:171-173."""
+    x = np.asarray(x, dtype=np.float64)
+    N, Jr, Jc = len(x), len(co.ar), len(co.ac)
+    J = Jr + 2 * Jc
+    c = np.empty(J)
+    c[:Jr] = co.cr
+    c[Jr::2] = co.cc
+    c[Jr + 1::2] = co.cc
+    a = diag + np.sum(co.ar) + np.sum(co.ac)
+    U = np.empty((N, J))
+    V = np.empty((N, J))
+    U[:, :Jr] = co.ar
+    V[:, :Jr] = 1.0
+    arg = co.dc[None, :] * x[:, None]
+    cs, sn = np.cos(arg), np.sin(arg)
+    V[:, Jr::2] = cs
+    V[:, Jr + 1::2] = sn
+    U[:, Jr::2] = co.ac * cs + co.bc * sn
+    U[:, Jr + 1::2] = co.ac * sn - co.bc * cs
+    return c, np.ascontiguousarray(a), np.ascontiguousarray(U), np.ascontiguousarray(V)
+
+
+def get_matrices(size=100, kernel=None, vector=False, conditional=False, include_dense=False, no_diag=False):
+    """The reference's python test-input recipe (python/celerite2/testing.py:10-49)."""
+    random = np.random.default_rng(721)
+    x = np.sort(random.uniform(0, 10, size))
+    if vector:
+        Y = np.sin(x)
+    else:
+        Y = np.ascontiguousarray(np.vstack([np.sin(x), np.cos(x), x**2]).T, dtype=np.float64)
+    if no_diag:
+        diag = np.zeros_like(x)
+    else:
+        diag = random.uniform(0.1, 0.3, len(x))
+    kernel = kernel if kernel is not None else sho_term(S0=5.0, w0=0.1, Q=3.45)
+    c, a, U, V = celerite_matrices(kernel, x, diag)
+    out = dict(x=x, c=c, a=a, U=U, V=V, Y=Y, diag=diag, kernel=kernel)
+    if include_dense:
+        out["K"] = dense_matrix(kernel, x, diag)
+    if conditional:
+        t = np.sort(random.uniform(-1, 12, 200))
+        _, _, U2, V2 = celerite_matrices(kernel, t, np.zeros_like(t))
+        out.update(t=t, U2=U2, V2=V2)
+        if include_dense:
+            out["K_star"] = kernel_value(kernel, t[:, None] - x[None, :])
+    return out
+
+
+def cpp_test_data(N=50, Nrhs=5):
+    """c++/test/helpers.hpp:14-24."""
+    delta = np.arange(N, dtype=np.float64) / (N - 1)
+    x = 10 * delta + delta * delta
+    diag = np.full(N, 0.5)
+    Y = np.sin(x[:, None] + np.arange(Nrhs, dtype=np.float64)[None, :] / Nrhs)
+    return x, diag, np.ascontiguousarray(Y)
+
+
+def cpp_test_kernels():
+    """c++/test/helpers.hpp:27-62 (true sums; not the operator+ slip at terms.hpp:160-162)."""
+    real = real_term(1.0, 0.1)
+    cplx = complex_term(0.8, 0.03, 1.0, 0.1)
+    sho1 = sho_term(1.2, 0.3, 0.1)
+    sho2 = sho_term(0.1, 1.3, 5.3)
+    return {
+        "real": real, "complex": cplx, "sho1": sho1, "sho2": sho2,
+        "sum1": real + cplx, "sum2": real + cplx + sho1, "sum3": real + cplx + sho1 + sho2, "sum4": sho1 + sho2,
+    }
+
+
+def dense_loglik(K, y):
+    """-0.5 (y^T K^-1 y + log det K + N log 2 pi)."""
+    L = np.linalg.cholesky(K)
+    alpha = np.linalg.solve(L, y)
+    return -0.5 * (alpha @ alpha) - np.sum(np.log(np.diag(L))) - 0.5 * len(y) * np.log(2 * np.pi)
+
+
+def sho_sum_coeffs(J, xi=0.0):
+    """Sum of J/2 underdamped SHO terms: S0=5*0.7^k, w0=0.1*3^k*(1+0.05 xi), Q=3.45+k.
+    k=0, xi=0 is exactly the reference test kernel SHOTerm(S0=5, w0=0.1, Q=3.45) (testing.py:30)."""
+    assert J % 2 == 0
+    terms = [sho_term(5.0 * 0.7**k, 0.1 * 3.0**k * (1.0 + 0.05 * xi), 3.45 + k) for k in range(J // 2)]
+    return term_sum(*terms)
+
+
+def synthetic_batch(B, N, J, seed0=721):
+    """Synthetic batch of independent GPs: per-series default_rng(seed0+b),
+    t = sort(U(0, N/10)), diag ~ U(0.1, 0.3), y = sin t + 0.1 eps, kernel = sho_sum_coeffs(J, xi_b)."""
+    t = np.empty((B, N)); c = np.empty((B, J)); a = np.empty((B, N))
+    U = np.empty((B, N, J)); V = np.empty((B, N, J)); y = np.empty((B, N))
+    for b in range(B):
+        rng = np.random.default_rng(seed0 + b)
+        t[b] = np.sort(rng.uniform(0, N / 10.0, N))
+        diag = rng.uniform(0.1, 0.3, N)
+        xi = rng.uniform(-1, 1)
+        y[b] = np.sin(t[b]) + 0.1 * rng.standard_normal(N)
+        c[b], a[b], U[b], V[b] = celerite_matrices(sho_sum_coeffs(J, xi), t[b], diag)
+    return t, c, a, U, V, y

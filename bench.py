@@ -1,0 +1,173 @@
+# -*- coding: utf-8 -*-
+"""bench.py -- headline benchmark: batched float64 GP log-likelihood + gradient per second at
+N=4096, J=8 (BASELINE.json metric; configs[2] sharded: 8192 series per GPU, weak scaling -- at 8 GPUs
+this is exactly "batch 65536 sharded across 8 x MI355X").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (fused log-lik + reverse-mode gradient w.r.t. t, c, a, U, V, y)
+over the rank's shard of independent series, inputs already resident in HBM, followed for N>1 by the one
+real exchange of the path: an RCCL all-gather of the per-rank log-likelihood vector.  Rank 0 prints ONE
+JSON line.  `roofline` prices the step against the HBM roofline with the ALGORITHMIC bytes of SURVEY.md
+section 8(d) (each input read once, each output written once: 16(3+2J) B per time step per series);
+`cpu_baseline` times the CPU restatement (oracle/, "port" -- the Eigen reference is unbuildable here) on a
+bounded sample of the same workload on the host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes_per_gp(N, J, grad):
+    """fwd N*8(3+2J)+8J+8 ; fwd+grad N*16(3+2J)+16J+8."""
+    return N * 16 * (3 + 2 * J) + 16 * J + 8 if grad else N * 8 * (3 + 2 * J) + 8 * J + 8
+
+
+def cpu_baseline(N, J, grad, seconds):
+    """Time the CPU restatement on a bounded sample of the same synthetic workload."""
+    import numpy as np
+
+    from oracle import cpu, dense
+
+    cpu.build()
+    cores = os.cpu_count() or 1
+    nthreads = min(cores, cpu.num_threads()) or 1
+    # build matrices on the host with the numpy recipe (this is the checker side)
+    def mats(first, count):
+        T, C, A, U, V, Y = dense.synthetic_batch(count, N, J, seed0=721 + first)
+        return T, C, A, U, V, Y
+    fn = cpu.loglik_grad_batched if grad else cpu.loglik_batched
+    T, C, A, U, V, Y = mats(0, 2)
+    t0 = time.perf_counter(); fn(T, C, A, U, V, Y, nthreads=1); per = (time.perf_counter() - t0) / 2
+    # sample sized for ~`seconds` of all-core work, at least 4 series per thread
+    count = int(max(4 * nthreads, min(64 * nthreads, seconds * nthreads / max(per, 1e-6))))
+    T, C, A, U, V, Y = mats(0, count)
+    fn(T[:nthreads], C[:nthreads], A[:nthreads], U[:nthreads], V[:nthreads], Y[:nthreads], nthreads=nthreads)  # warm
+    t0 = time.perf_counter(); fn(T, C, A, U, V, Y, nthreads=nthreads); dt_all = time.perf_counter() - t0
+    n1 = max(2, min(count, int(0.3 * seconds / max(per, 1e-6))))
+    t0 = time.perf_counter(); fn(T[:n1], C[:n1], A[:n1], U[:n1], V[:n1], Y[:n1], nthreads=1); dt_1 = time.perf_counter() - t0
+    return {
+        "value": count / dt_all, "unit": "GP/s", "cores": nthreads, "kind": "port",
+        "sample": "%d series of N=%d J=%d (%s), CPU restatement of celerite2 recursions (Eigen unavailable), "
+                  "OpenMP over the batch" % (count, N, J, "fwd+grad" if grad else "fwd"),
+        "single_thread_value": n1 / dt_1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-per-gpu", type=int, default=8192)
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--J", type=int, default=8)
+    ap.add_argument("--mode", choices=["grad", "fwd"], default="grad")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from celerite2_amd import _lib, ops, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    _lib.load()
+
+    Bp, N, J = args.batch_per_gpu, args.N, args.J
+    grad = args.mode == "grad"
+    # shard: contiguous block of series per rank, generated directly on the owning GPU
+    t, c, a, U, V, y = synth.device_batch(rank * Bp, Bp, N, J, dev)
+    if grad:
+        work = ops.loglik_grad_workspace(Bp, N, J, dev)
+        out = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
+               torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
+               torch.empty((Bp, N), dtype=torch.float64, device=dev))
+    gathered = torch.empty(world * Bp, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        if grad:
+            ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
+        else:
+            ll, flag = ops.loglik(t, c, a, U, V, y)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, ll)  # the path's only exchange: B/n_gpu log-liks per rank
+        return ll, flag
+
+    for _ in range(args.warmup):
+        ll, flag = step()
+    torch.cuda.synchronize()
+    nfail = int((flag != 0).sum())
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        ll, flag = step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+    kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        total_gps = world * Bp * args.steps
+        value = total_gps / elapsed
+        bytes_per_gp = algorithmic_bytes_per_gp(N, J, grad)
+        achieved = Bp * bytes_per_gp / (kernel_ms_avg * 1e-3) / 1e9  # per GPU, HIP-event time of the hot path
+        line = {
+            "metric": "float64 GP log-lik+grad/sec at N=%d J=%d, batched" % (N, J) if grad
+                      else "float64 GP log-lik/sec at N=%d J=%d, batched" % (N, J),
+            "value": value, "unit": "GP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2] shard: %d independent GPs per GPU, N=%d, J=%d (sum of %d SHO terms), %s, "
+                                   "inputs resident in HBM" % (Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
+                       "global_batch": world * Bp, "batch_per_gpu": Bp, "N": N, "J": J,
+                       "parallelism": "batch-sharded x%d, all-gather of log-liks" % world,
+                       "failed_factorizations": nfail},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_gp": bytes_per_gp, "kernel_ms_avg": kernel_ms_avg,
+                         "kernel_ms_median": kernel_ms[len(kernel_ms) // 2]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(N, J, grad, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

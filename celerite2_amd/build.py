@@ -1,0 +1,73 @@
+# -*- coding: utf-8 -*-
+"""In-tree build of the gfx950 HIP library and the pybind11 drop-in modules.
+
+    python -m celerite2_amd.build            # build what is stale
+    python -m celerite2_amd.build --force
+
+Outputs (git-ignored, but they travel to the GPU box with the tree):
+    celerite2_amd/libcelerite2_amd.so                  C-ABI + HIP kernels (hipcc, --offload-arch=gfx950)
+    celerite2_amd/driver.cpython-*.so                  pybind11, mirrors celerite2.driver
+    celerite2_amd/backprop.cpython-*.so                pybind11, mirrors celerite2.backprop
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libcelerite2_amd.so")
+HIP_SOURCES = ["c2_ops.hip", "c2_fused.hip", "c2_host.hip"]
+HIP_HEADERS = ["c2_common.hpp", os.path.join(INCLUDE, "celerite2_amd.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    tt = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > tt for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_hip(force=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    if force or _stale(LIB, deps):
+        _run([HIPCC] + HIPFLAGS + srcs + ["-o", LIB])
+    return LIB
+
+
+def ext_path(name):
+    return os.path.join(HERE, name + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False):
+    import pybind11
+
+    out = []
+    for name in ("driver", "backprop"):
+        src = os.path.join(CSRC, "py_%s.cpp" % name)
+        target = ext_path(name)
+        deps = [src, os.path.join(CSRC, "py_common.hpp"), os.path.join(INCLUDE, "celerite2_amd.h"), LIB]
+        if force or _stale(target, deps):
+            _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+                  "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src,
+                  "-L" + HERE, "-lcelerite2_amd", "-Wl,-rpath,$ORIGIN", "-o", target])
+        out.append(target)
+    return out
+
+
+def build_all(force=False):
+    build_hip(force)
+    build_pybind(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

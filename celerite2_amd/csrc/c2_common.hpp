@@ -1,0 +1,60 @@
+// c2_common.hpp -- device-side helpers shared by the gfx950 kernels.
+//
+// Execution mapping used by every recursion kernel in this library
+// ("sub-wave packing"): a series is walked by a GROUP of G consecutive lanes
+// of one 64-lane wavefront, G = J rounded up to a power of two (1..32), so a
+// wavefront carries 64/G independent series.  Lane j of a group owns index j of
+// the width-J objects: column j of the J x J factor state S, row j of the
+// J x nrhs sweep state F.  Quantities that are scalars of the recursion (d_n,
+// z_n, ...) are held redundantly by all G lanes.  Cross-lane traffic is limited
+// to group all-reduces (DPP butterflies) and group broadcasts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c2 {
+
+constexpr int kWave = 64;
+
+// ---- DPP lane permutations on a 64-bit value (two 32-bit DPP moves) --------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // row_half_mirror: lane i <- 7-i  (within 8)
+constexpr int kDppMirror = 0x140;     // row_mirror:      lane i <- 15-i (within 16)
+
+// All-reduce (sum) over each aligned group of G lanes; every lane of the group
+// receives the sum.  Levels 1,2 use quad permutes, 4 and 8 the mirror patterns
+// (legal because after the earlier levels all lanes of the smaller block already
+// hold the same partial sum), level 16 goes through ds_bpermute.
+template <int G>
+__device__ __forceinline__ double gsum(double x) {
+  if constexpr (G >= 2) x += dpp_mov<kDppXor1>(x);
+  if constexpr (G >= 4) x += dpp_mov<kDppXor2>(x);
+  if constexpr (G >= 8) x += dpp_mov<kDppHalfMirror>(x);
+  if constexpr (G >= 16) x += dpp_mov<kDppMirror>(x);
+  if constexpr (G >= 32) x += __shfl_xor(x, 16, kWave);
+  return x;
+}
+
+// Value of x held by lane i of the caller's group.
+template <int G>
+__device__ __forceinline__ double gget(double x, int i) {
+  if constexpr (G == 1) return x;
+  return __shfl(x, i, G);
+}
+
+// Group-size dispatch: G = next power of two >= J.
+inline int group_size(int64_t J) {
+  int G = 1;
+  while (G < J) G <<= 1;
+  return G;
+}
+
+}  // namespace c2

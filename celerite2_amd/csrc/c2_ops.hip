@@ -1,0 +1,802 @@
+// c2_ops.hip -- op-level gfx950 kernels behind the c2_* device entry points.
+//
+// One kernel per reference recursion (reference file:line in each header
+// comment), all on the sub-wave mapping described in c2_common.hpp: G lanes per
+// series, lane j owns column j of the J x J state / row j of the J x nrhs state.
+//
+// These kernels are the faithful, aliasing-tolerant implementations of the
+// reference's per-op API (in-place d==a, W==V, Z==Y allowed).  Input rows are
+// software-prefetched PF steps ahead through a register ring so that the serial
+// recursion never waits on HBM latency; a row is always LOADED before the same
+// row of an aliased output is STORED (program order, no __restrict__ on
+// aliasable pairs), which is the device equivalent of the reference's `tmp`
+// previous-row trick (internal.hpp:134-141).
+#include "c2_common.hpp"
+#include "../../include/celerite2_amd.h"
+
+namespace c2 {
+
+constexpr int PF = 4;  // prefetch distance (steps) of the register ring
+
+struct Lane {
+  int64_t b;   // series index (clamped to B-1 for padding lanes)
+  int j;       // index inside the group
+  bool valid;  // series < B
+};
+template <int G>
+__device__ __forceinline__ Lane lane_of(int64_t B) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Lane L;
+  L.b = g / G;
+  L.j = (int)(g % G);
+  L.valid = L.b < B;
+  if (!L.valid) L.b = B - 1;
+  return L;
+}
+
+// =============================================================================
+// factor -- reference forward.hpp:69-135.
+//   d_0 = a_0, W_0 = V_0/d_0;  per n: S += d w^T w; S = diag(p) S [-> workspace];
+//   S = S diag(p); tau = U_n S; d_n = a_n - tau.U_n; W_n = (V_n - tau)/d_n.
+// Lane j holds column j of S (Sc[i] = S(i,j)).
+// =============================================================================
+template <int G>
+__global__ __launch_bounds__(kWave) void k_factor(int64_t B, int64_t N, int J, const double *t, int64_t t_bs,
+                                                  const double *c, int64_t c_bs, const double *a, const double *U,
+                                                  const double *V, double *d, double *W, double *S, int32_t *flag) {
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const bool act = j < J;
+  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const int jj = act ? j : 0;
+  const double *tb = t + L.b * t_bs, *ab = a + L.b * N;
+  const double *Ub = U + L.b * N * J + jj, *Vb = V + L.b * N * J + jj;
+  double *db = d + L.b * N, *Wb = W + L.b * N * J + jj;
+  double *Sb = S ? S + L.b * N * J * J + (int64_t)jj * J : nullptr;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+
+  double Sc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) Sc[i] = 0.0;
+
+  double dprev = ab[0];
+  double w = act ? Vb[0] / dprev : 0.0;
+  double tprev = tb[0];
+
+  // prefetch ring for rows 1..PF
+  double rt[PF], ra[PF], ru[PF], rv[PF];
+#pragma unroll
+  for (int r = 0; r < PF; ++r) {
+    const int64_t nn = (1 + r < N) ? 1 + r : N - 1;
+    rt[r] = tb[nn]; ra[r] = ab[nn];
+    ru[r] = act ? Ub[nn * J] : 0.0; rv[r] = act ? Vb[nn * J] : 0.0;
+  }
+  if (st0) db[0] = dprev;
+  if (st) Wb[0] = w;
+  if (Sb && st)
+    for (int i = 0; i < J; ++i) Sb[i] = 0.0;  // S.row(0).setZero() (forward.hpp:92)
+
+  int32_t fl = 0;
+  bool alive = true;
+  for (int64_t n0 = 1; n0 < N; n0 += PF) {
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+      const int64_t n = n0 + r;
+      if (n < N && alive) {
+        const double tn = rt[r], an = ra[r], u = ru[r], v = rv[r];
+        {  // refill this ring slot with row n+PF (before any store to row n)
+          const int64_t nn = (n + PF < N) ? n + PF : N - 1;
+          rt[r] = tb[nn]; ra[r] = ab[nn];
+          ru[r] = act ? Ub[nn * J] : 0.0; rv[r] = act ? Vb[nn * J] : 0.0;
+        }
+        const double p = exp(cj * (tprev - tn));
+        tprev = tn;
+        const double dw = dprev * w;
+        double tau = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const double wi = gget<G>(w, i), pi = gget<G>(p, i), ui = gget<G>(u, i);
+          double s = pi * fma(dw, wi, Sc[i]);
+          if (Sb && st && i < J) Sb[n * J * J + i] = s;  // S[n, i + J*j], half-scaled (forward.hpp:120)
+          s *= p;
+          Sc[i] = s;
+          tau = fma(ui, s, tau);
+        }
+        const double dn = an - gsum<G>(tau * u);
+        if (st0) db[n] = dn;
+        if (dn <= 0.0) {  // forward.hpp:128 (NaN passes, as in the reference)
+          fl = (int32_t)n;
+          alive = false;
+        } else {
+          w = (v - tau) / dn;
+          if (st) Wb[n * J] = w;
+          dprev = dn;
+        }
+      }
+    }
+    if (!alive) break;
+  }
+  if (st0) flag[L.b] = fl;
+}
+
+// =============================================================================
+// Shared sweeps -- reference internal.hpp:105-146 (forward) / 148-189 (backward).
+//   LOWER: n = 1..N-1,  F += V_{n-1}^T x_{n-1}; [F -> workspace row n]; F = diag(p) F; Z_n -/+= U_n F
+//   UPPER: n = N-2..0,  F += U_{n+1}^T x_{n+1}; [F -> workspace row n]; F = diag(p) F; Z_n -/+= V_n F
+//   x = Z (solve) or Y (matmul).  Lane j holds F(j, k0..k0+KT-1); blockIdx.y = rhs tile.
+// =============================================================================
+template <int G, int KT, bool LOWER, bool SOLVE>
+__global__ __launch_bounds__(kWave) void k_sweep(int64_t B, int64_t N, int J, int64_t nrhs, const double *t,
+                                                 int64_t t_bs, const double *c, int64_t c_bs, const double *U,
+                                                 const double *V, const double *Y, double *Z, double *F,
+                                                 int zero_z) {
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const bool act = j < J;
+  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const int jj = act ? j : 0;
+  const int64_t k0 = (int64_t)blockIdx.y * KT;
+  const int kn = (nrhs - k0 < KT) ? (int)(nrhs - k0) : KT;
+  const double *tb = t + L.b * t_bs;
+  const double *Ab = (LOWER ? V : U) + L.b * N * J + jj;  // row fed into F
+  const double *Bb = (LOWER ? U : V) + L.b * N * J + jj;  // row applied to F
+  const double *Yb = Y + L.b * N * nrhs + k0;
+  double *Zb = Z + L.b * N * nrhs + k0;
+  double *Fb = F ? F + L.b * N * J * nrhs + jj + J * k0 : nullptr;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  const bool loadz = !SOLVE && !zero_z;
+
+  const int64_t r0 = LOWER ? 0 : N - 1;
+  double Fk[KT], xprev[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    Fk[k] = 0.0;
+    const double y0 = (k < kn) ? Yb[r0 * nrhs + k] : 0.0;
+    xprev[k] = y0;
+  }
+  double am = act ? Ab[r0 * J] : 0.0;
+  double tprev = tb[r0];
+
+  double rt[PF], rb[PF], ra[PF], ry[PF][KT], rz[PF][KT];
+  auto load_row = [&](int r, int64_t s) {
+    const int64_t sc = (s < N) ? s : N - 1;
+    const int64_t n = LOWER ? sc : N - 1 - sc;
+    rt[r] = tb[n];
+    rb[r] = act ? Bb[n * J] : 0.0;
+    ra[r] = act ? Ab[n * J] : 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      ry[r][k] = (k < kn) ? Yb[n * nrhs + k] : 0.0;
+      rz[r][k] = (loadz && k < kn) ? Zb[n * nrhs + k] : 0.0;
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < PF; ++r) load_row(r, 1 + r);
+
+  // first row: solve -> Z = Y (forward.hpp:168,205); matmul(zero_z) -> Z = 0
+  if (st0) {
+    for (int k = 0; k < kn; ++k) {
+      if (SOLVE) Zb[r0 * nrhs + k] = xprev[k];
+      else if (zero_z) Zb[r0 * nrhs + k] = 0.0;
+    }
+  }
+  if (Fb && st)
+    for (int k = 0; k < kn; ++k) Fb[r0 * J * nrhs + J * k] = 0.0;  // internal.hpp:127 / 170
+
+  for (int64_t s0 = 1; s0 < N; s0 += PF) {
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+      const int64_t s = s0 + r;
+      if (s < N) {
+        const int64_t n = LOWER ? s : N - 1 - s;
+        const double tn = rt[r], bn = rb[r], an = ra[r];
+        double yk[KT], zk[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { yk[k] = ry[r][k]; zk[k] = rz[r][k]; }
+        load_row(r, s + PF);
+        const double p = exp(cj * (LOWER ? tprev - tn : tn - tprev));
+        tprev = tn;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          double f = fma(am, xprev[k], Fk[k]);
+          if (Fb && st && k < kn) Fb[n * J * nrhs + J * k] = f;  // F[n, j + J*k] before the decay (internal.hpp:142)
+          f *= p;
+          Fk[k] = f;
+          const double red = gsum<G>(bn * f);
+          const double znew = SOLVE ? yk[k] - red : zk[k] + red;
+          if (st0 && k < kn) Zb[n * nrhs + k] = znew;
+          xprev[k] = SOLVE ? znew : yk[k];
+        }
+        am = an;
+      }
+    }
+  }
+}
+
+// =============================================================================
+// Reverse of the shared sweeps -- reference internal.hpp:191-246 (forward_rev),
+// 248-303 (backward_rev), wrapped as in reverse.hpp:87-217 (outputs zeroed, for
+// solves bY = bZ and the running cotangent lives in bY).
+// Lane j holds bF(j, k-tile).  rhs tiles are processed sequentially inside the
+// kernel; bt, bc and the two low-rank cotangents accumulate across tiles.
+// =============================================================================
+template <int G, int KT, bool LOWER, bool SOLVE>
+__global__ __launch_bounds__(kWave) void k_sweep_rev(int64_t B, int64_t N, int J, int64_t nrhs,
+                                                     const double *__restrict__ t, int64_t t_bs,
+                                                     const double *__restrict__ c, int64_t c_bs,
+                                                     const double *__restrict__ U, const double *__restrict__ V,
+                                                     const double *__restrict__ Y, const double *__restrict__ Z,
+                                                     const double *__restrict__ F, const double *bZ, double *bt,
+                                                     double *bc, double *bU, double *bV, double *bY) {
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const bool act = j < J;
+  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const int jj = act ? j : 0;
+  const double *tb = t + L.b * t_bs;
+  const double *Ab = (LOWER ? V : U) + L.b * N * J + jj;
+  const double *Bb = (LOWER ? U : V) + L.b * N * J + jj;
+  double *bAb = (LOWER ? bV : bU) + L.b * N * J + jj;
+  double *bBb = (LOWER ? bU : bV) + L.b * N * J + jj;
+  const double *Xb = (SOLVE ? Z : Y) + L.b * N * nrhs;
+  const double *bZb = bZ + L.b * N * nrhs;
+  double *bYb = bY + L.b * N * nrhs;
+  double *btb = bt + L.b * N;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  const double sgn = SOLVE ? -1.0 : 1.0;
+
+  for (int64_t k0 = 0; k0 < nrhs; k0 += KT) {
+    const int kn = (nrhs - k0 < KT) ? (int)(nrhs - k0) : KT;
+    const bool acc = k0 > 0;
+    const double *Fb = F + L.b * N * J * nrhs + jj + J * k0;
+    double bF[KT], bz[KT];
+    const int64_t nfirst = LOWER ? N - 1 : 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      bF[k] = 0.0;
+      bz[k] = (k < kn) ? bZb[nfirst * nrhs + k0 + k] : 0.0;
+    }
+    if (st0)
+      for (int k = 0; k < kn; ++k) bYb[nfirst * nrhs + k0 + k] = SOLVE ? bz[k] : 0.0;
+    if (st && !acc) bAb[nfirst * J] = 0.0;  // never receives a contribution
+    double bcj = 0.0, carry = 0.0;
+
+    // ring: everything row-indexed that step (n, m) needs
+    double rtn[PF], rtm[PF], rbn[PF], ram[PF], rF[PF][KT], rX[PF][KT], rbz[PF][KT];
+    auto load_row = [&](int r, int64_t s) {  // s = N-1 .. 1 (clamped)
+      const int64_t sc = (s >= 1) ? s : 1;
+      const int64_t n = LOWER ? sc : N - 1 - sc;
+      const int64_t m = LOWER ? n - 1 : n + 1;
+      rtn[r] = tb[n]; rtm[r] = tb[m];
+      rbn[r] = act ? Bb[n * J] : 0.0;
+      ram[r] = act ? Ab[m * J] : 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const bool ok = k < kn;
+        rF[r][k] = (ok && act) ? Fb[n * J * nrhs + J * k] : 0.0;
+        rX[r][k] = ok ? Xb[m * nrhs + k0 + k] : 0.0;
+        rbz[r][k] = ok ? bZb[m * nrhs + k0 + k] : 0.0;
+      }
+    };
+    if (N > 1) {
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_row(r, N - 1 - r);
+    }
+
+    for (int64_t s0 = N - 1; s0 >= 1; s0 -= PF) {
+#pragma unroll
+      for (int r = 0; r < PF; ++r) {
+        const int64_t s = s0 - r;
+        if (s >= 1) {
+          const int64_t n = LOWER ? s : N - 1 - s;
+          const int64_t m = LOWER ? n - 1 : n + 1;
+          const double dt = LOWER ? rtm[r] - rtn[r] : rtn[r] - rtm[r];
+          const double bn = rbn[r], am = ram[r];
+          double Fn[KT], Xm[KT], bzm[KT];
+#pragma unroll
+          for (int k = 0; k < KT; ++k) { Fn[k] = rF[r][k]; Xm[k] = rX[r][k]; bzm[k] = rbz[r][k]; }
+          load_row(r, s - PF);
+
+          const double p = exp(cj * dt);
+          // reverse of update_z (internal.hpp:232-233 / 289-290)
+          double val = 0.0, dotFbF = 0.0;
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            val = fma(bz[k], p * Fn[k], val);
+            bF[k] = fma(sgn * bn, bz[k], bF[k]);
+            dotFbF = fma(Fn[k], bF[k], dotFbF);
+          }
+          if (st) bBb[n * J] = acc ? bBb[n * J] + sgn * val : sgn * val;
+          // reverse of the decay (internal.hpp:236-241 / 293-298)
+          const double bp = dotFbF * p;
+          bcj = fma(dt, bp, bcj);
+          const double f = gsum<G>(cj * bp);
+          if (st0) {
+            const double v = LOWER ? carry - f : f - carry;
+            btb[n] = acc ? btb[n] + v : v;
+          }
+          carry = f;
+          // update_f::reverse (internal.hpp:55-63 matmul, 76-84 solve)
+          double bam = 0.0;
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            bF[k] *= p;
+            bam = fma(Xm[k], bF[k], bam);
+            const double g = gsum<G>(am * bF[k]);
+            const double out = SOLVE ? bzm[k] + g : g;
+            if (st0 && k < kn) bYb[m * nrhs + k0 + k] = out;
+            bz[k] = SOLVE ? out : bzm[k];
+          }
+          if (st) bAb[m * J] = acc ? bAb[m * J] + bam : bam;
+        }
+      }
+    }
+    const int64_t mlast = LOWER ? 0 : N - 1;
+    if (st0) {
+      const double v = LOWER ? carry : -carry;
+      btb[mlast] = acc ? btb[mlast] + v : v;
+    }
+    if (st && !acc) bBb[mlast * J] = 0.0;  // bU.row(0) / bV.row(N-1) never touched
+    if (st) {
+      double *bcb = bc + L.b * J + j;
+      *bcb = acc ? *bcb + bcj : bcj;
+    }
+  }
+}
+
+// =============================================================================
+// factor_rev -- reference reverse.hpp:10-85.
+// Only the symmetric part of the reference's bS ever reaches an output (bp uses
+// bS(k,i)+bS(i,k); ba uses w bS w^T; bV uses bS+bS^T; the P bS P update keeps
+// the symmetric/antisymmetric split), so the kernel carries M = bS + bS^T with
+// lane j owning column j, next to column j of the workspace S_n.  `accumulate`
+// adds into bt, bc, bU (used by the fused log-likelihood gradient).
+// =============================================================================
+template <int G>
+__global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int J, const double *__restrict__ t,
+                                                      int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                      const double *__restrict__ U, const double *__restrict__ d,
+                                                      const double *__restrict__ W, const double *__restrict__ S,
+                                                      const double *__restrict__ bd, const double *__restrict__ bW,
+                                                      double *bt, double *bc, double *ba, double *bU, double *bV,
+                                                      int accumulate) {
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const bool act = j < J;
+  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const int jj = act ? j : 0;
+  const double *tb = t + L.b * t_bs, *db = d + L.b * N, *bdb = bd + L.b * N;
+  const double *Ub = U + L.b * N * J + jj, *Wb = W + L.b * N * J + jj, *bWb = bW + L.b * N * J + jj;
+  const double *Sb = S + L.b * N * J * J + (int64_t)jj * J;
+  double *btb = bt + L.b * N, *bab = ba + L.b * N;
+  double *bUb = bU + L.b * N * J + jj, *bVb = bV + L.b * N * J + jj;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  const bool acc = accumulate != 0;
+
+  double M[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) M[i] = 0.0;
+
+  double ban = bdb[N - 1];
+  double bVn = act ? bWb[(N - 1) * J] / db[N - 1] : 0.0;
+  double bcj = 0.0, carry = 0.0;
+
+  constexpr int PFR = 2;
+  double rtn[PFR], rtm[PFR], ru[PFR], rwn[PFR], rwm[PFR], rdm[PFR], rbdm[PFR], rbWm[PFR], rS[PFR][G];
+  auto load_row = [&](int r, int64_t n) {
+    const int64_t nc = (n >= 1) ? n : 1;
+    rtn[r] = tb[nc]; rtm[r] = tb[nc - 1];
+    ru[r] = act ? Ub[nc * J] : 0.0;
+    rwn[r] = act ? Wb[nc * J] : 0.0;
+    rwm[r] = act ? Wb[(nc - 1) * J] : 0.0;
+    rdm[r] = db[nc - 1]; rbdm[r] = bdb[nc - 1];
+    rbWm[r] = act ? bWb[(nc - 1) * J] : 0.0;
+#pragma unroll
+    for (int i = 0; i < G; ++i) rS[r][i] = (act && i < J) ? Sb[nc * J * J + i] : 0.0;
+  };
+  if (N > 1) {
+#pragma unroll
+    for (int r = 0; r < PFR; ++r) load_row(r, N - 1 - r);
+  }
+
+  for (int64_t n0 = N - 1; n0 >= 1; n0 -= PFR) {
+#pragma unroll
+    for (int r = 0; r < PFR; ++r) {
+      const int64_t n = n0 - r;
+      if (n >= 1) {
+        const double dt = rtm[r] - rtn[r];
+        const double u = ru[r], wn = rwn[r], wm = rwm[r], dm = rdm[r], bdm = rbdm[r], bWm = rbWm[r];
+        double Sc[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) Sc[i] = rS[r][i];
+        load_row(r, n - PFR);
+
+        const double p = exp(cj * dt);
+        // Step 6 (reverse.hpp:65-67)
+        ban -= gsum<G>(wn * bVn);
+        if (st0) bab[n] = ban;
+        if (st) bVb[n * J] = bVn;
+        const double y = fma(ban, u, bVn);   // bV + ba U
+        const double x = fma(ban, u, y);     // bV + 2 ba U
+        double xs = 0.0, bpacc = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const double xi = gget<G>(x, i), ui = gget<G>(u, i), yi = gget<G>(y, i);
+          xs = fma(xi, Sc[i], xs);
+          M[i] -= fma(ui, y, yi * u);          // M -= U^T y + y^T U
+          bpacc = fma(Sc[i], M[i], bpacc);     // diag(bS Sn + Sn^T bS)_j = sum_i Sn(i,j) M(i,j)
+        }
+        const double bun = -p * xs;
+        if (st) bUb[n * J] = acc ? bUb[n * J] + bun : bun;
+        // Step 4 (reverse.hpp:70-74)
+        const double bp = bpacc * p;
+        bcj = fma(dt, bp, bcj);
+        const double f = gsum<G>(cj * bp);
+        if (st0) {
+          const double v = carry - f;
+          btb[n] = acc ? btb[n] + v : v;
+        }
+        carry = f;
+        // Step 3 (reverse.hpp:77-80)
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const double pi = gget<G>(p, i), wi = gget<G>(wm, i);
+          M[i] *= pi * p;
+          q = fma(wi, M[i], q);               // (w M)_j
+        }
+        ban = fma(0.5, gsum<G>(q * wm), bdm);  // ba_{n-1} = bd_{n-1} + w bS w^T = bd + (w M w^T)/2
+        bVn = bWm / dm + q;                    // bV_{n-1} = bW_{n-1}/d_{n-1} + w (bS + bS^T)
+      }
+    }
+  }
+  // reverse.hpp:83-84
+  ban -= gsum<G>(bVn * (act ? Wb[0] : 0.0));
+  if (st0) {
+    bab[0] = ban;
+    btb[0] = acc ? btb[0] + carry : carry;
+  }
+  if (st) {
+    bVb[0] = bVn;
+    if (!acc) bUb[0] = 0.0;
+    double *bcb = bc + L.b * J + j;
+    *bcb = acc ? *bcb + bcj : bcj;
+  }
+}
+
+// =============================================================================
+// general_matmul_lower / upper -- reference forward.hpp:285-332 / 346-392.
+// Two-pointer merge of the sorted grids t1 (N) and t2 (M); the merge indices are
+// uniform inside a group (they depend on the series only).
+// =============================================================================
+template <int G, int KT, bool LOWER>
+__global__ __launch_bounds__(kWave) void k_general(int64_t B, int64_t N, int64_t M, int J, int64_t nrhs,
+                                                   const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs,
+                                                   const double *c, int64_t c_bs, const double *U, const double *V,
+                                                   const double *Y, double *Z, double *F) {
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const bool act = j < J;
+  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const int jj = act ? j : 0;
+  const int64_t k0 = (int64_t)blockIdx.y * KT;
+  const int kn = (nrhs - k0 < KT) ? (int)(nrhs - k0) : KT;
+  const double *t1b = t1 + L.b * t1_bs, *t2b = t2 + L.b * t2_bs;
+  const double *Ub = U + L.b * N * J + jj, *Vb = V + L.b * M * J + jj;
+  const double *Yb = Y + L.b * M * nrhs + k0;
+  double *Zb = Z + L.b * N * nrhs + k0;
+  double *Fb = F ? F + L.b * M * J * nrhs + (int64_t)jj * nrhs + k0 : nullptr;  // row-major F[m, j*nrhs + k]
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+
+  double Fm[KT];
+  const int64_t m0 = LOWER ? 0 : M - 1;
+  {
+    const double v0 = act ? Vb[m0 * J] : 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) Fm[k] = (k < kn) ? v0 * Yb[m0 * nrhs + k] : 0.0;
+  }
+  if (Fb && st) {
+    // F.row(0).setZero() in both variants (forward.hpp:297, 358); the lower variant then
+    // stores Fm into row 0 (forward.hpp:313), the upper variant stores nothing for row M-1.
+    for (int k = 0; k < kn; ++k) Fb[k] = LOWER ? Fm[k] : 0.0;
+  }
+  auto absorb = [&](int64_t m, double dt) {
+    const double p = exp(cj * dt);
+    const double vm = act ? Vb[m * J] : 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const double yk = (k < kn) ? Yb[m * nrhs + k] : 0.0;
+      Fm[k] = fma(vm, yk, p * Fm[k]);
+      if (Fb && st && k < kn) Fb[m * J * nrhs + k] = Fm[k];
+    }
+  };
+  auto emit = [&](int64_t n, double dt) {
+    const double p = exp(cj * dt);
+    const double up = (act ? Ub[n * J] : 0.0) * p;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const double red = gsum<G>(up * Fm[k]);
+      if (st0 && k < kn) Zb[n * nrhs + k] += red;
+    }
+  };
+  if (LOWER) {
+    double tn = t2b[0];
+    int64_t n = 0, m = 1;
+    for (; n < N; ++n)
+      if (t1b[n] >= tn) break;
+    for (; n < N; ++n) {
+      tn = t1b[n];
+      while (m < M && t2b[m] <= tn) {
+        absorb(m, t2b[m - 1] - t2b[m]);
+        m++;
+      }
+      emit(n, t2b[m - 1] - tn);
+    }
+  } else {
+    double tn = t2b[M - 1];
+    int64_t n = N - 1, m = M - 2;
+    for (; n >= 0; --n)
+      if (t1b[n] < tn) break;
+    for (; n >= 0; --n) {
+      tn = t1b[n];
+      while (m >= 0 && t2b[m] > tn) {
+        absorb(m, t2b[m] - t2b[m + 1]);
+        m--;
+      }
+      emit(n, tn - t2b[m + 1]);
+    }
+  }
+}
+
+// =============================================================================
+// get_celerite_matrices -- reference python/celerite2/driver.cpp:422-477.
+// One thread per (series, row).
+// =============================================================================
+__global__ void k_matrices(int64_t B, int64_t N, int Jr, int Jc, const double *ar, const double *ac, const double *bc,
+                           const double *dc, int coef_batched, const double *x, int64_t x_bs, const double *diag,
+                           double *a, double *U, double *V) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * N) return;
+  const int64_t b = g / N, n = g % N;
+  const int J = Jr + 2 * Jc;
+  const double *arb = ar + (coef_batched ? b * Jr : 0);
+  const double *acb = ac + (coef_batched ? b * Jc : 0), *bcb = bc + (coef_batched ? b * Jc : 0),
+               *dcb = dc + (coef_batched ? b * Jc : 0);
+  double sum = 0.0;
+  for (int i = 0; i < Jr; ++i) sum += arb[i];
+  for (int i = 0; i < Jc; ++i) sum += acb[i];
+  const double xn = x[b * x_bs + n];
+  a[g] = diag[g] + sum;
+  double *Un = U + g * J, *Vn = V + g * J;
+  for (int i = 0; i < Jr; ++i) { Vn[i] = 1.0; Un[i] = arb[i]; }
+  for (int i = 0, ind = Jr; i < Jc; ++i, ind += 2) {
+    double sn, cs;
+    sincos(dcb[i] * xn, &sn, &cs);
+    Vn[ind] = cs; Vn[ind + 1] = sn;
+    Un[ind] = acb[i] * cs + bcb[i] * sn;
+    Un[ind + 1] = acb[i] * sn - bcb[i] * cs;
+  }
+}
+
+// Z = Y * sqrt(d)[:, None]   (numpy.py:101)
+__global__ void k_scale_sqrt(int64_t total, int64_t nrhs, const double *d, const double *Y, double *Z) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < total) Z[g] = Y[g] * sqrt(d[g / nrhs]);
+}
+
+}  // namespace c2
+
+// =============================================================================
+// C-ABI launchers
+// =============================================================================
+using namespace c2;
+
+namespace {
+thread_local char g_err[256] = "";
+inline int hip_check(hipError_t e) {
+  if (e == hipSuccess) return C2_OK;
+  snprintf(g_err, sizeof(g_err), "%s", hipGetErrorString(e));
+  return C2_ERR_HIP;
+}
+inline int check_launch() { return hip_check(hipGetLastError()); }
+inline dim3 grid_for(int64_t B, int G, int64_t ytiles = 1) {
+  const int64_t lanes = B * G;
+  return dim3((unsigned)((lanes + kWave - 1) / kWave), (unsigned)ytiles, 1);
+}
+inline int check_dims(int64_t B, int64_t N, int64_t J) {
+  if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
+  if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
+  return C2_OK;
+}
+}  // namespace
+
+#define C2_DISPATCH_G(G_, ...)                                  \
+  switch (G_) {                                                 \
+    case 1: { constexpr int G = 1; __VA_ARGS__; } break;        \
+    case 2: { constexpr int G = 2; __VA_ARGS__; } break;        \
+    case 4: { constexpr int G = 4; __VA_ARGS__; } break;        \
+    case 8: { constexpr int G = 8; __VA_ARGS__; } break;        \
+    case 16: { constexpr int G = 16; __VA_ARGS__; } break;      \
+    default: { constexpr int G = 32; __VA_ARGS__; } break;      \
+  }
+
+template <bool LOWER, bool SOLVE>
+static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                        int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
+                        int zero_z, c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z) return C2_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (nrhs == 1) {
+    C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL((k_sweep<G, 1, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s,
+                                                    B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
+  } else {
+    constexpr int KT = 4;
+    C2_DISPATCH_G(group_size(J),
+                  hipLaunchKernelGGL((k_sweep<G, KT, LOWER, SOLVE>), grid_for(B, G, (nrhs + KT - 1) / KT),
+                                     dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
+  }
+  return check_launch();
+}
+
+template <bool LOWER>
+static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, int64_t t1_bs,
+                          const double *t2, int64_t t2_bs, const double *c, int64_t c_bs, const double *U,
+                          const double *V, const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (M < 1 || nrhs < 1 || !t1 || !t2 || !c || !U || !V || !Y || !Z) return C2_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (zero_z) {
+    if (int e = hip_check(hipMemsetAsync(Z, 0, sizeof(double) * B * N * nrhs, s))) return e;
+  }
+  constexpr int KT = 4;
+  C2_DISPATCH_G(group_size(J),
+                hipLaunchKernelGGL((k_general<G, KT, LOWER>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0, s,
+                                   B, N, M, (int)J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F));
+  return check_launch();
+}
+template <bool LOWER, bool SOLVE>
+static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
+                            const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
+                            const double *Z, const double *F, const double *bZ, double *bt, double *bc, double *bU,
+                            double *bV, double *bY, c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z || !F || !bZ || !bt || !bc || !bU || !bV || !bY)
+    return C2_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (nrhs == 1) {
+    C2_DISPATCH_G(group_size(J),
+                  hipLaunchKernelGGL((k_sweep_rev<G, 1, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J,
+                                     nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));
+  } else {
+    C2_DISPATCH_G(group_size(J),
+                  hipLaunchKernelGGL((k_sweep_rev<G, 4, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J,
+                                     nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));
+  }
+  return check_launch();
+}
+extern "C" {
+
+const char *c2_version(void) { return "celerite2_amd 0.1.0 (gfx950)"; }
+const char *c2_last_error(void) { return g_err; }
+void c2_internal_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+int c2_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+              const double *a, const double *U, const double *V, double *d, double *W, double *S, int32_t *flag,
+              c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (!t || !c || !a || !U || !V || !d || !W || !flag) return C2_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL(k_factor<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J, t,
+                                                  t_bs, c, c_bs, a, U, V, d, W, S, flag));
+  return check_launch();
+}
+
+int c2_solve_lower(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                   int64_t c_bs, const double *U, const double *W, const double *Y, double *Z, double *F,
+                   c2_stream_t stream) {
+  return launch_sweep<true, true>(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, Y, Z, F, 0, stream);
+}
+int c2_solve_upper(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                   int64_t c_bs, const double *U, const double *W, const double *Y, double *Z, double *F,
+                   c2_stream_t stream) {
+  return launch_sweep<false, true>(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, Y, Z, F, 0, stream);
+}
+int c2_matmul_lower(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                    int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z,
+                    c2_stream_t stream) {
+  return launch_sweep<true, false>(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+}
+int c2_matmul_upper(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                    int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z,
+                    c2_stream_t stream) {
+  return launch_sweep<false, false>(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+}
+
+int c2_general_matmul_lower(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, int64_t t1_bs,
+                            const double *t2, int64_t t2_bs, const double *c, int64_t c_bs, const double *U,
+                            const double *V, const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream) {
+  return launch_general<true>(B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+}
+int c2_general_matmul_upper(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, int64_t t1_bs,
+                            const double *t2, int64_t t2_bs, const double *c, int64_t c_bs, const double *U,
+                            const double *V, const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream) {
+  return launch_general<false>(B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+}
+
+// Internal: factor_rev with optional accumulation into bt/bc/bU (used by c2_loglik_grad).
+int c2_factor_rev_acc(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                      const double *U, const double *d, const double *W, const double *S, const double *bd,
+                      const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV, int accumulate,
+                      c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (!t || !c || !U || !d || !W || !S || !bd || !bW || !bt || !bc || !ba || !bU || !bV) return C2_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL(k_factor_rev<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J, t,
+                                                  t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, accumulate));
+  return check_launch();
+}
+
+int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                  const double *a, const double *U, const double *V, const double *d, const double *W,
+                  const double *S, const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
+                  double *bV, c2_stream_t stream) {
+  (void)a; (void)V;  // unused by the reference as well (reverse.hpp:29-30)
+  return c2_factor_rev_acc(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, 0, stream);
+}
+
+int c2_solve_lower_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                       int64_t c_bs, const double *U, const double *W, const double *Y, const double *Z,
+                       const double *F, const double *bZ, double *bt, double *bc, double *bU, double *bW, double *bY,
+                       c2_stream_t stream) {
+  return launch_sweep_rev<true, true>(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, Y, Z, F, bZ, bt, bc, bU, bW, bY, stream);
+}
+int c2_solve_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                       int64_t c_bs, const double *U, const double *W, const double *Y, const double *Z,
+                       const double *F, const double *bZ, double *bt, double *bc, double *bU, double *bW, double *bY,
+                       c2_stream_t stream) {
+  return launch_sweep_rev<false, true>(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, Y, Z, F, bZ, bt, bc, bU, bW, bY, stream);
+}
+int c2_matmul_lower_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                        int64_t c_bs, const double *U, const double *V, const double *Y, const double *Z,
+                        const double *F, const double *bZ, double *bt, double *bc, double *bU, double *bV, double *bY,
+                        c2_stream_t stream) {
+  return launch_sweep_rev<true, false>(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY, stream);
+}
+int c2_matmul_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                        int64_t c_bs, const double *U, const double *V, const double *Y, const double *Z,
+                        const double *F, const double *bZ, double *bt, double *bc, double *bU, double *bV, double *bY,
+                        c2_stream_t stream) {
+  return launch_sweep_rev<false, false>(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY,
+                                        stream);
+}
+
+int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
+                             const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
+                             const double *diag, double *a, double *U, double *V, c2_stream_t stream) {
+  if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
+  if (!x || !diag || !a || !U || !V || (Jr && !ar) || (Jc && (!ac || !bc || !dc))) return C2_ERR_INVALID;
+  const int64_t total = B * N;
+  hipLaunchKernelGGL(k_matrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
+                     (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V);
+  return check_launch();
+}
+
+int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                int64_t c_bs, const double *U, const double *W, const double *d, const double *Y, double *Z,
+                c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (nrhs < 1 || !t || !c || !U || !W || !d || !Y || !Z) return C2_ERR_INVALID;
+  const int64_t total = B * N * nrhs;
+  hipLaunchKernelGGL(k_scale_sqrt, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
+                     nrhs, d, Y, Z);
+  if (int e = check_launch()) return e;
+  return launch_sweep<true, false>(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, Z, Z, nullptr, 0, stream);
+}
+
+}  // extern "C"

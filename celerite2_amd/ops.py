@@ -1,0 +1,226 @@
+# -*- coding: utf-8 -*-
+"""Batched, device-resident operator API over the C-ABI (include/celerite2_amd.h).
+
+Same op names and argument meaning as the reference's backend-op layer
+(python/celerite2/definitions.json; jax/ops.py:40-72; pymc/ops.py:38-159) with a
+leading batch dimension B of independent series.  All tensors are float64,
+contiguous, on one HIP device; t may be (B,N) or shared (N,), c (B,J) or (J,).
+Launches go on torch's current stream.  torch is plumbing here (device memory,
+streams); the arithmetic is in the gfx950 kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "general_matmul_lower",
+    "general_matmul_upper", "factor_rev", "solve_lower_rev", "solve_upper_rev", "matmul_lower_rev",
+    "matmul_upper_rev", "get_celerite_matrices", "loglik", "loglik_grad", "loglik_grad_workspace", "dot_tril",
+]
+
+_i64 = ctypes.c_int64
+
+
+def _p(x):
+    return ctypes.c_void_p(0 if x is None else x.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*xs):
+    for x in xs:
+        if x is None:
+            continue
+        if not (x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()):
+            raise ValueError("celerite2_amd ops need contiguous float64 tensors on the GPU")
+
+
+def _bs(x, per):
+    """(tensor, batch stride in elements): 0 when shared by the batch."""
+    return 0 if x.dim() == 1 else per
+
+
+def _dims(U):
+    if U.dim() != 3:
+        raise ValueError("U must be (B, N, J)")
+    return U.shape
+
+
+def factor(t, c, a, U, V, d=None, W=None, S=None, *, workspace=False):
+    """Batched core::factor.  Returns (d, W, flag) or (d, W, S, flag); d may alias a, W may alias V."""
+    B, N, J = _dims(U)
+    d = torch.empty_like(a) if d is None else d
+    W = torch.empty_like(V) if W is None else W
+    if workspace and S is None:
+        S = torch.empty((B, N, J, J), dtype=torch.float64, device=U.device)
+    flag = torch.empty(B, dtype=torch.int32, device=U.device)
+    _chk(t, c, a, U, V, d, W, S)
+    rc = _lib.load().c2_factor(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                               _p(U), _p(V), _p(d), _p(W), _p(S), _p(flag), _stream())
+    _lib.check(rc, "factor")
+    return (d, W, S, flag) if S is not None else (d, W, flag)
+
+
+def _sweep(name, matmul):
+    def op(t, c, U, W, Y, Z=None, F=None, *, workspace=False, zero_z=False):
+        B, N, J = _dims(U)
+        nrhs = Y.shape[-1]
+        if Z is None:
+            Z = torch.zeros_like(Y) if matmul else torch.empty_like(Y)
+        if workspace and F is None:
+            F = torch.empty((B, N, J, nrhs), dtype=torch.float64, device=U.device)
+        _chk(t, c, U, W, Y, Z, F)
+        args = [_i64(B), _i64(N), _i64(J), _i64(nrhs), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(U), _p(W),
+                _p(Y), _p(Z), _p(F)]
+        if matmul:
+            args.append(ctypes.c_int(1 if zero_z else 0))
+        rc = getattr(_lib.load(), "c2_" + name)(*args, _stream())
+        _lib.check(rc, name)
+        return (Z, F) if F is not None else Z
+    op.__name__ = name
+    return op
+
+
+solve_lower = _sweep("solve_lower", False)
+solve_upper = _sweep("solve_upper", False)
+matmul_lower = _sweep("matmul_lower", True)
+matmul_upper = _sweep("matmul_upper", True)
+
+
+def _general(name):
+    def op(t1, t2, c, U, V, Y, Z=None, F=None, *, workspace=False, zero_z=False):
+        B, N, J = _dims(U)
+        M, nrhs = V.shape[1], Y.shape[-1]
+        if Z is None:
+            Z = torch.zeros((B, N, nrhs), dtype=torch.float64, device=U.device)
+        if workspace and F is None:
+            F = torch.zeros((B, M, J, nrhs), dtype=torch.float64, device=U.device)
+        _chk(t1, t2, c, U, V, Y, Z, F)
+        rc = getattr(_lib.load(), "c2_" + name)(
+            _i64(B), _i64(N), _i64(M), _i64(J), _i64(nrhs), _p(t1), _i64(_bs(t1, N)), _p(t2), _i64(_bs(t2, M)), _p(c),
+            _i64(_bs(c, J)), _p(U), _p(V), _p(Y), _p(Z), _p(F), ctypes.c_int(1 if zero_z else 0), _stream())
+        _lib.check(rc, name)
+        return (Z, F) if F is not None else Z
+    op.__name__ = name
+    return op
+
+
+general_matmul_lower = _general("general_matmul_lower")
+general_matmul_upper = _general("general_matmul_upper")
+
+
+def factor_rev(t, c, a, U, V, d, W, S, bd, bW):
+    B, N, J = _dims(U)
+    dev = U.device
+    bt = torch.empty((B, N), dtype=torch.float64, device=dev)
+    bc = torch.empty((B, J), dtype=torch.float64, device=dev)
+    ba = torch.empty((B, N), dtype=torch.float64, device=dev)
+    bU = torch.empty_like(U)
+    bV = torch.empty_like(U)
+    _chk(t, c, a, U, V, d, W, S, bd, bW)
+    rc = _lib.load().c2_factor_rev(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                                   _p(U), _p(V), _p(d), _p(W), _p(S), _p(bd), _p(bW), _p(bt), _p(bc), _p(ba), _p(bU),
+                                   _p(bV), _stream())
+    _lib.check(rc, "factor_rev")
+    return bt, bc, ba, bU, bV
+
+
+def _sweep_rev(name):
+    def op(t, c, U, W, Y, Z, F, bZ):
+        B, N, J = _dims(U)
+        nrhs = Y.shape[-1]
+        dev = U.device
+        bt = torch.empty((B, N), dtype=torch.float64, device=dev)
+        bc = torch.empty((B, J), dtype=torch.float64, device=dev)
+        bU = torch.empty_like(U)
+        bW = torch.empty_like(U)
+        bY = torch.empty_like(Y)
+        _chk(t, c, U, W, Y, Z, F, bZ)
+        rc = getattr(_lib.load(), "c2_" + name)(
+            _i64(B), _i64(N), _i64(J), _i64(nrhs), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(U), _p(W), _p(Y),
+            _p(Z), _p(F), _p(bZ), _p(bt), _p(bc), _p(bU), _p(bW), _p(bY), _stream())
+        _lib.check(rc, name)
+        return bt, bc, bU, bW, bY
+    op.__name__ = name
+    return op
+
+
+solve_lower_rev = _sweep_rev("solve_lower_rev")
+solve_upper_rev = _sweep_rev("solve_upper_rev")
+matmul_lower_rev = _sweep_rev("matmul_lower_rev")
+matmul_upper_rev = _sweep_rev("matmul_upper_rev")
+
+
+def get_celerite_matrices(ar, ac, bc, dc, x, diag):
+    """Batched driver.get_celerite_matrices.  ar (Jr,)|(B,Jr); ac,bc,dc (Jc,)|(B,Jc); x (N,)|(B,N); diag (B,N)."""
+    B, N = diag.shape
+    Jr, Jc = ar.shape[-1], ac.shape[-1]
+    J = Jr + 2 * Jc
+    batched = ar.dim() == 2 or ac.dim() == 2
+    if batched and (ar.dim() != 2 or ac.dim() != 2 or bc.dim() != 2 or dc.dim() != 2):
+        raise ValueError("coefficients must be all shared or all per-series")
+    dev = diag.device
+    a = torch.empty((B, N), dtype=torch.float64, device=dev)
+    U = torch.empty((B, N, J), dtype=torch.float64, device=dev)
+    V = torch.empty((B, N, J), dtype=torch.float64, device=dev)
+    _chk(ar, ac, bc, dc, x, diag)
+    rc = _lib.load().c2_get_celerite_matrices(
+        _i64(B), _i64(N), _i64(Jr), _i64(Jc), _p(ar if Jr else None), _p(ac if Jc else None), _p(bc if Jc else None),
+        _p(dc if Jc else None), ctypes.c_int(1 if batched else 0), _p(x), _i64(_bs(x, N)), _p(diag), _p(a), _p(U),
+        _p(V), _stream())
+    _lib.check(rc, "get_celerite_matrices")
+    return a, U, V
+
+
+def loglik(t, c, a, U, V, y):
+    """Fused batched log-likelihood.  Returns (ll (B,), flag (B,) int32)."""
+    B, N, J = _dims(U)
+    ll = torch.empty(B, dtype=torch.float64, device=U.device)
+    flag = torch.empty(B, dtype=torch.int32, device=U.device)
+    _chk(t, c, a, U, V, y)
+    rc = _lib.load().c2_loglik(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                               _p(U), _p(V), _p(y), _p(ll), _p(flag), _stream())
+    _lib.check(rc, "loglik")
+    return ll, flag
+
+
+def loglik_grad_workspace(B, N, J, device):
+    nbytes = _lib.load().c2_loglik_grad_workspace_bytes(B, N, J)
+    return torch.empty(nbytes // 8, dtype=torch.float64, device=device)
+
+
+def loglik_grad(t, c, a, U, V, y, *, work=None, out=None):
+    """Fused batched log-likelihood + gradient.  Returns (ll, (bt, bc, ba, bU, bV, by), flag)."""
+    B, N, J = _dims(U)
+    dev = U.device
+    if work is None:
+        work = loglik_grad_workspace(B, N, J, dev)
+    if out is None:
+        out = (torch.empty((B, N), dtype=torch.float64, device=dev), torch.empty((B, J), dtype=torch.float64, device=dev),
+               torch.empty((B, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
+               torch.empty((B, N), dtype=torch.float64, device=dev))
+    bt, bc, ba, bU, bV, by = out
+    ll = torch.empty(B, dtype=torch.float64, device=dev)
+    flag = torch.empty(B, dtype=torch.int32, device=dev)
+    _chk(t, c, a, U, V, y, bt, bc, ba, bU, bV, by)
+    rc = _lib.load().c2_loglik_grad(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                                    _p(U), _p(V), _p(y), _p(ll), _p(bt), _p(bc), _p(ba), _p(bU), _p(bV), _p(by),
+                                    _p(flag), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
+    _lib.check(rc, "loglik_grad")
+    return ll, out, flag
+
+
+def dot_tril(t, c, U, W, d, Y, Z=None):
+    """Z = L sqrt(D) Y (numpy.py:100-102).  Y may be passed as Z for in-place use."""
+    B, N, J = _dims(U)
+    nrhs = Y.shape[-1]
+    Z = torch.empty_like(Y) if Z is None else Z
+    _chk(t, c, U, W, d, Y, Z)
+    rc = _lib.load().c2_dot_tril(_i64(B), _i64(N), _i64(J), _i64(nrhs), _p(t), _i64(_bs(t, N)), _p(c),
+                                 _i64(_bs(c, J)), _p(U), _p(W), _p(d), _p(Y), _p(Z), _stream())
+    _lib.check(rc, "dot_tril")
+    return Z

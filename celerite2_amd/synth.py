@@ -1,0 +1,51 @@
+# -*- coding: utf-8 -*-
+"""Synthetic batches of independent GPs (SURVEY.md section 8d recipe), used by bench.py and smoke().
+
+Per series b: rng = default_rng(seed0 + b) (the reference's seed convention, testing.py:18);
+t = sort(U(0, N/10)); diag ~ U(0.1, 0.3); xi ~ U(-1, 1); y = sin t + 0.1 N(0,1);
+kernel = sum of J/2 underdamped SHOTerms, S0 = 5*0.7^k, w0 = 0.1*3^k*(1 + 0.05 xi), Q = 3.45 + k
+(k = 0, xi = 0 is the reference test kernel SHOTerm(S0=5, w0=0.1, Q=3.45), testing.py:30).
+Coefficients follow python/celerite2/terms.py:658-691; the matrices (a, U, V) are then built ON DEVICE
+by the c2_get_celerite_matrices kernel (driver.cpp:422-477)."""
+import numpy as np
+
+
+def sho_underdamped(S0, w0, Q, eps=1e-5):
+    f = np.sqrt(np.maximum(4.0 * Q**2 - 1.0, eps))
+    a = S0 * w0 * Q
+    c = 0.5 * w0 / Q
+    return a, a / f, c, c * f  # ac, bc, cc, dc
+
+
+def host_inputs(first, count, N, J, seed0=721):
+    """t, diag, y (count, N) and complex-term coefficients ac, bc, cc, dc (count, J/2) on the host."""
+    assert J % 2 == 0, "the synthetic kernel is a sum of J/2 complex (underdamped SHO) terms"
+    Jc = J // 2
+    t = np.empty((count, N)); diag = np.empty((count, N)); y = np.empty((count, N)); xi = np.empty(count)
+    for i in range(count):
+        rng = np.random.default_rng(seed0 + first + i)
+        t[i] = np.sort(rng.uniform(0, N / 10.0, N))
+        diag[i] = rng.uniform(0.1, 0.3, N)
+        xi[i] = rng.uniform(-1, 1)
+        y[i] = np.sin(t[i]) + 0.1 * rng.standard_normal(N)
+    k = np.arange(Jc, dtype=np.float64)
+    S0 = 5.0 * 0.7**k
+    w0 = 0.1 * 3.0**k[None, :] * (1.0 + 0.05 * xi[:, None])
+    Q = 3.45 + k
+    ac, bc, cc, dc = sho_underdamped(S0[None, :], w0, Q[None, :])
+    return t, diag, y, ac, bc, cc, dc
+
+
+def device_batch(first, count, N, J, device, seed0=721):
+    """Device-resident (t, c, a, U, V, y) for series [first, first+count)."""
+    import torch
+
+    from . import ops
+
+    t, diag, y, ac, bc, cc, dc = host_inputs(first, count, N, J, seed0)
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    td, diagd, yd, acd, bcd, dcd = map(to, (t, diag, y, ac, bc, dc))
+    ar = torch.zeros((count, 0), dtype=torch.float64, device=device)
+    c = np.repeat(cc, 2, axis=1)  # c = [cc0, cc0, cc1, cc1, ...] (terms.py:171-173)
+    a, U, V = ops.get_celerite_matrices(ar, acd, bcd, dcd, td, diagd)
+    return td, to(c), a, U, V, yd

@@ -1,0 +1,216 @@
+/* =============================================================================
+ * celerite2_amd.h -- C-ABI of libcelerite2_amd.so (MI355X / gfx950 HIP backend)
+ *
+ * Drop-in boundary for ONE hot path of exoplanet-dev/celerite2: the O(N)
+ * semiseparable GP linear algebra (factor / solve_* / matmul_* /
+ * general_matmul_* and the *_rev reverse-mode passes).  Each entry point cites
+ * the reference interface it replaces (paths relative to the reference repo).
+ *
+ * Conventions (all entry points)
+ *   - float64 only, C-contiguous row-major, exactly like the reference's
+ *     `py::array_t<double, py::array::c_style>` arguments
+ *     (python/celerite2/driver.cpp:13-21).
+ *   - Caller allocates every output and workspace; the library keeps no state
+ *     between calls and allocates no user-visible memory (driver.cpp:13-64).
+ *   - Exact-pointer aliasing the reference allows is allowed here too:
+ *     d == a and W == V for factor (forward.hpp:55-58), Z == Y for
+ *     solve_* / matmul_* (numpy.py:95-108).
+ *   - Return value: C2_OK (0) or a negative C2_ERR_* code.  A non positive
+ *     definite matrix is NOT an error code: `flag[b]` receives the first row
+ *     index n >= 1 with d[n] <= 0, or 0 on success (forward.hpp:128,134), and
+ *     rows 0..n of d / 0..n-1 of W are already written, as in the reference.
+ *
+ * Two families
+ *   c2_*   device entry points: every pointer is a DEVICE pointer, there is a
+ *          leading batch dimension B (B independent series, contiguous
+ *          batch-major: t (B,N) or shared (N,), c (B,J) or shared (J,),
+ *          a (B,N), U (B,N,J), Y (B,N,nrhs), S (B,N,J,J), F (B,N,J,nrhs) ...),
+ *          and the launch is asynchronous on `stream` (a hipStream_t passed as
+ *          void*; NULL = the default stream).  `t_bs` / `c_bs` are the batch
+ *          strides of t and c in elements (N / J, or 0 when shared by the batch).
+ *   c2h_*  host entry points: every pointer is a HOST pointer, B == 1, the call
+ *          stages through device memory, runs the same kernels and returns
+ *          after the results are back on the host.  These are what the
+ *          `driver` / `backprop` pybind11 modules bind.
+ *
+ * Width limit: 1 <= J <= 32 (the reference's CELERITE_MAX_WIDTH,
+ * c++/include/celerite2/terms.hpp:10-12); larger J returns C2_ERR_UNSUPPORTED.
+ * ============================================================================= */
+#ifndef CELERITE2_AMD_H_
+#define CELERITE2_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C2_OK 0
+#define C2_ERR_INVALID (-1)     /* bad size / null pointer ("Invalid shape", driver.cpp:40-46) */
+#define C2_ERR_UNSUPPORTED (-2) /* J > C2_MAX_WIDTH */
+#define C2_ERR_HIP (-3)         /* HIP runtime error (no device, launch failure, OOM) */
+#define C2_MAX_WIDTH 32
+
+typedef void *c2_stream_t; /* hipStream_t */
+
+/* Library / device information. */
+const char *c2_version(void);
+int c2_device_count(void);         /* number of visible HIP devices, 0 if none */
+const char *c2_last_error(void);   /* text of the last HIP error seen by this thread */
+
+/* ---------------------------------------------------------------------------
+ * DEVICE entry points (batched, asynchronous)
+ * ------------------------------------------------------------------------- */
+
+/* core::factor  -- c++/include/celerite2/forward.hpp:69-135 (with workspace S)
+ * and interface.hpp:37-48 (S == NULL).  driver.factor (driver.cpp:13-64),
+ * backprop.factor_fwd (backprop.cpp:12-67).
+ * d (B,N), W (B,N,J), S (B,N,J,J) with S[n, i + J*j] = Sn(i,j), flag (B,) int32. */
+int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+              const double *a, const double *U, const double *V, double *d, double *W, double *S /* nullable */,
+              int32_t *flag, c2_stream_t stream);
+
+/* core::solve_lower / solve_upper -- forward.hpp:156-170, 193-207 (F nullable:
+ * interface.hpp:70-80, 102-112).  Z = L^-1 Y / L^-T Y, L = I + tril(U W^T).
+ * driver.solve_lower/upper (driver.cpp:66-178).  F[n, j + J*k] = Fn(j,k). */
+int c2_solve_lower(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                   int64_t c_bs, const double *U, const double *W, const double *Y, double *Z,
+                   double *F /* nullable */, c2_stream_t stream);
+int c2_solve_upper(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                   int64_t c_bs, const double *U, const double *W, const double *Y, double *Z,
+                   double *F /* nullable */, c2_stream_t stream);
+
+/* core::matmul_lower / matmul_upper -- forward.hpp:228-239, 260-271.
+ * Z += tril(U V^T) Y / Z += triu(V U^T) Y: ACCUMULATES into the caller's Z
+ * (driver.cpp:180-292).  The backprop *_fwd variants zero Z first
+ * (backprop.cpp:505,511): pass zero_z != 0. */
+int c2_matmul_lower(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                    int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
+                    double *F /* nullable */, int zero_z, c2_stream_t stream);
+int c2_matmul_upper(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                    int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
+                    double *F /* nullable */, int zero_z, c2_stream_t stream);
+
+/* core::general_matmul_lower / upper -- forward.hpp:285-332, 346-392
+ * (driver.cpp:294-420, backprop.cpp:761-901).  t1 (B,N) / t2 (B,M) sorted;
+ * U (B,N,J), V (B,M,J), Y (B,M,nrhs), Z (B,N,nrhs) accumulated,
+ * F (B,M,J,nrhs) nullable, row-major F[m, j*nrhs + k]. */
+int c2_general_matmul_lower(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1,
+                            int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c, int64_t c_bs,
+                            const double *U, const double *V, const double *Y, double *Z, double *F /* nullable */,
+                            int zero_z, c2_stream_t stream);
+int c2_general_matmul_upper(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1,
+                            int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c, int64_t c_bs,
+                            const double *U, const double *V, const double *Y, double *Z, double *F /* nullable */,
+                            int zero_z, c2_stream_t stream);
+
+/* core::factor_rev -- c++/include/celerite2/reverse.hpp:10-85
+ * (backprop.factor_rev, backprop.cpp:68-150).  Outputs fully overwritten:
+ * bt (B,N), bc (B,J), ba (B,N), bU (B,N,J), bV (B,N,J). */
+int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                  const double *a, const double *U, const double *V, const double *d, const double *W,
+                  const double *S, const double *bd, const double *bW, double *bt, double *bc, double *ba,
+                  double *bU, double *bV, c2_stream_t stream);
+
+/* core::solve_lower_rev / solve_upper_rev / matmul_lower_rev / matmul_upper_rev
+ * -- reverse.hpp:87-217 over internal::forward_rev / backward_rev
+ * (internal.hpp:191-303); backprop.cpp:216-302, 368-454, 520-606, 672-758.
+ * Outputs fully overwritten: bt (B,N), bc (B,J), bU, bW|bV (B,N,J), bY (B,N,nrhs). */
+int c2_solve_lower_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                       int64_t c_bs, const double *U, const double *W, const double *Y, const double *Z,
+                       const double *F, const double *bZ, double *bt, double *bc, double *bU, double *bW, double *bY,
+                       c2_stream_t stream);
+int c2_solve_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                       int64_t c_bs, const double *U, const double *W, const double *Y, const double *Z,
+                       const double *F, const double *bZ, double *bt, double *bc, double *bU, double *bW, double *bY,
+                       c2_stream_t stream);
+int c2_matmul_lower_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
+                        const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
+                        const double *Z, const double *F, const double *bZ, double *bt, double *bc, double *bU,
+                        double *bV, double *bY, c2_stream_t stream);
+int c2_matmul_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
+                        const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
+                        const double *Z, const double *F, const double *bZ, double *bt, double *bc, double *bU,
+                        double *bV, double *bY, c2_stream_t stream);
+
+/* driver::get_celerite_matrices -- python/celerite2/driver.cpp:422-477.
+ * Coefficients ar (B,Jr), ac/bc/dc (B,Jc) with batch stride coef_bs in
+ * {0 = shared, 1 = per series}; x (B,N) / shared (N,) via x_bs; diag (B,N).
+ * Outputs a (B,N), U (B,N,J), V (B,N,J), J = Jr + 2 Jc, complex terms at
+ * interleaved columns (Jr+2j, Jr+2j+1). */
+int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
+                             const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
+                             const double *diag, double *a, double *U, double *V, c2_stream_t stream);
+
+/* Fused log-likelihood -- the assembly the reference's callers perform around
+ * factor + solve_lower (python/celerite2/numpy.py:66-87,104-109, core.py:407-428):
+ *   ll[b] = -1/2 (sum log d + N log 2pi) - 1/2 sum z^2/d,  z = L^-1 y.
+ * No d/W/z is materialised.  flag[b] != 0 -> ll[b] = -inf (numpy.py:78-82). */
+int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+              const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+              c2_stream_t stream);
+
+/* Fused log-likelihood + reverse-mode gradient w.r.t. (t, c, a, U, V, y): the
+ * chain factor_fwd -> solve_lower_fwd -> [seeds] -> solve_lower_rev -> factor_rev
+ * an autodiff frontend runs (python/celerite2/pymc/ops.py:104-141,
+ * pymc/distribution.py:123-128), with per-series outputs bt (B,N), bc (B,J),
+ * ba (B,N), bU (B,N,J), bV (B,N,J), by (B,N).  `work` is caller-provided device
+ * scratch of c2_loglik_grad_workspace_bytes(B,N,J) bytes. */
+size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J);
+int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                   const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
+                   double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
+                   size_t work_bytes, c2_stream_t stream);
+
+/* dot_tril -- python/celerite2/numpy.py:100-102: Z = Y * sqrt(d)[:,None];
+ * Z += tril(U W^T) Z.  Y == Z allowed. */
+int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
+                int64_t c_bs, const double *U, const double *W, const double *d, const double *Y, double *Z,
+                c2_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * HOST entry points (B == 1, synchronous) -- what celerite2.driver /
+ * celerite2.backprop bind.  Same argument meaning as the pybind11 functions of
+ * python/celerite2/driver.cpp and backprop.cpp; shapes are passed explicitly.
+ * c2h_factor returns C2_OK and stores the reference's flag in *flag.
+ * ------------------------------------------------------------------------- */
+int c2h_factor(int64_t N, int64_t J, const double *t, const double *c, const double *a, const double *U,
+               const double *V, double *d, double *W, double *S /* nullable */, int64_t *flag);
+int c2h_solve_lower(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                    const double *W, const double *Y, double *Z, double *F /* nullable */);
+int c2h_solve_upper(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                    const double *W, const double *Y, double *Z, double *F /* nullable */);
+int c2h_matmul_lower(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                     const double *V, const double *Y, double *Z, double *F /* nullable */, int zero_z);
+int c2h_matmul_upper(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                     const double *V, const double *Y, double *Z, double *F /* nullable */, int zero_z);
+int c2h_general_matmul_lower(int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, const double *t2,
+                             const double *c, const double *U, const double *V, const double *Y, double *Z,
+                             double *F /* nullable */, int zero_z);
+int c2h_general_matmul_upper(int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, const double *t2,
+                             const double *c, const double *U, const double *V, const double *Y, double *Z,
+                             double *F /* nullable */, int zero_z);
+int c2h_factor_rev(int64_t N, int64_t J, const double *t, const double *c, const double *a, const double *U,
+                   const double *V, const double *d, const double *W, const double *S, const double *bd,
+                   const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV);
+int c2h_solve_lower_rev(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                        const double *W, const double *Y, const double *Z, const double *F, const double *bZ,
+                        double *bt, double *bc, double *bU, double *bW, double *bY);
+int c2h_solve_upper_rev(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                        const double *W, const double *Y, const double *Z, const double *F, const double *bZ,
+                        double *bt, double *bc, double *bU, double *bW, double *bY);
+int c2h_matmul_lower_rev(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                         const double *V, const double *Y, const double *Z, const double *F, const double *bZ,
+                         double *bt, double *bc, double *bU, double *bV, double *bY);
+int c2h_matmul_upper_rev(int64_t N, int64_t J, int64_t nrhs, const double *t, const double *c, const double *U,
+                         const double *V, const double *Y, const double *Z, const double *F, const double *bZ,
+                         double *bt, double *bc, double *bU, double *bV, double *bY);
+int c2h_get_celerite_matrices(int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
+                              const double *bc, const double *dc, const double *x, const double *diag, double *a,
+                              double *U, double *V);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CELERITE2_AMD_H_ */

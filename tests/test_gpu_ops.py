@@ -1,0 +1,239 @@
+# -*- coding: utf-8 -*-
+"""GPU parity tests of the batched device C-ABI (celerite2_amd.ops -> c2_*), against the CPU oracle
+on identical inputs (tolerance 1e-10 relative, north_star) and against the committed golden vectors;
+plus size-independent properties at the BASELINE sizes (N=4096, J=4/8)."""
+import numpy as np
+import pytest
+
+from oracle import dense
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+CPP_KERNELS = ["real", "complex", "sho1", "sho2", "sum1", "sum2", "sum3", "sum4"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+    from celerite2_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def dev(*xs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in xs]
+
+
+def close(a, b, tol=TOL):
+    a = a.cpu().numpy() if hasattr(a, "cpu") else a
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max())))
+
+
+def batch_from_golden(golden, names):
+    """Stack golden cases with the same J into a batch."""
+    return [np.stack([golden["cpp_%s_%s" % (n, k)] for n in names]) for k in ("x", "c", "a", "U", "V", "Y")]
+
+
+@pytest.mark.parametrize("names", [["real"], ["complex", "sho1"], ["sho2"], ["sum1"], ["sum2"], ["sum3"], ["sum4"]])
+def test_golden_cpp_kernels(ops, golden, names):
+    """J = 1, 2, 2, 3, 5, 7, 4 -- every group size up to 8, padded lanes included."""
+    x, c, a, U, V, Y = batch_from_golden(golden, names)
+    xd, cd, ad, Ud, Vd, Yd = dev(x, c, a, U, V, Y)
+    d, W, flag = ops.factor(xd, cd, ad, Ud, Vd)
+    assert int(flag.abs().sum()) == 0
+    for b, n in enumerate(names):
+        p = "cpp_%s_" % n
+        close(d[b], golden[p + "d"])
+    sd = d.sqrt()[:, :, None]
+    close(ops.solve_lower(xd, cd, Ud, W, Yd) / sd, np.stack([golden["cpp_%s_solve_lower" % n] for n in names]), 1e-9)
+    close(ops.solve_upper(xd, cd, Ud, W, (Yd / sd).contiguous()),
+          np.stack([golden["cpp_%s_solve_upper" % n] for n in names]), 1e-8)
+    close(ops.matmul_lower(xd, cd, Ud, Vd, Yd), np.stack([golden["cpp_%s_matmul_lower" % n] for n in names]))
+    close(ops.matmul_upper(xd, cd, Ud, Vd, Yd), np.stack([golden["cpp_%s_matmul_upper" % n] for n in names]))
+    close(ops.dot_tril(xd, cd, Ud, W, d, Yd), np.stack([golden["cpp_%s_dot_tril" % n] for n in names]))
+    ll, flag = ops.loglik(xd, cd, ad, Ud, Vd, Yd[:, :, 0].contiguous())
+    close(ll, np.array([golden["cpp_%s_loglik" % n] for n in names]))
+
+
+def test_config1_loglik(ops, golden):
+    """BASELINE configs[0] through the HIP path: N=1000, J=2, rel err <= 1e-10 vs dense."""
+    t, diag, y = golden["cfg1_t"], golden["cfg1_diag"], golden["cfg1_y"]
+    c, a, U, V = dense.celerite_matrices(dense.sho_term(5.0, 0.1, 3.45), t, diag)
+    td, cd, ad, Ud, Vd, yd = dev(t[None], c[None], a[None], U[None], V[None], y[None])
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    assert int(flag[0]) == 0
+    assert abs(float(ll[0]) - golden["cfg1_loglik"]) <= 1e-10 * abs(golden["cfg1_loglik"])
+
+
+@pytest.mark.parametrize("J", [2, 4, 6, 8, 16, 32])
+def test_ops_vs_oracle_batched(ops, oracle, J):
+    import torch
+    B, N, nrhs = 5, 257, 3
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    rng = np.random.default_rng(3)
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, ad, Ud, Vd, yd, Yd = dev(t, c, a, U, V, y, Y)
+    d, W, S, flag = ops.factor(td, cd, ad, Ud, Vd, workspace=True)
+    do = np.empty_like(a); Wo = np.empty_like(V); So = np.empty((B, N, J, J))
+    for b in range(B):
+        oracle.factor(t[b], c[b], a[b], U[b], V[b], do[b], Wo[b], So[b])
+    assert int(flag.abs().sum()) == 0
+    close(d, do); close(W, Wo); close(S, So)
+    # in-place factor: d aliases a, W aliases V
+    a2, V2 = ad.clone(), Vd.clone()
+    d2, W2, _ = ops.factor(td, cd, a2, Ud, V2, d=a2, W=V2)
+    assert torch.equal(d2, d) and torch.equal(W2, W)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        second = W if name.startswith("solve") else Vd
+        second_o = Wo if name.startswith("solve") else V
+        Z, F = getattr(ops, name)(td, cd, Ud, second, Yd, workspace=True, zero_z=True) if "matmul" in name else \
+            getattr(ops, name)(td, cd, Ud, second, Yd, workspace=True)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], second_o[b], Y[b], Zo[b], Fo[b])
+        close(Z, Zo); close(F, Fo)
+        # in place (Y is Z)
+        Yc = Yd.clone()
+        Zi = getattr(ops, name)(td, cd, Ud, second, Yc, Z=Yc)
+        ref = Zo if name.startswith("solve") else Zo + Y
+        close(Zi, ref)
+        # reverse
+        bZ = rng.standard_normal((B, N, nrhs))
+        (bZd,) = dev(bZ)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, second, Yd, Z, F, bZd)
+        for b in range(B):
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], second_o[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+            for r, e in zip(res, outs):
+                close(r[b], e)
+    # factor_rev
+    bd = rng.standard_normal((B, N)); bW = rng.standard_normal((B, N, J))
+    bdd, bWd = dev(bd, bW)
+    res = ops.factor_rev(td, cd, ad, Ud, Vd, d, W, S, bdd, bWd)
+    for b in range(B):
+        outs = [np.empty(N), np.empty(J), np.empty(N), np.empty((N, J)), np.empty((N, J))]
+        oracle.factor_rev(t[b], c[b], a[b], U[b], V[b], do[b], Wo[b], So[b], bd[b], bW[b], *outs)
+        for r, e in zip(res, outs):
+            close(r[b], e)
+
+
+@pytest.mark.parametrize("J", [2, 4, 8])
+def test_loglik_and_grad_vs_oracle(ops, oracle, J):
+    B, N = 9, 300
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    close(ll, llo)
+    ll2, grads, flag2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    close(ll2, llo)
+    for g, e in zip(grads, go):
+        close(g, e)
+
+
+def test_loglik_grad_golden(ops, golden):
+    x, c, a, U, V = (golden["py_" + k] for k in ("x", "c", "a", "U", "V"))
+    y = np.ascontiguousarray(golden["py_Y"][:, 0])
+    xd, cd, ad, Ud, Vd, yd = dev(x[None], c[None], a[None], U[None], V[None], y[None])
+    ll, grads, flag = ops.loglik_grad(xd, cd, ad, Ud, Vd, yd)
+    close(ll, np.array([golden["py_loglik"]]))
+    for name, g in zip(("bt", "bc", "ba", "bU", "bV", "by"), grads):
+        close(g[0], golden["py_grad_" + name])
+
+
+def test_shared_t_and_c(ops, oracle):
+    """t (N,) and c (J,) shared by the whole batch (batch stride 0)."""
+    B, N, J = 4, 200, 4
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    t0, c0 = t[0].copy(), c[0].copy()
+    td, cd, ad, Ud, Vd, yd = dev(t0, c0, a, U, V, y)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    for b in range(B):
+        e, f = oracle.loglik(t0, c0, a[b], U[b], V[b], y[b])
+        if f == 0:
+            close(ll[b:b + 1], np.array([e]))
+        else:
+            assert int(flag[b]) == f
+
+
+def test_not_positive_definite_flags(ops, oracle):
+    B, N, J = 6, 128, 4
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    a[2, 57] = -3.0
+    a[4, 1] = -1.0
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    d, W, flag = ops.factor(td, cd, ad, Ud, Vd)
+    assert flag.cpu().tolist() == [0, 0, 57, 0, 1, 0]
+    ll, flag2 = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    assert flag2.cpu().tolist() == [0, 0, 57, 0, 1, 0]
+    assert np.isneginf(ll.cpu().numpy()[[2, 4]]).all() and np.isfinite(ll.cpu().numpy()[[0, 1, 3, 5]]).all()
+
+
+def test_edge_sizes(ops, oracle):
+    """N = 1, N = 2, B not a multiple of the series-per-wave packing."""
+    for N in (1, 2, 5):
+        B, J = 11, 2
+        t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+        td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+        llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=1)
+        ll, grads, flag = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+        close(ll, llo)
+        for g, e in zip(grads, go):
+            close(g, e)
+    with pytest.raises(ValueError):
+        import torch
+        z = torch.zeros((1, 0, 2), dtype=torch.float64, device="cuda")
+        ops.loglik(torch.zeros((1, 0), dtype=torch.float64, device="cuda"), torch.zeros((1, 2), dtype=torch.float64, device="cuda"),
+                   torch.zeros((1, 0), dtype=torch.float64, device="cuda"), z, z, torch.zeros((1, 0), dtype=torch.float64, device="cuda"))
+
+
+def test_get_celerite_matrices_batched(ops):
+    import torch
+    B, N, J = 3, 100, 6
+    rng = np.random.default_rng(9)
+    x = np.sort(rng.uniform(0, 10, (B, N)), axis=1); diag = rng.uniform(0.1, 0.3, (B, N))
+    cos = [dense.sho_sum_coeffs(J, xi) for xi in (-0.5, 0.0, 0.7)]
+    ac = np.stack([co.ac for co in cos]); bc = np.stack([co.bc for co in cos]); dc = np.stack([co.dc for co in cos])
+    ar = np.zeros((B, 0))
+    a, U, V = ops.get_celerite_matrices(*dev(ar, ac, bc, dc, x, diag))
+    for b in range(B):
+        c_, a_, U_, V_ = dense.celerite_matrices(cos[b], x[b], diag[b])
+        close(a[b], a_, 1e-13); close(U[b], U_, 1e-12); close(V[b], V_, 1e-12)
+
+
+# ---- BASELINE sizes: size-independent properties (the oracle is only run on a few series) --------------
+@pytest.mark.parametrize("J,B", [(4, 1024), (8, 512)])
+def test_full_size_properties(ops, oracle, J, B):
+    import torch
+    N = 4096
+    nb = 4  # distinct series; the batch tiles them
+    t, c, a, U, V, y = dense.synthetic_batch(nb, N, J)
+    rep = B // nb
+    td, cd, ad, Ud, Vd, yd = [x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous() for x in dev(t, c, a, U, V, y)]
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0
+    # (1) identical series -> bit-identical results wherever they sit in the batch / wavefront
+    assert torch.equal(ll[:nb].repeat(rep), ll)
+    # (2) oracle parity on the distinct series
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=4)
+    close(ll[:nb], llo)
+    # (3) gradient: parity + directional finite difference of the GPU forward
+    ll2, grads, flag2 = ops.loglik_grad(td[:64], cd[:64], ad[:64], Ud[:64], Vd[:64], yd[:64])
+    close(ll2[:nb], llo)
+    for g, e in zip(grads, go):
+        close(g[:nb], e)
+    # (4) solve/matmul round trip: L^-1 (L z) == z with L = I + tril(U W^T)
+    d, W, _ = ops.factor(td[:8], cd[:8], ad[:8], Ud[:8], Vd[:8])
+    z = torch.randn((8, N, 2), dtype=torch.float64, device="cuda")
+    Lz = ops.matmul_lower(td[:8], cd[:8], Ud[:8], W, z, Z=z.clone())
+    back = ops.solve_lower(td[:8], cd[:8], Ud[:8], W, Lz)
+    assert float((back - z).abs().max()) < 1e-9
+    # (5) linearity of matmul_lower in Y
+    y1 = torch.randn((8, N, 1), dtype=torch.float64, device="cuda")
+    y2 = torch.randn((8, N, 1), dtype=torch.float64, device="cuda")
+    f = lambda v: ops.matmul_lower(td[:8], cd[:8], Ud[:8], Vd[:8], v.contiguous())
+    lhs, rhs = f(2.0 * y1 - 3.0 * y2), 2.0 * f(y1) - 3.0 * f(y2)
+    assert float((lhs - rhs).abs().max()) <= 1e-10 * float(rhs.abs().max())

@@ -1,0 +1,203 @@
+# -*- coding: utf-8 -*-
+"""Pins the CPU restatement (oracle/c2_oracle.cpp) against the committed golden vectors and against
+dense math / finite differences, replaying the checks of the reference's own tests:
+c++/test/test_factor.cpp:16-77, test_solve_lower.cpp:23-43, test_matmul_lower.cpp:17-23,
+python/test/test_driver.py:8-135, python/test/test_backprop.py:9-174, c++/test/helpers.hpp:230-244."""
+import numpy as np
+import pytest
+
+from oracle import dense
+
+CPP_KERNELS = ["real", "complex", "sho1", "sho2", "sum1", "sum2", "sum3", "sum4"]
+PREFIXES = ["cpp_%s_" % k for k in CPP_KERNELS] + ["py_"]
+
+
+def _get(golden, p):
+    return tuple(np.ascontiguousarray(golden[p + k]) for k in ("x", "c", "a", "U", "V", "Y"))
+
+
+@pytest.mark.parametrize("p", PREFIXES)
+def test_factor_vs_dense(oracle, golden, p):
+    x, c, a, U, V, Y = _get(golden, p)
+    d = np.empty_like(a); W = np.empty_like(V)
+    oracle.factor(x, c, a, U, V, d, W)
+    np.testing.assert_allclose(d, golden[p + "d"], rtol=1e-11, atol=1e-12)
+    # I + tril(U W^T) (with the decay) must be the unit-lower Cholesky factor (test_factor.cpp:24-38)
+    Lunit = np.eye(len(x))
+    Z = np.zeros_like(Lunit)
+    oracle.matmul_lower(x, c, U, W, np.eye(len(x)), Z)
+    np.testing.assert_allclose(Lunit + Z, golden[p + "Lunit"], atol=1e-11)
+    # in-place == out-of-place (test_factor.cpp:60-77, test_driver.py:11-15)
+    a2 = a.copy(); V2 = V.copy()
+    d2, W2 = oracle.factor(x, c, a2, U, V2, a2, V2)
+    assert d2 is a2 and W2 is V2
+    np.testing.assert_array_equal(a2, d); np.testing.assert_array_equal(V2, W)
+    # workspace variant == plain (test_backprop.py:45-56)
+    S = np.empty((len(x), len(c), len(c)))
+    d3 = np.empty_like(a); W3 = np.empty_like(V)
+    oracle.factor(x, c, a, U, V, d3, W3, S)
+    np.testing.assert_array_equal(d3, d); np.testing.assert_array_equal(W3, W)
+    assert np.all(S[0] == 0.0)
+
+
+@pytest.mark.parametrize("p", PREFIXES)
+def test_solves_and_matmuls_vs_dense(oracle, golden, p):
+    x, c, a, U, V, Y = _get(golden, p)
+    d = np.empty_like(a); W = np.empty_like(V)
+    oracle.factor(x, c, a, U, V, d, W)
+    sd = np.sqrt(d)[:, None]
+    Z = np.empty_like(Y)
+    oracle.solve_lower(x, c, U, W, Y, Z)
+    np.testing.assert_allclose(Z / sd, golden[p + "solve_lower"], rtol=1e-9, atol=1e-10)
+    Yin = np.ascontiguousarray(Y / sd)
+    Z = Yin.copy()
+    out = oracle.solve_upper(x, c, U, W, Z, Z)  # in place (test_driver.py:53-56)
+    assert out is Z
+    np.testing.assert_allclose(Z, golden[p + "solve_upper"], rtol=1e-8, atol=1e-9)
+    for name in ("matmul_lower", "matmul_upper"):
+        Z = np.zeros_like(Y)
+        getattr(oracle, name)(x, c, U, V, Y, Z)
+        e = golden[p + name]
+        np.testing.assert_allclose(Z, e, atol=1e-11 * np.abs(e).max())
+        Z2 = np.empty_like(Y); F = np.empty((len(x), len(c), Y.shape[1]))
+        getattr(oracle, name + "_fwd")(x, c, U, V, Y, Z2, F)
+        np.testing.assert_array_equal(Z2, Z)
+    # dot_tril (numpy.py:100-102): z = y sqrt(d); z += tril(U W^T) z
+    z = np.ascontiguousarray(Y * sd)
+    oracle.matmul_lower(x, c, U, W, z, z)
+    e = golden[p + "dot_tril"]
+    np.testing.assert_allclose(z, e, atol=1e-11 * np.abs(e).max())
+    ll, flag = oracle.loglik(x, c, a, U, V, np.ascontiguousarray(Y[:, 0]))
+    assert flag == 0
+    np.testing.assert_allclose(ll, golden[p + "loglik"], rtol=1e-12)
+
+
+def test_general_matmul_vs_dense(oracle, golden):
+    p = "py_"
+    x, c, a, U, V, Y = _get(golden, p)
+    t, U2, V2 = golden["py_t"], np.ascontiguousarray(golden["py_U2"]), np.ascontiguousarray(golden["py_V2"])
+    Z = np.zeros((len(t), Y.shape[1]))
+    oracle.general_matmul_lower(t, x, c, U2, V, Y, Z)
+    oracle.general_matmul_upper(t, x, c, V2, U, Y, Z)
+    e = golden["py_general_matmul"]
+    np.testing.assert_allclose(Z, e, atol=1e-11 * np.abs(e).max())
+    # fallback case: same grid on both sides, no diagonal (test_driver.py:117-135)
+    m = dense.get_matrices(include_dense=True, no_diag=True)
+    Z = np.zeros_like(m["Y"])
+    oracle.general_matmul_lower(m["x"], m["x"], m["c"], m["U"], m["V"], m["Y"], Z)
+    oracle.general_matmul_upper(m["x"], m["x"], m["c"], m["V"], m["U"], m["Y"], Z)
+    e = m["K"] @ m["Y"]
+    np.testing.assert_allclose(Z, e, atol=1e-10 * np.abs(e).max())
+
+
+def test_get_celerite_matrices(oracle, golden):
+    co = dense.cpp_test_kernels()["sum3"]
+    x, diag = golden["cpp_sum3_x"], golden["cpp_sum3_diag"]
+    J = co.J
+    a = np.empty(len(x)); U = np.empty((len(x), J)); V = np.empty((len(x), J))
+    oracle.get_celerite_matrices(co.ar, co.ac, co.bc, co.dc, x, diag, a, U, V)
+    np.testing.assert_allclose(a, golden["cpp_sum3_a"], rtol=1e-15)
+    np.testing.assert_allclose(U, golden["cpp_sum3_U"], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(V, golden["cpp_sum3_V"], rtol=1e-14, atol=1e-15)
+    # semiseparable identity K_nm = sum_j U_nj V_mj exp(-c_j (t_n - t_m)), n > m (forward.hpp:33-41)
+    c = golden["cpp_sum3_c"]
+    K = dense.dense_matrix(co, x, diag)
+    n, m = 17, 5
+    np.testing.assert_allclose(np.sum(U[n] * V[m] * np.exp(-c * (x[n] - x[m]))), K[n, m], rtol=1e-12)
+
+
+def _fd_jacobian_check(fwd, rev, in_args, n_out, extra, eps=1.234e-8, tol=500 * 1.234e-8):
+    """helpers.hpp:230-244 / test_backprop.py:9-42: one-hot cotangents vs first-order forward differences."""
+    def run():
+        outs = [np.zeros_like(o) for o in n_out]
+        ex = [np.zeros_like(e) for e in extra]
+        res = fwd(*(list(in_args) + outs + ex))
+        return [np.copy(r) for r in res[:len(n_out)]], [np.copy(r) for r in res[len(n_out):]]
+    vals0, extra0 = run()
+    jac = []
+    for arg in in_args:
+        rows = [np.empty((arg.size, o.size)) for o in vals0]
+        for m in range(arg.size):
+            old = arg.flat[m]
+            arg.flat[m] = old + eps
+            vals, _ = run()
+            arg.flat[m] = old
+            for k in range(len(vals0)):
+                rows[k][m] = (vals[k] - vals0[k]).ravel() / eps
+        jac.append(rows)
+    for k in range(len(vals0)):
+        for i in range(0, vals0[k].size, max(1, vals0[k].size // 9)):
+            b_out = [np.zeros_like(v) for v in vals0]
+            b_out[k].flat[i] = 1.0
+            b_in = [np.zeros_like(a) for a in in_args]
+            res = rev(*(list(in_args) + vals0 + extra0 + b_out + b_in))
+            for n, b in enumerate(res):
+                scale = 1.0 + np.abs(jac[n][k][:, i]).max()
+                np.testing.assert_allclose(b.ravel(), jac[n][k][:, i], atol=tol * scale * 50)
+
+
+@pytest.mark.parametrize("kernel", ["real", "sum2", "sum3"])
+def test_factor_rev_fd(oracle, kernel):
+    x, diag, Y = dense.cpp_test_data(10, 5)
+    c, a, U, V = dense.celerite_matrices(dense.cpp_test_kernels()[kernel], x, diag)
+    J = len(c)
+    _fd_jacobian_check(oracle.factor_fwd, oracle.factor_rev, [x, c, a, U, V], [np.empty(10), np.empty((10, J))],
+                       [np.empty((10, J, J))])
+
+
+@pytest.mark.parametrize("op", ["solve_lower", "solve_upper", "matmul_lower", "matmul_upper"])
+@pytest.mark.parametrize("kernel", ["complex", "sum3"])
+def test_sweep_rev_fd(oracle, op, kernel):
+    x, diag, Y = dense.cpp_test_data(10, 3)
+    c, a, U, V = dense.celerite_matrices(dense.cpp_test_kernels()[kernel], x, diag)
+    J = len(c)
+    if op.startswith("solve"):
+        d = np.empty_like(a); W = np.empty_like(V)
+        oracle.factor(x, c, a, U, V, d, W)
+        V = W
+    _fd_jacobian_check(getattr(oracle, op + "_fwd"), getattr(oracle, op + "_rev"), [x, c, U, V, Y],
+                       [np.empty_like(Y)], [np.empty((10, J, 3))])
+
+
+def test_loglik_grad_golden(oracle, golden):
+    x, c, a, U, V, Y = _get(golden, "py_")
+    y = np.ascontiguousarray(Y[:, 0])
+    ll, grads, flag = oracle.loglik_grad(x, c, a, U, V, y)
+    assert flag == 0
+    np.testing.assert_allclose(ll, golden["py_loglik"], rtol=1e-12)
+    for name, g in zip(("bt", "bc", "ba", "bU", "bV", "by"), grads):
+        e = golden["py_grad_" + name]
+        np.testing.assert_allclose(g, e, rtol=1e-10, atol=1e-12 * np.abs(e).max())
+
+
+def test_config1_loglik(oracle, golden):
+    """BASELINE.json configs[0]: single GP, N=1000, J=2 (one SHOTerm) -> rel err <= 1e-10 vs dense."""
+    t, diag, y = golden["cfg1_t"], golden["cfg1_diag"], golden["cfg1_y"]
+    c, a, U, V = dense.celerite_matrices(dense.sho_term(5.0, 0.1, 3.45), t, diag)
+    ll, flag = oracle.loglik(t, c, a, U, V, y)
+    assert flag == 0
+    assert abs(ll - golden["cfg1_loglik"]) <= 1e-10 * abs(golden["cfg1_loglik"])
+
+
+def test_not_positive_definite_flag(oracle):
+    m = dense.get_matrices()
+    a = m["a"].copy()
+    a[37] = -5.0
+    d = np.empty_like(a); W = np.empty_like(m["V"])
+    assert oracle.factor_flag(m["x"], m["c"], a, m["U"], m["V"], d, W) == 37
+    assert d[37] <= 0
+    with pytest.raises(oracle.LinAlgError):
+        oracle.factor(m["x"], m["c"], a, m["U"], m["V"], d, W)
+
+
+def test_batched_matches_single(oracle):
+    t, c, a, U, V, y = dense.synthetic_batch(5, 64, 4)
+    ll, flag = oracle.loglik_batched(t, c, a, U, V, y, nthreads=2)
+    ll2, g2, flag2 = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    for b in range(5):
+        l1, f1 = oracle.loglik(t[b], c[b], a[b], U[b], V[b], y[b])
+        assert f1 == 0 and flag[b] == 0 and flag2[b] == 0
+        assert l1 == ll[b] == ll2[b]
+        _, g1, _ = oracle.loglik_grad(t[b], c[b], a[b], U[b], V[b], y[b])
+        for u, v in zip(g1, g2):
+            np.testing.assert_array_equal(u, v[b])

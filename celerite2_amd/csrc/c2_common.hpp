@@ -20,8 +20,10 @@ constexpr int kWave = 64;
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  // mov_dpp with bound_ctrl: no tied "old" operand, so no extra v_mov to initialise the destination.
+  // Every permutation used here stays inside a DPP row, so no lane ever reads an invalid source.
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]

@@ -19,6 +19,8 @@
 // Scalar all-reduces (d_n, z_n, ...) are DPP butterflies (gsum).  With 8192 series per GPU at J=8 the
 // launch is exactly one wavefront per SIMD, so HBM latency is hidden by an explicit register prefetch
 // ring (R rows ahead), not by occupancy.
+#include <type_traits>
+
 #include "c2_common.hpp"
 #include "../../include/celerite2_amd.h"
 
@@ -45,52 +47,109 @@ __device__ __forceinline__ double rcp_nr(double d) {
   return r;
 }
 
-// Broadcast read of the G doubles a group wrote into an LDS slot.
-template <int G>
-__device__ __forceinline__ void lds_get(const double *slot, int gbase, double (&out)[G]) {
-  if constexpr (G == 1) {
-    out[0] = slot[gbase];
-  } else {
-    const double2 *p = reinterpret_cast<const double2 *>(slot + gbase);
-#pragma unroll
-    for (int k = 0; k < G / 2; ++k) {
-      const double2 v = p[k];
-      out[2 * k] = v.x;
-      out[2 * k + 1] = v.y;
-    }
-  }
+// exp(x) for the decay factors p = exp(c (t_{n-1} - t_n)), x <= 0 in every valid call.
+// k = rint(x log2 e), r = x - k ln2 (two-term Cody-Waite), degree-11 near-minimax polynomial on
+// |r| <= ln2/2 (Chebyshev fit, exact-arithmetic error 4e-18, 1 ulp in double Horner), result scaled by
+// v_ldexp_f64 (which also flushes the underflow range to 0).  16 VALU instructions.
+__device__ __forceinline__ double exp_decay(double x) {
+  x = fmax(x, -1000.0);
+  const double k = rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  double q = 2.51100492048186583e-08;
+  q = fma(q, r, 2.76326547225277896e-07);
+  q = fma(q, r, 2.75572408872298695e-06);
+  q = fma(q, r, 2.48014854415613131e-05);
+  q = fma(q, r, 1.98412698900764028e-04);
+  q = fma(q, r, 1.38888889523528631e-03);
+  q = fma(q, r, 8.33333333331958900e-03);
+  q = fma(q, r, 4.16666666664879531e-02);
+  q = fma(q, r, 1.66666666666666796e-01);
+  q = fma(q, r, 5.00000000000001887e-01);
+  q = fma(q, r, 1.0);
+  q = fma(q, r, 1.0);
+  return ldexp(q, (int)k);
 }
+
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 
-// Checkpoint record of one lane: S[0..G-1] (column j), F_j, w_j, d, z  -> G+4 doubles.
+// -----------------------------------------------------------------------------------------------
+// XOR-ordered group gathers.  Every width-J object a lane keeps in registers is stored in XOR order:
+// slot k of lane j holds element (j ^ k), so that a gathered vector x becomes xX[k] = x[j ^ k] and all
+// contractions sum_i a_i B(i,j) read sum_k aX[k] BX[k].  Two ways to gather:
+//   xgather_dpp : on the VALU with DPP lane permutes (7 permutes of a double at G=8) -- low latency, used
+//                 for the ONE vector per step that sits on the recursion's critical path;
+//   xgather_lds : through LDS (lane j reads slot[(lane ^ k)], G conflict-free ds_read_b64) -- free for
+//                 the VALU, used for vectors known ahead of time (p, U_n, saved W_{n-1}).
+// -----------------------------------------------------------------------------------------------
+constexpr int kDppXor3 = 0x1B;  // quad_perm [3,2,1,0]
+
+template <int G>
+__device__ __forceinline__ void xgather_lds(const double *slot, int lane, double (&out)[G]) {
+#pragma unroll
+  for (int k = 0; k < G; ++k) out[k] = slot[lane ^ k];
+}
+
+template <int G>
+__device__ __forceinline__ void xgather_dpp(double x, double *xslot, int lane, double (&out)[G]) {
+  out[0] = x;
+  if constexpr (G == 2) {
+    out[1] = dpp_mov<kDppXor1>(x);
+  } else if constexpr (G == 4 || G == 8 || G == 16) {
+    out[1] = dpp_mov<kDppXor1>(x);
+    out[2] = dpp_mov<kDppXor2>(x);
+    out[3] = dpp_mov<kDppXor3>(x);
+    if constexpr (G >= 8) {
+      const double y = dpp_mov<kDppHalfMirror>(x);  // lane l <- l ^ 7
+      out[7] = y;
+      out[6] = dpp_mov<kDppXor1>(y);
+      out[5] = dpp_mov<kDppXor2>(y);
+      out[4] = dpp_mov<kDppXor3>(y);
+    }
+    if constexpr (G == 16) {
+      const double z = dpp_mov<kDppMirror>(x);      // lane l <- l ^ 15
+      out[15] = z;
+      out[14] = dpp_mov<kDppXor1>(z);
+      out[13] = dpp_mov<kDppXor2>(z);
+      out[12] = dpp_mov<kDppXor3>(z);
+      const double zy = dpp_mov<kDppHalfMirror>(z);  // lane l <- l ^ 8
+      out[8] = zy;
+      out[9] = dpp_mov<kDppXor1>(zy);
+      out[10] = dpp_mov<kDppXor2>(zy);
+      out[11] = dpp_mov<kDppXor3>(zy);
+    }
+  } else if constexpr (G == 32) {  // crosses DPP rows: go through LDS
+    xslot[lane] = x;
+    lds_order();
+    xgather_lds<G>(xslot, lane, out);
+  }
+}
+
+// Checkpoint record of one lane: SX[0..G-1] (column j, XOR order), F_j, w_j, d, z  -> G+4 doubles.
 template <int G>
 struct Ckpt {
   static constexpr int W = G + 4;
 };
 
-// One forward step (row n) of factor + solve_lower.  On entry S/F/w/d/z describe row n-1, on exit row n.
-// Returns p_j; the half... (see callers for what is saved).
+// The chain part of one forward step (row n) of factor + solve_lower: everything that depends on the
+// previous row's W.  pX/uX are the XOR-gathered p_n and U_n (prepared ahead of time, off the chain).
+// On entry SX/F/w/d/z describe row n-1, on exit row n.
 template <int G>
-__device__ __forceinline__ double fwd_step(double cj, double dt, double an, double yn, double u, double v,
-                                           double (&S)[G], double &F, double &w, double &d, double &z, double &rd,
-                                           double *slotP, double *slotU, double *slotW, int lane, int gbase) {
-  const double p = exp(cj * dt);
-  slotP[lane] = p;
-  slotU[lane] = u;
-  slotW[lane] = w;  // W row n-1
-  lds_order();
-  double pi[G], ui[G], wi[G];
-  lds_get<G>(slotP, gbase, pi);
-  lds_get<G>(slotU, gbase, ui);
-  lds_get<G>(slotW, gbase, wi);
+__device__ __forceinline__ void fwd_chain(double p, double u, double v, double an, double yn, const double (&pX)[G],
+                                          const double (&uX)[G], double (&SX)[G], double &F, double &w, double &d,
+                                          double &z, double &rd, double *xslot, int lane) {
+  double wX[G];
+  xgather_dpp<G>(w, xslot, lane, wX);
   const double dw = d * w;
-  double tau = 0.0;
+  double tau0 = 0.0, tau1 = 0.0;
 #pragma unroll
-  for (int i = 0; i < G; ++i) {
-    const double s = (pi[i] * p) * fma(dw, wi[i], S[i]);  // S = P (S + d w^T w) P   (forward.hpp:115-123)
-    S[i] = s;
-    tau = fma(ui[i], s, tau);                              // tau = U_n S            (forward.hpp:126)
+  for (int k = 0; k < G; ++k) {
+    const double s = (pX[k] * p) * fma(dw, wX[k], SX[k]);  // S = P (S + d w^T w) P   (forward.hpp:115-123)
+    SX[k] = s;
+    if (k & 1) tau1 = fma(uX[k], s, tau1);                 // tau = U_n S            (forward.hpp:126)
+    else tau0 = fma(uX[k], s, tau0);
   }
+  const double tau = tau0 + tau1;
   F = p * fma(w, z, F);                                    // F = P (F + W_{n-1}^T z_{n-1})  (internal.hpp:140-143)
   const double dn = an - gsum<G>(tau * u);                 // forward.hpp:127
   const double zn = yn - gsum<G>(u * F);                   // internal.hpp:144
@@ -98,11 +157,37 @@ __device__ __forceinline__ double fwd_step(double cj, double dt, double an, doub
   w = (v - tau) * rd;                                      // forward.hpp:131
   d = dn;
   z = zn;
-  return p;
 }
+
+// Lane geometry shared by the forward and reverse kernels: wave-uniform bases + small per-lane offsets,
+// so that global addresses are (SGPR base) + (VGPR offset) + (immediate) and cost no VALU per load.
+template <int G>
+struct Geo {
+  int lane, j, jj;
+  bool valid, act;
+  int64_t b0;     // first series of this wavefront (uniform)
+  int64_t b;      // this lane's series (clamped)
+  int sl;         // series index inside the wavefront (clamped)
+  __device__ __forceinline__ Geo(int64_t B, int J) {
+    constexpr int SPW = kWave / G;
+    lane = threadIdx.x;
+    j = lane & (G - 1);
+    b0 = (int64_t)blockIdx.x * SPW;
+    sl = lane / G;
+    const int64_t maxsl = B - 1 - b0;
+    valid = sl <= maxsl;
+    if (!valid) sl = (int)maxsl;
+    b = b0 + sl;
+    act = j < J;
+    jj = act ? j : 0;
+  }
+};
 
 // =============================================================================
 // Forward pass.  R = prefetch ring length (rows), C = checkpoint interval (R % C == 0).
+// Software pipeline per step n:   (a) p_{n+1} = exp(c dt_{n+1}) and U_{n+1} go to the LDS slots and are
+// gathered back in XOR order for the NEXT step;  (b) the chain of step n runs on the vectors gathered
+// during step n-1;  (c) ring slot r is refilled with row n+R.
 // =============================================================================
 template <int G, int R, int C, bool CKPT>
 __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, int J, const double *__restrict__ t,
@@ -115,82 +200,111 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, i
                                                          int64_t nseg) {
   static_assert(R % C == 0, "ring length must be a multiple of the checkpoint interval");
   __shared__ __attribute__((aligned(16))) double xs[3][kWave];
-  const int lane = threadIdx.x;
-  const int gbase = lane & ~(G - 1);
-  const int64_t g = (int64_t)blockIdx.x * kWave + lane;
-  int64_t b = g / G;
-  const int j = lane & (G - 1);
-  const bool valid = b < B;
-  if (!valid) b = B - 1;
-  const bool act = j < J;
-  const int jj = act ? j : 0;
-  const double *tb = t + b * t_bs, *ab = a + b * N, *yb = y + b * N;
-  const double *Ub = U + b * N * J + jj, *Vb = V + b * N * J + jj;
-  const double cj = act ? c[b * c_bs + j] : 0.0;
-  double *ck = CKPT ? ckpt + ((b * nseg) * G + j) * Ckpt<G>::W : nullptr;
+  const Geo<G> L(B, J);
+  const int lane = L.lane, j = L.j;
+  const bool act = L.act;
+  // wave-uniform bases, per-lane element offsets
+  const double *tw = t + L.b0 * t_bs, *aw = a + L.b0 * N, *yw = y + L.b0 * N;
+  const double *Uw = U + L.b0 * N * J, *Vw = V + L.b0 * N * J;
+  const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
+  const double *tb = tw + ot, *ab = aw + on, *yb = yw + on, *Ub = Uw + oj, *Vb = Vw + oj;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  double *ck = CKPT ? ckpt + ((L.b * nseg) * G + j) * Ckpt<G>::W : nullptr;
 
-  double S[G];
+  double SX[G];
 #pragma unroll
-  for (int i = 0; i < G; ++i) S[i] = 0.0;
+  for (int k = 0; k < G; ++k) SX[k] = 0.0;
   double d = ab[0];
   double rd = 1.0 / d;
   double w = act ? Vb[0] * rd : 0.0;
   double z = yb[0];
   double F = 0.0;
-  double tprev = tb[0];
   double prod = d;       // running product of pivots, renormalised with frexp -> log det
   int eacc = 0;
   double quad = z * z * rd;
+  int32_t fl = 0;
 
   double rt[R], ra[R], ry[R], ru[R], rv[R];
-  auto load_row = [&](int r, int64_t n) {
-    const int64_t nn = (n < N) ? n : N - 1;
+  auto load_row = [&](int r, int64_t n, bool clamp) {
+    const int64_t nn = (!clamp || n < N) ? n : N - 1;
     rt[r] = tb[nn]; ra[r] = ab[nn]; ry[r] = yb[nn];
     ru[r] = act ? Ub[nn * J] : 0.0; rv[r] = act ? Vb[nn * J] : 0.0;
   };
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+  for (int r = 0; r < R; ++r) load_row(r, 1 + r, true);
 
-  int32_t fl = 0;
-  bool alive = true;
-  for (int64_t n0 = 1; n0 < N; n0 += R) {
+  // prepare step 1
+  double tcur = tb[0];
+  double pc = exp_decay(cj * (tcur - rt[0])), uc = ru[0];
+  double pXc[G], uXc[G];
+  xs[0][lane] = pc; xs[1][lane] = uc;
+  lds_order();
+  xgather_lds<G>(xs[0], lane, pXc);
+  xgather_lds<G>(xs[1], lane, uXc);
+  lds_order();
+
+  auto block = [&](int64_t n0, auto checked_tag) {
+    constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t n = n0 + r;
-      if (n < N && alive) {
-        if (CKPT && (r % C == 0) && valid) {  // state after row n-1 = checkpoint (n-1)/C
+      if (!CHECKED || n < N) {
+        if (CKPT && (r % C == 0) && L.valid) {  // state after row n-1 = checkpoint (n-1)/C
           double *q = ck + ((n - 1) / C) * (G * Ckpt<G>::W);
+          if constexpr (Ckpt<G>::W % 2 == 0) {
+            double2 *q2 = reinterpret_cast<double2 *>(q);
 #pragma unroll
-          for (int i = 0; i < G; ++i) q[i] = S[i];
-          q[G] = F; q[G + 1] = w; q[G + 2] = d; q[G + 3] = z;
-        }
-        const double tn = rt[r], an = ra[r], yn = ry[r], u = ru[r], v = rv[r];
-        load_row(r, n + R);
-        fwd_step<G>(cj, tprev - tn, an, yn, u, v, S, F, w, d, z, rd, xs[0], xs[1], xs[2], lane, gbase);
-        tprev = tn;
-        if (d <= 0.0) {  // forward.hpp:128 (NaN passes, as in the reference)
-          fl = (int32_t)n;
-          alive = false;
-        } else {
-          prod *= d;
-          quad = fma(z * z, rd, quad);
-          if (r % 8 == 7) {
-            int e;
-            prod = frexp(prod, &e);
-            eacc += e;
+            for (int k = 0; k < G / 2; ++k) q2[k] = make_double2(SX[2 * k], SX[2 * k + 1]);
+            q2[G / 2] = make_double2(F, w);
+            q2[G / 2 + 1] = make_double2(d, z);
+          } else {
+#pragma unroll
+            for (int k = 0; k < G; ++k) q[k] = SX[k];
+            q[G] = F; q[G + 1] = w; q[G + 2] = d; q[G + 3] = z;
           }
         }
+        const double tn = rt[r], an = ra[r], yn = ry[r], v = rv[r];
+        // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
+        const int rn = (r + 1) % R;
+        const double pn1 = exp_decay(cj * (tn - rt[rn])), un1 = ru[rn];
+        xs[0][lane] = pn1; xs[1][lane] = un1;
+        lds_order();
+        double pXn[G], uXn[G];
+        xgather_lds<G>(xs[0], lane, pXn);
+        xgather_lds<G>(xs[1], lane, uXn);
+        lds_order();
+        // (b) the chain of step n
+        fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
+        // (c) refill ring slot r with row n + R
+        load_row(r, n + R, CHECKED);
+        // forward.hpp:128: first non-positive pivot (NaN passes, as in the reference); no early exit --
+        // a failed series simply runs to the end on garbage, its outputs are flagged.
+        fl = (fl == 0 && d <= 0.0) ? (int32_t)n : fl;
+        prod *= d;
+        quad = fma(z * z, rd, quad);
+        if (r % 8 == 7) {
+          int e;
+          prod = frexp(prod, &e);
+          eacc += e;
+        }
+        pc = pn1; uc = un1;
+#pragma unroll
+        for (int k = 0; k < G; ++k) { pXc[k] = pXn[k]; uXc[k] = uXn[k]; }
       }
     }
-    if (!alive) break;
-  }
-  if (valid && j == 0) {
-    flag[b] = fl;
-    const double logdet = log(prod) + (double)eacc * kLn2;
-    ll[b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
+  };
+  int64_t n0 = 1;
+  for (; n0 + 2 * R <= N; n0 += R) block(n0, std::false_type{});  // every load in range: no clamps
+  for (; n0 < N; n0 += R) block(n0, std::true_type{});
+
+  if (L.valid && j == 0) {
+    flag[L.b] = fl;
+    int e;
+    prod = frexp(prod, &e);
+    const double logdet = log(prod) + (double)(eacc + e) * kLn2;
+    ll[L.b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
   }
 }
-
 
 // =============================================================================
 // Reverse sweep with segment recomputation.  For segment k (rows n_lo = 1 + kC ... n_lo + C - 1), last
@@ -224,131 +338,149 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, i
                                                          double *__restrict__ bc, double *__restrict__ ba,
                                                          double *__restrict__ bU, double *__restrict__ bV,
                                                          double *__restrict__ by) {
-  __shared__ __attribute__((aligned(16))) double vP[C][kWave], vU[C][kWave], vW[C][kWave], xB[kWave];
-  const int lane = threadIdx.x;
-  const int gbase = lane & ~(G - 1);
-  const int64_t g = (int64_t)blockIdx.x * kWave + lane;
-  int64_t b = g / G;
-  const int j = lane & (G - 1);
-  const bool valid = b < B;
-  if (!valid) b = B - 1;
-  const bool act = j < J;
-  const int jj = act ? j : 0;
-  const bool st = valid && act, st0 = valid && j == 0;
-  const double *tb = t + b * t_bs, *ab = a + b * N, *yb = y + b * N;
-  const double *Ub = U + b * N * J + jj, *Vb = V + b * N * J + jj;
-  const double *ck = ckpt + ((b * nseg) * G + j) * Ckpt<G>::W;
-  double *btb = bt + b * N, *bab = ba + b * N, *byb = by + b * N;
-  double *bUb = bU + b * N * J + jj, *bVb = bV + b * N * J + jj;
-  const double cj = act ? c[b * c_bs + j] : 0.0;
-  if (flag[b] != 0) return;  // failed factorisation: gradient undefined (uniform inside a group)
+  // per-step vectors of the current segment (own-lane value at [r][lane]; XOR-gathered by the group)
+  __shared__ __attribute__((aligned(16))) double vP[C][kWave], vU[C][kWave], vW[C][kWave], vF[C][kWave];
+  // group-uniform scalars of rows n_lo-1 .. n_lo+C-1 (1/d, z) and steps (dt), kept per lane for simplicity
+  __shared__ __attribute__((aligned(16))) double vR[C + 1][kWave], vZ[C + 1][kWave], vT[C][kWave];
+  __shared__ __attribute__((aligned(16))) double xB[kWave];
+  const Geo<G> L(B, J);
+  const int lane = L.lane, j = L.j;
+  const bool act = L.act;
+  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const double *tw = t + L.b0 * t_bs, *aw = a + L.b0 * N, *yw = y + L.b0 * N;
+  const double *Uw = U + L.b0 * N * J, *Vw = V + L.b0 * N * J;
+  const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
+  const double *tb = tw + ot, *ab = aw + on, *yb = yw + on, *Ub = Uw + oj, *Vb = Vw + oj;
+  const double *ck = ckpt + ((L.b * nseg) * G + j) * Ckpt<G>::W;
+  double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
+  double *bUb = bU + L.b0 * N * J + oj, *bVb = bV + L.b0 * N * J + oj;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  if (flag[L.b] != 0) return;  // failed factorisation: gradient undefined (uniform inside a group)
 
-  double M[G];
+  double MX[G];  // column j of M = bS + bS^T, XOR order
 #pragma unroll
-  for (int i = 0; i < G; ++i) M[i] = 0.0;
+  for (int k = 0; k < G; ++k) MX[k] = 0.0;
   double bF = 0.0, carry = 0.0, bcj = 0.0;
   double bVn = 0.0, ban = 0.0, bzn = 0.0;
 
-  // "current segment" inputs / checkpoint (loaded one segment ahead)
+  // inputs + checkpoint of the segment about to be recomputed (loaded one half-segment ahead)
   double it[C + 1], ia[C], iy[C], iu[C], iv[C];
   double cS[G], cF, cw, cd, cz;
   auto load_segment = [&](int64_t k) {
     const int64_t n_lo = 1 + k * C;
+    const bool full = n_lo + C <= N;
     it[0] = tb[n_lo - 1];
 #pragma unroll
     for (int r = 0; r < C; ++r) {
-      const int64_t n = (n_lo + r < N) ? n_lo + r : N - 1;
+      const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
       it[r + 1] = tb[n]; ia[r] = ab[n]; iy[r] = yb[n];
       iu[r] = act ? Ub[n * J] : 0.0; iv[r] = act ? Vb[n * J] : 0.0;
     }
     const double *q = ck + k * (G * Ckpt<G>::W);
+    if constexpr (Ckpt<G>::W % 2 == 0) {
+      const double2 *q2 = reinterpret_cast<const double2 *>(q);
 #pragma unroll
-    for (int i = 0; i < G; ++i) cS[i] = q[i];
-    cF = q[G]; cw = q[G + 1]; cd = q[G + 2]; cz = q[G + 3];
+      for (int i = 0; i < G / 2; ++i) { const double2 v2 = q2[i]; cS[2 * i] = v2.x; cS[2 * i + 1] = v2.y; }
+      const double2 f2 = q2[G / 2], d2 = q2[G / 2 + 1];
+      cF = f2.x; cw = f2.y; cd = d2.x; cz = d2.y;
+    } else {
+#pragma unroll
+      for (int i = 0; i < G; ++i) cS[i] = q[i];
+      cF = q[G]; cw = q[G + 1]; cd = q[G + 2]; cz = q[G + 3];
+    }
   };
 
   if (nseg > 0) load_segment(nseg - 1);
-  else {  // N == 1: no steps, only the seeds of row 0
-    cd = ab[0]; cz = yb[0];
-  }
+  else { cd = ab[0]; cz = yb[0]; }  // N == 1: no steps, only the seeds of row 0
 
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
 
-    // ---- recompute the forward steps of this segment ------------------------------------------------
-    double S[G];
+    // ---- phase A: all decay factors of the segment at once (independent exps), p and U to LDS ----------
 #pragma unroll
-    for (int i = 0; i < G; ++i) S[i] = cS[i];
+    for (int r = 0; r < C; ++r) {
+      const double dt = it[r] - it[r + 1];
+      vP[r][lane] = exp_decay(cj * dt);
+      vU[r][lane] = iu[r];
+      vT[r][lane] = dt;
+    }
+    // ---- phase B: recompute the forward chain, keep S_n columns in registers ---------------------------
+    double SX[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) SX[i] = cS[i];
     double F = cF, w = cw, d = cd, z = cz, rd = rcp_nr(cd);
-    double Sf[C][G], Fp[C], pv[C], dtv[C], rdv[C + 1], zv[C + 1];
-    rdv[0] = rd; zv[0] = z;
+    double Sf[C][G];
+    vR[0][lane] = rd; vZ[0][lane] = z;
+    lds_order();
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       if (r < cnt) {
-        const double dt = it[r] - it[r + 1];
-        const double p = fwd_step<G>(cj, dt, ia[r], iy[r], iu[r], iv[r], S, F, w, d, z, rd, vP[r], vU[r], vW[r],
-                                     lane, gbase);
+        double pX[G], uX[G];
+        xgather_lds<G>(vP[r], lane, pX);
+        xgather_lds<G>(vU[r], lane, uX);
+        vW[r][lane] = w;  // W row n-1 (own lane)
+        fwd_chain<G>(pX[0], uX[0], iv[r], ia[r], iy[r], pX, uX, SX, F, w, d, z, rd, xB, lane);
 #pragma unroll
-        for (int i = 0; i < G; ++i) Sf[r][i] = S[i];
-        Fp[r] = F; pv[r] = p; dtv[r] = dt; rdv[r + 1] = rd; zv[r + 1] = z;
+        for (int i = 0; i < G; ++i) Sf[r][i] = SX[i];
+        vF[r][lane] = F; vR[r + 1][lane] = rd; vZ[r + 1][lane] = z;
       }
     }
     if (k == nseg - 1) {  // cotangents of the last row: pure seeds
-      const double rdl = rdv[cnt], zl = zv[cnt];
-      ban = 0.5 * rdl * (zl * zl * rdl - 1.0);
-      bzn = -zl * rdl;
+      ban = 0.5 * rd * (z * z * rd - 1.0);
+      bzn = -z * rd;
       bVn = 0.0;
       if (st0) byb[N - 1] = bzn;
     }
-    // ---- prefetch the next (earlier) segment while the reverse steps run --------------------------------
-    if (k > 0) load_segment(k - 1);
+    lds_order();
 
-    // ---- fused reverse steps ----------------------------------------------------------------------------
+    // ---- phase C: fused reverse steps; the next (earlier) segment is fetched half way through ---------
 #pragma unroll
     for (int r = C - 1; r >= 0; --r) {
+      if (r == C / 2 - 1 || (C == 1)) {
+        if (k > 0) load_segment(k - 1);
+      }
       if (r < cnt) {
         const int64_t n = n_lo + r;
-        const double p = pv[r], dt = dtv[r], Fpn = Fp[r];
-        const double rdm = rdv[r], zm = zv[r];
-        const double u = vU[r][lane], wm = vW[r][lane];
+        const double p = vP[r][lane], u = vU[r][lane], wm = vW[r][lane], Fpn = vF[r][lane];
+        const double rdm = vR[r][lane], zm = vZ[r][lane], dt = vT[r][lane];
+        double uX[G], pX[G], wX[G], bVX[G];
+        xgather_lds<G>(vU[r], lane, uX);
+        xgather_lds<G>(vP[r], lane, pX);
+        xgather_lds<G>(vW[r], lane, wX);
         if (st0) bab[n] = ban;
         if (st) bVb[n * J] = bVn;
-        xB[lane] = bVn;
-        lds_order();
-        double bVi[G], ui[G], pi[G], wi[G];
-        lds_get<G>(xB, gbase, bVi);
-        lds_get<G>(vU[r], gbase, ui);
-        lds_get<G>(vP[r], gbase, pi);
-        lds_get<G>(vW[r], gbase, wi);
-        // solve_lower_rev part
+        xgather_dpp<G>(bVn, xB, lane, bVX);
+        // solve_lower_rev part (internal.hpp:232-245)
         const double bU1 = -bzn * Fpn;
         bF = fma(-u, bzn, bF);
         const double bp_s = Fpn * bF;
         bF *= p;
-        // factor_rev part
+        // factor_rev part (reverse.hpp:65-80)
         const double yv = fma(ban, u, bVn);
-        double xs = 0.0, bpf = 0.0;
+        double xs0 = 0.0, xs1 = 0.0, bp0 = 0.0, bp1 = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-          const double yi = fma(ban, ui[i], bVi[i]);
-          const double xi = fma(ban, ui[i], yi);
-          xs = fma(xi, Sf[r][i], xs);
-          M[i] -= fma(ui[i], yv, yi * u);
-          bpf = fma(Sf[r][i], M[i], bpf);
+          const double yi = fma(ban, uX[i], bVX[i]);
+          const double xi = fma(ban, uX[i], yi);
+          MX[i] -= fma(uX[i], yv, yi * u);
+          if (i & 1) { xs1 = fma(xi, Sf[r][i], xs1); bp1 = fma(Sf[r][i], MX[i], bp1); }
+          else { xs0 = fma(xi, Sf[r][i], xs0); bp0 = fma(Sf[r][i], MX[i], bp0); }
         }
-        if (st) bUb[n * J] = bU1 - xs;
-        const double bp = bp_s + bpf;
+        if (st) bUb[n * J] = bU1 - (xs0 + xs1);
+        const double bp = bp_s + (bp0 + bp1);
         bcj = fma(dt, bp, bcj);
         const double f = gsum<G>(cj * bp);
         if (st0) btb[n] = carry - f;
         carry = f;
-        double q = 0.0;
+        double q0 = 0.0, q1 = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-          M[i] *= pi[i] * p;
-          q = fma(wi[i], M[i], q);
+          MX[i] *= pX[i] * p;
+          if (i & 1) q1 = fma(wX[i], MX[i], q1);
+          else q0 = fma(wX[i], MX[i], q0);
         }
+        const double q = q0 + q1;
         const double Gs = gsum<G>(wm * bF);
         const double Q = gsum<G>(q * wm);
         const double zr = zm * rdm;
@@ -358,6 +490,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, i
         ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
       }
     }
+    lds_order();
   }
   if (nseg == 0) {  // N == 1
     const double rd0 = 1.0 / cd;
@@ -367,12 +500,16 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, i
   }
   // row 0 (reverse.hpp:83-84)
   if (st0) { bab[0] = ban; btb[0] = carry; }
-  if (st) { bVb[0] = bVn; bUb[0] = 0.0; bc[b * J + j] = bcj; }
+  if (st) { bVb[0] = bVn; bUb[0] = 0.0; bc[L.b * J + j] = bcj; }
 }
 
 }  // namespace c2
 
 using namespace c2;
+
+#ifndef C2_FWD_R
+#define C2_FWD_R 8
+#endif
 
 namespace {
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP; }
@@ -387,10 +524,10 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
   hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a, U, \
                      V, y, ll, flag, ckpt, nseg)
   switch (G_) {
-    case 1: C2_FWD(1, 16, 8); break;
-    case 2: C2_FWD(2, 16, 8); break;
-    case 4: C2_FWD(4, 16, 8); break;
-    case 8: C2_FWD(8, 16, 8); break;
+    case 1: C2_FWD(1, C2_FWD_R, 8); break;
+    case 2: C2_FWD(2, C2_FWD_R, 8); break;
+    case 4: C2_FWD(4, C2_FWD_R, 8); break;
+    case 8: C2_FWD(8, C2_FWD_R, 8); break;
     case 16: C2_FWD(16, 8, 4); break;
     default: C2_FWD(32, 4, 2); break;
   }

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcelerite2_amd.so")
+LIB_PATH = os.environ.get("C2_LIB_PATH", os.path.join(_HERE, "libcelerite2_amd.so"))  # override: A/B builds
 
 C2_OK, C2_ERR_INVALID, C2_ERR_UNSUPPORTED, C2_ERR_HIP = 0, -1, -2, -3
 C2_MAX_WIDTH = 32

@@ -51,21 +51,27 @@ __device__ __forceinline__ double rcp_nr(double d) {
 // k = rint(x log2 e), r = x - k ln2 (two-term Cody-Waite), degree-11 near-minimax polynomial on
 // |r| <= ln2/2 (Chebyshev fit, exact-arithmetic error 4e-18, 1 ulp in double Horner), result scaled by
 // v_ldexp_f64 (which also flushes the underflow range to 0).  16 VALU instructions.
+// q*r + c with the constant forced into an SGPR pair (VOP3 v_fma_f64 takes one scalar operand).  Left to
+// itself hipcc keeps the eleven coefficients in VGPRs and emits v_mov_b64 + v_fmac_f64 per Horner step.
+__device__ __forceinline__ double fma_sconst(double q, double r, double c) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(q), "v"(r), "s"(c));
+  return o;
+}
 __device__ __forceinline__ double exp_decay(double x) {
   x = fmax(x, -1000.0);
   const double k = rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
   r = fma(k, -1.90821492927058770002e-10, r);
-  double q = 2.51100492048186583e-08;
-  q = fma(q, r, 2.76326547225277896e-07);
-  q = fma(q, r, 2.75572408872298695e-06);
-  q = fma(q, r, 2.48014854415613131e-05);
-  q = fma(q, r, 1.98412698900764028e-04);
-  q = fma(q, r, 1.38888889523528631e-03);
-  q = fma(q, r, 8.33333333331958900e-03);
-  q = fma(q, r, 4.16666666664879531e-02);
-  q = fma(q, r, 1.66666666666666796e-01);
-  q = fma(q, r, 5.00000000000001887e-01);
+  double q = fma_sconst(2.51100492048186583e-08, r, 2.76326547225277896e-07);
+  q = fma_sconst(q, r, 2.75572408872298695e-06);
+  q = fma_sconst(q, r, 2.48014854415613131e-05);
+  q = fma_sconst(q, r, 1.98412698900764028e-04);
+  q = fma_sconst(q, r, 1.38888889523528631e-03);
+  q = fma_sconst(q, r, 8.33333333331958900e-03);
+  q = fma_sconst(q, r, 4.16666666664879531e-02);
+  q = fma_sconst(q, r, 1.66666666666666796e-01);
+  q = fma_sconst(q, r, 5.00000000000001887e-01);
   q = fma(q, r, 1.0);
   q = fma(q, r, 1.0);
   return ldexp(q, (int)k);
@@ -137,7 +143,7 @@ struct Ckpt {
 template <int G>
 __device__ __forceinline__ void fwd_chain(double p, double u, double v, double an, double yn, const double (&pX)[G],
                                           const double (&uX)[G], double (&SX)[G], double &F, double &w, double &d,
-                                          double &z, double &rd, double *xslot, int lane) {
+                                          double &z, double &rd, double *xslot, int lane, double *tau_out = nullptr) {
   double wX[G];
   xgather_dpp<G>(w, xslot, lane, wX);
   const double dw = d * w;
@@ -150,6 +156,7 @@ __device__ __forceinline__ void fwd_chain(double p, double u, double v, double a
     else tau0 = fma(uX[k], s, tau0);
   }
   const double tau = tau0 + tau1;
+  if (tau_out) *tau_out = tau;
   F = p * fma(w, z, F);                                    // F = P (F + W_{n-1}^T z_{n-1})  (internal.hpp:140-143)
   const double dn = an - gsum<G>(tau * u);                 // forward.hpp:127
   const double zn = yn - gsum<G>(u * F);                   // internal.hpp:144
@@ -189,8 +196,14 @@ struct Geo {
 // gathered back in XOR order for the NEXT step;  (b) the chain of step n runs on the vectors gathered
 // during step n-1;  (c) ring slot r is refilled with row n+R.
 // =============================================================================
-template <int G, int R, int C, bool CKPT>
-__global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, int J, const double *__restrict__ t,
+#ifndef C2_FWD_OCC
+#define C2_FWD_OCC 1
+#endif
+#ifndef C2_REV_OCC
+#define C2_REV_OCC 1
+#endif
+template <int G, int R, int C, bool CKPT, bool PAD>
+__global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
                                                          const double *__restrict__ U,
@@ -198,11 +211,12 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, i
                                                          const double *__restrict__ y, double *__restrict__ ll,
                                                          int32_t *__restrict__ flag, double *__restrict__ ckpt,
                                                          int64_t nseg) {
-  static_assert(R % C == 0, "ring length must be a multiple of the checkpoint interval");
+  static_assert(!CKPT || R % C == 0, "ring length must be a multiple of the checkpoint interval");
   __shared__ __attribute__((aligned(16))) double xs[3][kWave];
+  const int J = PAD ? Jrt : G;  // PAD == false: J == G is a compile-time constant (immediate row strides)
   const Geo<G> L(B, J);
   const int lane = L.lane, j = L.j;
-  const bool act = L.act;
+  const bool act = PAD ? L.act : true;
   // wave-uniform bases, per-lane element offsets
   const double *tw = t + L.b0 * t_bs, *aw = a + L.b0 * N, *yw = y + L.b0 * N;
   const double *Uw = U + L.b0 * N * J, *Vw = V + L.b0 * N * J;
@@ -224,14 +238,18 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, i
   double quad = z * z * rd;
   int32_t fl = 0;
 
+  // Ring of R prefetched rows.  tp/ap/... point at row n0 of the current block, so every load of the
+  // unrolled block is (pointer) + (compile-time immediate).
   double rt[R], ra[R], ry[R], ru[R], rv[R];
-  auto load_row = [&](int r, int64_t n, bool clamp) {
-    const int64_t nn = (!clamp || n < N) ? n : N - 1;
-    rt[r] = tb[nn]; ra[r] = ab[nn]; ry[r] = yb[nn];
-    ru[r] = act ? Ub[nn * J] : 0.0; rv[r] = act ? Vb[nn * J] : 0.0;
+  const double *tp = tb + 1, *ap = ab + 1, *yp = yb + 1, *up = Ub + J, *vp = Vb + J;
+  auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {  // row n = n0 + ahead
+    int64_t o = ahead;
+    if (clamp && n >= N) o -= n - (N - 1);
+    rt[r] = tp[o]; ra[r] = ap[o]; ry[r] = yp[o];
+    ru[r] = act ? up[o * J] : 0.0; rv[r] = act ? vp[o * J] : 0.0;
   };
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, 1 + r, true);
+  for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
 
   // prepare step 1
   double tcur = tb[0];
@@ -276,10 +294,10 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, i
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         // (c) refill ring slot r with row n + R
-        load_row(r, n + R, CHECKED);
+        load_row(r, r + R, n + R, CHECKED);
         // forward.hpp:128: first non-positive pivot (NaN passes, as in the reference); no early exit --
         // a failed series simply runs to the end on garbage, its outputs are flagged.
-        fl = (fl == 0 && d <= 0.0) ? (int32_t)n : fl;
+        fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
         prod *= d;
         quad = fma(z * z, rd, quad);
         if (r % 8 == 7) {
@@ -294,8 +312,9 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, i
     }
   };
   int64_t n0 = 1;
-  for (; n0 + 2 * R <= N; n0 += R) block(n0, std::false_type{});  // every load in range: no clamps
-  for (; n0 < N; n0 += R) block(n0, std::true_type{});
+  auto advance = [&]() { tp += R; ap += R; yp += R; up += R * J; vp += R * J; };
+  for (; n0 + 2 * R <= N; n0 += R) { block(n0, std::false_type{}); advance(); }  // every load in range
+  for (; n0 < N; n0 += R) { block(n0, std::true_type{}); advance(); }
 
   if (L.valid && j == 0) {
     flag[L.b] = fl;
@@ -326,8 +345,8 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_fwd(int64_t B, int64_t N, i
 //   ba_{n-1} = bd_{n-1} - Q/2 - z_{n-1} G / d_{n-1}                 (bd + w bS w^T - W_{n-1}.bV_{n-1})
 // with the seeds bd = (z^2/d - 1)/(2d), the derivative of the log-likelihood w.r.t. d (and -z/d w.r.t. z).
 // =============================================================================
-template <int G, int C>
-__global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, int J, const double *__restrict__ t,
+template <int G, int C, bool PAD>
+__global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
                                                          const double *__restrict__ U,
@@ -339,14 +358,18 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, i
                                                          double *__restrict__ bU, double *__restrict__ bV,
                                                          double *__restrict__ by) {
   // per-step vectors of the current segment (own-lane value at [r][lane]; XOR-gathered by the group)
-  __shared__ __attribute__((aligned(16))) double vP[C][kWave], vU[C][kWave], vW[C][kWave], vF[C][kWave];
+  __shared__ __attribute__((aligned(16))) double vP[C][kWave], vU[C][kWave], vW[C][kWave], vF[C][kWave], vTau[C][kWave];
   // group-uniform scalars of rows n_lo-1 .. n_lo+C-1 (1/d, z) and steps (dt), kept per lane for simplicity
   __shared__ __attribute__((aligned(16))) double vR[C + 1][kWave], vZ[C + 1][kWave], vT[C][kWave];
   __shared__ __attribute__((aligned(16))) double xB[kWave];
+  const int J = PAD ? Jrt : G;
   const Geo<G> L(B, J);
   const int lane = L.lane, j = L.j;
-  const bool act = L.act;
-  const bool st = L.valid && act, st0 = L.valid && j == 0;
+  const bool act = PAD ? L.act : true;
+  // Store predicates.  Lanes of a padding (clamped) series recompute the LAST valid series bit for bit and
+  // the G lanes of a group hold identical copies of every group scalar, so duplicate stores of identical
+  // values to the same address are harmless: without column padding no store needs an exec mask.
+  const bool st = PAD ? (L.valid && act) : true, st0 = PAD ? (L.valid && j == 0) : true;
   const double *tw = t + L.b0 * t_bs, *aw = a + L.b0 * N, *yw = y + L.b0 * N;
   const double *Uw = U + L.b0 * N * J, *Vw = V + L.b0 * N * J;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
@@ -420,7 +443,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, i
         xgather_lds<G>(vP[r], lane, pX);
         xgather_lds<G>(vU[r], lane, uX);
         vW[r][lane] = w;  // W row n-1 (own lane)
-        fwd_chain<G>(pX[0], uX[0], iv[r], ia[r], iy[r], pX, uX, SX, F, w, d, z, rd, xB, lane);
+        fwd_chain<G>(pX[0], uX[0], iv[r], ia[r], iy[r], pX, uX, SX, F, w, d, z, rd, xB, lane, &vTau[r][lane]);
 #pragma unroll
         for (int i = 0; i < G; ++i) Sf[r][i] = SX[i];
         vF[r][lane] = F; vR[r + 1][lane] = rd; vZ[r + 1][lane] = z;
@@ -456,17 +479,20 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_rev(int64_t B, int64_t N, i
         bF = fma(-u, bzn, bF);
         const double bp_s = Fpn * bF;
         bF *= p;
-        // factor_rev part (reverse.hpp:65-80)
-        const double yv = fma(ban, u, bVn);
+        // factor_rev part (reverse.hpp:65-80).  With x = bV + 2 ba U (own lane: xv):
+        //   bU2_j = -sum_i x_i S(i,j) = -(sum_i bV_i S(i,j) + 2 ba tau_j),  tau_j = sum_i U_i S(i,j)
+        //   M    -= U^T y + y^T U  =  U^T x + bV^T U                         (y = bV + ba U)
+        const double xv = fma(2.0 * ban, u, bVn);
         double xs0 = 0.0, xs1 = 0.0, bp0 = 0.0, bp1 = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-          const double yi = fma(ban, uX[i], bVX[i]);
-          const double xi = fma(ban, uX[i], yi);
-          MX[i] -= fma(uX[i], yv, yi * u);
-          if (i & 1) { xs1 = fma(xi, Sf[r][i], xs1); bp1 = fma(Sf[r][i], MX[i], bp1); }
-          else { xs0 = fma(xi, Sf[r][i], xs0); bp0 = fma(Sf[r][i], MX[i], bp0); }
+          double m = fma(-uX[i], xv, MX[i]);
+          m = fma(-bVX[i], u, m);
+          MX[i] = m;
+          if (i & 1) { xs1 = fma(bVX[i], Sf[r][i], xs1); bp1 = fma(Sf[r][i], m, bp1); }
+          else { xs0 = fma(bVX[i], Sf[r][i], xs0); bp0 = fma(Sf[r][i], m, bp0); }
         }
+        xs0 = fma(2.0 * ban, vTau[r][lane], xs0);
         if (st) bUb[n * J] = bU1 - (xs0 + xs1);
         const double bp = bp_s + (bp0 + bp1);
         bcj = fma(dt, bp, bcj);
@@ -520,9 +546,15 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
                double *ckpt, int64_t nseg, hipStream_t s) {
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
-#define C2_FWD(G, R, C)                                                                                             \
-  hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a, U, \
-                     V, y, ll, flag, ckpt, nseg)
+#define C2_FWD(G, R, C)                                                                                          \
+  do {                                                                                                           \
+    if (J == G)                                                                                                  \
+      hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg);                                            \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,    \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg);                                            \
+  } while (0)
   switch (G_) {
     case 1: C2_FWD(1, C2_FWD_R, 8); break;
     case 2: C2_FWD(2, C2_FWD_R, 8); break;
@@ -574,8 +606,14 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   if (int e = launch_fwd<true>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, s)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_REV(G, C)                                                                                              \
-  hipLaunchKernelGGL((k_loglik_rev<G, C>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a, U, V, y,   \
-                     (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by)
+  do {                                                                                                            \
+    if (J == G)                                                                                                   \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a, \
+                         U, V, y, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);     \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a,  \
+                         U, V, y, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);     \
+  } while (0)
   switch (G_) {
     case 1: C2_REV(1, 8); break;
     case 2: C2_REV(2, 8); break;

@@ -49,3 +49,35 @@ def device_batch(first, count, N, J, device, seed0=721):
     c = np.repeat(cc, 2, axis=1)  # c = [cc0, cc0, cc1, cc1, ...] (terms.py:171-173)
     a, U, V = ops.get_celerite_matrices(ar, acd, bcd, dcd, td, diagd)
     return td, to(c), a, U, V, yd
+
+
+def device_batch_fast(first, count, N, J, device, seed0=721):
+    """Same synthetic distribution as device_batch, but drawn with torch's device generator (seeded with
+    seed0 + first) so that very large shards (65536 x 4096) are ready in a fraction of a second.  Used by
+    bench.py; parity tests use the numpy recipe (host_inputs) so that the CPU oracle sees identical numbers."""
+    import torch
+
+    from . import ops
+
+    assert J % 2 == 0
+    Jc = J // 2
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed0 + int(first))
+    f64 = dict(dtype=torch.float64, device=device)
+    t = torch.sort(torch.rand((count, N), generator=gen, **f64) * (N / 10.0), dim=1).values.contiguous()
+    diag = 0.1 + 0.2 * torch.rand((count, N), generator=gen, **f64)
+    xi = 2.0 * torch.rand((count, 1), generator=gen, **f64) - 1.0
+    y = torch.sin(t) + 0.1 * torch.randn((count, N), generator=gen, **f64)
+    k = torch.arange(Jc, **f64)[None, :]
+    S0 = 5.0 * 0.7**k
+    w0 = 0.1 * 3.0**k * (1.0 + 0.05 * xi)
+    Q = 3.45 + k
+    f = torch.sqrt(torch.clamp(4.0 * Q**2 - 1.0, min=1e-5))
+    ac = (S0 * w0 * Q).contiguous()
+    bc = (ac / f).contiguous()
+    cc = (0.5 * w0 / Q).contiguous()
+    dc = (cc * f).contiguous()
+    ar = torch.zeros((count, 0), **f64)
+    c = torch.repeat_interleave(cc, 2, dim=1).contiguous()
+    a, U, V = ops.get_celerite_matrices(ar, ac, bc, dc, t, diag)
+    return t, c, a, U, V, y

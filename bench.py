@@ -1,7 +1,9 @@
 # -*- coding: utf-8 -*-
 """bench.py -- headline benchmark: batched float64 GP log-likelihood + gradient per second at
-N=4096, J=8 (BASELINE.json metric; configs[2] sharded: 8192 series per GPU, weak scaling -- at 8 GPUs
-this is exactly "batch 65536 sharded across 8 x MI355X").
+N=4096, J=8 (BASELINE.json metric).  Workload = BASELINE.json configs[2]: a batch of 65536 independent GPs,
+forward + reverse-mode gradient.  It fits one MI355X (41 GB inputs + 41 GB gradients + 26 GB checkpoints), so
+N=1 runs all 65536 series on one GPU and N GPUs shard the SAME batch (strong scaling; at N=8 each GPU owns
+8192 series -- "batch 65536 sharded across 8 x MI355X").  --batch-per-gpu B switches to weak scaling.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -81,7 +83,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from celerite2_amd import _lib, ops, synth
+    from celerite2_amd import _lib, ops, parallel, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,17 +100,17 @@ def main():
     _lib.load()
 
     weak = args.batch_per_gpu > 0
-    Bp = args.batch_per_gpu if weak else args.global_batch // world
+    Btot = args.batch_per_gpu * world if weak else args.global_batch
+    first, Bp = parallel.shard_range(Btot, rank, world)   # contiguous shard of this rank
     N, J = args.N, args.J
     grad = args.mode == "grad"
     # shard: contiguous block of series per rank, generated directly on the owning GPU
-    t, c, a, U, V, y = synth.device_batch_fast(rank * Bp, Bp, N, J, dev)
+    t, c, a, U, V, y = synth.device_batch_fast(first, Bp, N, J, dev)
     if grad:
         work = ops.loglik_grad_workspace(Bp, N, J, dev)
         out = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
                torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
                torch.empty((Bp, N), dtype=torch.float64, device=dev))
-    gathered = torch.empty(world * Bp, dtype=torch.float64, device=dev) if world > 1 else None
 
     def step():
         if grad:
@@ -116,7 +118,7 @@ def main():
         else:
             ll, flag = ops.loglik(t, c, a, U, V, y)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, ll)  # the path's only exchange: B/n_gpu log-liks per rank
+            ll = parallel.gather_loglik(ll, Btot, world)  # the path's only exchange: B/n_gpu log-liks per rank
         return ll, flag
 
     for _ in range(args.warmup):
@@ -145,7 +147,7 @@ def main():
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
 
     if rank == 0:
-        total_gps = world * Bp * args.steps
+        total_gps = Btot * args.steps
         value = total_gps / elapsed
         bytes_per_gp = algorithmic_bytes_per_gp(N, J, grad)
         achieved = Bp * bytes_per_gp / (kernel_ms_avg * 1e-3) / 1e9  # per GPU, HIP-event time of the hot path
@@ -156,8 +158,8 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: batch of %d independent GPs (%d per GPU), N=%d, J=%d (sum of %d SHO terms), %s, "
-                                   "inputs resident in HBM" % (world * Bp, Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
-                       "global_batch": world * Bp, "batch_per_gpu": Bp, "N": N, "J": J,
+                                   "inputs resident in HBM" % (Btot, Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
+                       "global_batch": Btot, "batch_per_gpu": Bp, "N": N, "J": J,
                        "parallelism": "batch-sharded x%d, all-gather of log-liks" % world,
                        "failed_factorizations": nfail},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

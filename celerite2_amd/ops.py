@@ -224,3 +224,25 @@ def dot_tril(t, c, U, W, d, Y, Z=None):
                                  _i64(_bs(c, J)), _p(U), _p(W), _p(d), _p(Y), _p(Z), _stream())
     _lib.check(rc, "dot_tril")
     return Z
+
+
+def _loglik_grad_composite(t, c, a, U, V, y):
+    """Internal cross-check: the literal op chain (factor_fwd -> solve_lower_fwd -> seeds -> solve_lower_rev ->
+    factor_rev) with S/F workspaces materialised in HBM, as the reference's autodiff frontends run it."""
+    B, N, J = _dims(U)
+    dev = U.device
+    lib = _lib.load()
+    lib.c2_loglik_grad_composite_workspace_bytes.restype = ctypes.c_size_t
+    lib.c2_loglik_grad_composite_workspace_bytes.argtypes = [ctypes.c_int64] * 3
+    work = torch.empty(lib.c2_loglik_grad_composite_workspace_bytes(B, N, J) // 8, dtype=torch.float64, device=dev)
+    out = (torch.empty((B, N), dtype=torch.float64, device=dev), torch.empty((B, J), dtype=torch.float64, device=dev),
+           torch.empty((B, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
+           torch.empty((B, N), dtype=torch.float64, device=dev))
+    bt, bc, ba, bU, bV, by = out
+    ll = torch.empty(B, dtype=torch.float64, device=dev)
+    flag = torch.empty(B, dtype=torch.int32, device=dev)
+    rc = lib.c2_loglik_grad_composite(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                                      _p(U), _p(V), _p(y), _p(ll), _p(bt), _p(bc), _p(ba), _p(bU), _p(bV), _p(by),
+                                      _p(flag), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
+    _lib.check(rc, "loglik_grad_composite")
+    return ll, out, flag

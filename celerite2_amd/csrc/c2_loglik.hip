@@ -533,8 +533,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
 
 using namespace c2;
 
+#ifndef C2_CKPT_C
+#define C2_CKPT_C 8   // checkpoint interval for G <= 8
+#endif
 #ifndef C2_FWD_R
-#define C2_FWD_R 8
+#define C2_FWD_R C2_CKPT_C   // prefetch ring length (rows); multiple of the checkpoint interval
 #endif
 
 namespace {
@@ -556,10 +559,10 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
                          c, c_bs, a, U, V, y, ll, flag, ckpt, nseg);                                            \
   } while (0)
   switch (G_) {
-    case 1: C2_FWD(1, C2_FWD_R, 8); break;
-    case 2: C2_FWD(2, C2_FWD_R, 8); break;
-    case 4: C2_FWD(4, C2_FWD_R, 8); break;
-    case 8: C2_FWD(8, C2_FWD_R, 8); break;
+    case 1: C2_FWD(1, C2_FWD_R, C2_CKPT_C); break;
+    case 2: C2_FWD(2, C2_FWD_R, C2_CKPT_C); break;
+    case 4: C2_FWD(4, C2_FWD_R, C2_CKPT_C); break;
+    case 8: C2_FWD(8, C2_FWD_R, C2_CKPT_C); break;
     case 16: C2_FWD(16, 8, 4); break;
     default: C2_FWD(32, 4, 2); break;
   }
@@ -580,7 +583,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
 }
 
 // Checkpoint interval per group size (must match launch_fwd / launch_rev below).
-static inline int ckpt_interval(int G_) { return G_ <= 8 ? 8 : (G_ == 16 ? 4 : 2); }
+static inline int ckpt_interval(int G_) { return G_ <= 8 ? C2_CKPT_C : (G_ == 16 ? 4 : 2); }
 
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
@@ -615,10 +618,10 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
                          U, V, y, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);     \
   } while (0)
   switch (G_) {
-    case 1: C2_REV(1, 8); break;
-    case 2: C2_REV(2, 8); break;
-    case 4: C2_REV(4, 8); break;
-    case 8: C2_REV(8, 8); break;
+    case 1: C2_REV(1, C2_CKPT_C); break;
+    case 2: C2_REV(2, C2_CKPT_C); break;
+    case 4: C2_REV(4, C2_CKPT_C); break;
+    case 8: C2_REV(8, C2_CKPT_C); break;
     case 16: C2_REV(16, 4); break;
     default: C2_REV(32, 2); break;
   }

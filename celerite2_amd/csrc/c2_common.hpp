@@ -45,6 +45,25 @@ __device__ __forceinline__ double gsum(double x) {
   return x;
 }
 
+// Two / three independent all-reduces with their butterfly levels interleaved, so that the DPP moves of one
+// value fill the wait states (VALU write -> DPP read) and the add latency of the others.
+template <int G>
+__device__ __forceinline__ void gsum2(double &a, double &b) {
+  if constexpr (G >= 2) { const double ta = dpp_mov<kDppXor1>(a), tb = dpp_mov<kDppXor1>(b); a += ta; b += tb; }
+  if constexpr (G >= 4) { const double ta = dpp_mov<kDppXor2>(a), tb = dpp_mov<kDppXor2>(b); a += ta; b += tb; }
+  if constexpr (G >= 8) { const double ta = dpp_mov<kDppHalfMirror>(a), tb = dpp_mov<kDppHalfMirror>(b); a += ta; b += tb; }
+  if constexpr (G >= 16) { const double ta = dpp_mov<kDppMirror>(a), tb = dpp_mov<kDppMirror>(b); a += ta; b += tb; }
+  if constexpr (G >= 32) { a += __shfl_xor(a, 16, kWave); b += __shfl_xor(b, 16, kWave); }
+}
+template <int G>
+__device__ __forceinline__ void gsum3(double &a, double &b, double &c) {
+  if constexpr (G >= 2) { const double ta = dpp_mov<kDppXor1>(a), tb = dpp_mov<kDppXor1>(b), tc = dpp_mov<kDppXor1>(c); a += ta; b += tb; c += tc; }
+  if constexpr (G >= 4) { const double ta = dpp_mov<kDppXor2>(a), tb = dpp_mov<kDppXor2>(b), tc = dpp_mov<kDppXor2>(c); a += ta; b += tb; c += tc; }
+  if constexpr (G >= 8) { const double ta = dpp_mov<kDppHalfMirror>(a), tb = dpp_mov<kDppHalfMirror>(b), tc = dpp_mov<kDppHalfMirror>(c); a += ta; b += tb; c += tc; }
+  if constexpr (G >= 16) { const double ta = dpp_mov<kDppMirror>(a), tb = dpp_mov<kDppMirror>(b), tc = dpp_mov<kDppMirror>(c); a += ta; b += tb; c += tc; }
+  if constexpr (G >= 32) { a += __shfl_xor(a, 16, kWave); b += __shfl_xor(b, 16, kWave); c += __shfl_xor(c, 16, kWave); }
+}
+
 // Value of x held by lane i of the caller's group.
 template <int G>
 __device__ __forceinline__ double gget(double x, int i) {

@@ -158,8 +158,10 @@ __device__ __forceinline__ void fwd_chain(double p, double u, double v, double a
   const double tau = tau0 + tau1;
   if (tau_out) *tau_out = tau;
   F = p * fma(w, z, F);                                    // F = P (F + W_{n-1}^T z_{n-1})  (internal.hpp:140-143)
-  const double dn = an - gsum<G>(tau * u);                 // forward.hpp:127
-  const double zn = yn - gsum<G>(u * F);                   // internal.hpp:144
+  double rd_ = tau * u, rz_ = u * F;
+  gsum2<G>(rd_, rz_);
+  const double dn = an - rd_;                              // forward.hpp:127
+  const double zn = yn - rz_;                              // internal.hpp:144
   rd = rcp_nr(dn);
   w = (v - tau) * rd;                                      // forward.hpp:131
   d = dn;
@@ -210,7 +212,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          const double *__restrict__ V,
                                                          const double *__restrict__ y, double *__restrict__ ll,
                                                          int32_t *__restrict__ flag, double *__restrict__ ckpt,
-                                                         int64_t nseg) {
+                                                         int64_t nseg, double *__restrict__ Wst,
+                                                         double2 *__restrict__ DZst) {
   static_assert(!CKPT || R % C == 0, "ring length must be a multiple of the checkpoint interval");
   __shared__ __attribute__((aligned(16))) double xs[3][kWave];
   const int J = PAD ? Jrt : G;  // PAD == false: J == G is a compile-time constant (immediate row strides)
@@ -224,6 +227,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   const double *tb = tw + ot, *ab = aw + on, *yb = yw + on, *Ub = Uw + oj, *Vb = Vw + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
   double *ck = CKPT ? ckpt + ((L.b * nseg) * G + j) * Ckpt<G>::W : nullptr;
+  // per-step records for the reverse sweep (CKPT only): W_n (like the reference's factor output) and (d_n, z_n)
+  double *wst = CKPT ? Wst + L.b0 * N * J + oj : nullptr;
+  double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
+  const bool stw = PAD ? (L.valid && act) : true;  // duplicate stores of identical values are harmless
 
   double SX[G];
 #pragma unroll
@@ -237,6 +244,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   int eacc = 0;
   double quad = z * z * rd;
   int32_t fl = 0;
+  if (CKPT) {
+    if (stw) wst[0] = w;
+    dzst[0] = make_double2(d, z);
+  }
 
   // Ring of R prefetched rows.  tp/ap/... point at row n0 of the current block, so every load of the
   // unrolled block is (pointer) + (compile-time immediate).
@@ -293,6 +304,14 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         lds_order();
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
+        if (CKPT) {
+#ifndef C2_AB_NO_WST
+          if (stw) wst[n * J] = w;
+#endif
+#ifndef C2_AB_NO_DZ
+          dzst[n] = make_double2(d, z);
+#endif
+        }
         // (c) refill ring slot r with row n + R
         load_row(r, r + R, n + R, CHECKED);
         // forward.hpp:128: first non-positive pivot (NaN passes, as in the reference); no early exit --
@@ -345,40 +364,61 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 //   ba_{n-1} = bd_{n-1} - Q/2 - z_{n-1} G / d_{n-1}                 (bd + w bS w^T - W_{n-1}.bV_{n-1})
 // with the seeds bd = (z^2/d - 1)/(2d), the derivative of the log-likelihood w.r.t. d (and -z/d w.r.t. z).
 // =============================================================================
+// Packed symmetric storage of the C saved S_n columns in LDS.  In XOR order slot k of lane j is S(j^k, j) and
+// slot k of lane j^k is its transpose twin S(j, j^k) -- the same number up to rounding -- so for k >= 1 only
+// the lane whose bit hb(k) (highest set bit of k) is clear stores it and both lanes read that copy:
+// G + (G-1) G/2 doubles per series and step instead of G^2 (36 instead of 64 at G = 8).
+template <int G>
+struct SymPack {
+  static constexpr int PER_STEP = kWave + (G - 1) * (kWave / 2);  // doubles per wavefront per step
+  // offset (in doubles) of slot k >= 1 for wave-local lane l
+  static __device__ __forceinline__ int off(int l, int k) {
+    const int b = 31 - __builtin_clz(k), hb = 1 << b;
+    const int o = (l & hb) ? (l ^ k) : l;  // owner lane (bit b clear)
+    const int idx = ((o >> (b + 1)) << b) | (o & (hb - 1));
+    return kWave + (k - 1) * (kWave / 2) + idx;
+  }
+};
+
 template <int G, int C, bool PAD>
 __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
-                                                         const double *__restrict__ a,
                                                          const double *__restrict__ U,
-                                                         const double *__restrict__ V,
-                                                         const double *__restrict__ y,
+                                                         const double *__restrict__ Wst,
+                                                         const double2 *__restrict__ DZst,
                                                          const double *__restrict__ ckpt, int64_t nseg,
                                                          const int32_t *__restrict__ flag, double *__restrict__ bt,
                                                          double *__restrict__ bc, double *__restrict__ ba,
                                                          double *__restrict__ bU, double *__restrict__ bV,
                                                          double *__restrict__ by) {
-  // per-step vectors of the current segment (own-lane value at [r][lane]; XOR-gathered by the group)
-  __shared__ __attribute__((aligned(16))) double vP[C][kWave], vU[C][kWave], vW[C][kWave], vF[C][kWave], vTau[C][kWave];
-  // group-uniform scalars of rows n_lo-1 .. n_lo+C-1 (1/d, z) and steps (dt), kept per lane for simplicity
-  __shared__ __attribute__((aligned(16))) double vR[C + 1][kWave], vZ[C + 1][kWave], vT[C][kWave];
+  constexpr int SPW = kWave / G;  // series per wavefront
+  // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
+  __shared__ __attribute__((aligned(16))) double vv[C][3][kWave];
+  __shared__ __attribute__((aligned(16))) double sfL[C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
+  __shared__ __attribute__((aligned(16))) double scR[C + 1][SPW], scZ[C + 1][SPW], scT[C][SPW];  // 1/d, z, dt per series
   __shared__ __attribute__((aligned(16))) double xB[kWave];
   const int J = PAD ? Jrt : G;
   const Geo<G> L(B, J);
   const int lane = L.lane, j = L.j;
+  const int grp = lane / G;
   const bool act = PAD ? L.act : true;
   // Store predicates.  Lanes of a padding (clamped) series recompute the LAST valid series bit for bit and
   // the G lanes of a group hold identical copies of every group scalar, so duplicate stores of identical
   // values to the same address are harmless: without column padding no store needs an exec mask.
   const bool st = PAD ? (L.valid && act) : true, st0 = PAD ? (L.valid && j == 0) : true;
-  const double *tw = t + L.b0 * t_bs, *aw = a + L.b0 * N, *yw = y + L.b0 * N;
-  const double *Uw = U + L.b0 * N * J, *Vw = V + L.b0 * N * J;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
-  const double *tb = tw + ot, *ab = aw + on, *yb = yw + on, *Ub = Uw + oj, *Vb = Vw + oj;
+  const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Wb = Wst + L.b0 * N * J + oj;
+  const double2 *dzb = DZst + L.b0 * N + on;
   const double *ck = ckpt + ((L.b * nseg) * G + j) * Ckpt<G>::W;
   double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
   double *bUb = bU + L.b0 * N * J + oj, *bVb = bV + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
   if (flag[L.b] != 0) return;  // failed factorisation: gradient undefined (uniform inside a group)
+
+  int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
+  soff[0] = lane;
+#pragma unroll
+  for (int k = 1; k < G; ++k) soff[k] = SymPack<G>::off(lane, k);
 
   double MX[G];  // column j of M = bS + bS^T, XOR order
 #pragma unroll
@@ -386,70 +426,102 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   double bF = 0.0, carry = 0.0, bcj = 0.0;
   double bVn = 0.0, ban = 0.0, bzn = 0.0;
 
-  // inputs + checkpoint of the segment about to be recomputed (loaded one half-segment ahead)
-  double it[C + 1], ia[C], iy[C], iu[C], iv[C];
-  double cS[G], cF, cw, cd, cz;
+  // Records of the segment about to be replayed (loaded one half-segment ahead): t, U_n, W_{n-1}, (d, z) of
+  // rows n_lo-1 .. n_lo+C-1 and the checkpointed S column / F of row n_lo-1.
+  double it[C + 1], iu[C], iw[C];
+  double2 idz[C + 1];
+  double cS[G], cF;
   auto load_segment = [&](int64_t k) {
     const int64_t n_lo = 1 + k * C;
     const bool full = n_lo + C <= N;
     it[0] = tb[n_lo - 1];
+    idz[0] = dzb[n_lo - 1];
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      it[r + 1] = tb[n]; ia[r] = ab[n]; iy[r] = yb[n];
-      iu[r] = act ? Ub[n * J] : 0.0; iv[r] = act ? Vb[n * J] : 0.0;
+      it[r + 1] = tb[n];
+      idz[r + 1] = dzb[n];
+      iu[r] = act ? Ub[n * J] : 0.0;
+      iw[r] = act ? Wb[(n - 1) * J] : 0.0;  // W row n-1
     }
     const double *q = ck + k * (G * Ckpt<G>::W);
     if constexpr (Ckpt<G>::W % 2 == 0) {
       const double2 *q2 = reinterpret_cast<const double2 *>(q);
 #pragma unroll
       for (int i = 0; i < G / 2; ++i) { const double2 v2 = q2[i]; cS[2 * i] = v2.x; cS[2 * i + 1] = v2.y; }
-      const double2 f2 = q2[G / 2], d2 = q2[G / 2 + 1];
-      cF = f2.x; cw = f2.y; cd = d2.x; cz = d2.y;
+      cF = q2[G / 2].x;
     } else {
 #pragma unroll
       for (int i = 0; i < G; ++i) cS[i] = q[i];
-      cF = q[G]; cw = q[G + 1]; cd = q[G + 2]; cz = q[G + 3];
+      cF = q[G];
     }
   };
 
   if (nseg > 0) load_segment(nseg - 1);
-  else { cd = ab[0]; cz = yb[0]; }  // N == 1: no steps, only the seeds of row 0
+  else idz[0] = dzb[0];  // N == 1: no steps, only the seeds of row 0
 
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
 
-    // ---- phase A: all decay factors of the segment at once (independent exps), p and U to LDS ----------
+    // ---- phase A: everything row-indexed goes to LDS: p_n (C independent exps), U_n, W_{n-1}, 1/d, z, dt --
+    double dprev[C];  // d_{n-1} of every step (pivot of the previous row)
+    scR[0][grp] = rcp_nr(idz[0].x); scZ[0][grp] = idz[0].y;
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const double dt = it[r] - it[r + 1];
-      vP[r][lane] = exp_decay(cj * dt);
-      vU[r][lane] = iu[r];
-      vT[r][lane] = dt;
+      vv[r][0][lane] = exp_decay(cj * dt);
+      vv[r][1][lane] = iu[r];
+      vv[r][2][lane] = iw[r];
+      scT[r][grp] = dt;
+      scR[r + 1][grp] = rcp_nr(idz[r + 1].x); scZ[r + 1][grp] = idz[r + 1].y;
+      dprev[r] = idz[r].x;
     }
-    // ---- phase B: recompute the forward chain, keep S_n columns in registers ---------------------------
+    double zprev[C];
+#pragma unroll
+    for (int r = 0; r < C; ++r) zprev[r] = idz[r].y;
+    // ---- phase B: replay S_n = P (S + d w^T w) P and F_n = P (F + w z) -- with W, d, z on record there is no
+    // recursion chain left (no reductions, no division): a pure throughput loop.  S_n columns go to LDS
+    // (packed), F_n and tau_n = U_n S_n stay in registers.
     double SX[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) SX[i] = cS[i];
-    double F = cF, w = cw, d = cd, z = cz, rd = rcp_nr(cd);
-    double Sf[C][G];
-    vR[0][lane] = rd; vZ[0][lane] = z;
+    double F = cF;
+    double Fp[C], tauS[C];
     lds_order();
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       if (r < cnt) {
-        double pX[G], uX[G];
-        xgather_lds<G>(vP[r], lane, pX);
-        xgather_lds<G>(vU[r], lane, uX);
-        vW[r][lane] = w;  // W row n-1 (own lane)
-        fwd_chain<G>(pX[0], uX[0], iv[r], ia[r], iy[r], pX, uX, SX, F, w, d, z, rd, xB, lane, &vTau[r][lane]);
+        double pX[G], uX[G], wX[G];
+        xgather_lds<G>(vv[r][0], lane, pX);
+        xgather_lds<G>(vv[r][1], lane, uX);
+        xgather_lds<G>(vv[r][2], lane, wX);
+        const double p = pX[0], w = wX[0];
+        const double dw = dprev[r] * w;
+        double tau0 = 0.0, tau1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < G; ++i) Sf[r][i] = SX[i];
-        vF[r][lane] = F; vR[r + 1][lane] = rd; vZ[r + 1][lane] = z;
+        for (int i = 0; i < G; ++i) {
+          const double sv = (pX[i] * p) * fma(dw, wX[i], SX[i]);
+          SX[i] = sv;
+          if (i & 1) tau1 = fma(uX[i], sv, tau1);
+          else tau0 = fma(uX[i], sv, tau0);
+        }
+        tauS[r] = tau0 + tau1;
+        F = p * fma(w, zprev[r], F);
+        Fp[r] = F;
+        double *sfr = sfL[r];
+        sfr[lane] = SX[0];
+#pragma unroll
+        for (int b = 0; (1 << b) < G; ++b) {
+          if ((j & (1 << b)) == 0) {  // owner lanes of slots k in [2^b, 2^(b+1))
+#pragma unroll
+            for (int kk = (1 << b); kk < (2 << b); ++kk) sfr[soff[kk]] = SX[kk];
+          }
+        }
       }
     }
-    if (k == nseg - 1) {  // cotangents of the last row: pure seeds
+    if (k == nseg - 1) {  // cotangents of the last row: pure seeds (1/d, z of row N-1 are in LDS by now)
+      const double rd = scR[cnt][grp], z = scZ[cnt][grp];
       ban = 0.5 * rd * (z * z * rd - 1.0);
       bzn = -z * rd;
       bVn = 0.0;
@@ -465,12 +537,15 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
       if (r < cnt) {
         const int64_t n = n_lo + r;
-        const double p = vP[r][lane], u = vU[r][lane], wm = vW[r][lane], Fpn = vF[r][lane];
-        const double rdm = vR[r][lane], zm = vZ[r][lane], dt = vT[r][lane];
-        double uX[G], pX[G], wX[G], bVX[G];
-        xgather_lds<G>(vU[r], lane, uX);
-        xgather_lds<G>(vP[r], lane, pX);
-        xgather_lds<G>(vW[r], lane, wX);
+        const double p = vv[r][0][lane], u = vv[r][1][lane], wm = vv[r][2][lane], Fpn = Fp[r];
+        const double rdm = scR[r][grp], zm = scZ[r][grp], dt = scT[r][grp];
+        double uX[G], pX[G], wX[G], bVX[G], Sf[G];
+        xgather_lds<G>(vv[r][1], lane, uX);
+        xgather_lds<G>(vv[r][0], lane, pX);
+        xgather_lds<G>(vv[r][2], lane, wX);
+        const double *sfr = sfL[r];
+#pragma unroll
+        for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];
         if (st0) bab[n] = ban;
         if (st) bVb[n * J] = bVn;
         xgather_dpp<G>(bVn, xB, lane, bVX);
@@ -489,16 +564,13 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           double m = fma(-uX[i], xv, MX[i]);
           m = fma(-bVX[i], u, m);
           MX[i] = m;
-          if (i & 1) { xs1 = fma(bVX[i], Sf[r][i], xs1); bp1 = fma(Sf[r][i], m, bp1); }
-          else { xs0 = fma(bVX[i], Sf[r][i], xs0); bp0 = fma(Sf[r][i], m, bp0); }
+          if (i & 1) { xs1 = fma(bVX[i], Sf[i], xs1); bp1 = fma(Sf[i], m, bp1); }
+          else { xs0 = fma(bVX[i], Sf[i], xs0); bp0 = fma(Sf[i], m, bp0); }
         }
-        xs0 = fma(2.0 * ban, vTau[r][lane], xs0);
+        xs0 = fma(2.0 * ban, tauS[r], xs0);
         if (st) bUb[n * J] = bU1 - (xs0 + xs1);
         const double bp = bp_s + (bp0 + bp1);
         bcj = fma(dt, bp, bcj);
-        const double f = gsum<G>(cj * bp);
-        if (st0) btb[n] = carry - f;
-        carry = f;
         double q0 = 0.0, q1 = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -507,8 +579,10 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           else q0 = fma(wX[i], MX[i], q0);
         }
         const double q = q0 + q1;
-        const double Gs = gsum<G>(wm * bF);
-        const double Q = gsum<G>(q * wm);
+        double f = cj * bp, Gs = wm * bF, Q = q * wm;
+        gsum3<G>(f, Gs, Q);
+        if (st0) btb[n] = carry - f;
+        carry = f;
         const double zr = zm * rdm;
         bzn = Gs - zr;
         if (st0) byb[n - 1] = bzn;
@@ -519,7 +593,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     lds_order();
   }
   if (nseg == 0) {  // N == 1
-    const double rd0 = 1.0 / cd;
+    const double rd0 = 1.0 / idz[0].x, cz = idz[0].y;
     ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);
     bzn = -cz * rd0;
     if (st0) byb[0] = bzn;
@@ -546,17 +620,17 @@ inline int launch_ok() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR
 template <bool CKPT>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
-               double *ckpt, int64_t nseg, hipStream_t s) {
+               double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s) {
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
     if (J == G)                                                                                                  \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
-                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg);                                            \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst);                                 \
     else                                                                                                         \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,    \
-                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg);                                            \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst);                                 \
   } while (0)
   switch (G_) {
     case 1: C2_FWD(1, C2_FWD_R, C2_CKPT_C); break;
@@ -579,18 +653,33 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
-  return launch_fwd<false>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, (hipStream_t)stream);
+  return launch_fwd<false>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
+                           (hipStream_t)stream);
 }
 
 // Checkpoint interval per group size (must match launch_fwd / launch_rev below).
 static inline int ckpt_interval(int G_) { return G_ <= 8 ? C2_CKPT_C : (G_ == 16 ? 4 : 2); }
 
-size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
-  if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
+// Workspace layout: [checkpoints B*nseg*G*(G+4)] [W rows B*N*J] [(d,z) pairs B*N*2]  (doubles)
+struct GradWs {
+  size_t ck, w, dz, total;
+};
+static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
-  const size_t bytes = (size_t)B * (size_t)nseg * G_ * (G_ + 4) * sizeof(double);
-  return bytes ? bytes : 8;
+  GradWs g;
+  g.ck = (size_t)B * (size_t)nseg * G_ * (G_ + 4);
+  g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
+  g.w = (size_t)B * N * J;
+  g.w = (g.w + 1) & ~(size_t)1;
+  g.dz = (size_t)B * N * 2;
+  g.total = g.ck + g.w + g.dz;
+  return g;
+}
+
+size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
+  if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
+  return grad_ws(B, N, J).total * sizeof(double);
 }
 
 int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
@@ -605,17 +694,22 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
+  const GradWs ws = grad_ws(B, N, J);
   double *ckpt = (double *)work;
-  if (int e = launch_fwd<true>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, s)) return e;
+  double *Wst = ckpt + ws.ck;
+  double2 *DZst = reinterpret_cast<double2 *>(Wst + ws.w);
+  if (int e = launch_fwd<true>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, s)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \
     if (J == G)                                                                                                   \
-      hipLaunchKernelGGL((k_loglik_rev<G, C, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a, \
-                         U, V, y, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);     \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
+                         (const double *)Wst, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by);                                          \
     else                                                                                                          \
-      hipLaunchKernelGGL((k_loglik_rev<G, C, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, a,  \
-                         U, V, y, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);     \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,   \
+                         (const double *)Wst, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by);                                          \
   } while (0)
   switch (G_) {
     case 1: C2_REV(1, C2_CKPT_C); break;

@@ -11,6 +11,47 @@
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
 
+// VMEM instruction cost: PATTERN 0 = 64 lanes x 8 B contiguous (one 512-B run); 1 = eight 64-B runs 256 KB apart
+// (the sub-wave-packed row access); 2 = eight 8-B words, each shared by 8 lanes (a per-series scalar).
+template <int STORE, int PATTERN>
+__global__ __launch_bounds__(64) void kmem(unsigned long long *out, double *buf, int iters) {
+  const int l = threadIdx.x;
+  size_t off;
+  if (PATTERN == 0) off = (size_t)blockIdx.x * 4096 + l;
+  else if (PATTERN == 1) off = ((size_t)blockIdx.x * 8 + (l >> 3)) * 32768 + (l & 7);
+  else off = ((size_t)blockIdx.x * 8 + (l >> 3)) * 32768;
+  double *p = buf + off;
+  double acc = 0.0;
+  unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (STORE) p[(it * 16 + k) * 8 % 2048] = acc + k;
+      else acc += p[(it * 16 + k) * 8 % 2048];
+    }
+  }
+  unsigned long long t1 = __builtin_readcyclecounter();
+  if (l == 0) out[blockIdx.x] = t1 - t0;
+  if (acc == 12345.678) out[0] = 0;
+}
+
+template <int STORE, int PATTERN>
+void runmem(const char *name, int waves_per_simd, unsigned long long *d_out, double *buf) {
+  const int blocks = 1024 * waves_per_simd, iters = 500;
+  hipLaunchKernelGGL((kmem<STORE, PATTERN>), dim3(blocks), dim3(64), 0, 0, d_out, buf, 5);
+  hipDeviceSynchronize();
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0);
+  hipLaunchKernelGGL((kmem<STORE, PATTERN>), dim3(blocks), dim3(64), 0, 0, d_out, buf, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  fprintf(stderr, "%-40s waves/SIMD=%d  wall %.3f ms  wall-ns per VMEM instr per wave %.1f  (per CU: %.1f ns)\n", name,
+          waves_per_simd, ms, ms * 1e6 / (16.0 * iters), ms * 1e6 / (16.0 * iters) / (4 * waves_per_simd));
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k(unsigned long long *out, int iters, double seed) {
   __shared__ double lds[512];
@@ -120,6 +161,14 @@ int main(int argc, char **argv) {
   run<6>("ds_read_b64 x8 + wait", w, d_out);
   run<7>("gsum-like (6 dpp + 2 add)/8", w, d_out);
   run<8>("s_nop 0", w, d_out);
+  double *buf;
+  hipMalloc(&buf, (size_t)4096 * 8 * 32768 * sizeof(double) + (1 << 24));
+  runmem<0, 0>("load dwordx2, 512 B contiguous", w, d_out, buf);
+  runmem<0, 1>("load dwordx2, 8 x 64 B runs", w, d_out, buf);
+  runmem<0, 2>("load dwordx2, 8 x 8 B (8 lanes each)", w, d_out, buf);
+  runmem<1, 0>("store dwordx2, 512 B contiguous", w, d_out, buf);
+  runmem<1, 1>("store dwordx2, 8 x 64 B runs", w, d_out, buf);
+  runmem<1, 2>("store dwordx2, 8 x 8 B (8 lanes each)", w, d_out, buf);
 
   return 0;
 }

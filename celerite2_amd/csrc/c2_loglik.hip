@@ -204,6 +204,41 @@ struct Geo {
 #ifndef C2_REV_OCC
 #define C2_REV_OCC 1
 #endif
+// Checkpoints are private to a wavefront (written by k_loglik_fwd, read back by the same lanes of
+// k_loglik_rev), so they are stored wave-blocked and component-major: record (wave, segment) is W/2 rows of
+// 64 double2 (or W rows of 64 doubles when W is odd) -- every store/load instruction moves one fully
+// contiguous 1 KiB (512 B) run instead of 64 scattered 16-byte pieces.
+template <int G>
+__device__ __forceinline__ void ckpt_store(double *rec, int lane, const double (&SX)[G], double F, double w, double d,
+                                           double z) {
+  if constexpr (Ckpt<G>::W % 2 == 0) {
+    double2 *q = reinterpret_cast<double2 *>(rec) + lane;
+#pragma unroll
+    for (int k = 0; k < G / 2; ++k) q[k * kWave] = make_double2(SX[2 * k], SX[2 * k + 1]);
+    q[(G / 2) * kWave] = make_double2(F, w);
+    q[(G / 2 + 1) * kWave] = make_double2(d, z);
+  } else {
+    double *q = rec + lane;
+#pragma unroll
+    for (int k = 0; k < G; ++k) q[k * kWave] = SX[k];
+    q[G * kWave] = F; q[(G + 1) * kWave] = w; q[(G + 2) * kWave] = d; q[(G + 3) * kWave] = z;
+  }
+}
+template <int G>
+__device__ __forceinline__ void ckpt_load(const double *rec, int lane, double (&SX)[G], double &F) {
+  if constexpr (Ckpt<G>::W % 2 == 0) {
+    const double2 *q = reinterpret_cast<const double2 *>(rec) + lane;
+#pragma unroll
+    for (int k = 0; k < G / 2; ++k) { const double2 v = q[k * kWave]; SX[2 * k] = v.x; SX[2 * k + 1] = v.y; }
+    F = q[(G / 2) * kWave].x;
+  } else {
+    const double *q = rec + lane;
+#pragma unroll
+    for (int k = 0; k < G; ++k) SX[k] = q[k * kWave];
+    F = q[G * kWave];
+  }
+}
+
 template <int G, int R, int C, bool CKPT, bool PAD>
 __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -214,19 +249,25 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          int32_t *__restrict__ flag, double *__restrict__ ckpt,
                                                          int64_t nseg, double *__restrict__ Wst,
                                                          double2 *__restrict__ DZst) {
-  static_assert(!CKPT || R % C == 0, "ring length must be a multiple of the checkpoint interval");
+  static_assert(!CKPT || R % C == 0, "block length must be a multiple of the checkpoint interval");
+  constexpr int SPW = kWave / G;         // series per wavefront
+  constexpr int NV = (R + G - 1) / G;    // vector loads per scalar stream per block of R rows
   __shared__ __attribute__((aligned(16))) double xs[3][kWave];
+  // Per-series scalar streams (t, a, y) are read TRANSPOSED: one instruction fetches R consecutive rows of a
+  // series (lane j <-> row j), two blocks are staged here, and each step broadcasts its row to the group with
+  // one ds_read.  (A per-step load in which 8 lanes fetch the same 8 bytes costs the CU's address unit as
+  // much as a full 512-byte access: profiles/r01_ubench_instruction_costs.md.)
+  __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];
+  __shared__ __attribute__((aligned(16))) double2 sout[SPW][R];  // (d_n, z_n) of the current block
   const int J = PAD ? Jrt : G;  // PAD == false: J == G is a compile-time constant (immediate row strides)
   const Geo<G> L(B, J);
-  const int lane = L.lane, j = L.j;
+  const int lane = L.lane, j = L.j, grp = L.lane / G;
   const bool act = PAD ? L.act : true;
-  // wave-uniform bases, per-lane element offsets
-  const double *tw = t + L.b0 * t_bs, *aw = a + L.b0 * N, *yw = y + L.b0 * N;
-  const double *Uw = U + L.b0 * N * J, *Vw = V + L.b0 * N * J;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
-  const double *tb = tw + ot, *ab = aw + on, *yb = yw + on, *Ub = Uw + oj, *Vb = Vw + oj;
+  const double *tb = t + L.b0 * t_bs + ot, *ab = a + L.b0 * N + on, *yb = y + L.b0 * N + on;
+  const double *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
-  double *ck = CKPT ? ckpt + ((L.b * nseg) * G + j) * Ckpt<G>::W : nullptr;
+  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * nseg * (Ckpt<G>::W * kWave) : nullptr;
   // per-step records for the reverse sweep (CKPT only): W_n (like the reference's factor output) and (d_n, z_n)
   double *wst = CKPT ? Wst + L.b0 * N * J + oj : nullptr;
   double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
@@ -249,22 +290,45 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
     dzst[0] = make_double2(d, z);
   }
 
-  // Ring of R prefetched rows.  tp/ap/... point at row n0 of the current block, so every load of the
-  // unrolled block is (pointer) + (compile-time immediate).
-  double rt[R], ra[R], ry[R], ru[R], rv[R];
-  const double *tp = tb + 1, *ap = ab + 1, *yp = yb + 1, *up = Ub + J, *vp = Vb + J;
+  // ---- transposed scalar streams: registers hold the rows of block b+2, LDS the rows of blocks b, b+1 ----
+  double vt[NV], va[NV], vy[NV];
+  auto vload = [&](int64_t nb) {  // rows nb .. nb+R-1, lane j takes rows nb + m*G + j
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      int64_t row = nb + m * G + j;
+      row = (row < N) ? row : N - 1;
+      vt[m] = tb[row]; va[m] = ab[row]; vy[m] = yb[row];
+    }
+  };
+  auto vstage = [&](int q) {
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * G + j;
+      if (G * NV == R || idx < R) {
+        sin_[q][0][grp][idx] = vt[m]; sin_[q][1][grp][idx] = va[m]; sin_[q][2][grp][idx] = vy[m];
+      }
+    }
+  };
+  vload(1); vstage(0);
+  vload(1 + R); vstage(1);
+  vload(1 + 2 * R);
+
+  // ---- row streams (U_n, V_n): register ring, one row per step, R rows ahead ------------------------------
+  double ru[R], rv[R];
+  const double *up = Ub + J, *vp = Vb + J;  // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {  // row n = n0 + ahead
     int64_t o = ahead;
     if (clamp && n >= N) o -= n - (N - 1);
-    rt[r] = tp[o]; ra[r] = ap[o]; ry[r] = yp[o];
     ru[r] = act ? up[o * J] : 0.0; rv[r] = act ? vp[o * J] : 0.0;
   };
 #pragma unroll
   for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
 
   // prepare step 1
+  lds_order();
   double tcur = tb[0];
-  double pc = exp_decay(cj * (tcur - rt[0])), uc = ru[0];
+  double tnext = sin_[0][0][grp][0];
+  double pc = exp_decay(cj * (tcur - tnext)), uc = ru[0];
   double pXc[G], uXc[G];
   xs[0][lane] = pc; xs[1][lane] = uc;
   lds_order();
@@ -272,30 +336,19 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   xgather_lds<G>(xs[1], lane, uXc);
   lds_order();
 
-  auto block = [&](int64_t n0, auto checked_tag) {
+  auto block = [&](int64_t n0, int q, auto checked_tag) {
     constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
-        if (CKPT && (r % C == 0) && L.valid) {  // state after row n-1 = checkpoint (n-1)/C
-          double *q = ck + ((n - 1) / C) * (G * Ckpt<G>::W);
-          if constexpr (Ckpt<G>::W % 2 == 0) {
-            double2 *q2 = reinterpret_cast<double2 *>(q);
-#pragma unroll
-            for (int k = 0; k < G / 2; ++k) q2[k] = make_double2(SX[2 * k], SX[2 * k + 1]);
-            q2[G / 2] = make_double2(F, w);
-            q2[G / 2 + 1] = make_double2(d, z);
-          } else {
-#pragma unroll
-            for (int k = 0; k < G; ++k) q[k] = SX[k];
-            q[G] = F; q[G + 1] = w; q[G + 2] = d; q[G + 3] = z;
-          }
-        }
-        const double tn = rt[r], an = ra[r], yn = ry[r], v = rv[r];
+        if (CKPT && (r % C == 0))  // state after row n-1 = checkpoint (n-1)/C
+          ckpt_store<G>(ckw + ((n - 1) / C) * (Ckpt<G>::W * kWave), lane, SX, F, w, d, z);
+        const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
+        const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
         const int rn = (r + 1) % R;
-        const double pn1 = exp_decay(cj * (tn - rt[rn])), un1 = ru[rn];
+        const double pn1 = exp_decay(cj * (tn - tn1)), un1 = ru[rn];
         xs[0][lane] = pn1; xs[1][lane] = un1;
         lds_order();
         double pXn[G], uXn[G];
@@ -305,12 +358,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (CKPT) {
-#ifndef C2_AB_NO_WST
           if (stw) wst[n * J] = w;
-#endif
-#ifndef C2_AB_NO_DZ
-          dzst[n] = make_double2(d, z);
-#endif
+          sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
         load_row(r, r + R, n + R, CHECKED);
@@ -324,16 +373,30 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
           prod = frexp(prod, &e);
           eacc += e;
         }
+        tnext = tn1;
         pc = pn1; uc = un1;
 #pragma unroll
         for (int k = 0; k < G; ++k) { pXc[k] = pXn[k]; uXc[k] = uXn[k]; }
       }
     }
+    // end of block: flush (d, z) of the block transposed, stage block b+2's scalars, fetch block b+3's
+    lds_order();
+    if (CKPT) {
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        const int idx = m * G + j;
+        if ((G * NV == R || idx < R) && (!CHECKED || n0 + idx < N)) dzst[n0 + idx] = sout[grp][idx];
+      }
+    }
+    vstage(q);
+    vload(n0 + 3 * R);
+    lds_order();
   };
   int64_t n0 = 1;
-  auto advance = [&]() { tp += R; ap += R; yp += R; up += R * J; vp += R * J; };
-  for (; n0 + 2 * R <= N; n0 += R) { block(n0, std::false_type{}); advance(); }  // every load in range
-  for (; n0 < N; n0 += R) { block(n0, std::true_type{}); advance(); }
+  int q = 0;
+  auto advance = [&]() { up += R * J; vp += R * J; q ^= 1; };
+  for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, std::false_type{}); advance(); }  // every row load in range
+  for (; n0 < N; n0 += R) { block(n0, q, std::true_type{}); advance(); }
 
   if (L.valid && j == 0) {
     flag[L.b] = fl;
@@ -391,11 +454,15 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          double *__restrict__ bc, double *__restrict__ ba,
                                                          double *__restrict__ bU, double *__restrict__ bV,
                                                          double *__restrict__ by) {
-  constexpr int SPW = kWave / G;  // series per wavefront
+  constexpr int SPW = kWave / G;         // series per wavefront
+  constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
   __shared__ __attribute__((aligned(16))) double vv[C][3][kWave];
   __shared__ __attribute__((aligned(16))) double sfL[C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
-  __shared__ __attribute__((aligned(16))) double scR[C + 1][SPW], scZ[C + 1][SPW], scT[C][SPW];  // 1/d, z, dt per series
+  // per-series scalars of rows n_lo-1 .. n_lo+C-1 (entry e <-> row n_lo-1+e): t, d, 1/d, z
+  __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
+  // per-series scalar outputs of the segment, flushed transposed (lane j <-> row j): ba_n, bt_n, by_{n-1}
+  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[SPW][C], oBY[SPW][C];
   __shared__ __attribute__((aligned(16))) double xB[kWave];
   const int J = PAD ? Jrt : G;
   const Geo<G> L(B, J);
@@ -409,7 +476,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
   const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Wb = Wst + L.b0 * N * J + oj;
   const double2 *dzb = DZst + L.b0 * N + on;
-  const double *ck = ckpt + ((L.b * nseg) * G + j) * Ckpt<G>::W;
+  const double *ckw = ckpt + (size_t)blockIdx.x * nseg * (Ckpt<G>::W * kWave);
   double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
   double *bUb = bU + L.b0 * N * J + oj, *bVb = bV + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
@@ -426,60 +493,65 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   double bF = 0.0, carry = 0.0, bcj = 0.0;
   double bVn = 0.0, ban = 0.0, bzn = 0.0;
 
-  // Records of the segment about to be replayed (loaded one half-segment ahead): t, U_n, W_{n-1}, (d, z) of
-  // rows n_lo-1 .. n_lo+C-1 and the checkpointed S column / F of row n_lo-1.
-  double it[C + 1], iu[C], iw[C];
-  double2 idz[C + 1];
+  // Records of the segment about to be replayed (loaded half a segment ahead).  Scalar streams (t and the
+  // (d, z) pairs) are fetched TRANSPOSED: lane j takes row n_lo-1+j, i.e. entries 0..C-1; entry C (the last
+  // row of the segment) is the previous iteration's entry 0 and is carried in registers.
+  double vt[NV];
+  double2 vdz[NV];
+  double iu[C], iw[C];
   double cS[G], cF;
   auto load_segment = [&](int64_t k) {
     const int64_t n_lo = 1 + k * C;
     const bool full = n_lo + C <= N;
-    it[0] = tb[n_lo - 1];
-    idz[0] = dzb[n_lo - 1];
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      int64_t row = n_lo - 1 + m * G + j;
+      row = (row < N) ? row : N - 1;
+      vt[m] = tb[row]; vdz[m] = dzb[row];
+    }
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      it[r + 1] = tb[n];
-      idz[r + 1] = dzb[n];
       iu[r] = act ? Ub[n * J] : 0.0;
       iw[r] = act ? Wb[(n - 1) * J] : 0.0;  // W row n-1
     }
-    const double *q = ck + k * (G * Ckpt<G>::W);
-    if constexpr (Ckpt<G>::W % 2 == 0) {
-      const double2 *q2 = reinterpret_cast<const double2 *>(q);
-#pragma unroll
-      for (int i = 0; i < G / 2; ++i) { const double2 v2 = q2[i]; cS[2 * i] = v2.x; cS[2 * i + 1] = v2.y; }
-      cF = q2[G / 2].x;
-    } else {
-#pragma unroll
-      for (int i = 0; i < G; ++i) cS[i] = q[i];
-      cF = q[G];
-    }
+    ckpt_load<G>(ckw + k * (Ckpt<G>::W * kWave), lane, cS, cF);
   };
 
+  // entry `cnt` of the first processed segment = row N-1
+  double carT = tb[N - 1];
+  double2 carDZ = dzb[N - 1];
+  double carR = rcp_nr(carDZ.x);
   if (nseg > 0) load_segment(nseg - 1);
-  else idz[0] = dzb[0];  // N == 1: no steps, only the seeds of row 0
 
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
 
-    // ---- phase A: everything row-indexed goes to LDS: p_n (C independent exps), U_n, W_{n-1}, 1/d, z, dt --
-    double dprev[C];  // d_{n-1} of every step (pivot of the previous row)
-    scR[0][grp] = rcp_nr(idz[0].x); scZ[0][grp] = idz[0].y;
+    // ---- phase A: scalar rows to LDS (lane-parallel), then p_n (C independent exps), U_n, W_{n-1} ----------
 #pragma unroll
-    for (int r = 0; r < C; ++r) {
-      const double dt = it[r] - it[r + 1];
-      vv[r][0][lane] = exp_decay(cj * dt);
-      vv[r][1][lane] = iu[r];
-      vv[r][2][lane] = iw[r];
-      scT[r][grp] = dt;
-      scR[r + 1][grp] = rcp_nr(idz[r + 1].x); scZ[r + 1][grp] = idz[r + 1].y;
-      dprev[r] = idz[r].x;
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * G + j;
+      if (G * NV == C || idx < C) {
+        rowT[idx][grp] = vt[m]; rowD[idx][grp] = vdz[m].x; rowR[idx][grp] = rcp_nr(vdz[m].x); rowZ[idx][grp] = vdz[m].y;
+      }
     }
-    double zprev[C];
+    lds_order();
+    rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
+    lds_order();
+    double dtv[C];
+    {
+      double tprev = rowT[0][grp];
 #pragma unroll
-    for (int r = 0; r < C; ++r) zprev[r] = idz[r].y;
+      for (int r = 0; r < C; ++r) {
+        const double tn = rowT[r + 1][grp];
+        dtv[r] = tprev - tn;
+        tprev = tn;
+        vv[r][0][lane] = exp_decay(cj * dtv[r]);
+        vv[r][1][lane] = iu[r];
+        vv[r][2][lane] = iw[r];
+      }
+    }
     // ---- phase B: replay S_n = P (S + d w^T w) P and F_n = P (F + w z) -- with W, d, z on record there is no
     // recursion chain left (no reductions, no division): a pure throughput loop.  S_n columns go to LDS
     // (packed), F_n and tau_n = U_n S_n stay in registers.
@@ -497,7 +569,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         xgather_lds<G>(vv[r][1], lane, uX);
         xgather_lds<G>(vv[r][2], lane, wX);
         const double p = pX[0], w = wX[0];
-        const double dw = dprev[r] * w;
+        const double dw = rowD[r][grp] * w;
         double tau0 = 0.0, tau1 = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
@@ -507,7 +579,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           else tau0 = fma(uX[i], sv, tau0);
         }
         tauS[r] = tau0 + tau1;
-        F = p * fma(w, zprev[r], F);
+        F = p * fma(w, rowZ[r][grp], F);
         Fp[r] = F;
         double *sfr = sfL[r];
         sfr[lane] = SX[0];
@@ -520,13 +592,15 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         }
       }
     }
-    if (k == nseg - 1) {  // cotangents of the last row: pure seeds (1/d, z of row N-1 are in LDS by now)
-      const double rd = scR[cnt][grp], z = scZ[cnt][grp];
+    if (k == nseg - 1) {  // cotangents of the last row: pure seeds
+      const double rd = rowR[cnt][grp], z = rowZ[cnt][grp];
       ban = 0.5 * rd * (z * z * rd - 1.0);
       bzn = -z * rd;
       bVn = 0.0;
       if (st0) byb[N - 1] = bzn;
     }
+    // entry 0 (row n_lo-1) is entry C of the next, earlier segment
+    carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
     lds_order();
 
     // ---- phase C: fused reverse steps; the next (earlier) segment is fetched half way through ---------
@@ -538,7 +612,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       if (r < cnt) {
         const int64_t n = n_lo + r;
         const double p = vv[r][0][lane], u = vv[r][1][lane], wm = vv[r][2][lane], Fpn = Fp[r];
-        const double rdm = scR[r][grp], zm = scZ[r][grp], dt = scT[r][grp];
+        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
         double uX[G], pX[G], wX[G], bVX[G], Sf[G];
         xgather_lds<G>(vv[r][1], lane, uX);
         xgather_lds<G>(vv[r][0], lane, pX);
@@ -546,7 +620,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         const double *sfr = sfL[r];
 #pragma unroll
         for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];
-        if (st0) bab[n] = ban;
+        oBA[grp][r] = ban;
         if (st) bVb[n * J] = bVn;
         xgather_dpp<G>(bVn, xB, lane, bVX);
         // solve_lower_rev part (internal.hpp:232-245)
@@ -581,19 +655,30 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         const double q = q0 + q1;
         double f = cj * bp, Gs = wm * bF, Q = q * wm;
         gsum3<G>(f, Gs, Q);
-        if (st0) btb[n] = carry - f;
+        oBT[grp][r] = carry - f;
         carry = f;
         const double zr = zm * rdm;
         bzn = Gs - zr;
-        if (st0) byb[n - 1] = bzn;
+        oBY[grp][r] = bzn;
         bVn = fma(zr, bF, q);
         ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
       }
     }
     lds_order();
+    // flush the segment's per-series scalar outputs, transposed: lane j <-> row n_lo + j (by: row n_lo-1+j)
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * G + j;
+      if ((G * NV == C || idx < C) && idx < cnt && (PAD ? L.valid : true)) {
+        bab[n_lo + idx] = oBA[grp][idx];
+        btb[n_lo + idx] = oBT[grp][idx];
+        byb[n_lo - 1 + idx] = oBY[grp][idx];
+      }
+    }
+    lds_order();
   }
   if (nseg == 0) {  // N == 1
-    const double rd0 = 1.0 / idz[0].x, cz = idz[0].y;
+    const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;
     ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);
     bzn = -cz * rd0;
     if (st0) byb[0] = bzn;
@@ -668,7 +753,8 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   GradWs g;
-  g.ck = (size_t)B * (size_t)nseg * G_ * (G_ + 4);
+  const size_t waves = ((size_t)B * G_ + kWave - 1) / kWave;       // checkpoints are wave-blocked
+  g.ck = waves * (size_t)nseg * (G_ + 4) * kWave;
   g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
   g.w = (size_t)B * N * J;
   g.w = (g.w + 1) & ~(size_t)1;

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void k(unsigned long long *out, int iters, doub
 template <int MODE>
 void run(const char *name, int waves_per_simd, unsigned long long *d_out) {
   fprintf(stderr, "start %s\n", name);
-  const int blocks = 1024 * waves_per_simd, iters = 2000;
+  const int blocks = 1024 * waves_per_simd, iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d_out, 10, 1.0);

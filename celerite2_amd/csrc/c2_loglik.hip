@@ -204,39 +204,49 @@ struct Geo {
 #ifndef C2_REV_OCC
 #define C2_REV_OCC 1
 #endif
-// Checkpoints are private to a wavefront (written by k_loglik_fwd, read back by the same lanes of
-// k_loglik_rev), so they are stored wave-blocked and component-major: record (wave, segment) is W/2 rows of
-// 64 double2 (or W rows of 64 doubles when W is odd) -- every store/load instruction moves one fully
-// contiguous 1 KiB (512 B) run instead of 64 scattered 16-byte pieces.
+// Packed symmetric storage of the C saved S_n columns in LDS.  In XOR order slot k of lane j is S(j^k, j) and
+// slot k of lane j^k is its transpose twin S(j, j^k) -- the same number up to rounding -- so for k >= 1 only
+// the lane whose bit hb(k) (highest set bit of k) is clear stores it and both lanes read that copy:
+// G + (G-1) G/2 doubles per series and step instead of G^2 (36 instead of 64 at G = 8).
 template <int G>
-__device__ __forceinline__ void ckpt_store(double *rec, int lane, const double (&SX)[G], double F, double w, double d,
-                                           double z) {
-  if constexpr (Ckpt<G>::W % 2 == 0) {
-    double2 *q = reinterpret_cast<double2 *>(rec) + lane;
-#pragma unroll
-    for (int k = 0; k < G / 2; ++k) q[k * kWave] = make_double2(SX[2 * k], SX[2 * k + 1]);
-    q[(G / 2) * kWave] = make_double2(F, w);
-    q[(G / 2 + 1) * kWave] = make_double2(d, z);
-  } else {
-    double *q = rec + lane;
-#pragma unroll
-    for (int k = 0; k < G; ++k) q[k * kWave] = SX[k];
-    q[G * kWave] = F; q[(G + 1) * kWave] = w; q[(G + 2) * kWave] = d; q[(G + 3) * kWave] = z;
+struct SymPack {
+  static constexpr int PER_STEP = kWave + (G - 1) * (kWave / 2);  // doubles per wavefront per step
+  // offset (in doubles) of slot k >= 1 for wave-local lane l
+  static __device__ __forceinline__ int off(int l, int k) {
+    const int b = 31 - __builtin_clz(k), hb = 1 << b;
+    const int o = (l & hb) ? (l ^ k) : l;  // owner lane (bit b clear)
+    const int idx = ((o >> (b + 1)) << b) | (o & (hb - 1));
+    return kWave + (k - 1) * (kWave / 2) + idx;
   }
+};
+
+// Checkpoints are private to a wavefront (written by k_loglik_fwd, read back by the same lanes of
+// k_loglik_rev), so they are stored wave-blocked, component-major and SYMMETRIC-PACKED exactly like the LDS copy
+// of the saved states above: one record = SymPack<G>::PER_STEP doubles of S (slot 0: 64 contiguous doubles,
+// every slot k >= 1: 32 contiguous doubles written by the owner lanes) + 64 doubles of F.  Every store/load
+// instruction moves one contiguous 256/512-byte run; 44 instead of 96 bytes per series and step at G = C = 8.
+template <int G>
+struct CkptRec {
+  static constexpr int DOUBLES = SymPack<G>::PER_STEP + kWave;  // per wavefront and checkpoint
+};
+template <int G>
+__device__ __forceinline__ void ckpt_store(double *rec, int lane, const int (&soff)[G], const double (&SX)[G], double F) {
+  const int j = lane & (G - 1);
+  rec[lane] = SX[0];
+#pragma unroll
+  for (int b = 0; (1 << b) < G; ++b) {
+    if ((j & (1 << b)) == 0) {  // owner lanes of slots k in [2^b, 2^(b+1))
+#pragma unroll
+      for (int kk = (1 << b); kk < (2 << b); ++kk) rec[soff[kk]] = SX[kk];
+    }
+  }
+  rec[SymPack<G>::PER_STEP + lane] = F;
 }
 template <int G>
-__device__ __forceinline__ void ckpt_load(const double *rec, int lane, double (&SX)[G], double &F) {
-  if constexpr (Ckpt<G>::W % 2 == 0) {
-    const double2 *q = reinterpret_cast<const double2 *>(rec) + lane;
+__device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int (&soff)[G], double (&SX)[G], double &F) {
 #pragma unroll
-    for (int k = 0; k < G / 2; ++k) { const double2 v = q[k * kWave]; SX[2 * k] = v.x; SX[2 * k + 1] = v.y; }
-    F = q[(G / 2) * kWave].x;
-  } else {
-    const double *q = rec + lane;
-#pragma unroll
-    for (int k = 0; k < G; ++k) SX[k] = q[k * kWave];
-    F = q[G * kWave];
-  }
+  for (int k = 0; k < G; ++k) SX[k] = rec[soff[k]];
+  F = rec[SymPack<G>::PER_STEP + lane];
 }
 
 template <int G, int R, int C, bool CKPT, bool PAD>
@@ -267,7 +277,11 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   const double *tb = t + L.b0 * t_bs + ot, *ab = a + L.b0 * N + on, *yb = y + L.b0 * N + on;
   const double *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
-  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * nseg * (Ckpt<G>::W * kWave) : nullptr;
+  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES : nullptr;
+  int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
+  soff[0] = lane;
+#pragma unroll
+  for (int k = 1; k < G; ++k) soff[k] = SymPack<G>::off(lane, k);
   // per-step records for the reverse sweep (CKPT only): W_n (like the reference's factor output) and (d_n, z_n)
   double *wst = CKPT ? Wst + L.b0 * N * J + oj : nullptr;
   double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
         if (CKPT && (r % C == 0))  // state after row n-1 = checkpoint (n-1)/C
-          ckpt_store<G>(ckw + ((n - 1) / C) * (Ckpt<G>::W * kWave), lane, SX, F, w, d, z);
+          ckpt_store<G>(ckw + ((n - 1) / C) * CkptRec<G>::DOUBLES, lane, soff, SX, F);
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
@@ -427,22 +441,6 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 //   ba_{n-1} = bd_{n-1} - Q/2 - z_{n-1} G / d_{n-1}                 (bd + w bS w^T - W_{n-1}.bV_{n-1})
 // with the seeds bd = (z^2/d - 1)/(2d), the derivative of the log-likelihood w.r.t. d (and -z/d w.r.t. z).
 // =============================================================================
-// Packed symmetric storage of the C saved S_n columns in LDS.  In XOR order slot k of lane j is S(j^k, j) and
-// slot k of lane j^k is its transpose twin S(j, j^k) -- the same number up to rounding -- so for k >= 1 only
-// the lane whose bit hb(k) (highest set bit of k) is clear stores it and both lanes read that copy:
-// G + (G-1) G/2 doubles per series and step instead of G^2 (36 instead of 64 at G = 8).
-template <int G>
-struct SymPack {
-  static constexpr int PER_STEP = kWave + (G - 1) * (kWave / 2);  // doubles per wavefront per step
-  // offset (in doubles) of slot k >= 1 for wave-local lane l
-  static __device__ __forceinline__ int off(int l, int k) {
-    const int b = 31 - __builtin_clz(k), hb = 1 << b;
-    const int o = (l & hb) ? (l ^ k) : l;  // owner lane (bit b clear)
-    const int idx = ((o >> (b + 1)) << b) | (o & (hb - 1));
-    return kWave + (k - 1) * (kWave / 2) + idx;
-  }
-};
-
 template <int G, int C, bool PAD>
 __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -476,7 +474,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
   const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Wb = Wst + L.b0 * N * J + oj;
   const double2 *dzb = DZst + L.b0 * N + on;
-  const double *ckw = ckpt + (size_t)blockIdx.x * nseg * (Ckpt<G>::W * kWave);
+  const double *ckw = ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES;
   double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
   double *bUb = bU + L.b0 * N * J + oj, *bVb = bV + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
@@ -515,7 +513,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       iu[r] = act ? Ub[n * J] : 0.0;
       iw[r] = act ? Wb[(n - 1) * J] : 0.0;  // W row n-1
     }
-    ckpt_load<G>(ckw + k * (Ckpt<G>::W * kWave), lane, cS, cF);
+    ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF);
   };
 
   // entry `cnt` of the first processed segment = row N-1
@@ -754,7 +752,7 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   GradWs g;
   const size_t waves = ((size_t)B * G_ + kWave - 1) / kWave;       // checkpoints are wave-blocked
-  g.ck = waves * (size_t)nseg * (G_ + 4) * kWave;
+  g.ck = waves * (size_t)nseg * ((size_t)kWave + (size_t)(G_ - 1) * (kWave / 2) + kWave);  // CkptRec<G>::DOUBLES
   g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
   g.w = (size_t)B * N * J;
   g.w = (g.w + 1) & ~(size_t)1;

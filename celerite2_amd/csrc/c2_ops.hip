@@ -620,6 +620,11 @@ inline int check_dims(int64_t B, int64_t N, int64_t J) {
     default: { constexpr int G = 32; __VA_ARGS__; } break;      \
   }
 
+extern "C" int c2_internal_matmul_chunked(int lower, int64_t B, int64_t N, int64_t J, int64_t nrhs, int64_t Lc,
+                                          const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                          const double *U, const double *V, const double *Y, double *Z, double *F,
+                                          int zero_z, c2_stream_t stream);
+
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -627,6 +632,18 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
   if (int e = check_dims(B, N, J)) return e;
   if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z) return C2_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
+  if (!SOLVE) {
+    // Long series with too few (series x rhs-tile) chains to fill the chip: the matmul recurrence is linear with
+    // a diagonal transition, so it is cut into time chunks that run in parallel (c2_scan.hip).
+    const int64_t chains = B * ((nrhs + 3) / 4) * group_size(J);  // lanes kept busy by the sequential kernel
+    if (N >= 16384 && chains < (int64_t)kWave * 2048) {
+      // chunk length: aim at ~2048 units in flight per rhs slab, between 1024 and 16384 rows
+      int64_t Lc = 1024;
+      while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
+      return c2_internal_matmul_chunked(LOWER ? 1 : 0, B, N, J, nrhs, Lc, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
+                                        stream);
+    }
+  }
   if (nrhs == 1) {
     C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL((k_sweep<G, 1, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s,
                                                     B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));

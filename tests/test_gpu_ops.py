@@ -290,3 +290,34 @@ def test_gp_frontend_matches_dense(ops):
         np.testing.assert_allclose(mu_self[b], y[b] - diag[b] * a_r, rtol=1e-8, atol=1e-9)
     s = gp.sample(size=4)
     assert s.shape == (B, 4, N) and bool(torch.isfinite(s).all())
+
+
+@pytest.mark.parametrize("J,nrhs,N", [(16, 32, 40000), (4, 1, 70001), (6, 5, 20000)])
+def test_long_series_chunked_matmul(ops, oracle, J, nrhs, N):
+    """Long-series matmul_lower/upper take the time-chunked scan (c2_scan.hip): compare with the sequential
+    oracle, incl. the F workspace, accumulation into Z, and in-place dot_tril (BASELINE config 4 shape)."""
+    import torch
+    B = 1
+    rng = np.random.default_rng(17)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J if J % 2 == 0 else J + 1)
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, ad, Ud, Vd, Yd = dev(t, c, a, U, V, Y)
+    for name in ("matmul_lower", "matmul_upper"):
+        Z0 = rng.standard_normal((B, N, nrhs))
+        (Zd,) = dev(Z0)
+        Zd, Fd = getattr(ops, name)(td, cd, Ud, Vd, Yd, Z=Zd, workspace=True)
+        Zo = Z0[0].copy(); Fo = np.empty((N, J, nrhs))
+        getattr(oracle, name)(t[0], c[0], U[0], V[0], Y[0], Zo, Fo)
+        close(Zd[0], Zo, 1e-9); close(Fd[0], Fo, 1e-9)
+    d, W, flag = ops.factor(td, cd, ad, Ud, Vd)
+    assert int(flag[0]) == 0
+    Yc = Yd.clone()
+    Zi = ops.dot_tril(td, cd, Ud, W, d, Yc, Z=Yc)   # in place
+    z = np.ascontiguousarray(Y[0] * np.sqrt(d[0].cpu().numpy())[:, None])
+    oracle.matmul_lower(t[0], c[0], U[0], W[0].cpu().numpy(), z, z)
+    close(Zi[0], z, 1e-9)
+    # size-independent property: linearity in Y
+    y2 = torch.randn_like(Yd)
+    f = lambda v: ops.matmul_lower(td, cd, Ud, Vd, v.contiguous())
+    lhs, rhs = f(Yd - 2.0 * y2), f(Yd) - 2.0 * f(y2)
+    assert float((lhs - rhs).abs().max()) <= 1e-9 * max(1.0, float(rhs.abs().max()))

@@ -35,6 +35,18 @@ def algorithmic_bytes_per_gp(N, J, grad):
     return N * 16 * (3 + 2 * J) + 16 * J + 8 if grad else N * 8 * (3 + 2 * J) + 8 * J + 8
 
 
+def measured_traffic(grad, Bp, N, J):
+    """HBM bytes per step from the committed rocprofv3 PMC measurement of this exact workload (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            for w in json.load(f)["workloads"]:
+                if (w["mode"] == ("grad" if grad else "fwd") and w["batch_per_gpu"] == Bp and w["N"] == N and w["J"] == J):
+                    return w["traffic_bytes_per_step"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(N, J, grad, seconds):
     """Time the CPU restatement on a bounded sample of the same synthetic workload."""
     import numpy as np
@@ -163,7 +175,7 @@ def main():
                        "parallelism": "batch-sharded x%d, all-gather of log-liks" % world,
                        "failed_factorizations": nfail},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(grad, Bp, N, J),
                          "algorithmic_bytes_per_gp": bytes_per_gp, "kernel_ms_avg": kernel_ms_avg,
                          "kernel_ms_median": kernel_ms[len(kernel_ms) // 2]},
         }

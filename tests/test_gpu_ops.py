@@ -321,3 +321,43 @@ def test_long_series_chunked_matmul(ops, oracle, J, nrhs, N):
     f = lambda v: ops.matmul_lower(td, cd, Ud, Vd, v.contiguous())
     lhs, rhs = f(Yd - 2.0 * y2), f(Yd) - 2.0 * f(y2)
     assert float((lhs - rhs).abs().max()) <= 1e-9 * max(1.0, float(rhs.abs().max()))
+
+
+def test_torch_autograd_adapter(ops, oracle):
+    """autograd.log_likelihood: values and gradients (incl. a shared time grid and shared c) vs the oracle."""
+    import torch
+    from celerite2_amd import autograd as ag
+
+    B, N, J = 6, 150, 4
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    t0, c0 = t[0].copy(), c[0].copy()
+    # per-series t and c
+    td, cd, ad, Ud, Vd, yd = [x.requires_grad_(True) for x in dev(t, c, a, U, V, y)]
+    ll = ag.log_likelihood(td, cd, ad, Ud, Vd, yd)
+    wts = torch.linspace(0.5, 1.5, B, dtype=torch.float64, device="cuda")
+    (ll * wts).sum().backward()
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    close(ll.detach(), llo)
+    w = wts.cpu().numpy()
+    for x, e in zip((td, cd, ad, Ud, Vd, yd), go):
+        close(x.grad, e * w.reshape((B,) + (1,) * (e.ndim - 1)))
+    # shared t and c (one light-curve grid, one kernel, different noise / data): gradients are summed over the batch
+    rng = np.random.default_rng(2)
+    co = dense.sho_sum_coeffs(J, 0.0)
+    for b in range(B):
+        c0, a[b], U[b], V[b] = dense.celerite_matrices(co, t0, rng.uniform(0.1, 0.3, N))
+        y[b] = np.sin(t0) + 0.1 * rng.standard_normal(N)
+    td, cd = [x.requires_grad_(True) for x in dev(t0, c0)]
+    ad, Ud, Vd, yd = dev(a, U, V, y)
+    ll = ag.log_likelihood(td, cd, ad, Ud, Vd, yd)
+    ll.sum().backward()
+    gt = np.zeros(N); gc = np.zeros(J)
+    for b in range(B):
+        l1, g1, f1 = oracle.loglik_grad(t0, c0, a[b], U[b], V[b], y[b])
+        assert f1 == 0
+        gt += g1[0]; gc += g1[1]
+    close(td.grad, gt, 1e-9); close(cd.grad, gc, 1e-9)
+    # no-grad call takes the forward-only kernel
+    with torch.no_grad():
+        ll2 = ag.log_likelihood(td, cd, ad, Ud, Vd, yd)
+    close(ll2, ll.detach().cpu().numpy())

@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
 """bench.py -- headline benchmark: batched float64 GP log-likelihood + gradient per second at
 N=4096, J=8 (BASELINE.json metric).  Workload = BASELINE.json configs[2]: a batch of 65536 independent GPs,
-forward + reverse-mode gradient.  It fits one MI355X (41 GB inputs + 41 GB gradients + 26 GB checkpoints), so
+forward + reverse-mode gradient.  It fits one MI355X (41 GB inputs + 41 GB gradients + 33 GB replay records), so
 N=1 runs all 65536 series on one GPU and N GPUs shard the SAME batch (strong scaling; at N=8 each GPU owns
 8192 series -- "batch 65536 sharded across 8 x MI355X").  --batch-per-gpu B switches to weak scaling.
 

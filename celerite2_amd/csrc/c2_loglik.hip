@@ -609,12 +609,13 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
       if (r < cnt) {
         const int64_t n = n_lo + r;
-        const double p = vv[r][0][lane], u = vv[r][1][lane], wm = vv[r][2][lane], Fpn = Fp[r];
+        const double Fpn = Fp[r];
         const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
         double uX[G], pX[G], wX[G], bVX[G], Sf[G];
         xgather_lds<G>(vv[r][1], lane, uX);
         xgather_lds<G>(vv[r][0], lane, pX);
         xgather_lds<G>(vv[r][2], lane, wX);
+        const double p = pX[0], u = uX[0], wm = wX[0];  // slot 0 of an XOR gather is the lane's own element
         const double *sfr = sfL[r];
 #pragma unroll
         for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];

@@ -249,7 +249,7 @@ __device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int
   F = rec[SymPack<G>::PER_STEP + lane];
 }
 
-template <int G, int R, int C, bool CKPT, bool PAD>
+template <int G, int R, int C, int MODE, bool PAD>
 __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
@@ -259,6 +259,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          int32_t *__restrict__ flag, double *__restrict__ ckpt,
                                                          int64_t nseg, double *__restrict__ Wst,
                                                          double2 *__restrict__ DZst) {
+  // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
+  // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
+  // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
+  constexpr bool CKPT = MODE == 1, FACTOR = MODE == 2, REC = MODE != 0;
   static_assert(!CKPT || R % C == 0, "block length must be a multiple of the checkpoint interval");
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (R + G - 1) / G;    // vector loads per scalar stream per block of R rows
@@ -283,8 +287,9 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 #pragma unroll
   for (int k = 1; k < G; ++k) soff[k] = SymPack<G>::off(lane, k);
   // per-step records for the reverse sweep (CKPT only): W_n (like the reference's factor output) and (d_n, z_n)
-  double *wst = CKPT ? Wst + L.b0 * N * J + oj : nullptr;
+  double *wst = REC ? Wst + L.b0 * N * J + oj : nullptr;
   double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
+  double *dst = FACTOR ? reinterpret_cast<double *>(DZst) + L.b0 * N + on : nullptr;
   const bool stw = PAD ? (L.valid && act) : true;  // duplicate stores of identical values are harmless
 
   double SX[G];
@@ -299,9 +304,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   int eacc = 0;
   double quad = z * z * rd;
   int32_t fl = 0;
-  if (CKPT) {
+  if (REC) {
     if (stw) wst[0] = w;
-    dzst[0] = make_double2(d, z);
+    if (CKPT) dzst[0] = make_double2(d, z);
+    else dst[0] = d;
   }
 
   // ---- transposed scalar streams: registers hold the rows of block b+2, LDS the rows of blocks b, b+1 ----
@@ -371,8 +377,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         lds_order();
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
-        if (CKPT) {
-          if (stw) wst[n * J] = w;
+        if (REC) {
+          if (stw && (!FACTOR || ((fl == 0) & (d > 0.0)))) wst[n * J] = w;
           sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
@@ -395,11 +401,14 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
     }
     // end of block: flush (d, z) of the block transposed, stage block b+2's scalars, fetch block b+3's
     lds_order();
-    if (CKPT) {
+    if (REC) {
 #pragma unroll
       for (int m = 0; m < NV; ++m) {
         const int idx = m * G + j;
-        if ((G * NV == R || idx < R) && (!CHECKED || n0 + idx < N)) dzst[n0 + idx] = sout[grp][idx];
+        if ((G * NV == R || idx < R) && (!CHECKED || n0 + idx < N)) {
+          if (CKPT) dzst[n0 + idx] = sout[grp][idx];
+          else if (fl == 0 || n0 + idx <= fl) dst[n0 + idx] = sout[grp][idx].x;  // rows 0..n of d (forward.hpp:127-128)
+        }
       }
     }
     vstage(q);
@@ -414,10 +423,12 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 
   if (L.valid && j == 0) {
     flag[L.b] = fl;
-    int e;
-    prod = frexp(prod, &e);
-    const double logdet = log(prod) + (double)(eacc + e) * kLn2;
-    ll[L.b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
+    if (!FACTOR) {
+      int e;
+      prod = frexp(prod, &e);
+      const double logdet = log(prod) + (double)(eacc + e) * kLn2;
+      ll[L.b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
+    }
   }
 }
 
@@ -701,7 +712,7 @@ using namespace c2;
 namespace {
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP; }
 
-template <bool CKPT>
+template <int MODE>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s) {
@@ -710,10 +721,10 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
     if (J == G)                                                                                                  \
-      hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
+      hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
                          c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst);                                 \
     else                                                                                                         \
-      hipLaunchKernelGGL((k_loglik_fwd<G, R, C, CKPT, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,    \
+      hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,    \
                          c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst);                                 \
   } while (0)
   switch (G_) {
@@ -737,7 +748,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
-  return launch_fwd<false>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
+  return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
                            (hipStream_t)stream);
 }
 
@@ -762,6 +773,15 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
   return g;
 }
 
+// core::factor without the S workspace (interface.hpp:37-48) on the fused forward kernel: d and W straight
+// into the caller's arrays (d == a and W == V allowed: every row is read blocks ahead of the row being written).
+int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                             int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
+                             int32_t *flag, c2_stream_t stream) {
+  return launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, /*y (unused: any readable (B,N) array)*/ a, nullptr, flag,
+                       nullptr, 0, W, reinterpret_cast<double2 *>(d), (hipStream_t)stream);
+}
+
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
   return grad_ws(B, N, J).total * sizeof(double);
@@ -783,7 +803,7 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   double *ckpt = (double *)work;
   double *Wst = ckpt + ws.ck;
   double2 *DZst = reinterpret_cast<double2 *>(Wst + ws.w);
-  if (int e = launch_fwd<true>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, s)) return e;
+  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, s)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \

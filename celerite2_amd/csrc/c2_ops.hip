@@ -703,11 +703,17 @@ int c2_device_count(void) {
   return n;
 }
 
+int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                             int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
+                             int32_t *flag, c2_stream_t stream);
+
 int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
               const double *a, const double *U, const double *V, double *d, double *W, double *S, int32_t *flag,
               c2_stream_t stream) {
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !a || !U || !V || !d || !W || !flag) return C2_ERR_INVALID;
+  if (!S)  // no workspace requested: the tuned forward kernel of the fused log-likelihood doubles as factor
+    return c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, stream);
   hipStream_t s = (hipStream_t)stream;
   C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL(k_factor<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J, t,
                                                   t_bs, c, c_bs, a, U, V, d, W, S, flag));

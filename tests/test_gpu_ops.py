@@ -84,7 +84,9 @@ def test_ops_vs_oracle_batched(ops, oracle, J):
     # in-place factor: d aliases a, W aliases V
     a2, V2 = ad.clone(), Vd.clone()
     d2, W2, _ = ops.factor(td, cd, a2, Ud, V2, d=a2, W=V2)
-    assert torch.equal(d2, d) and torch.equal(W2, W)
+    d3, W3, _ = ops.factor(td, cd, ad, Ud, Vd)            # same (workspace-free) path, out of place
+    assert d2.data_ptr() == a2.data_ptr() and torch.equal(d2, d3) and torch.equal(W2, W3)
+    close(d2, do); close(W2, Wo)
     for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
         second = W if name.startswith("solve") else Vd
         second_o = Wo if name.startswith("solve") else V

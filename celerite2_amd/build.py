@@ -21,7 +21,9 @@ LIB = os.path.join(HERE, "libcelerite2_amd.so")
 HIP_SOURCES = ["c2_ops.hip", "c2_fused.hip", "c2_loglik.hip", "c2_scan.hip", "c2_host.hip"]
 HIP_HEADERS = ["c2_common.hpp", os.path.join(INCLUDE, "celerite2_amd.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+# max-ilp machine scheduling: the kernels run at one wavefront per SIMD, so latency is hidden by ILP, not occupancy
+# (measured +5 % on the fused gradient pair vs the default occupancy-driven strategy).
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "--amdgpu-sched-strategy=max-ilp"]
 
 
 def _stale(target, sources):

@@ -104,11 +104,18 @@ def main():
         raise SystemExit("--gpus must equal WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; C2_DIST_BACKEND=gloo (+ several ranks on one device) exists only to exercise this
+    # multi-rank path on a single-GPU box -- the real runs use RCCL ("nccl" backend on ROCm)
+    backend = os.environ.get("C2_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     _lib.load()
 
     weak = args.batch_per_gpu > 0
@@ -129,8 +136,11 @@ def main():
             ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
         else:
             ll, flag = ops.loglik(t, c, a, U, V, y)
-        if world > 1:
-            ll = parallel.gather_loglik(ll, Btot, world)  # the path's only exchange: B/n_gpu log-liks per rank
+        if world > 1:  # the path's only exchange: B/n_gpu log-liks per rank
+            if backend == "nccl":
+                ll = parallel.gather_loglik(ll, Btot, world)
+            else:
+                ll = parallel.gather_loglik(ll.cpu(), Btot, world).to(dev)
         return ll, flag
 
     for _ in range(args.warmup):
@@ -152,7 +162,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
     kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)

@@ -11,6 +11,8 @@
 // row of an aliased output is STORED (program order, no __restrict__ on
 // aliasable pairs), which is the device equivalent of the reference's `tmp`
 // previous-row trick (internal.hpp:134-141).
+#include <cstdint>
+
 #include "c2_common.hpp"
 #include "../../include/celerite2_amd.h"
 
@@ -34,6 +36,63 @@ __device__ __forceinline__ Lane lane_of(int64_t B) {
   return L;
 }
 
+// Group all-gather in NATURAL order through a per-wave LDS slot: every lane publishes its value, then reads the G
+// values of its group with G/2 broadcast ds_read_b128 (no ds_bpermute, no VALU).
+template <int G>
+__device__ __forceinline__ void lds_allgather(double *slot, int lane, double x, double (&out)[G]) {
+  if constexpr (G == 1) {
+    out[0] = x;
+  } else {
+    slot[lane] = x;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const double2 *p = reinterpret_cast<const double2 *>(slot + (lane & ~(G - 1)));
+#pragma unroll
+    for (int k = 0; k < G / 2; ++k) {
+      const double2 v = p[k];
+      out[2 * k] = v.x;
+      out[2 * k + 1] = v.y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+}
+
+// Coalesced movement of the S workspace (B,N,J,J).  Lane (s, j) owns column j of its series' J x J row, i.e.
+// J contiguous doubles at offset j*J -- addressed directly, one instruction touches 64 separate 8-byte words.
+// Instead the wavefront's rows are transposed through an LDS tile so that every global instruction moves
+// 16 bytes per lane in 2J*8-byte contiguous runs per series (J == G only; padded widths keep the direct path).
+template <int G>
+__device__ __forceinline__ void s_row_store(double *tile, int lane, const double (&col)[G], double *row) {
+  const int s = lane / G, j = lane % G;
+  double2 *tw = reinterpret_cast<double2 *>(tile + s * G * G + j * G);
+#pragma unroll
+  for (int k = 0; k < G / 2; ++k) tw[k] = make_double2(col[2 * k], col[2 * k + 1]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int q = 0; q < G / 2; ++q) {
+    const int e = q * 2 * G + 2 * j;
+    *reinterpret_cast<double2 *>(row + e) = *reinterpret_cast<const double2 *>(tile + s * G * G + e);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+template <int G>
+__device__ __forceinline__ void s_row_fetch(double2 (&raw)[G / 2 > 0 ? G / 2 : 1], int lane, const double *row) {
+  const int j = lane % G;
+#pragma unroll
+  for (int q = 0; q < G / 2; ++q) raw[q] = *reinterpret_cast<const double2 *>(row + q * 2 * G + 2 * j);
+}
+template <int G>
+__device__ __forceinline__ void s_row_unpack(double *tile, int lane, const double2 (&raw)[G / 2 > 0 ? G / 2 : 1],
+                                             double (&col)[G]) {
+  const int s = lane / G, j = lane % G;
+#pragma unroll
+  for (int q = 0; q < G / 2; ++q) *reinterpret_cast<double2 *>(tile + s * G * G + q * 2 * G + 2 * j) = raw[q];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const double2 *tr = reinterpret_cast<const double2 *>(tile + s * G * G + j * G);
+#pragma unroll
+  for (int k = 0; k < G / 2; ++k) { const double2 v = tr[k]; col[2 * k] = v.x; col[2 * k + 1] = v.y; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // =============================================================================
 // factor -- reference forward.hpp:69-135.
 //   d_0 = a_0, W_0 = V_0/d_0;  per n: S += d w^T w; S = diag(p) S [-> workspace];
@@ -44,11 +103,16 @@ template <int G>
 __global__ __launch_bounds__(kWave) void k_factor(int64_t B, int64_t N, int J, const double *t, int64_t t_bs,
                                                   const double *c, int64_t c_bs, const double *a, const double *U,
                                                   const double *V, double *d, double *W, double *S, int32_t *flag) {
+  __shared__ __attribute__((aligned(16))) double gs[3][kWave];
+  __shared__ __attribute__((aligned(16))) double stile[G >= 2 ? kWave * G : 2];
+  const int lane = threadIdx.x;
   const Lane L = lane_of<G>(B);
   const int j = L.j;
   const bool act = j < J;
   const bool st = L.valid && act, st0 = L.valid && j == 0;
   const int jj = act ? j : 0;
+  const bool tiled = (G >= 2) && (J == G) && S && (((uintptr_t)S) % 16 == 0);  // coalesced S rows
+  double *Srow = S ? S + L.b * N * J * J : nullptr;
   const double *tb = t + L.b * t_bs, *ab = a + L.b * N;
   const double *Ub = U + L.b * N * J + jj, *Vb = V + L.b * N * J + jj;
   double *db = d + L.b * N, *Wb = W + L.b * N * J + jj;
@@ -93,14 +157,22 @@ __global__ __launch_bounds__(kWave) void k_factor(int64_t B, int64_t N, int J, c
         tprev = tn;
         const double dw = dprev * w;
         double tau = 0.0;
+        double wA[G], pA[G], uA[G], sh[G];
+        lds_allgather<G>(gs[0], lane, w, wA);
+        lds_allgather<G>(gs[1], lane, p, pA);
+        lds_allgather<G>(gs[2], lane, u, uA);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-          const double wi = gget<G>(w, i), pi = gget<G>(p, i), ui = gget<G>(u, i);
+          const double wi = wA[i], pi = pA[i], ui = uA[i];
           double s = pi * fma(dw, wi, Sc[i]);
-          if (Sb && st && i < J) Sb[n * J * J + i] = s;  // S[n, i + J*j], half-scaled (forward.hpp:120)
+          sh[i] = s;  // S[n, i + J*j], half-scaled (forward.hpp:120)
+          if (Sb && !tiled && st && i < J) Sb[n * J * J + i] = s;
           s *= p;
           Sc[i] = s;
           tau = fma(ui, s, tau);
+        }
+        if constexpr (G >= 2) {
+          if (tiled) s_row_store<G>(stile, lane, sh, Srow + n * J * J);
         }
         const double dn = an - gsum<G>(tau * u);
         if (st0) db[n] = dn;
@@ -360,11 +432,18 @@ __global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int 
                                                       const double *__restrict__ bd, const double *__restrict__ bW,
                                                       double *bt, double *bc, double *ba, double *bU, double *bV,
                                                       int accumulate) {
+  __shared__ __attribute__((aligned(16))) double gs[5][kWave];
+  __shared__ __attribute__((aligned(16))) double stile[G >= 2 ? kWave * G : 2];
+  const int lane = threadIdx.x;
   const Lane L = lane_of<G>(B);
   const int j = L.j;
   const bool act = j < J;
   const bool st = L.valid && act, st0 = L.valid && j == 0;
   const int jj = act ? j : 0;
+  // (reading S through the LDS tile was measured slower here -- 13.9 vs 9.7 ms: with a 2-row ring the extra LDS
+  //  round trip lands on the critical path -- so the reverse kernel keeps the direct column loads)
+  const bool tiled = false;
+  const double *Srow = S + L.b * N * J * J;
   const double *tb = t + L.b * t_bs, *db = d + L.b * N, *bdb = bd + L.b * N;
   const double *Ub = U + L.b * N * J + jj, *Wb = W + L.b * N * J + jj, *bWb = bW + L.b * N * J + jj;
   const double *Sb = S + L.b * N * J * J + (int64_t)jj * J;
@@ -383,6 +462,7 @@ __global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int 
 
   constexpr int PFR = 2;
   double rtn[PFR], rtm[PFR], ru[PFR], rwn[PFR], rwm[PFR], rdm[PFR], rbdm[PFR], rbWm[PFR], rS[PFR][G];
+  double2 rawS[PFR][G / 2 > 0 ? G / 2 : 1];
   auto load_row = [&](int r, int64_t n) {
     const int64_t nc = (n >= 1) ? n : 1;
     rtn[r] = tb[nc]; rtm[r] = tb[nc - 1];
@@ -391,8 +471,12 @@ __global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int 
     rwm[r] = act ? Wb[(nc - 1) * J] : 0.0;
     rdm[r] = db[nc - 1]; rbdm[r] = bdb[nc - 1];
     rbWm[r] = act ? bWb[(nc - 1) * J] : 0.0;
+    if (tiled) {
+      if constexpr (G >= 2) s_row_fetch<G>(rawS[r], lane, Srow + nc * J * J);
+    } else {
 #pragma unroll
-    for (int i = 0; i < G; ++i) rS[r][i] = (act && i < J) ? Sb[nc * J * J + i] : 0.0;
+      for (int i = 0; i < G; ++i) rS[r][i] = (act && i < J) ? Sb[nc * J * J + i] : 0.0;
+    }
   };
   if (N > 1) {
 #pragma unroll
@@ -407,8 +491,12 @@ __global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int 
         const double dt = rtm[r] - rtn[r];
         const double u = ru[r], wn = rwn[r], wm = rwm[r], dm = rdm[r], bdm = rbdm[r], bWm = rbWm[r];
         double Sc[G];
+        if (tiled) {
+          if constexpr (G >= 2) s_row_unpack<G>(stile, lane, rawS[r], Sc);
+        } else {
 #pragma unroll
-        for (int i = 0; i < G; ++i) Sc[i] = rS[r][i];
+          for (int i = 0; i < G; ++i) Sc[i] = rS[r][i];
+        }
         load_row(r, n - PFR);
 
         const double p = exp(cj * dt);
@@ -419,9 +507,15 @@ __global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int 
         const double y = fma(ban, u, bVn);   // bV + ba U
         const double x = fma(ban, u, y);     // bV + 2 ba U
         double xs = 0.0, bpacc = 0.0;
+        double xA[G], uA[G], yA[G], pA[G], wA[G];
+        lds_allgather<G>(gs[0], lane, x, xA);
+        lds_allgather<G>(gs[1], lane, u, uA);
+        lds_allgather<G>(gs[2], lane, y, yA);
+        lds_allgather<G>(gs[3], lane, p, pA);
+        lds_allgather<G>(gs[4], lane, wm, wA);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-          const double xi = gget<G>(x, i), ui = gget<G>(u, i), yi = gget<G>(y, i);
+          const double xi = xA[i], ui = uA[i], yi = yA[i];
           xs = fma(xi, Sc[i], xs);
           M[i] -= fma(ui, y, yi * u);          // M -= U^T y + y^T U
           bpacc = fma(Sc[i], M[i], bpacc);     // diag(bS Sn + Sn^T bS)_j = sum_i Sn(i,j) M(i,j)
@@ -441,7 +535,7 @@ __global__ __launch_bounds__(kWave) void k_factor_rev(int64_t B, int64_t N, int 
         double q = 0.0;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-          const double pi = gget<G>(p, i), wi = gget<G>(wm, i);
+          const double pi = pA[i], wi = wA[i];
           M[i] *= pi * p;
           q = fma(wi, M[i], q);               // (w M)_j
         }

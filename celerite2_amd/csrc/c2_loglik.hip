@@ -19,9 +19,11 @@
 // Scalar all-reduces (d_n, z_n, ...) are DPP butterflies (gsum).  With 8192 series per GPU at J=8 the
 // launch is exactly one wavefront per SIMD, so HBM latency is hidden by an explicit register prefetch
 // ring (R rows ahead), not by occupancy.
+#include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
-#include "c2_common.hpp"
+#include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
 extern "C" int c2_loglik_grad_composite(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
@@ -32,104 +34,6 @@ extern "C" int c2_loglik_grad_composite(int64_t B, int64_t N, int64_t J, const d
 extern "C" size_t c2_loglik_grad_composite_workspace_bytes(int64_t B, int64_t N, int64_t J);
 
 namespace c2 {
-
-constexpr double kLog2Pi = 1.8378770664093454835606594728112;
-constexpr double kLn2 = 0.69314718055994530941723212145818;
-
-// 1/d for a well-scaled positive d: v_rcp_f64 seed + two Newton steps (full fp64 accuracy; the
-// denormal/overflow scaling of a general IEEE division is not needed for pivots of an SPD matrix).
-__device__ __forceinline__ double rcp_nr(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  double e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-d, r, 1.0);
-  r = fma(r, e, r);
-  return r;
-}
-
-// exp(x) for the decay factors p = exp(c (t_{n-1} - t_n)), x <= 0 in every valid call.
-// k = rint(x log2 e), r = x - k ln2 (two-term Cody-Waite), degree-11 near-minimax polynomial on
-// |r| <= ln2/2 (Chebyshev fit, exact-arithmetic error 4e-18, 1 ulp in double Horner), result scaled by
-// v_ldexp_f64 (which also flushes the underflow range to 0).  16 VALU instructions.
-// q*r + c with the constant forced into an SGPR pair (VOP3 v_fma_f64 takes one scalar operand).  Left to
-// itself hipcc keeps the eleven coefficients in VGPRs and emits v_mov_b64 + v_fmac_f64 per Horner step.
-__device__ __forceinline__ double fma_sconst(double q, double r, double c) {
-  double o;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(q), "v"(r), "s"(c));
-  return o;
-}
-__device__ __forceinline__ double exp_decay(double x) {
-  x = fmax(x, -1000.0);
-  const double k = rint(x * 1.4426950408889634074);
-  double r = fma(k, -6.93147180369123816490e-01, x);
-  r = fma(k, -1.90821492927058770002e-10, r);
-  double q = fma_sconst(2.51100492048186583e-08, r, 2.76326547225277896e-07);
-  q = fma_sconst(q, r, 2.75572408872298695e-06);
-  q = fma_sconst(q, r, 2.48014854415613131e-05);
-  q = fma_sconst(q, r, 1.98412698900764028e-04);
-  q = fma_sconst(q, r, 1.38888889523528631e-03);
-  q = fma_sconst(q, r, 8.33333333331958900e-03);
-  q = fma_sconst(q, r, 4.16666666664879531e-02);
-  q = fma_sconst(q, r, 1.66666666666666796e-01);
-  q = fma_sconst(q, r, 5.00000000000001887e-01);
-  q = fma(q, r, 1.0);
-  q = fma(q, r, 1.0);
-  return ldexp(q, (int)k);
-}
-
-__device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
-
-// -----------------------------------------------------------------------------------------------
-// XOR-ordered group gathers.  Every width-J object a lane keeps in registers is stored in XOR order:
-// slot k of lane j holds element (j ^ k), so that a gathered vector x becomes xX[k] = x[j ^ k] and all
-// contractions sum_i a_i B(i,j) read sum_k aX[k] BX[k].  Two ways to gather:
-//   xgather_dpp : on the VALU with DPP lane permutes (7 permutes of a double at G=8) -- low latency, used
-//                 for the ONE vector per step that sits on the recursion's critical path;
-//   xgather_lds : through LDS (lane j reads slot[(lane ^ k)], G conflict-free ds_read_b64) -- free for
-//                 the VALU, used for vectors known ahead of time (p, U_n, saved W_{n-1}).
-// -----------------------------------------------------------------------------------------------
-constexpr int kDppXor3 = 0x1B;  // quad_perm [3,2,1,0]
-
-template <int G>
-__device__ __forceinline__ void xgather_lds(const double *slot, int lane, double (&out)[G]) {
-#pragma unroll
-  for (int k = 0; k < G; ++k) out[k] = slot[lane ^ k];
-}
-
-template <int G>
-__device__ __forceinline__ void xgather_dpp(double x, double *xslot, int lane, double (&out)[G]) {
-  out[0] = x;
-  if constexpr (G == 2) {
-    out[1] = dpp_mov<kDppXor1>(x);
-  } else if constexpr (G == 4 || G == 8 || G == 16) {
-    out[1] = dpp_mov<kDppXor1>(x);
-    out[2] = dpp_mov<kDppXor2>(x);
-    out[3] = dpp_mov<kDppXor3>(x);
-    if constexpr (G >= 8) {
-      const double y = dpp_mov<kDppHalfMirror>(x);  // lane l <- l ^ 7
-      out[7] = y;
-      out[6] = dpp_mov<kDppXor1>(y);
-      out[5] = dpp_mov<kDppXor2>(y);
-      out[4] = dpp_mov<kDppXor3>(y);
-    }
-    if constexpr (G == 16) {
-      const double z = dpp_mov<kDppMirror>(x);      // lane l <- l ^ 15
-      out[15] = z;
-      out[14] = dpp_mov<kDppXor1>(z);
-      out[13] = dpp_mov<kDppXor2>(z);
-      out[12] = dpp_mov<kDppXor3>(z);
-      const double zy = dpp_mov<kDppHalfMirror>(z);  // lane l <- l ^ 8
-      out[8] = zy;
-      out[9] = dpp_mov<kDppXor1>(zy);
-      out[10] = dpp_mov<kDppXor2>(zy);
-      out[11] = dpp_mov<kDppXor3>(zy);
-    }
-  } else if constexpr (G == 32) {  // crosses DPP rows: go through LDS
-    xslot[lane] = x;
-    lds_order();
-    xgather_lds<G>(xslot, lane, out);
-  }
-}
 
 // Checkpoint record of one lane: SX[0..G-1] (column j, XOR order), F_j, w_j, d, z  -> G+4 doubles.
 template <int G>
@@ -167,30 +71,6 @@ __device__ __forceinline__ void fwd_chain(double p, double u, double v, double a
   d = dn;
   z = zn;
 }
-
-// Lane geometry shared by the forward and reverse kernels: wave-uniform bases + small per-lane offsets,
-// so that global addresses are (SGPR base) + (VGPR offset) + (immediate) and cost no VALU per load.
-template <int G>
-struct Geo {
-  int lane, j, jj;
-  bool valid, act;
-  int64_t b0;     // first series of this wavefront (uniform)
-  int64_t b;      // this lane's series (clamped)
-  int sl;         // series index inside the wavefront (clamped)
-  __device__ __forceinline__ Geo(int64_t B, int J) {
-    constexpr int SPW = kWave / G;
-    lane = threadIdx.x;
-    j = lane & (G - 1);
-    b0 = (int64_t)blockIdx.x * SPW;
-    sl = lane / G;
-    const int64_t maxsl = B - 1 - b0;
-    valid = sl <= maxsl;
-    if (!valid) sl = (int)maxsl;
-    b = b0 + sl;
-    act = j < J;
-    jj = act ? j : 0;
-  }
-};
 
 // =============================================================================
 // Forward pass.  R = prefetch ring length (rows), C = checkpoint interval (R % C == 0).
@@ -705,6 +585,9 @@ using namespace c2;
 #ifndef C2_CKPT_C
 #define C2_CKPT_C 8   // checkpoint interval for G <= 8
 #endif
+#ifndef C2_LANES4_MIN_BATCH
+#define C2_LANES4_MIN_BATCH 16384   // forward-only two-columns-per-lane variant from this batch size up
+#endif
 #ifndef C2_FWD_R
 #define C2_FWD_R C2_CKPT_C   // prefetch ring length (rows); multiple of the checkpoint interval
 #endif
@@ -740,6 +623,30 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
 }
 }  // namespace
 
+// Two-columns-per-lane variant for J == 8 (c2_loglik4.hip).
+extern "C" size_t c2_internal_loglik4_workspace_doubles(int64_t B, int64_t N, size_t *ck_doubles);
+extern "C" int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                   const double *a, const double *U, const double *V, const double *y, double *ll,
+                                   int32_t *flag, c2_stream_t stream);
+extern "C" int c2_internal_loglik4_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,
+                                        int64_t c_bs, const double *a, const double *U, const double *V,
+                                        const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
+                                        double *bV, double *by, int32_t *flag, void *work, c2_stream_t stream);
+
+// Which lane mapping serves (B, J)?  The two-columns-per-lane kernels carry 16 series per wavefront, so they need
+// twice the batch to fill the chip.  Measured on MI355X at N = 4096 (profiles/r01_lanes4.md): the forward-only
+// kernel is 14-15 % faster from B = 16384 up and equal at 8192; the gradient pair is slower (its forward pass is
+// bound by the larger checkpoint stream), so it is only taken when forced.  C2_LANES=4 / C2_LANES=8 force one or
+// the other (tests, benchmarks).
+static bool use_lanes4(int64_t B, int64_t J, bool grad) {
+  if (J != 8) return false;
+  const char *e = getenv("C2_LANES");  // read per call: tests switch it at run time
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 4) return true;
+  if (forced == 8) return false;
+  return !grad && B >= C2_LANES4_MIN_BATCH;
+}
+
 extern "C" {
 
 int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
@@ -748,6 +655,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
+  if (use_lanes4(B, J, false)) return c2_internal_loglik4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
                            (hipStream_t)stream);
 }
@@ -784,7 +692,9 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
 
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
-  return grad_ws(B, N, J).total * sizeof(double);
+  size_t n = grad_ws(B, N, J).total;
+  if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
+  return n * sizeof(double);
 }
 
 int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
@@ -796,6 +706,8 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   if (!t || !c || !a || !U || !V || !y || !ll || !bt || !bc || !ba || !bU || !bV || !by || !flag || !work)
     return C2_ERR_INVALID;
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
+  if (use_lanes4(B, J, true))
+    return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;

@@ -1,0 +1,576 @@
+// c2_loglik4.hip -- the fused log-likelihood / gradient kernels with TWO columns per lane.
+//
+// Same algorithm, records and checkpoint/replay structure as c2_loglik.hip, different lane mapping: a series of
+// width J = 2*LG is walked by LG lanes, lane jl owning columns 2jl and 2jl+1 of the J x J state, so a wavefront
+// carries 64/LG series (16 at J = 8 instead of 8).  Per series this halves everything that c2_loglik.hip
+// replicates or pays per lane group -- the scalar chain (reductions, reciprocal), the cross-lane traffic (a
+// quad_perm-only gather of 2 doubles from 3 partners instead of 7, two butterfly levels instead of three), the
+// LDS gathers (one ds_read_b128 per partner) -- at the price of twice the per-series register/LDS footprint per
+// wavefront, hence a checkpoint interval of 4 instead of 8.  It needs >= 1024 * 64/LG series to fill the chip
+// (16384 at J = 8), so it is the large-batch variant; c2_loglik.hip stays the small-batch one.
+//
+// Conventions (XOR order over the lane index): slot q = 2k + e of a gathered vector is element 2(jl^k) + e;
+// SX[m][q] = S(2(jl^k)+e, 2jl+m).
+#include <type_traits>
+
+#include "c2_loglik_helpers.hpp"
+#include "../../include/celerite2_amd.h"
+
+namespace c2 {
+
+// XOR gather of a pair vector from an LDS slot (one double2 per lane): LG ds_read_b128.
+template <int LG>
+__device__ __forceinline__ void xgather2_lds(const double2 *slot, int lane, double (&out)[2 * LG]) {
+#pragma unroll
+  for (int k = 0; k < LG; ++k) {
+    const double2 v = slot[lane ^ k];
+    out[2 * k] = v.x;
+    out[2 * k + 1] = v.y;
+  }
+}
+// ... and on the VALU with DPP (the one chain-critical gather per step)
+template <int LG>
+__device__ __forceinline__ void xgather2_dpp(double x0, double x1, double (&out)[2 * LG]) {
+  double a[LG], b[LG];
+  xgather_dpp<LG>(x0, nullptr, 0, a);
+  xgather_dpp<LG>(x1, nullptr, 0, b);
+#pragma unroll
+  for (int k = 0; k < LG; ++k) { out[2 * k] = a[k]; out[2 * k + 1] = b[k]; }
+}
+
+// Symmetric-packed storage of the 2-columns-per-lane state.  For k >= 1 the 2x2 block (e, m) -> S(2(jl^k)+e, 2jl+m)
+// of lane jl is the transpose of the block of lane jl^k, so only the lane whose bit hb(k) is clear stores it (at
+// position e*2+m) and its partner reads it with e and m exchanged.  The diagonal block (k = 0) is stored by everyone.
+template <int LG>
+struct SymPack2 {
+  static constexpr int PER_REC = kWave * 4 + (LG - 1) * (kWave / 2) * 4;  // doubles per wavefront and record
+  // Offsets in double2 units.  Component-major: the (e=0) halves of all lanes are contiguous, then the (e=1) halves,
+  // so every 16-byte access of a wavefront is one dense run (LDS: conflict-free, HBM: whole sectors).
+  static __device__ __forceinline__ int off(int l, int k) {
+    if (k == 0) return l;
+    const int b = 31 - __builtin_clz(k), hb = 1 << b;
+    const int o = (l & hb) ? (l ^ k) : l;
+    const int idx = ((o >> (b + 1)) << b) | (o & (hb - 1));
+    return 2 * kWave + (k - 1) * kWave + idx;
+  }
+  static __device__ __forceinline__ constexpr int half(int k) { return k == 0 ? kWave : kWave / 2; }
+  template <typename P>
+  static __device__ __forceinline__ void store(P *rec, int lane, const int (&boff)[LG], const double (&SX)[2][2 * LG]) {
+    const int jl = lane & (LG - 1);
+    double2 *r = reinterpret_cast<double2 *>(rec);
+    r[boff[0]] = make_double2(SX[0][0], SX[1][0]);            // (e=0: m=0,1)
+    r[boff[0] + half(0)] = make_double2(SX[0][1], SX[1][1]);  // (e=1: m=0,1)
+#pragma unroll
+    for (int b = 0; (1 << b) < LG; ++b) {
+      if ((jl & (1 << b)) == 0) {
+#pragma unroll
+        for (int k = (1 << b); k < (2 << b); ++k) {
+          r[boff[k]] = make_double2(SX[0][2 * k], SX[1][2 * k]);
+          r[boff[k] + half(k)] = make_double2(SX[0][2 * k + 1], SX[1][2 * k + 1]);
+        }
+      }
+    }
+  }
+  template <typename P>
+  static __device__ __forceinline__ void load(const P *rec, int lane, const int (&boff)[LG], double (&SX)[2][2 * LG]) {
+    const int jl = lane & (LG - 1);
+    const double2 *r = reinterpret_cast<const double2 *>(rec);
+#pragma unroll
+    for (int k = 0; k < LG; ++k) {
+      const double2 r0 = r[boff[k]], r1 = r[boff[k] + half(k)];  // owner's (e=0: m=0,1), (e=1: m=0,1)
+      const int hbk = (k == 0) ? 0 : (1 << (31 - __builtin_clz(k)));
+      const bool partner = (jl & hbk) != 0;  // read the owner's block transposed
+      SX[0][2 * k] = r0.x;
+      SX[1][2 * k + 1] = r1.y;
+      SX[1][2 * k] = partner ? r1.x : r0.y;      // (e=0, m=1) <- owner's (e=1, m=0) when transposed
+      SX[0][2 * k + 1] = partner ? r0.y : r1.x;  // (e=1, m=0) <- owner's (e=0, m=1)
+    }
+  }
+};
+template <int LG>
+struct CkptRec2 {
+  static constexpr int DOUBLES = SymPack2<LG>::PER_REC + 2 * kWave;  // + F[2] per lane
+};
+
+// The chain part of one forward step, two columns per lane.
+template <int LG>
+__device__ __forceinline__ void fwd_chain2(const double (&p)[2], const double (&u)[2], const double (&v)[2], double an,
+                                           double yn, const double (&pX)[2 * LG], const double (&uX)[2 * LG],
+                                           double (&SX)[2][2 * LG], double (&F)[2], double (&w)[2], double &d, double &z,
+                                           double &rd) {
+  constexpr int J = 2 * LG;
+  double wX[J];
+  xgather2_dpp<LG>(w[0], w[1], wX);
+  const double dw0 = d * w[0], dw1 = d * w[1];
+  double t0a = 0.0, t0b = 0.0, t1a = 0.0, t1b = 0.0;
+#pragma unroll
+  for (int q = 0; q < J; ++q) {
+    const double s0 = (pX[q] * p[0]) * fma(dw0, wX[q], SX[0][q]);
+    const double s1 = (pX[q] * p[1]) * fma(dw1, wX[q], SX[1][q]);
+    SX[0][q] = s0;
+    SX[1][q] = s1;
+    if (q & 1) { t0b = fma(uX[q], s0, t0b); t1b = fma(uX[q], s1, t1b); }
+    else { t0a = fma(uX[q], s0, t0a); t1a = fma(uX[q], s1, t1a); }
+  }
+  const double tau0 = t0a + t0b, tau1 = t1a + t1b;
+  F[0] = p[0] * fma(w[0], z, F[0]);
+  F[1] = p[1] * fma(w[1], z, F[1]);
+  double rd_ = fma(tau0, u[0], tau1 * u[1]), rz_ = fma(u[0], F[0], u[1] * F[1]);
+  gsum2<LG>(rd_, rz_);
+  const double dn = an - rd_, zn = yn - rz_;
+  rd = rcp_nr(dn);
+  w[0] = (v[0] - tau0) * rd;
+  w[1] = (v[1] - tau1) * rd;
+  d = dn;
+  z = zn;
+}
+
+// =============================================================================
+// Forward pass (MODE 0: log-likelihood only, MODE 1: + records for the reverse sweep).
+// =============================================================================
+template <int LG, int R, int C, int MODE>
+__global__ __launch_bounds__(kWave, 1) void k_loglik4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                                          const double *__restrict__ c, int64_t c_bs,
+                                                          const double *__restrict__ a, const double *__restrict__ U,
+                                                          const double *__restrict__ V, const double *__restrict__ y,
+                                                          double *__restrict__ ll, int32_t *__restrict__ flag,
+                                                          double *__restrict__ ckpt, int64_t nseg,
+                                                          double *__restrict__ Wst, double2 *__restrict__ DZst) {
+  constexpr bool CKPT = MODE == 1;
+  static_assert(!CKPT || R % C == 0, "block length must be a multiple of the checkpoint interval");
+  constexpr int J = 2 * LG, SPW = kWave / LG, NV = (R + LG - 1) / LG;
+  __shared__ __attribute__((aligned(16))) double2 xs2[2][kWave];
+  __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];
+  __shared__ __attribute__((aligned(16))) double2 sout[SPW][R];
+  const Geo<LG> L(B, LG);
+  const int lane = L.lane, jl = L.j, grp = lane / LG;
+  const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + 2 * jl;
+  const double *tb = t + L.b0 * t_bs + ot, *ab = a + L.b0 * N + on, *yb = y + L.b0 * N + on;
+  const double2 *Ub = reinterpret_cast<const double2 *>(U + L.b0 * N * J + oj);  // row stride LG double2
+  const double2 *Vb = reinterpret_cast<const double2 *>(V + L.b0 * N * J + oj);
+  const double cj[2] = {c[L.b * c_bs + 2 * jl], c[L.b * c_bs + 2 * jl + 1]};
+  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * nseg * CkptRec2<LG>::DOUBLES : nullptr;
+  double2 *wst = CKPT ? reinterpret_cast<double2 *>(Wst + L.b0 * N * J + oj) : nullptr;
+  double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
+  int boff[LG];
+#pragma unroll
+  for (int k = 0; k < LG; ++k) boff[k] = SymPack2<LG>::off(lane, k);
+
+  double SX[2][J];
+#pragma unroll
+  for (int q = 0; q < J; ++q) { SX[0][q] = 0.0; SX[1][q] = 0.0; }
+  double d = ab[0];
+  double rd = 1.0 / d;
+  const double2 v0 = Vb[0];
+  double w[2] = {v0.x * rd, v0.y * rd};
+  double z = yb[0];
+  double F[2] = {0.0, 0.0};
+  double prod = d;
+  int eacc = 0;
+  double quad = z * z * rd;
+  int32_t fl = 0;
+  if (CKPT) {
+    wst[0] = make_double2(w[0], w[1]);
+    dzst[0] = make_double2(d, z);
+  }
+
+  // transposed scalar streams (see c2_loglik.hip): registers hold block b+2, LDS blocks b and b+1
+  double vt[NV], va[NV], vy[NV];
+  auto vload = [&](int64_t nb) {
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      int64_t row = nb + m * LG + jl;
+      row = (row < N) ? row : N - 1;
+      vt[m] = tb[row]; va[m] = ab[row]; vy[m] = yb[row];
+    }
+  };
+  auto vstage = [&](int q) {
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * LG + jl;
+      if (LG * NV == R || idx < R) {
+        sin_[q][0][grp][idx] = vt[m]; sin_[q][1][grp][idx] = va[m]; sin_[q][2][grp][idx] = vy[m];
+      }
+    }
+  };
+  vload(1); vstage(0);
+  vload(1 + R); vstage(1);
+  vload(1 + 2 * R);
+
+  double2 ru[R], rv[R];
+  const double2 *up = Ub + LG, *vp = Vb + LG;  // row n0 of the current block
+  auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {
+    int64_t o = ahead;
+    if (clamp && n >= N) o -= n - (N - 1);
+    ru[r] = up[o * LG]; rv[r] = vp[o * LG];
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+
+  lds_order();
+  double tcur = tb[0];
+  double tnext = sin_[0][0][grp][0];
+  double pc[2] = {exp_decay(cj[0] * (tcur - tnext)), exp_decay(cj[1] * (tcur - tnext))};
+  double uc[2] = {ru[0].x, ru[0].y};
+  double pXc[J], uXc[J];
+  xs2[0][lane] = make_double2(pc[0], pc[1]);
+  xs2[1][lane] = ru[0];
+  lds_order();
+  xgather2_lds<LG>(xs2[0], lane, pXc);
+  xgather2_lds<LG>(xs2[1], lane, uXc);
+  lds_order();
+
+  auto block = [&](int64_t n0, int q, auto checked_tag) {
+    constexpr bool CHECKED = decltype(checked_tag)::value;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t n = n0 + r;
+      if (!CHECKED || n < N) {
+        if (CKPT && (r % C == 0)) {  // state after row n-1 = checkpoint (n-1)/C
+          double *rec = ckw + ((n - 1) / C) * CkptRec2<LG>::DOUBLES;
+          SymPack2<LG>::store(rec, lane, boff, SX);
+          reinterpret_cast<double2 *>(rec + SymPack2<LG>::PER_REC)[lane] = make_double2(F[0], F[1]);
+        }
+        const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r];
+        const double vv_[2] = {rv[r].x, rv[r].y};
+        const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
+        const int rn = (r + 1) % R;
+        const double pn1[2] = {exp_decay(cj[0] * (tn - tn1)), exp_decay(cj[1] * (tn - tn1))};
+        const double2 un1 = ru[rn];
+        xs2[0][lane] = make_double2(pn1[0], pn1[1]);
+        xs2[1][lane] = un1;
+        lds_order();
+        double pXn[J], uXn[J];
+        xgather2_lds<LG>(xs2[0], lane, pXn);
+        xgather2_lds<LG>(xs2[1], lane, uXn);
+        lds_order();
+        fwd_chain2<LG>(pc, uc, vv_, an, yn, pXc, uXc, SX, F, w, d, z, rd);
+        if (CKPT) {
+          wst[n * LG] = make_double2(w[0], w[1]);
+          sout[grp][r] = make_double2(d, z);
+        }
+        load_row(r, r + R, n + R, CHECKED);
+        fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
+        prod *= d;
+        quad = fma(z * z, rd, quad);
+        if (r % 8 == 7 || r == R - 1) {
+          int e;
+          prod = frexp(prod, &e);
+          eacc += e;
+        }
+        tnext = tn1;
+        pc[0] = pn1[0]; pc[1] = pn1[1]; uc[0] = un1.x; uc[1] = un1.y;
+#pragma unroll
+        for (int k = 0; k < J; ++k) { pXc[k] = pXn[k]; uXc[k] = uXn[k]; }
+      }
+    }
+    lds_order();
+    if (CKPT) {
+#pragma unroll
+      for (int m = 0; m < NV; ++m) {
+        const int idx = m * LG + jl;
+        if ((LG * NV == R || idx < R) && (!CHECKED || n0 + idx < N)) dzst[n0 + idx] = sout[grp][idx];
+      }
+    }
+    vstage(q);
+    vload(n0 + 3 * R);
+    lds_order();
+  };
+  int64_t n0 = 1;
+  int q = 0;
+  auto advance = [&]() { up += R * LG; vp += R * LG; q ^= 1; };
+  for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, std::false_type{}); advance(); }
+  for (; n0 < N; n0 += R) { block(n0, q, std::true_type{}); advance(); }
+
+  if (L.valid && jl == 0) {
+    flag[L.b] = fl;
+    int e;
+    prod = frexp(prod, &e);
+    const double logdet = log(prod) + (double)(eacc + e) * kLn2;
+    ll[L.b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
+  }
+}
+
+// =============================================================================
+// Reverse sweep with segment replay (see c2_loglik.hip for the derivation; identical steps, two columns per lane).
+// =============================================================================
+template <int LG, int C>
+__global__ __launch_bounds__(kWave, 1) void k_loglik4_rev(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                                          const double *__restrict__ c, int64_t c_bs,
+                                                          const double *__restrict__ U, const double *__restrict__ Wst,
+                                                          const double2 *__restrict__ DZst,
+                                                          const double *__restrict__ ckpt, int64_t nseg,
+                                                          const int32_t *__restrict__ flag, double *__restrict__ bt,
+                                                          double *__restrict__ bc, double *__restrict__ ba,
+                                                          double *__restrict__ bU, double *__restrict__ bV,
+                                                          double *__restrict__ by) {
+  constexpr int J = 2 * LG, SPW = kWave / LG, NV = (C + LG - 1) / LG;
+  __shared__ __attribute__((aligned(16))) double2 vv[C][3][kWave];  // [r][0] = p_n, [1] = U_n, [2] = W_{n-1}
+  __shared__ __attribute__((aligned(16))) double sfL[C][SymPack2<LG>::PER_REC];
+  __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
+  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[SPW][C], oBY[SPW][C];
+  const Geo<LG> L(B, LG);
+  const int lane = L.lane, jl = L.j, grp = lane / LG;
+  const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + 2 * jl;
+  const double *tb = t + L.b0 * t_bs + ot;
+  const double2 *Ub = reinterpret_cast<const double2 *>(U + L.b0 * N * J + oj);
+  const double2 *Wb = reinterpret_cast<const double2 *>(Wst + L.b0 * N * J + oj);
+  const double2 *dzb = DZst + L.b0 * N + on;
+  const double *ckw = ckpt + (size_t)blockIdx.x * nseg * CkptRec2<LG>::DOUBLES;
+  double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
+  double2 *bUb = reinterpret_cast<double2 *>(bU + L.b0 * N * J + oj);
+  double2 *bVb = reinterpret_cast<double2 *>(bV + L.b0 * N * J + oj);
+  const double cj[2] = {c[L.b * c_bs + 2 * jl], c[L.b * c_bs + 2 * jl + 1]};
+  if (flag[L.b] != 0) return;
+
+  int boff[LG];
+#pragma unroll
+  for (int k = 0; k < LG; ++k) boff[k] = SymPack2<LG>::off(lane, k);
+
+  double MX[2][J];
+#pragma unroll
+  for (int q = 0; q < J; ++q) { MX[0][q] = 0.0; MX[1][q] = 0.0; }
+  double bF[2] = {0.0, 0.0}, bcj[2] = {0.0, 0.0}, bVn[2] = {0.0, 0.0};
+  double carry = 0.0, ban = 0.0, bzn = 0.0;
+
+  double vt[NV];
+  double vd[NV], vz[NV];
+  double iu[C][2], iw[C][2];  // plain doubles: arrays of double2 end up in scratch
+  double cS[2][J], cF[2];
+  auto load_segment = [&](int64_t k) {
+    const int64_t n_lo = 1 + k * C;
+    const bool full = n_lo + C <= N;
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      int64_t row = n_lo - 1 + m * LG + jl;
+      row = (row < N) ? row : N - 1;
+      vt[m] = tb[row];
+      const double2 dz = dzb[row];
+      vd[m] = dz.x; vz[m] = dz.y;
+    }
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+      const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
+      const double2 u2 = Ub[n * LG], w2 = Wb[(n - 1) * LG];
+      iu[r][0] = u2.x; iu[r][1] = u2.y; iw[r][0] = w2.x; iw[r][1] = w2.y;
+    }
+    const double *rec = ckw + k * CkptRec2<LG>::DOUBLES;
+    SymPack2<LG>::load(rec, lane, boff, cS);
+    const double2 f2 = reinterpret_cast<const double2 *>(rec + SymPack2<LG>::PER_REC)[lane];
+    cF[0] = f2.x; cF[1] = f2.y;
+  };
+
+  double carT = tb[N - 1];
+  double2 carDZ = dzb[N - 1];
+  double carR = rcp_nr(carDZ.x);
+  if (nseg > 0) load_segment(nseg - 1);
+
+  for (int64_t k = nseg - 1; k >= 0; --k) {
+    const int64_t n_lo = 1 + k * C;
+    const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
+
+    // ---- phase A ----
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * LG + jl;
+      if (LG * NV == C || idx < C) {
+        rowT[idx][grp] = vt[m]; rowD[idx][grp] = vd[m]; rowR[idx][grp] = rcp_nr(vd[m]); rowZ[idx][grp] = vz[m];
+      }
+    }
+    lds_order();
+    rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
+    lds_order();
+    double dtv[C];
+    {
+      double tprev = rowT[0][grp];
+#pragma unroll
+      for (int r = 0; r < C; ++r) {
+        const double tn = rowT[r + 1][grp];
+        dtv[r] = tprev - tn;
+        tprev = tn;
+        vv[r][0][lane] = make_double2(exp_decay(cj[0] * dtv[r]), exp_decay(cj[1] * dtv[r]));
+        vv[r][1][lane] = make_double2(iu[r][0], iu[r][1]);
+        vv[r][2][lane] = make_double2(iw[r][0], iw[r][1]);
+      }
+    }
+    // ---- phase B: chain-free replay ----
+    double SX[2][J];
+#pragma unroll
+    for (int q = 0; q < J; ++q) { SX[0][q] = cS[0][q]; SX[1][q] = cS[1][q]; }
+    double F[2] = {cF[0], cF[1]};
+    double Fp[C][2], tauS[C][2];
+    lds_order();
+    if (k > 0) load_segment(k - 1);  // a whole segment of work ahead of its use
+#pragma unroll
+    for (int r = 0; r < C; ++r) {
+      if (r < cnt) {
+        double pX[J], uX[J], wX[J];
+        xgather2_lds<LG>(vv[r][0], lane, pX);
+        xgather2_lds<LG>(vv[r][1], lane, uX);
+        xgather2_lds<LG>(vv[r][2], lane, wX);
+        const double dprev = rowD[r][grp], zprev = rowZ[r][grp];
+        const double dw0 = dprev * wX[0], dw1 = dprev * wX[1];
+        double t0a = 0.0, t0b = 0.0, t1a = 0.0, t1b = 0.0;
+#pragma unroll
+        for (int q = 0; q < J; ++q) {
+          const double s0 = (pX[q] * pX[0]) * fma(dw0, wX[q], SX[0][q]);
+          const double s1 = (pX[q] * pX[1]) * fma(dw1, wX[q], SX[1][q]);
+          SX[0][q] = s0;
+          SX[1][q] = s1;
+          if (q & 1) { t0b = fma(uX[q], s0, t0b); t1b = fma(uX[q], s1, t1b); }
+          else { t0a = fma(uX[q], s0, t0a); t1a = fma(uX[q], s1, t1a); }
+        }
+        tauS[r][0] = t0a + t0b; tauS[r][1] = t1a + t1b;
+        F[0] = pX[0] * fma(wX[0], zprev, F[0]);
+        F[1] = pX[1] * fma(wX[1], zprev, F[1]);
+        Fp[r][0] = F[0]; Fp[r][1] = F[1];
+        SymPack2<LG>::store(sfL[r], lane, boff, SX);
+      }
+    }
+    if (k == nseg - 1) {
+      const double rd = rowR[cnt][grp], z = rowZ[cnt][grp];
+      ban = 0.5 * rd * (z * z * rd - 1.0);
+      bzn = -z * rd;
+      bVn[0] = 0.0; bVn[1] = 0.0;
+      byb[N - 1] = bzn;
+    }
+    carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
+    lds_order();
+
+    // ---- phase C: fused reverse steps ----
+#pragma unroll
+    for (int r = C - 1; r >= 0; --r) {
+      if (r < cnt) {
+        const int64_t n = n_lo + r;
+        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
+        double uX[J], pX[J], wX[J], bVX[J], Sf[2][J];
+        xgather2_lds<LG>(vv[r][1], lane, uX);
+        xgather2_lds<LG>(vv[r][0], lane, pX);
+        xgather2_lds<LG>(vv[r][2], lane, wX);
+        SymPack2<LG>::load(sfL[r], lane, boff, Sf);
+        const double p[2] = {pX[0], pX[1]}, u[2] = {uX[0], uX[1]}, wm[2] = {wX[0], wX[1]};
+        oBA[grp][r] = ban;
+        bVb[n * LG] = make_double2(bVn[0], bVn[1]);
+        xgather2_dpp<LG>(bVn[0], bVn[1], bVX);
+        double bUo[2], bpt[2], qv[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const double bU1 = -bzn * Fp[r][m];
+          bF[m] = fma(-u[m], bzn, bF[m]);
+          const double bp_s = Fp[r][m] * bF[m];
+          bF[m] *= p[m];
+          const double xv = fma(2.0 * ban, u[m], bVn[m]);
+          double xs0 = 0.0, xs1 = 0.0, bp0 = 0.0, bp1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < J; ++q) {
+            double mm = fma(-uX[q], xv, MX[m][q]);
+            mm = fma(-bVX[q], u[m], mm);
+            MX[m][q] = mm;
+            if (q & 1) { xs1 = fma(bVX[q], Sf[m][q], xs1); bp1 = fma(Sf[m][q], mm, bp1); }
+            else { xs0 = fma(bVX[q], Sf[m][q], xs0); bp0 = fma(Sf[m][q], mm, bp0); }
+          }
+          xs0 = fma(2.0 * ban, tauS[r][m], xs0);
+          bUo[m] = bU1 - (xs0 + xs1);
+          bpt[m] = bp_s + (bp0 + bp1);
+          bcj[m] = fma(dt, bpt[m], bcj[m]);
+          double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+          for (int q = 0; q < J; ++q) {
+            MX[m][q] *= pX[q] * p[m];
+            if (q & 1) q1 = fma(wX[q], MX[m][q], q1);
+            else q0 = fma(wX[q], MX[m][q], q0);
+          }
+          qv[m] = q0 + q1;
+        }
+        bUb[n * LG] = make_double2(bUo[0], bUo[1]);
+        double f = fma(cj[0], bpt[0], cj[1] * bpt[1]), Gs = fma(wm[0], bF[0], wm[1] * bF[1]),
+               Q = fma(qv[0], wm[0], qv[1] * wm[1]);
+        gsum3<LG>(f, Gs, Q);
+        oBT[grp][r] = carry - f;
+        carry = f;
+        const double zr = zm * rdm;
+        bzn = Gs - zr;
+        oBY[grp][r] = bzn;
+        bVn[0] = fma(zr, bF[0], qv[0]);
+        bVn[1] = fma(zr, bF[1], qv[1]);
+        ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+      }
+    }
+    lds_order();
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * LG + jl;
+      if ((LG * NV == C || idx < C) && idx < cnt) {
+        bab[n_lo + idx] = oBA[grp][idx];
+        btb[n_lo + idx] = oBT[grp][idx];
+        byb[n_lo - 1 + idx] = oBY[grp][idx];
+      }
+    }
+    lds_order();
+  }
+  if (nseg == 0) {  // N == 1
+    const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;
+    ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);
+    bzn = -cz * rd0;
+    byb[0] = bzn;
+  }
+  bab[0] = ban; btb[0] = carry;
+  bVb[0] = make_double2(bVn[0], bVn[1]);
+  bUb[0] = make_double2(0.0, 0.0);
+  reinterpret_cast<double2 *>(bc + L.b * J)[jl] = make_double2(bcj[0], bcj[1]);
+}
+
+}  // namespace c2
+
+using namespace c2;
+
+namespace {
+inline int launch_ok4() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP; }
+constexpr int kC4 = 4;  // checkpoint interval of the two-columns-per-lane variant
+}  // namespace
+
+extern "C" {
+
+// J == 8 only (LG = 4).  Workspace layout: [checkpoints][W rows][(d,z) pairs].
+size_t c2_internal_loglik4_workspace_doubles(int64_t B, int64_t N, size_t *ck_doubles) {
+  constexpr int LG = 4, J = 8;
+  const int64_t nseg = (N - 1 + kC4 - 1) / kC4;
+  const size_t waves = ((size_t)B * LG + kWave - 1) / kWave;
+  size_t ck = waves * (size_t)nseg * CkptRec2<LG>::DOUBLES;
+  ck = (ck + 1) & ~(size_t)1;
+  if (ck_doubles) *ck_doubles = ck;
+  return ck + (size_t)B * N * J + (size_t)B * N * 2;
+}
+
+int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                        const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+                        c2_stream_t stream) {
+  constexpr int LG = 4;
+  const dim3 grid((unsigned)((B * LG + kWave - 1) / kWave));
+  hipLaunchKernelGGL((k_loglik4_fwd<LG, 8, kC4, 0>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a,
+                     U, V, y, ll, flag, nullptr, 0, nullptr, nullptr);
+  return launch_ok4();
+}
+
+int c2_internal_loglik4_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                             const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
+                             double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
+                             c2_stream_t stream) {
+  constexpr int LG = 4, J = 8;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nseg = (N - 1 + kC4 - 1) / kC4;
+  size_t ck = 0;
+  (void)c2_internal_loglik4_workspace_doubles(B, N, &ck);
+  double *ckpt = (double *)work;
+  double *Wst = ckpt + ck;
+  double2 *DZst = reinterpret_cast<double2 *>(Wst + (size_t)B * N * J);
+  const dim3 grid((unsigned)((B * LG + kWave - 1) / kWave));
+  hipLaunchKernelGGL((k_loglik4_fwd<LG, 8, kC4, 1>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll,
+                     flag, ckpt, nseg, Wst, DZst);
+  if (int e = launch_ok4()) return e;
+  hipLaunchKernelGGL((k_loglik4_rev<LG, kC4>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, (const double *)Wst,
+                     (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);
+  return launch_ok4();
+}
+
+}  // extern "C"

@@ -136,6 +136,48 @@ def test_loglik_and_grad_vs_oracle(ops, oracle, J):
         close(g, e)
 
 
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 2), (17, 5), (16, 9), (33, 300), (70, 1031)])
+def test_two_columns_per_lane_variant(ops, oracle, monkeypatch, B, N):
+    """J = 8 has a second lane mapping (c2_loglik4.hip, 4 lanes x 2 columns per series, checkpoint interval 4):
+    same results as the oracle, incl. shared t/c, ragged last wavefront and non-positive-definite flags."""
+    monkeypatch.setenv("C2_LANES", "4")
+    J = 8
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    close(ll, llo)
+    ll2, grads, flag2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    close(ll2, llo)
+    for g, e in zip(grads, go):
+        close(g, e)
+    # against the one-column-per-lane kernels on the same inputs
+    monkeypatch.setenv("C2_LANES", "8")
+    ll8, grads8, _ = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    close(ll2, ll8.cpu().numpy())
+    for g, e in zip(grads, grads8):
+        close(g, e.cpu().numpy(), 1e-9)
+    monkeypatch.setenv("C2_LANES", "4")
+    if N > 2 and B > 2:
+        a2 = a.copy(); a2[1, N // 2] = -5.0
+        (a2d,) = dev(a2)
+        ll3, grads3, flag3 = ops.loglik_grad(td, cd, a2d, Ud, Vd, yd)
+        assert int(flag3[1]) == N // 2 and int(flag3[0]) == 0 and np.isneginf(float(ll3[1]))
+        close(ll3[0:1], llo[0:1])
+        close(grads3[2][0], go[2][0])
+    # shared time grid and decay rates
+    t0, c0 = t[0].copy(), c[0].copy()
+    t0d, c0d = dev(t0, c0)
+    ll4, flag4 = ops.loglik(t0d, c0d, ad, Ud, Vd, yd)
+    for b in range(min(B, 3)):
+        e, f = oracle.loglik(t0, c0, a[b], U[b], V[b], y[b])
+        if f == 0:
+            close(ll4[b:b + 1], np.array([e]))
+        else:
+            assert int(flag4[b]) == f
+
+
 def test_loglik_grad_golden(ops, golden):
     x, c, a, U, V = (golden["py_" + k] for k in ("x", "c", "a", "U", "V"))
     y = np.ascontiguousarray(golden["py_Y"][:, 0])

@@ -16,6 +16,13 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+#ifndef C2_FWD4_R0
+#define C2_FWD4_R0 8
+#endif
+#ifndef C2_FWD4_OCC
+#define C2_FWD4_OCC 1
+#endif
+
 namespace c2 {
 
 // XOR gather of a pair vector from an LDS slot (one double2 per lane): LG ds_read_b128.
@@ -129,7 +136,7 @@ __device__ __forceinline__ void fwd_chain2(const double (&p)[2], const double (&
 // Forward pass (MODE 0: log-likelihood only, MODE 1: + records for the reverse sweep).
 // =============================================================================
 template <int LG, int R, int C, int MODE>
-__global__ __launch_bounds__(kWave, 1) void k_loglik4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+__global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                           const double *__restrict__ c, int64_t c_bs,
                                                           const double *__restrict__ a, const double *__restrict__ U,
                                                           const double *__restrict__ V, const double *__restrict__ y,
@@ -547,7 +554,7 @@ int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, con
                         c2_stream_t stream) {
   constexpr int LG = 4;
   const dim3 grid((unsigned)((B * LG + kWave - 1) / kWave));
-  hipLaunchKernelGGL((k_loglik4_fwd<LG, 8, kC4, 0>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a,
+  hipLaunchKernelGGL((k_loglik4_fwd<LG, C2_FWD4_R0, kC4, 0>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a,
                      U, V, y, ll, flag, nullptr, 0, nullptr, nullptr);
   return launch_ok4();
 }

@@ -642,6 +642,191 @@ __global__ __launch_bounds__(kWave) void k_general(int64_t B, int64_t N, int64_t
   }
 }
 
+// -----------------------------------------------------------------------------
+// general_matmul_* in two data-parallel phases.  The merge of forward.hpp:316-330 only decides WHICH state row an
+// output row reads: the state itself, F_m = p_m o F_{m-1} + V_m^T Y_m (lower; mirrored for upper), depends on the
+// t2 grid alone.  Phase 1 (k_gm_state) is a plain sweep over m that writes every visited F_m (the `F` output of the
+// backprop variant, or a stream-ordered temporary); phase 2 (k_gm_emit) is embarrassingly parallel over the output
+// rows: m(n) by binary search in t2, then Z_n += (U_n o exp(c dt)) F_{m(n)}.
+// -----------------------------------------------------------------------------
+// first index with t2[idx] > x (t2 sorted, length M)
+__device__ __forceinline__ int64_t upper_bound_t(const double *t2, int64_t M, double x) {
+  int64_t lo = 0, hi = M;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (t2[mid] <= x) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// The same search done by the G lanes of a group together: each round probes G interior points of [lo, hi), the
+// group's ballot tells between which two probes the answer lies ((G+1)-ary search: 5 rounds instead of 13 dependent
+// loads at M = 4096, G = 8).  x must be uniform inside the group; the result is uniform too.
+template <int G>
+__device__ __forceinline__ int64_t group_upper_bound_t(const double *t2, int64_t M, double x, int lane) {
+  if constexpr (G == 1) {
+    return upper_bound_t(t2, M, x);
+  } else {
+    const int jg = lane & (G - 1), shift = lane & ~(G - 1);
+    int64_t lo = 0, hi = M;
+    while (lo < hi) {
+      const int64_t width = hi - lo;
+      const int64_t pos = lo + ((int64_t)(jg + 1) * width) / (G + 1);
+      const bool le = t2[pos] <= x;
+      const unsigned long long mask = __ballot(le);
+      const int cnt = __popcll((mask >> shift) & ((1ull << G) - 1ull));  // probes are sorted: the first cnt are <= x
+      const int64_t below = lo + ((int64_t)cnt * width) / (G + 1);       // probe cnt-1
+      const int64_t above = lo + ((int64_t)(cnt + 1) * width) / (G + 1); // probe cnt
+      const int64_t nlo = (cnt > 0) ? below + 1 : lo;
+      const int64_t nhi = (cnt < G) ? above : hi;
+      lo = nlo;
+      hi = nhi;
+    }
+    return lo;
+  }
+}
+
+template <int G, int KT, bool LOWER>
+__global__ __launch_bounds__(kWave) void k_gm_state(int64_t B, int64_t N, int64_t M, int J, int64_t nrhs,
+                                                    const double *__restrict__ t1, int64_t t1_bs,
+                                                    const double *__restrict__ t2, int64_t t2_bs,
+                                                    const double *__restrict__ c, int64_t c_bs,
+                                                    const double *__restrict__ V, const double *__restrict__ Y,
+                                                    double *__restrict__ F) {
+  constexpr int PFG = 8;
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const bool act = j < J;
+  const bool st = L.valid && act;
+  const int jj = act ? j : 0;
+  const int64_t k0 = (int64_t)blockIdx.y * KT;
+  const int kn = (nrhs - k0 < KT) ? (int)(nrhs - k0) : KT;
+  const double *t1b = t1 + L.b * t1_bs, *t2b = t2 + L.b * t2_bs;
+  const double *Vb = V + L.b * M * J + jj;
+  const double *Yb = Y + L.b * M * nrhs + k0;
+  double *Fb = F + L.b * M * J * nrhs + (int64_t)jj * nrhs + k0;  // row-major F[m, j*nrhs + k] (forward.hpp:300)
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+
+  // rows the reference's merge visits: lower 0..m_hi, upper m_lo..M-2 (plus the zeroed row 0)
+  int64_t nsteps;  // number of absorb steps after the initial row
+  if (LOWER) {
+    const int64_t ub = upper_bound_t(t2b, M, t1b[N - 1]);  // rows with t2 <= t1[N-1]
+    nsteps = (ub >= 1) ? ub - 1 : 0;
+  } else {
+    const int64_t ub = upper_bound_t(t2b, M, t1b[0]);  // first row with t2 > t1[0]
+    nsteps = (ub <= M - 2) ? (M - 1 - ub) : 0;
+  }
+  const int64_t m0 = LOWER ? 0 : M - 1;
+  const bool vec2 = (nrhs % 2 == 0) && kn == KT;
+  double Fm[KT];
+  {
+    const double v0 = act ? Vb[m0 * J] : 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) Fm[k] = (k < kn) ? v0 * Yb[m0 * nrhs + k] : 0.0;
+  }
+  if (st) {
+    // F.row(0).setZero() in both variants (forward.hpp:297, 358); the lower variant then stores Fm into row 0
+    // (forward.hpp:313), the upper variant never stores row M-1.
+    for (int k = 0; k < kn; ++k) Fb[k] = LOWER ? Fm[k] : 0.0;
+  }
+  double tprev = t2b[m0];
+  double rt[PFG], rv[PFG], ry[PFG][KT];
+  auto load_row = [&](int r, int64_t s) {  // s = 1 .. nsteps (clamped)
+    const int64_t sc = (s <= nsteps) ? s : (nsteps > 0 ? nsteps : 0);
+    const int64_t m = LOWER ? sc : M - 1 - sc;
+    rt[r] = t2b[m];
+    rv[r] = act ? Vb[m * J] : 0.0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) ry[r][k] = (k < kn) ? Yb[m * nrhs + k] : 0.0;
+  };
+#pragma unroll
+  for (int r = 0; r < PFG; ++r) load_row(r, 1 + r);
+  for (int64_t s0 = 1; s0 <= nsteps; s0 += PFG) {
+#pragma unroll
+    for (int r = 0; r < PFG; ++r) {
+      const int64_t s = s0 + r;
+      if (s <= nsteps) {
+        const int64_t m = LOWER ? s : M - 1 - s;
+        const double tm = rt[r], vm = rv[r];
+        double yk[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) yk[k] = ry[r][k];
+        load_row(r, s + PFG);
+        const double p = exp(cj * (LOWER ? tprev - tm : tm - tprev));
+        tprev = tm;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) Fm[k] = fma(vm, yk[k], p * Fm[k]);
+        if (st) {
+          double *Fr = Fb + m * J * nrhs;
+          if (KT % 2 == 0 && vec2) {  // 16-byte stores: the lane's KT entries are contiguous in the row-major state
+#pragma unroll
+            for (int k = 0; k < KT; k += 2) reinterpret_cast<double2 *>(Fr)[k / 2] = make_double2(Fm[k], Fm[k + 1]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+              if (k < kn) Fr[k] = Fm[k];
+          }
+        }
+      }
+    }
+  }
+}
+
+// One group of G lanes per output row (b, n); all right-hand sides in a loop.
+template <int G, bool LOWER>
+__global__ __launch_bounds__(kWave) void k_gm_emit(int64_t B, int64_t N, int64_t M, int J, int64_t nrhs,
+                                                   const double *__restrict__ t1, int64_t t1_bs,
+                                                   const double *__restrict__ t2, int64_t t2_bs,
+                                                   const double *__restrict__ c, int64_t c_bs,
+                                                   const double *__restrict__ U, const double *__restrict__ V,
+                                                   const double *__restrict__ Y, const double *__restrict__ F,
+                                                   double *__restrict__ Z) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t row = g / G;
+  const int j = (int)(g % G);
+  const bool valid = row < B * N;
+  if (!valid) row = B * N - 1;
+  const int64_t b = row / N, n = row % N;
+  const bool act = j < J;
+  const int jj = act ? j : 0;
+  const double *t2b = t2 + b * t2_bs;
+  const double tn = t1[b * t1_bs + n];
+  const int64_t ub = group_upper_bound_t<G>(t2b, M, tn, (int)(threadIdx.x & (kWave - 1)));
+  const int64_t m = LOWER ? ub - 1 : ub;       // state row this output reads
+  const bool hit = LOWER ? (m >= 0) : (m <= M - 1);  // uniform inside a group
+  const int64_t mc = hit ? m : 0;
+  const double dt = LOWER ? t2b[mc] - tn : tn - t2b[mc];
+  const double cj = act ? c[b * c_bs + j] : 0.0;
+  const double up = (act ? U[(b * N + n) * J + jj] : 0.0) * exp(cj * dt);
+  // the upper variant never stores its initial row M-1 (forward.hpp:358-375): rebuild it from V, Y
+  const bool rebuild = !LOWER && mc == M - 1;
+  const double vlast = (rebuild && act) ? V[(b * M + mc) * J + jj] : 0.0;
+  const double *Fr = F + ((b * M + mc) * J + jj) * nrhs;
+  const double *Yr = Y + (b * M + mc) * nrhs;
+  double *Zr = Z + (b * N + n) * nrhs;
+  int64_t k = 0;
+  if (nrhs % 2 == 0) {  // 16-byte loads of the state row
+    for (; k < nrhs; k += 2) {
+      double2 f = make_double2(0.0, 0.0);
+      if (rebuild) f = make_double2(vlast * Yr[k], vlast * Yr[k + 1]);
+      else if (act) f = *reinterpret_cast<const double2 *>(Fr + k);
+      double r0 = up * f.x, r1 = up * f.y;
+      gsum2<G>(r0, r1);
+      if (valid && hit && j == 0) {
+        double2 z = *reinterpret_cast<double2 *>(Zr + k);
+        z.x += r0; z.y += r1;
+        *reinterpret_cast<double2 *>(Zr + k) = z;
+      }
+    }
+  }
+  for (; k < nrhs; ++k) {
+    const double f = rebuild ? vlast * Yr[k] : (act ? Fr[k] : 0.0);
+    const double red = gsum<G>(up * f);
+    if (valid && hit && j == 0) Zr[k] += red;
+  }
+}
+
 // =============================================================================
 // get_celerite_matrices -- reference python/celerite2/driver.cpp:422-477.
 // One thread per (series, row).
@@ -719,6 +904,10 @@ extern "C" int c2_internal_matmul_chunked(int lower, int64_t B, int64_t N, int64
                                           const double *U, const double *V, const double *Y, double *Z, double *F,
                                           int zero_z, c2_stream_t stream);
 
+extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                  const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
+                                  double *Z, int zero_z, c2_stream_t stream);
+
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -738,6 +927,8 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
                                         stream);
     }
   }
+  if (nrhs == 1 && !F)  // a vector without the workspace: the tuned single-rhs kernel (c2_sweep.hip)
+    return c2_internal_sweep1(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, zero_z, stream);
   if (nrhs == 1) {
     C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL((k_sweep<G, 1, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s,
                                                     B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
@@ -761,10 +952,39 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
     if (int e = hip_check(hipMemsetAsync(Z, 0, sizeof(double) * B * N * nrhs, s))) return e;
   }
   constexpr int KT = 4;
-  C2_DISPATCH_G(group_size(J),
-                hipLaunchKernelGGL((k_general<G, KT, LOWER>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0, s,
-                                   B, N, M, (int)J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F));
-  return check_launch();
+  // Two data-parallel phases (state sweep over t2, then one group per output row) need every state row in memory:
+  // the caller's F when it asks for it, otherwise a stream-ordered temporary.  Above kGeneralTempMax bytes of
+  // temporary the sequential merge kernel runs instead (no scratch memory at all).
+  constexpr size_t kGeneralTempMax = (size_t)32 << 30;
+  const size_t fbytes = sizeof(double) * (size_t)B * M * J * nrhs;
+  double *Fw = F;
+  if (!Fw) {
+    // without a caller workspace the state rows are pure overhead (2 x 8 J nrhs bytes per row): two phases pay off
+    // for one or two right-hand sides (prediction), the sequential merge moves fewer bytes beyond that
+    if (nrhs > 2 || fbytes > kGeneralTempMax || hipMallocAsync((void **)&Fw, fbytes, s) != hipSuccess) {
+      (void)hipGetLastError();
+      C2_DISPATCH_G(group_size(J),
+                    hipLaunchKernelGGL((k_general<G, KT, LOWER>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0,
+                                       s, B, N, M, (int)J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F));
+      return check_launch();
+    }
+  }
+  C2_DISPATCH_G(group_size(J), {
+    if (nrhs == 1)
+      hipLaunchKernelGGL((k_gm_state<G, 1, LOWER>), grid_for(B, G), dim3(kWave), 0, s, B, N, M, (int)J, nrhs, t1, t1_bs,
+                         t2, t2_bs, c, c_bs, V, Y, Fw);
+    else
+      hipLaunchKernelGGL((k_gm_state<G, KT, LOWER>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0, s, B, N, M,
+                         (int)J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, V, Y, Fw);
+    hipLaunchKernelGGL((k_gm_emit<G, LOWER>), grid_for(B * N, G), dim3(kWave), 0, s, B, N, M, (int)J, nrhs, t1, t1_bs,
+                       t2, t2_bs, c, c_bs, U, V, Y, (const double *)Fw, Z);
+  });
+  int rc = check_launch();
+  if (!F) {
+    const int rf = hip_check(hipFreeAsync(Fw, s));
+    if (rc == C2_OK) rc = rf;
+  }
+  return rc;
 }
 template <bool LOWER, bool SOLVE>
 static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,

@@ -367,6 +367,84 @@ def test_long_series_chunked_matmul(ops, oracle, J, nrhs, N):
     assert float((lhs - rhs).abs().max()) <= 1e-9 * max(1.0, float(rhs.abs().max()))
 
 
+@pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 12, 16, 32])
+@pytest.mark.parametrize("N", [1, 2, 9, 300])
+def test_single_rhs_sweeps(ops, oracle, J, N):
+    """nrhs = 1 without the F workspace takes the tuned single-rhs kernels (c2_sweep.hip, transposed scalar streams):
+    all four sweeps against the oracle, out of place, in place (Z is Y), accumulating into Z and with zero_z, on
+    every group size incl. padded widths, a ragged last wavefront (B = 11) and a shared time grid."""
+    B = 11
+    rng = np.random.default_rng(1000 + 10 * J + N)
+    Je = J if J % 2 == 0 else J + 1
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), Je)
+    t = np.ascontiguousarray(t[:, :N]); U = np.ascontiguousarray(U[:, :N, :J]); V = np.ascontiguousarray(V[:, :N, :J])
+    c = np.ascontiguousarray(c[:, :J])
+    W = (0.3 / J) * rng.standard_normal((B, N, J))   # keeps L = I + tril(U W^T) well conditioned
+    Y = rng.standard_normal((B, N, 1))
+    td, cd, Ud, Vd, Wd, Yd = dev(t, c, U, V, W, Y)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Z0 = rng.standard_normal((B, N, 1))
+        Zo = Z0.copy()
+        for b in range(B):
+            getattr(oracle, name)(t[b], c[b], U[b], sec[b], Y[b], Zo[b])   # solve overwrites, matmul accumulates
+        (Zd,) = dev(Z0)
+        close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Zd), Zo, 1e-9)
+        Yc = Yd.clone()
+        Zi = getattr(ops, name)(td, cd, Ud, secd, Yc, Z=Yc)                  # in place
+        assert Zi.data_ptr() == Yc.data_ptr()
+        ref = Zo if solve else (Zo - Z0) + Y
+        close(Zi, ref, 1e-9)
+        if not solve:
+            close(getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True), Zo - Z0, 1e-9)
+    # shared time grid and decay rates (batch stride 0)
+    t0, c0 = t[0].copy(), c[0].copy()
+    t0d, c0d = dev(t0, c0)
+    Zs = ops.solve_lower(t0d, c0d, Ud, Wd, Yd)
+    for b in (0, B - 1):
+        zo = Y[b].copy()
+        oracle.solve_lower(t0, c0, U[b], W[b], Y[b], zo)
+        close(Zs[b], zo, 1e-9)
+
+
+@pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 97, 64), (3, 3, 40, 131), (6, 5, 200, 33), (16, 2, 50, 50), (2, 7, 1, 1)])
+def test_general_matmul_batched(ops, oracle, J, nrhs, N, M):
+    """general_matmul_lower/upper on the device, batched (two-phase: state sweep over t2 + one lane group per
+    output row): against the sequential-merge oracle with and without the F workspace, accumulation into Z,
+    ties between the two grids, output rows entirely before / after the input grid, and rows of F the merge
+    never visits (left untouched, forward.hpp:313/375)."""
+    B = 5
+    rng = np.random.default_rng(100 * J + nrhs)
+    Je = J if J % 2 == 0 else J + 1
+    t2, c, a, Ue, Ve, y = dense.synthetic_batch(B, max(M, 2), Je)
+    t2 = np.ascontiguousarray(t2[:, :M]); V = np.ascontiguousarray(Ve[:, :M, :J]); c = np.ascontiguousarray(c[:, :J])
+    lo, hi = t2[:, :1], t2[:, -1:]
+    t1 = np.sort(lo - 0.3 * (hi - lo + 1.0) + (1.6 * (hi - lo + 1.0)) * rng.random((B, N)), axis=1)
+    if N > 4 and M > 4:
+        t1[0, 3] = t2[0, 2]; t1[0, 4] = t2[0, 2]   # ties: t1 == t2, repeated
+        t1[1, :] = np.sort(t2[1, 0] - 1.0 - rng.random(N))   # every output row before the input grid
+        t1[2, :] = np.sort(t2[2, -1] + 0.5 + rng.random(N))  # every output row after it
+        t1 = np.sort(t1, axis=1)
+    U = rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, M, nrhs))
+    t1d, t2d, cd, Ud, Vd, Yd = dev(t1, t2, c, U, V, Y)
+    for name in ("general_matmul_lower", "general_matmul_upper"):
+        Z0 = rng.standard_normal((B, N, nrhs))
+        Zo = Z0.copy(); Fo = np.full((B, M, J, nrhs), -7.0)
+        for b in range(B):
+            getattr(oracle, name)(t1[b], t2[b], c[b], U[b], V[b], Y[b], Zo[b], Fo[b])
+        (Zd,) = dev(Z0)
+        (Fd,) = dev(np.full((B, M, J, nrhs), -7.0))
+        Zd, Fd = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd, F=Fd)
+        close(Zd, Zo, 1e-9); close(Fd, Fo, 1e-9)
+        (Zd2,) = dev(Z0)
+        Zd2 = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd2)   # internal temporary for the state rows
+        close(Zd2, Zo, 1e-9)
+        Zz = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, zero_z=True)
+        close(Zz, Zo - Z0, 1e-9)
+
+
 def test_torch_autograd_adapter(ops, oracle):
     """autograd.log_likelihood: values and gradients (incl. a shared time grid and shared c) vs the oracle."""
     import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-op measurements on one MI355X: HIP-event time of each batched device op at
 B series x N=4096 x J=8 and the algorithmic-byte rate (each input read once, each output written once).
-Usage: python tools/bench_ops.py [B]   -> markdown table on stdout."""
+Usage: python tools/bench_ops.py [B [substring-of-op-name]]   -> markdown table on stdout."""
 import os
 import sys
 
@@ -31,7 +31,11 @@ def main():
     d, W, S, flag = ops.factor(t, c, a, U, V, workspace=True)
     rows = []
 
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
+
     def add(name, row, fn, bytes_per_step):
+        if only not in name:
+            return
         ms = timed(fn)
         gb = B * N * bytes_per_step / 1e9
         rows.append((name, row, ms, B / ms * 1e3, gb / ms * 1e3, gb / ms * 1e3 / 8000))
@@ -60,8 +64,17 @@ def main():
     add("factor_rev", "H", lambda: ops.factor_rev(t, c, a, U, V, d, W, S, bd, bW), 8 * (5 + 5 * J + J * J))
     M = N
     ts = (t + 0.03).contiguous()
-    Y = torch.randn((B, N, 1), **f64)
-    add("general_matmul_lower (M=N) nrhs=1", "K", lambda: ops.general_matmul_lower(ts, t, c, U, V, Y), 16 * (1 + J + 1))
+    for nrhs in (1, 8):
+        Y = torch.randn((B, N, nrhs), **f64)
+        Zg = torch.zeros((B, N, nrhs), **f64)
+        add("general_matmul_lower (M=N) nrhs=%d" % nrhs, "K", lambda: ops.general_matmul_lower(ts, t, c, U, V, Y, Z=Zg),
+            16 * (1 + J + nrhs))
+        add("general_matmul_upper (M=N) nrhs=%d" % nrhs, "K", lambda: ops.general_matmul_upper(ts, t, c, U, V, Y, Z=Zg),
+            16 * (1 + J + nrhs))
+        Fg = torch.empty((B, N, J, nrhs), **f64)
+        add("general_matmul_lower + F workspace nrhs=%d" % nrhs, "K",
+            lambda: ops.general_matmul_lower(ts, t, c, U, V, Y, Z=Zg, F=Fg), 16 * (1 + J + nrhs) + 8 * J * nrhs)
+        del Fg
     ll = lambda: ops.loglik(t, c, a, U, V, y)
     add("fused log-lik", "L", ll, 8 * (3 + 2 * J))
     work = ops.loglik_grad_workspace(B, N, J, dev)

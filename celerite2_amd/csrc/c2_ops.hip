@@ -829,31 +829,45 @@ __global__ __launch_bounds__(kWave) void k_gm_emit(int64_t B, int64_t N, int64_t
 
 // =============================================================================
 // get_celerite_matrices -- reference python/celerite2/driver.cpp:422-477.
-// One thread per (series, row).
+// One thread per (series, row, term): consecutive threads write consecutive columns of the same row (a complex term
+// its cos/sin column pair as one 16-byte store when the pair is aligned), so a wavefront's stores are dense runs and
+// every sincos is evaluated once.
 // =============================================================================
-__global__ void k_matrices(int64_t B, int64_t N, int Jr, int Jc, const double *ar, const double *ac, const double *bc,
-                           const double *dc, int coef_batched, const double *x, int64_t x_bs, const double *diag,
-                           double *a, double *U, double *V) {
+__global__ void k_matrices(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ar,
+                           const double *__restrict__ ac, const double *__restrict__ bc, const double *__restrict__ dc,
+                           int coef_batched, const double *__restrict__ x, int64_t x_bs, const double *__restrict__ diag,
+                           double *__restrict__ a, double *__restrict__ U, double *__restrict__ V) {
+  const int Q = Jr + Jc, J = Jr + 2 * Jc;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * N) return;
-  const int64_t b = g / N, n = g % N;
-  const int J = Jr + 2 * Jc;
+  if (g >= B * N * Q) return;
+  const int64_t row = g / Q;
+  const int q = (int)(g - row * Q);
+  const int64_t b = row / N, n = row - b * N;
   const double *arb = ar + (coef_batched ? b * Jr : 0);
   const double *acb = ac + (coef_batched ? b * Jc : 0), *bcb = bc + (coef_batched ? b * Jc : 0),
                *dcb = dc + (coef_batched ? b * Jc : 0);
-  double sum = 0.0;
-  for (int i = 0; i < Jr; ++i) sum += arb[i];
-  for (int i = 0; i < Jc; ++i) sum += acb[i];
-  const double xn = x[b * x_bs + n];
-  a[g] = diag[g] + sum;
-  double *Un = U + g * J, *Vn = V + g * J;
-  for (int i = 0; i < Jr; ++i) { Vn[i] = 1.0; Un[i] = arb[i]; }
-  for (int i = 0, ind = Jr; i < Jc; ++i, ind += 2) {
-    double sn, cs;
-    sincos(dcb[i] * xn, &sn, &cs);
+  if (q == 0) {  // a = diag + sum(ar) + sum(ac), in the reference's summation order (driver.cpp:456-458)
+    double sum = 0.0;
+    for (int i = 0; i < Jr; ++i) sum += arb[i];
+    for (int i = 0; i < Jc; ++i) sum += acb[i];
+    a[row] = diag[row] + sum;
+  }
+  double *Un = U + row * J, *Vn = V + row * J;
+  if (q < Jr) {
+    Vn[q] = 1.0;
+    Un[q] = arb[q];
+    return;
+  }
+  const int i = q - Jr, ind = Jr + 2 * i;
+  double sn, cs;
+  sincos(dcb[i] * x[b * x_bs + n], &sn, &cs);
+  const double u0 = acb[i] * cs + bcb[i] * sn, u1 = acb[i] * sn - bcb[i] * cs;
+  if ((Jr & 1) == 0) {  // J even and ind even: the pair is 16-byte aligned
+    *reinterpret_cast<double2 *>(Vn + ind) = make_double2(cs, sn);
+    *reinterpret_cast<double2 *>(Un + ind) = make_double2(u0, u1);
+  } else {
     Vn[ind] = cs; Vn[ind + 1] = sn;
-    Un[ind] = acb[i] * cs + bcb[i] * sn;
-    Un[ind + 1] = acb[i] * sn - bcb[i] * cs;
+    Un[ind] = u0; Un[ind + 1] = u1;
   }
 }
 
@@ -1118,7 +1132,7 @@ int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const
                              const double *diag, double *a, double *U, double *V, c2_stream_t stream) {
   if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
   if (!x || !diag || !a || !U || !V || (Jr && !ar) || (Jc && (!ac || !bc || !dc))) return C2_ERR_INVALID;
-  const int64_t total = B * N;
+  const int64_t total = B * N * (Jr + Jc);
   hipLaunchKernelGGL(k_matrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
                      (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V);
   return check_launch();

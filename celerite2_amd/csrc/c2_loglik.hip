@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     lds_order();
     rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
     lds_order();
-    double dtv[C];
+    double dtv[C], pown[C];
     {
       double tprev = rowT[0][grp];
 #pragma unroll
@@ -436,7 +436,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         const double tn = rowT[r + 1][grp];
         dtv[r] = tprev - tn;
         tprev = tn;
-        vv[r][0][lane] = exp_decay(cj * dtv[r]);
+        pown[r] = exp_decay(cj * dtv[r]);
+        vv[r][0][lane] = pown[r];
         vv[r][1][lane] = iu[r];
         vv[r][2][lane] = iw[r];
       }
@@ -454,9 +455,15 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     for (int r = 0; r < C; ++r) {
       if (r < cnt) {
         double pX[G], uX[G], wX[G];
-        xgather_lds<G>(vv[r][0], lane, pX);
-        xgather_lds<G>(vv[r][1], lane, uX);
-        xgather_lds<G>(vv[r][2], lane, wX);
+        if constexpr (G <= 16) {  // the lane's own values are still in registers: gather by DPP, no LDS traffic
+          xgather_dpp<G>(pown[r], xB, lane, pX);
+          xgather_dpp<G>(iu[r], xB, lane, uX);
+          xgather_dpp<G>(iw[r], xB, lane, wX);
+        } else {
+          xgather_lds<G>(vv[r][0], lane, pX);
+          xgather_lds<G>(vv[r][1], lane, uX);
+          xgather_lds<G>(vv[r][2], lane, wX);
+        }
         const double p = pX[0], w = wX[0];
         const double dw = rowD[r][grp] * w;
         double tau0 = 0.0, tau1 = 0.0;
@@ -503,9 +510,17 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         const double Fpn = Fp[r];
         const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
         double uX[G], pX[G], wX[G], bVX[G], Sf[G];
-        xgather_lds<G>(vv[r][1], lane, uX);
-        xgather_lds<G>(vv[r][0], lane, pX);
-        xgather_lds<G>(vv[r][2], lane, wX);
+        // own value back from LDS, the rest of the group by DPP: on this chip a ds_read_b64 costs the issuing
+        // wavefront ~13 cycles against ~10 for the two DPP moves (profiles/r01_ubench_instruction_costs.md)
+        if constexpr (G <= 16) {
+          xgather_dpp<G>(vv[r][1][lane], xB, lane, uX);
+          xgather_dpp<G>(vv[r][0][lane], xB, lane, pX);
+          xgather_dpp<G>(vv[r][2][lane], xB, lane, wX);
+        } else {
+          xgather_lds<G>(vv[r][1], lane, uX);
+          xgather_lds<G>(vv[r][0], lane, pX);
+          xgather_lds<G>(vv[r][2], lane, wX);
+        }
         const double p = pX[0], u = uX[0], wm = wX[0];  // slot 0 of an XOR gather is the lane's own element
         const double *sfr = sfL[r];
 #pragma unroll

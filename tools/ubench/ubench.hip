@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
+#define REP2(x) x x
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
 
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(64) void kmem(unsigned long long *out, double *buf,
 
 template <int STORE, int PATTERN>
 void runmem(const char *name, int waves_per_simd, unsigned long long *d_out, double *buf) {
-  const int blocks = 1024 * waves_per_simd, iters = 500;
+  const int blocks = getenv("UB_BLOCKS") ? atoi(getenv("UB_BLOCKS")) : 1024 * waves_per_simd, iters = 500;
   hipLaunchKernelGGL((kmem<STORE, PATTERN>), dim3(blocks), dim3(64), 0, 0, d_out, buf, 5);
   hipDeviceSynchronize();
   hipEvent_t e0, e1;
@@ -54,12 +55,17 @@ void runmem(const char *name, int waves_per_simd, unsigned long long *d_out, dou
 
 template <int MODE>
 __global__ __launch_bounds__(64) void k(unsigned long long *out, int iters, double seed) {
-  __shared__ double lds[512];
+  __shared__ double lds[1024];
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 q0, q1, q2, q3, q4, q5, q6, q7;
+  q0 = q1 = q2 = q3 = q4 = q5 = q6 = q7 = (d2)(0.0);
   double a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   double m = 1.0000001, c = 1e-9;
+  double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
   int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3, j0 = i0 + 4, j1 = i0 + 5, j2 = i0 + 6, j3 = i0 + 7;
   lds[threadIdx.x] = a0;
   int addr = (threadIdx.x ^ 3) * 8;
+  int addr16 = (threadIdx.x ^ 3) * 16;
   __syncthreads();
   unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -113,6 +119,36 @@ __global__ __launch_bounds__(64) void k(unsigned long long *out, int iters, doub
                         : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(a0), "+v"(a1) :);)
     } else if (MODE == 8) {  // s_nop 0
       REP64(asm volatile("s_nop 0\n");)
+    } else if (MODE == 10) {  // the kernels' mix: 3 fp64 FMA per ds_read_b64 (24 + 8 per body, reads drained at the end)
+      REP2(asm volatile("v_fma_f64 %0, %0, %16, %17\n v_fma_f64 %1, %1, %16, %17\n v_fma_f64 %2, %2, %16, %17\n ds_read_b64 %8, %18\n"
+                        "v_fma_f64 %3, %3, %16, %17\n v_fma_f64 %4, %4, %16, %17\n v_fma_f64 %5, %5, %16, %17\n ds_read_b64 %9, %18 offset:64\n"
+                        "v_fma_f64 %6, %6, %16, %17\n v_fma_f64 %7, %7, %16, %17\n v_fma_f64 %0, %0, %16, %17\n ds_read_b64 %10, %18 offset:128\n"
+                        "v_fma_f64 %1, %1, %16, %17\n v_fma_f64 %2, %2, %16, %17\n v_fma_f64 %3, %3, %16, %17\n ds_read_b64 %11, %18 offset:192\n"
+                        "v_fma_f64 %4, %4, %16, %17\n v_fma_f64 %5, %5, %16, %17\n v_fma_f64 %6, %6, %16, %17\n ds_read_b64 %12, %18 offset:256\n"
+                        "v_fma_f64 %7, %7, %16, %17\n v_fma_f64 %0, %0, %16, %17\n v_fma_f64 %1, %1, %16, %17\n ds_read_b64 %13, %18 offset:320\n"
+                        "v_fma_f64 %2, %2, %16, %17\n v_fma_f64 %3, %3, %16, %17\n v_fma_f64 %4, %4, %16, %17\n ds_read_b64 %14, %18 offset:384\n"
+                        "v_fma_f64 %5, %5, %16, %17\n v_fma_f64 %6, %6, %16, %17\n v_fma_f64 %7, %7, %16, %17\n ds_read_b64 %15, %18 offset:448\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2),
+                          "+v"(b3), "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7)
+                        : "v"(m), "v"(c), "v"(addr)
+                        : "memory");)
+    } else if (MODE == 12) {  // ds_read_b128, 8 in flight then wait
+      REP8(asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:64\n ds_read_b128 %2, %8 offset:128\n ds_read_b128 %3, %8 offset:192\n"
+                        "ds_read_b128 %4, %8 offset:256\n ds_read_b128 %5, %8 offset:320\n ds_read_b128 %6, %8 offset:384\n ds_read_b128 %7, %8 offset:448\n s_waitcnt lgkmcnt(0)\n"
+                        : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7) : "v"(addr16) : "memory");)
+    } else if (MODE == 13) {  // ds_read2st64_b64 (two 8-byte words 512 B apart), 8 in flight then wait
+      REP8(asm volatile("ds_read2st64_b64 %0, %8 offset1:1\n ds_read2st64_b64 %1, %8 offset0:2 offset1:3\n ds_read2st64_b64 %2, %8 offset0:4 offset1:5\n ds_read2st64_b64 %3, %8 offset0:6 offset1:7\n"
+                        "ds_read2st64_b64 %4, %8 offset1:1\n ds_read2st64_b64 %5, %8 offset0:2 offset1:3\n ds_read2st64_b64 %6, %8 offset0:4 offset1:5\n ds_read2st64_b64 %7, %8 offset0:6 offset1:7\n s_waitcnt lgkmcnt(0)\n"
+                        : "=v"(q0), "=v"(q1), "=v"(q2), "=v"(q3), "=v"(q4), "=v"(q5), "=v"(q6), "=v"(q7) : "v"(addr) : "memory");)
+    } else if (MODE == 14) {  // ds_write_b64, 8 then wait
+      REP8(asm volatile("ds_write_b64 %8, %0\n ds_write_b64 %8, %1 offset:512\n ds_write_b64 %8, %2 offset:1024\n ds_write_b64 %8, %3 offset:1536\n"
+                        "ds_write_b64 %8, %4\n ds_write_b64 %8, %5 offset:512\n ds_write_b64 %8, %6 offset:1024\n ds_write_b64 %8, %7 offset:1536\n s_waitcnt lgkmcnt(0)\n"
+                        : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(addr) : "memory");)
+    } else if (MODE == 11) {  // fp64 FMA with three distinct, rotating VGPR-pair operands (register-file port pressure)
+      REP8(asm volatile("v_fma_f64 %0, %1, %2, %3\n v_fma_f64 %1, %2, %3, %4\n v_fma_f64 %2, %3, %4, %5\n v_fma_f64 %3, %4, %5, %6\n"
+                        "v_fma_f64 %4, %5, %6, %7\n v_fma_f64 %5, %6, %7, %0\n v_fma_f64 %6, %7, %0, %1\n v_fma_f64 %7, %0, %1, %2\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) :);)
     } else if (MODE == 9) {  // SALU add
       int s = it;
       REP64(asm volatile("s_add_u32 %0, %0, 1\n" : "+s"(s));)
@@ -121,13 +157,15 @@ __global__ __launch_bounds__(64) void k(unsigned long long *out, int iters, doub
   }
   unsigned long long t1 = __builtin_readcyclecounter();
   if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+  if (b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 == 0.123) out[1] = 0;
+  if (q0.x + q1.x + q2.y + q3.x + q4.x + q5.y + q6.x + q7.x + addr16 == 0.123) out[2] = 0;
   if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + i0 + i1 + i2 + i3 + j0 + j1 + j2 + j3 + addr == 12345.678) out[0] = 0;
 }
 
 template <int MODE>
 void run(const char *name, int waves_per_simd, unsigned long long *d_out) {
   fprintf(stderr, "start %s\n", name);
-  const int blocks = 1024 * waves_per_simd, iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 2000;
+  const int blocks = getenv("UB_BLOCKS") ? atoi(getenv("UB_BLOCKS")) : 1024 * waves_per_simd, iters = getenv("UB_ITERS") ? atoi(getenv("UB_ITERS")) : 2000;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(64), 0, 0, d_out, 10, 1.0);
@@ -161,6 +199,12 @@ int main(int argc, char **argv) {
   run<6>("ds_read_b64 x8 + wait", w, d_out);
   run<7>("gsum-like (6 dpp + 2 add)/8", w, d_out);
   run<8>("s_nop 0", w, d_out);
+  run<10>("mix 3 fma_f64 : 1 ds_read_b64", w, d_out);
+  run<12>("ds_read_b128 x8 + wait", w, d_out);
+  run<13>("ds_read2st64_b64 x8 + wait", w, d_out);
+  run<14>("ds_write_b64 x8 + wait", w, d_out);
+  run<11>("fma_f64 3 distinct operands", w, d_out);
+  if (getenv("UB_NOMEM")) return 0;
   double *buf;
   hipMalloc(&buf, (size_t)4096 * 8 * 32768 * sizeof(double) + (1 << 24));
   runmem<0, 0>("load dwordx2, 512 B contiguous", w, d_out, buf);

@@ -33,6 +33,14 @@ extern "C" int c2_loglik_grad_composite(int64_t B, int64_t N, int64_t J, const d
                                         size_t work_bytes, c2_stream_t stream);
 extern "C" size_t c2_loglik_grad_composite_workspace_bytes(int64_t B, int64_t N, int64_t J);
 
+#ifdef C2_REV_TIMING
+__device__ unsigned long long c2_dbg[8];
+extern "C" void c2_internal_read_dbg(unsigned long long *out) {  // read and clear
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(c2_dbg), sizeof(unsigned long long) * 8);
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(c2_dbg), z, sizeof(z));
+}
+#endif
 namespace c2 {
 
 // Checkpoint record of one lane: SX[0..G-1] (column j, XOR order), F_j, w_j, d, z  -> G+4 doubles.
@@ -412,11 +420,19 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   double2 carDZ = dzb[N - 1];
   double carR = rcp_nr(carDZ.x);
   if (nseg > 0) load_segment(nseg - 1);
+  // -DC2_REV_TIMING: s_memtime deltas of the four phases, summed per wavefront into c2_dbg (tools/rev_phase_timing.py)
+#ifdef C2_REV_TIMING
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = 0;
+#define C2_TCK(i) do { const unsigned long long tn_ = __builtin_readcyclecounter(); if (i) tacc[i] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define C2_TCK(i)
+#endif
 
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
 
+    C2_TCK(0);
     // ---- phase A: scalar rows to LDS (lane-parallel), then p_n (C independent exps), U_n, W_{n-1} ----------
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
@@ -451,6 +467,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     double F = cF;
     double Fp[C], tauS[C];
     lds_order();
+    C2_TCK(1);
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       if (r < cnt) {
@@ -498,6 +515,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     // entry 0 (row n_lo-1) is entry C of the next, earlier segment
     carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
     lds_order();
+    C2_TCK(2);
 
     // ---- phase C: fused reverse steps; the next (earlier) segment is fetched half way through ---------
 #pragma unroll
@@ -570,6 +588,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
     }
     lds_order();
+    C2_TCK(3);
     // flush the segment's per-series scalar outputs, transposed: lane j <-> row n_lo + j (by: row n_lo-1+j)
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
@@ -581,7 +600,14 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
     }
     lds_order();
+    C2_TCK(4);
   }
+#ifdef C2_REV_TIMING
+  if (lane == 0) {
+    for (int i = 1; i < 5; ++i) atomicAdd(&c2_dbg[i], tacc[i]);
+    atomicAdd(&c2_dbg[0], 1ull);
+  }
+#endif
   if (nseg == 0) {  // N == 1
     const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;
     ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);

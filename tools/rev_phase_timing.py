@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-phase cycle counts of k_loglik_rev from a library built with -DC2_REV_TIMING (s_memtime deltas accumulated per
-wavefront): C2_LIB_PATH=celerite2_amd/_exp_t.so python tools/rev_phase_timing.py [B ...]"""
+wavefront).  Build: hipcc <HIPFLAGS of celerite2_amd/build.py> -DC2_REV_TIMING <sources> -o celerite2_amd/_exp_t.so, then
+C2_LIB_PATH=$PWD/celerite2_amd/_exp_t.so python tools/rev_phase_timing.py [B ...]"""
 import ctypes
 import os
 import sys

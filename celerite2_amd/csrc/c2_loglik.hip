@@ -92,6 +92,9 @@ __device__ __forceinline__ void fwd_chain(double p, double u, double v, double a
 #ifndef C2_REV_OCC
 #define C2_REV_OCC 1
 #endif
+#ifndef C2_REV_APARK
+#define C2_REV_APARK 1
+#endif
 // Packed symmetric storage of the C saved S_n columns in LDS.  In XOR order slot k of lane j is S(j^k, j) and
 // slot k of lane j^k is its transpose twin S(j, j^k) -- the same number up to rounding -- so for k >= 1 only
 // the lane whose bit hb(k) (highest set bit of k) is clear stores it and both lanes read that copy:
@@ -340,6 +343,19 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 //   ba_{n-1} = bd_{n-1} - Q/2 - z_{n-1} G / d_{n-1}                 (bd + w bS w^T - W_{n-1}.bV_{n-1})
 // with the seeds bd = (z^2/d - 1)/(2d), the derivative of the log-likelihood w.r.t. d (and -z/d w.r.t. z).
 // =============================================================================
+// A double parked in a pair of accumulation registers (gfx950: 256 AGPRs per lane at one wavefront per SIMD, unused by
+// these kernels).  Round trip = 4 v_accvgpr moves (~19 cycles of issue) against ~38 for ds_write_b64 + ds_read_b64.
+__device__ __forceinline__ void apark(double x, int &lo, int &hi) {
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(x)));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(x)));
+}
+__device__ __forceinline__ double afetch(int lo, int hi) {
+  int l, h;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+  return __hiloint2double(h, l);
+}
+
 template <int G, int C, bool PAD>
 __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -354,8 +370,13 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
-  __shared__ __attribute__((aligned(16))) double vv[C][3][kWave];
-  __shared__ __attribute__((aligned(16))) double sfL[C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
+  __shared__ __attribute__((aligned(16))) double vv[(C2_REV_APARK && G <= 8) ? 1 : C][3][kWave];
+  // The replayed S_n columns wait for their reverse step in AGPRs (G <= 8: C*G*2 = 128 of them); wider groups
+  // keep them in LDS, symmetric-packed.
+  constexpr bool APARK = C2_REV_APARK && G <= 8;
+  __shared__ __attribute__((aligned(16))) double sfL[APARK ? 1 : C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
+  int sAlo[APARK ? C : 1][G], sAhi[APARK ? C : 1][G];
+  int uAlo[APARK ? C : 1], uAhi[APARK ? C : 1], wAlo[APARK ? C : 1], wAhi[APARK ? C : 1];  // own U_n, W_{n-1}
   // per-series scalars of rows n_lo-1 .. n_lo+C-1 (entry e <-> row n_lo-1+e): t, d, 1/d, z
   __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
   // per-series scalar outputs of the segment, flushed transposed (lane j <-> row j): ba_n, bt_n, by_{n-1}
@@ -453,9 +474,14 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         dtv[r] = tprev - tn;
         tprev = tn;
         pown[r] = exp_decay(cj * dtv[r]);
-        vv[r][0][lane] = pown[r];
-        vv[r][1][lane] = iu[r];
-        vv[r][2][lane] = iw[r];
+        if constexpr (APARK) {  // the prefetch registers are refilled half way through phase C
+          apark(iu[r], uAlo[r], uAhi[r]);
+          apark(iw[r], wAlo[r], wAhi[r]);
+        } else {
+          vv[r][0][lane] = pown[r];
+          vv[r][1][lane] = iu[r];
+          vv[r][2][lane] = iw[r];
+        }
       }
     }
     // ---- phase B: replay S_n = P (S + d w^T w) P and F_n = P (F + w z) -- with W, d, z on record there is no
@@ -494,13 +520,18 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         tauS[r] = tau0 + tau1;
         F = p * fma(w, rowZ[r][grp], F);
         Fp[r] = F;
-        double *sfr = sfL[r];
-        sfr[lane] = SX[0];
+        if constexpr (APARK) {
 #pragma unroll
-        for (int b = 0; (1 << b) < G; ++b) {
-          if ((j & (1 << b)) == 0) {  // owner lanes of slots k in [2^b, 2^(b+1))
+          for (int i = 0; i < G; ++i) apark(SX[i], sAlo[r][i], sAhi[r][i]);
+        } else {
+          double *sfr = sfL[r];
+          sfr[lane] = SX[0];
 #pragma unroll
-            for (int kk = (1 << b); kk < (2 << b); ++kk) sfr[soff[kk]] = SX[kk];
+          for (int b = 0; (1 << b) < G; ++b) {
+            if ((j & (1 << b)) == 0) {  // owner lanes of slots k in [2^b, 2^(b+1))
+#pragma unroll
+              for (int kk = (1 << b); kk < (2 << b); ++kk) sfr[soff[kk]] = SX[kk];
+            }
           }
         }
       }
@@ -530,7 +561,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         double uX[G], pX[G], wX[G], bVX[G], Sf[G];
         // own value back from LDS, the rest of the group by DPP: on this chip a ds_read_b64 costs the issuing
         // wavefront ~13 cycles against ~10 for the two DPP moves (profiles/r01_ubench_instruction_costs.md)
-        if constexpr (G <= 16) {
+        if constexpr (APARK) {
+          xgather_dpp<G>(afetch(uAlo[r], uAhi[r]), xB, lane, uX);
+          xgather_dpp<G>(pown[r], xB, lane, pX);
+          xgather_dpp<G>(afetch(wAlo[r], wAhi[r]), xB, lane, wX);
+        } else if constexpr (G <= 16) {
           xgather_dpp<G>(vv[r][1][lane], xB, lane, uX);
           xgather_dpp<G>(vv[r][0][lane], xB, lane, pX);
           xgather_dpp<G>(vv[r][2][lane], xB, lane, wX);
@@ -540,9 +575,14 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           xgather_lds<G>(vv[r][2], lane, wX);
         }
         const double p = pX[0], u = uX[0], wm = wX[0];  // slot 0 of an XOR gather is the lane's own element
-        const double *sfr = sfL[r];
+        if constexpr (APARK) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];
+          for (int i = 0; i < G; ++i) Sf[i] = afetch(sAlo[r][i], sAhi[r][i]);
+        } else {
+          const double *sfr = sfL[r];
+#pragma unroll
+          for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];
+        }
         oBA[grp][r] = ban;
         if (st) bVb[n * J] = bVn;
         xgather_dpp<G>(bVn, xB, lane, bVX);

@@ -118,10 +118,11 @@ struct SymPack {
 // instruction moves one contiguous 256/512-byte run; 44 instead of 96 bytes per series and step at G = C = 8.
 template <int G>
 struct CkptRec {
-  static constexpr int DOUBLES = SymPack<G>::PER_STEP + kWave;  // per wavefront and checkpoint
+  static constexpr int DOUBLES = SymPack<G>::PER_STEP + 2 * kWave;  // S (packed) + F_j + W_j, per wavefront and checkpoint
 };
 template <int G>
-__device__ __forceinline__ void ckpt_store(double *rec, int lane, const int (&soff)[G], const double (&SX)[G], double F) {
+__device__ __forceinline__ void ckpt_store(double *rec, int lane, const int (&soff)[G], const double (&SX)[G], double F,
+                                           double w) {
   const int j = lane & (G - 1);
   rec[lane] = SX[0];
 #pragma unroll
@@ -132,12 +133,15 @@ __device__ __forceinline__ void ckpt_store(double *rec, int lane, const int (&so
     }
   }
   rec[SymPack<G>::PER_STEP + lane] = F;
+  rec[SymPack<G>::PER_STEP + kWave + lane] = w;
 }
 template <int G>
-__device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int (&soff)[G], double (&SX)[G], double &F) {
+__device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int (&soff)[G], double (&SX)[G], double &F,
+                                          double &w) {
 #pragma unroll
   for (int k = 0; k < G; ++k) SX[k] = rec[soff[k]];
   F = rec[SymPack<G>::PER_STEP + lane];
+  w = rec[SymPack<G>::PER_STEP + kWave + lane];
 }
 
 template <int G, int R, int C, int MODE, bool PAD>
@@ -177,8 +181,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   soff[0] = lane;
 #pragma unroll
   for (int k = 1; k < G; ++k) soff[k] = SymPack<G>::off(lane, k);
-  // per-step records for the reverse sweep (CKPT only): W_n (like the reference's factor output) and (d_n, z_n)
-  double *wst = REC ? Wst + L.b0 * N * J + oj : nullptr;
+  // per-step record for the reverse sweep (CKPT only): (d_n, z_n).  W_n is NOT recorded: the reverse sweep replays
+  // W_n = (V_n - tau_n) / d_n bit for bit next to S_n, from the W of the checkpointed row (64 B per step less to
+  // write and to read back; the forward pass is HBM-bound).  FACTOR: W is the caller's output.
+  double *wst = FACTOR ? Wst + L.b0 * N * J + oj : nullptr;
   double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
   double *dst = FACTOR ? reinterpret_cast<double *>(DZst) + L.b0 * N + on : nullptr;
   const bool stw = PAD ? (L.valid && act) : true;  // duplicate stores of identical values are harmless
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   double quad = z * z * rd;
   int32_t fl = 0;
   if (REC) {
-    if (stw) wst[0] = w;
+    if (FACTOR && stw) wst[0] = w;
     if (CKPT) dzst[0] = make_double2(d, z);
     else dst[0] = d;
   }
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
         if (CKPT && (r % C == 0))  // state after row n-1 = checkpoint (n-1)/C
-          ckpt_store<G>(ckw + ((n - 1) / C) * CkptRec<G>::DOUBLES, lane, soff, SX, F);
+          ckpt_store<G>(ckw + ((n - 1) / C) * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
@@ -269,7 +275,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (REC) {
-          if (stw && (!FACTOR || ((fl == 0) & (d > 0.0)))) wst[n * J] = w;
+          if (FACTOR && stw && ((fl == 0) & (d > 0.0))) wst[n * J] = w;
           sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
@@ -360,7 +366,7 @@ template <int G, int C, bool PAD>
 __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
-                                                         const double *__restrict__ Wst,
+                                                         const double *__restrict__ V,
                                                          const double2 *__restrict__ DZst,
                                                          const double *__restrict__ ckpt, int64_t nseg,
                                                          const int32_t *__restrict__ flag, double *__restrict__ bt,
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   // values to the same address are harmless: without column padding no store needs an exec mask.
   const bool st = PAD ? (L.valid && act) : true, st0 = PAD ? (L.valid && j == 0) : true;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
-  const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Wb = Wst + L.b0 * N * J + oj;
+  const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double2 *dzb = DZst + L.b0 * N + on;
   const double *ckw = ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES;
   double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   double vt[NV];
   double2 vdz[NV];
   double iu[C], iw[C];
-  double cS[G], cF;
+  double cS[G], cF, cW;
   auto load_segment = [&](int64_t k) {
     const int64_t n_lo = 1 + k * C;
     const bool full = n_lo + C <= N;
@@ -431,9 +437,9 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
       iu[r] = act ? Ub[n * J] : 0.0;
-      iw[r] = act ? Wb[(n - 1) * J] : 0.0;  // W row n-1
+      iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay)
     }
-    ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF);
+    ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
   };
 
   // entry `cnt` of the first processed segment = row N-1
@@ -476,11 +482,9 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         pown[r] = exp_decay(cj * dtv[r]);
         if constexpr (APARK) {  // the prefetch registers are refilled half way through phase C
           apark(iu[r], uAlo[r], uAhi[r]);
-          apark(iw[r], wAlo[r], wAhi[r]);
         } else {
           vv[r][0][lane] = pown[r];
           vv[r][1][lane] = iu[r];
-          vv[r][2][lane] = iw[r];
         }
       }
     }
@@ -491,18 +495,25 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
 #pragma unroll
     for (int i = 0; i < G; ++i) SX[i] = cS[i];
     double F = cF;
+    const double Wck = cW;  // W of the checkpointed row n_lo-1
     double Fp[C], tauS[C];
     lds_order();
     C2_TCK(1);
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       if (r < cnt) {
+        // W_{n-1} = (V_{n-1} - tau_{n-1}) / d_{n-1}, exactly as the forward pass formed it (forward.hpp:131)
+        double wown = Wck;
+        if (r > 0) wown = (iw[r] - tauS[r > 0 ? r - 1 : 0]) * rowR[r][grp];
+        if constexpr (APARK) apark(wown, wAlo[r], wAhi[r]);
+        else vv[r][2][lane] = wown;
         double pX[G], uX[G], wX[G];
         if constexpr (G <= 16) {  // the lane's own values are still in registers: gather by DPP, no LDS traffic
           xgather_dpp<G>(pown[r], xB, lane, pX);
           xgather_dpp<G>(iu[r], xB, lane, uX);
-          xgather_dpp<G>(iw[r], xB, lane, wX);
+          xgather_dpp<G>(wown, xB, lane, wX);
         } else {
+          lds_order();
           xgather_lds<G>(vv[r][0], lane, pX);
           xgather_lds<G>(vv[r][1], lane, uX);
           xgather_lds<G>(vv[r][2], lane, wX);
@@ -744,7 +755,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
 // Checkpoint interval per group size (must match launch_fwd / launch_rev below).
 static inline int ckpt_interval(int G_) { return G_ <= 8 ? C2_CKPT_C : (G_ == 16 ? 4 : 2); }
 
-// Workspace layout: [checkpoints B*nseg*G*(G+4)] [W rows B*N*J] [(d,z) pairs B*N*2]  (doubles)
+// Workspace layout: [checkpoints: waves*nseg*CkptRec<G>::DOUBLES] [(d,z) pairs B*N*2]  (doubles)
 struct GradWs {
   size_t ck, w, dz, total;
 };
@@ -753,10 +764,9 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   GradWs g;
   const size_t waves = ((size_t)B * G_ + kWave - 1) / kWave;       // checkpoints are wave-blocked
-  g.ck = waves * (size_t)nseg * ((size_t)kWave + (size_t)(G_ - 1) * (kWave / 2) + kWave);  // CkptRec<G>::DOUBLES
+  g.ck = waves * (size_t)nseg * ((size_t)kWave + (size_t)(G_ - 1) * (kWave / 2) + 2 * kWave);  // CkptRec<G>::DOUBLES
   g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
-  g.w = (size_t)B * N * J;
-  g.w = (g.w + 1) & ~(size_t)1;
+  g.w = 0;  // W rows are replayed, not recorded
   g.dz = (size_t)B * N * 2;
   g.total = g.ck + g.w + g.dz;
   return g;
@@ -794,19 +804,18 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   const GradWs ws = grad_ws(B, N, J);
   double *ckpt = (double *)work;
-  double *Wst = ckpt + ws.ck;
-  double2 *DZst = reinterpret_cast<double2 *>(Wst + ws.w);
-  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, s)) return e;
+  double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck);
+  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, nullptr, DZst, s)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \
     if (J == G)                                                                                                   \
       hipLaunchKernelGGL((k_loglik_rev<G, C, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
-                         (const double *)Wst, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
+                         V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
                          (const int32_t *)flag, bt, bc, ba, bU, bV, by);                                          \
     else                                                                                                          \
       hipLaunchKernelGGL((k_loglik_rev<G, C, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,   \
-                         (const double *)Wst, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
+                         V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
                          (const int32_t *)flag, bt, bc, ba, bU, bV, by);                                          \
   } while (0)
   switch (G_) {

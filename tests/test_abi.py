@@ -51,11 +51,11 @@ def test_argument_errors_without_gpu(built):
                          null) == _lib.C2_ERR_INVALID
     assert lib.c2_loglik(i64(1), i64(4), i64(33), null, i64(0), null, i64(0), null, null, null, null, null, null,
                          null) == _lib.C2_ERR_UNSUPPORTED
-    # workspace = wave-blocked packed checkpoints + W rows (B,N,J) + (d,z) pairs (B,N,2)  
+    # workspace = wave-blocked packed checkpoints + (d,z) pairs (B,N,2)  
     B, N, J = 2, 8, 3                      # G = 4, C = 8 -> 1 segment, 1 wavefront
-    ck = 1 * 1 * (64 + 3 * 32 + 64)        # S slot 0 (64) + slots 1..3 (32 owners each) + F (64)
-    assert lib.c2_loglik_grad_workspace_bytes(B, N, J) == 8 * (ck + B * N * J + B * N * 2)
-    assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) < 32 * 2**30
+    ck = 1 * 1 * (64 + 3 * 32 + 64 + 64)   # S slot 0 (64) + slots 1..3 (32 owners each) + F (64) + W (64)
+    assert lib.c2_loglik_grad_workspace_bytes(B, N, J) == 8 * (ck + B * N * 2)
+    assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) < 20 * 2**30
     assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 33) == 0   # unsupported width
 
 

@@ -6,19 +6,20 @@
 //                    pass over (t, a, U, V, y); only ll[b] and flag[b] are written.
 //   c2_loglik_grad : the same forward pass, additionally dropping a small CHECKPOINT of the recursion
 //                    state every C steps, followed by one reverse sweep that -- segment by segment, last
-//                    to first -- recomputes the C forward steps from the checkpoint (keeping the C
-//                    J x J states in registers) and runs solve_lower_rev (internal.hpp:225-245) fused
-//                    with factor_rev (reverse.hpp:52-84) over them.  The reference's S (N,J,J) and
-//                    F (N,J) workspaces (1312 B per step at J=8) are never materialised in HBM.
+//                    to first -- recomputes the C forward steps from the checkpoint (S_n, tau_n, W_n, F_n; the
+//                    C J x J states wait in accumulation registers) and runs solve_lower_rev
+//                    (internal.hpp:225-245) fused with factor_rev (reverse.hpp:52-84) over them.  The
+//                    reference's S (N,J,J) and F (N,J) workspaces (1312 B per step at J=8) and even its W
+//                    (N,J) are never materialised in HBM.
 //
 // Mapping (c2_common.hpp): G = 2^ceil(log2 J) lanes per series, 64/G series per wavefront, one
-// wavefront per workgroup.  Lane j owns column j of S / M and element j of every width-J vector.
-// Width-J vectors that every lane of a group needs (p, U_n, W_{n-1}, bV_n) are exchanged through a
-// per-wave LDS slot: one ds_write_b64 by each lane, G/2 broadcast ds_read_b128 by every lane -- the LDS
-// pipe is otherwise idle and this keeps the exchange off the VALU, which is the binding unit here.
-// Scalar all-reduces (d_n, z_n, ...) are DPP butterflies (gsum).  With 8192 series per GPU at J=8 the
-// launch is exactly one wavefront per SIMD, so HBM latency is hidden by an explicit register prefetch
-// ring (R rows ahead), not by occupancy.
+// wavefront per workgroup.  Lane j owns column j of S / M and element j of every width-J vector, in XOR
+// order (c2_loglik_helpers.hpp).  Width-J vectors that every lane of a group needs are gathered by DPP lane
+// permutes when they sit on the recursion's critical path or when the kernel runs one wavefront per SIMD (the
+// reverse sweep), and through a per-wave LDS slot, one step ahead, where a second wavefront hides the LDS
+// instructions (the forward pass) -- measured costs in profiles/r01_ubench_instruction_costs.md.
+// Scalar all-reduces (d_n, z_n, ...) are DPP butterflies (gsum).  HBM latency is hidden by an explicit
+// register prefetch ring (R rows ahead): at 8192 series per GPU and J=8 there is one wavefront per SIMD.
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
 
     C2_TCK(0);
-    // ---- phase A: scalar rows to LDS (lane-parallel), then p_n (C independent exps), U_n, W_{n-1} ----------
+    // ---- phase A: scalar rows to LDS (lane-parallel), then p_n (C independent exps); own U_n parked ----------
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
@@ -488,9 +489,9 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         }
       }
     }
-    // ---- phase B: replay S_n = P (S + d w^T w) P and F_n = P (F + w z) -- with W, d, z on record there is no
-    // recursion chain left (no reductions, no division): a pure throughput loop.  S_n columns go to LDS
-    // (packed), F_n and tau_n = U_n S_n stay in registers.
+    // ---- phase B: replay S_n = P (S + d w^T w) P, tau_n = U_n S_n, W_n = (V_n - tau_n) / d_n and
+    // F_n = P (F + w z) -- with d, 1/d, z on record there are no reductions and no division.  S_n columns and
+    // the lane's own W_{n-1} are parked (AGPRs; LDS for G > 8), F_n and tau_n stay in registers.
     double SX[G];
 #pragma unroll
     for (int i = 0; i < G; ++i) SX[i] = cS[i];

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
         prod *= d;
         quad = fma(z * z, rd, quad);
-        if (r % 8 == 7) {
+        if (r % 8 == 7 || r == R - 1) {  // renormalise at least once per block (R = 4 for the widest groups)
           int e;
           prod = frexp(prod, &e);
           eacc += e;

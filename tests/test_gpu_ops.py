@@ -178,6 +178,49 @@ def test_two_columns_per_lane_variant(ops, oracle, monkeypatch, B, N):
             assert int(flag4[b]) == f
 
 
+@pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])
+@pytest.mark.parametrize("N", [1, 2, 8, 9, 10, 17, 100])
+def test_loglik_grad_widths_and_segment_edges(ops, oracle, J, N):
+    """Fused log-lik + gradient on padded widths (J < G), on the wide groups (G = 16, 32: LDS-parked replay) and at
+    series lengths around the checkpoint interval (N-1 = 0, 1, 7, 8, 9, 16: empty, partial and exactly full
+    segments; the replayed W rows start from the W stored with each checkpoint)."""
+    B = 10
+    Je = J if J % 2 == 0 else J + 1
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), Je)
+    t = np.ascontiguousarray(t[:, :N]); a = np.ascontiguousarray(a[:, :N]) + (Je - J) * 0.0
+    U = np.ascontiguousarray(U[:, :N, :J]); V = np.ascontiguousarray(V[:, :N, :J])
+    c = np.ascontiguousarray(c[:, :J]); y = np.ascontiguousarray(y[:, :N])
+    a = a + 1.0   # dropping a column keeps K positive definite only with some head room on the diagonal
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    assert int(np.abs(flago).sum()) == 0
+    ll, grads, flag = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0
+    close(ll, llo)
+    for g, e in zip(grads, go):
+        close(g, e)
+    ll0, flag0 = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    close(ll0, llo)
+
+
+@pytest.mark.parametrize("J", [8, 16, 24, 32])
+def test_loglik_long_series_log_det_range(ops, oracle, J):
+    """4096 pivots far from 1: the running product behind log det must be renormalised in every block of every
+    group size (the widest groups use 4-row blocks) -- caught as ll = -inf for J > 16 once."""
+    B, N = 3, 4096
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    s = 1e-3                        # K -> s K: every pivot ~1e-3, product of 4096 of them ~1e-12288
+    a, U, y = a * s, U * s, y * np.sqrt(s)
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    ll2, grads, flag2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    for b in range(B):
+        e, f = oracle.loglik(t[b], c[b], a[b], U[b], V[b], y[b])
+        assert f == 0 and np.isfinite(e)
+        close(ll[b:b + 1], np.array([e])); close(ll2[b:b + 1], np.array([e]))
+
+
 def test_loglik_grad_golden(ops, golden):
     x, c, a, U, V = (golden["py_" + k] for k in ("x", "c", "a", "U", "V"))
     y = np.ascontiguousarray(golden["py_Y"][:, 0])

@@ -326,6 +326,29 @@ def test_full_size_properties(ops, oracle, J, B):
     assert float((lhs - rhs).abs().max()) <= 1e-10 * float(rhs.abs().max())
 
 
+def test_bench_scale_batch(ops, oracle):
+    """A chip-filling batch at the bench shape (16384 x N=4096 x J=8: two wavefronts per SIMD, and the batch size
+    from which c2_loglik switches to the two-columns-per-lane kernel by itself): results identical for identical
+    series wherever they sit, equal to the oracle on the distinct ones, forward-only == forward of the gradient."""
+    import torch
+    B, N, J, nb = 16384, 4096, 8, 4
+    t, c, a, U, V, y = dense.synthetic_batch(nb, N, J)
+    rep = B // nb
+    td, cd, ad, Ud, Vd, yd = [x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous() for x in dev(t, c, a, U, V, y)]
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=4)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0
+    assert torch.equal(ll[:nb].repeat(rep), ll)
+    close(ll[:nb], llo)
+    ll2, grads, flag2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag2.abs().sum()) == 0
+    close(ll2[:nb], llo)
+    assert float((ll2 - ll).abs().max()) <= 1e-10 * float(ll.abs().max())
+    for g, e in zip(grads, go):
+        close(g[:nb], e)
+        assert torch.equal(g[:nb].repeat((rep,) + (1,) * (g.dim() - 1)), g)
+
+
 @pytest.mark.parametrize("J,N", [(8, 1000), (4, 333), (3, 64), (16, 130), (32, 40)])
 def test_fused_grad_matches_composite_chain(ops, J, N):
     """The checkpoint/recompute kernels vs the literal op chain with S/F materialised in HBM (both on the GPU)."""

@@ -920,7 +920,7 @@ extern "C" int c2_internal_matmul_chunked(int lower, int64_t B, int64_t N, int64
 
 extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
                                   const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
-                                  double *Z, int zero_z, c2_stream_t stream);
+                                  double *Z, double *F, int zero_z, c2_stream_t stream);
 
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
@@ -941,17 +941,12 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
                                         stream);
     }
   }
-  if (nrhs == 1 && !F)  // a vector without the workspace: the tuned single-rhs kernel (c2_sweep.hip)
-    return c2_internal_sweep1(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, zero_z, stream);
-  if (nrhs == 1) {
-    C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL((k_sweep<G, 1, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s,
-                                                    B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
-  } else {
-    constexpr int KT = 4;
-    C2_DISPATCH_G(group_size(J),
-                  hipLaunchKernelGGL((k_sweep<G, KT, LOWER, SOLVE>), grid_for(B, G, (nrhs + KT - 1) / KT),
-                                     dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
-  }
+  if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
+    return c2_internal_sweep1(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+  constexpr int KT = 4;
+  C2_DISPATCH_G(group_size(J),
+                hipLaunchKernelGGL((k_sweep<G, KT, LOWER, SOLVE>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0,
+                                   s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
   return check_launch();
 }
 

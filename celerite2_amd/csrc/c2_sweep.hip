@@ -1,5 +1,5 @@
-// c2_sweep.hip -- the single-right-hand-side lower / upper sweeps (solve_lower, solve_upper, matmul_lower, matmul_upper
-// without the F workspace: what GaussianProcess.apply_inverse / dot_tril / sample call, numpy.py:95-108) in the
+// c2_sweep.hip -- the single-right-hand-side lower / upper sweeps (solve_lower, solve_upper, matmul_lower, matmul_upper,
+// with or without the F workspace: what GaussianProcess.apply_inverse / dot_tril / sample call, numpy.py:95-108) in the
 // formulation of the fused log-likelihood kernel instead of the first-cut one in c2_ops.hip:
 //   * per-series scalar streams (t, y, z in; z out) move TRANSPOSED in time -- lane j of a group takes row n0 + j, one
 //     global_load / global_store per R rows, staged through LDS -- instead of eight lanes sharing every 8-byte word;
@@ -18,7 +18,7 @@ namespace c2 {
 template <int G, int R, bool LOWER, bool SOLVE, bool PAD>
 __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt, const double *t, int64_t t_bs,
                                                   const double *__restrict__ c, int64_t c_bs, const double *U,
-                                                  const double *V, const double *Y, double *Z, int zero_z) {
+                                                  const double *V, const double *Y, double *Z, double *F, int zero_z) {
   constexpr int SPW = kWave / G, NV = (R + G - 1) / G;
   __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];  // t, y, z-in of two blocks
   __shared__ __attribute__((aligned(16))) double sout[SPW][R];
@@ -33,6 +33,8 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   const double *Ab = (LOWER ? V : U) + L.b0 * N * J + oj;  // row fed into F
   const double *Bb = (LOWER ? U : V) + L.b0 * N * J + oj;  // row applied to F
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  double *Fb = F ? F + L.b0 * N * J + oj : nullptr;  // workspace F[n, j] (nrhs = 1), written before the decay
+  const bool stf = F && (PAD ? (L.valid && act) : true);
   auto rowof = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
 
   // step 0: Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / untouched (matmul accumulate)
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   else if (zero_z) zb[r0] = 0.0;
   double aprev = act ? Ab[r0 * J] : 0.0;
   double tprev = tb[r0];
-  double F = 0.0;
+  double Fs = 0.0;
+  if (stf) Fb[r0 * J] = 0.0;  // internal.hpp:127 / :170
 
   // transposed scalar streams: registers hold block b+2, LDS blocks b and b+1
   double vt[NV], vy[NV], vz[NV];
@@ -91,8 +94,10 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
         load_row(r, s + R);
         const double p = exp_decay(cj * (LOWER ? tprev - tn : tn - tprev));
         tprev = tn;
-        const double f = p * fma(aprev, xprev, F);  // internal.hpp:140,143 (lower) / :183,186 (upper)
-        F = f;
+        const double fpre = fma(aprev, xprev, Fs);  // internal.hpp:140 (lower) / :183 (upper)
+        if (stf) Fb[rowof(s) * J] = fpre;            // saved before the decay (internal.hpp:142 / :185)
+        const double f = p * fpre;                   // internal.hpp:143 / :186
+        Fs = f;
         const double red = gsum<G>(bn * f);
         const double zn = SOLVE ? yn - red : zin + red;  // internal.hpp:144 / :187
         sout[grp][r] = zn;
@@ -123,7 +128,7 @@ using namespace c2;
 // lower != 0: solve_lower / matmul_lower, else the upper sweeps; solve != 0: Z = Y -/+ ..., else Z (+)= ...
 extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
                                   const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
-                                  double *Z, int zero_z, c2_stream_t stream) {
+                                  double *Z, double *F, int zero_z, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
@@ -131,10 +136,10 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
   do {                                                                                                             \
     if (J == G)                                                                                                    \
       hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
-                         V, Y, Z, zero_z);                                                                         \
+                         V, Y, Z, F, zero_z);                                                                         \
     else                                                                                                           \
       hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
-                         V, Y, Z, zero_z);                                                                         \
+                         V, Y, Z, F, zero_z);                                                                         \
   } while (0)
 #define C2_SW_G(LO, SO)                    \
   switch (G_) {                            \

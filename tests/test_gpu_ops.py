@@ -464,6 +464,12 @@ def test_single_rhs_sweeps(ops, oracle, J, N):
         close(Zi, ref, 1e-9)
         if not solve:
             close(getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True), Zo - Z0, 1e-9)
+        # with the F workspace (backprop.*_fwd: Z zeroed first), every element of F
+        Zf, Ff = getattr(ops, name)(td, cd, Ud, secd, Yd, workspace=True, zero_z=True)
+        for b in (0, B - 1):
+            zo = np.empty((N, 1)); fo = np.empty((N, J, 1))
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], zo, fo)
+            close(Zf[b], zo, 1e-9); close(Ff[b], fo, 1e-9)
     # shared time grid and decay rates (batch stride 0)
     t0, c0 = t[0].copy(), c[0].copy()
     t0d, c0d = dev(t0, c0)

@@ -922,6 +922,11 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
                                   const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
                                   double *Z, double *F, int zero_z, c2_stream_t stream);
 
+extern "C" int c2_internal_sweep1_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, const double *t,
+                                      int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                      const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
+                                      double *bc, double *bU, double *bV, double *bY, c2_stream_t stream);
+
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -1004,15 +1009,12 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z || !F || !bZ || !bt || !bc || !bU || !bV || !bY)
     return C2_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
-  if (nrhs == 1) {
-    C2_DISPATCH_G(group_size(J),
-                  hipLaunchKernelGGL((k_sweep_rev<G, 1, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J,
-                                     nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));
-  } else {
-    C2_DISPATCH_G(group_size(J),
-                  hipLaunchKernelGGL((k_sweep_rev<G, 4, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J,
-                                     nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));
-  }
+  if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
+    return c2_internal_sweep1_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU,
+                                  bV, bY, stream);
+  C2_DISPATCH_G(group_size(J),
+                hipLaunchKernelGGL((k_sweep_rev<G, 4, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J,
+                                   nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));
   return check_launch();
 }
 extern "C" {

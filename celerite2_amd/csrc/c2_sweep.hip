@@ -121,6 +121,145 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   for (; s0 < N; s0 += R, q ^= 1) block(s0, q, std::true_type{});
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Reverse of the single-rhs sweeps: internal::forward_rev / backward_rev (internal.hpp:191-246 / 248-303) behind
+// solve_lower_rev, solve_upper_rev, matmul_lower_rev, matmul_upper_rev (reverse.hpp:87-217), nrhs = 1.
+// Positions q = 0 .. N-1 run against the forward sweep: row(q) = N-1-q (lower) or q (upper).  Step u = 0 .. N-2
+// handles n = row(u) (its U/V row, its workspace row F_n, outputs bt_n and the row gradient bB_n) and m = row(u+1)
+// (its V/U row, x_m, bZ_m; outputs bY_m and the row gradient bA_m).  Same stream handling as k_sweep1.
+// -----------------------------------------------------------------------------------------------------------------
+template <int G, int R, bool LOWER, bool SOLVE, bool PAD>
+__global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
+                                                      int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                      const double *__restrict__ U, const double *__restrict__ V,
+                                                      const double *__restrict__ Y, const double *__restrict__ Z,
+                                                      const double *__restrict__ F, const double *__restrict__ bZ,
+                                                      double *__restrict__ bt, double *__restrict__ bc,
+                                                      double *__restrict__ bU, double *__restrict__ bV,
+                                                      double *__restrict__ bY) {
+  constexpr int SPW = kWave / G, NV = (R + G - 1) / G;
+  __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];  // t, x, bZ at positions u+1 of two blocks
+  __shared__ __attribute__((aligned(16))) double sout[2][SPW][R];     // bt (position u), bY (position u+1)
+  const int J = PAD ? Jrt : G;
+  const Geo<G> L(B, J);
+  const int j = L.j, grp = L.lane / G;
+  const bool act = PAD ? L.act : true;
+  const bool st = PAD ? (L.valid && act) : true;
+  const int64_t on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
+  const double *tb = t + L.b0 * t_bs + (int64_t)L.sl * t_bs;
+  const double *xb = (SOLVE ? Z : Y) + L.b0 * N + on, *bzb = bZ + L.b0 * N + on;
+  double *btb = bt + L.b0 * N + on, *byb = bY + L.b0 * N + on;
+  const double *Ab = (LOWER ? V : U) + L.b0 * N * J + oj;  // row fed into F (index m)
+  const double *Bb = (LOWER ? U : V) + L.b0 * N * J + oj;  // row applied to F (index n)
+  double *bAb = (LOWER ? bV : bU) + L.b0 * N * J + oj, *bBb = (LOWER ? bU : bV) + L.b0 * N * J + oj;
+  const double *Fb = F + L.b0 * N * J + oj;
+  const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  constexpr double sgn = SOLVE ? -1.0 : 1.0;
+  auto rowof = [&](int64_t q) { return LOWER ? N - 1 - q : q; };
+
+  const int64_t r0 = rowof(0);
+  double bz = bzb[r0];
+  byb[r0] = SOLVE ? bz : 0.0;      // reverse.hpp:112 (bY = bZ) / :178 (bY = 0)
+  if (st) bAb[r0 * J] = 0.0;       // never receives a contribution
+  double tprev = tb[r0];
+  double bF = 0.0, bcj = 0.0, carry = 0.0;
+
+  double vt[NV], vx[NV], vbz[NV];
+  auto vload = [&](int64_t qb) {
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      int64_t q = qb + m * G + j;
+      q = (q < N) ? q : N - 1;
+      const int64_t n = rowof(q);
+      vt[m] = tb[n]; vx[m] = xb[n]; vbz[m] = bzb[n];
+    }
+  };
+  auto vstage = [&](int s) {
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * G + j;
+      if (G * NV == R || idx < R) {
+        sin_[s][0][grp][idx] = vt[m]; sin_[s][1][grp][idx] = vx[m]; sin_[s][2][grp][idx] = vbz[m];
+      }
+    }
+  };
+  vload(1); vstage(0);
+  vload(1 + R); vstage(1);
+  vload(1 + 2 * R);
+
+  double rb[R], rf[R], ra[R];
+  auto load_row = [&](int r, int64_t u) {  // B and F rows of position u, A row of position u+1
+    const int64_t qn = (u < N) ? u : N - 1, qm = (u + 1 < N) ? u + 1 : N - 1;
+    const int64_t n = rowof(qn), m = rowof(qm);
+    rb[r] = act ? Bb[n * J] : 0.0;
+    rf[r] = act ? Fb[n * J] : 0.0;
+    ra[r] = act ? Ab[m * J] : 0.0;
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) load_row(r, r);
+  lds_order();
+
+  auto block = [&](int64_t u0, int s, auto checked_tag) {
+    constexpr bool CHECKED = decltype(checked_tag)::value;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t u = u0 + r;
+      if (!CHECKED || u + 1 < N) {
+        const int64_t n = rowof(u), m = rowof(u + 1);
+        const double tm = sin_[s][0][grp][r], xm = sin_[s][1][grp][r], bzm = sin_[s][2][grp][r];
+        const double bn = rb[r], Fn = rf[r], am = ra[r];
+        load_row(r, u + R);
+        const double dt = tm - tprev;  // lower: t[m] - t[n]; upper: t[n] - t[m] with the roles of prev/next swapped
+        const double dte = LOWER ? dt : -dt;
+        tprev = tm;
+        const double p = exp_decay(cj * dte);
+        // reverse of update_z (internal.hpp:232-233 / 289-290)
+        const double val = bz * (p * Fn);
+        bF = fma(sgn * bn, bz, bF);
+        const double dotFbF = Fn * bF;
+        if (st) bBb[n * J] = sgn * val;
+        // reverse of the decay (internal.hpp:236-241 / 293-298)
+        const double bp = dotFbF * p;
+        bcj = fma(dte, bp, bcj);
+        bF *= p;
+        // update_f::reverse (internal.hpp:55-63 matmul, 76-84 solve)
+        const double bam = xm * bF;
+        double f = cj * bp, g = am * bF;
+        gsum2<G>(f, g);
+        sout[0][grp][r] = LOWER ? carry - f : f - carry;
+        carry = f;
+        const double out = SOLVE ? bzm + g : g;
+        sout[1][grp][r] = out;
+        bz = SOLVE ? out : bzm;
+        if (st) bAb[m * J] = bam;
+      }
+    }
+    lds_order();
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      const int idx = m * G + j;
+      if ((G * NV == R || idx < R) && (!CHECKED || u0 + idx + 1 < N)) {
+        btb[rowof(u0 + idx)] = sout[0][grp][idx];
+        byb[rowof(u0 + idx + 1)] = sout[1][grp][idx];
+      }
+    }
+    vstage(s);
+    vload(u0 + 1 + 3 * R);
+    lds_order();
+  };
+  int64_t u0 = 0;
+  int s = 0;
+  for (; u0 + 2 * R + 1 <= N; u0 += R, s ^= 1) block(u0, s, std::false_type{});
+  for (; u0 + 1 < N; u0 += R, s ^= 1) block(u0, s, std::true_type{});
+
+  const int64_t rl = rowof(N - 1);
+  btb[rl] = LOWER ? carry : -carry;
+  if (st) {
+    bBb[rl * J] = 0.0;  // bU.row(0) / bV.row(N-1) never touched
+    bc[L.b * J + j] = bcj;
+  }
+}
+
 }  // namespace c2
 
 using namespace c2;
@@ -157,5 +296,40 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
   }
 #undef C2_SW_G
 #undef C2_SW
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+extern "C" int c2_internal_sweep1_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, const double *t,
+                                      int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                      const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
+                                      double *bc, double *bU, double *bV, double *bY, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int G_ = group_size(J);
+  const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+#define C2_SWR(G, LO, SO)                                                                                             \
+  do {                                                                                                                \
+    if (J == G)                                                                                                       \
+      hipLaunchKernelGGL((k_sweep1_rev<G, 8, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, \
+                         U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY);                                                      \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_sweep1_rev<G, 8, LO, SO, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs,  \
+                         U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY);                                                      \
+  } while (0)
+#define C2_SWR_G(LO, SO)                    \
+  switch (G_) {                             \
+    case 1: C2_SWR(1, LO, SO); break;       \
+    case 2: C2_SWR(2, LO, SO); break;       \
+    case 4: C2_SWR(4, LO, SO); break;       \
+    case 8: C2_SWR(8, LO, SO); break;       \
+    case 16: C2_SWR(16, LO, SO); break;     \
+    default: C2_SWR(32, LO, SO); break;     \
+  }
+  if (lower) {
+    if (solve) { C2_SWR_G(true, true); } else { C2_SWR_G(true, false); }
+  } else {
+    if (solve) { C2_SWR_G(false, true); } else { C2_SWR_G(false, false); }
+  }
+#undef C2_SWR_G
+#undef C2_SWR
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }

@@ -470,6 +470,17 @@ def test_single_rhs_sweeps(ops, oracle, J, N):
             zo = np.empty((N, 1)); fo = np.empty((N, J, 1))
             getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], zo, fo)
             close(Zf[b], zo, 1e-9); close(Ff[b], fo, 1e-9)
+        # reverse pass (single-rhs kernel): bt, bc, bU, bV|bW, bY against the oracle
+        bZ = rng.standard_normal((B, N, 1))
+        (bZd,) = dev(bZ)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zf, Ff, bZd)
+        for b in (0, B // 2, B - 1):
+            zo = np.empty((N, 1)); fo = np.empty((N, J, 1))
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], zo, fo)
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, 1))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], zo, fo, bZ[b], *outs)
+            for r_, e_ in zip(res, outs):
+                close(r_[b], e_, 1e-9)
     # shared time grid and decay rates (batch stride 0)
     t0, c0 = t[0].copy(), c[0].copy()
     t0d, c0d = dev(t0, c0)

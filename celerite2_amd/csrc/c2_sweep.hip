@@ -8,6 +8,7 @@
 // Reference: internal::forward / backward, c++/include/celerite2/internal.hpp:105-146 / 148-189 (policy structs
 // update_f :45-85, update_z :87-103); wrappers forward.hpp:156-170, 193-207, 228-239, 260-271.
 // A sweep runs over steps s = 1 .. N-1; step s is row n = s (lower) or n = N-1-s (upper).
+#include <cstdint>
 #include <type_traits>
 
 #include "c2_loglik_helpers.hpp"
@@ -260,6 +261,112 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// Several right-hand sides: lanes <-> right-hand sides.  A series is walked by KL lanes (KL = nrhs rounded up to a
+// power of two, at most 64; more right-hand sides -> tiles of 64 in blockIdx.y), lane k owning column k of the
+// J x nrhs state F: z_n[k] = y_n[k] -/+ sum_j B_n[j] F[j][k] needs NO cross-lane reduction and the Y / Z rows move
+// as dense runs.  What every lane needs per step are the three width-J vectors p_n, A_{n-1}, B_n: lane j (< J)
+// loads / computes element j, they are staged in LDS and read back as broadcasts (ds_read_b128, 3J/2 per step).
+// Same semantics as k_sweep (internal.hpp:105-189): in-place Z == Y is legal (rows are read R steps ahead of the
+// row being written), matmul accumulates into Z unless zero_z.  The F workspace variant stays on k_sweep: here a
+// lane's J entries of F[n, j + J k] would leave as 16-byte pieces of 64 separate lines (measured 12 ms against 9).
+// -----------------------------------------------------------------------------------------------------------------
+template <int KL, int JM, int R, bool LOWER, bool SOLVE>
+__global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, int64_t nrhs, const double *t, int64_t t_bs,
+                                                  const double *__restrict__ c, int64_t c_bs, const double *U,
+                                                  const double *V, const double *Y, double *Z, int zero_z) {
+  static_assert(JM <= KL, "the lanes of a series also carry its width-J vectors");
+  constexpr int SPW = kWave / KL;
+  __shared__ __attribute__((aligned(16))) double rowbuf[2][SPW][3][KL];  // p_n, A_{n-1}, B_n of two consecutive steps
+  const int lane = threadIdx.x, sl = lane / KL, k = lane % KL;
+  int64_t b = (int64_t)blockIdx.x * SPW + sl;
+  const bool vb = b < B;
+  if (!vb) b = B - 1;
+  int64_t kk = (int64_t)blockIdx.y * KL + k;
+  const bool vk = vb && kk < nrhs;
+  if (kk >= nrhs) kk = nrhs - 1;
+  const bool actj = k < J;  // this lane also carries element k of the width-J vectors
+  const int jk = actj ? k : 0;
+  const bool loadz = !SOLVE && !zero_z;
+  const double *tb = t + b * t_bs;
+  const double *Ab = (LOWER ? V : U) + b * N * J + jk;  // row fed into F
+  const double *Bb = (LOWER ? U : V) + b * N * J + jk;  // row applied to F
+  const double *yb = Y + b * N * nrhs + kk;
+  double *zb = Z + b * N * nrhs + kk;
+  const double cj = actj ? c[b * c_bs + k] : 0.0;
+  auto rowof = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
+
+  const int64_t r0 = rowof(0);
+  double xprev = yb[r0 * nrhs];
+  if (vk) {
+    if (SOLVE) zb[r0 * nrhs] = xprev;        // forward.hpp:168, 205
+    else if (zero_z) zb[r0 * nrhs] = 0.0;
+  }
+  double aprev = actj ? Ab[r0 * J] : 0.0;
+  double tprev = tb[r0];
+  double Fj[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) Fj[j] = 0.0;
+
+  double rt[R], ra[R], rb[R], ry[R], rz[R];
+  auto load_row = [&](int r, int64_t s) {
+    s = (s < N) ? s : N - 1;
+    const int64_t n = rowof(s);
+    rt[r] = tb[n];
+    ra[r] = actj ? Ab[n * J] : 0.0;
+    rb[r] = actj ? Bb[n * J] : 0.0;
+    ry[r] = yb[n * nrhs];
+    rz[r] = loadz ? zb[n * nrhs] : 0.0;
+  };
+#pragma unroll
+  for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+
+  int q = 0;
+  for (int64_t s0 = 1; s0 < N; s0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t s = s0 + r;
+      if (s < N) {
+        const int64_t n = rowof(s);
+        const double tn = rt[r], an = ra[r], bn = rb[r], yn = ry[r], zin = rz[r];
+        load_row(r, s + R);
+        const double p = exp_decay(cj * (LOWER ? tprev - tn : tn - tprev));
+        tprev = tn;
+        rowbuf[q][sl][0][k] = p; rowbuf[q][sl][1][k] = aprev; rowbuf[q][sl][2][k] = bn;
+        lds_order();
+        double red = 0.0;
+#pragma unroll
+        for (int j = 0; j < JM; j += 2) {
+          double2 p2, a2, b2;
+          if constexpr (JM >= 2) {
+            p2 = *reinterpret_cast<const double2 *>(&rowbuf[q][sl][0][j]);
+            a2 = *reinterpret_cast<const double2 *>(&rowbuf[q][sl][1][j]);
+            b2 = *reinterpret_cast<const double2 *>(&rowbuf[q][sl][2][j]);
+          } else {
+            p2 = make_double2(rowbuf[q][sl][0][0], 0.0); a2 = make_double2(rowbuf[q][sl][1][0], 0.0);
+            b2 = make_double2(rowbuf[q][sl][2][0], 0.0);
+          }
+          const double f0 = fma(a2.x, xprev, Fj[j]);   // internal.hpp:140 / :183
+          Fj[j] = p2.x * f0;                            // internal.hpp:143 / :186
+          red = fma(b2.x, Fj[j], red);
+          double f1 = 0.0;
+          if (j + 1 < JM) {
+            f1 = fma(a2.y, xprev, Fj[j + 1]);
+            Fj[j + 1] = p2.y * f1;
+            red = fma(b2.y, Fj[j + 1], red);
+          }
+
+        }
+        const double zn = SOLVE ? yn - red : zin + red;  // internal.hpp:144 / :187
+        if (vk) zb[n * nrhs] = zn;
+        xprev = SOLVE ? zn : yn;
+        aprev = an;
+        q ^= 1;
+      }
+    }
+  }
+}
+
 }  // namespace c2
 
 using namespace c2;
@@ -331,5 +438,41 @@ extern "C" int c2_internal_sweep1_rev(int lower, int solve, int64_t B, int64_t N
   }
 #undef C2_SWR_G
 #undef C2_SWR
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// Multi-rhs sweeps with lanes over the right-hand sides.  Returns C2_ERR_UNSUPPORTED when the shape does not fit the
+// mapping (J wider than the lanes of a series); the caller then takes the generic kernel.
+extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
+                                  int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                  const double *Y, double *Z, int zero_z, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int KL = 8;
+  while (KL < 64 && KL < nrhs) KL *= 2;
+  const int JM = J <= 8 ? 8 : (J <= 16 ? 16 : 32);
+  if (JM > KL) return C2_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((B + (kWave / KL) - 1) / (kWave / KL)), (unsigned)((nrhs + KL - 1) / KL));
+#define C2_SK(KL_, JM_)                                                                                              \
+  do {                                                                                                               \
+    if (lower) {                                                                                                     \
+      if (solve) hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, true, true>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);   \
+      else hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, true, false>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);        \
+    } else {                                                                                                         \
+      if (solve) hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);  \
+      else hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, false, false>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);       \
+    }                                                                                                                \
+  } while (0)
+  switch (KL * 100 + JM) {
+    case 808: C2_SK(8, 8); break;
+    case 1608: C2_SK(16, 8); break;
+    case 1616: C2_SK(16, 16); break;
+    case 3208: C2_SK(32, 8); break;
+    case 3216: C2_SK(32, 16); break;
+    case 3232: C2_SK(32, 32); break;
+    case 6408: C2_SK(64, 8); break;
+    case 6416: C2_SK(64, 16); break;
+    default: C2_SK(64, 32); break;
+  }
+#undef C2_SK
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }

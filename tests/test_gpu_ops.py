@@ -491,6 +491,36 @@ def test_single_rhs_sweeps(ops, oracle, J, N):
         close(Zs[b], zo, 1e-9)
 
 
+@pytest.mark.parametrize("J,nrhs", [(8, 5), (8, 8), (3, 8), (16, 8), (16, 20), (32, 33), (8, 64), (6, 70), (32, 7)])
+def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
+    """nrhs >= 5 takes the kernel with lanes over the right-hand sides (c2_sweep.hip) when J fits the lanes of a
+    series, the generic kernel otherwise ((16, 8), (32, 7)): all four sweeps with the F workspace, in place,
+    accumulating, with ragged rhs tiles (70 = 64 + 6) and a ragged last wavefront."""
+    B, N = 5, 131
+    rng = np.random.default_rng(7 * J + nrhs)
+    Je = J if J % 2 == 0 else J + 1
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, Je)
+    U = np.ascontiguousarray(U[:, :, :J]); V = np.ascontiguousarray(V[:, :, :J]); c = np.ascontiguousarray(c[:, :J])
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Wd, Yd = dev(t, c, U, V, W, Y)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b])
+        Zd, Fd = getattr(ops, name)(td, cd, Ud, secd, Yd, workspace=True, zero_z=True)
+        close(Zd, Zo, 1e-9); close(Fd, Fo, 1e-9)
+        Yc = Yd.clone()
+        Zi = getattr(ops, name)(td, cd, Ud, secd, Yc, Z=Yc)   # in place: solve overwrites, matmul adds to Y
+        close(Zi, Zo if solve else Zo + Y, 1e-9)
+        if not solve:
+            Z0 = rng.standard_normal((B, N, nrhs))
+            (Z0d,) = dev(Z0)
+            close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d), Z0 + Zo, 1e-9)
+
+
 @pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 97, 64), (3, 3, 40, 131), (6, 5, 200, 33), (16, 2, 50, 50), (2, 7, 1, 1)])
 def test_general_matmul_batched(ops, oracle, J, nrhs, N, M):
     """general_matmul_lower/upper on the device, batched (two-phase: state sweep over t2 + one lane group per

@@ -39,10 +39,27 @@ def _run(cmd):
 
 
 def build_hip(force=False):
+    """Compile every .hip source to an object in parallel (one hipcc per file), then link the shared library."""
+    from concurrent.futures import ThreadPoolExecutor
+
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
-    if force or _stale(LIB, deps):
-        _run([HIPCC] + HIPFLAGS + srcs + ["-o", LIB])
+    if not (force or _stale(LIB, deps)):
+        return LIB
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in HIPFLAGS if f != "-shared"]
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            _run([HIPCC] + cflags + ["-c", src, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
     return LIB
 
 

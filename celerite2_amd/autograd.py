@@ -4,12 +4,20 @@
 `log_likelihood(t, c, a, U, V, y)` is differentiable w.r.t. every argument: the forward call runs
 c2_loglik_grad once (value and the six cotangents come out of the same checkpoint/replay pass, exactly what the
 reference's PyMC/JAX ops do in two steps -- pymc/ops.py:104-141), backward just scales the saved gradients by
-the incoming cotangent.  Shared `t` (N,) / `c` (J,) receive the batch-summed gradient."""
+the incoming cotangent.  Shared `t` (N,) / `c` (J,) receive the batch-summed gradient.
+
+`factor`, `solve_lower`, `solve_upper`, `matmul_lower`, `matmul_upper` are the reference's five differentiable ops
+(python/celerite2/pymc/ops.py:61-141, jax/ops.py:33-172: forward = `backprop.<op>_fwd` with its workspace, gradient =
+`backprop.<op>_rev`), batched, on the device kernels -- for models that compose the ops themselves."""
 import torch
 
 from . import ops
 
-__all__ = ["log_likelihood"]
+__all__ = ["log_likelihood", "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "LinAlgError"]
+
+
+class LinAlgError(RuntimeError):
+    """failed to factorize or solve matrix (driver.hpp:13-19); `.flag` holds the per-series first bad row."""
 
 
 class _LogLik(torch.autograd.Function):
@@ -40,3 +48,65 @@ class _LogLik(torch.autograd.Function):
 def log_likelihood(t, c, a, U, V, y):
     """Batched GP log-likelihood (B,), differentiable through torch.autograd."""
     return _LogLik.apply(t, c, a, U, V, y)
+
+
+def _reduce(g, like):
+    """Gradient of an argument that was shared by the batch (one fewer dimension): sum over the batch."""
+    return g.sum(0) if like.dim() == g.dim() - 1 else g
+
+
+class _Factor(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, c, a, U, V):
+        args = [x.detach().contiguous() for x in (t, c, a, U, V)]
+        d, W, S, flag = ops.factor(*args, workspace=True)
+        if bool((flag != 0).any()):
+            err = LinAlgError("failed to factorize or solve matrix")
+            err.flag = flag
+            raise err
+        ctx.save_for_backward(*args, d, W, S)
+        return d, W
+
+    @staticmethod
+    def backward(ctx, bd, bW):
+        t, c, a, U, V, d, W, S = ctx.saved_tensors
+        bt, bc, ba, bU, bV = ops.factor_rev(t, c, a, U, V, d, W, S, bd.contiguous(), bW.contiguous())
+        return _reduce(bt, t), _reduce(bc, c), ba, bU, bV
+
+
+def factor(t, c, a, U, V):
+    """(d, W) = LDL^T factors of the batch (forward.hpp:69-135), differentiable (reverse.hpp:10-85)."""
+    return _Factor.apply(t, c, a, U, V)
+
+
+def _sweep(name):
+    fwd, rev = getattr(ops, name), getattr(ops, name + "_rev")
+
+    class _Op(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t, c, U, W, Y):
+            args = [x.detach().contiguous() for x in (t, c, U, W, Y)]
+            Z, F = fwd(*args, workspace=True, zero_z=True) if name.startswith("matmul") else fwd(*args, workspace=True)
+            ctx.save_for_backward(*args, Z, F)
+            return Z
+
+        @staticmethod
+        def backward(ctx, bZ):
+            t, c, U, W, Y, Z, F = ctx.saved_tensors
+            bt, bc, bU, bW, bY = rev(t, c, U, W, Y, Z, F, bZ.contiguous())
+            return _reduce(bt, t), _reduce(bc, c), bU, bW, bY
+
+    _Op.__name__ = "_" + name
+
+    def op(t, c, U, W, Y):
+        return _Op.apply(t, c, U, W, Y)
+
+    op.__name__ = name
+    op.__doc__ = "Batched %s (B,N,nrhs), differentiable w.r.t. (t, c, U, W|V, Y); internal.hpp:105-303." % name
+    return op
+
+
+solve_lower = _sweep("solve_lower")
+solve_upper = _sweep("solve_upper")
+matmul_lower = _sweep("matmul_lower")
+matmul_upper = _sweep("matmul_upper")

@@ -596,3 +596,44 @@ def test_torch_autograd_adapter(ops, oracle):
     with torch.no_grad():
         ll2 = ag.log_likelihood(td, cd, ad, Ud, Vd, yd)
     close(ll2, ll.detach().cpu().numpy())
+
+
+def test_torch_autograd_ops(ops, oracle):
+    """The five differentiable ops as torch.autograd Functions: a log-likelihood composed from them
+    (factor -> solve_lower -> reductions, numpy.py:84-87) has the value and gradients of the fused kernel, and
+    matmul / solve_upper pass a directional finite-difference check."""
+    import torch
+    from celerite2_amd import autograd as ag
+
+    B, N, J = 4, 60, 4
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    leaves = [x.requires_grad_(True) for x in dev(t, c, a, U, V, y)]
+    td, cd, ad, Ud, Vd, yd = leaves
+    d, W = ag.factor(td, cd, ad, Ud, Vd)
+    z = ag.solve_lower(td, cd, Ud, W, yd[:, :, None])[:, :, 0]
+    ll = -0.5 * (torch.log(d).sum(1) + N * np.log(2 * np.pi)) - 0.5 * (z * z / d).sum(1)
+    wts = torch.linspace(0.5, 1.5, B, dtype=torch.float64, device="cuda")
+    (ll * wts).sum().backward()
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    close(ll.detach(), llo)
+    w = wts.cpu().numpy()
+    for x, e in zip(leaves, go):
+        close(x.grad, e * w.reshape((B,) + (1,) * (e.ndim - 1)), 1e-9)
+    # directional finite differences through matmul_lower / matmul_upper / solve_upper, 3 right-hand sides
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((B, N, 3))
+    for name in ("matmul_lower", "matmul_upper", "solve_upper"):
+        base = [x.detach().clone() for x in dev(t, c, U, 0.05 * V, Y)]
+        dirs = [torch.from_numpy(rng.standard_normal(x.shape)).cuda() for x in base]
+        f = lambda xs: (getattr(ag, name)(*xs) ** 2).sum()
+        xs = [x.clone().requires_grad_(True) for x in base]
+        f(xs).backward()
+        lin = sum(float((x.grad * dv).sum()) for x, dv in zip(xs, dirs))
+        eps = 1e-6
+        fp = f([x + eps * dv for x, dv in zip(base, dirs)]); fm = f([x - eps * dv for x, dv in zip(base, dirs)])
+        fd = float(fp - fm) / (2 * eps)
+        assert abs(fd - lin) <= 1e-6 * max(1.0, abs(lin)), (name, fd, lin)
+    # a non-positive-definite series raises like the reference
+    a2 = a.copy(); a2[1, 7] = -4.0
+    with pytest.raises(ag.LinAlgError):
+        ag.factor(*dev(t, c, a2, U, V))

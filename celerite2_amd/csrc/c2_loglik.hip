@@ -363,7 +363,11 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
   return __hiloint2double(h, l);
 }
 
-template <int G, int C, bool PAD>
+// FR = true turns the same kernel into core::factor_rev (reverse.hpp:10-85) on the reference's own arguments: V is
+// then the caller's W, `ckpt` the caller's S workspace -- of which only every C-th row is read, as the checkpoint the
+// rows in between are replayed from (64 instead of 512 bytes of S per step at J = 8) --, fr_d / fr_bd / fr_bW the
+// pivots and the incoming cotangents of d and W; the solve_lower_rev half (F, z, bF, by) drops out.
+template <int G, int C, bool PAD, bool FR>
 __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
@@ -373,17 +377,20 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          const int32_t *__restrict__ flag, double *__restrict__ bt,
                                                          double *__restrict__ bc, double *__restrict__ ba,
                                                          double *__restrict__ bU, double *__restrict__ bV,
-                                                         double *__restrict__ by) {
+                                                         double *__restrict__ by, const double *__restrict__ fr_d,
+                                                         const double *__restrict__ fr_bd,
+                                                         const double *__restrict__ fr_bW) {
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
-  __shared__ __attribute__((aligned(16))) double vv[(C2_REV_APARK && G <= 8) ? 1 : C][3][kWave];
+  __shared__ __attribute__((aligned(16))) double vv[(C2_REV_APARK && G <= 8) ? 1 : C][4][kWave];  // [3] = bW_{n-1} (FR)
   // The replayed S_n columns wait for their reverse step in AGPRs (G <= 8: C*G*2 = 128 of them); wider groups
   // keep them in LDS, symmetric-packed.
   constexpr bool APARK = C2_REV_APARK && G <= 8;
   __shared__ __attribute__((aligned(16))) double sfL[APARK ? 1 : C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
   int sAlo[APARK ? C : 1][G], sAhi[APARK ? C : 1][G];
   int uAlo[APARK ? C : 1], uAhi[APARK ? C : 1], wAlo[APARK ? C : 1], wAhi[APARK ? C : 1];  // own U_n, W_{n-1}
+  int xAlo[(APARK && FR) ? C : 1], xAhi[(APARK && FR) ? C : 1];                               // own bW_{n-1} (FR)
   // per-series scalars of rows n_lo-1 .. n_lo+C-1 (entry e <-> row n_lo-1+e): t, d, 1/d, z
   __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
   // per-series scalar outputs of the segment, flushed transposed (lane j <-> row j): ba_n, bt_n, by_{n-1}
@@ -400,12 +407,17 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   const bool st = PAD ? (L.valid && act) : true, st0 = PAD ? (L.valid && j == 0) : true;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
   const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
-  const double2 *dzb = DZst + L.b0 * N + on;
-  const double *ckw = ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES;
+  const double2 *dzb = FR ? nullptr : DZst + L.b0 * N + on;
+  const double *ckw = FR ? nullptr : ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES;
+  const double *fdb = FR ? fr_d + L.b0 * N + on : nullptr, *fbdb = FR ? fr_bd + L.b0 * N + on : nullptr;
+  const double *fbWb = FR ? fr_bW + L.b0 * N * J + oj : nullptr;
+  const double *Scol = FR ? ckpt + (L.b0 + L.sl) * N * J * J + (int64_t)L.jj * J : nullptr;  // S[n, i + J j]: column j
   double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
   double *bUb = bU + L.b0 * N * J + oj, *bVb = bV + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
-  if (flag[L.b] != 0) return;  // failed factorisation: gradient undefined (uniform inside a group)
+  if constexpr (!FR) {
+    if (flag[L.b] != 0) return;  // failed factorisation: gradient undefined (uniform inside a group)
+  }
 
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
   soff[0] = lane;
@@ -423,8 +435,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   // row of the segment) is the previous iteration's entry 0 and is carried in registers.
   double vt[NV];
   double2 vdz[NV];
-  double iu[C], iw[C];
-  double cS[G], cF, cW;
+  double iu[C], iw[C], ibw[FR ? C : 1];
+  double cS[G], cF = 0.0, cW = 0.0, tck = 0.0;
   auto load_segment = [&](int64_t k) {
     const int64_t n_lo = 1 + k * C;
     const bool full = n_lo + C <= N;
@@ -432,21 +444,38 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     for (int m = 0; m < NV; ++m) {
       int64_t row = n_lo - 1 + m * G + j;
       row = (row < N) ? row : N - 1;
-      vt[m] = tb[row]; vdz[m] = dzb[row];
+      vt[m] = tb[row];
+      if constexpr (FR) vdz[m] = make_double2(fdb[row], fbdb[row]);  // (d, bd) take the place of (d, z)
+      else vdz[m] = dzb[row];
     }
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
       iu[r] = act ? Ub[n * J] : 0.0;
-      iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay)
+      iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1
+      if constexpr (FR) ibw[r] = act ? fbWb[(n - 1) * J] : 0.0;
     }
-    ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
+    if constexpr (FR) {
+      // checkpoint = row m = n_lo-1 of the caller's S workspace: S_ws[m] = diag(p_m)(S + d w^T w) (forward.hpp:120),
+      // the state after row m is S_ws[m] diag(p_m).  Column j in XOR order; row 0 of the workspace is zero.
+      const int64_t m = n_lo - 1;
+#pragma unroll
+      for (int kk = 0; kk < G; ++kk) {
+        const int i = j ^ kk;
+        cS[kk] = (m >= 1 && act && i < J) ? Scol[m * J * J + i] : 0.0;
+      }
+      tck = tb[m >= 1 ? m - 1 : 0];
+    } else {
+      ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
+    }
   };
 
   // entry `cnt` of the first processed segment = row N-1
   double carT = tb[N - 1];
-  double2 carDZ = dzb[N - 1];
+  double2 carDZ = FR ? make_double2(fdb[N - 1], fbdb[N - 1]) : dzb[N - 1];
   double carR = rcp_nr(carDZ.x);
+  // FR: the last row's W and bW (seeds: bV_{N-1} = bW_{N-1}/d_{N-1}, ba_{N-1} = bd_{N-1} - W_{N-1}.bV_{N-1})
+  const double wlast = (FR && act) ? Vb[(N - 1) * J] : 0.0, bwlast = (FR && act) ? fbWb[(N - 1) * J] : 0.0;
   if (nseg > 0) load_segment(nseg - 1);
   // -DC2_REV_TIMING: s_memtime deltas of the four phases, summed per wavefront into c2_dbg (tools/rev_phase_timing.py)
 #ifdef C2_REV_TIMING
@@ -483,9 +512,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         pown[r] = exp_decay(cj * dtv[r]);
         if constexpr (APARK) {  // the prefetch registers are refilled half way through phase C
           apark(iu[r], uAlo[r], uAhi[r]);
+          if constexpr (FR) apark(ibw[r], xAlo[r], xAhi[r]);
         } else {
           vv[r][0][lane] = pown[r];
           vv[r][1][lane] = iu[r];
+          if constexpr (FR) vv[r][3][lane] = ibw[r];
         }
       }
     }
@@ -493,8 +524,9 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     // F_n = P (F + w z) -- with d, 1/d, z on record there are no reductions and no division.  S_n columns and
     // the lane's own W_{n-1} are parked (AGPRs; LDS for G > 8), F_n and tau_n stay in registers.
     double SX[G];
+    const double pck = FR ? exp_decay(cj * (tck - rowT[0][grp])) : 1.0;  // FR: right scaling of the workspace row
 #pragma unroll
-    for (int i = 0; i < G; ++i) SX[i] = cS[i];
+    for (int i = 0; i < G; ++i) SX[i] = FR ? cS[i] * pck : cS[i];
     double F = cF;
     const double Wck = cW;  // W of the checkpointed row n_lo-1
     double Fp[C], tauS[C];
@@ -505,7 +537,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       if (r < cnt) {
         // W_{n-1} = (V_{n-1} - tau_{n-1}) / d_{n-1}, exactly as the forward pass formed it (forward.hpp:131)
         double wown = Wck;
-        if (r > 0) wown = (iw[r] - tauS[r > 0 ? r - 1 : 0]) * rowR[r][grp];
+        if constexpr (FR) wown = iw[r];  // W is an input of factor_rev
+        else if (r > 0) wown = (iw[r] - tauS[r > 0 ? r - 1 : 0]) * rowR[r][grp];
         if constexpr (APARK) apark(wown, wAlo[r], wAhi[r]);
         else vv[r][2][lane] = wown;
         double pX[G], uX[G], wX[G];
@@ -530,8 +563,10 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           else tau0 = fma(uX[i], sv, tau0);
         }
         tauS[r] = tau0 + tau1;
-        F = p * fma(w, rowZ[r][grp], F);
-        Fp[r] = F;
+        if constexpr (!FR) {
+          F = p * fma(w, rowZ[r][grp], F);
+          Fp[r] = F;
+        }
         if constexpr (APARK) {
 #pragma unroll
           for (int i = 0; i < G; ++i) apark(SX[i], sAlo[r][i], sAhi[r][i]);
@@ -550,10 +585,15 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     }
     if (k == nseg - 1) {  // cotangents of the last row: pure seeds
       const double rd = rowR[cnt][grp], z = rowZ[cnt][grp];
-      ban = 0.5 * rd * (z * z * rd - 1.0);
-      bzn = -z * rd;
-      bVn = 0.0;
-      if (st0) byb[N - 1] = bzn;
+      if constexpr (FR) {  // reverse.hpp:55-57 and step 6 of the last row (:65); z holds bd_{N-1}
+        bVn = bwlast * rd;
+        ban = z - gsum<G>(wlast * bwlast) * rd;
+      } else {
+        ban = 0.5 * rd * (z * z * rd - 1.0);
+        bzn = -z * rd;
+        bVn = 0.0;
+        if (st0) byb[N - 1] = bzn;
+      }
     }
     // entry 0 (row n_lo-1) is entry C of the next, earlier segment
     carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
@@ -568,8 +608,13 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
       if (r < cnt) {
         const int64_t n = n_lo + r;
-        const double Fpn = Fp[r];
-        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
+        const double Fpn = FR ? 0.0 : Fp[r];
+        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];  // FR: zm = bd_{n-1}
+        double bWm = 0.0;  // FR: the lane's own bW_{n-1}
+        if constexpr (FR) {
+          if constexpr (APARK) bWm = afetch(xAlo[r], xAhi[r]);
+          else bWm = vv[r][3][lane];
+        }
         double uX[G], pX[G], wX[G], bVX[G], Sf[G];
         // own value back from LDS, the rest of the group by DPP: on this chip a ds_read_b64 costs the issuing
         // wavefront ~13 cycles against ~10 for the two DPP moves (profiles/r01_ubench_instruction_costs.md)
@@ -599,10 +644,13 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         if (st) bVb[n * J] = bVn;
         xgather_dpp<G>(bVn, xB, lane, bVX);
         // solve_lower_rev part (internal.hpp:232-245)
-        const double bU1 = -bzn * Fpn;
-        bF = fma(-u, bzn, bF);
-        const double bp_s = Fpn * bF;
-        bF *= p;
+        double bU1 = 0.0, bp_s = 0.0;
+        if constexpr (!FR) {
+          bU1 = -bzn * Fpn;
+          bF = fma(-u, bzn, bF);
+          bp_s = Fpn * bF;
+          bF *= p;
+        }
         // factor_rev part (reverse.hpp:65-80).  With x = bV + 2 ba U (own lane: xv):
         //   bU2_j = -sum_i x_i S(i,j) = -(sum_i bV_i S(i,j) + 2 ba tau_j),  tau_j = sum_i U_i S(i,j)
         //   M    -= U^T y + y^T U  =  U^T x + bV^T U                         (y = bV + ba U)
@@ -628,15 +676,22 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           else q0 = fma(wX[i], MX[i], q0);
         }
         const double q = q0 + q1;
-        double f = cj * bp, Gs = wm * bF, Q = q * wm;
+        double f = cj * bp, Gs = wm * (FR ? bWm : bF), Q = q * wm;  // FR: Gs = W_{n-1} . bW_{n-1}
         gsum3<G>(f, Gs, Q);
         oBT[grp][r] = carry - f;
         carry = f;
-        const double zr = zm * rdm;
-        bzn = Gs - zr;
-        oBY[grp][r] = bzn;
-        bVn = fma(zr, bF, q);
-        ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+        if constexpr (FR) {
+          // bV_{n-1} = bW_{n-1}/d_{n-1} + w M (reverse.hpp:80); ba_{n-1} = bd_{n-1} + w bS w^T (:79) - W_{n-1}.bV_{n-1}
+          // (step 6 of the next row, :65) = bd_{n-1} - Q/2 - (W_{n-1}.bW_{n-1})/d_{n-1}
+          bVn = fma(bWm, rdm, q);
+          ban = zm - 0.5 * Q - Gs * rdm;
+        } else {
+          const double zr = zm * rdm;
+          bzn = Gs - zr;
+          oBY[grp][r] = bzn;
+          bVn = fma(zr, bF, q);
+          ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+        }
       }
     }
     lds_order();
@@ -648,7 +703,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       if ((G * NV == C || idx < C) && idx < cnt && (PAD ? L.valid : true)) {
         bab[n_lo + idx] = oBA[grp][idx];
         btb[n_lo + idx] = oBT[grp][idx];
-        byb[n_lo - 1 + idx] = oBY[grp][idx];
+        if constexpr (!FR) byb[n_lo - 1 + idx] = oBY[grp][idx];
       }
     }
     lds_order();
@@ -662,9 +717,14 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
 #endif
   if (nseg == 0) {  // N == 1
     const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;
-    ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);
-    bzn = -cz * rd0;
-    if (st0) byb[0] = bzn;
+    if constexpr (FR) {
+      bVn = bwlast * rd0;
+      ban = cz - gsum<G>(wlast * bwlast) * rd0;
+    } else {
+      ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);
+      bzn = -cz * rd0;
+      if (st0) byb[0] = bzn;
+    }
   }
   // row 0 (reverse.hpp:83-84)
   if (st0) { bab[0] = ban; btb[0] = carry; }
@@ -811,13 +871,13 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \
     if (J == G)                                                                                                   \
-      hipLaunchKernelGGL((k_loglik_rev<G, C, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, false, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
                          V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
-                         (const int32_t *)flag, bt, bc, ba, bU, bV, by);                                          \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr);               \
     else                                                                                                          \
-      hipLaunchKernelGGL((k_loglik_rev<G, C, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,   \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, true, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,   \
                          V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
-                         (const int32_t *)flag, bt, bc, ba, bU, bV, by);                                          \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr);               \
   } while (0)
   switch (G_) {
     case 1: C2_REV(1, C2_CKPT_C); break;
@@ -828,6 +888,39 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
     default: C2_REV(32, 2); break;
   }
 #undef C2_REV
+  return launch_ok();
+}
+
+// core::factor_rev on the segment-replay kernel (FR mode of k_loglik_rev): the caller's S workspace serves as the
+// checkpoint every C rows, everything in between is replayed from d and W.
+int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                  int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
+                                  const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
+                                  double *bV, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int G_ = group_size(J), C_ = ckpt_interval(G_);
+  const int64_t nseg = (N - 1 + C_ - 1) / C_;
+  const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+#define C2_FREV(G, C)                                                                                              \
+  do {                                                                                                             \
+    if (J == G)                                                                                                    \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, \
+                         U, W, (const double2 *)nullptr, S, nseg, (const int32_t *)nullptr, bt, bc, ba, bU, bV,    \
+                         (double *)nullptr, d, bd, bW);                                                            \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, true, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs,  \
+                         U, W, (const double2 *)nullptr, S, nseg, (const int32_t *)nullptr, bt, bc, ba, bU, bV,    \
+                         (double *)nullptr, d, bd, bW);                                                            \
+  } while (0)
+  switch (G_) {
+    case 1: C2_FREV(1, C2_CKPT_C); break;
+    case 2: C2_FREV(2, C2_CKPT_C); break;
+    case 4: C2_FREV(4, C2_CKPT_C); break;
+    case 8: C2_FREV(8, C2_CKPT_C); break;
+    case 16: C2_FREV(16, 4); break;
+    default: C2_FREV(32, 2); break;
+  }
+#undef C2_FREV
   return launch_ok();
 }
 

@@ -1087,6 +1087,11 @@ int c2_general_matmul_upper(int64_t B, int64_t N, int64_t M, int64_t J, int64_t 
 }
 
 // Internal: factor_rev with optional accumulation into bt/bc/bU (used by c2_loglik_grad).
+int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                  int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
+                                  const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
+                                  double *bV, c2_stream_t stream);
+
 int c2_factor_rev_acc(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                       const double *U, const double *d, const double *W, const double *S, const double *bd,
                       const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV, int accumulate,
@@ -1104,7 +1109,10 @@ int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs
                   const double *S, const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
                   double *bV, c2_stream_t stream) {
   (void)a; (void)V;  // unused by the reference as well (reverse.hpp:29-30)
-  return c2_factor_rev_acc(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, 0, stream);
+  if (int e = check_dims(B, N, J)) return e;
+  if (!t || !c || !U || !d || !W || !S || !bd || !bW || !bt || !bc || !ba || !bU || !bV) return C2_ERR_INVALID;
+  // the segment-replay kernel of the fused gradient, with the caller's S rows as checkpoints (c2_loglik.hip)
+  return c2_internal_factor_rev_replay(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, stream);
 }
 
 int c2_solve_lower_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,

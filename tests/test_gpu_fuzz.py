@@ -59,11 +59,19 @@ def test_fuzz_loglik_grad(ops, oracle, seed):
     ll0, flag0 = ops.loglik(td, cd, ad, Ud, Vd, yd)
     close(ll0[ok], llo[ok])
     d, W, flagf = ops.factor(td, cd, ad, Ud, Vd)
+    d2, W2, S2, _ = ops.factor(td, cd, ad, Ud, Vd, workspace=True)
+    bd = rng.standard_normal((B, N)); bW = rng.standard_normal((B, N, J))
+    bdd, bWd = dev(bd, bW)
+    res = ops.factor_rev(td, cd, ad, Ud, Vd, d2, W2, S2, bdd, bWd)   # segment replay from every 8th / 4th / 2nd S row
     for b in range(min(B, 3)):
-        do = np.empty(N); Wo = np.empty((N, J))
-        fo = oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo)
+        do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+        fo = oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So)
         if fo == 0:
-            close(d[b], do); close(W[b], Wo)
+            close(d[b], do); close(W[b], Wo); close(d2[b], do); close(W2[b], Wo); close(S2[b], So)
+            outs = [np.empty(N), np.empty(J), np.empty(N), np.empty((N, J)), np.empty((N, J))]
+            oracle.factor_rev(t[b], c[b], a[b], U[b], V[b], do, Wo, So, bd[b], bW[b], *outs)
+            for r_, e_ in zip(res, outs):
+                close(r_[b], e_)
 
 
 @pytest.mark.parametrize("seed", [s for (s,) in CASES])

@@ -12,8 +12,10 @@
 // aliasable pairs), which is the device equivalent of the reference's `tmp`
 // previous-row trick (internal.hpp:134-141).
 #include <cstdint>
+#include <type_traits>
 
 #include "c2_common.hpp"
+#include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
 namespace c2 {
@@ -189,6 +191,93 @@ __global__ __launch_bounds__(kWave) void k_factor(int64_t B, int64_t N, int J, c
     if (!alive) break;
   }
   if (st0) flag[L.b] = fl;
+}
+
+// -----------------------------------------------------------------------------
+// The S workspace of core::factor (forward.hpp:92-120) as a second, chain-free pass once d and W exist (they come
+// from the tuned fused kernel): S_ws[n] = diag(p_n)(T + d_{n-1} w_{n-1}^T w_{n-1}), T <- S_ws[n] diag(p_n) has no
+// reduction, no division and no dependence on d_n, so it runs at the speed of its stores.  Lane j owns column j in
+// natural order; rows leave through the LDS tile of s_row_store as dense 16-byte-per-lane runs.  J == G only.
+// Rows after a failed pivot stay untouched, like the reference's early return (forward.hpp:128).
+// -----------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(kWave) void k_s_replay(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                                    const double *__restrict__ c, int64_t c_bs,
+                                                    const double *__restrict__ d, const double *__restrict__ W,
+                                                    const int32_t *__restrict__ flag, double *__restrict__ S) {
+  constexpr int J = G, R = 8;
+  __shared__ __attribute__((aligned(16))) double gs[2][kWave];
+  __shared__ __attribute__((aligned(16))) double stile[kWave * G];
+  const int lane = threadIdx.x;
+  const Lane L = lane_of<G>(B);
+  const int j = L.j;
+  const double *tb = t + L.b * t_bs, *db = d + L.b * N, *Wb = W + L.b * N * J + j;
+  double *Srow = S + L.b * N * J * J;
+  const double cj = c[L.b * c_bs + j];
+  const int32_t fl = flag[L.b];
+  const int64_t nlast = fl ? (int64_t)fl : N - 1;  // the reference saves row n before it tests d_n
+  // the series of a wavefront run to the longest of their ranges (they differ only after a failed pivot)
+  int64_t nmax = nlast;
+  for (int o = G; o < kWave; o *= 2) {
+    const int64_t other = __shfl_xor((long long)nmax, o);
+    nmax = other > nmax ? other : nmax;
+  }
+  double Sc[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) Sc[i] = 0.0;
+  if (L.valid) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) Srow[j * J + i] = 0.0;  // S.row(0).setZero() (forward.hpp:92)
+  }
+  double rt[R], rdm[R], rw[R];
+  auto load_row = [&](int r, int64_t n) {
+    n = (n < N) ? n : N - 1;
+    n = (n >= 1) ? n : 1;
+    rt[r] = tb[n]; rdm[r] = db[n - 1]; rw[r] = Wb[(n - 1) * J];
+  };
+  if (N > 1) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+  }
+  double tprev = tb[0];
+  auto step = [&](int r, int64_t n, auto guarded_tag) {
+    constexpr bool GUARDED = decltype(guarded_tag)::value;
+    const double tn = rt[r], dw = rdm[r] * rw[r], w = rw[r];
+    load_row(r, n + R);
+    const double p = exp_decay(cj * (tprev - tn));
+    tprev = tn;
+    double wA[G], pA[G], sh[G];
+    lds_allgather<G>(gs[0], lane, w, wA);
+    lds_allgather<G>(gs[1], lane, p, pA);
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      sh[i] = pA[i] * fma(dw, wA[i], Sc[i]);  // diag(p) (S + d w^T w)   (forward.hpp:115-116)
+      Sc[i] = sh[i] * p;                      // S diag(p)               (forward.hpp:123)
+    }
+    if (!GUARDED || (L.valid && n <= nlast)) s_row_store<G>(stile, lane, sh, Srow + n * J * J);  // forward.hpp:120
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+  // Full blocks of a full wavefront run without a single branch: with row guards in the body the compiler can no
+  // longer count the stores behind a prefetched load and waits for ALL of them (vmcnt(0)) once per row.
+  int64_t nmin = nlast;
+  for (int o = G; o < kWave; o *= 2) {
+    const int64_t other = __shfl_xor((long long)nmin, o);
+    nmin = other < nmin ? other : nmin;
+  }
+  const bool wave_full = __all(L.valid);
+  int64_t n0 = 1;
+  if (wave_full) {
+    for (; n0 + R - 1 <= nmin; n0 += R) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) step(r, n0 + r, std::false_type{});
+    }
+  }
+  for (; n0 <= nmax; n0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (n0 + r <= nmax) step(r, n0 + r, std::true_type{});
+    }
+  }
 }
 
 // =============================================================================
@@ -1049,6 +1138,16 @@ int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (!S)  // no workspace requested: the tuned forward kernel of the fused log-likelihood doubles as factor
     return c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, stream);
   hipStream_t s = (hipStream_t)stream;
+  if ((J == 2 || J == 4 || J == 8 || J == 16) && ((uintptr_t)S) % 16 == 0) {
+    // d, W, flag from the tuned fused kernel, then the S rows by a chain-free replay (store-bound)
+    if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, stream)) return e;
+    C2_DISPATCH_G(group_size(J), {
+      if constexpr (G >= 2 && G <= 16)
+        hipLaunchKernelGGL(k_s_replay<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs,
+                           (const double *)d, (const double *)W, (const int32_t *)flag, S);
+    });
+    return check_launch();
+  }
   C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL(k_factor<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J, t,
                                                   t_bs, c, c_bs, a, U, V, d, W, S, flag));
   return check_launch();

@@ -831,33 +831,49 @@ __global__ __launch_bounds__(kWave) void k_gm_state(int64_t B, int64_t N, int64_
   };
 #pragma unroll
   for (int r = 0; r < PFG; ++r) load_row(r, 1 + r);
-  for (int64_t s0 = 1; s0 <= nsteps; s0 += PFG) {
+  auto step = [&](int r, int64_t s, auto plain_tag) {
+    constexpr bool PLAIN = decltype(plain_tag)::value;  // every lane stores its full tile: no store predicate
+    const int64_t m = LOWER ? s : M - 1 - s;
+    const double tm = rt[r], vm = rv[r];
+    double yk[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) yk[k] = ry[r][k];
+    load_row(r, s + PFG);
+    const double p = exp_decay(cj * (LOWER ? tprev - tm : tm - tprev));
+    tprev = tm;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) Fm[k] = fma(vm, yk[k], p * Fm[k]);
+    if (PLAIN || st) {
+      double *Fr = Fb + m * J * nrhs;
+      if (KT % 2 == 0 && vec2) {  // 16-byte stores: the lane's KT entries are contiguous in the row-major state
+#pragma unroll
+        for (int k = 0; k < KT; k += 2) reinterpret_cast<double2 *>(Fr)[k / 2] = make_double2(Fm[k], Fm[k + 1]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (PLAIN || k < kn) Fr[k] = Fm[k];
+      }
+    }
+  };
+  // Full blocks of a wavefront whose lanes all store run branch-free: behind a row guard the compiler cannot count
+  // the stores issued after a prefetched load and drains them all (s_waitcnt vmcnt(0)) once per row.
+  int64_t nmin = nsteps;
+  for (int o = G; o < kWave; o *= 2) {
+    const int64_t other = __shfl_xor((long long)nmin, o);
+    nmin = other < nmin ? other : nmin;
+  }
+  const bool plain = __all(st && kn == KT);
+  int64_t s0 = 1;
+  if (plain) {
+    for (; s0 + PFG - 1 <= nmin; s0 += PFG) {
+#pragma unroll
+      for (int r = 0; r < PFG; ++r) step(r, s0 + r, std::true_type{});
+    }
+  }
+  for (; s0 <= nsteps; s0 += PFG) {
 #pragma unroll
     for (int r = 0; r < PFG; ++r) {
-      const int64_t s = s0 + r;
-      if (s <= nsteps) {
-        const int64_t m = LOWER ? s : M - 1 - s;
-        const double tm = rt[r], vm = rv[r];
-        double yk[KT];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) yk[k] = ry[r][k];
-        load_row(r, s + PFG);
-        const double p = exp(cj * (LOWER ? tprev - tm : tm - tprev));
-        tprev = tm;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) Fm[k] = fma(vm, yk[k], p * Fm[k]);
-        if (st) {
-          double *Fr = Fb + m * J * nrhs;
-          if (KT % 2 == 0 && vec2) {  // 16-byte stores: the lane's KT entries are contiguous in the row-major state
-#pragma unroll
-            for (int k = 0; k < KT; k += 2) reinterpret_cast<double2 *>(Fr)[k / 2] = make_double2(Fm[k], Fm[k + 1]);
-          } else {
-#pragma unroll
-            for (int k = 0; k < KT; ++k)
-              if (k < kn) Fr[k] = Fm[k];
-          }
-        }
-      }
+      if (s0 + r <= nsteps) step(r, s0 + r, std::false_type{});
     }
   }
 }

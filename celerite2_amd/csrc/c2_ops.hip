@@ -344,32 +344,46 @@ __global__ __launch_bounds__(kWave) void k_sweep(int64_t B, int64_t N, int J, in
   if (Fb && st)
     for (int k = 0; k < kn; ++k) Fb[r0 * J * nrhs + J * k] = 0.0;  // internal.hpp:127 / 170
 
-  for (int64_t s0 = 1; s0 < N; s0 += PF) {
+  auto step = [&](int r, int64_t s, auto plain_tag) {
+    // PLAIN: a full rhs tile on a wavefront without padding lanes -- no store predicates at all (the G lanes of a
+    // group hold the same z and store it to the same address, which is harmless), hence no branches in the body.
+    constexpr bool PLAIN = decltype(plain_tag)::value;
+    const int64_t n = LOWER ? s : N - 1 - s;
+    const double tn = rt[r], bn = rb[r], an = ra[r];
+    double yk[KT], zk[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) { yk[k] = ry[r][k]; zk[k] = rz[r][k]; }
+    load_row(r, s + PF);
+    const double p = exp_decay(cj * (LOWER ? tprev - tn : tn - tprev));
+    tprev = tn;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      double f = fma(am, xprev[k], Fk[k]);
+      if (PLAIN) { if (Fb) Fb[n * J * nrhs + J * k] = f; }
+      else if (Fb && st && k < kn) Fb[n * J * nrhs + J * k] = f;  // F[n, j + J*k] before the decay (internal.hpp:142)
+      f *= p;
+      Fk[k] = f;
+      const double red = gsum<G>(bn * f);
+      const double znew = SOLVE ? yk[k] - red : zk[k] + red;
+      if (PLAIN || (st0 && k < kn)) Zb[n * nrhs + k] = znew;
+      xprev[k] = SOLVE ? znew : yk[k];
+    }
+    am = an;
+  };
+  // Full blocks of such wavefronts run branch-free: behind a row guard the compiler cannot count the stores issued
+  // after a prefetched load and drains them all (s_waitcnt vmcnt(0)) once per row.
+  const bool plain = __all(st && kn == KT);
+  int64_t s0 = 1;
+  if (plain) {
+    for (; s0 + PF <= N; s0 += PF) {
+#pragma unroll
+      for (int r = 0; r < PF; ++r) step(r, s0 + r, std::true_type{});
+    }
+  }
+  for (; s0 < N; s0 += PF) {
 #pragma unroll
     for (int r = 0; r < PF; ++r) {
-      const int64_t s = s0 + r;
-      if (s < N) {
-        const int64_t n = LOWER ? s : N - 1 - s;
-        const double tn = rt[r], bn = rb[r], an = ra[r];
-        double yk[KT], zk[KT];
-#pragma unroll
-        for (int k = 0; k < KT; ++k) { yk[k] = ry[r][k]; zk[k] = rz[r][k]; }
-        load_row(r, s + PF);
-        const double p = exp(cj * (LOWER ? tprev - tn : tn - tprev));
-        tprev = tn;
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          double f = fma(am, xprev[k], Fk[k]);
-          if (Fb && st && k < kn) Fb[n * J * nrhs + J * k] = f;  // F[n, j + J*k] before the decay (internal.hpp:142)
-          f *= p;
-          Fk[k] = f;
-          const double red = gsum<G>(bn * f);
-          const double znew = SOLVE ? yk[k] - red : zk[k] + red;
-          if (st0 && k < kn) Zb[n * nrhs + k] = znew;
-          xprev[k] = SOLVE ? znew : yk[k];
-        }
-        am = an;
-      }
+      if (s0 + r < N) step(r, s0 + r, std::false_type{});
     }
   }
 }

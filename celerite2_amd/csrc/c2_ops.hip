@@ -458,52 +458,63 @@ __global__ __launch_bounds__(kWave) void k_sweep_rev(int64_t B, int64_t N, int J
       for (int r = 0; r < PF; ++r) load_row(r, N - 1 - r);
     }
 
-    for (int64_t s0 = N - 1; s0 >= 1; s0 -= PF) {
+    auto step = [&](int r, int64_t s, auto plain_tag) {
+      // PLAIN: full rhs tile, no padding lanes -- no store predicates (group scalars are stored by all G lanes of the
+      // group to the same address with the same value), hence no branches and exact vmcnt waits
+      constexpr bool PLAIN = decltype(plain_tag)::value;
+      const int64_t n = LOWER ? s : N - 1 - s;
+      const int64_t m = LOWER ? n - 1 : n + 1;
+      const double dt = LOWER ? rtm[r] - rtn[r] : rtn[r] - rtm[r];
+      const double bn = rbn[r], am = ram[r];
+      double Fn[KT], Xm[KT], bzm[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) { Fn[k] = rF[r][k]; Xm[k] = rX[r][k]; bzm[k] = rbz[r][k]; }
+      load_row(r, s - PF);
+
+      const double p = exp_decay(cj * dt);
+      // reverse of update_z (internal.hpp:232-233 / 289-290)
+      double val = 0.0, dotFbF = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        val = fma(bz[k], p * Fn[k], val);
+        bF[k] = fma(sgn * bn, bz[k], bF[k]);
+        dotFbF = fma(Fn[k], bF[k], dotFbF);
+      }
+      if (PLAIN || st) bBb[n * J] = acc ? bBb[n * J] + sgn * val : sgn * val;
+      // reverse of the decay (internal.hpp:236-241 / 293-298)
+      const double bp = dotFbF * p;
+      bcj = fma(dt, bp, bcj);
+      const double f = gsum<G>(cj * bp);
+      if (PLAIN || st0) {
+        const double v = LOWER ? carry - f : f - carry;
+        btb[n] = acc ? btb[n] + v : v;
+      }
+      carry = f;
+      // update_f::reverse (internal.hpp:55-63 matmul, 76-84 solve)
+      double bam = 0.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        bF[k] *= p;
+        bam = fma(Xm[k], bF[k], bam);
+        const double g = gsum<G>(am * bF[k]);
+        const double out = SOLVE ? bzm[k] + g : g;
+        if (PLAIN || (st0 && k < kn)) bYb[m * nrhs + k0 + k] = out;
+        bz[k] = SOLVE ? out : bzm[k];
+      }
+      if (PLAIN || st) bAb[m * J] = acc ? bAb[m * J] + bam : bam;
+    };
+    const bool plain = __all(st && kn == KT);
+    int64_t s0 = N - 1;
+    if (plain) {
+      for (; s0 - PF + 1 >= 1; s0 -= PF) {
+#pragma unroll
+        for (int r = 0; r < PF; ++r) step(r, s0 - r, std::true_type{});
+      }
+    }
+    for (; s0 >= 1; s0 -= PF) {
 #pragma unroll
       for (int r = 0; r < PF; ++r) {
-        const int64_t s = s0 - r;
-        if (s >= 1) {
-          const int64_t n = LOWER ? s : N - 1 - s;
-          const int64_t m = LOWER ? n - 1 : n + 1;
-          const double dt = LOWER ? rtm[r] - rtn[r] : rtn[r] - rtm[r];
-          const double bn = rbn[r], am = ram[r];
-          double Fn[KT], Xm[KT], bzm[KT];
-#pragma unroll
-          for (int k = 0; k < KT; ++k) { Fn[k] = rF[r][k]; Xm[k] = rX[r][k]; bzm[k] = rbz[r][k]; }
-          load_row(r, s - PF);
-
-          const double p = exp(cj * dt);
-          // reverse of update_z (internal.hpp:232-233 / 289-290)
-          double val = 0.0, dotFbF = 0.0;
-#pragma unroll
-          for (int k = 0; k < KT; ++k) {
-            val = fma(bz[k], p * Fn[k], val);
-            bF[k] = fma(sgn * bn, bz[k], bF[k]);
-            dotFbF = fma(Fn[k], bF[k], dotFbF);
-          }
-          if (st) bBb[n * J] = acc ? bBb[n * J] + sgn * val : sgn * val;
-          // reverse of the decay (internal.hpp:236-241 / 293-298)
-          const double bp = dotFbF * p;
-          bcj = fma(dt, bp, bcj);
-          const double f = gsum<G>(cj * bp);
-          if (st0) {
-            const double v = LOWER ? carry - f : f - carry;
-            btb[n] = acc ? btb[n] + v : v;
-          }
-          carry = f;
-          // update_f::reverse (internal.hpp:55-63 matmul, 76-84 solve)
-          double bam = 0.0;
-#pragma unroll
-          for (int k = 0; k < KT; ++k) {
-            bF[k] *= p;
-            bam = fma(Xm[k], bF[k], bam);
-            const double g = gsum<G>(am * bF[k]);
-            const double out = SOLVE ? bzm[k] + g : g;
-            if (st0 && k < kn) bYb[m * nrhs + k0 + k] = out;
-            bz[k] = SOLVE ? out : bzm[k];
-          }
-          if (st) bAb[m * J] = acc ? bAb[m * J] + bam : bam;
-        }
+        if (s0 - r >= 1) step(r, s0 - r, std::false_type{});
       }
     }
     const int64_t mlast = LOWER ? 0 : N - 1;

@@ -637,3 +637,50 @@ def test_torch_autograd_ops(ops, oracle):
     a2 = a.copy(); a2[1, 7] = -4.0
     with pytest.raises(ag.LinAlgError):
         ag.factor(*dev(t, c, a2, U, V))
+
+
+def test_million_row_series(ops, oracle):
+    """N = 1.2e6 rows per series (64-bit row offsets everywhere, 150 000 checkpoint segments): fused log-lik + gradient,
+    single- and multi-rhs solves with their reverse, factor_rev from sparse checkpoints and the two-phase prediction
+    product against the oracle on one of the series."""
+    B, N, J = 3, 1_200_000, 4
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    b = 1
+    llo, go, flago = oracle.loglik_grad(t[b], c[b], a[b], U[b], V[b], y[b])
+    assert flago == 0
+    ll, grads, flag = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0
+    close(ll[b:b + 1], np.array([llo]))
+    for g, e in zip(grads, go):
+        close(g[b], e, 1e-9)
+    d, W, S, _ = ops.factor(td, cd, ad, Ud, Vd, workspace=True)
+    do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+    assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So) == 0
+    close(d[b], do); close(W[b], Wo); close(S[b], So)
+    rng = np.random.default_rng(8)
+    bd = rng.standard_normal((B, N)); bW = rng.standard_normal((B, N, J))
+    res = ops.factor_rev(td, cd, ad, Ud, Vd, d, W, S, *dev(bd, bW))
+    outs = [np.empty(N), np.empty(J), np.empty(N), np.empty((N, J)), np.empty((N, J))]
+    oracle.factor_rev(t[b], c[b], a[b], U[b], V[b], do, Wo, So, bd[b], bW[b], *outs)
+    for r_, e_ in zip(res, outs):
+        close(r_[b], e_, 1e-9)
+    for nrhs in (1, 6):
+        Y = rng.standard_normal((B, N, nrhs)); (Yd,) = dev(Y)
+        Zd, Fd = ops.solve_lower(td, cd, Ud, W, Yd, workspace=True)
+        Zo = np.empty((N, nrhs)); Fo = np.empty((N, J, nrhs))
+        oracle.solve_lower_fwd(t[b], c[b], U[b], Wo, Y[b], Zo, Fo)
+        close(Zd[b], Zo, 1e-9)
+        close(ops.solve_upper(td, cd, Ud, W, Yd)[b], oracle.solve_upper(t[b], c[b], U[b], Wo, Y[b], np.empty((N, nrhs))), 1e-9)
+        bZ = rng.standard_normal((B, N, nrhs)); (bZd,) = dev(bZ)
+        res = ops.solve_lower_rev(td, cd, Ud, W, Yd, Zd, Fd, bZd)
+        outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+        oracle.solve_lower_rev(t[b], c[b], U[b], Wo, Y[b], Zo, Fo, bZ[b], *outs)
+        for r_, e_ in zip(res, outs):
+            close(r_[b], e_, 1e-9)
+    M = 900_001
+    t2 = np.ascontiguousarray(t[:, :M]); V2 = np.ascontiguousarray(V[:, :M]); Y2 = rng.standard_normal((B, M, 1))
+    Zg = ops.general_matmul_lower(td, *dev(t2), cd, Ud, *dev(V2, Y2))
+    zo = np.zeros((N, 1))
+    oracle.general_matmul_lower(t[b], t2[b], c[b], U[b], V2[b], Y2[b], zo)
+    close(Zg[b], zo, 1e-9)

@@ -21,6 +21,9 @@
 namespace c2 {
 
 constexpr int PF = 4;  // prefetch distance (steps) of the register ring
+#ifndef C2_GM_TWO_PHASE_MAX_NRHS
+#define C2_GM_TWO_PHASE_MAX_NRHS 2
+#endif
 
 struct Lane {
   int64_t b;   // series index (clamped to B-1 for padding lanes)
@@ -1113,8 +1116,9 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   double *Fw = F;
   if (!Fw) {
     // without a caller workspace the state rows are pure overhead (2 x 8 J nrhs bytes per row): two phases pay off
-    // for one or two right-hand sides (prediction), the sequential merge moves fewer bytes beyond that
-    if (nrhs > 2 || fbytes > kGeneralTempMax || hipMallocAsync((void **)&Fw, fbytes, s) != hipSuccess) {
+    // for one or two right-hand sides (prediction); beyond that they only draw level with the sequential merge
+    // (22.5 against 24 ms at nrhs = 8, measured with -DC2_GM_TWO_PHASE_MAX_NRHS=64), which needs no scratch memory
+    if (nrhs > C2_GM_TWO_PHASE_MAX_NRHS || fbytes > kGeneralTempMax || hipMallocAsync((void **)&Fw, fbytes, s) != hipSuccess) {
       (void)hipGetLastError();
       C2_DISPATCH_G(group_size(J),
                     hipLaunchKernelGGL((k_general<G, KT, LOWER>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0,

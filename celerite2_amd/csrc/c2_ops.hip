@@ -1085,10 +1085,17 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
   }
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
     return c2_internal_sweep1(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
-  if (nrhs >= 5 && !F) {  // lanes over the right-hand sides (c2_sweep.hip) when the shape fits
+  if (nrhs >= 3 && !F) {  // lanes over the right-hand sides (c2_sweep.hip) when the shape fits
     const int e = c2_internal_sweepK(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z,
                                      stream);
     if (e != C2_ERR_UNSUPPORTED) return e;
+  }
+  if (nrhs == 2) {  // a full tile of two: the branch-free body
+    constexpr int KT = 2;
+    C2_DISPATCH_G(group_size(J),
+                  hipLaunchKernelGGL((k_sweep<G, KT, LOWER, SOLVE>), grid_for(B, G, 1), dim3(kWave), 0, s, B, N, (int)J,
+                                     nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z));
+    return check_launch();
   }
   constexpr int KT = 4;
   C2_DISPATCH_G(group_size(J),

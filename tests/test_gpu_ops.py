@@ -493,7 +493,7 @@ def test_single_rhs_sweeps(ops, oracle, J, N):
 
 @pytest.mark.parametrize("J,nrhs", [(8, 5), (8, 8), (3, 8), (16, 8), (16, 20), (32, 33), (8, 64), (6, 70), (32, 7)])
 def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
-    """nrhs >= 5 takes the kernel with lanes over the right-hand sides (c2_sweep.hip) when J fits the lanes of a
+    """nrhs >= 3 takes the kernel with lanes over the right-hand sides (c2_sweep.hip) when J fits the lanes of a
     series, the generic kernel otherwise ((16, 8), (32, 7)): all four sweeps with the F workspace, in place,
     accumulating, with ragged rhs tiles (70 = 64 + 6) and a ragged last wavefront."""
     B, N = 5, 131

@@ -268,16 +268,19 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
 // as dense runs.  What every lane needs per step are the three width-J vectors p_n, A_{n-1}, B_n: lane j (< J)
 // loads / computes element j, they are staged in LDS and read back as broadcasts (ds_read_b128, 3J/2 per step).
 // Same semantics as k_sweep (internal.hpp:105-189): in-place Z == Y is legal (rows are read R steps ahead of the
-// row being written), matmul accumulates into Z unless zero_z.  The F workspace variant stays on k_sweep: here a
-// lane's J entries of F[n, j + J k] would leave as 16-byte pieces of 64 separate lines (measured 12 ms against 9).
+// row being written), matmul accumulates into Z unless zero_z.
 // -----------------------------------------------------------------------------------------------------------------
-template <int KL, int JM, int R, bool LOWER, bool SOLVE>
+// WF: also write the F workspace.  Shapes with nrhs == KL and J == JM only (the launcher checks): a row of F is then
+// KL x J doubles, lane k holding the J consecutive entries F[n, j + J k]; they leave through an LDS tile as dense
+// 16-byte-per-lane runs (stored straight from the lanes they would be 16-byte pieces of 64 separate lines).
+template <int KL, int JM, int R, bool LOWER, bool SOLVE, bool WF>
 __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, int64_t nrhs, const double *t, int64_t t_bs,
                                                   const double *__restrict__ c, int64_t c_bs, const double *U,
-                                                  const double *V, const double *Y, double *Z, int zero_z) {
+                                                  const double *V, const double *Y, double *Z, double *F, int zero_z) {
   static_assert(JM <= KL, "the lanes of a series also carry its width-J vectors");
   constexpr int SPW = kWave / KL;
   __shared__ __attribute__((aligned(16))) double rowbuf[2][SPW][3][KL];  // p_n, A_{n-1}, B_n of two consecutive steps
+  __shared__ __attribute__((aligned(16))) double ftile[WF ? SPW * KL * JM : 2];
   const int lane = threadIdx.x, sl = lane / KL, k = lane % KL;
   int64_t b = (int64_t)blockIdx.x * SPW + sl;
   const bool vb = b < B;
@@ -295,12 +298,18 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
   double *zb = Z + b * N * nrhs + kk;
   const double cj = actj ? c[b * c_bs + k] : 0.0;
   auto rowof = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
+  double *Frow = WF ? F + b * N * (int64_t)(KL * JM) : nullptr;  // WF: nrhs == KL, J == JM
 
   const int64_t r0 = rowof(0);
   double xprev = yb[r0 * nrhs];
   if (vk) {
     if (SOLVE) zb[r0 * nrhs] = xprev;        // forward.hpp:168, 205
     else if (zero_z) zb[r0 * nrhs] = 0.0;
+  }
+  if (WF && vb) {  // internal.hpp:127 / :170
+#pragma unroll
+    for (int qq = 0; qq < JM / 2; ++qq)
+      *reinterpret_cast<double2 *>(Frow + r0 * (KL * JM) + qq * 2 * KL + 2 * k) = make_double2(0.0, 0.0);
   }
   double aprev = actj ? Ab[r0 * J] : 0.0;
   double tprev = tb[r0];
@@ -355,7 +364,20 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
             Fj[j + 1] = p2.y * f1;
             red = fma(b2.y, Fj[j + 1], red);
           }
-
+          if constexpr (WF)  // saved before the decay (internal.hpp:142 / :185)
+            *reinterpret_cast<double2 *>(&ftile[(sl * KL + k) * JM + j]) = make_double2(f0, f1);
+        }
+        if constexpr (WF) {
+          lds_order();
+          if (vb) {
+#pragma unroll
+            for (int qq = 0; qq < JM / 2; ++qq) {
+              const int e = qq * 2 * KL + 2 * k;
+              *reinterpret_cast<double2 *>(Frow + n * (KL * JM) + e) =
+                  *reinterpret_cast<const double2 *>(&ftile[sl * KL * JM + e]);
+            }
+          }
+          lds_order();
         }
         const double zn = SOLVE ? yn - red : zin + red;  // internal.hpp:144 / :187
         if (vk) zb[n * nrhs] = zn;
@@ -445,21 +467,26 @@ extern "C" int c2_internal_sweep1_rev(int lower, int solve, int64_t B, int64_t N
 // mapping (J wider than the lanes of a series); the caller then takes the generic kernel.
 extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
                                   int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
-                                  const double *Y, double *Z, int zero_z, c2_stream_t stream) {
+                                  const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   int KL = 8;
   while (KL < 64 && KL < nrhs) KL *= 2;
   const int JM = J <= 8 ? 8 : (J <= 16 ? 16 : 32);
   if (JM > KL) return C2_ERR_UNSUPPORTED;
+  // the F workspace goes through the LDS tile: whole rows only
+  if (F && !(nrhs == KL && J == JM && ((uintptr_t)F) % 16 == 0)) return C2_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((B + (kWave / KL) - 1) / (kWave / KL)), (unsigned)((nrhs + KL - 1) / KL));
+#define C2_SK1(KL_, JM_, LO, SO)                                                                                     \
+  do {                                                                                                               \
+    if (F) hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, LO, SO, true>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z);  \
+    else hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z); \
+  } while (0)
 #define C2_SK(KL_, JM_)                                                                                              \
   do {                                                                                                               \
     if (lower) {                                                                                                     \
-      if (solve) hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, true, true>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);   \
-      else hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, true, false>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);        \
+      if (solve) C2_SK1(KL_, JM_, true, true); else C2_SK1(KL_, JM_, true, false);                                  \
     } else {                                                                                                         \
-      if (solve) hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);  \
-      else hipLaunchKernelGGL((k_sweepK<KL_, JM_, 8, false, false>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, zero_z);       \
+      if (solve) C2_SK1(KL_, JM_, false, true); else C2_SK1(KL_, JM_, false, false);                                \
     }                                                                                                                \
   } while (0)
   switch (KL * 100 + JM) {
@@ -474,5 +501,6 @@ extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, in
     default: C2_SK(64, 32); break;
   }
 #undef C2_SK
+#undef C2_SK1
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }

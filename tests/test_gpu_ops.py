@@ -491,7 +491,7 @@ def test_single_rhs_sweeps(ops, oracle, J, N):
         close(Zs[b], zo, 1e-9)
 
 
-@pytest.mark.parametrize("J,nrhs", [(8, 5), (8, 8), (3, 8), (16, 8), (16, 20), (32, 33), (8, 64), (6, 70), (32, 7)])
+@pytest.mark.parametrize("J,nrhs", [(8, 5), (8, 8), (3, 8), (16, 8), (16, 16), (16, 20), (32, 32), (32, 33), (8, 64), (6, 70), (32, 7), (8, 3)])
 def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
     """nrhs >= 3 takes the kernel with lanes over the right-hand sides (c2_sweep.hip) when J fits the lanes of a
     series, the generic kernel otherwise ((16, 8), (32, 7)): all four sweeps with the F workspace, in place,

@@ -36,15 +36,45 @@ def algorithmic_bytes_per_gp(N, J, grad):
 
 
 def measured_traffic(grad, Bp, N, J):
-    """HBM bytes per step from the committed rocprofv3 PMC measurement of this exact workload (profiles/), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            for w in json.load(f)["workloads"]:
-                if (w["mode"] == ("grad" if grad else "fwd") and w["batch_per_gpu"] == Bp and w["N"] == N and w["J"] == J):
-                    return w["traffic_bytes_per_step"]
-    except Exception:
-        pass
+    """HBM bytes per step from the committed rocprofv3 PMC measurement of this exact workload (profiles/, newest
+    round first), or None."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                for w in json.load(f)["workloads"]:
+                    if (w["mode"] == ("grad" if grad else "fwd") and w["batch_per_gpu"] == Bp and w["N"] == N
+                            and w["J"] == J):
+                        return w["traffic_bytes_per_step"]
+        except Exception:
+            pass
     return None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: re-exec this script under torch.distributed.run, one rank per
+    GPU.  Refuses (rc 2) when fewer than N devices are visible -- never a silent one-GPU run."""
+    import socket
+    import subprocess
+
+    import torch
+
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    oversub = os.environ.get("C2_DIST_BACKEND", "nccl") != "nccl"  # test mode: several gloo ranks on one device
+    if ndev < 1 or (ndev < args.gpus and not oversub):
+        sys.stderr.write("bench.py: --gpus %d requested but %d HIP device(s) visible; refusing to run a smaller job\n"
+                         % (args.gpus, ndev))
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(N, J, grad, seconds):
@@ -53,7 +83,7 @@ def cpu_baseline(N, J, grad, seconds):
 
     from oracle import cpu, dense
 
-    cpu.build()
+    cpu.build_native()  # -march=native, compiled on the host that times it; portable build if that fails
     cores = os.cpu_count() or 1
     nthreads = min(cores, cpu.num_threads()) or 1
     # build matrices on the host with the numpy recipe (this is the checker side)
@@ -72,8 +102,10 @@ def cpu_baseline(N, J, grad, seconds):
     t0 = time.perf_counter(); fn(T[:n1], C[:n1], A[:n1], U[:n1], V[:n1], Y[:n1], nthreads=1); dt_1 = time.perf_counter() - t0
     return {
         "value": count / dt_all, "unit": "GP/s", "cores": nthreads, "kind": "port",
-        "sample": "%d series of N=%d J=%d (%s), CPU restatement of celerite2 recursions (Eigen unavailable), "
-                  "OpenMP over the batch" % (count, N, J, "fwd+grad" if grad else "fwd"),
+        "sample": "%d series of N=%d J=%d (%s), CPU restatement of celerite2 recursions (Eigen unavailable; a "
+                  "baseline, not a target: the 2 MiB/series S workspace thrashes the caches with all cores busy), "
+                  "g++ %s, %d OpenMP threads over the batch of %d host cores"
+                  % (count, N, J, "fwd+grad" if grad else "fwd", cpu.build_flags(), nthreads, cores),
         "single_thread_value": n1 / dt_1,
     }
 
@@ -90,7 +122,12 @@ def main():
     ap.add_argument("--mode", choices=["grad", "fwd"], default="grad")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-synth", action="store_true",
+                    help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
+    ap.add_argument("--dump-ll", default="", help="rank 0 saves the gathered log-likelihood vector here (.npy)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -100,18 +137,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
+    if world != args.gpus:
+        raise SystemExit("--gpus %d must equal WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     # one process per GPU; C2_DIST_BACKEND=gloo (+ several ranks on one device) exists only to exercise this
     # multi-rank path on a single-GPU box -- the real runs use RCCL ("nccl" backend on ROCm)
     backend = os.environ.get("C2_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d HIP device(s) visible" % (world, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # C2_FORCE_DIST=1: initialise the process group and run the gather even with ONE rank -- lets a single-GPU box
+    # execute the real RCCL communicator setup + all-gather on device tensors (tests/test_gpu_bench.py)
+    dist_on = world > 1 or os.environ.get("C2_FORCE_DIST", "0") == "1"
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -124,7 +168,8 @@ def main():
     N, J = args.N, args.J
     grad = args.mode == "grad"
     # shard: contiguous block of series per rank, generated directly on the owning GPU
-    t, c, a, U, V, y = synth.device_batch_fast(first, Bp, N, J, dev)
+    make = synth.device_batch if args.exact_synth else synth.device_batch_fast
+    t, c, a, U, V, y = make(first, Bp, N, J, dev)
     if grad:
         work = ops.loglik_grad_workspace(Bp, N, J, dev)
         out = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
@@ -136,18 +181,18 @@ def main():
             ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
         else:
             ll, flag = ops.loglik(t, c, a, U, V, y)
-        if world > 1:  # the path's only exchange: B/n_gpu log-liks per rank
+        if dist_on:  # the path's only exchange: B/n_gpu log-liks per rank
             if backend == "nccl":
-                ll = parallel.gather_loglik(ll, Btot, world)
+                ll = parallel.gather_loglik(ll, Btot, world, force=True)
             else:
-                ll = parallel.gather_loglik(ll.cpu(), Btot, world).to(dev)
+                ll = parallel.gather_loglik(ll.cpu(), Btot, world, force=True).to(dev)
         return ll, flag
 
     for _ in range(args.warmup):
         ll, flag = step()
     torch.cuda.synchronize()
     nfail = int((flag != 0).sum())
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -157,17 +202,21 @@ def main():
         ll, flag = step()
         ev[i][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
     kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
 
+    if rank == 0 and args.dump_ll:
+        import numpy as np
+
+        np.save(args.dump_ll, ll.detach().cpu().numpy())
     if rank == 0:
         total_gps = Btot * args.steps
         value = total_gps / elapsed
@@ -192,7 +241,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, J, grad, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

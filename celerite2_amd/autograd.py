@@ -38,11 +38,16 @@ class _LogLik(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        # A series whose factorisation failed has ll = -inf and NaN gradients (c2_loglik_grad, celerite2_amd.h).
+        # A series that receives a ZERO cotangent contributes exactly zero -- so masking failed series out of the
+        # objective keeps the batch-summed gradients of a shared t / c finite; left in, they turn NaN, never garbage.
         bt, bc, ba, bU, bV, by = ctx.saved_tensors
         g1, g2 = g[:, None], g[:, None, None]
-        gt = (bt * g1).sum(0) if ctx.shared_t else bt * g1
-        gc = (bc * g1).sum(0) if ctx.shared_c else bc * g1
-        return gt, gc, ba * g1, bU * g2, bV * g2, by * g1
+        z1, z2 = g1 == 0, g2 == 0
+        sc = lambda x, gg, zz: torch.where(zz, torch.zeros((), dtype=x.dtype, device=x.device), x * gg)
+        gt = sc(bt, g1, z1).sum(0) if ctx.shared_t else sc(bt, g1, z1)
+        gc = sc(bc, g1, z1).sum(0) if ctx.shared_c else sc(bc, g1, z1)
+        return gt, gc, sc(ba, g1, z1), sc(bU, g2, z2), sc(bV, g2, z2), sc(by, g1, z1)
 
 
 def log_likelihood(t, c, a, U, V, y):

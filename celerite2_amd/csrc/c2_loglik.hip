@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
         prod *= d;
         quad = fma(z * z, rd, quad);
-        if (r % 8 == 7 || r == R - 1) {  // renormalise at least once per block (R = 4 for the widest groups)
+        if (r % 2 == 1 || r == R - 1) {  // renormalise every second row: safe for pivots in 1e-150 .. 1e150
           int e;
           prod = frexp(prod, &e);
           eacc += e;
@@ -416,7 +416,20 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   double *bUb = bU + L.b0 * N * J + oj, *bVb = bV + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
   if constexpr (!FR) {
-    if (flag[L.b] != 0) return;  // failed factorisation: gradient undefined (uniform inside a group)
+    // Failed factorisation (uniform inside a group): the reference raises (driver.hpp:13-19), the batched kernel
+    // reports it through flag[b] / ll[b] = -inf and fills the six gradients of THAT series with NaN -- never
+    // stale memory -- so that a sum over the batch (shared t or c) cannot silently absorb garbage.
+    if (flag[L.b] != 0) {
+      const double nan = __builtin_nan("");
+      for (int64_t n = j; n < N; n += G) {
+        if (PAD ? L.valid : true) { btb[n] = nan; bab[n] = nan; byb[n] = nan; }
+      }
+      for (int64_t n = 0; n < N; ++n) {
+        if (st) { bUb[n * J] = nan; bVb[n * J] = nan; }
+      }
+      if (st) bc[L.b * J + j] = nan;
+      return;
+    }
   }
 
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
         fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
         prod *= d;
         quad = fma(z * z, rd, quad);
-        if (r % 8 == 7 || r == R - 1) {
+        if (r % 2 == 1 || r == R - 1) {  // renormalise every second row: safe for pivots in 1e-150 .. 1e150
           int e;
           prod = frexp(prod, &e);
           eacc += e;
@@ -328,7 +328,15 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik4_rev(int64_t B, int64_t N, 
   double2 *bUb = reinterpret_cast<double2 *>(bU + L.b0 * N * J + oj);
   double2 *bVb = reinterpret_cast<double2 *>(bV + L.b0 * N * J + oj);
   const double cj[2] = {c[L.b * c_bs + 2 * jl], c[L.b * c_bs + 2 * jl + 1]};
-  if (flag[L.b] != 0) return;
+  if (flag[L.b] != 0) {  // failed factorisation: NaN gradients for this series (see k_loglik_rev)
+    const double nan = __builtin_nan("");
+    if (L.valid) {
+      for (int64_t n = jl; n < N; n += LG) { btb[n] = nan; bab[n] = nan; byb[n] = nan; }
+      for (int64_t n = 0; n < N; ++n) { bUb[n * LG] = make_double2(nan, nan); bVb[n * LG] = make_double2(nan, nan); }
+      bc[L.b * J + 2 * jl] = nan; bc[L.b * J + 2 * jl + 1] = nan;
+    }
+    return;
+  }
 
   int boff[LG];
 #pragma unroll

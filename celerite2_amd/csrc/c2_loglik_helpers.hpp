@@ -31,7 +31,7 @@ __device__ __forceinline__ double fma_sconst(double q, double r, double c) {
   return o;
 }
 __device__ __forceinline__ double exp_decay(double x) {
-  x = fmax(x, -1000.0);
+  x = (x < -1000.0) ? -1000.0 : x;  // clamp the underflow range; a NaN in t or c propagates (fmax would drop it)
   const double k = rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
   r = fma(k, -1.90821492927058770002e-10, r);

@@ -42,6 +42,8 @@ class GaussianProcess:
             raise ValueError("'diag' or 'yerr' (B, N) is required: it defines the batch")
         if diag.dim() != 2:
             raise ValueError("diag / yerr must be (B, N)")
+        if t.shape[-1] != diag.shape[-1] or (t.dim() == 2 and t.shape[0] != diag.shape[0]):
+            raise ValueError("Invalid shape: t %s does not match diag %s" % (tuple(t.shape), tuple(diag.shape)))
         self._t, self._diag = t.contiguous(), diag.contiguous()
         self._size = t.shape[-1]
         self._c, self._a, self._U, self._V = self.kernel.get_celerite_matrices(self._t, self._diag)
@@ -59,13 +61,20 @@ class GaussianProcess:
         if self._t is None:
             raise RuntimeError("you must call 'compute' first")
 
-    @staticmethod
-    def _as_matrix(y):
+    def _as_matrix(self, y):
+        if y.dim() not in (2, 3) or tuple(y.shape[:2]) != tuple(self._diag.shape):
+            raise ValueError("Invalid shape: y %s, expected (B, N) or (B, N, nrhs) with (B, N) = %s"
+                             % (tuple(y.shape), tuple(self._diag.shape)))
         return (y[..., None], True) if y.dim() == 2 else (y, False)
+
+    def _check_vector(self, y):
+        if tuple(y.shape) != tuple(self._diag.shape):  # core.py:312-330 (_process_input)
+            raise ValueError("Invalid shape: y %s, expected (B, N) = %s" % (tuple(y.shape), tuple(self._diag.shape)))
 
     # -- core.py:407-428 + numpy.py:104-109 -------------------------------------------------------------
     def log_likelihood(self, y):
         self._need()
+        self._check_vector(y)
         r = (y - self.mean)[..., None].contiguous()
         z = ops.solve_lower(self._t, self._c, self._U, self._W, r)[..., 0]
         return self._norm - 0.5 * (z * z / self._d).sum(dim=1)
@@ -73,12 +82,14 @@ class GaussianProcess:
     def log_likelihood_fused(self, y):
         """Same value straight from the one-pass fused kernel (no d / W / z materialised)."""
         self._need()
+        self._check_vector(y)
         ll, flag = ops.loglik(self._t, self._c, self._a, self._U, self._V, (y - self.mean).contiguous())
         return ll
 
     def log_likelihood_and_grad(self, y, work=None):
         """(ll, (bt, bc, ba, bU, bV, by), flag): gradients w.r.t. the celerite matrices and the data."""
         self._need()
+        self._check_vector(y)
         return ops.loglik_grad(self._t, self._c, self._a, self._U, self._V, (y - self.mean).contiguous(), work=work)
 
     # -- core.py:342-376 + numpy.py:94-98 ----------------------------------------------------------------
@@ -111,6 +122,7 @@ class GaussianProcess:
     # -- conditional mean, core.py:115-132 + numpy.py:15-22 ----------------------------------------------
     def predict(self, y, t=None, *, include_mean=True):
         self._need()
+        self._check_vector(y)
         alpha = self.apply_inverse(y - self.mean)
         if t is None:
             mu = y - self._diag * alpha

@@ -32,11 +32,26 @@ def _stream():
 
 
 def _chk(*xs):
+    dev = None
     for x in xs:
         if x is None:
             continue
         if not (x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()):
             raise ValueError("celerite2_amd ops need contiguous float64 tensors on the GPU")
+        if dev is None:
+            dev = x.device
+        elif x.device != dev:
+            raise ValueError("celerite2_amd ops need every tensor on the same device")
+
+
+def _shape(name, x, *allowed):
+    """The reference raises "Invalid shape: <name>" for every argument (driver.cpp:40-46,94-99); so does this layer,
+    BEFORE any pointer reaches a kernel (the kernels compute their strides from (B, N, J, nrhs) alone)."""
+    if x is None:
+        return
+    if tuple(x.shape) not in allowed:
+        raise ValueError("Invalid shape: %s (got %s, expected %s)"
+                         % (name, tuple(x.shape), " or ".join(str(a) for a in allowed)))
 
 
 def _bs(x, per):
@@ -59,6 +74,8 @@ def factor(t, c, a, U, V, d=None, W=None, S=None, *, workspace=False):
         S = torch.empty((B, N, J, J), dtype=torch.float64, device=U.device)
     flag = torch.empty(B, dtype=torch.int32, device=U.device)
     _chk(t, c, a, U, V, d, W, S)
+    _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("a", a, (B, N)); _shape("V", V, (B, N, J))
+    _shape("d", d, (B, N)); _shape("W", W, (B, N, J)); _shape("S", S, (B, N, J, J))
     rc = _lib.load().c2_factor(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
                                _p(U), _p(V), _p(d), _p(W), _p(S), _p(flag), _stream())
     _lib.check(rc, "factor")
@@ -68,12 +85,16 @@ def factor(t, c, a, U, V, d=None, W=None, S=None, *, workspace=False):
 def _sweep(name, matmul):
     def op(t, c, U, W, Y, Z=None, F=None, *, workspace=False, zero_z=False):
         B, N, J = _dims(U)
+        if Y.dim() != 3:
+            raise ValueError("Invalid shape: Y (must be (B, N, nrhs))")
         nrhs = Y.shape[-1]
         if Z is None:
             Z = torch.zeros_like(Y) if matmul else torch.empty_like(Y)
         if workspace and F is None:
             F = torch.empty((B, N, J, nrhs), dtype=torch.float64, device=U.device)
         _chk(t, c, U, W, Y, Z, F)
+        _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("W", W, (B, N, J))
+        _shape("Y", Y, (B, N, nrhs)); _shape("Z", Z, (B, N, nrhs)); _shape("F", F, (B, N, J, nrhs))
         args = [_i64(B), _i64(N), _i64(J), _i64(nrhs), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(U), _p(W),
                 _p(Y), _p(Z), _p(F)]
         if matmul:
@@ -94,12 +115,17 @@ matmul_upper = _sweep("matmul_upper", True)
 def _general(name):
     def op(t1, t2, c, U, V, Y, Z=None, F=None, *, workspace=False, zero_z=False):
         B, N, J = _dims(U)
+        if V.dim() != 3 or Y.dim() != 3:
+            raise ValueError("Invalid shape: V must be (B, M, J) and Y (B, M, nrhs)")
         M, nrhs = V.shape[1], Y.shape[-1]
         if Z is None:
             Z = torch.zeros((B, N, nrhs), dtype=torch.float64, device=U.device)
         if workspace and F is None:
             F = torch.zeros((B, M, J, nrhs), dtype=torch.float64, device=U.device)
         _chk(t1, t2, c, U, V, Y, Z, F)
+        _shape("t1", t1, (N,), (B, N)); _shape("t2", t2, (M,), (B, M)); _shape("c", c, (J,), (B, J))
+        _shape("V", V, (B, M, J)); _shape("Y", Y, (B, M, nrhs)); _shape("Z", Z, (B, N, nrhs))
+        _shape("F", F, (B, M, J, nrhs))
         rc = getattr(_lib.load(), "c2_" + name)(
             _i64(B), _i64(N), _i64(M), _i64(J), _i64(nrhs), _p(t1), _i64(_bs(t1, N)), _p(t2), _i64(_bs(t2, M)), _p(c),
             _i64(_bs(c, J)), _p(U), _p(V), _p(Y), _p(Z), _p(F), ctypes.c_int(1 if zero_z else 0), _stream())
@@ -122,6 +148,9 @@ def factor_rev(t, c, a, U, V, d, W, S, bd, bW):
     bU = torch.empty_like(U)
     bV = torch.empty_like(U)
     _chk(t, c, a, U, V, d, W, S, bd, bW)
+    _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("a", a, (B, N)); _shape("V", V, (B, N, J))
+    _shape("d", d, (B, N)); _shape("W", W, (B, N, J)); _shape("S", S, (B, N, J, J)); _shape("bd", bd, (B, N))
+    _shape("bW", bW, (B, N, J))
     rc = _lib.load().c2_factor_rev(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
                                    _p(U), _p(V), _p(d), _p(W), _p(S), _p(bd), _p(bW), _p(bt), _p(bc), _p(ba), _p(bU),
                                    _p(bV), _stream())
@@ -132,6 +161,8 @@ def factor_rev(t, c, a, U, V, d, W, S, bd, bW):
 def _sweep_rev(name):
     def op(t, c, U, W, Y, Z, F, bZ):
         B, N, J = _dims(U)
+        if Y.dim() != 3:
+            raise ValueError("Invalid shape: Y (must be (B, N, nrhs))")
         nrhs = Y.shape[-1]
         dev = U.device
         bt = torch.empty((B, N), dtype=torch.float64, device=dev)
@@ -140,6 +171,9 @@ def _sweep_rev(name):
         bW = torch.empty_like(U)
         bY = torch.empty_like(Y)
         _chk(t, c, U, W, Y, Z, F, bZ)
+        _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("W", W, (B, N, J))
+        _shape("Y", Y, (B, N, nrhs)); _shape("Z", Z, (B, N, nrhs)); _shape("F", F, (B, N, J, nrhs))
+        _shape("bZ", bZ, (B, N, nrhs))
         rc = getattr(_lib.load(), "c2_" + name)(
             _i64(B), _i64(N), _i64(J), _i64(nrhs), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(U), _p(W), _p(Y),
             _p(Z), _p(F), _p(bZ), _p(bt), _p(bc), _p(bU), _p(bW), _p(bY), _stream())
@@ -157,6 +191,8 @@ matmul_upper_rev = _sweep_rev("matmul_upper_rev")
 
 def get_celerite_matrices(ar, ac, bc, dc, x, diag):
     """Batched driver.get_celerite_matrices.  ar (Jr,)|(B,Jr); ac,bc,dc (Jc,)|(B,Jc); x (N,)|(B,N); diag (B,N)."""
+    if diag.dim() != 2:
+        raise ValueError("Invalid shape: diag (must be (B, N))")
     B, N = diag.shape
     Jr, Jc = ar.shape[-1], ac.shape[-1]
     J = Jr + 2 * Jc
@@ -168,6 +204,10 @@ def get_celerite_matrices(ar, ac, bc, dc, x, diag):
     U = torch.empty((B, N, J), dtype=torch.float64, device=dev)
     V = torch.empty((B, N, J), dtype=torch.float64, device=dev)
     _chk(ar, ac, bc, dc, x, diag)
+    _shape("x", x, (N,), (B, N))
+    _shape("ar", ar, (Jr,), (B, Jr))
+    for nm, v in (("ac", ac), ("bc", bc), ("dc", dc)):
+        _shape(nm, v, (Jc,), (B, Jc))
     rc = _lib.load().c2_get_celerite_matrices(
         _i64(B), _i64(N), _i64(Jr), _i64(Jc), _p(ar if Jr else None), _p(ac if Jc else None), _p(bc if Jc else None),
         _p(dc if Jc else None), ctypes.c_int(1 if batched else 0), _p(x), _i64(_bs(x, N)), _p(diag), _p(a), _p(U),
@@ -176,12 +216,18 @@ def get_celerite_matrices(ar, ac, bc, dc, x, diag):
     return a, U, V
 
 
+def _loglik_shapes(B, N, J, t, c, a, V, y):
+    _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("a", a, (B, N)); _shape("V", V, (B, N, J))
+    _shape("y", y, (B, N))
+
+
 def loglik(t, c, a, U, V, y):
     """Fused batched log-likelihood.  Returns (ll (B,), flag (B,) int32)."""
     B, N, J = _dims(U)
     ll = torch.empty(B, dtype=torch.float64, device=U.device)
     flag = torch.empty(B, dtype=torch.int32, device=U.device)
     _chk(t, c, a, U, V, y)
+    _loglik_shapes(B, N, J, t, c, a, V, y)
     rc = _lib.load().c2_loglik(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
                                _p(U), _p(V), _p(y), _p(ll), _p(flag), _stream())
     _lib.check(rc, "loglik")
@@ -207,6 +253,9 @@ def loglik_grad(t, c, a, U, V, y, *, work=None, out=None):
     ll = torch.empty(B, dtype=torch.float64, device=dev)
     flag = torch.empty(B, dtype=torch.int32, device=dev)
     _chk(t, c, a, U, V, y, bt, bc, ba, bU, bV, by)
+    _loglik_shapes(B, N, J, t, c, a, V, y)
+    _shape("bt", bt, (B, N)); _shape("bc", bc, (B, J)); _shape("ba", ba, (B, N)); _shape("bU", bU, (B, N, J))
+    _shape("bV", bV, (B, N, J)); _shape("by", by, (B, N))
     rc = _lib.load().c2_loglik_grad(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
                                     _p(U), _p(V), _p(y), _p(ll), _p(bt), _p(bc), _p(ba), _p(bU), _p(bV), _p(by),
                                     _p(flag), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
@@ -217,9 +266,13 @@ def loglik_grad(t, c, a, U, V, y, *, work=None, out=None):
 def dot_tril(t, c, U, W, d, Y, Z=None):
     """Z = L sqrt(D) Y (numpy.py:100-102).  Y may be passed as Z for in-place use."""
     B, N, J = _dims(U)
+    if Y.dim() != 3:
+        raise ValueError("Invalid shape: Y (must be (B, N, nrhs))")
     nrhs = Y.shape[-1]
     Z = torch.empty_like(Y) if Z is None else Z
     _chk(t, c, U, W, d, Y, Z)
+    _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("W", W, (B, N, J)); _shape("d", d, (B, N))
+    _shape("Y", Y, (B, N, nrhs)); _shape("Z", Z, (B, N, nrhs))
     rc = _lib.load().c2_dot_tril(_i64(B), _i64(N), _i64(J), _i64(nrhs), _p(t), _i64(_bs(t, N)), _p(c),
                                  _i64(_bs(c, J)), _p(U), _p(W), _p(d), _p(Y), _p(Z), _stream())
     _lib.check(rc, "dot_tril")

@@ -18,11 +18,12 @@ def shard_range(B, rank, world):
     return first, count
 
 
-def gather_loglik(ll_local, B, world=None):
-    """All-gather the per-rank (count_r,) vectors into the full (B,) vector on every rank."""
+def gather_loglik(ll_local, B, world=None, force=False):
+    """All-gather the per-rank (count_r,) vectors into the full (B,) vector on every rank.  `force` runs the
+    collective even for a single rank (communicator smoke test on a one-GPU box)."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return ll_local
     counts = [shard_range(B, r, world)[1] for r in range(world)]
     if len(set(counts)) == 1:

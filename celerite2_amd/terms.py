@@ -132,10 +132,17 @@ class SHOTerm(Term):
         if w0 is None:
             w0 = 2 * np.pi / _col(rho)
         if Q is None:
-            Q = 0.5 * float(np.ravel(w0)[0]) * tau if np.ndim(w0) == 0 else 0.5 * _col(w0) * tau
+            Q = 0.5 * np.asarray(w0, dtype=np.float64) * tau
+        # One over/under-damped branch serves the whole batch, so Q must be ONE number: a per-series Q (given, or
+        # derived from a per-series rho / w0 and tau) would be truncated silently -- refuse it instead.
+        Qv = np.unique(np.ravel(np.asarray(Q, dtype=np.float64)))
+        if Qv.size != 1:
+            raise ValueError("SHOTerm: Q must be a scalar shared by the batch (got %d distinct values); "
+                             "pass a scalar Q, or scalar rho/w0 together with tau" % Qv.size)
+        Q = float(Qv[0])
         if S0 is None:
-            S0 = _col(sigma) ** 2 / (_col(w0) * Q)
-        self.S0, self.w0, self.Q, self.eps = S0, w0, float(np.ravel(Q)[0]) if np.ndim(Q) else float(Q), float(eps)
+            S0 = _col(sigma) ** 2 / (_col(w0) * Q)  # the same Q that is stored and used below
+        self.S0, self.w0, self.Q, self.eps = S0, w0, Q, float(eps)
 
     def get_coefficients(self):
         S0, w0, Q = _col(self.S0), _col(self.w0), self.Q

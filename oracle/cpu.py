@@ -28,14 +28,37 @@ def build(force=False):
 
 
 _lib = None
+_so_in_use = _SO
+_flags_in_use = "-O3 -march=x86-64-v3 -fopenmp"
+
+
+def build_native():
+    """Timing build for bench.py's cpu_baseline leg: the same source with -march=native, compiled ON the machine
+    that times it, into oracle/libc2_oracle_native.so.  Falls back to the portable build
+    (x86-64-v3) when no compiler is there.  Must be called before the first lib()."""
+    global _so_in_use, _flags_in_use
+    src, out = os.path.join(_HERE, "c2_oracle.cpp"), os.path.join(_HERE, "libc2_oracle_native.so")
+    flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-fopenmp"]
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.check_call(["g++"] + flags + ["-shared", "-o", out, src])
+        assert _lib is None, "build_native() must precede the first use of the oracle"
+        _so_in_use, _flags_in_use = out, "-O3 -march=native -fopenmp"
+    except Exception:
+        build()
+    return _so_in_use
+
+
+def build_flags():
+    return _flags_in_use
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        if not os.path.exists(_so_in_use):
             build()
-        _lib = ctypes.CDLL(_SO)
+        _lib = ctypes.CDLL(_so_in_use)
         _lib.c2o_factor.restype = _i64
         _lib.c2o_loglik.restype = _i64
         _lib.c2o_loglik_grad.restype = _i64

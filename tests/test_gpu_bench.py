@@ -1,0 +1,71 @@
+# -*- coding: utf-8 -*-
+"""bench.py as the driver calls it (`python bench.py --gpus N ...`, no torchrun): it must launch N ranks by
+itself, refuse when it cannot, and produce the same gathered log-likelihoods whatever the sharding.
+
+On the single-GPU test box two ranks share the one device over gloo (C2_DIST_BACKEND=gloo: RCCL refuses two
+ranks on one device); the RCCL communicator itself is exercised with ONE rank (C2_FORCE_DIST=1: process-group
+init with device_id + all_gather_into_tensor on device tensors), and with two when two devices are visible."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--global-batch", "64", "--N", "256", "--steps", "2", "--warmup", "1", "--exact-synth", "--no-cpu-baseline"]
+
+
+def run_bench(args, env_extra, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_self_launches_two_ranks(tmp_path):
+    one, two = str(tmp_path / "ll1.npy"), str(tmp_path / "ll2.npy")
+    rc, line1, err = run_bench(["--gpus", "1", "--dump-ll", one] + SMALL, {})
+    assert rc == 0 and line1["n_gpus"] == 1, err
+    rc, line2, err = run_bench(["--gpus", "2", "--dump-ll", two] + SMALL, {"C2_DIST_BACKEND": "gloo"})
+    assert rc == 0, err
+    assert line2["n_gpus"] == 2 and line2["config"]["batch_per_gpu"] == 32 and line2["config"]["global_batch"] == 64
+    assert line2["scaling"] == "strong" and "roofline" in line2
+    a, b = np.load(one), np.load(two)
+    assert a.shape == (64,) and np.array_equal(a, b)      # same series -> same bits, whichever rank computed them
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    import torch
+    n = torch.cuda.device_count() + 1
+    rc, line, err = run_bench(["--gpus", str(n)] + SMALL, {})
+    assert rc != 0 and line is None and "refusing" in err
+
+
+def test_bench_rccl_communicator_one_rank(tmp_path):
+    """The real `nccl` (= RCCL) backend: communicator bound to the device, all-gather of the device-resident
+    log-likelihood vector, barrier, max-reduce of the step time -- on the one GPU this box has."""
+    out = str(tmp_path / "ll.npy")
+    rc, line, err = run_bench(["--gpus", "1", "--dump-ll", out] + SMALL, {"C2_FORCE_DIST": "1"})
+    assert rc == 0 and line["n_gpus"] == 1, err
+    ref = str(tmp_path / "ref.npy")
+    rc, _, err = run_bench(["--gpus", "1", "--dump-ll", ref] + SMALL, {})
+    assert rc == 0, err
+    assert np.array_equal(np.load(out), np.load(ref))
+
+
+def test_bench_rccl_two_ranks_if_two_devices(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two MI355X")
+    one, two = str(tmp_path / "ll1.npy"), str(tmp_path / "ll2.npy")
+    rc, _, err = run_bench(["--gpus", "1", "--dump-ll", one] + SMALL, {})
+    assert rc == 0, err
+    rc, line, err = run_bench(["--gpus", "2", "--dump-ll", two] + SMALL, {})
+    assert rc == 0 and line["n_gpus"] == 2, err
+    assert np.array_equal(np.load(one), np.load(two))

@@ -18,6 +18,7 @@ __all__ = [
     "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "general_matmul_lower",
     "general_matmul_upper", "factor_rev", "solve_lower_rev", "solve_upper_rev", "matmul_lower_rev",
     "matmul_upper_rev", "get_celerite_matrices", "loglik", "loglik_grad", "loglik_grad_workspace", "dot_tril",
+    "kron_loglik", "kron_loglik_grad",
 ]
 
 _i64 = ctypes.c_int64
@@ -277,6 +278,65 @@ def dot_tril(t, c, U, W, d, Y, Z=None):
                                  _i64(_bs(c, J)), _p(U), _p(W), _p(d), _p(Y), _p(Z), _stream())
     _lib.check(rc, "dot_tril")
     return Z
+
+
+_KRON_METHODS = {"collapsed": 0, "interleaved": 1}
+
+
+def _kron_args(t, c, a, U, V, alpha, diag, y, method):
+    B, N, J = _dims(U)
+    if diag.dim() != 3:
+        raise ValueError("Invalid shape: diag (must be (B, N, M))")
+    M = diag.shape[-1]
+    if method not in _KRON_METHODS:
+        raise ValueError("method must be 'collapsed' or 'interleaved'")
+    _chk(t, c, a, U, V, alpha, diag, y)
+    _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("a", a, (B, N)); _shape("V", V, (B, N, J))
+    _shape("alpha", alpha, (M,), (B, M)); _shape("diag", diag, (B, N, M)); _shape("y", y, (B, N, M))
+    return B, N, M, J, _KRON_METHODS[method]
+
+
+def kron_loglik(t, c, a, U, V, alpha, diag, y, *, method="collapsed", work=None):
+    """2-D (multi-band) log-likelihood, rank-1 band covariance K = T (x) alpha alpha^T + diag (extension; the
+    reference has no 2-D code).  (t, c, a, U, V): celerite matrices of the EPOCH grid built with zero white noise
+    (a = k(0)); alpha (M,)|(B,M); diag, y (B,N,M).  Returns (ll (B,), flag (B,) int32)."""
+    B, N, M, J, meth = _kron_args(t, c, a, U, V, alpha, diag, y, method)
+    lib = _lib.load()
+    nbytes = lib.c2_kron_loglik_workspace_bytes(B, N, M, J, meth, 0)
+    if work is None or work.numel() * 8 < nbytes:
+        work = torch.empty(nbytes // 8, dtype=torch.float64, device=U.device)
+    ll = torch.empty(B, dtype=torch.float64, device=U.device)
+    flag = torch.empty(B, dtype=torch.int32, device=U.device)
+    rc = lib.c2_kron_loglik(_i64(B), _i64(N), _i64(M), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                            _p(U), _p(V), _p(alpha), _i64(_bs(alpha, M)), _p(diag), _p(y), _p(ll), _p(flag),
+                            ctypes.c_int(meth), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
+    _lib.check(rc, "kron_loglik")
+    return ll, flag
+
+
+def kron_loglik_grad(t, c, a, U, V, alpha, diag, y, *, method="collapsed", work=None):
+    """kron_loglik + reverse-mode gradient.  Returns (ll, (bt, bc, ba, bU, bV, balpha, bdiag, by), flag); balpha is
+    per series (B, M) also for a shared alpha.  (ba, bU, bV) are the partials of the method's own parametrisation
+    ("collapsed": T_nn = a_n, the literal Kronecker definition; "interleaved": same-epoch cross-band terms through
+    U_n.V_n); the total derivatives bU + ba V, bV + ba U along a = U.V agree."""
+    B, N, M, J, meth = _kron_args(t, c, a, U, V, alpha, diag, y, method)
+    lib = _lib.load()
+    dev = U.device
+    nbytes = lib.c2_kron_loglik_workspace_bytes(B, N, M, J, meth, 1)
+    if work is None or work.numel() * 8 < nbytes:
+        work = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    f64 = dict(dtype=torch.float64, device=dev)
+    bt, bc, ba = torch.empty((B, N), **f64), torch.empty((B, J), **f64), torch.empty((B, N), **f64)
+    bU, bV = torch.empty_like(U), torch.empty_like(U)
+    balpha, bdiag, by = torch.empty((B, M), **f64), torch.empty_like(diag), torch.empty_like(y)
+    ll = torch.empty(B, **f64)
+    flag = torch.empty(B, dtype=torch.int32, device=dev)
+    rc = lib.c2_kron_loglik_grad(_i64(B), _i64(N), _i64(M), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)),
+                                 _p(a), _p(U), _p(V), _p(alpha), _i64(_bs(alpha, M)), _p(diag), _p(y), _p(ll), _p(bt),
+                                 _p(bc), _p(ba), _p(bU), _p(bV), _p(balpha), _p(bdiag), _p(by), _p(flag),
+                                 ctypes.c_int(meth), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
+    _lib.check(rc, "kron_loglik_grad")
+    return ll, (bt, bc, ba, bU, bV, balpha, bdiag, by), flag
 
 
 def _loglik_grad_composite(t, c, a, U, V, y):

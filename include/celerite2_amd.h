@@ -166,6 +166,30 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
                    double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
                    size_t work_bytes, c2_stream_t stream);
 
+/* 2-D (multi-band) extension, rank-1 band covariance K = T (x) alpha alpha^T + diag over N epochs x M bands
+ * (observations interleaved epoch-major: row n*M + m).  EXTENSION -- the reference has no 2-D code (no core2.hpp;
+ * README.md:14-17 only cites the paper), so this entry point replaces nothing and its parity is pinned by the dense
+ * Kronecker matrix and by the 1-D recursions on the interleaved series, not by the reference.
+ * Inputs: the 1-D celerite matrices of the EPOCH grid built with zero white noise -- t (B,N)|(N,), c (B,J)|(J,),
+ * a (B,N) = k(0), U, V (B,N,J) -- plus alpha (B,M)|(M,) (alpha_bs = M or 0), diag (B,N,M) and y (B,N,M).
+ * method: C2_KRON_COLLAPSED (each epoch's M bands fold into one effective observation; needs diag > 0; the
+ * recursion runs over N rows) or C2_KRON_INTERLEAVED (the 1-D recursions on the N*M series with U' = U (x) alpha).
+ * flag[b]: first failing row in the method's own series (epoch index / interleaved row), -1 for a non-positive
+ * band variance under the collapsed method.  Gradients: bt (B,N), bc (B,J), ba (B,N), bU, bV (B,N,J),
+ * balpha (B,M) (per series, also when alpha is shared), bdiag (B,N,M), by (B,N,M). */
+#define C2_KRON_COLLAPSED 0
+#define C2_KRON_INTERLEAVED 1
+size_t c2_kron_loglik_workspace_bytes(int64_t B, int64_t N, int64_t M, int64_t J, int method, int grad);
+int c2_kron_loglik(int64_t B, int64_t N, int64_t M, int64_t J, const double *t, int64_t t_bs, const double *c,
+                   int64_t c_bs, const double *a, const double *U, const double *V, const double *alpha,
+                   int64_t alpha_bs, const double *diag, const double *y, double *ll, int32_t *flag, int method,
+                   void *work, size_t work_bytes, c2_stream_t stream);
+int c2_kron_loglik_grad(int64_t B, int64_t N, int64_t M, int64_t J, const double *t, int64_t t_bs, const double *c,
+                        int64_t c_bs, const double *a, const double *U, const double *V, const double *alpha,
+                        int64_t alpha_bs, const double *diag, const double *y, double *ll, double *bt, double *bc,
+                        double *ba, double *bU, double *bV, double *balpha, double *bdiag, double *by, int32_t *flag,
+                        int method, void *work, size_t work_bytes, c2_stream_t stream);
+
 /* dot_tril -- python/celerite2/numpy.py:100-102: Z = Y * sqrt(d)[:,None];
  * Z += tril(U W^T) Z.  Y == Z allowed. */
 int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,

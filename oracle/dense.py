@@ -189,3 +189,64 @@ def synthetic_batch(B, N, J, seed0=721):
         y[b] = np.sin(t[b]) + 0.1 * rng.standard_normal(N)
         c[b], a[b], U[b], V[b] = celerite_matrices(sho_sum_coeffs(J, xi), t[b], diag)
     return t, c, a, U, V, y
+
+
+# ---- 2-D (multi-band) extension, rank-1 band covariance -------------------------------
+# No reference code exists for this row (no core2.hpp): the dense Kronecker matrix below IS the definition the
+# device path is checked against; kron_interleaved gives the 1-D view of the same model for the CPU oracle.
+def kron_dense(co, x, alpha, diag):
+    """K = T (x) alpha alpha^T + diag, T_nn' = k(|x_n - x_n'|); rows ordered epoch-major (n*M + m); diag (N, M)."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    T = kernel_value(co, x[:, None] - x[None, :])
+    K = np.kron(T, np.outer(alpha, alpha))
+    K[np.diag_indices_from(K)] += np.asarray(diag, dtype=np.float64).ravel()
+    return K
+
+
+def kron_interleaved(c, a, U, V, x, alpha, diag):
+    """(t', c, a', U', V') of the length N*M series: U' = U (x) alpha, V' = V (x) alpha, a' = diag + alpha^2 k(0),
+    dt = 0 between the bands of one epoch.  (c, a, U, V) are the epoch grid's celerite matrices with ZERO diag."""
+    alpha = np.asarray(alpha, dtype=np.float64)
+    N, J = U.shape
+    M = len(alpha)
+    t2 = np.repeat(x, M)
+    a2 = (np.asarray(diag) + alpha[None, :] ** 2 * a[:, None]).ravel()
+    U2 = (U[:, None, :] * alpha[None, :, None]).reshape(N * M, J)
+    V2 = (V[:, None, :] * alpha[None, :, None]).reshape(N * M, J)
+    return t2, c, np.ascontiguousarray(a2), np.ascontiguousarray(U2), np.ascontiguousarray(V2)
+
+
+def kron_fold_gradients(grads2, a, U, V, alpha):
+    """Gradients of the interleaved series (bt', bc, ba', bU', bV', by') folded back onto the 2-D model's inputs:
+    returns (bt, bc, ba, bU, bV, balpha, bdiag, by)."""
+    bt2, bc, ba2, bU2, bV2, by2 = grads2
+    alpha = np.asarray(alpha, dtype=np.float64)
+    N, J = U.shape
+    M = len(alpha)
+    ba2 = ba2.reshape(N, M); bU2 = bU2.reshape(N, M, J); bV2 = bV2.reshape(N, M, J)
+    bt = bt2.reshape(N, M).sum(1)
+    ba = (ba2 * alpha[None, :] ** 2).sum(1)
+    bU = (bU2 * alpha[None, :, None]).sum(1)
+    bV = (bV2 * alpha[None, :, None]).sum(1)
+    balpha = (2.0 * alpha[None, :] * a[:, None] * ba2).sum(0) + (bU2 * U[:, None, :] + bV2 * V[:, None, :]).sum((0, 2))
+    return bt, bc, ba, bU, bV, balpha, ba2.copy(), by2.reshape(N, M).copy()
+
+
+def kron_synthetic(B, N, M, J, seed0=1721):
+    """Synthetic multi-band batch: the section-8d kernel / epoch grid per series, alpha ~ U(0.5, 1.5)^M,
+    diag ~ U(0.1, 0.3)^(N x M), y_nm = alpha_m sin(t_n) + sqrt(diag) eps."""
+    t = np.empty((B, N)); c = np.empty((B, J)); a = np.empty((B, N)); U = np.empty((B, N, J)); V = np.empty((B, N, J))
+    alpha = np.empty((B, M)); diag = np.empty((B, N, M)); y = np.empty((B, N, M)); cos = []
+    for b in range(B):
+        rng = np.random.default_rng(seed0 + b)
+        t[b] = np.sort(rng.uniform(0, N / 10.0, N))
+        xi = rng.uniform(-1, 1)
+        alpha[b] = rng.uniform(0.5, 1.5, M)
+        diag[b] = rng.uniform(0.1, 0.3, (N, M))
+        y[b] = alpha[b][None, :] * np.sin(t[b])[:, None] + np.sqrt(diag[b]) * rng.standard_normal((N, M))
+        co = sho_sum_coeffs(J - J % 2, xi) if J >= 2 else None   # odd widths: one real term in front
+        if J % 2:
+            co = real_term(1.3, 0.4 * (1.0 + 0.05 * xi)) if co is None else real_term(1.3, 0.4 * (1.0 + 0.05 * xi)) + co
+        c[b], a[b], U[b], V[b] = celerite_matrices(co, t[b], np.zeros(N))
+        cos.append(co)
+    return t, c, a, U, V, alpha, diag, y, cos

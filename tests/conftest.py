@@ -28,3 +28,11 @@ def golden():
 
     path = os.path.join(ROOT, "tests", "golden", "golden.npz")
     return dict(np.load(path))
+
+
+@pytest.fixture(scope="session")
+def golden_kron():
+    """Dense-Kronecker fixtures of the 2-D extension (tests/golden/make_golden_kron.py)."""
+    import numpy as np
+
+    return dict(np.load(os.path.join(ROOT, "tests", "golden", "kron.npz")))

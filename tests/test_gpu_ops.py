@@ -415,8 +415,9 @@ def test_failed_series_gradients_are_nan(ops, oracle, monkeypatch, J, lanes):
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J + (J % 2))
     U, V, c = np.ascontiguousarray(U[:, :, :J]), np.ascontiguousarray(V[:, :, :J]), np.ascontiguousarray(c[:, :J])
     a = a + 1.0
-    for b in range(B):   # one shared grid and one shared set of rates
-        t[b], c[b] = t[0], c[0]
+    for b in range(B):   # one shared grid and one shared set of rates: same kernel matrices, own diagonal and data
+        t[b], c[b], U[b], V[b] = t[0], c[0], U[0], V[0]
+        a[b] = a[0] + 0.01 * b
     bad = 6
     a[bad, 77] = -5.0
     td, cd, ad, Ud, Vd, yd = dev(t[0], c[0], a, U, V, y)

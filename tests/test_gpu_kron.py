@@ -32,6 +32,13 @@ def close(a, b, tol=1e-10, floor=1e-12):
     np.testing.assert_allclose(a, b, rtol=tol, atol=floor * max(1.0, float(np.abs(b).max())))
 
 
+# The collapsed method is a different (mathematically equivalent) formulation from the oracle's interleaved recursion:
+# the two agree to the conditioning of the problem, k(0) / (effective per-epoch noise 1/A) ~ 1e3..1e4 here, i.e.
+# 1e-12..1e-10 of the largest element (measured: tools/kron_err.py; the interleaved method, which shares the oracle's
+# arithmetic, agrees to 1e-12).  Log-likelihoods agree to 1e-13.
+COLLAPSED_FLOOR = 5e-10
+
+
 def oracle_interleaved(oracle, t, c, a, U, V, alpha, diag, y):
     """Per series: 1-D CPU oracle on the interleaved series, gradients folded back (oracle/dense.py)."""
     lls, folded = [], []
@@ -88,7 +95,7 @@ def test_kron_vs_interleaved_oracle(ops, oracle, B, N, M, J):
     close(ll_c, llo)
     Ud, Vd = args[3], args[4]
     for g, e in zip(totals(g_c, Ud, Vd), totals(go, U, V)):
-        close(g, e)
+        close(g, e, 1e-10, COLLAPSED_FLOOR)
     ll_f, _ = ops.kron_loglik(*args, method="collapsed")
     close(ll_f, llo)
     # shared alpha (M,): same numbers as the batched alpha
@@ -137,12 +144,12 @@ def test_config4_full_shape(ops, oracle):
     close(ll_c[:nb], llo)
     assert bool((ll_c.view(rep, nb) == ll_c[:nb]).all())
     for g, e in zip(totals([x[:nb] for x in g_c], args[3][:nb], args[4][:nb]), totals(go, U, V)):
-        close(g, e, floor=1e-11)
+        close(g, e, 1e-10, COLLAPSED_FLOOR)
     for g in g_c:
         assert bool((g.view((rep, nb) + tuple(g.shape[1:])) == g[:nb]).all())
     ll_i, g_i, flag = ops.kron_loglik_grad(*args, method="interleaved")
     assert int(flag.abs().sum()) == 0
     close(ll_i[:nb], llo)
     for g, e in zip(g_i, go):
-        close(g[:nb], e, floor=1e-11)
+        close(g[:nb], e)
     assert float((ll_i - ll_c).abs().max()) <= 1e-10 * float(ll_c.abs().max())

@@ -154,7 +154,11 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          const double *__restrict__ y, double *__restrict__ ll,
                                                          int32_t *__restrict__ flag, double *__restrict__ ckpt,
                                                          int64_t nseg, double *__restrict__ Wst,
-                                                         double2 *__restrict__ DZst) {
+                                                         double2 *__restrict__ DZst,
+                                                         const unsigned long long *__restrict__ gate) {
+  // `gate` (nullable): this launch is the fallback of the one-lane-per-series path and runs only when the stability
+  // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
+  if (gate && !(__longlong_as_double((long long)*gate) > kBackwardGuard)) return;
   // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
   // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
   // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
@@ -379,7 +383,9 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          double *__restrict__ bU, double *__restrict__ bV,
                                                          double *__restrict__ by, const double *__restrict__ fr_d,
                                                          const double *__restrict__ fr_bd,
-                                                         const double *__restrict__ fr_bW) {
+                                                         const double *__restrict__ fr_bW,
+                                                         const unsigned long long *__restrict__ gate) {
+  if (gate && !(__longlong_as_double((long long)*gate) > kBackwardGuard)) return;  // see k_loglik_fwd
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
@@ -764,17 +770,18 @@ inline int launch_ok() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR
 template <int MODE>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
-               double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s) {
+               double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s,
+               const unsigned long long *gate = nullptr) {
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
     if (J == G)                                                                                                  \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
-                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst);                                 \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate);                           \
     else                                                                                                         \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,    \
-                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst);                                 \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate);                           \
   } while (0)
   switch (G_) {
     case 1: C2_FWD(1, C2_FWD_R, C2_CKPT_C); break;
@@ -809,8 +816,25 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
   const char *e = getenv("C2_LANES");  // read per call: tests switch it at run time
   const int forced = e ? atoi(e) : 0;
   if (forced == 4) return true;
-  if (forced == 8) return false;
+  if (forced == 8 || forced == 1) return false;
   return !grad && B >= C2_LANES4_MIN_BATCH;
+}
+
+// One lane per series (c2_loglik_t.hip, J == 8): 64 series per wavefront, so it needs 64 x 1024 series to put one
+// wavefront on every SIMD; taken from C2_LANES1_MIN_BATCH up, or when forced with C2_LANES=1.
+#ifndef C2_LANES1_MIN_BATCH
+#define C2_LANES1_MIN_BATCH 49152
+#endif
+extern "C" int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                    const double *a, const double *U, const double *V, const double *y, double *ll,
+                                    int32_t *flag, c2_stream_t stream);
+static bool use_lanes1(int64_t B, int64_t J) {
+  if (J != 8) return false;
+  const char *e = getenv("C2_LANES");
+  const int forced = e ? atoi(e) : 0;
+  if (forced == 1) return true;
+  if (forced == 4 || forced == 8) return false;
+  return B >= C2_LANES1_MIN_BATCH;
 }
 
 extern "C" {
@@ -821,6 +845,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
+  if (use_lanes1(B, J)) return c2_internal_loglik_t(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   if (use_lanes4(B, J, false)) return c2_internal_loglik4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
                            (hipStream_t)stream);
@@ -855,10 +880,21 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
                        nullptr, 0, W, reinterpret_cast<double2 *>(d), (hipStream_t)stream);
 }
 
+extern "C" size_t c2_internal_loglik_t_record_doubles(int64_t B, int64_t N);
+extern "C" int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,
+                                         int64_t c_bs, const double *a, const double *U, const double *V,
+                                         const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
+                                         double *bV, double *by, int32_t *flag, double *rec, unsigned long long *guard,
+                                         c2_stream_t stream);
+
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
   size_t n = grad_ws(B, N, J).total;
   if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
+  if (use_lanes1(B, J)) {  // [guard word (16 bytes)] [records of the one-lane path | workspace of the replay fallback]
+    const size_t r = c2_internal_loglik_t_record_doubles(B, N);
+    n = 2 + (r > n ? r : n);
+  }
   return n * sizeof(double);
 }
 
@@ -874,23 +910,36 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   if (use_lanes4(B, J, true))
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   hipStream_t s = (hipStream_t)stream;
+  const unsigned long long *gate = nullptr;
+  if (use_lanes1(B, J)) {
+    // One lane per series: forward with records, then the backward-recursion reverse sweep.  The forward pass leaves
+    // its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the gated
+    // replay pair below produces the gradients (same outputs, same workspace region, decided on the device).
+    unsigned long long *guard = (unsigned long long *)work;
+    if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
+    work = (double *)work + 2;
+    if (int e = c2_internal_loglik_t_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
+                                          (double *)work, guard, stream))
+      return e;
+    gate = guard;
+  }
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   const GradWs ws = grad_ws(B, N, J);
   double *ckpt = (double *)work;
   double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck);
-  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, nullptr, DZst, s)) return e;
+  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, nullptr, DZst, s, gate)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \
     if (J == G)                                                                                                   \
       hipLaunchKernelGGL((k_loglik_rev<G, C, false, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
                          V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
-                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr);               \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate);         \
     else                                                                                                          \
       hipLaunchKernelGGL((k_loglik_rev<G, C, true, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,   \
                          V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
-                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr);               \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate);         \
   } while (0)
   switch (G_) {
     case 1: C2_REV(1, C2_CKPT_C); break;
@@ -919,11 +968,11 @@ int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double 
     if (J == G)                                                                                                    \
       hipLaunchKernelGGL((k_loglik_rev<G, C, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, \
                          U, W, (const double2 *)nullptr, S, nseg, (const int32_t *)nullptr, bt, bc, ba, bU, bV,    \
-                         (double *)nullptr, d, bd, bW);                                                            \
+                         (double *)nullptr, d, bd, bW, (const unsigned long long *)nullptr);                       \
     else                                                                                                           \
       hipLaunchKernelGGL((k_loglik_rev<G, C, true, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs,  \
                          U, W, (const double2 *)nullptr, S, nseg, (const int32_t *)nullptr, bt, bc, ba, bU, bV,    \
-                         (double *)nullptr, d, bd, bW);                                                            \
+                         (double *)nullptr, d, bd, bW, (const unsigned long long *)nullptr);                       \
   } while (0)
   switch (G_) {
     case 1: C2_FREV(1, C2_CKPT_C); break;

@@ -7,6 +7,9 @@ namespace c2 {
 
 constexpr double kLog2Pi = 1.8378770664093454835606594728112;
 constexpr double kLn2 = 0.69314718055994530941723212145818;
+// One-lane-per-series gradient path (c2_loglik_t.hip): the backward recursion is used only while
+// max_j c_j * (t_end - t_start) <= kBackwardGuard on every checkpoint segment (error growth <= e^{2 * guard}).
+constexpr double kBackwardGuard = 2.0;
 
 // 1/d for a well-scaled positive d: v_rcp_f64 seed + two Newton steps (full fp64 accuracy; the
 // denormal/overflow scaling of a general IEEE division is not needed for pivots of an SPD matrix).

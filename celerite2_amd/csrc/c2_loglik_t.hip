@@ -31,8 +31,13 @@ using namespace c2;
 constexpr int J = 8;
 constexpr int NS = J * (J + 1) / 2;  // packed symmetric J x J
 constexpr int C = 16;                // checkpoint interval (rows)
-constexpr double kGuard = 2.0;       // largest allowed max_j c_j * (t_end - t_start) of a segment
-constexpr int RT = 2;                // rows per tile of the width-J streams (128-byte runs in HBM)
+constexpr double kGuard = kBackwardGuard;  // largest allowed max_j c_j * (t_end - t_start) of a segment
+#ifndef C2T_RT
+#define C2T_RT 2
+#endif
+constexpr int RT = C2T_RT;           // rows per tile of the width-J streams (RT * 64-byte runs in HBM)
+constexpr int LPS = RT * J / 2;      // lanes that fetch one series' run (16 bytes each)
+constexpr int NI = LPS;              // global instructions per row tile (64 / LPS series each)
 constexpr int ST = 8;                // rows per tile of the per-series scalar streams (64-byte runs)
 constexpr int RSTR = RT * J + 2;     // LDS stride (doubles) of a series in a row tile: 144 B, conflict-free b128
 constexpr int SSTR = ST + 1;         // LDS stride (doubles) of a series in a scalar tile: 72 B, conflict-free b64
@@ -50,7 +55,10 @@ struct Rec {
   size_t w, dz, ck, total;  // offsets / total in doubles
   int64_t nck;              // checkpoints per series
 };
-__host__ __device__ inline int64_t n_ckpt(int64_t N) { return (N - 1) / C + 1; }  // rows C, 2C, ... and row N-1
+// Checkpoints = state after rows C, 2C, ... and after the last row N-1: ceil((N-1)/C) of them; row n sits at
+// ck_index(n) (the last row takes the final slot whether or not it is a multiple of C).
+__host__ __device__ inline int64_t n_ckpt(int64_t N) { return N >= 2 ? (N - 2) / C + 1 : 0; }
+__host__ __device__ inline int64_t ck_index(int64_t n, int64_t nck) { return (n % C == 0) ? n / C - 1 : nck - 1; }
 __host__ inline Rec rec_layout(int64_t B, int64_t N) {
   const size_t waves = ((size_t)B + kWave - 1) / kWave;
   Rec r;
@@ -66,32 +74,35 @@ __host__ inline Rec rec_layout(int64_t B, int64_t N) {
 // A wavefront owns series b0 .. b0+63 (clamped to B-1).  Row tile: RT rows of J doubles of every series.  One global
 // instruction moves 8 series x 128 bytes (lane l: series 8 i + l / 8, 16-byte piece l % 8).
 struct RowIO {
-  int sl[8];       // clamped series (within the wavefront) this lane serves in instruction i
-  int piece;       // l % 8
-  __device__ __forceinline__ RowIO(int lane, int last) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int s = 8 * i + lane / 8;
-      sl[i] = s < last ? s : last;
-    }
-    piece = lane & 7;
-  }
+  int lane, last;
+  int piece;       // l % 8 (scalar tiles)
+  int rpiece;      // l % LPS (row tiles)
+  __device__ __forceinline__ RowIO(int lane_, int last_) : lane(lane_), last(last_), piece(lane_ & 7), rpiece(lane_ % LPS) {}
+  // clamped series (within the wavefront) this lane serves in instruction i of a scalar / row tile -- recomputed at
+  // every use (two VALU instructions) rather than kept in registers
+  __device__ __forceinline__ int sl(int i) const { const int s = 8 * i + lane / 8; return s < last ? s : last; }
+  __device__ __forceinline__ int rl(int i) const { const int s = (kWave / LPS) * i + lane / LPS; return s < last ? s : last; }
 };
 
-// global -> registers: rows n0, n0+1 (clamped to [0, N-1]) of every series
+// global -> registers: rows n0 .. n0+RT-1 (clamped to [0, N-1]) of every series
+// (staging registers are plain doubles: arrays of double2 end up in scratch)
 __device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, const RowIO &io,
-                                          double2 (&st)[8]) {
-  int64_t r = n0 + (io.piece >> 2);
+                                          double (&st)[2 * NI]) {
+  int64_t r = n0 + (io.rpiece >> 2);
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
-  const int64_t off = r * J + 2 * (io.piece & 3);
+  const int64_t off = r * J + 2 * (io.rpiece & 3);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) st[i] = *reinterpret_cast<const double2 *>(base + (int64_t)io.sl[i] * N * J + off);
+  for (int i = 0; i < NI; ++i) {
+    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)io.rl(i) * N * J + off);
+    st[2 * i] = v.x; st[2 * i + 1] = v.y;
+  }
 }
 // registers -> LDS tile
-__device__ __forceinline__ void row_stage(double *tile, int lane, const double2 (&st)[8]) {
+__device__ __forceinline__ void row_stage(double *tile, int lane, const double (&st)[2 * NI]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    *reinterpret_cast<double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * (lane & 7)) = st[i];
+  for (int i = 0; i < NI; ++i)
+    *reinterpret_cast<double2 *>(tile + ((kWave / LPS) * i + lane / LPS) * RSTR + 2 * (lane % LPS)) =
+        make_double2(st[2 * i], st[2 * i + 1]);
 }
 // LDS tile -> this lane's row r
 __device__ __forceinline__ void row_read(const double *tile, int lane, int r, double (&x)[J]) {
@@ -106,17 +117,39 @@ __device__ __forceinline__ void row_write(double *tile, int lane, int r, const d
   for (int q = 0; q < J / 2; ++q)
     *reinterpret_cast<double2 *>(tile + lane * RSTR + r * J + 2 * q) = make_double2(x[2 * q], x[2 * q + 1]);
 }
-// LDS tile -> global: rows n0, n0+1 of every series; rows outside [lo, hi] and series beyond `last` are skipped
+// LDS tile -> global: rows n0 .. n0+RT-1 of every series; rows outside [lo, hi] and series beyond `last` are skipped
 __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, int64_t n0, int64_t lo, int64_t hi,
                                           const double *tile, int lane, int last) {
-  const int piece = lane & 7;
+  const int piece = lane % LPS;
   const int64_t r = n0 + (piece >> 2);
+  if (last == kWave - 1 && n0 >= lo && n0 + RT - 1 <= hi) {  // uniform: full wavefront, whole tile in range
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int s = 8 * i + lane / 8;
+    for (int i = 0; i < NI; ++i) {
+      const int s = (kWave / LPS) * i + lane / LPS;
+      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece & 3)) =
+          *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int s = (kWave / LPS) * i + lane / LPS;
     const double2 v = *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
     if (s <= last && r >= lo && r <= hi)
       *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece & 3)) = v;
+  }
+}
+
+// The same for a full wavefront and a tile that lies inside the series: no tests, no branches.
+__device__ __forceinline__ void row_flush_full(double *__restrict__ base, int64_t N, int64_t n0, const double *tile,
+                                               int lane) {
+  const int piece = lane % LPS;
+  const int64_t off = (n0 + (piece >> 2)) * J + 2 * (piece & 3);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int s = (kWave / LPS) * i + lane / LPS;
+    *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + off) =
+        *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
   }
 }
 
@@ -126,7 +159,7 @@ __device__ __forceinline__ void sc_fetch(const double *__restrict__ base, int64_
   int64_t r = n0 + io.piece;
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) st[i] = base[(int64_t)io.sl[i] * N + r];
+  for (int i = 0; i < 8; ++i) st[i] = base[(int64_t)io.sl(i) * N + r];
 }
 __device__ __forceinline__ void sc_stage(double *tile, int lane, const double (&st)[8]) {
 #pragma unroll
@@ -135,12 +168,36 @@ __device__ __forceinline__ void sc_stage(double *tile, int lane, const double (&
 __device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, int64_t n0, int64_t lo, int64_t hi,
                                          const double *tile, int lane, int last) {
   const int64_t r = n0 + (lane & 7);
+  if (last == kWave - 1 && n0 >= lo && n0 + ST - 1 <= hi) {  // uniform: full wavefront, whole tile in range
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int s = 8 * i + lane / 8;
+      base[(int64_t)s * N + r] = tile[s * SSTR + (lane & 7)];
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int s = 8 * i + lane / 8;
     const double v = tile[s * SSTR + (lane & 7)];
     if (s <= last && r >= lo && r <= hi) base[(int64_t)s * N + r] = v;
   }
+}
+
+// A double parked in a pair of accumulation registers (see c2_loglik.hip): VALU instructions cannot read AGPRs, but
+// the 256 a lane owns at one wavefront per SIMD are otherwise idle -- the reverse sweep keeps the forward state S
+// there (72 of them) and pays two v_accvgpr moves per access, leaving the arithmetic registers to M and the vectors.
+// `volatile`: the moves keep their program order, so the scheduler cannot hoist all 144 reads of a step to its top
+// (which is what an ILP-driven schedule does with them, and what made the first version of this kernel spill).
+__device__ __forceinline__ void apark(double x, int &lo, int &hi) {
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(x)));
+  asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(x)));
+}
+__device__ __forceinline__ double afetch(int lo, int hi) {
+  int l, h;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+  return __hiloint2double(h, l);
 }
 
 // p_j = exp(c_j dt).  PAIRED: c_{2k} == c_{2k+1} for every series of the wavefront (complex terms, terms.py:171-173):
@@ -211,25 +268,26 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
     recDZ[lane] = make_double2(d, z);
   }
 
-  // ---- prologue: tiles of rows 1.. --------------------------------------------------------------------------------
-  double2 su[8], sv[8];
+  // ---- prologue: tiles start at row 0 so that every run is aligned (128 B row tiles, 64 B scalar tiles); row 0 itself
+  // was consumed above and is skipped in the loop
+  double su[2 * NI], sv[2 * NI];
   double st_[8], sa_[8], sy_[8];
-  row_fetch(Ub, N, 1, io, su); row_fetch(Vb, N, 1, io, sv);
+  row_fetch(Ub, N, 0, io, su); row_fetch(Vb, N, 0, io, sv);
   {  // scalar fetch with the t stride
-    int64_t r = 1 + io.piece; r = r > N - 1 ? N - 1 : r;
+    int64_t r = io.piece; r = r > N - 1 ? N - 1 : r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) st_[i] = tb[(int64_t)io.sl[i] * tN + r];
+    for (int i = 0; i < 8; ++i) st_[i] = tb[(int64_t)io.sl(i) * tN + r];
   }
-  sc_fetch(ab, N, 1, io, sa_); sc_fetch(yb, N, 1, io, sy_);
+  sc_fetch(ab, N, 0, io, sa_); sc_fetch(yb, N, 0, io, sy_);
 
-  for (int64_t n0 = 1; n0 < N; n0 += ST) {
+  for (int64_t n0 = 0; n0 < N; n0 += ST) {
     // scalar tile of rows n0 .. n0+ST-1
     lds_order();
     sc_stage(tT, lane, st_); sc_stage(tA, lane, sa_); sc_stage(tY, lane, sy_);
     {
       int64_t r = n0 + ST + io.piece; r = r > N - 1 ? N - 1 : r;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) st_[i] = tb[(int64_t)io.sl[i] * tN + r];
+      for (int i = 0; i < 8; ++i) st_[i] = tb[(int64_t)io.sl(i) * tN + r];
     }
     sc_fetch(ab, N, n0 + ST, io, sa_); sc_fetch(yb, N, n0 + ST, io, sy_);
 #pragma unroll
@@ -243,7 +301,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           const int64_t n = nt + r;
-          if (n < N) {
+          if (n < N && n > 0) {
             const int rs = rt * RT + r;
             const double tn = tT[lane * SSTR + rs], an = tA[lane * SSTR + rs], yn = tY[lane * SSTR + rs];
             double u[J], v[J], p[J];
@@ -288,7 +346,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
               recDZ[(size_t)n * kWave + lane] = make_double2(d, z);
               const bool seg_end = (n % C == 0) || (n == N - 1);
               if (seg_end) {  // uniform over the wavefront
-                double *ck = recCK + (size_t)((n % C == 0) ? n / C - 1 : R.nck - 1) * (NS + J) * kWave;
+                double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
 #pragma unroll
                 for (int k = 0; k < NS; ++k) ck[k * kWave + lane] = S[k];
 #pragma unroll
@@ -339,6 +397,326 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_fwd(int64_t B, int64_t N,
     fwd_body<REC, false>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
 }
 
+// =============================================================================================================
+// Reverse sweep: fused solve_lower_rev (internal.hpp:225-245) + factor_rev (reverse.hpp:52-84) per row, the
+// step derived in c2_loglik.hip, with the forward state S_n / F_n obtained by running the recursion backward
+// from the checkpoint at the end of the current segment.  Entering step n: bz, ba, bV = complete cotangents of row n;
+// S, F = post-decay state of row n; M = bS + bS^T (symmetric-packed), bF, carry = f_{n+1}.
+//
+// Memory choreography.  Loads and stores share ONE in-order counter on gfx9 (vmcnt): a wait for a prefetched row also
+// waits for every store issued before that row was requested, and behind run-time tile tests the compiler has to assume
+// the shortest path and ends up draining the stores it has just issued, once per step.  So every step issues the SAME
+// sequence: row tiles hold ONE row (64-byte runs: U_n in, bU_n and bV_{n-1} out, each step, no test), rows are
+// requested two steps ahead, and only the scalar tiles (8 rows) and the checkpoint turn every 8th / 16th step, at the
+// END of a step, where the stores that get drained are two steps old.
+// =============================================================================================================
+constexpr int RS1 = J + 2;   // LDS stride (doubles) of a series in a one-row tile: 80 B, conflict-free b128
+constexpr int kRevLds = (2 * kWave * RS1 + 4 * kWave * SSTR + kWave * RS1) * 8;  // U/bU, bV, t, ba, by, bt, c
+
+// One-row tiles: an instruction moves 16 series x 64 bytes (lane l: series 16 i + l / 4, 16-byte piece l % 4).  Lanes of
+// a partial wavefront are clamped onto the last valid series: they move the same bytes to the same place again.
+__device__ __forceinline__ void row1_fetch(const double *__restrict__ base, int64_t N, int64_t n, int lane, int last,
+                                           double (&st)[8]) {
+  n = n < 0 ? 0 : n;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
+    const double2 v = *reinterpret_cast<const double2 *>(base + ((int64_t)sr * N + n) * J + 2 * (lane & 3));
+    st[2 * i] = v.x; st[2 * i + 1] = v.y;
+  }
+}
+__device__ __forceinline__ void row1_stage(double *tile, int lane, const double (&st)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<double2 *>(tile + (16 * i + lane / 4) * RS1 + 2 * (lane & 3)) = make_double2(st[2 * i], st[2 * i + 1]);
+}
+__device__ __forceinline__ void row1_read(const double *tile, int lane, double (&x)[J]) {
+#pragma unroll
+  for (int q = 0; q < J / 2; ++q) {
+    const double2 v = *reinterpret_cast<const double2 *>(tile + lane * RS1 + 2 * q);
+    x[2 * q] = v.x; x[2 * q + 1] = v.y;
+  }
+}
+__device__ __forceinline__ void row1_write(double *tile, int lane, const double (&x)[J]) {
+#pragma unroll
+  for (int q = 0; q < J / 2; ++q)
+    *reinterpret_cast<double2 *>(tile + lane * RS1 + 2 * q) = make_double2(x[2 * q], x[2 * q + 1]);
+}
+__device__ __forceinline__ void row1_flush(double *__restrict__ base, int64_t N, int64_t n, const double *tile, int lane,
+                                           int last) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
+    *reinterpret_cast<double2 *>(base + ((int64_t)sr * N + n) * J + 2 * (lane & 3)) =
+        *reinterpret_cast<const double2 *>(tile + sr * RS1 + 2 * (lane & 3));
+  }
+}
+
+template <bool PAIRED>
+__device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                         const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
+                                         const int32_t *__restrict__ flag, const double *__restrict__ rec, Rec R,
+                                         double *__restrict__ bt, double *__restrict__ bc, double *__restrict__ ba,
+                                         double *__restrict__ bU, double *__restrict__ bV, double *__restrict__ by,
+                                         double *lds) {
+  const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * kWave;
+  const int last = (int)((B - 1 - b0) < (kWave - 1) ? (B - 1 - b0) : (kWave - 1));
+  const int sl = lane < last ? lane : last;
+  const int64_t b = b0 + sl;
+  const RowIO io(lane, last);
+  double *tU = lds, *tBV = tU + kWave * RS1, *tT = tBV + kWave * RS1, *tBA = tT + kWave * SSTR,
+         *tBY = tBA + kWave * SSTR, *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR;
+  const double *Ub = U + b0 * N * J;
+  const double *tb = t + (t_bs ? b0 * N : 0);
+  const int64_t tN = t_bs ? N : 0;
+  double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
+  const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
+  const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave);
+  const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave;
+  const bool failed = flag[b] != 0;  // NaN gradients for a failed factorisation (see k_loglik_rev)
+  const double nan = __builtin_nan("");
+
+  // the rates c_j wait in LDS (read twice per step) rather than in 16 registers
+  double bcj[J];
+  {
+    double cj[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; bcj[j] = 0.0; }
+    row1_write(tC, lane, cj);
+  }
+
+  double F[J], bF[J], bVn[J];
+  // Both J x J states -- the forward state S of the current row and the adjoint M = bS + bS^T -- live in AGPRs (144 of
+  // the 256 a lane owns); each is read and written once per step.  The arithmetic registers hold the width-J vectors
+  // only; the extra accvgpr moves are covered by the HBM time of the step.
+  int Slo[NS], Shi[NS], Mlo[NS], Mhi[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) { apark(0.0, Slo[k], Shi[k]); apark(0.0, Mlo[k], Mhi[k]); }
+#pragma unroll
+  for (int j = 0; j < J; ++j) { F[j] = 0.0; bF[j] = 0.0; bVn[j] = failed ? nan : 0.0; }
+  double carry = 0.0;
+
+  // seeds of the last row (reverse.hpp:55-57 with bd = d ll / d d, bz = d ll / d z)
+  const double2 dzl = recDZ[(size_t)(N - 1) * kWave + lane];
+  const double rdl = 1.0 / dzl.x;
+  double ban = 0.5 * rdl * (dzl.y * dzl.y * rdl - 1.0), bzn = -dzl.y * rdl;
+  // A failed series gets NaN seeds: every gradient of the series is an arithmetic function of them (bF <- u bz,
+  // M <- x = bV + 2 ba u, bp <- F bF + ..., bt <- bp, bc <- bp), so NaN reaches all six outputs by propagation.
+  if (failed) { ban = nan; bzn = nan; }
+  double tcur = t[b * t_bs + (N - 1)];
+
+  auto load_ckpt = [&](int64_t n) {
+    const double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) apark(ck[k * kWave + lane], Slo[k], Shi[k]);
+#pragma unroll
+    for (int j = 0; j < J; ++j) F[j] = ck[(NS + j) * kWave + lane];
+  };
+  auto t_fetch = [&](int64_t n0, double (&st)[8]) {
+    int64_t r = n0 + io.piece; r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = tb[(int64_t)io.sl(i) * tN + r];
+  };
+  auto w_fetch = [&](int64_t row, double (&wv)[J]) {
+    row = row < 0 ? 0 : row;
+#pragma unroll
+    for (int q = 0; q < J / 2; ++q) {
+      const double2 v = recW[((size_t)row * (J / 2) + q) * kWave + lane];
+      wv[2 * q] = v.x; wv[2 * q + 1] = v.y;
+    }
+  };
+  auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)(row < 0 ? 0 : row) * kWave + lane]; };
+
+  if (N >= 2) {
+    const int64_t nf = N - 1;
+    // ---- prologue ------------------------------------------------------------------------------------------------------
+    // bV, ba, by of the last row are pure seeds: they leave at once (their slots in the tiles belong to lower rows)
+    row1_write(tBV, lane, bVn);
+    tBA[lane * SSTR + (nf & (ST - 1))] = ban;
+    tBY[lane * SSTR + (nf & (ST - 1))] = bzn;
+    lds_order();
+    row1_flush(bVb, N, nf, tBV, lane, last);
+    if ((nf & (ST - 1)) == 0) {  // the last row sits alone at the bottom of its scalar tile
+      sc_flush(bab, N, nf, nf, nf, tBA, lane, last);
+      sc_flush(byb, N, nf, nf, nf, tBY, lane, last);
+    }
+    double ua[8], stt[8];                 // U row n (requested one step ahead); the next t tile
+    double wa[J];                         // W_{n-1}
+    double2 dza;                          // (d, z)_{n-1}
+    row1_fetch(Ub, N, nf, lane, last, ua);
+    t_fetch(((nf - 1) / ST) * ST, stt);
+    w_fetch(nf - 1, wa);
+    dza = dz_fetch(nf - 1);
+    load_ckpt(nf);
+    lds_order();
+    sc_stage(tT, lane, stt);
+    t_fetch(((nf - 1) / ST) * ST - ST, stt);
+    lds_order();
+
+    for (int64_t n = nf; n >= 1; --n) {
+      // ---- fixed part: U_n into its tile, requests for two steps ahead ------------------------------------------------
+      lds_order();
+      row1_stage(tU, lane, ua);
+      double wb[J];
+      row1_fetch(Ub, N, n - 1, lane, last, ua);
+      w_fetch(n - 2, wb);
+      const double2 dzb = dz_fetch(n - 2);
+      lds_order();
+
+      // ---- the step ---------------------------------------------------------------------------------------------
+      const int rs = (int)((n - 1) & (ST - 1));
+      double u[J], p[J], ip[J];
+      row1_read(tU, lane, u);
+      const double tm = tT[lane * SSTR + rs];
+      const double dt = tm - tcur;
+      tcur = tm;
+      {
+        double cj[J];
+        row1_read(tC, lane, cj);
+        decay<PAIRED>(cj, dt, p);
+      }
+      // solve_lower_rev part (internal.hpp:232-245)
+      double bp[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        bF[j] = fma(-u[j], bzn, bF[j]);
+        bp[j] = F[j] * bF[j];
+        bF[j] *= p[j];
+      }
+      // factor_rev part (reverse.hpp:65-80) and the backward recursion of the forward state, ONE pass over the 36 packed
+      // elements of S and M:
+      //   x = bV + 2 ba U;  xs = x S (-> bU2 = -xs);  M -= U^T x + bV^T U;  bp += diag(S M);  M = P M P;  q = W_{n-1} M;
+      //   S_{n-1} = P^-1 S_n P^-1 - d_{n-1} w_{n-1}^T w_{n-1}   (where row n-1 is a checkpointed row the result is
+      //   replaced at the end of the step)
+      const double rdm = rcp_nr(dza.x), zm = dza.y, dm = dza.x;
+      // (bV_i = x_i - 2 ba u_i, so M -= u_i x_j + x_i u_j - 2 ba u_i u_j: x takes the registers of bV)
+      double (&x)[J] = bVn;
+      double xs[J], q[J];
+      const double ba2 = 2.0 * ban;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { x[j] = fma(ba2, u[j], bVn[j]); xs[j] = 0.0; q[j] = 0.0; ip[j] = rcp_nr(p[j]); }
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        const double dwi = dm * wa[i];
+#pragma unroll
+        for (int j2 = i; j2 < J; ++j2) {
+          const int k = sidx(i, j2);
+          const double sv = afetch(Slo[k], Shi[k]);
+          double m = afetch(Mlo[k], Mhi[k]);
+          xs[j2] = fma(x[i], sv, xs[j2]);
+          if (j2 != i) xs[i] = fma(x[j2], sv, xs[i]);
+          m = fma(-u[i], x[j2], m);
+          m = fma(-x[i], u[j2], m);
+          m = fma(ba2 * u[i], u[j2], m);
+          bp[j2] = fma(sv, m, bp[j2]);
+          if (j2 != i) bp[i] = fma(sv, m, bp[i]);
+          m *= p[i] * p[j2];
+          apark(m, Mlo[k], Mhi[k]);
+          q[j2] = fma(wa[i], m, q[j2]);
+          if (j2 != i) q[i] = fma(wa[j2], m, q[i]);
+          apark(fma(-dwi, wa[j2], sv * (ip[i] * ip[j2])), Slo[k], Shi[k]);
+        }
+      }
+      {
+        double o[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) o[j] = fma(-bzn, F[j], -xs[j]);  // bU_n = -bz_n F_n - x S_n
+        row1_write(tU, lane, o);  // bU_n takes the place of U_n in the tile
+      }
+      double f = 0.0;
+      {
+        double cj[J];
+        row1_read(tC, lane, cj);
+#pragma unroll
+        for (int j = 0; j < J; ++j) { bcj[j] = fma(dt, bp[j], bcj[j]); f = fma(cj[j], bp[j], f); }
+      }
+      const double btn = carry - f;
+      carry = f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) F[j] = fma(-wa[j], zm, F[j] * ip[j]);   // F_{n-1} = P^-1 F_n - w_{n-1} z_{n-1}
+      double Gs = 0.0, Q = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { Gs = fma(wa[j], bF[j], Gs); Q = fma(q[j], wa[j], Q); }
+      const double zr = zm * rdm;
+      bzn = Gs - zr;
+#pragma unroll
+      for (int j = 0; j < J; ++j) bVn[j] = fma(zr, bF[j], q[j]);
+      ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+      // outputs of rows n-1 (ba, by, bV) and n (bt, bU)
+      tBA[lane * SSTR + rs] = ban;
+      tBY[lane * SSTR + rs] = bzn;
+      tBT[lane * SSTR + (int)(n & (ST - 1))] = btn;
+      row1_write(tBV, lane, bVn);
+      lds_order();
+      row1_flush(bUb, N, n, tU, lane, last);
+      row1_flush(bVb, N, n - 1, tBV, lane, last);
+
+      // ---- every 8th step: scalar tiles turn; every 16th: the checkpoint replaces the recursed state -----------------
+      if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, 0, N - 1, tBT, lane, last);  // bt rows n .. n+7
+      if (rs == 0) {  // row n-1 is the lowest row of its tile
+        sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, last);
+        sc_flush(byb, N, n - 1, 0, N - 1, tBY, lane, last);
+        if (n >= 2) {
+          sc_stage(tT, lane, stt);
+          t_fetch(n - 1 - 2 * ST, stt);
+          if ((n - 1) % C == 0) load_ckpt(n - 1);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) wa[j] = wb[j];
+      dza = dzb;
+    }
+    // row 0: bU_0 = 0 (reverse.hpp:83), bt_0 = f_1; ba_0 / by_0 / bV_0 left with the last step
+    {
+      double zero[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) zero[j] = failed ? nan : 0.0;
+      lds_order();
+      row1_write(tU, lane, zero);
+      tBT[lane * SSTR] = carry;
+      lds_order();
+      row1_flush(bUb, N, 0, tU, lane, last);
+      sc_flush(btb, N, 0, 0, (ST - 1) < (N - 1) ? (ST - 1) : (N - 1), tBT, lane, last);
+    }
+  } else {  // N == 1: seeds only
+    if (lane <= last) {
+      bab[(int64_t)lane * N] = ban;
+      byb[(int64_t)lane * N] = bzn;
+      btb[(int64_t)lane * N] = failed ? nan : 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { bUb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; }
+    }
+  }
+  if (lane <= last) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) bc[b * J + j] = bcj[j];
+  }
+}
+
+__global__ __launch_bounds__(kWave, 1) void k_loglik_t_rev(int64_t B, int64_t N, const double *__restrict__ t,
+                                                           int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                           const double *__restrict__ U,
+                                                           const int32_t *__restrict__ flag,
+                                                           const double *__restrict__ rec, Rec R,
+                                                           const unsigned long long *__restrict__ guard,
+                                                           double *__restrict__ bt, double *__restrict__ bc,
+                                                           double *__restrict__ ba, double *__restrict__ bU,
+                                                           double *__restrict__ bV, double *__restrict__ by) {
+  __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
+  if (__longlong_as_double((long long)*guard) > kGuard) return;  // the replay kernels take this batch
+  const int lane = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * kWave;
+  const int64_t bb = (b0 + lane) < B ? (b0 + lane) : (B - 1);
+  bool paired = true;
+#pragma unroll
+  for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
+  if (__all(paired))
+    rev_body<true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+  else
+    rev_body<false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+}
+
 }  // namespace c2t
 
 using namespace c2t;
@@ -353,6 +731,28 @@ int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, co
   Rec R{};
   hipLaunchKernelGGL((k_loglik_t_fwd<false>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a, U,
                      V, y, ll, flag, (double *)nullptr, R, (unsigned long long *)nullptr);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// Records of the fwd/rev pair, in doubles (the caller overlays them with the replay kernels' workspace: only one of
+// the two paths runs).
+size_t c2_internal_loglik_t_record_doubles(int64_t B, int64_t N) { return rec_layout(B, N).total; }
+
+// Forward with records + backward-recursion reverse sweep.  `guard` (device, 8 bytes, zeroed by the caller on the same
+// stream) receives max over series and segments of c_max * span; k_loglik_t_rev returns at once when it exceeds
+// kBackwardGuard, and the caller's gated replay kernels then produce the gradients instead.
+int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                              const double *a, const double *U, const double *V, const double *y, double *ll,
+                              double *bt, double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag,
+                              double *rec, unsigned long long *guard, c2_stream_t stream) {
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave));
+  const Rec R = rec_layout(B, N);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((k_loglik_t_fwd<true>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec,
+                     R, guard);
+  if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(k_loglik_t_rev, grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, (const int32_t *)flag,
+                     (const double *)rec, R, (const unsigned long long *)guard, bt, bc, ba, bU, bV, by);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

@@ -184,6 +184,66 @@ def test_two_columns_per_lane_variant(ops, oracle, monkeypatch, B, N):
             assert int(flag4[b]) == f
 
 
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 2), (5, 3), (64, 16), (65, 17), (70, 33), (130, 100), (7, 1031), (200, 257)])
+def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N):
+    """J = 8 has a third lane mapping for chip-filling batches (c2_loglik_t.hip: one lane per series, rows through LDS
+    transposes, reverse sweep by the backward recursion between checkpoints every 16 rows): same results as the oracle
+    on ragged wavefronts, around the tile (8 rows) and checkpoint (16 rows) edges, with unpaired rates, with a failed
+    series, with shared t / c -- and the stability guard hands a batch with long gaps to the replay kernels."""
+    monkeypatch.setenv("C2_LANES", "1")
+    J = 8
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    close(ll, llo)
+    ll2, grads, flag2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    close(ll2, llo)
+    for g, e in zip(grads, go):
+        close(g, e)
+    # rates that are not pairwise equal take the general exponential path
+    c2 = c.copy(); c2[:, 1] *= 1.01; c2[:, 6] *= 0.97
+    (c2d,) = dev(c2)
+    llo2, go2, _ = oracle.loglik_grad_batched(t, c2, a, U, V, y, nthreads=2)
+    ll3, grads3, _ = ops.loglik_grad(td, c2d, ad, Ud, Vd, yd)
+    close(ll3, llo2)
+    for g, e in zip(grads3, go2):
+        close(g, e)
+    close(ops.loglik(td, c2d, ad, Ud, Vd, yd)[0], llo2)
+    if N > 2 and B > 2:   # a failed series: flag, -inf, NaN gradients; its neighbours in the wavefront untouched
+        a2 = a.copy(); a2[1, N // 2] = -5.0
+        (a2d,) = dev(a2)
+        ll4, grads4, flag4 = ops.loglik_grad(td, cd, a2d, Ud, Vd, yd)
+        assert int(flag4[1]) == N // 2 and int(flag4[0]) == 0 and np.isneginf(float(ll4[1]))
+        good = [b for b in range(B) if b != 1]
+        close(ll4[good], llo[good])
+        for g, e in zip(grads4, go):
+            assert bool(np.isnan(g[1].cpu().numpy()).all())
+            close(g[good], e[good])
+    # shared time grid and decay rates
+    t0d, c0d = dev(t[0].copy(), c[0].copy())
+    ts, cs = np.tile(t[0], (B, 1)), np.tile(c[0], (B, 1))
+    llo5, go5, flo5 = oracle.loglik_grad_batched(ts, cs, a, U, V, y, nthreads=2)
+    ll5, grads5, flag5 = ops.loglik_grad(t0d, c0d, ad, Ud, Vd, yd)
+    ok = flo5 == 0
+    assert np.array_equal(flag5.cpu().numpy() != 0, ~ok)
+    close(ll5[ok], llo5[ok])
+    for g, e in zip(grads5, go5):
+        close(g[ok], e[ok])
+    # gaps that make the backward recursion unsafe (c * span >> guard): the device-side gate routes the batch to the
+    # replay kernels; the results are the oracle's either way
+    if N >= 4:
+        tg = t.copy(); tg[:, N // 2:] += 300.0
+        (tgd,) = dev(tg)
+        llo6, go6, flo6 = oracle.loglik_grad_batched(tg, c, a, U, V, y, nthreads=2)
+        ll6, grads6, flag6 = ops.loglik_grad(tgd, cd, ad, Ud, Vd, yd)
+        ok = flo6 == 0
+        close(ll6[ok], llo6[ok])
+        for g, e in zip(grads6, go6):
+            close(g[ok], e[ok])
+
+
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])
 @pytest.mark.parametrize("N", [1, 2, 8, 9, 10, 17, 100])
 def test_loglik_grad_widths_and_segment_edges(ops, oracle, J, N):

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_fwd(int64_t B, int64_t N,
 // END of a step, where the stores that get drained are two steps old.
 // =============================================================================================================
 constexpr int RS1 = J + 2;   // LDS stride (doubles) of a series in a one-row tile: 80 B, conflict-free b128
-constexpr int kRevLds = (2 * kWave * RS1 + 4 * kWave * SSTR + kWave * RS1) * 8;  // U/bU, bV, t, ba, by, bt, c
+constexpr int kRevLds = (2 * kWave * RS1 + 4 * kWave * SSTR + 2 * kWave * RS1) * 8;  // U/bU, bV, t, ba, by, bt, c, bc
 
 // One-row tiles: an instruction moves 16 series x 64 bytes (lane l: series 16 i + l / 4, 16-byte piece l % 4).  Lanes of
 // a partial wavefront are clamped onto the last valid series: they move the same bytes to the same place again.
@@ -466,7 +466,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const int64_t b = b0 + sl;
   const RowIO io(lane, last);
   double *tU = lds, *tBV = tU + kWave * RS1, *tT = tBV + kWave * RS1, *tBA = tT + kWave * SSTR,
-         *tBY = tBA + kWave * SSTR, *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR;
+         *tBY = tBA + kWave * SSTR, *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * RS1;
   const double *Ub = U + b0 * N * J;
   const double *tb = t + (t_bs ? b0 * N : 0);
   const int64_t tN = t_bs ? N : 0;
@@ -477,13 +477,14 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const bool failed = flag[b] != 0;  // NaN gradients for a failed factorisation (see k_loglik_rev)
   const double nan = __builtin_nan("");
 
-  // the rates c_j wait in LDS (read twice per step) rather than in 16 registers
-  double bcj[J];
+  // the rates c_j (read twice per step) and the accumulators of bc (read-modify-write once per step) live in LDS rather
+  // than in 32 registers
   {
-    double cj[J];
+    double cj[J], zero[J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; bcj[j] = 0.0; }
+    for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; zero[j] = 0.0; }
     row1_write(tC, lane, cj);
+    row1_write(tBC, lane, zero);
   }
 
   double F[J], bF[J], bVn[J];
@@ -541,10 +542,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       sc_flush(bab, N, nf, nf, nf, tBA, lane, last);
       sc_flush(byb, N, nf, nf, nf, tBY, lane, last);
     }
-    double ua[8], stt[8];                 // U row n (requested one step ahead); the next t tile
-    double wa[J];                         // W_{n-1}
+    double ua[8], ub[8], stt[8];          // U rows n, n-1 (requested two steps ahead: staged first thing in a step)
+    double wa[J];                         // W_{n-1} (requested one step ahead: first used well into the step)
     double2 dza;                          // (d, z)_{n-1}
-    row1_fetch(Ub, N, nf, lane, last, ua);
+    row1_fetch(Ub, N, nf, lane, last, ua); row1_fetch(Ub, N, nf - 1, lane, last, ub);
     t_fetch(((nf - 1) / ST) * ST, stt);
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
@@ -558,8 +559,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       // ---- fixed part: U_n into its tile, requests for two steps ahead ------------------------------------------------
       lds_order();
       row1_stage(tU, lane, ua);
-      double wb[J];
-      row1_fetch(Ub, N, n - 1, lane, last, ua);
+      double uc[8], wb[J];
+      row1_fetch(Ub, N, n - 2, lane, last, uc);
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
       lds_order();
@@ -626,10 +627,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       }
       double f = 0.0;
       {
-        double cj[J];
+        double cj[J], bcj[J];
         row1_read(tC, lane, cj);
+        row1_read(tBC, lane, bcj);
 #pragma unroll
         for (int j = 0; j < J; ++j) { bcj[j] = fma(dt, bp[j], bcj[j]); f = fma(cj[j], bp[j], f); }
+        row1_write(tBC, lane, bcj);
       }
       const double btn = carry - f;
       carry = f;
@@ -664,6 +667,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         }
       }
 #pragma unroll
+      for (int i = 0; i < 8; ++i) { ua[i] = ub[i]; ub[i] = uc[i]; }
+#pragma unroll
       for (int j = 0; j < J; ++j) wa[j] = wb[j];
       dza = dzb;
     }
@@ -689,6 +694,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     }
   }
   if (lane <= last) {
+    double bcj[J];
+    row1_read(tBC, lane, bcj);
 #pragma unroll
     for (int j = 0; j < J; ++j) bc[b * J + j] = bcj[j];
   }

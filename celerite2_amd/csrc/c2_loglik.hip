@@ -820,21 +820,26 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
   return !grad && B >= C2_LANES4_MIN_BATCH;
 }
 
-// One lane per series (c2_loglik_t.hip, J == 8): 64 series per wavefront, so it needs 64 x 1024 series to put one
-// wavefront on every SIMD; taken from C2_LANES1_MIN_BATCH up, or when forced with C2_LANES=1.
-#ifndef C2_LANES1_MIN_BATCH
-#define C2_LANES1_MIN_BATCH 49152
+// One lane per series (c2_loglik_t.hip, J == 8): 64 series per wavefront, so it takes 64 x 1024 series to put one
+// wavefront on every SIMD.  Measured on MI355X at N = 4096 (profiles/r02_lane_mappings.md): the forward-only kernel
+// wins from 24576 series up (3.3 vs 4.2 ms; 6.9 vs 9.2 ms at 65536), the gradient pair from 49152 up (31.1 vs 32.8 ms;
+// 36.7 vs 43.1 ms at 65536).  C2_LANES=1 forces it.
+#ifndef C2_LANES1_MIN_BATCH_FWD
+#define C2_LANES1_MIN_BATCH_FWD 24576
+#endif
+#ifndef C2_LANES1_MIN_BATCH_GRAD
+#define C2_LANES1_MIN_BATCH_GRAD 49152
 #endif
 extern "C" int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                                     const double *a, const double *U, const double *V, const double *y, double *ll,
                                     int32_t *flag, c2_stream_t stream);
-static bool use_lanes1(int64_t B, int64_t J) {
+static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8) return false;
   const char *e = getenv("C2_LANES");
   const int forced = e ? atoi(e) : 0;
   if (forced == 1) return true;
   if (forced == 4 || forced == 8) return false;
-  return B >= C2_LANES1_MIN_BATCH;
+  return B >= (grad ? C2_LANES1_MIN_BATCH_GRAD : C2_LANES1_MIN_BATCH_FWD);
 }
 
 extern "C" {
@@ -845,7 +850,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
-  if (use_lanes1(B, J)) return c2_internal_loglik_t(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
+  if (use_lanes1(B, J, false)) return c2_internal_loglik_t(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   if (use_lanes4(B, J, false)) return c2_internal_loglik4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
                            (hipStream_t)stream);
@@ -891,7 +896,7 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
   size_t n = grad_ws(B, N, J).total;
   if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
-  if (use_lanes1(B, J)) {  // [guard word (16 bytes)] [records of the one-lane path | workspace of the replay fallback]
+  if (use_lanes1(B, J, true)) {  // [guard word (16 bytes)] [records of the one-lane path | workspace of the replay fallback]
     const size_t r = c2_internal_loglik_t_record_doubles(B, N);
     n = 2 + (r > n ? r : n);
   }
@@ -911,7 +916,7 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   hipStream_t s = (hipStream_t)stream;
   const unsigned long long *gate = nullptr;
-  if (use_lanes1(B, J)) {
+  if (use_lanes1(B, J, true)) {
     // One lane per series: forward with records, then the backward-recursion reverse sweep.  The forward pass leaves
     // its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the gated
     // replay pair below produces the gradients (same outputs, same workspace region, decided on the device).

@@ -12,6 +12,7 @@
 // aliasable pairs), which is the device equivalent of the reference's `tmp`
 // previous-row trick (internal.hpp:134-141).
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "c2_common.hpp"
@@ -1064,6 +1065,15 @@ extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, in
                                   int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
                                   const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream);
 
+extern "C" int c2_internal_matmul_lower_mfma(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
+                                             const double *c, int64_t c_bs, const double *U, const double *V,
+                                             const double *d, const double *Y, double *Z, int zero_z,
+                                             c2_stream_t stream);
+static bool use_mfma() {
+  const char *e = getenv("C2_MFMA");  // read per call: tests and A/B runs switch it at run time
+  return !(e && e[0] == '0');
+}
+
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -1076,6 +1086,12 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
     // a diagonal transition, so it is cut into time chunks that run in parallel (c2_scan.hip).
     const int64_t chains = B * ((nrhs + 3) / 4) * group_size(J);  // lanes kept busy by the sequential kernel
     if (N >= 16384 && chains < (int64_t)kWave * 2048) {
+      // J = 16 with 16 / 32 / 64 right-hand sides and no workspace: the blocks of 16 rows are dense fp64 contractions
+      // on the matrix cores (c2_mfma.hip).  C2_MFMA=0 keeps the VALU path (A/B runs).
+      if (LOWER && !F && use_mfma()) {
+        const int e = c2_internal_matmul_lower_mfma(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, nullptr, Y, Z, zero_z, stream);
+        if (e != C2_ERR_UNSUPPORTED) return e;
+      }
       // chunk length: aim at ~2048 units in flight per rhs slab, between 1024 and 16384 rows
       int64_t Lc = 1024;
       while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
@@ -1308,6 +1324,11 @@ int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, 
                 c2_stream_t stream) {
   if (int e = check_dims(B, N, J)) return e;
   if (nrhs < 1 || !t || !c || !U || !W || !d || !Y || !Z) return C2_ERR_INVALID;
+  // long series, J = 16: scaling, unit-lower product and accumulation in one matrix-core pass (c2_mfma.hip)
+  if (N >= 16384 && B * ((nrhs + 3) / 4) * group_size(J) < (int64_t)kWave * 2048 && use_mfma()) {
+    const int e = c2_internal_matmul_lower_mfma(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, d, Y, Z, 0, stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
+  }
   const int64_t total = B * N * nrhs;
   hipLaunchKernelGGL(k_scale_sqrt, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
                      nrhs, d, Y, Z);

@@ -624,6 +624,41 @@ def test_long_series_chunked_matmul(ops, oracle, J, nrhs, N):
     assert float((lhs - rhs).abs().max()) <= 1e-10 * max(1.0, float(rhs.abs().max()))
 
 
+@pytest.mark.parametrize("B,N,nrhs,gap", [(1, 40000, 32, False), (1, 40003, 32, False), (3, 20001, 16, False),
+                                          (2, 17000, 64, False), (1, 40000, 32, True), (1, 16384, 32, False)])
+def test_matrix_core_matmul_lower(ops, oracle, monkeypatch, B, N, nrhs, gap):
+    """Long series with J = 16 and 16 / 32 / 64 right-hand sides take the matrix-core path (c2_mfma.hip: blocks of 16
+    rows as fp64 MFMA contractions): matmul_lower with accumulation and dot_tril in place against the sequential oracle,
+    ragged last block, several series, and gaps long enough that blocks fall back to the row-by-row walk; the VALU
+    path (C2_MFMA=0) stays covered and must agree."""
+    import torch
+    J = 16
+    rng = np.random.default_rng(3)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    if gap:
+        t[:, N // 3:] += 5000.0
+        t[:, N // 2 + 5:] += 1e5
+    Y = rng.standard_normal((B, N, nrhs))
+    Z0 = rng.standard_normal((B, N, nrhs))
+    td, cd, ad, Ud, Vd, Yd = dev(t, c, a, U, V, Y)
+    d, W, flag = ops.factor(td, cd, ad, Ud, Vd)
+    assert int(flag.abs().sum()) == 0
+    dh, Wh = d.cpu().numpy(), W.cpu().numpy()
+    for mode in ("1", "0"):
+        monkeypatch.setenv("C2_MFMA", mode)
+        (Zd,) = dev(Z0)
+        Zd = ops.matmul_lower(td, cd, Ud, Vd, Yd, Z=Zd)
+        Yc = Yd.clone()
+        Zi = ops.dot_tril(td, cd, Ud, W, d, Yc, Z=Yc)      # in place
+        for b in range(B):
+            Zo = Z0[b].copy()
+            oracle.matmul_lower(t[b], c[b], U[b], V[b], Y[b], Zo)
+            close(Zd[b], Zo)
+            z = np.ascontiguousarray(Y[b] * np.sqrt(dh[b])[:, None])
+            oracle.matmul_lower(t[b], c[b], U[b], np.ascontiguousarray(Wh[b]), z, z)
+            close(Zi[b], z)
+
+
 @pytest.mark.parametrize("J", [1, 2, 3, 5, 8, 12, 16, 32])
 @pytest.mark.parametrize("N", [1, 2, 9, 300])
 def test_single_rhs_sweeps(ops, oracle, J, N):

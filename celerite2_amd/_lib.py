@@ -21,6 +21,7 @@ SYMBOLS = [
     "c2_solve_lower_rev", "c2_solve_upper_rev", "c2_matmul_lower_rev", "c2_matmul_upper_rev",
     "c2_get_celerite_matrices", "c2_loglik", "c2_loglik_grad_workspace_bytes", "c2_loglik_grad", "c2_dot_tril",
     "c2_kron_loglik_workspace_bytes", "c2_kron_loglik", "c2_kron_loglik_grad",
+    "c2_loglik_terms_workspace_bytes", "c2_loglik_terms", "c2_loglik_terms_grad",
     "c2h_factor", "c2h_solve_lower", "c2h_solve_upper", "c2h_matmul_lower", "c2h_matmul_upper",
     "c2h_general_matmul_lower", "c2h_general_matmul_upper", "c2h_factor_rev",
     "c2h_solve_lower_rev", "c2h_solve_upper_rev", "c2h_matmul_lower_rev", "c2h_matmul_upper_rev",
@@ -54,6 +55,8 @@ def load():
     lib.c2_device_count.restype = ctypes.c_int
     lib.c2_loglik_grad_workspace_bytes.restype = ctypes.c_size_t
     lib.c2_loglik_grad_workspace_bytes.argtypes = [ctypes.c_int64] * 3
+    lib.c2_loglik_terms_workspace_bytes.restype = ctypes.c_size_t
+    lib.c2_loglik_terms_workspace_bytes.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_int]
     lib.c2_kron_loglik_workspace_bytes.restype = ctypes.c_size_t
     lib.c2_kron_loglik_workspace_bytes.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_int] * 2
     _lib = lib

@@ -13,7 +13,7 @@ import torch
 
 from . import ops
 
-__all__ = ["log_likelihood", "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "LinAlgError"]
+__all__ = ["log_likelihood", "log_likelihood_terms", "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "LinAlgError"]
 
 
 class LinAlgError(RuntimeError):
@@ -53,6 +53,37 @@ class _LogLik(torch.autograd.Function):
 def log_likelihood(t, c, a, U, V, y):
     """Batched GP log-likelihood (B,), differentiable through torch.autograd."""
     return _LogLik.apply(t, c, a, U, V, y)
+
+
+class _LogLikTerms(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ar, cr, ac, bc, cc, dc, x, diag, y):
+        args = [v.detach().contiguous() for v in (ar, cr, ac, bc, cc, dc, x, diag, y)]
+        if not any(v.requires_grad for v in (ar, cr, ac, bc, cc, dc, x, diag, y)):
+            ll, flag = ops.loglik_terms(*args)
+            return ll
+        ll, grads, flag = ops.loglik_terms_grad(*args)
+        ctx.shared = [v.dim() == 1 for v in (ar, cr, ac, bc, cc, dc, x)]
+        ctx.save_for_backward(*grads)
+        return ll
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.saved_tensors
+        g1 = g[:, None]
+        zero = torch.zeros((), dtype=g.dtype, device=g.device)
+        out = []
+        for k, gr in enumerate(grads):
+            v = torch.where(g1 == 0, zero, gr * g1)   # a masked-out (failed) series contributes exactly zero
+            out.append(v.sum(0) if (k < 7 and ctx.shared[k]) else v)
+        return tuple(out)
+
+
+def log_likelihood_terms(ar, cr, ac, bc, cc, dc, x, diag, y):
+    """Batched GP log-likelihood (B,) as a differentiable function of the celerite coefficients, the times, the
+    white-noise diagonal and the data -- the gradient a sampler needs, computed by the device chain of c2_terms.hip.
+    Shared coefficients / times (one fewer dimension) receive the batch-summed gradient."""
+    return _LogLikTerms.apply(ar, cr, ac, bc, cc, dc, x, diag, y)
 
 
 def _reduce(g, like):

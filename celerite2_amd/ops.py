@@ -18,7 +18,7 @@ __all__ = [
     "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "general_matmul_lower",
     "general_matmul_upper", "factor_rev", "solve_lower_rev", "solve_upper_rev", "matmul_lower_rev",
     "matmul_upper_rev", "get_celerite_matrices", "loglik", "loglik_grad", "loglik_grad_workspace", "dot_tril",
-    "kron_loglik", "kron_loglik_grad",
+    "kron_loglik", "kron_loglik_grad", "loglik_terms", "loglik_terms_grad",
 ]
 
 _i64 = ctypes.c_int64
@@ -337,6 +337,66 @@ def kron_loglik_grad(t, c, a, U, V, alpha, diag, y, *, method="collapsed", work=
                                  ctypes.c_int(meth), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
     _lib.check(rc, "kron_loglik_grad")
     return ll, (bt, bc, ba, bU, bV, balpha, bdiag, by), flag
+
+
+def _terms_args(ar, cr, ac, bc, cc, dc, x, diag, y):
+    if diag.dim() != 2:
+        raise ValueError("Invalid shape: diag (must be (B, N))")
+    B, N = diag.shape
+    Jr, Jc = ar.shape[-1], ac.shape[-1]
+    batched = any(v.dim() == 2 for v in (ar, cr, ac, bc, cc, dc))
+    if batched and not all(v.dim() == 2 for v in (ar, cr, ac, bc, cc, dc)):
+        raise ValueError("coefficients must be all shared or all per-series")
+    _chk(ar, cr, ac, bc, cc, dc, x, diag, y)
+    _shape("x", x, (N,), (B, N)); _shape("y", y, (B, N))
+    for nm, v, w in (("ar", ar, Jr), ("cr", cr, Jr), ("ac", ac, Jc), ("bc", bc, Jc), ("cc", cc, Jc), ("dc", dc, Jc)):
+        _shape(nm, v, (w,), (B, w))
+    return B, N, Jr, Jc, batched
+
+
+def _coef_ptrs(ar, cr, ac, bc, cc, dc, Jr, Jc):
+    return [_p(ar if Jr else None), _p(cr if Jr else None), _p(ac if Jc else None), _p(bc if Jc else None),
+            _p(cc if Jc else None), _p(dc if Jc else None)]
+
+
+def loglik_terms(ar, cr, ac, bc, cc, dc, x, diag, y, *, work=None):
+    """Batched log-likelihood straight from the celerite coefficients (terms.py:117-177 + numpy.py:84-109).
+    ar, cr (Jr,)|(B,Jr); ac, bc, cc, dc (Jc,)|(B,Jc); x (N,)|(B,N); diag, y (B,N).  Returns (ll, flag)."""
+    B, N, Jr, Jc, batched = _terms_args(ar, cr, ac, bc, cc, dc, x, diag, y)
+    lib = _lib.load()
+    nbytes = lib.c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 0)
+    if work is None or work.numel() * 8 < nbytes:
+        work = torch.empty(nbytes // 8, dtype=torch.float64, device=diag.device)
+    ll = torch.empty(B, dtype=torch.float64, device=diag.device)
+    flag = torch.empty(B, dtype=torch.int32, device=diag.device)
+    rc = lib.c2_loglik_terms(_i64(B), _i64(N), _i64(Jr), _i64(Jc), *_coef_ptrs(ar, cr, ac, bc, cc, dc, Jr, Jc),
+                             ctypes.c_int(1 if batched else 0), _p(x), _i64(_bs(x, N)), _p(diag), _p(y), _p(ll),
+                             _p(flag), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
+    _lib.check(rc, "loglik_terms")
+    return ll, flag
+
+
+def loglik_terms_grad(ar, cr, ac, bc, cc, dc, x, diag, y, *, work=None):
+    """loglik_terms + reverse-mode gradient w.r.t. every input: returns
+    (ll, (bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, by), flag); coefficient gradients are per series (B, Jr|Jc) also when
+    the coefficients are shared by the batch."""
+    B, N, Jr, Jc, batched = _terms_args(ar, cr, ac, bc, cc, dc, x, diag, y)
+    lib = _lib.load()
+    dev = diag.device
+    nbytes = lib.c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 1)
+    if work is None or work.numel() * 8 < nbytes:
+        work = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+    f64 = dict(dtype=torch.float64, device=dev)
+    outs = [torch.empty((B, Jr), **f64), torch.empty((B, Jr), **f64)] + [torch.empty((B, Jc), **f64) for _ in range(4)] + \
+           [torch.empty((B, N), **f64) for _ in range(3)]
+    ll = torch.empty(B, **f64)
+    flag = torch.empty(B, dtype=torch.int32, device=dev)
+    optr = [_p(o if o.numel() else None) for o in outs[:6]] + [_p(o) for o in outs[6:]]
+    rc = lib.c2_loglik_terms_grad(_i64(B), _i64(N), _i64(Jr), _i64(Jc), *_coef_ptrs(ar, cr, ac, bc, cc, dc, Jr, Jc),
+                                  ctypes.c_int(1 if batched else 0), _p(x), _i64(_bs(x, N)), _p(diag), _p(y), _p(ll),
+                                  *optr, _p(flag), _p(work), ctypes.c_size_t(work.numel() * 8), _stream())
+    _lib.check(rc, "loglik_terms_grad")
+    return ll, tuple(outs), flag
 
 
 def _loglik_grad_composite(t, c, a, U, V, y):

@@ -190,6 +190,24 @@ int c2_kron_loglik_grad(int64_t B, int64_t N, int64_t M, int64_t J, const double
                         double *ba, double *bU, double *bV, double *balpha, double *bdiag, double *by, int32_t *flag,
                         int method, void *work, size_t work_bytes, c2_stream_t stream);
 
+/* Log-likelihood (+ gradient) from the celerite COEFFICIENTS: the chain
+ * get_celerite_matrices (driver.cpp:422-477, terms.py:117-177) -> factor -> solve_lower -> reductions and its
+ * reverse, which the reference's jax / pymc frontends obtain by autodiff of their term code
+ * (python/celerite2/jax/terms.py, pymc/terms.py), kept on the device.  Coefficients ar, cr (B,Jr), ac, bc, cc, dc
+ * (B,Jc), all per series (coef_batched = 1) or all shared by the batch (0); x (B,N) / shared (N,) via x_bs;
+ * diag, y (B,N).  J = Jr + 2 Jc <= C2_MAX_WIDTH.  Gradients (per series, also for shared coefficients):
+ * bar, bcr (B,Jr); bac, bbc, bcc, bdc (B,Jc); bx, bdiag, by (B,N).  A failed series: ll = -inf, NaN gradients. */
+size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t Jc, int grad);
+int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr, const double *ac,
+                    const double *bc, const double *cc, const double *dc, int coef_batched, const double *x,
+                    int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag, void *work,
+                    size_t work_bytes, c2_stream_t stream);
+int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr,
+                         const double *ac, const double *bc, const double *cc, const double *dc, int coef_batched,
+                         const double *x, int64_t x_bs, const double *diag, const double *y, double *ll, double *bar,
+                         double *bcr, double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag,
+                         double *by, int32_t *flag, void *work, size_t work_bytes, c2_stream_t stream);
+
 /* dot_tril -- python/celerite2/numpy.py:100-102: Z = Y * sqrt(d)[:,None];
  * Z += tril(U W^T) Z.  Y == Z allowed. */
 int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,

@@ -1,0 +1,135 @@
+# -*- coding: utf-8 -*-
+"""Log-likelihood and its gradient w.r.t. the celerite COEFFICIENTS on the device (c2_terms.hip; SURVEY.md section
+8f-1) against (1) the CPU oracle's gradients w.r.t. (t, c, a, U, V, y) pushed through a numpy restatement of the reverse
+of get_celerite_matrices (driver.cpp:456-474), and (2) central finite differences of the DENSE log-likelihood."""
+import numpy as np
+import pytest
+
+from oracle import dense
+
+pytestmark = pytest.mark.gpu
+NAMES = ("bar", "bcr", "bac", "bbc", "bcc", "bdc", "bx", "bdiag", "by")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+    from celerite2_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def dev(*xs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in xs]
+
+
+def close(a, b, tol=1e-10, floor=1e-12):
+    a = a.cpu().numpy() if hasattr(a, "cpu") else a
+    np.testing.assert_allclose(a, b, rtol=tol, atol=floor * max(1.0, float(np.abs(b).max())))
+
+
+def coeffs(B, Jr, Jc, rng):
+    ar = rng.uniform(0.5, 1.5, (B, Jr)); cr = rng.uniform(0.05, 0.5, (B, Jr))
+    ac = rng.uniform(0.5, 2.0, (B, Jc)); bc = ac * rng.uniform(0.0, 0.2, (B, Jc))
+    cc = rng.uniform(0.02, 0.3, (B, Jc)); dc = rng.uniform(0.2, 3.0, (B, Jc))
+    return ar, cr, ac, bc, cc, dc
+
+
+def oracle_chain(oracle, ar, cr, ac, bc, cc, dc, x, diag, y):
+    """ll and the nine gradients for ONE series: CPU oracle + the reverse of the matrix recipe in numpy."""
+    co = dense.Coeffs(ar=ar, cr=cr, ac=ac, bc=bc, cc=cc, dc=dc)
+    c, a, U, V = dense.celerite_matrices(co, x, diag)
+    ll, (bt, bcv, ba, bU, bV, by), flag = oracle.loglik_grad(x, c, a, U, V, y)
+    assert flag == 0
+    Jr, Jc = len(ar), len(ac)
+    bar = ba.sum() + bU[:, :Jr].sum(0)
+    bcr = bcv[:Jr]
+    arg = dc[None, :] * x[:, None]
+    co_, s_ = np.cos(arg), np.sin(arg)
+    U0, U1 = U[:, Jr::2], U[:, Jr + 1::2]
+    bU0, bU1, bV0, bV1 = bU[:, Jr::2], bU[:, Jr + 1::2], bV[:, Jr::2], bV[:, Jr + 1::2]
+    bac = ba.sum() + (bU0 * co_ + bU1 * s_).sum(0)
+    bbc = (bU0 * s_ - bU1 * co_).sum(0)
+    bcc = bcv[Jr::2] + bcv[Jr + 1::2]
+    g = -bU0 * U1 + bU1 * U0 - bV0 * s_ + bV1 * co_
+    bdc = (g * x[:, None]).sum(0)
+    bx = bt + (g * dc[None, :]).sum(1)
+    return ll, (bar, bcr, bac, bbc, bcc, bdc, bx, ba.copy(), by)
+
+
+@pytest.mark.parametrize("B,N,Jr,Jc", [(5, 200, 1, 2), (3, 1000, 0, 4), (70, 64, 2, 0), (2, 33, 3, 1), (1, 1, 1, 1)])
+def test_loglik_terms_vs_oracle_chain(ops, oracle, B, N, Jr, Jc):
+    rng = np.random.default_rng(11)
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, N / 10.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    want = [oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b]) for b in range(B)]
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    ll, flag = ops.loglik_terms(*args)
+    assert int(flag.abs().sum()) == 0
+    close(ll, np.array([w[0] for w in want]))
+    ll2, grads, flag2 = ops.loglik_terms_grad(*args)
+    close(ll2, np.array([w[0] for w in want]))
+    for k, (nm, g) in enumerate(zip(NAMES, grads)):
+        e = np.stack([w[1][k] for w in want])
+        if e.size:
+            close(g, e)
+    # shared coefficients and a shared grid: same series replicated with its own data
+    args_s = dev(ar[0], cr[0], ac[0], bc[0], cc[0], dc[0], x[0], diag, y)
+    want_s = [oracle_chain(oracle, ar[0], cr[0], ac[0], bc[0], cc[0], dc[0], x[0], diag[b], y[b]) for b in range(B)]
+    ll3, grads3, _ = ops.loglik_terms_grad(*args_s)
+    close(ll3, np.array([w[0] for w in want_s]))
+    for k, g in enumerate(grads3):
+        e = np.stack([w[1][k] for w in want_s])
+        if e.size:
+            close(g, e)
+
+
+def test_loglik_terms_vs_dense_finite_differences(ops):
+    """Independent of the oracle: central differences of the dense Cholesky log-likelihood in every coefficient."""
+    rng = np.random.default_rng(5)
+    B, N, Jr, Jc = 1, 40, 1, 2
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, 8.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+
+    def ll_dense(vals):
+        co = dense.Coeffs(**vals)
+        return dense.dense_loglik(dense.dense_matrix(co, x[0], diag[0]), y[0])
+
+    base = dict(ar=ar[0], cr=cr[0], ac=ac[0], bc=bc[0], cc=cc[0], dc=dc[0])
+    ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
+    assert abs(float(ll[0]) - ll_dense(base)) <= 1e-10 * abs(ll_dense(base))
+    got = dict(zip(("ar", "cr", "ac", "bc", "cc", "dc"), [g[0].cpu().numpy() for g in grads[:6]]))
+    h = 1e-6
+    for name in base:
+        for k in range(len(base[name])):
+            vp = {n: v.copy() for n, v in base.items()}; vm = {n: v.copy() for n, v in base.items()}
+            vp[name][k] += h; vm[name][k] -= h
+            fd = (ll_dense(vp) - ll_dense(vm)) / (2 * h)
+            assert abs(fd - got[name][k]) <= 2e-6 * max(1.0, abs(fd)), (name, k, fd, got[name][k])
+
+
+def test_log_likelihood_terms_autograd(ops, oracle):
+    """torch.autograd over the coefficients: per-series and shared hyper-parameters."""
+    import torch
+    from celerite2_amd import autograd as ag
+    rng = np.random.default_rng(2)
+    B, N, Jr, Jc = 4, 120, 1, 2
+    ar, cr, ac, bc, cc, dc = coeffs(1, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, 12.0, N))
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x)[None, :] + 0.1 * rng.standard_normal((B, N))
+    want = [oracle_chain(oracle, ar[0], cr[0], ac[0], bc[0], cc[0], dc[0], x, diag[b], y[b]) for b in range(B)]
+    leaves = [v.requires_grad_(True) for v in dev(ar[0], cr[0], ac[0], bc[0], cc[0], dc[0], x, diag, y)]
+    w = torch.tensor([0.5, -1.0, 2.0, 0.25], dtype=torch.float64, device="cuda")
+    (ag.log_likelihood_terms(*leaves) * w).sum().backward()
+    wn = w.cpu().numpy()
+    for k, leaf in enumerate(leaves):
+        per = np.stack([wn[b] * want[b][1][k] for b in range(B)])
+        close(leaf.grad, per.sum(0) if k < 7 else per)
+    with pytest.raises(ValueError, match="Invalid shape: y"):
+        ops.loglik_terms(*[v.detach() for v in leaves[:8]], leaves[8].detach()[:, :5].contiguous())

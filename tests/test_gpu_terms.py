@@ -31,8 +31,9 @@ def close(a, b, tol=1e-10, floor=1e-12):
 
 def coeffs(B, Jr, Jc, rng):
     ar = rng.uniform(0.5, 1.5, (B, Jr)); cr = rng.uniform(0.05, 0.5, (B, Jr))
-    ac = rng.uniform(0.5, 2.0, (B, Jc)); bc = ac * rng.uniform(0.0, 0.2, (B, Jc))
+    ac = rng.uniform(0.5, 2.0, (B, Jc))
     cc = rng.uniform(0.02, 0.3, (B, Jc)); dc = rng.uniform(0.2, 3.0, (B, Jc))
+    bc = ac * cc / dc * rng.uniform(0.0, 0.9, (B, Jc))   # a valid (positive semi-definite) term needs ac cc >= bc dc
     return ar, cr, ac, bc, cc, dc
 
 

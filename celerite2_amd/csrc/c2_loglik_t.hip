@@ -169,11 +169,12 @@ __device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, i
                                          const double *tile, int lane, int last) {
   const int64_t r = n0 + (lane & 7);
   if (last == kWave - 1 && n0 >= lo && n0 + ST - 1 <= hi) {  // uniform: full wavefront, whole tile in range
+    double v[8];  // all reads first, then all stores (one reused register would serialise eight LDS latencies)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int s = 8 * i + lane / 8;
-      base[(int64_t)s * N + r] = tile[s * SSTR + (lane & 7)];
-    }
+    for (int i = 0; i < 8; ++i) v[i] = tile[(8 * i + lane / 8) * SSTR + (lane & 7)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) base[(int64_t)(8 * i + lane / 8) * N + r] = v[i];
     return;
   }
 #pragma unroll
@@ -652,8 +653,24 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tBT[lane * SSTR + (int)(n & (ST - 1))] = btn;
       row1_write(tBV, lane, bVn);
       lds_order();
-      row1_flush(bUb, N, n, tU, lane, last);
-      row1_flush(bVb, N, n - 1, tBV, lane, last);
+      {  // both rows leave together: the eight LDS reads are issued back to back, then the eight stores (one register
+         // reused for all of them makes every read wait out the LDS latency on its own: ~1000 cycles per step)
+        double fl[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
+          const double2 v0 = *reinterpret_cast<const double2 *>(tU + sr * RS1 + 2 * (lane & 3));
+          const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RS1 + 2 * (lane & 3));
+          fl[4 * i] = v0.x; fl[4 * i + 1] = v0.y; fl[4 * i + 2] = v1.x; fl[4 * i + 3] = v1.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
+          *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 3)) = make_double2(fl[4 * i], fl[4 * i + 1]);
+          *reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)) = make_double2(fl[4 * i + 2], fl[4 * i + 3]);
+        }
+      }
 
       // ---- every 8th step: scalar tiles turn; every 16th: the checkpoint replaces the recursed state -----------------
       if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, 0, N - 1, tBT, lane, last);  // bt rows n .. n+7

@@ -1120,6 +1120,14 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
   return check_launch();
 }
 
+extern "C" int c2_internal_generalK(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1,
+                                    int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c, int64_t c_bs,
+                                    const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z,
+                                    c2_stream_t stream);
+static bool use_generalK() {
+  const char *e = getenv("C2_GENERALK");  // C2_GENERALK=0: the first-round kernels (A/B runs, tests of both paths)
+  return !(e && e[0] == '0');
+}
 template <bool LOWER>
 static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, int64_t t1_bs,
                           const double *t2, int64_t t2_bs, const double *c, int64_t c_bs, const double *U,
@@ -1129,6 +1137,12 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   hipStream_t s = (hipStream_t)stream;
   if (zero_z) {
     if (int e = hip_check(hipMemsetAsync(Z, 0, sizeof(double) * B * N * nrhs, s))) return e;
+  }
+  // three or more right-hand sides: lanes over the right-hand sides, one merge event per iteration (c2_general.hip)
+  if (nrhs >= 3 && use_generalK()) {
+    const int e = c2_internal_generalK(LOWER ? 1 : 0, B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F, 0,
+                                       stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
   }
   constexpr int KT = 4;
   // Two data-parallel phases (state sweep over t2, then one group per output row) need every state row in memory:

@@ -1180,6 +1180,10 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   }
   return rc;
 }
+extern "C" int c2_internal_sweepK_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
+                                      int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                      const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
+                                      double *bc, double *bU, double *bV, double *bY, c2_stream_t stream);
 template <bool LOWER, bool SOLVE>
 static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
                             const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
@@ -1192,6 +1196,14 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
     return c2_internal_sweep1_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU,
                                   bV, bY, stream);
+  {  // several right-hand sides: lanes over them (c2_sweep_rev.hip) where the shape fits; C2_SWEEPK_REV=0 for A/B runs
+    const char *ev = getenv("C2_SWEEPK_REV");
+    if (!(ev && ev[0] == '0')) {
+      const int e = c2_internal_sweepK_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ,
+                                           bt, bc, bU, bV, bY, stream);
+      if (e != C2_ERR_UNSUPPORTED) return e;
+    }
+  }
   C2_DISPATCH_G(group_size(J),
                 hipLaunchKernelGGL((k_sweep_rev<G, 4, LOWER, SOLVE>), grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J,
                                    nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));

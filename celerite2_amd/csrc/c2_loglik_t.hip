@@ -30,7 +30,10 @@ using namespace c2;
 
 constexpr int J = 8;
 constexpr int NS = J * (J + 1) / 2;  // packed symmetric J x J
-constexpr int C = 16;                // checkpoint interval (rows)
+#ifndef C2T_C
+#define C2T_C 32
+#endif
+constexpr int C = C2T_C;             // checkpoint interval (rows)
 constexpr double kGuard = kBackwardGuard;  // largest allowed max_j c_j * (t_end - t_start) of a segment
 #ifndef C2T_RT
 #define C2T_RT 2
@@ -672,7 +675,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         }
       }
 
-      // ---- every 8th step: scalar tiles turn; every 16th: the checkpoint replaces the recursed state -----------------
+      // ---- every 8th step: scalar tiles turn; every 32nd: the checkpoint replaces the recursed state -----------------
       if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, 0, N - 1, tBT, lane, last);  // bt rows n .. n+7
       if (rs == 0) {  // row n-1 is the lowest row of its tile
         sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, last);

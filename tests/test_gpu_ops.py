@@ -187,8 +187,8 @@ def test_two_columns_per_lane_variant(ops, oracle, monkeypatch, B, N):
 @pytest.mark.parametrize("B,N", [(1, 1), (3, 2), (5, 3), (64, 16), (65, 17), (70, 33), (130, 100), (7, 1031), (200, 257)])
 def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N):
     """J = 8 has a third lane mapping for chip-filling batches (c2_loglik_t.hip: one lane per series, rows through LDS
-    transposes, reverse sweep by the backward recursion between checkpoints every 16 rows): same results as the oracle
-    on ragged wavefronts, around the tile (8 rows) and checkpoint (16 rows) edges, with unpaired rates, with a failed
+    transposes, reverse sweep by the backward recursion between checkpoints every 32 rows): same results as the oracle
+    on ragged wavefronts, around the tile (8 rows) and checkpoint (32 rows) edges, with unpaired rates, with a failed
     series, with shared t / c -- and the stability guard hands a batch with long gaps to the replay kernels."""
     monkeypatch.setenv("C2_LANES", "1")
     J = 8

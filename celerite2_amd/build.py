@@ -84,8 +84,23 @@ def build_pybind(force=False):
 
 
 def build_all(force=False):
+    """Build what is stale; prints one summary line (wall time, what was recompiled) so that a build log says
+    unambiguously whether the compilers ran or everything was already up to date."""
+    import time
+
+    t0 = time.time()
+    before = {f: os.path.getmtime(f) for f in [LIB] + [ext_path(n) for n in ("driver", "backprop")] if os.path.exists(f)}
+    objdir = os.path.join(HERE, "build")
+    obj_before = {f: os.path.getmtime(os.path.join(objdir, f)) for f in (os.listdir(objdir) if os.path.isdir(objdir) else [])}
     build_hip(force)
     build_pybind(force)
+    rebuilt = [os.path.basename(f) for f in [LIB] + [ext_path(n) for n in ("driver", "backprop")]
+               if before.get(f) != os.path.getmtime(f)]
+    objs = [f for f in (os.listdir(objdir) if os.path.isdir(objdir) else [])
+            if obj_before.get(f) != os.path.getmtime(os.path.join(objdir, f))]
+    print("celerite2_amd.build: %.1f s; recompiled objects: %s; relinked: %s"
+          % (time.time() - t0, ", ".join(sorted(objs)) or "none (up to date)", ", ".join(rebuilt) or "none (up to date)"),
+          flush=True)
 
 
 if __name__ == "__main__":

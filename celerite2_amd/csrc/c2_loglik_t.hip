@@ -204,6 +204,43 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
   return __hiloint2double(h, l);
 }
 
+// Streaming hints (C2T_NT): the records are written once by the forward pass and read once by the reverse sweep, the
+// gradients are written once -- none of it should displace the half-used lines of the API rows from L2.
+#ifndef C2T_NT
+#define C2T_NT 0
+#endif
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2_stream(const double2 *p) {
+#if C2T_NT
+  const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ double ld1_stream(const double *p) {
+#if C2T_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st2_stream(double2 *p, double2 v) {
+#if C2T_NT
+  d2v w; w.x = v.x; w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<d2v *>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st1_stream(double *p, double v) {
+#if C2T_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // p_j = exp(c_j dt).  PAIRED: c_{2k} == c_{2k+1} for every series of the wavefront (complex terms, terms.py:171-173):
 // one exponential per pair -- bit-identical to evaluating both.
 template <bool PAIRED>
@@ -346,15 +383,15 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
             if (r & 1) { int e; prod = frexp(prod, &e); eacc += e; }
             if (REC) {
 #pragma unroll
-              for (int q = 0; q < J / 2; ++q) recW[((size_t)n * (J / 2) + q) * kWave + lane] = make_double2(w[2 * q], w[2 * q + 1]);
-              recDZ[(size_t)n * kWave + lane] = make_double2(d, z);
+              for (int q = 0; q < J / 2; ++q) st2_stream(&recW[((size_t)n * (J / 2) + q) * kWave + lane], make_double2(w[2 * q], w[2 * q + 1]));
+              st2_stream(&recDZ[(size_t)n * kWave + lane], make_double2(d, z));
               const bool seg_end = (n % C == 0) || (n == N - 1);
               if (seg_end) {  // uniform over the wavefront
                 double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) ck[k * kWave + lane] = S[k];
+                for (int k = 0; k < NS; ++k) st1_stream(&ck[k * kWave + lane], S[k]);
 #pragma unroll
-                for (int j2 = 0; j2 < J; ++j2) ck[(NS + j2) * kWave + lane] = F[j2];
+                for (int j2 = 0; j2 < J; ++j2) st1_stream(&ck[(NS + j2) * kWave + lane], F[j2]);
                 gmax = fmax(gmax, cmax * (tn - tseg));
                 tseg = tn;
               }
@@ -514,9 +551,9 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   auto load_ckpt = [&](int64_t n) {
     const double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) apark(ck[k * kWave + lane], Slo[k], Shi[k]);
+    for (int k = 0; k < NS; ++k) apark(ld1_stream(&ck[k * kWave + lane]), Slo[k], Shi[k]);
 #pragma unroll
-    for (int j = 0; j < J; ++j) F[j] = ck[(NS + j) * kWave + lane];
+    for (int j = 0; j < J; ++j) F[j] = ld1_stream(&ck[(NS + j) * kWave + lane]);
   };
   auto t_fetch = [&](int64_t n0, double (&st)[8]) {
     int64_t r = n0 + io.piece; r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
@@ -527,11 +564,11 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     row = row < 0 ? 0 : row;
 #pragma unroll
     for (int q = 0; q < J / 2; ++q) {
-      const double2 v = recW[((size_t)row * (J / 2) + q) * kWave + lane];
+      const double2 v = ld2_stream(&recW[((size_t)row * (J / 2) + q) * kWave + lane]);
       wv[2 * q] = v.x; wv[2 * q + 1] = v.y;
     }
   };
-  auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)(row < 0 ? 0 : row) * kWave + lane]; };
+  auto dz_fetch = [&](int64_t row) { return ld2_stream(&recDZ[(size_t)(row < 0 ? 0 : row) * kWave + lane]); };
 
   if (N >= 2) {
     const int64_t nf = N - 1;
@@ -670,8 +707,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
-          *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 3)) = make_double2(fl[4 * i], fl[4 * i + 1]);
-          *reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)) = make_double2(fl[4 * i + 2], fl[4 * i + 3]);
+          st2_stream(reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 3)), make_double2(fl[4 * i], fl[4 * i + 1]));
+          st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)), make_double2(fl[4 * i + 2], fl[4 * i + 3]));
         }
       }
 

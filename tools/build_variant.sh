@@ -7,8 +7,11 @@ tag=$1; src=$2; shift 2
 obj=celerite2_amd/build/$(basename ${src%.hip})_$tag.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -mllvm --amdgpu-sched-strategy=max-ilp "$@" -c celerite2_amd/csrc/$src -o $obj
 objs=""
+stem=$(basename ${src%.hip})
 for o in celerite2_amd/build/*.o; do
-  case $o in *_*_$tag.o|*_$tag.o) ;; *) b=$(basename $o .o); if [ "$b" != "$(basename ${src%.hip})" ] && [[ ! $b =~ _(rt|v)[0-9a-z]+$ ]]; then objs="$objs $o"; fi;; esac
+  b=$(basename $o .o)
+  # every regular object except the one being replaced and except variant objects of earlier A/B builds (<stem>_<tag>.o)
+  case $b in ${stem}|${stem}_*) ;; *) objs="$objs $o";; esac
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $obj -o celerite2_amd/libcelerite2_amd_$tag.so
 echo built celerite2_amd/libcelerite2_amd_$tag.so

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          const unsigned long long *__restrict__ gate) {
   // `gate` (nullable): this launch is the fallback of the one-lane-per-series path and runs only when the stability
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
-  if (gate && !(__longlong_as_double((long long)*gate) > kBackwardGuard)) return;
+  if (gate_closed(gate)) return;
   // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
   // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
   // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          const double *__restrict__ fr_bd,
                                                          const double *__restrict__ fr_bW,
                                                          const unsigned long long *__restrict__ gate) {
-  if (gate && !(__longlong_as_double((long long)*gate) > kBackwardGuard)) return;  // see k_loglik_fwd
+  if (gate_closed(gate)) return;  // see k_loglik_fwd
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
@@ -844,6 +844,12 @@ static bool use_lanes1(int64_t B, int64_t J, bool grad) {
 
 extern "C" {
 
+int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                   int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                                   double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                   int32_t *flag, void *work, const unsigned long long *gate, c2_stream_t stream);
+size_t c2_internal_loglik_grad_replay_doubles(int64_t B, int64_t N, int64_t J);
+
 int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
               const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
               c2_stream_t stream) {
@@ -892,6 +898,8 @@ extern "C" int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, 
                                          double *bV, double *by, int32_t *flag, double *rec, unsigned long long *guard,
                                          c2_stream_t stream);
 
+size_t c2_internal_loglik_grad_replay_doubles(int64_t B, int64_t N, int64_t J) { return grad_ws(B, N, J).total; }
+
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
   size_t n = grad_ws(B, N, J).total;
@@ -914,9 +922,9 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
   if (use_lanes4(B, J, true))
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
-  hipStream_t s = (hipStream_t)stream;
   const unsigned long long *gate = nullptr;
   if (use_lanes1(B, J, true)) {
+    hipStream_t s = (hipStream_t)stream;
     // One lane per series: forward with records, then the backward-recursion reverse sweep.  The forward pass leaves
     // its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the gated
     // replay pair below produces the gradients (same outputs, same workspace region, decided on the device).
@@ -928,6 +936,17 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
       return e;
     gate = guard;
   }
+  return c2_internal_loglik_grad_replay(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, gate,
+                                        stream);
+}
+
+// The checkpoint / replay pair (lanes of a series share its state), every kernel behind `gate` (gate_closed; nullptr: run).
+// `work`: grad_ws(B, N, J).total doubles.
+int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                   int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                                   double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                   int32_t *flag, void *work, const unsigned long long *gate, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   const GradWs ws = grad_ws(B, N, J);

@@ -10,6 +10,10 @@ constexpr double kLn2 = 0.69314718055994530941723212145818;
 // One-lane-per-series gradient path (c2_loglik_t.hip): the backward recursion is used only while
 // max_j c_j * (t_end - t_start) <= kBackwardGuard on every checkpoint segment (error growth <= e^{2 * guard}).
 constexpr double kBackwardGuard = 2.0;
+// Kernels of a fallback chain take the guard word as `gate` and run only if the fast path declined (nullptr: always run).
+__device__ __forceinline__ bool gate_closed(const unsigned long long *gate) {
+  return gate && !(__longlong_as_double((long long)*gate) > kBackwardGuard);
+}
 
 // 1/d for a well-scaled positive d: v_rcp_f64 seed + two Newton steps (full fp64 accuracy; the
 // denormal/overflow scaling of a general IEEE division is not needed for pivots of an SPD matrix).
@@ -50,6 +54,43 @@ __device__ __forceinline__ double exp_decay(double x) {
   q = fma(q, r, 1.0);
   q = fma(q, r, 1.0);
   return ldexp(q, (int)k);
+}
+
+// sin and cos of the phase of a complex term, dc * x (driver.cpp:466-467), for the kernels that generate U and V rows
+// on the fly.  Cody-Waite reduction by pi/2 in three fused steps (pi/2 = hi + mid + lo to ~160 bits; the first product
+// is exact inside the fma), then the fdlibm kernel polynomials on |r| <= pi/4 (sin: degree 13, cos: degree 14; < 1 ulp).
+// ~32 VALU instructions against ~100 for the library call; arguments beyond 2^20 quarter turns take the library path.
+constexpr double kSincosFastMax = 1.6e6;
+// |x| < kSincosFastMax only (the caller guarantees it; no branch, no library code in the caller's loop)
+__device__ __forceinline__ void sincos_cw_fast(double x, double &sn, double &cs) {
+  const double k = rint(x * 6.36619772367581382433e-01);
+  double r = fma(k, -1.57079632679489655800e+00, x);
+  r = fma(k, -6.12323399573676603587e-17, r);
+  r = fma(k, 1.49738490485916983e-33, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(ps, z, 2.75573137070700676789e-06);
+  ps = fma(ps, z, -1.98412698298579493134e-04);
+  ps = fma(ps, z, 8.33333333332248946124e-03);
+  ps = fma(ps, z, -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(pc, z, -2.75573143513906633035e-07);
+  pc = fma(pc, z, 2.48015872894767294178e-05);
+  pc = fma(pc, z, -1.38888888888741095749e-03);
+  pc = fma(pc, z, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int q = (int)k & 3;
+  const double a = (q & 1) ? cr : sr, b = (q & 1) ? sr : cr;
+  sn = (q & 2) ? -a : a;
+  cs = ((q + 1) & 2) ? -b : b;
+}
+__device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs) {
+  if (!(fabs(x) < kSincosFastMax)) {  // also NaN / inf
+    sincos(x, &sn, &cs);
+    return;
+  }
+  sincos_cw_fast(x, sn, cs);
 }
 
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }

@@ -55,7 +55,7 @@ __host__ __device__ constexpr int sym(int i, int j) { return i <= j ? sidx(i, j)
 //   DZ  : [wave][n][64] double2           ((d_n, z_n))
 //   CK  : [wave][k][NS + J][64] double    (state after row n_k: S packed, F)
 struct Rec {
-  size_t w, dz, ck, total;  // offsets / total in doubles
+  size_t w, dz, ck, t, total;  // offsets / total in doubles
   int64_t nck;              // checkpoints per series
 };
 // Checkpoints = state after rows C, 2C, ... and after the last row N-1: ceil((N-1)/C) of them; row n sits at
@@ -69,7 +69,8 @@ __host__ inline Rec rec_layout(int64_t B, int64_t N) {
   r.w = 0;
   r.dz = r.w + waves * (size_t)N * J * kWave;
   r.ck = r.dz + waves * (size_t)N * 2 * kWave;
-  r.total = r.ck + waves * (size_t)r.nck * (NS + J) * kWave;
+  r.t = r.ck + waves * (size_t)r.nck * (NS + J) * kWave;
+  r.total = r.t + waves * (size_t)N * kWave;
   return r;
 }
 
@@ -197,6 +198,14 @@ __device__ __forceinline__ void apark(double x, int &lo, int &hi) {
   asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(__double2loint(x)));
   asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(__double2hiint(x)));
 }
+// A global load straight into an AGPR (no arithmetic register in flight): dst = *(int *)(sbase + voff + IMM).  The
+// compiler does not see it as a load -- the consumer waits with await_aloads().  (Its own s_waitcnt's stay correct: the
+// counter is in order, an extra outstanding load only makes them wait longer.)
+template <int IMM>
+__device__ __forceinline__ void aload(int &dst, const double *sbase, unsigned voff) {
+  asm volatile("global_load_dword %0, %1, %2 offset:%3 nt" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
+}
+__device__ __forceinline__ void await_aloads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ double afetch(int lo, int hi) {
   int l, h;
   asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
@@ -254,17 +263,111 @@ __device__ __forceinline__ void decay(const double (&c)[J], double dt, double (&
   }
 }
 
+// Section timing of the reverse step (diagnostic builds only: tools/build_variant.sh prof c2_loglik_t.hip -DC2T_PROF).
+#ifdef C2T_PROF
+__device__ unsigned long long c2t_prof[8];
+#define C2T_TICK(k)                                                    \
+  do {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();      \
+    prof_[k] += now_ - tick_;                                          \
+    tick_ = now_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  } while (0)
+#else
+#define C2T_TICK(k) do {} while (0)
+#endif
+
+// ---- rows generated from the celerite coefficients (driver.cpp:456-474) ----------------------------------------------------
+// JC >= 0 turns a kernel into its coefficient-level form: the series has JR = J - 2 JC real and
+// JC complex terms, U_n and V_n are formed in the lane from (ar, ac, bc, dc) and x_n (one sincos per complex term), the
+// `a` argument is the white-noise diagonal (a_n = diag_n + sum ar + sum ac), the rates are c = [cr, cc0, cc0, ...].
+// No U / V rows are read: 24 bytes of input per step instead of 152.  JC = -1: rows come from the caller's arrays.
+struct TermsArgs {
+  const double *ar, *cr, *ac, *bc, *cc, *dc;
+  int batched;  // coefficients per series (1) or shared by the batch (0)
+};
+template <int JC>
+struct TermCoef {
+  static constexpr int JR = J - 2 * (JC > 0 ? JC : 0);
+  double ar[JR > 0 ? JR : 1], ac[JC > 0 ? JC : 1], bc[JC > 0 ? JC : 1], dc[JC > 0 ? JC : 1], A0;
+  __device__ __forceinline__ void load(const TermsArgs &T, int64_t b, double (&cj)[J]) {
+    const int64_t br = T.batched ? b * JR : 0, bk = T.batched ? b * JC : 0;
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < JR; ++r) { ar[r] = T.ar[br + r]; cj[r] = T.cr[br + r]; sum += ar[r]; }
+#pragma unroll
+    for (int k = 0; k < JC; ++k) {
+      ac[k] = T.ac[bk + k]; bc[k] = T.bc[bk + k]; dc[k] = T.dc[bk + k];
+      cj[JR + 2 * k] = cj[JR + 2 * k + 1] = T.cc[bk + k];
+      sum += ac[k];   // driver.cpp:456-458: sum of ar, then of ac
+    }
+    A0 = sum;
+  }
+  // FAST: every phase dc_k x of the wavefront is known to lie inside the range of the branch-free reduction (phases_fast
+  // below); otherwise the library's sincos with its large-argument reduction -- as two instantiations of the whole
+  // kernel body, so that the common case carries neither the branch nor the library code in its loop.
+  template <bool FAST>
+  static __device__ __forceinline__ void sc(double ph, double &sn, double &cs) {
+    if constexpr (FAST) sincos_cw_fast(ph, sn, cs);
+    else sincos(ph, &sn, &cs);
+  }
+  // t sorted: the largest |x| of a series sits at one of its ends
+  __device__ __forceinline__ bool phases_fast(double x_first, double x_last) const {
+    const double xm = fmax(fabs(x_first), fabs(x_last));
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < JC; ++k) ok = ok && (fabs(dc[k]) * xm < kSincosFastMax);
+    return ok;
+  }
+  template <bool FAST>
+  __device__ __forceinline__ void rows(double xn, double (&u)[J], double (&v)[J]) const {
+#pragma unroll
+    for (int r = 0; r < JR; ++r) { u[r] = ar[r]; v[r] = 1.0; }
+#pragma unroll
+    for (int k = 0; k < JC; ++k) {
+      double sn, cs;
+      sc<FAST>(dc[k] * xn, sn, cs);
+      v[JR + 2 * k] = cs; v[JR + 2 * k + 1] = sn;
+      u[JR + 2 * k] = fma(ac[k], cs, bc[k] * sn);
+      u[JR + 2 * k + 1] = fma(ac[k], sn, -(bc[k] * cs));
+    }
+  }
+  // the same, keeping sin / cos of every complex term for the reverse of the recipe
+  template <bool FAST>
+  __device__ __forceinline__ void rows_sc(double xn, double (&u)[J], double (&sn)[JC > 0 ? JC : 1],
+                                          double (&cs)[JC > 0 ? JC : 1]) const {
+#pragma unroll
+    for (int r = 0; r < JR; ++r) u[r] = ar[r];
+#pragma unroll
+    for (int k = 0; k < JC; ++k) {
+      sc<FAST>(dc[k] * xn, sn[k], cs[k]);
+      u[JR + 2 * k] = fma(ac[k], cs[k], bc[k] * sn[k]);
+      u[JR + 2 * k + 1] = fma(ac[k], sn[k], -(bc[k] * cs[k]));
+    }
+  }
+  // decays: one exponential per real column and per complex PAIR
+  __device__ __forceinline__ void decay(const double (&cj)[J], double dt, double (&p)[J]) const {
+#pragma unroll
+    for (int r = 0; r < JR; ++r) p[r] = exp_decay(cj[r] * dt);
+#pragma unroll
+    for (int k = 0; k < JC; ++k) p[JR + 2 * k] = p[JR + 2 * k + 1] = exp_decay(cj[JR + 2 * k] * dt);
+  }
+};
+
 // =============================================================================================================
 // Forward pass.  REC = false: log-likelihood only.  REC = true: also W rows, (d, z) pairs, checkpoints and the
 // stability guard of the backward recursion.
 // =============================================================================================================
-template <bool REC, bool PAIRED>
+template <bool REC, bool PAIRED, int JC = -1, bool FAST = true>
 __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                          const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                          const double *__restrict__ U, const double *__restrict__ V,
                                          const double *__restrict__ y, double *__restrict__ ll,
                                          int32_t *__restrict__ flag, double *__restrict__ rec, Rec R,
-                                         unsigned long long *__restrict__ guard, double *lds) {
+                                         unsigned long long *__restrict__ guard, double *lds,
+                                         const TermsArgs T = TermsArgs{}) {
+  constexpr bool TERMS = JC >= 0;
   const int lane = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * kWave;
   const int last = (int)((B - 1 - b0) < (kWave - 1) ? (B - 1 - b0) : (kWave - 1));
@@ -278,8 +381,12 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   const int64_t tN = t_bs ? N : 0;  // series stride of t
 
   double cj[J];
+  TermCoef<JC> tc;
+  if constexpr (TERMS) tc.load(T, b, cj);
+  else {
 #pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+    for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+  }
   double cmax = 0.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) cmax = fmax(cmax, cj[j]);
@@ -288,17 +395,26 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave) : nullptr;
   double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave) : nullptr;
   double *recCK = REC ? rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave : nullptr;
+  double *recT = REC ? rec + R.t + (size_t)blockIdx.x * N * kWave : nullptr;  // the grid, lane-major like (d, z)
 
   // ---- row 0 --------------------------------------------------------------------------------------------------
   double S[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) S[k] = 0.0;
   double F[J], w[J];
-  double d = a[b * N], z = y[b * N];
-  double rd = 1.0 / d;
   double tprev = t[b * t_bs];
+  double d = a[b * N], z = y[b * N];
+  if constexpr (TERMS) d += tc.A0;
+  double rd = 1.0 / d;
+  if constexpr (TERMS) {
+    double u0[J], v0[J];
+    tc.template rows<FAST>(tprev, u0, v0);
 #pragma unroll
-  for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = V[b * N * J + j] * rd; }
+    for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = v0[j] * rd; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = V[b * N * J + j] * rd; }
+  }
   double prod = d, quad = z * z * rd;
   int eacc = 0;
   int32_t fl = 0;
@@ -307,13 +423,14 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
     for (int q = 0; q < J / 2; ++q) recW[q * kWave + lane] = make_double2(w[2 * q], w[2 * q + 1]);
     recDZ[lane] = make_double2(d, z);
+    recT[lane] = tprev;
   }
 
   // ---- prologue: tiles start at row 0 so that every run is aligned (128 B row tiles, 64 B scalar tiles); row 0 itself
   // was consumed above and is skipped in the loop
   double su[2 * NI], sv[2 * NI];
   double st_[8], sa_[8], sy_[8];
-  row_fetch(Ub, N, 0, io, su); row_fetch(Vb, N, 0, io, sv);
+  if constexpr (!TERMS) { row_fetch(Ub, N, 0, io, su); row_fetch(Vb, N, 0, io, sv); }
   {  // scalar fetch with the t stride
     int64_t r = io.piece; r = r > N - 1 ? N - 1 : r;
 #pragma unroll
@@ -335,21 +452,30 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
     for (int rt = 0; rt < ST / RT; ++rt) {
       const int64_t nt = n0 + rt * RT;
       if (nt < N) {
-        lds_order();
-        row_stage(tU, lane, su); row_stage(tV, lane, sv);
-        row_fetch(Ub, N, nt + RT, io, su); row_fetch(Vb, N, nt + RT, io, sv);
-        lds_order();
+        if constexpr (!TERMS) {
+          lds_order();
+          row_stage(tU, lane, su); row_stage(tV, lane, sv);
+          row_fetch(Ub, N, nt + RT, io, su); row_fetch(Vb, N, nt + RT, io, sv);
+          lds_order();
+        }
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
           const int64_t n = nt + r;
           if (n < N && n > 0) {
             const int rs = rt * RT + r;
-            const double tn = tT[lane * SSTR + rs], an = tA[lane * SSTR + rs], yn = tY[lane * SSTR + rs];
+            const double tn = tT[lane * SSTR + rs], yn = tY[lane * SSTR + rs];
+            double an = tA[lane * SSTR + rs];
             double u[J], v[J], p[J];
-            row_read(tU, lane, r, u); row_read(tV, lane, r, v);
             const double dt = tprev - tn;
             tprev = tn;
-            decay<PAIRED>(cj, dt, p);
+            if constexpr (TERMS) {
+              an += tc.A0;
+              tc.template rows<FAST>(tn, u, v);
+              tc.decay(cj, dt, p);
+            } else {
+              row_read(tU, lane, r, u); row_read(tV, lane, r, v);
+              decay<PAIRED>(cj, dt, p);
+            }
             // S = P (S + d w^T w) P   (forward.hpp:115-123);  tau = U_n S  (forward.hpp:126)
             double dw[J], tau[J];
 #pragma unroll
@@ -385,6 +511,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
               for (int q = 0; q < J / 2; ++q) st2_stream(&recW[((size_t)n * (J / 2) + q) * kWave + lane], make_double2(w[2 * q], w[2 * q + 1]));
               st2_stream(&recDZ[(size_t)n * kWave + lane], make_double2(d, z));
+              st1_stream(&recT[(size_t)n * kWave + lane], tn);
               const bool seg_end = (n % C == 0) || (n == N - 1);
               if (seg_end) {  // uniform over the wavefront
                 double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
@@ -436,6 +563,32 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_fwd(int64_t B, int64_t N,
     fwd_body<REC, true>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
   else
     fwd_body<REC, false>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
+}
+
+// wavefront-uniform: every phase dc_k x_n of the 64 series inside the range of the branch-free sincos
+template <int JC>
+__device__ __forceinline__ bool terms_phases_fast(int64_t B, int64_t N, const double *__restrict__ x, int64_t x_bs,
+                                                  const TermsArgs &T) {
+  const int64_t b0 = (int64_t)blockIdx.x * kWave;
+  const int64_t b = (b0 + threadIdx.x) < B ? (b0 + threadIdx.x) : (B - 1);
+  TermCoef<JC> tc;
+  double cj[J];
+  tc.load(T, b, cj);
+  return __all(tc.phases_fast(x[b * x_bs], x[b * x_bs + N - 1]));
+}
+
+// Coefficient-level forward: same body, rows generated in the lane (TermsArgs).  `diag` is the white-noise diagonal.
+template <int JC, bool REC>
+__global__ __launch_bounds__(kWave, 1) void k_loglik_tt_fwd(int64_t B, int64_t N, const double *__restrict__ t,
+                                                            int64_t t_bs, TermsArgs T, const double *__restrict__ diag,
+                                                            const double *__restrict__ y, double *__restrict__ ll,
+                                                            int32_t *__restrict__ flag, double *__restrict__ rec, Rec R,
+                                                            unsigned long long *__restrict__ guard) {
+  __shared__ __attribute__((aligned(16))) double lds[kFwdLds / 8];
+  if (terms_phases_fast<JC>(B, N, t, t_bs, T))
+    fwd_body<REC, true, JC, true>(B, N, t, t_bs, nullptr, 0, diag, nullptr, nullptr, y, ll, flag, rec, R, guard, lds, T);
+  else
+    fwd_body<REC, true, JC, false>(B, N, t, t_bs, nullptr, 0, diag, nullptr, nullptr, y, ll, flag, rec, R, guard, lds, T);
 }
 
 // =============================================================================================================
@@ -493,13 +646,29 @@ __device__ __forceinline__ void row1_flush(double *__restrict__ base, int64_t N,
   }
 }
 
-template <bool PAIRED>
+// Coefficient-level form (JC >= 0, see TermsArgs): U_n is generated in the lane; bU_n and bV_n never leave it -- they are
+// contracted on the spot with the reverse of the matrix recipe (driver.cpp:456-474 transposed):
+//     bar_r += ba_n + bU_n[r]                       bac_k += ba_n + bU0 cos + bU1 sin          bbc_k += bU0 sin - bU1 cos
+//     g_k = -bU0 U1 + bU1 U0 - bV0 sin + bV1 cos    bdc_k += g_k x_n                           bx_n = bt_n + sum_k g_k dc_k
+// (bU0 = bU_n[Jr + 2k], bU1 = bU_n[Jr + 2k + 1], same for bV, U), bcr = bc[:Jr], bcc_k = bc[Jr + 2k] + bc[Jr + 2k + 1],
+// bdiag = ba.  In that form `bt` receives bx, `ba` receives bdiag, bU / bV / U / c are not touched and the per-series sums
+// go to TermsGrads; the running sums live in an LDS tile next to the accumulators of bc.
+struct TermsGrads {
+  double *bar, *bcr, *bac, *bbc, *bcc, *bdc;
+};
+constexpr int AS1 = 14;   // LDS stride (doubles) of a series in the accumulator tile: 112 B, conflict-free b128
+
+template <bool PAIRED, int JC = -1, bool FAST = true>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                          const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                          const int32_t *__restrict__ flag, const double *__restrict__ rec, Rec R,
                                          double *__restrict__ bt, double *__restrict__ bc, double *__restrict__ ba,
                                          double *__restrict__ bU, double *__restrict__ bV, double *__restrict__ by,
-                                         double *lds) {
+                                         double *lds, const TermsArgs T = TermsArgs{}, const TermsGrads G = TermsGrads{}) {
+  constexpr bool TERMS = JC >= 0;
+  constexpr int JR = TermCoef<JC>::JR, JCN = JC > 0 ? JC : 1;
+  constexpr int NACC = TERMS ? JR + 3 * JC + 1 : 1;   // [sum bU real] [bac, bbc, bdc per complex term] [sum ba]
+  static_assert(NACC <= AS1, "accumulator tile");
   const int lane = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * kWave;
   const int last = (int)((B - 1 - b0) < (kWave - 1) ? (B - 1 - b0) : (kWave - 1));
@@ -508,25 +677,62 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const RowIO io(lane, last);
   double *tU = lds, *tBV = tU + kWave * RS1, *tT = tBV + kWave * RS1, *tBA = tT + kWave * SSTR,
          *tBY = tBA + kWave * SSTR, *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * RS1;
+  double *tACC = lds;   // coefficient-level form: takes the place of the U / bV tiles (64 x 14 <= 2 x 64 x 10 doubles)
   const double *Ub = U + b0 * N * J;
-  const double *tb = t + (t_bs ? b0 * N : 0);
-  const int64_t tN = t_bs ? N : 0;
   double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
   const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave);
   const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave;
+  const double *recT = rec + R.t + (size_t)blockIdx.x * N * kWave;
   const bool failed = flag[b] != 0;  // NaN gradients for a failed factorisation (see k_loglik_rev)
   const double nan = __builtin_nan("");
 
   // the rates c_j (read twice per step) and the accumulators of bc (read-modify-write once per step) live in LDS rather
   // than in 32 registers
+  TermCoef<JC> tc;
   {
     double cj[J], zero[J];
+    if constexpr (TERMS) tc.load(T, b, cj);
+    else {
 #pragma unroll
-    for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; zero[j] = 0.0; }
+      for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) zero[j] = 0.0;
     row1_write(tC, lane, cj);
     row1_write(tBC, lane, zero);
+    if constexpr (TERMS) {
+#pragma unroll
+      for (int q = 0; q < AS1 / 2; ++q) *reinterpret_cast<double2 *>(tACC + lane * AS1 + 2 * q) = make_double2(0.0, 0.0);
+    }
   }
+  // one step's contribution to the running sums (TERMS): gv = -bV0 sin + bV1 cos of the row, bu = bU of the row
+  auto accumulate = [&](const double (&u)[J], const double (&bu)[J], const double (&sn)[JCN], const double (&cs)[JCN],
+                        const double (&gv)[JCN], double ba_n, double xn) -> double {
+    double acc[AS1];
+#pragma unroll
+    for (int q = 0; q < AS1 / 2; ++q) {
+      const double2 v = *reinterpret_cast<const double2 *>(tACC + lane * AS1 + 2 * q);
+      acc[2 * q] = v.x; acc[2 * q + 1] = v.y;
+    }
+    double gsum = 0.0;
+#pragma unroll
+    for (int r = 0; r < JR; ++r) acc[r] += bu[r];
+#pragma unroll
+    for (int k = 0; k < JC; ++k) {
+      const double b0_ = bu[JR + 2 * k], b1_ = bu[JR + 2 * k + 1];
+      acc[JR + 3 * k] = fma(b0_, cs[k], fma(b1_, sn[k], acc[JR + 3 * k]));
+      acc[JR + 3 * k + 1] = fma(b0_, sn[k], fma(-b1_, cs[k], acc[JR + 3 * k + 1]));
+      const double g = fma(-b0_, u[JR + 2 * k + 1], fma(b1_, u[JR + 2 * k], gv[k]));
+      acc[JR + 3 * k + 2] = fma(g, xn, acc[JR + 3 * k + 2]);
+      gsum = fma(g, tc.dc[k], gsum);
+    }
+    acc[NACC - 1] += ba_n;
+#pragma unroll
+    for (int q = 0; q < AS1 / 2; ++q)
+      *reinterpret_cast<double2 *>(tACC + lane * AS1 + 2 * q) = make_double2(acc[2 * q], acc[2 * q + 1]);
+    return gsum;
+  };
 
   double F[J], bF[J], bVn[J];
   // Both J x J states -- the forward state S of the current row and the adjoint M = bS + bS^T -- live in AGPRs (144 of
@@ -546,20 +752,35 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   // A failed series gets NaN seeds: every gradient of the series is an arithmetic function of them (bF <- u bz,
   // M <- x = bV + 2 ba u, bp <- F bF + ..., bt <- bp, bc <- bp), so NaN reaches all six outputs by propagation.
   if (failed) { ban = nan; bzn = nan; }
-  double tcur = t[b * t_bs + (N - 1)];
+  double tcur = recT[(size_t)(N - 1) * kWave + lane];
 
+  // The recorded S / F of a checkpointed row replace the recursed ones.  The 36 elements of S go straight into their
+  // AGPRs (aload: no arithmetic register in flight), all 80 loads are issued back to back and waited for ONCE.  (Through
+  // arithmetic registers, each v_accvgpr_write being a scheduling barrier, the same loads were waited for in ~13 separate
+  // groups, 2-3 us each under load: ~90k cycles per checkpoint, a quarter of the sweep.)
   auto load_ckpt = [&](int64_t n) {
     const double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
+    const unsigned voff = (unsigned)lane * 8u;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) apark(ld1_stream(&ck[k * kWave + lane]), Slo[k], Shi[k]);
+    for (int k = 0; k < NS; ++k) {
+      const double *base = ck + (k / 8) * 8 * kWave;   // immediate offsets reach 4 KB: one scalar base per 8 elements
+      if ((k & 7) == 0) { aload<0>(Slo[k], base, voff); aload<4>(Shi[k], base, voff); }
+      if ((k & 7) == 1) { aload<512>(Slo[k], base, voff); aload<516>(Shi[k], base, voff); }
+      if ((k & 7) == 2) { aload<1024>(Slo[k], base, voff); aload<1028>(Shi[k], base, voff); }
+      if ((k & 7) == 3) { aload<1536>(Slo[k], base, voff); aload<1540>(Shi[k], base, voff); }
+      if ((k & 7) == 4) { aload<2048>(Slo[k], base, voff); aload<2052>(Shi[k], base, voff); }
+      if ((k & 7) == 5) { aload<2560>(Slo[k], base, voff); aload<2564>(Shi[k], base, voff); }
+      if ((k & 7) == 6) { aload<3072>(Slo[k], base, voff); aload<3076>(Shi[k], base, voff); }
+      if ((k & 7) == 7) { aload<3584>(Slo[k], base, voff); aload<3588>(Shi[k], base, voff); }
+    }
 #pragma unroll
     for (int j = 0; j < J; ++j) F[j] = ld1_stream(&ck[(NS + j) * kWave + lane]);
+    await_aloads();
   };
-  auto t_fetch = [&](int64_t n0, double (&st)[8]) {
-    int64_t r = n0 + io.piece; r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st[i] = tb[(int64_t)io.sl(i) * tN + r];
-  };
+  // the grid comes back from the records of the forward pass, lane-major like (d, z): one coalesced 8-byte load per
+  // step, requested a step ahead.  (A register-staged tile of t requested eight steps ahead ends up in scratch -- the
+  // register file is full -- and scratch turns every one of its loads into load / wait / spill: ~3000 cycles per step.)
+  auto t_fetch = [&](int64_t row) { return ld1_stream(&recT[(size_t)(row < 0 ? 0 : row) * kWave + lane]); };
   auto w_fetch = [&](int64_t row, double (&wv)[J]) {
     row = row < 0 ? 0 : row;
 #pragma unroll
@@ -574,50 +795,66 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     const int64_t nf = N - 1;
     // ---- prologue ------------------------------------------------------------------------------------------------------
     // bV, ba, by of the last row are pure seeds: they leave at once (their slots in the tiles belong to lower rows)
-    row1_write(tBV, lane, bVn);
+    if constexpr (!TERMS) row1_write(tBV, lane, bVn);
     tBA[lane * SSTR + (nf & (ST - 1))] = ban;
     tBY[lane * SSTR + (nf & (ST - 1))] = bzn;
     lds_order();
-    row1_flush(bVb, N, nf, tBV, lane, last);
+    if constexpr (!TERMS) row1_flush(bVb, N, nf, tBV, lane, last);
     if ((nf & (ST - 1)) == 0) {  // the last row sits alone at the bottom of its scalar tile
       sc_flush(bab, N, nf, nf, nf, tBA, lane, last);
       sc_flush(byb, N, nf, nf, nf, tBY, lane, last);
     }
-    double ua[8], ub[8], stt[8];          // U rows n, n-1 (requested two steps ahead: staged first thing in a step)
+    double ua[8], ub[8];                  // U rows n, n-1 (requested two steps ahead: staged first thing in a step)
     double wa[J];                         // W_{n-1} (requested one step ahead: first used well into the step)
     double2 dza;                          // (d, z)_{n-1}
-    row1_fetch(Ub, N, nf, lane, last, ua); row1_fetch(Ub, N, nf - 1, lane, last, ub);
-    t_fetch(((nf - 1) / ST) * ST, stt);
+    double ta;                            // t_{n-1}
+    if constexpr (!TERMS) { row1_fetch(Ub, N, nf, lane, last, ua); row1_fetch(Ub, N, nf - 1, lane, last, ub); }
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
+    ta = t_fetch(nf - 1);
     load_ckpt(nf);
     lds_order();
-    sc_stage(tT, lane, stt);
-    t_fetch(((nf - 1) / ST) * ST - ST, stt);
-    lds_order();
 
+#ifdef C2T_PROF
+    unsigned long long prof_[6] = {0, 0, 0, 0, 0, 0}, tick_ = __builtin_readcyclecounter();
+#endif
     for (int64_t n = nf; n >= 1; --n) {
+      C2T_TICK(4);
       // ---- fixed part: U_n into its tile, requests for two steps ahead ------------------------------------------------
-      lds_order();
-      row1_stage(tU, lane, ua);
       double uc[8], wb[J];
-      row1_fetch(Ub, N, n - 2, lane, last, uc);
+      if constexpr (!TERMS) {
+        lds_order();
+        row1_stage(tU, lane, ua);
+        row1_fetch(Ub, N, n - 2, lane, last, uc);
+      }
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
-      lds_order();
+      const double tb2 = t_fetch(n - 2);
+      if constexpr (!TERMS) lds_order();
 
       // ---- the step ---------------------------------------------------------------------------------------------
       const int rs = (int)((n - 1) & (ST - 1));
       double u[J], p[J], ip[J];
-      row1_read(tU, lane, u);
-      const double tm = tT[lane * SSTR + rs];
+      double sn[JCN], cs[JCN], gv[JCN];
+      const double xn = tcur;
+      if constexpr (TERMS) {
+        tc.template rows_sc<FAST>(xn, u, sn, cs);
+#pragma unroll
+        for (int k = 0; k < JC; ++k) gv[k] = fma(bVn[JR + 2 * k + 1], cs[k], -(bVn[JR + 2 * k] * sn[k]));
+      } else {
+        row1_read(tU, lane, u);
+      }
+      const double ba_in = ban;
+      const double tm = ta;
       const double dt = tm - tcur;
       tcur = tm;
       {
         double cj[J];
         row1_read(tC, lane, cj);
-        decay<PAIRED>(cj, dt, p);
+        if constexpr (TERMS) tc.decay(cj, dt, p);
+        else decay<PAIRED>(cj, dt, p);
       }
+      C2T_TICK(0);
       // solve_lower_rev part (internal.hpp:232-245)
       double bp[J];
 #pragma unroll
@@ -660,11 +897,14 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
           apark(fma(-dwi, wa[j2], sv * (ip[i] * ip[j2])), Slo[k], Shi[k]);
         }
       }
+      C2T_TICK(1);
+      double gsum = 0.0;
       {
         double o[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) o[j] = fma(-bzn, F[j], -xs[j]);  // bU_n = -bz_n F_n - x S_n
-        row1_write(tU, lane, o);  // bU_n takes the place of U_n in the tile
+        if constexpr (TERMS) gsum = accumulate(u, o, sn, cs, gv, ba_in, xn);
+        else row1_write(tU, lane, o);  // bU_n takes the place of U_n in the tile
       }
       double f = 0.0;
       {
@@ -675,7 +915,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         for (int j = 0; j < J; ++j) { bcj[j] = fma(dt, bp[j], bcj[j]); f = fma(cj[j], bp[j], f); }
         row1_write(tBC, lane, bcj);
       }
-      const double btn = carry - f;
+      const double btn = carry - f + gsum;   // coefficient-level form: bx_n
       carry = f;
 #pragma unroll
       for (int j = 0; j < J; ++j) F[j] = fma(-wa[j], zm, F[j] * ip[j]);   // F_{n-1} = P^-1 F_n - w_{n-1} z_{n-1}
@@ -691,9 +931,9 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tBA[lane * SSTR + rs] = ban;
       tBY[lane * SSTR + rs] = bzn;
       tBT[lane * SSTR + (int)(n & (ST - 1))] = btn;
-      row1_write(tBV, lane, bVn);
+      if constexpr (!TERMS) row1_write(tBV, lane, bVn);
       lds_order();
-      {  // both rows leave together: the eight LDS reads are issued back to back, then the eight stores (one register
+      if constexpr (!TERMS) {  // both rows leave together: the eight LDS reads are issued back to back, then the eight stores (one register
          // reused for all of them makes every read wait out the LDS latency on its own: ~1000 cycles per step)
         double fl[16];
 #pragma unroll
@@ -712,33 +952,49 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         }
       }
 
+      C2T_TICK(2);
       // ---- every 8th step: scalar tiles turn; every 32nd: the checkpoint replaces the recursed state -----------------
       if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, 0, N - 1, tBT, lane, last);  // bt rows n .. n+7
       if (rs == 0) {  // row n-1 is the lowest row of its tile
         sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, last);
         sc_flush(byb, N, n - 1, 0, N - 1, tBY, lane, last);
-        if (n >= 2) {
-          sc_stage(tT, lane, stt);
-          t_fetch(n - 1 - 2 * ST, stt);
-          if ((n - 1) % C == 0) load_ckpt(n - 1);
-        }
+        if (n >= 2 && (n - 1) % C == 0) load_ckpt(n - 1);
       }
+      C2T_TICK(5);
+      if constexpr (!TERMS) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { ua[i] = ub[i]; ub[i] = uc[i]; }
+        for (int i = 0; i < 8; ++i) { ua[i] = ub[i]; ub[i] = uc[i]; }
+      }
 #pragma unroll
       for (int j = 0; j < J; ++j) wa[j] = wb[j];
       dza = dzb;
+      ta = tb2;
+      C2T_TICK(3);
     }
+#ifdef C2T_PROF
+    if (lane == 0 && blockIdx.x % 97 == 0)
+      for (int k = 0; k < 6; ++k) atomicAdd(&c2t_prof[k], prof_[k]);
+#endif
     // row 0: bU_0 = 0 (reverse.hpp:83), bt_0 = f_1; ba_0 / by_0 / bV_0 left with the last step
     {
       double zero[J];
 #pragma unroll
       for (int j = 0; j < J; ++j) zero[j] = failed ? nan : 0.0;
       lds_order();
-      row1_write(tU, lane, zero);
+      if constexpr (TERMS) {   // row 0: bU_0 = 0, bV_0 and ba_0 complete
+        double u0[J], sn[JCN], cs[JCN], gv[JCN], bu0[J];
+        tc.template rows_sc<FAST>(tcur, u0, sn, cs);
+#pragma unroll
+        for (int j = 0; j < J; ++j) bu0[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < JC; ++k) gv[k] = fma(bVn[JR + 2 * k + 1], cs[k], -(bVn[JR + 2 * k] * sn[k]));
+        carry += accumulate(u0, bu0, sn, cs, gv, ban, tcur);
+      } else {
+        row1_write(tU, lane, zero);
+      }
       tBT[lane * SSTR] = carry;
       lds_order();
-      row1_flush(bUb, N, 0, tU, lane, last);
+      if constexpr (!TERMS) row1_flush(bUb, N, 0, tU, lane, last);
       sc_flush(btb, N, 0, 0, (ST - 1) < (N - 1) ? (ST - 1) : (N - 1), tBT, lane, last);
     }
   } else {  // N == 1: seeds only
@@ -746,15 +1002,37 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       bab[(int64_t)lane * N] = ban;
       byb[(int64_t)lane * N] = bzn;
       btb[(int64_t)lane * N] = failed ? nan : 0.0;
+      if constexpr (TERMS) {
+        tACC[lane * AS1 + NACC - 1] = ban;   // the only row: sum ba = ba_0, every other sum is empty
+        if (failed) {
+          for (int q = 0; q < NACC; ++q) tACC[lane * AS1 + q] = nan;
+          for (int j = 0; j < J; ++j) tBC[lane * RS1 + j] = nan;
+        }
+      } else {
 #pragma unroll
-      for (int j = 0; j < J; ++j) { bUb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; }
+        for (int j = 0; j < J; ++j) { bUb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; }
+      }
     }
   }
   if (lane <= last) {
     double bcj[J];
     row1_read(tBC, lane, bcj);
+    if constexpr (TERMS) {
+      const double *acc = tACC + lane * AS1;
+      const double sba = acc[NACC - 1];
 #pragma unroll
-    for (int j = 0; j < J; ++j) bc[b * J + j] = bcj[j];
+      for (int r = 0; r < JR; ++r) { G.bar[b * JR + r] = sba + acc[r]; G.bcr[b * JR + r] = bcj[r]; }
+#pragma unroll
+      for (int k = 0; k < JC; ++k) {
+        G.bac[b * JC + k] = sba + acc[JR + 3 * k];
+        G.bbc[b * JC + k] = acc[JR + 3 * k + 1];
+        G.bdc[b * JC + k] = acc[JR + 3 * k + 2];
+        G.bcc[b * JC + k] = bcj[JR + 2 * k] + bcj[JR + 2 * k + 1];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < J; ++j) bc[b * J + j] = bcj[j];
+    }
   }
 }
 
@@ -779,6 +1057,23 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_rev(int64_t B, int64_t N,
     rev_body<true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
   else
     rev_body<false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+}
+
+template <int JC>
+__global__ __launch_bounds__(kWave, 1) void k_loglik_tt_rev(int64_t B, int64_t N, const double *__restrict__ x,
+                                                            int64_t x_bs, TermsArgs T, const int32_t *__restrict__ flag,
+                                                            const double *__restrict__ rec, Rec R,
+                                                            const unsigned long long *__restrict__ guard, TermsGrads G,
+                                                            double *__restrict__ bx, double *__restrict__ bdiag,
+                                                            double *__restrict__ by) {
+  __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
+  if (__longlong_as_double((long long)*guard) > kGuard) return;  // the composed chain takes this batch
+  if (terms_phases_fast<JC>(B, N, x, x_bs, T))
+    rev_body<true, JC, true>(B, N, x, x_bs, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by,
+                             lds, T, G);
+  else
+    rev_body<true, JC, false>(B, N, x, x_bs, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by,
+                              lds, T, G);
 }
 
 }  // namespace c2t
@@ -819,5 +1114,70 @@ int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, int64_t t_b
                      (const double *)rec, R, (const unsigned long long *)guard, bt, bc, ba, bU, bV, by);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
+
+// Coefficient-level forward (J = Jr + 2 Jc == 8): log-likelihood straight from (ar, cr, ac, bc, cc, dc, x, diag, y),
+// no U / V / c arrays in memory.
+int c2_internal_loglik_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                          const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                          int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag,
+                          c2_stream_t stream) {
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave));
+  const TermsArgs T{ar, cr, ac, bc, cc, dc, coef_batched};
+  Rec R{};
+#define C2_TT(JC_)                                                                                                       \
+  hipLaunchKernelGGL((k_loglik_tt_fwd<JC_, false>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, x, x_bs, T, diag, y, \
+                     ll, flag, (double *)nullptr, R, (unsigned long long *)nullptr)
+  switch (Jc) {
+    case 0: C2_TT(0); break;
+    case 1: C2_TT(1); break;
+    case 2: C2_TT(2); break;
+    case 3: C2_TT(3); break;
+    case 4: C2_TT(4); break;
+    default: return C2_ERR_UNSUPPORTED;
+  }
+#undef C2_TT
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// Coefficient-level forward with records + reverse sweep (see c2_internal_loglik_t_grad for `guard`).
+int c2_internal_loglik_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                               const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                               int64_t x_bs, const double *diag, const double *y, double *ll, double *bar, double *bcr,
+                               double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                               int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream) {
+  const dim3 grid((unsigned)((B + kWave - 1) / kWave));
+  const TermsArgs T{ar, cr, ac, bc, cc, dc, coef_batched};
+  const TermsGrads G{bar, bcr, bac, bbc, bcc, bdc};
+  const Rec R = rec_layout(B, N);
+  hipStream_t s = (hipStream_t)stream;
+#define C2_TT(JC_)                                                                                                       \
+  do {                                                                                                                   \
+    hipLaunchKernelGGL((k_loglik_tt_fwd<JC_, true>), grid, dim3(kWave), 0, s, B, N, x, x_bs, T, diag, y, ll, flag, rec, R, \
+                       guard);                                                                                           \
+    if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;                                                              \
+    hipLaunchKernelGGL((k_loglik_tt_rev<JC_>), grid, dim3(kWave), 0, s, B, N, x, x_bs, T, (const int32_t *)flag,           \
+                       (const double *)rec, R, (const unsigned long long *)guard, G, bx, bdiag, by);                     \
+  } while (0)
+  switch (Jc) {
+    case 0: C2_TT(0); break;
+    case 1: C2_TT(1); break;
+    case 2: C2_TT(2); break;
+    case 3: C2_TT(3); break;
+    case 4: C2_TT(4); break;
+    default: return C2_ERR_UNSUPPORTED;
+  }
+#undef C2_TT
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+#ifdef C2T_PROF
+// cycles per section summed over the sampled wavefronts (every 97th) since the last call; resets the counters
+void c2_internal_prof_read(unsigned long long *out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(c2t_prof), sizeof(unsigned long long) * 8);
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(c2t_prof), z, sizeof(z));
+}
+#endif
 
 }  // extern "C"

@@ -970,7 +970,9 @@ __global__ __launch_bounds__(kWave) void k_gm_emit(int64_t B, int64_t N, int64_t
 __global__ void k_matrices(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ar,
                            const double *__restrict__ ac, const double *__restrict__ bc, const double *__restrict__ dc,
                            int coef_batched, const double *__restrict__ x, int64_t x_bs, const double *__restrict__ diag,
-                           double *__restrict__ a, double *__restrict__ U, double *__restrict__ V) {
+                           double *__restrict__ a, double *__restrict__ U, double *__restrict__ V,
+                           const unsigned long long *__restrict__ gate) {
+  if (gate_closed(gate)) return;
   const int Q = Jr + Jc, J = Jr + 2 * Jc;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B * N * Q) return;
@@ -1334,15 +1336,22 @@ int c2_matmul_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
                                         stream);
 }
 
-int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
-                             const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
-                             const double *diag, double *a, double *U, double *V, c2_stream_t stream) {
+// `gate`: see gate_closed (c2_loglik_helpers.hpp); nullptr from the public entry point.
+int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
+                         const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
+                         const double *diag, double *a, double *U, double *V, const unsigned long long *gate,
+                         c2_stream_t stream) {
   if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
   if (!x || !diag || !a || !U || !V || (Jr && !ar) || (Jc && (!ac || !bc || !dc))) return C2_ERR_INVALID;
   const int64_t total = B * N * (Jr + Jc);
   hipLaunchKernelGGL(k_matrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
-                     (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V);
+                     (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V, gate);
   return check_launch();
+}
+int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
+                             const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
+                             const double *diag, double *a, double *U, double *V, c2_stream_t stream) {
+  return c2_internal_matrices(B, N, Jr, Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V, nullptr, stream);
 }
 
 int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,

@@ -18,7 +18,9 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
+#include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
 extern "C" void c2_internal_set_error(const char *msg);
@@ -29,7 +31,8 @@ constexpr int kThreads = 256;
 
 // c (B, J) = [cr, cc0, cc0, cc1, cc1, ...]   (terms.py:171-173)
 __global__ void k_rates(int64_t B, int Jr, int Jc, const double *__restrict__ cr, const double *__restrict__ cc,
-                        int coef_batched, double *__restrict__ c) {
+                        int coef_batched, double *__restrict__ c, const unsigned long long *__restrict__ gate) {
+  if (c2::gate_closed(gate)) return;
   const int J = Jr + 2 * Jc;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B * J) return;
@@ -43,7 +46,9 @@ __global__ void k_terms_rev_rows(int64_t B, int64_t N, int Jr, int Jc, const dou
                                  const double *__restrict__ bc, const double *__restrict__ dc, int coef_batched,
                                  const double *__restrict__ x, int64_t x_bs, const double *__restrict__ bt,
                                  const double *__restrict__ ba, const double *__restrict__ bU,
-                                 const double *__restrict__ bV, double *__restrict__ bx, double *__restrict__ bdiag) {
+                                 const double *__restrict__ bV, double *__restrict__ bx, double *__restrict__ bdiag,
+                                 const unsigned long long *__restrict__ gate) {
+  if (c2::gate_closed(gate)) return;
   const int J = Jr + 2 * Jc;
   const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= B * N) return;
@@ -82,11 +87,13 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev_coef(
     const double *__restrict__ dc, int coef_batched, const double *__restrict__ x, int64_t x_bs,
     const double *__restrict__ bcv, const double *__restrict__ ba, const double *__restrict__ bU,
     const double *__restrict__ bV, double *__restrict__ bar, double *__restrict__ bcr, double *__restrict__ bac,
-    double *__restrict__ bbc, double *__restrict__ bcc, double *__restrict__ bdc) {
+    double *__restrict__ bbc, double *__restrict__ bcc, double *__restrict__ bdc,
+    const unsigned long long *__restrict__ gate) {
   __shared__ double red[kThreads / 64];
+  if (c2::gate_closed(gate)) return;
   const int J = Jr + 2 * Jc;
-  const int64_t b = blockIdx.y;
-  const int q = blockIdx.x;  // term: real terms first
+  const int64_t b = blockIdx.x;
+  const int q = blockIdx.y;  // term: real terms first
   const double *bab = ba + b * N, *bUb = bU + b * N * J, *bVb = bV + b * N * J;
   if (q < Jr) {
     double s = 0.0;
@@ -152,7 +159,6 @@ inline Plan plan(int64_t B, int64_t N, int64_t J, int grad) {
 inline int check(int64_t B, int64_t N, int64_t Jr, int64_t Jc) {
   if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
   if (Jr + 2 * Jc > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
-  if (B > 65535) return C2_ERR_UNSUPPORTED;  // grid.y of the coefficient reduction
   return C2_OK;
 }
 
@@ -160,22 +166,66 @@ inline int check(int64_t B, int64_t N, int64_t Jr, int64_t Jc) {
 
 using namespace c2terms;
 
+// One-lane-per-series kernels that generate U_n / V_n from the coefficients in the lane (c2_loglik_t.hip): no matrices in
+// memory.  J == 8 only.  C2_TERMS_FUSED=1 forces them, =0 disables them; otherwise batches that fill the chip.
 extern "C" {
-
-size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t Jc, int grad) {
-  if (check(B, N, Jr, Jc)) return 0;
-  return plan(B, N, Jr + 2 * Jc, grad).total * sizeof(double);
+int c2_internal_loglik_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                          const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                          int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag,
+                          c2_stream_t stream);
+int c2_internal_loglik_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                               const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                               int64_t x_bs, const double *diag, const double *y, double *ll, double *bar, double *bcr,
+                               double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                               int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
+size_t c2_internal_loglik_t_record_doubles(int64_t B, int64_t N);
+int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
+                         const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
+                         const double *diag, double *a, double *U, double *V, const unsigned long long *gate,
+                         c2_stream_t stream);
+int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                   int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                                   double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                   int32_t *flag, void *work, const unsigned long long *gate, c2_stream_t stream);
+}
+#ifndef C2_TERMS_FUSED_MIN_BATCH_FWD
+#define C2_TERMS_FUSED_MIN_BATCH_FWD 16384
+#endif
+#ifndef C2_TERMS_FUSED_MIN_BATCH_GRAD
+#define C2_TERMS_FUSED_MIN_BATCH_GRAD 16384
+#endif
+static bool use_fused(int64_t B, int64_t J, bool grad) {
+  if (J != 8) return false;
+  const char *e = getenv("C2_TERMS_FUSED");
+  if (e) return atoi(e) != 0;
+  return B >= (grad ? C2_TERMS_FUSED_MIN_BATCH_GRAD : C2_TERMS_FUSED_MIN_BATCH_FWD);
 }
 
 static int matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr, const double *ac,
                     const double *bc, const double *cc, const double *dc, int coef_batched, const double *x,
-                    int64_t x_bs, const double *diag, double *w, const Plan &p, hipStream_t s) {
+                    int64_t x_bs, const double *diag, double *w, const Plan &p, const unsigned long long *gate,
+                    hipStream_t s) {
   const int64_t J = Jr + 2 * Jc;
   hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc,
-                     coef_batched, w + p.c);
+                     coef_batched, w + p.c, gate);
   if (int e = launch_ok()) return e;
-  return c2_get_celerite_matrices(B, N, Jr, Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, w + p.a, w + p.U, w + p.V,
-                                  (c2_stream_t)s);
+  return c2_internal_matrices(B, N, Jr, Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, w + p.a, w + p.U, w + p.V, gate,
+                              (c2_stream_t)s);
+}
+
+extern "C" {
+
+// Either variant fits: [guard word, 16 bytes] [records of the fused kernels | plan of the composed chain]; the choice
+// between them is made per call (batch size, C2_TERMS_FUSED), the size does not depend on it.
+size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t Jc, int grad) {
+  if (check(B, N, Jr, Jc)) return 0;
+  const int64_t J = Jr + 2 * Jc;
+  size_t n = plan(B, N, J, grad).total;
+  if (grad && J == 8) {
+    const size_t r = c2_internal_loglik_t_record_doubles(B, N);
+    n = 2 + (r > n ? r : n);
+  }
+  return n * sizeof(double);
 }
 
 int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr, const double *ac,
@@ -186,11 +236,13 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
   if (!x || !diag || !y || !ll || !flag || !work || (Jr && (!ar || !cr)) || (Jc && (!ac || !bc || !cc || !dc)))
     return C2_ERR_INVALID;
   const int64_t J = Jr + 2 * Jc;
+  if (work_bytes < c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 0)) return C2_ERR_INVALID;
+  if (use_fused(B, J, false))
+    return c2_internal_loglik_tt(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
   const Plan p = plan(B, N, J, 0);
-  if (work_bytes < p.total * sizeof(double)) return C2_ERR_INVALID;
   double *w = (double *)work;
   hipStream_t s = (hipStream_t)stream;
-  if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, s)) return e;
+  if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, nullptr, s)) return e;
   return c2_loglik(B, N, J, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, flag, stream);
 }
 
@@ -204,22 +256,40 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
       (Jc && (!ac || !bc || !cc || !dc || !bac || !bbc || !bcc || !bdc)))
     return C2_ERR_INVALID;
   const int64_t J = Jr + 2 * Jc;
+  if (work_bytes < c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 1)) return C2_ERR_INVALID;
   const Plan p = plan(B, N, J, 1);
-  if (work_bytes < p.total * sizeof(double)) return C2_ERR_INVALID;
   double *w = (double *)work;
   hipStream_t s = (hipStream_t)stream;
-  if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, s)) return e;
-  if (int e = c2_loglik_grad(B, N, J, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, w + p.bt, w + p.bc,
-                             w + p.ba, w + p.bU, w + p.bV, by, flag, w + p.one_d,
-                             c2_loglik_grad_workspace_bytes(B, N, J), stream))
+  const unsigned long long *gate = nullptr;
+  if (use_fused(B, J, true)) {
+    // Forward with records + reverse sweep, both forming the rows in the lane.  As in c2_loglik_grad, the forward pass
+    // leaves its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the
+    // composed chain below -- every kernel of it behind the same word -- produces the gradients instead.
+    unsigned long long *guard = (unsigned long long *)work;
+    if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
+    w += 2;
+    if (int e = c2_internal_loglik_tt_grad(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, bar, bcr,
+                                           bac, bbc, bcc, bdc, bx, bdiag, by, flag, w, guard, stream))
+      return e;
+    gate = guard;
+  }
+  if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, gate, s)) return e;
+  if (gate) {
+    if (int e = c2_internal_loglik_grad_replay(B, N, J, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, w + p.bt,
+                                               w + p.bc, w + p.ba, w + p.bU, w + p.bV, by, flag, w + p.one_d, gate,
+                                               stream))
+      return e;
+  } else if (int e = c2_loglik_grad(B, N, J, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, w + p.bt, w + p.bc,
+                                    w + p.ba, w + p.bU, w + p.bV, by, flag, w + p.one_d,
+                                    c2_loglik_grad_workspace_bytes(B, N, J), stream))
     return e;
   hipLaunchKernelGGL(k_terms_rev_rows, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, s, B, N, (int)Jr, (int)Jc,
                      ac, bc, dc, coef_batched, x, x_bs, (const double *)(w + p.bt), (const double *)(w + p.ba),
-                     (const double *)(w + p.bU), (const double *)(w + p.bV), bx, bdiag);
+                     (const double *)(w + p.bU), (const double *)(w + p.bV), bx, bdiag, gate);
   if (int e = launch_ok()) return e;
-  hipLaunchKernelGGL(k_terms_rev_coef, dim3((unsigned)(Jr + Jc), (unsigned)B), dim3(kThreads), 0, s, B, N, (int)Jr,
+  hipLaunchKernelGGL(k_terms_rev_coef, dim3((unsigned)B, (unsigned)(Jr + Jc)), dim3(kThreads), 0, s, B, N, (int)Jr,
                      (int)Jc, ac, bc, dc, coef_batched, x, x_bs, (const double *)(w + p.bc), (const double *)(w + p.ba),
-                     (const double *)(w + p.bU), (const double *)(w + p.bV), bar, bcr, bac, bbc, bcc, bdc);
+                     (const double *)(w + p.bU), (const double *)(w + p.bV), bar, bcr, bac, bbc, bcc, bdc, gate);
   return launch_ok();
 }
 

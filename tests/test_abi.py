@@ -55,10 +55,10 @@ def test_argument_errors_without_gpu(built):
     B, N, J = 2, 8, 3                      # G = 4, C = 8 -> 1 segment, 1 wavefront
     ck = 1 * 1 * (64 + 3 * 32 + 64 + 64)   # S slot 0 (64) + slots 1..3 (32 owners each) + F (64) + W (64)
     assert lib.c2_loglik_grad_workspace_bytes(B, N, J) == 8 * (ck + B * N * 2)
-    # chip-filling J = 8 batches take the one-lane-per-series path: records W (B,N,8) + (d,z) (B,N,2) + a checkpoint of
-    # 44 doubles every 32 rows, overlaid with the replay kernels' workspace, + the 16-byte stability word
+    # chip-filling J = 8 batches take the one-lane-per-series path: records W (B,N,8) + (d,z) (B,N,2) + t (B,N) + a
+    # checkpoint of 44 doubles every 32 rows, overlaid with the replay kernels' workspace, + the 16-byte stability word
     waves, nck = 65536 // 64, (4096 - 2) // 32 + 1
-    rec = waves * 64 * (4096 * 8 + 4096 * 2 + nck * 44)
+    rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44)
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) == 8 * (2 + rec) < 30 * 2**30
     assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 33) == 0   # unsupported width
 

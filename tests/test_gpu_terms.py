@@ -134,3 +134,105 @@ def test_log_likelihood_terms_autograd(ops, oracle):
         close(leaf.grad, per.sum(0) if k < 7 else per)
     with pytest.raises(ValueError, match="Invalid shape: y"):
         ops.loglik_terms(*[v.detach() for v in leaves[:8]], leaves[8].detach()[:, :5].contiguous())
+
+
+@pytest.mark.parametrize("Jr,Jc", [(0, 4), (2, 3), (4, 2), (6, 1), (8, 0)])
+@pytest.mark.parametrize("B,N", [(70, 200), (3, 1), (2, 2), (5, 9), (130, 67)])
+def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc):
+    """The one-lane-per-series kernels that form U_n, V_n in registers (c2_loglik_t.hip, width 8), forced for any batch
+    size, against the same oracle chain; and against the composed path (matrices in memory)."""
+    rng = np.random.default_rng(100 * Jr + N)
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, N / 10.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    nb = min(B, 6)
+    want = [oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b]) for b in range(nb)]
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    monkeypatch.setenv("C2_TERMS_FUSED", "0")
+    ll_c, flag_c = ops.loglik_terms(*args)
+    ll_cg, grads_c, _ = ops.loglik_terms_grad(*args)
+    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    ll, flag = ops.loglik_terms(*args)
+    assert int(flag.abs().sum()) == 0
+    close(ll[:nb], np.array([w[0] for w in want]))
+    close(ll, ll_c.cpu().numpy())
+    ll2, grads, flag2 = ops.loglik_terms_grad(*args)
+    assert int(flag2.abs().sum()) == 0
+    close(ll2, ll_c.cpu().numpy())
+    for k, (nm, g) in enumerate(zip(NAMES, grads)):
+        e = np.stack([w[1][k] for w in want])
+        if e.size:
+            close(g[:nb], e)
+            close(g, grads_c[k].cpu().numpy(), tol=1e-9, floor=1e-11)
+    # shared coefficients and grid
+    args_s = dev(ar[0], cr[0], ac[0], bc[0], cc[0], dc[0], x[0], diag, y)
+    ll3, grads3, _ = ops.loglik_terms_grad(*args_s)
+    monkeypatch.setenv("C2_TERMS_FUSED", "0")
+    ll4, grads4, _ = ops.loglik_terms_grad(*args_s)
+    close(ll3, ll4.cpu().numpy())
+    for g3, g4 in zip(grads3, grads4):
+        if g4.numel():
+            close(g3, g4.cpu().numpy(), tol=1e-9, floor=1e-11)
+
+
+def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, monkeypatch):
+    """Rates x segment span beyond kBackwardGuard: the fused reverse sweep declines on the device and the gated composed
+    chain delivers the gradients (same outputs); a batch inside the guard next to it takes the fused sweep."""
+    rng = np.random.default_rng(8)
+    B, N, Jr, Jc = 66, 150, 2, 3
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    for scale in (4.0, 0.02):     # c_max * span of 32 rows ~ 0.5 * 32 * scale
+        x = np.sort(rng.uniform(0, N * scale, (B, N)), axis=1)
+        y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+        want = [oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b]) for b in range(4)]
+        monkeypatch.setenv("C2_TERMS_FUSED", "1")
+        ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
+        assert int(flag.abs().sum()) == 0
+        close(ll[:4], np.array([w[0] for w in want]))
+        for k, g in enumerate(grads):
+            close(g[:4], np.stack([w[1][k] for w in want]))
+
+
+def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch):
+    import torch
+    rng = np.random.default_rng(3)
+    B, N, Jr, Jc = 70, 40, 2, 3
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, 4.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    diag[9, 17] = -50.0      # not positive definite
+    y = rng.standard_normal((B, N))
+    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
+    assert int(flag[9]) != 0 and int(flag.abs().sum()) == int(flag[9].abs())
+    for g in grads:
+        assert bool(torch.isnan(g[9]).all()), g[9]
+        ok = torch.cat([g[:9], g[10:]])
+        assert bool(torch.isfinite(ok).all())
+
+
+def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkeypatch):
+    """Raw Julian dates: dc * x beyond the range of the branch-free sincos -> the wavefront runs the instantiation with
+    the library's large-argument reduction; a neighbouring wavefront with small phases keeps the fast one."""
+    rng = np.random.default_rng(21)
+    B, N, Jr, Jc = 128, 90, 2, 3
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, 9.0, (B, N)), axis=1)
+    x[:64] += 2.45e6
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
+    ll_f, _ = ops.loglik_terms(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
+    assert int(flag.abs().sum()) == 0
+    for b in (0, 5, 63, 64, 100):
+        want = oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b])
+        close(ll[b:b + 1], np.array([want[0]]))
+        close(ll_f[b:b + 1], np.array([want[0]]))
+        for k, g in enumerate(grads):
+            # bdc = sum_n g_n x_n with x ~ 2.5e6 cancels to O(1): its rounding error scales with eps * N * max|x|
+            # whatever the summation order (the numpy chain and the device differ there), so that is its floor
+            floor = 1e-15 * N * float(np.abs(x[b]).max()) if NAMES[k] == "bdc" else 1e-10
+            close(g[b], want[1][k], tol=1e-10, floor=max(floor, 1e-10))

@@ -77,20 +77,26 @@ __host__ inline Rec rec_layout(int64_t B, int64_t N) {
 // ---- tile movers -------------------------------------------------------------------------------------------------------
 // A wavefront owns series b0 .. b0+63 (clamped to B-1).  Row tile: RT rows of J doubles of every series.  One global
 // instruction moves 8 series x 128 bytes (lane l: series 8 i + l / 8, 16-byte piece l % 8).
-struct RowIO {
+// FULL: the wavefront is known to own 64 valid series -- no clamp, so the addresses of a tile are one per-lane vector
+// plus uniform multiples of the series stride (with the clamp the compiler keeps one address vector per instruction
+// alive across the sweep, 32+ registers that end up in scratch).
+template <bool FULL>
+struct RowIOT {
   int lane, last;
   int piece;       // l % 8 (scalar tiles)
   int rpiece;      // l % LPS (row tiles)
-  __device__ __forceinline__ RowIO(int lane_, int last_) : lane(lane_), last(last_), piece(lane_ & 7), rpiece(lane_ % LPS) {}
+  __device__ __forceinline__ RowIOT(int lane_, int last_) : lane(lane_), last(last_), piece(lane_ & 7), rpiece(lane_ % LPS) {}
   // clamped series (within the wavefront) this lane serves in instruction i of a scalar / row tile -- recomputed at
   // every use (two VALU instructions) rather than kept in registers
-  __device__ __forceinline__ int sl(int i) const { const int s = 8 * i + lane / 8; return s < last ? s : last; }
-  __device__ __forceinline__ int rl(int i) const { const int s = (kWave / LPS) * i + lane / LPS; return s < last ? s : last; }
+  __device__ __forceinline__ int sl(int i) const { const int s = 8 * i + lane / 8; return (FULL || s < last) ? s : last; }
+  __device__ __forceinline__ int rl(int i) const { const int s = (kWave / LPS) * i + lane / LPS; return (FULL || s < last) ? s : last; }
 };
+using RowIO = RowIOT<false>;
 
 // global -> registers: rows n0 .. n0+RT-1 (clamped to [0, N-1]) of every series
 // (staging registers are plain doubles: arrays of double2 end up in scratch)
-__device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, const RowIO &io,
+template <class IO>
+__device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, const IO &io,
                                           double (&st)[2 * NI]) {
   int64_t r = n0 + (io.rpiece >> 2);
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
@@ -605,13 +611,19 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_tt_fwd(int64_t B, int64_t N
 // END of a step, where the stores that get drained are two steps old.
 // =============================================================================================================
 constexpr int RS1 = J + 2;   // LDS stride (doubles) of a series in a one-row tile: 80 B, conflict-free b128
-constexpr int kRevLds = (2 * kWave * RS1 + 4 * kWave * SSTR + 2 * kWave * RS1) * 8;  // U/bU, bV, t, ba, by, bt, c, bc
+constexpr int kRevLds = (kWave * RSTR + kWave * RS1 + 3 * kWave * SSTR + 2 * kWave * RS1) * 8;  // U/bU, bV, ba, by, bt, c, bc
 
 // One-row tiles: an instruction moves 16 series x 64 bytes (lane l: series 16 i + l / 4, 16-byte piece l % 4).  Lanes of
 // a partial wavefront are clamped onto the last valid series: they move the same bytes to the same place again.
 __device__ __forceinline__ void row1_fetch(const double *__restrict__ base, int64_t N, int64_t n, int lane, int last,
                                            double (&st)[8]) {
   n = n < 0 ? 0 : n;
+#ifdef C2T_X_NOU      // timing experiment: the U rows of the reverse sweep cost nothing (results are wrong)
+  n = 0; N = 0;
+#endif
+#ifdef C2T_X_UPAIR    // timing experiment: every row fetch pulls the aligned 128-byte pair (twice the requests, results right)
+  n &= ~(int64_t)1;
+#endif
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
@@ -658,7 +670,7 @@ struct TermsGrads {
 };
 constexpr int AS1 = 14;   // LDS stride (doubles) of a series in the accumulator tile: 112 B, conflict-free b128
 
-template <bool PAIRED, int JC = -1, bool FAST = true>
+template <bool PAIRED, int JC = -1, bool FAST = true, bool FULL = false>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                          const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                          const int32_t *__restrict__ flag, const double *__restrict__ rec, Rec R,
@@ -674,10 +686,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const int last = (int)((B - 1 - b0) < (kWave - 1) ? (B - 1 - b0) : (kWave - 1));
   const int sl = lane < last ? lane : last;
   const int64_t b = b0 + sl;
-  const RowIO io(lane, last);
-  double *tU = lds, *tBV = tU + kWave * RS1, *tT = tBV + kWave * RS1, *tBA = tT + kWave * SSTR,
-         *tBY = tBA + kWave * SSTR, *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * RS1;
-  double *tACC = lds;   // coefficient-level form: takes the place of the U / bV tiles (64 x 14 <= 2 x 64 x 10 doubles)
+  const RowIOT<FULL> io(lane, last);
+  // tU: TWO rows of U per series (the aligned pair 2p, 2p+1 = one 128-byte line, fetched once; single rows cost the
+  // line twice, +15 GB per sweep at the bench shape); bU_n takes the place of U_n in it
+  double *tU = lds, *tBV = tU + kWave * RSTR, *tBA = tBV + kWave * RS1, *tBY = tBA + kWave * SSTR,
+         *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * RS1;
+  double *tACC = lds;   // coefficient-level form: takes the place of the U tile (64 x 14 <= 64 x 18 doubles)
   const double *Ub = U + b0 * N * J;
   double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
@@ -804,11 +818,19 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       sc_flush(bab, N, nf, nf, nf, tBA, lane, last);
       sc_flush(byb, N, nf, nf, nf, tBY, lane, last);
     }
-    double ua[8], ub[8];                  // U rows n, n-1 (requested two steps ahead: staged first thing in a step)
+    double su[2 * NI];                    // the pair of U rows (2p, 2p+1) staged by the next odd step n = 2p+1
     double wa[J];                         // W_{n-1} (requested one step ahead: first used well into the step)
     double2 dza;                          // (d, z)_{n-1}
     double ta;                            // t_{n-1}
-    if constexpr (!TERMS) { row1_fetch(Ub, N, nf, lane, last, ua); row1_fetch(Ub, N, nf - 1, lane, last, ub); }
+    if constexpr (!TERMS) {
+      row_fetch(Ub, N, nf & ~(int64_t)1, io, su);
+      if (!(nf & 1)) {  // the first step is an even one: its pair goes into the tile here
+        lds_order();
+        row_stage(tU, lane, su);
+        lds_order();
+        row_fetch(Ub, N, nf - 2, io, su);
+      }
+    }
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
     ta = t_fetch(nf - 1);
@@ -818,19 +840,24 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #ifdef C2T_PROF
     unsigned long long prof_[6] = {0, 0, 0, 0, 0, 0}, tick_ = __builtin_readcyclecounter();
 #endif
-    for (int64_t n = nf; n >= 1; --n) {
+    // One step of the sweep.  ODD (matrix-level form): n = 2p+1, the step that puts the pair (2p, 2p+1) into the tile
+    // and requests the pair below it; the even step in between touches no U in memory.  Two instances, each a fixed
+    // instruction sequence (see "Memory choreography" above).
+    auto step = [&](const int64_t n, auto odd_tag) __attribute__((always_inline)) {
+      constexpr bool ODD = decltype(odd_tag)::value;
+      __builtin_amdgcn_sched_barrier(0);   // the two instances are scheduled (and their registers allocated) apart
       C2T_TICK(4);
       // ---- fixed part: U_n into its tile, requests for two steps ahead ------------------------------------------------
-      double uc[8], wb[J];
-      if constexpr (!TERMS) {
+      double wb[J];
+      if constexpr (!TERMS && ODD) {
         lds_order();
-        row1_stage(tU, lane, ua);
-        row1_fetch(Ub, N, n - 2, lane, last, uc);
+        row_stage(tU, lane, su);
+        row_fetch(Ub, N, n - 3, io, su);
       }
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
       const double tb2 = t_fetch(n - 2);
-      if constexpr (!TERMS) lds_order();
+      if constexpr (!TERMS && ODD) lds_order();
 
       // ---- the step ---------------------------------------------------------------------------------------------
       const int rs = (int)((n - 1) & (ST - 1));
@@ -842,7 +869,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
         for (int k = 0; k < JC; ++k) gv[k] = fma(bVn[JR + 2 * k + 1], cs[k], -(bVn[JR + 2 * k] * sn[k]));
       } else {
-        row1_read(tU, lane, u);
+        row_read(tU, lane, ODD ? 1 : 0, u);
       }
       const double ba_in = ban;
       const double tm = ta;
@@ -904,7 +931,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
         for (int j = 0; j < J; ++j) o[j] = fma(-bzn, F[j], -xs[j]);  // bU_n = -bz_n F_n - x S_n
         if constexpr (TERMS) gsum = accumulate(u, o, sn, cs, gv, ba_in, xn);
-        else row1_write(tU, lane, o);  // bU_n takes the place of U_n in the tile
+        else row_write(tU, lane, ODD ? 1 : 0, o);  // bU_n takes the place of U_n in the tile
       }
       double f = 0.0;
       {
@@ -938,15 +965,15 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         double fl[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
-          const double2 v0 = *reinterpret_cast<const double2 *>(tU + sr * RS1 + 2 * (lane & 3));
+          int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
+          const double2 v0 = *reinterpret_cast<const double2 *>(tU + sr * RSTR + (ODD ? J : 0) + 2 * (lane & 3));
           const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RS1 + 2 * (lane & 3));
           fl[4 * i] = v0.x; fl[4 * i + 1] = v0.y; fl[4 * i + 2] = v1.x; fl[4 * i + 3] = v1.y;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
+          int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
           st2_stream(reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 3)), make_double2(fl[4 * i], fl[4 * i + 1]));
           st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)), make_double2(fl[4 * i + 2], fl[4 * i + 3]));
         }
@@ -954,22 +981,26 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 
       C2T_TICK(2);
       // ---- every 8th step: scalar tiles turn; every 32nd: the checkpoint replaces the recursed state -----------------
-      if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, 0, N - 1, tBT, lane, last);  // bt rows n .. n+7
+      if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, 0, N - 1, tBT, lane, FULL ? kWave - 1 : last);  // bt rows n .. n+7
       if (rs == 0) {  // row n-1 is the lowest row of its tile
-        sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, last);
-        sc_flush(byb, N, n - 1, 0, N - 1, tBY, lane, last);
+        sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, FULL ? kWave - 1 : last);
+        sc_flush(byb, N, n - 1, 0, N - 1, tBY, lane, FULL ? kWave - 1 : last);
         if (n >= 2 && (n - 1) % C == 0) load_ckpt(n - 1);
       }
       C2T_TICK(5);
-      if constexpr (!TERMS) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { ua[i] = ub[i]; ub[i] = uc[i]; }
-      }
 #pragma unroll
       for (int j = 0; j < J; ++j) wa[j] = wb[j];
       dza = dzb;
       ta = tb2;
       C2T_TICK(3);
+    };
+    if constexpr (TERMS) {
+      for (int64_t n = nf; n >= 1; --n) step(n, std::false_type{});
+    } else {
+      for (int64_t n = nf | 1; n >= 1; n -= 2) {
+        if (n <= nf) step(n, std::true_type{});
+        if (n >= 2) step(n - 1, std::false_type{});
+      }
     }
 #ifdef C2T_PROF
     if (lane == 0 && blockIdx.x % 97 == 0)
@@ -1053,10 +1084,14 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_rev(int64_t B, int64_t N,
   bool paired = true;
 #pragma unroll
   for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
-  if (__all(paired))
-    rev_body<true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
-  else
-    rev_body<false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+  const bool full = b0 + kWave <= B;
+  if (__all(paired)) {
+    if (full) rev_body<true, -1, true, true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+    else rev_body<true, -1, true, false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+  } else {
+    if (full) rev_body<false, -1, true, true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+    else rev_body<false, -1, true, false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+  }
 }
 
 template <int JC>

@@ -110,6 +110,34 @@ def cpu_baseline(N, J, grad, seconds):
     }
 
 
+def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
+    import torch
+
+    from celerite2_amd import ops, synth
+
+    x, diag, y, ac, bc, cc, dc = synth.device_coeffs_fast(first, Bp, N, J, dev)
+    e = torch.zeros((Bp, 0), dtype=torch.float64, device=dev)
+    work = ops.loglik_terms_workspace(Bp, N, 0, J // 2, dev, grad=True)
+    outs = None
+    for _ in range(2):
+        ll, outs, flag = ops.loglik_terms_grad(e, e, ac, bc, cc, dc, x, diag, y, work=work, out=outs)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ll, outs, flag = ops.loglik_terms_grad(e, e, ac, bc, cc, dc, x, diag, y, work=work, out=outs)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    # bytes the entry point has to move: x, diag, y in; bx, bdiag, by out (the coefficients and their gradients are O(J))
+    nbytes = Bp * N * 6 * 8
+    return {"entry": "c2_loglik_terms_grad", "value": Bp / ms * 1e3, "unit": "GP/s", "ms_per_step": ms, "steps": steps,
+            "failed_factorizations": int((flag != 0).sum()),
+            "ll_max_rel_diff_vs_matrix_level": float(((ll - ll_matrix).abs() / ll_matrix.abs()).max()),
+            "algorithmic_bytes": nbytes, "bound": "valu (f64)",
+            "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +152,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-synth", action="store_true",
                     help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
+    ap.add_argument("--no-coefficient-level", action="store_true",
+                    help="skip the extra (informational) measurement of c2_loglik_terms_grad on the same series")
     ap.add_argument("--dump-ll", default="", help="rank 0 saves the gathered log-likelihood vector here (.npy)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -238,6 +268,13 @@ def main():
                          "algorithmic_bytes_per_gp": bytes_per_gp, "kernel_ms_avg": kernel_ms_avg,
                          "kernel_ms_median": kernel_ms[len(kernel_ms) // 2]},
         }
+        if world == 1 and grad and J == 8 and not args.exact_synth and not args.no_coefficient_level:
+            # Informational, not `value`: the same series through the coefficient-level entry point,
+            # log-likelihood + gradient w.r.t. (ac, bc, cc, dc, x, diag, y) with U, V formed inside the kernels.
+            ll_matrix = ll[:Bp].clone()
+            del t, c, a, U, V, y, out, work
+            torch.cuda.empty_cache()
+            line["coefficient_level"] = coefficient_level(first, Bp, N, J, dev, ll_matrix, min(args.steps, 5))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, J, grad, args.cpu_seconds)
         print(json.dumps(line), flush=True)

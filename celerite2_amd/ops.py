@@ -376,10 +376,17 @@ def loglik_terms(ar, cr, ac, bc, cc, dc, x, diag, y, *, work=None):
     return ll, flag
 
 
-def loglik_terms_grad(ar, cr, ac, bc, cc, dc, x, diag, y, *, work=None):
+def loglik_terms_workspace(B, N, Jr, Jc, device, grad=True):
+    """Scratch for loglik_terms[_grad] (reusable across calls of the same shape)."""
+    lib = _lib.load()
+    return torch.empty(lib.c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 1 if grad else 0) // 8, dtype=torch.float64,
+                       device=device)
+
+
+def loglik_terms_grad(ar, cr, ac, bc, cc, dc, x, diag, y, *, work=None, out=None):
     """loglik_terms + reverse-mode gradient w.r.t. every input: returns
     (ll, (bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, by), flag); coefficient gradients are per series (B, Jr|Jc) also when
-    the coefficients are shared by the batch."""
+    the coefficients are shared by the batch.  `out`: a previous call's nine gradient tensors to write into."""
     B, N, Jr, Jc, batched = _terms_args(ar, cr, ac, bc, cc, dc, x, diag, y)
     lib = _lib.load()
     dev = diag.device
@@ -387,8 +394,15 @@ def loglik_terms_grad(ar, cr, ac, bc, cc, dc, x, diag, y, *, work=None):
     if work is None or work.numel() * 8 < nbytes:
         work = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
     f64 = dict(dtype=torch.float64, device=dev)
-    outs = [torch.empty((B, Jr), **f64), torch.empty((B, Jr), **f64)] + [torch.empty((B, Jc), **f64) for _ in range(4)] + \
-           [torch.empty((B, N), **f64) for _ in range(3)]
+    if out is not None:
+        outs = list(out)
+        shapes = [(B, Jr)] * 2 + [(B, Jc)] * 4 + [(B, N)] * 3
+        if len(outs) != 9 or any(tuple(o.shape) != sh or o.dtype != torch.float64 or o.device != dev or not o.is_contiguous()
+                                 for o, sh in zip(outs, shapes)):
+            raise ValueError("Invalid shape: out (nine contiguous float64 tensors as returned by loglik_terms_grad)")
+    else:
+        outs = [torch.empty((B, Jr), **f64), torch.empty((B, Jr), **f64)] + [torch.empty((B, Jc), **f64) for _ in range(4)] + \
+               [torch.empty((B, N), **f64) for _ in range(3)]
     ll = torch.empty(B, **f64)
     flag = torch.empty(B, dtype=torch.int32, device=dev)
     optr = [_p(o if o.numel() else None) for o in outs[:6]] + [_p(o) for o in outs[6:]]

@@ -51,13 +51,9 @@ def device_batch(first, count, N, J, device, seed0=721):
     return td, to(c), a, U, V, yd
 
 
-def device_batch_fast(first, count, N, J, device, seed0=721):
-    """Same synthetic distribution as device_batch, but drawn with torch's device generator (seeded with
-    seed0 + first) so that very large shards (65536 x 4096) are ready in a fraction of a second.  Used by
-    bench.py; parity tests use the numpy recipe (host_inputs) so that the CPU oracle sees identical numbers."""
+def device_coeffs_fast(first, count, N, J, device, seed0=721):
+    """(t, diag, y, ac, bc, cc, dc) of device_batch_fast: the coefficient-level view of the same series."""
     import torch
-
-    from . import ops
 
     assert J % 2 == 0
     Jc = J // 2
@@ -77,7 +73,19 @@ def device_batch_fast(first, count, N, J, device, seed0=721):
     bc = (ac / f).contiguous()
     cc = (0.5 * w0 / Q).contiguous()
     dc = (cc * f).contiguous()
-    ar = torch.zeros((count, 0), **f64)
+    return t, diag, y, ac, bc, cc, dc
+
+
+def device_batch_fast(first, count, N, J, device, seed0=721):
+    """Same synthetic distribution as device_batch, but drawn with torch's device generator (seeded with
+    seed0 + first) so that very large shards (65536 x 4096) are ready in a fraction of a second.  Used by
+    bench.py; parity tests use the numpy recipe (host_inputs) so that the CPU oracle sees identical numbers."""
+    import torch
+
+    from . import ops
+
+    t, diag, y, ac, bc, cc, dc = device_coeffs_fast(first, count, N, J, device, seed0)
+    ar = torch.zeros((count, 0), dtype=torch.float64, device=device)
     c = torch.repeat_interleave(cc, 2, dim=1).contiguous()
     a, U, V = ops.get_celerite_matrices(ar, ac, bc, dc, t, diag)
     return t, c, a, U, V, y

@@ -611,7 +611,10 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_tt_fwd(int64_t B, int64_t N
 // END of a step, where the stores that get drained are two steps old.
 // =============================================================================================================
 constexpr int RS1 = J + 2;   // LDS stride (doubles) of a series in a one-row tile: 80 B, conflict-free b128
-constexpr int kRevLds = (kWave * RSTR + kWave * RS1 + 3 * kWave * SSTR + 2 * kWave * RS1) * 8;  // U/bU, bV, ba, by, bt, c, bc
+constexpr int CS4 = 6;        // LDS stride (doubles) of a series' four distinct rates (paired): 48 B, conflict-free b128
+// U/bU (two rows), bV (two rows with paired rates, else one), ba, by, bt, c, bc -- the larger of the two layouts
+constexpr int kRevLds = (2 * kWave * RSTR + 3 * kWave * SSTR + kWave * CS4 + kWave * RS1) * 8;
+static_assert(kRevLds <= 40960 && (kWave * RSTR + kWave * RS1 + 3 * kWave * SSTR + 2 * kWave * RS1) * 8 <= kRevLds, "four wavefronts per CU");
 
 // One-row tiles: an instruction moves 16 series x 64 bytes (lane l: series 16 i + l / 4, 16-byte piece l % 4).  Lanes of
 // a partial wavefront are clamped onto the last valid series: they move the same bytes to the same place again.
@@ -689,8 +692,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const RowIOT<FULL> io(lane, last);
   // tU: TWO rows of U per series (the aligned pair 2p, 2p+1 = one 128-byte line, fetched once; single rows cost the
   // line twice, +15 GB per sweep at the bench shape); bU_n takes the place of U_n in it
-  double *tU = lds, *tBV = tU + kWave * RSTR, *tBA = tBV + kWave * RS1, *tBY = tBA + kWave * SSTR,
-         *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * RS1;
+  // paired rates (matrix-level form): four distinct rates per series, and the room that saves holds a two-row bV tile
+  constexpr bool BVPAIR = PAIRED && !TERMS;
+  constexpr int CSTR = BVPAIR ? CS4 : RS1;
+  double *tU = lds, *tBV = tU + kWave * RSTR, *tBA = tBV + kWave * (BVPAIR ? RSTR : RS1), *tBY = tBA + kWave * SSTR,
+         *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * CSTR;
+  static_assert((kWave * RSTR + kWave * (BVPAIR ? RSTR : RS1) + 3 * kWave * SSTR + kWave * CSTR + kWave * RS1) * 8 <= kRevLds, "LDS");
   double *tACC = lds;   // coefficient-level form: takes the place of the U tile (64 x 14 <= 64 x 18 doubles)
   const double *Ub = U + b0 * N * J;
   double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
@@ -713,13 +720,27 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) zero[j] = 0.0;
-    row1_write(tC, lane, cj);
+    if constexpr (BVPAIR) {   // c[2k] == c[2k+1]: the four distinct rates
+      *reinterpret_cast<double2 *>(tC + lane * CS4) = make_double2(cj[0], cj[2]);
+      *reinterpret_cast<double2 *>(tC + lane * CS4 + 2) = make_double2(cj[4], cj[6]);
+    } else {
+      row1_write(tC, lane, cj);
+    }
     row1_write(tBC, lane, zero);
     if constexpr (TERMS) {
 #pragma unroll
       for (int q = 0; q < AS1 / 2; ++q) *reinterpret_cast<double2 *>(tACC + lane * AS1 + 2 * q) = make_double2(0.0, 0.0);
     }
   }
+  auto read_rates = [&](double (&cj)[J]) __attribute__((always_inline)) {
+    if constexpr (BVPAIR) {
+      const double2 c01 = *reinterpret_cast<const double2 *>(tC + lane * CS4);
+      const double2 c23 = *reinterpret_cast<const double2 *>(tC + lane * CS4 + 2);
+      cj[0] = cj[1] = c01.x; cj[2] = cj[3] = c01.y; cj[4] = cj[5] = c23.x; cj[6] = cj[7] = c23.y;
+    } else {
+      row1_read(tC, lane, cj);
+    }
+  };
   // one step's contribution to the running sums (TERMS): gv = -bV0 sin + bV1 cos of the row, bu = bU of the row
   auto accumulate = [&](const double (&u)[J], const double (&bu)[J], const double (&sn)[JCN], const double (&cs)[JCN],
                         const double (&gv)[JCN], double ba_n, double xn) -> double {
@@ -809,11 +830,19 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     const int64_t nf = N - 1;
     // ---- prologue ------------------------------------------------------------------------------------------------------
     // bV, ba, by of the last row are pure seeds: they leave at once (their slots in the tiles belong to lower rows)
-    if constexpr (!TERMS) row1_write(tBV, lane, bVn);
+    // bV of the last row is a pure seed.  One-row bV tile, or the last row an even one (its pair partner lies beyond the
+    // series): it leaves at once; otherwise it waits in row 1 of the pair tile for the first (odd) step
+    const bool bv_seed_waits = BVPAIR && (nf & 1);
+    if constexpr (!TERMS) {
+      if (bv_seed_waits) row_write(tBV, lane, 1, bVn);
+      else row1_write(tBV, lane, bVn);
+    }
     tBA[lane * SSTR + (nf & (ST - 1))] = ban;
     tBY[lane * SSTR + (nf & (ST - 1))] = bzn;
     lds_order();
-    if constexpr (!TERMS) row1_flush(bVb, N, nf, tBV, lane, last);
+    if constexpr (!TERMS) {
+      if (!bv_seed_waits) row1_flush(bVb, N, nf, tBV, lane, last);
+    }
     if ((nf & (ST - 1)) == 0) {  // the last row sits alone at the bottom of its scalar tile
       sc_flush(bab, N, nf, nf, nf, tBA, lane, last);
       sc_flush(byb, N, nf, nf, nf, tBY, lane, last);
@@ -877,7 +906,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tcur = tm;
       {
         double cj[J];
-        row1_read(tC, lane, cj);
+        read_rates(cj);
         if constexpr (TERMS) tc.decay(cj, dt, p);
         else decay<PAIRED>(cj, dt, p);
       }
@@ -936,7 +965,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       double f = 0.0;
       {
         double cj[J], bcj[J];
-        row1_read(tC, lane, cj);
+        read_rates(cj);
         row1_read(tBC, lane, bcj);
 #pragma unroll
         for (int j = 0; j < J; ++j) { bcj[j] = fma(dt, bp[j], bcj[j]); f = fma(cj[j], bp[j], f); }
@@ -958,24 +987,60 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tBA[lane * SSTR + rs] = ban;
       tBY[lane * SSTR + rs] = bzn;
       tBT[lane * SSTR + (int)(n & (ST - 1))] = btn;
-      if constexpr (!TERMS) row1_write(tBV, lane, bVn);
+      if constexpr (BVPAIR) row_write(tBV, lane, ODD ? 0 : 1, bVn);   // bV_{n-1}
+      else if constexpr (!TERMS) row1_write(tBV, lane, bVn);
       lds_order();
-      if constexpr (!TERMS) {  // both rows leave together: the eight LDS reads are issued back to back, then the eight stores (one register
-         // reused for all of them makes every read wait out the LDS latency on its own: ~1000 cycles per step)
-        double fl[16];
+      // Outputs of width J leave as aligned PAIRS of rows, 128-byte runs out of two-row tiles (64-byte rows cost ~4 % of
+      // the sweep in HBM efficiency): bU (n, n+1) at the end of the even step; with paired rates bV (n-1, n) at the end
+      // of the odd step (unpaired rates keep a one-row bV tile -- their LDS budget is spent on eight rates -- and write
+      // bV_{n-1} every step).  All LDS reads first, then all stores.
+      if constexpr (!TERMS) {
+        double fv[16], fu[16];
+        if constexpr (!BVPAIR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
-          const double2 v0 = *reinterpret_cast<const double2 *>(tU + sr * RSTR + (ODD ? J : 0) + 2 * (lane & 3));
-          const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RS1 + 2 * (lane & 3));
-          fl[4 * i] = v0.x; fl[4 * i + 1] = v0.y; fl[4 * i + 2] = v1.x; fl[4 * i + 3] = v1.y;
+          for (int i = 0; i < 4; ++i) {
+            int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
+            const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RS1 + 2 * (lane & 3));
+            fv[2 * i] = v1.x; fv[2 * i + 1] = v1.y;
+          }
+        } else if constexpr (ODD) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
+            const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RSTR + 2 * (lane & 7));
+            fv[2 * i] = v1.x; fv[2 * i + 1] = v1.y;
+          }
+        }
+        if constexpr (!ODD) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
+            const double2 v0 = *reinterpret_cast<const double2 *>(tU + sr * RSTR + 2 * (lane & 7));
+            fu[2 * i] = v0.x; fu[2 * i + 1] = v0.y;
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!BVPAIR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
-          st2_stream(reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 3)), make_double2(fl[4 * i], fl[4 * i + 1]));
-          st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)), make_double2(fl[4 * i + 2], fl[4 * i + 3]));
+          for (int i = 0; i < 4; ++i) {
+            int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
+            st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)), make_double2(fv[2 * i], fv[2 * i + 1]));
+          }
+        } else if constexpr (ODD) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {   // rows n-1 (even) and n
+            int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
+            st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 7)), make_double2(fv[2 * i], fv[2 * i + 1]));
+          }
+        }
+        if constexpr (!ODD) {
+          if (n + ((lane & 7) >> 2) <= nf) {   // the upper row of the top pair may lie beyond the series
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
+              st2_stream(reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 7)), make_double2(fu[2 * i], fu[2 * i + 1]));
+            }
+          }
         }
       }
 
@@ -1021,11 +1086,18 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         for (int k = 0; k < JC; ++k) gv[k] = fma(bVn[JR + 2 * k + 1], cs[k], -(bVn[JR + 2 * k] * sn[k]));
         carry += accumulate(u0, bu0, sn, cs, gv, ban, tcur);
       } else {
-        row1_write(tU, lane, zero);
+        row_write(tU, lane, 0, zero);   // bU_1 is waiting in row 1 of the tile
       }
       tBT[lane * SSTR] = carry;
       lds_order();
-      if constexpr (!TERMS) row1_flush(bUb, N, 0, tU, lane, last);
+      if constexpr (!TERMS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          int sr = 8 * i + lane / 8; sr = sr < last ? sr : last;
+          *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N) * J + 2 * (lane & 7)) =
+              *reinterpret_cast<const double2 *>(tU + sr * RSTR + 2 * (lane & 7));
+        }
+      }
       sc_flush(btb, N, 0, 0, (ST - 1) < (N - 1) ? (ST - 1) : (N - 1), tBT, lane, last);
     }
   } else {  // N == 1: seeds only

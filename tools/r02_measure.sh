@@ -9,7 +9,7 @@ python tools/bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err
 python tools/lanes_sweep.py > $O/lanes_sweep.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --mode fwd --no-cpu-baseline > $O/bench_fwd.json 2>> $O/bench_default.err
-python bench.py --global-batch 8192 --no-cpu-baseline > $O/bench_B8192.json 2>> $O/bench_default.err
+python bench.py --batch-per-gpu 8192 --no-cpu-baseline > $O/bench_B8192.json 2>> $O/bench_default.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o out --output-format csv -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/prof_bench.json 2> $O/prof_bench.err
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do

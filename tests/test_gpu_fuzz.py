@@ -130,3 +130,68 @@ def test_fuzz_general_matmul(ops, oracle, seed):
         close(Zd, Zo); close(Fd, Fo)
         (Zd2,) = dev(Z0)
         close(getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd2), Zo)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzz_one_lane_kernels(ops, oracle, monkeypatch, seed):
+    """The one-lane-per-series kernels (width 8; c2_loglik_t.hip) forced on random shapes: ragged wavefronts, series
+    lengths around the pair (2), scalar-tile (8) and checkpoint (32) periods, paired / unpaired rates, shared grids,
+    an occasional failed series, and gaps that trip the stability gate (the gated replay kernels then answer)."""
+    rng = np.random.default_rng(9000 + seed)
+    B = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 190]))
+    N = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 34, 63, 64, 65, 66, 97, 130, 257]))
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), 8)
+    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    a = a + 0.5
+    if rng.random() < 0.4:
+        c = c * rng.uniform(0.9, 1.1, c.shape)                       # unpaired rates
+    if N > 40 and rng.random() < 0.3:
+        t[:, N // 2:] += rng.choice([3.0, 400.0])                     # a gap: maybe beyond the guard
+    shared = rng.random() < 0.3
+    if shared:
+        t = np.tile(t[0], (B, 1)); c = np.tile(c[0], (B, 1))
+    bad = None
+    if N > 4 and B > 3 and rng.random() < 0.4:
+        bad = int(rng.integers(0, B)); a[bad, int(rng.integers(1, N))] = -7.0
+    llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    monkeypatch.setenv("C2_LANES", "1")
+    td, cd = dev(t[0].copy(), c[0].copy()) if shared else dev(t, c)
+    ad, Ud, Vd, yd = dev(a, U, V, y)
+    ll, grads, flag = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    ll0, flag0 = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    assert flag.cpu().tolist() == list(flago) and flag0.cpu().tolist() == list(flago)
+    ok = np.asarray(flago) == 0
+    if bad is not None:
+        assert not ok[bad]
+    close(ll[ok], llo[ok]); close(ll0[ok], llo[ok])
+    for g, e in zip(grads, go):
+        close(g[ok], e[ok])
+        if (~ok).any():
+            assert bool(np.isnan(g.cpu().numpy()[~ok]).all())
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
+    """Coefficient-level kernels (rows formed in the lane) against the composed chain on random term mixes and shapes."""
+    rng = np.random.default_rng(9500 + seed)
+    Jc = int(rng.integers(0, 5)); Jr = 8 - 2 * Jc
+    B = int(rng.choice([1, 3, 64, 65, 130])); N = int(rng.choice([1, 2, 3, 9, 31, 32, 33, 65, 120]))
+    ar = rng.uniform(0.5, 1.5, (B, Jr)); cr = rng.uniform(0.05, 0.5, (B, Jr))
+    ac = rng.uniform(0.5, 2.0, (B, Jc)); cc = rng.uniform(0.02, 0.3, (B, Jc)); dc = rng.uniform(0.2, 3.0, (B, Jc))
+    bc = ac * cc / dc * rng.uniform(0.0, 0.9, (B, Jc))
+    x = np.sort(rng.uniform(0, N / 10.0 + 0.1, (B, N)), axis=1) + rng.choice([0.0, 2.4e6])
+    diag = rng.uniform(0.1, 0.3, (B, N)); y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    monkeypatch.setenv("C2_TERMS_FUSED", "0")
+    ll_c, g_c, fl_c = ops.loglik_terms_grad(*args)
+    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    ll_f, g_f, fl_f = ops.loglik_terms_grad(*args)
+    ll_f0, _ = ops.loglik_terms(*args)
+    assert int(fl_c.abs().sum()) == 0 and int(fl_f.abs().sum()) == 0
+    close(ll_f, ll_c.cpu().numpy()); close(ll_f0, ll_c.cpu().numpy())
+    xmax = float(np.abs(x).max())
+    for k, (gf, gc) in enumerate(zip(g_f, g_c)):
+        if gc.numel():
+            # two device paths with different summation orders; bdc / bx carry the factor max|x| (see test_gpu_terms.py)
+            floor = 1e-11 if k not in (5,) else max(1e-11, 1e-15 * N * xmax)
+            close(gf, gc.cpu().numpy(), tol=1e-9, floor=floor)

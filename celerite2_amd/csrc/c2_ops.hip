@@ -963,47 +963,98 @@ __global__ __launch_bounds__(kWave) void k_gm_emit(int64_t B, int64_t N, int64_t
 
 // =============================================================================
 // get_celerite_matrices -- reference python/celerite2/driver.cpp:422-477.
-// One thread per (series, row, term): consecutive threads write consecutive columns of the same row (a complex term
-// its cos/sin column pair as one 16-byte store when the pair is aligned), so a wavefront's stores are dense runs and
-// every sincos is evaluated once.
+// A thread owns one term and walks kMatRows rows; consecutive threads write consecutive columns of the same row (a
+// complex term its cos/sin column pair as one 16-byte store when the pair is aligned), so a wavefront's stores are dense
+// runs and every sincos is evaluated once.  1.15-1.2 ms per 8192 x 4096 rows at J = 8 (0.53-0.56 of the roofline; the
+// one-(row, term)-per-thread version with the library sincos inlined ran 1.8 ms at 3 wavefronts per SIMD).
 // =============================================================================
-__global__ void k_matrices(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ar,
-                           const double *__restrict__ ac, const double *__restrict__ bc, const double *__restrict__ dc,
-                           int coef_batched, const double *__restrict__ x, int64_t x_bs, const double *__restrict__ diag,
-                           double *__restrict__ a, double *__restrict__ U, double *__restrict__ V,
-                           const unsigned long long *__restrict__ gate) {
+constexpr int kMatRows = 8;   // rows per thread of k_matrices
+// x sorted (a precondition of the recursions): the largest |x| of a series sits at one of its ends
+__device__ __forceinline__ bool matrices_big_phase(double dc_, const double *xb, int64_t N) {
+  return !(fabs(dc_) * fmax(fabs(xb[0]), fabs(xb[N - 1])) < kSincosFastMax);
+}
+__global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ar,
+                                                  const double *__restrict__ ac, const double *__restrict__ bc,
+                                                  const double *__restrict__ dc, int coef_batched,
+                                                  const double *__restrict__ x, int64_t x_bs,
+                                                  const double *__restrict__ diag, double *__restrict__ a,
+                                                  double *__restrict__ U, double *__restrict__ V,
+                                                  const unsigned long long *__restrict__ gate) {
   if (gate_closed(gate)) return;
+  // A thread owns ONE term and walks kMatRows rows of one series: its coefficients are loaded once and the row
+  // iterations are independent, so their x loads / sincos / stores overlap (one (row, term) pair per thread spent
+  // 74 % of its 7500 cycles waiting for dependent loads).  Consecutive threads hold consecutive terms of a row, so a
+  // wavefront's stores are dense runs (a complex term its cos / sin column pair as one 16-byte store when aligned).
   const int Q = Jr + Jc, J = Jr + 2 * Jc;
+  const int rpi = 256 / Q;                      // rows per block iteration
+  const int q = (int)threadIdx.x % Q, r = (int)threadIdx.x / Q;
+  if (r >= rpi) return;
+  const int64_t n0 = (int64_t)blockIdx.x * rpi * kMatRows + r;
+  for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    const double *arb = ar + (coef_batched ? b * Jr : 0);
+    const double *acb = ac + (coef_batched ? b * Jc : 0), *bcb = bc + (coef_batched ? b * Jc : 0),
+                 *dcb = dc + (coef_batched ? b * Jc : 0);
+    double asum = 0.0, c0 = 0.0, c1 = 0.0, c2_ = 0.0;
+    bool big = false;
+    if (q == 0) {  // a = diag + sum(ar) + sum(ac), in the reference's summation order (driver.cpp:456-458)
+      for (int i = 0; i < Jr; ++i) asum += arb[i];
+      for (int i = 0; i < Jc; ++i) asum += acb[i];
+    }
+    if (q < Jr) c0 = arb[q];
+    else {
+      c0 = acb[q - Jr]; c1 = bcb[q - Jr]; c2_ = dcb[q - Jr];
+      big = matrices_big_phase(c2_, x + b * x_bs, N);   // k_matrices_big writes this term's columns
+    }
+    const int ind = q < Jr ? q : Jr + 2 * (q - Jr);
+#pragma unroll 1   // one row in flight per thread: 86 registers, 5 wavefronts per SIMD (unrolled by 2: 106 / 4, 15 % slower)
+    for (int k = 0; k < kMatRows; ++k) {
+      const int64_t n = n0 + (int64_t)k * rpi;
+      if (n >= N) break;
+      const int64_t row = b * N + n;
+      if (q == 0) a[row] = diag[row] + asum;
+      if (big) continue;
+      double *Un = U + row * J + ind, *Vn = V + row * J + ind;
+      if (q < Jr) {
+        *Vn = 1.0;
+        *Un = c0;
+        continue;
+      }
+      double sn, cs;
+      sincos_cw_fast(c2_ * x[b * x_bs + n], sn, cs);
+      const double u0 = c0 * cs + c1 * sn, u1 = c0 * sn - c1 * cs;
+      if ((Jr & 1) == 0) {  // J even and ind even: the pair is 16-byte aligned
+        *reinterpret_cast<double2 *>(Vn) = make_double2(cs, sn);
+        *reinterpret_cast<double2 *>(Un) = make_double2(u0, u1);
+      } else {
+        Vn[0] = cs; Vn[1] = sn;
+        Un[0] = u0; Un[1] = u1;
+      }
+    }
+  }
+}
+
+// The complex terms k_matrices left out: phases beyond the range of the branch-free sincos (raw Julian dates times a
+// fast frequency).  One thread per (series, complex term); it returns at once in the common case, so the library's
+// large-argument reduction (and its 160 registers) stays out of the kernel that does the work.
+__global__ void k_matrices_big(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ac,
+                               const double *__restrict__ bc, const double *__restrict__ dc, int coef_batched,
+                               const double *__restrict__ x, int64_t x_bs, double *__restrict__ U,
+                               double *__restrict__ V, const unsigned long long *__restrict__ gate) {
+  if (gate_closed(gate)) return;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * N * Q) return;
-  const int64_t row = g / Q;
-  const int q = (int)(g - row * Q);
-  const int64_t b = row / N, n = row - b * N;
-  const double *arb = ar + (coef_batched ? b * Jr : 0);
-  const double *acb = ac + (coef_batched ? b * Jc : 0), *bcb = bc + (coef_batched ? b * Jc : 0),
-               *dcb = dc + (coef_batched ? b * Jc : 0);
-  if (q == 0) {  // a = diag + sum(ar) + sum(ac), in the reference's summation order (driver.cpp:456-458)
-    double sum = 0.0;
-    for (int i = 0; i < Jr; ++i) sum += arb[i];
-    for (int i = 0; i < Jc; ++i) sum += acb[i];
-    a[row] = diag[row] + sum;
-  }
-  double *Un = U + row * J, *Vn = V + row * J;
-  if (q < Jr) {
-    Vn[q] = 1.0;
-    Un[q] = arb[q];
-    return;
-  }
-  const int i = q - Jr, ind = Jr + 2 * i;
-  double sn, cs;
-  sincos(dcb[i] * x[b * x_bs + n], &sn, &cs);
-  const double u0 = acb[i] * cs + bcb[i] * sn, u1 = acb[i] * sn - bcb[i] * cs;
-  if ((Jr & 1) == 0) {  // J even and ind even: the pair is 16-byte aligned
-    *reinterpret_cast<double2 *>(Vn + ind) = make_double2(cs, sn);
-    *reinterpret_cast<double2 *>(Un + ind) = make_double2(u0, u1);
-  } else {
-    Vn[ind] = cs; Vn[ind + 1] = sn;
-    Un[ind] = u0; Un[ind + 1] = u1;
+  if (g >= B * Jc) return;
+  const int64_t b = g / Jc;
+  const int i = (int)(g - b * Jc), J = Jr + 2 * Jc, ind = Jr + 2 * i;
+  const int64_t o = coef_batched ? b * Jc : 0;
+  const double a_ = ac[o + i], b_ = bc[o + i], d_ = dc[o + i];
+  const double *xb = x + b * x_bs;
+  if (!matrices_big_phase(d_, xb, N)) return;
+  for (int64_t n = 0; n < N; ++n) {
+    double sn, cs;
+    sincos(d_ * xb[n], &sn, &cs);
+    double *Un = U + (b * N + n) * J + ind, *Vn = V + (b * N + n) * J + ind;
+    Vn[0] = cs; Vn[1] = sn;
+    Un[0] = a_ * cs + b_ * sn; Un[1] = a_ * sn - b_ * cs;
   }
 }
 
@@ -1343,9 +1394,13 @@ int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
                          c2_stream_t stream) {
   if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
   if (!x || !diag || !a || !U || !V || (Jr && !ar) || (Jc && (!ac || !bc || !dc))) return C2_ERR_INVALID;
-  const int64_t total = B * N * (Jr + Jc);
-  hipLaunchKernelGGL(k_matrices, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
+  const int64_t rows_per_block = (int64_t)(256 / (Jr + Jc)) * kMatRows;
+  hipLaunchKernelGGL(k_matrices, dim3((unsigned)((N + rows_per_block - 1) / rows_per_block), (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, (hipStream_t)stream, B, N,
                      (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V, gate);
+  if (int e = check_launch()) return e;
+  if (Jc > 0)
+    hipLaunchKernelGGL(k_matrices_big, dim3((unsigned)((B * Jc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
+                       (int)Jr, (int)Jc, ac, bc, dc, coef_batched, x, x_bs, U, V, gate);
   return check_launch();
 }
 int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,

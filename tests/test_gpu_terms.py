@@ -223,6 +223,12 @@ def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkey
     x[:64] += 2.45e6
     diag = rng.uniform(0.1, 0.3, (B, N))
     y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    # the matrix recipe on its own: the rare-path kernel (library sincos) owns the columns of the large-phase series
+    a_d, U_d, V_d = ops.get_celerite_matrices(*dev(ar, ac, bc, dc, x, diag))
+    for b in (0, 63, 64, 127):
+        _, a_o, U_o, V_o = dense.celerite_matrices(dense.Coeffs(ar=ar[b], cr=cr[b], ac=ac[b], bc=bc[b], cc=cc[b], dc=dc[b]),
+                                                   x[b], diag[b])
+        close(a_d[b], a_o); close(U_d[b], U_o); close(V_d[b], V_o)
     monkeypatch.setenv("C2_TERMS_FUSED", "1")
     ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
     ll_f, _ = ops.loglik_terms(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))

@@ -10,8 +10,11 @@ objs=""
 stem=$(basename ${src%.hip})
 for o in celerite2_amd/build/*.o; do
   b=$(basename $o .o)
-  # every regular object except the one being replaced and except variant objects of earlier A/B builds (<stem>_<tag>.o)
-  case $b in ${stem}|${stem}_*) ;; *) objs="$objs $o";; esac
+  # every REGULAR object (one with a source file of its name) except the one being replaced; variant objects of earlier
+  # A/B builds (<stem>_<tag>.o) have no source of that name
+  [ -f celerite2_amd/csrc/$b.hip ] || continue
+  [ "$b" = "$stem" ] && continue
+  objs="$objs $o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs $obj -o celerite2_amd/libcelerite2_amd_$tag.so
 echo built celerite2_amd/libcelerite2_amd_$tag.so

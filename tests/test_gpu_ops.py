@@ -910,3 +910,35 @@ def test_million_row_series(ops, oracle):
     zo = np.zeros((N, 1))
     oracle.general_matmul_lower(t[b], t2[b], c[b], U[b], V2[b], Y2[b], zo)
     close(Zg[b], zo)
+
+
+def test_hot_path_is_graph_capturable(ops, oracle, monkeypatch):
+    """The fused gradient is stream-ordered end to end -- no host round trip, no allocation with caller-provided
+    workspace / outputs, the choice between the backward-recursion sweep and the replay kernels made on the device --
+    so it can be captured once in a HIP graph and replayed on new data (both lane mappings, and a batch that trips the
+    stability gate on replay)."""
+    import torch
+    J = 8
+    for lanes, B, N in (("8", 9, 200), ("1", 70, 200)):
+        monkeypatch.setenv("C2_LANES", lanes)
+        t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+        td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+        work = ops.loglik_grad_workspace(B, N, J, td.device)
+        ll, out, flag = ops.loglik_grad(td, cd, ad, Ud, Vd, yd, work=work)      # warm-up outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ll_g, out_g, flag_g = ops.loglik_grad(td, cd, ad, Ud, Vd, yd, work=work, out=out)
+        for variant in range(3):
+            y2 = y + 0.01 * variant
+            t2 = t.copy()
+            if variant == 2:
+                t2[:, N // 2:] += 500.0     # beyond the guard of the one-lane sweep: the gated replay kernels answer
+            yd.copy_(torch.from_numpy(y2)); td.copy_(torch.from_numpy(t2))
+            g.replay()
+            torch.cuda.synchronize()
+            llo, go, flo = oracle.loglik_grad_batched(t2, c, a, U, V, y2, nthreads=2)
+            assert flag_g.cpu().tolist() == list(flo)
+            close(ll_g, llo)
+            for x, e in zip(out_g, go):
+                close(x, e)

@@ -830,11 +830,27 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
 #ifndef C2_LANES1_MIN_BATCH_GRAD
 #define C2_LANES1_MIN_BATCH_GRAD 24576
 #endif
-extern "C" int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
-                                    const double *a, const double *U, const double *V, const double *y, double *ll,
-                                    int32_t *flag, c2_stream_t stream);
+// the same kernels compiled per width (c2_loglik_t.hip with C2T_J = 8, 4, 2)
+#define C2_DECL_T(J_)                                                                                                  \
+  extern "C" int c2_internal_loglik_t##J_(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,       \
+                                          int64_t c_bs, const double *a, const double *U, const double *V,           \
+                                          const double *y, double *ll, int32_t *flag, c2_stream_t stream);           \
+  extern "C" size_t c2_internal_loglik_t_record_doubles##J_(int64_t B, int64_t N);                                   \
+  extern "C" int c2_internal_loglik_t_grad##J_(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, \
+                                               int64_t c_bs, const double *a, const double *U, const double *V,      \
+                                               const double *y, double *ll, double *bt, double *bc, double *ba,      \
+                                               double *bU, double *bV, double *by, int32_t *flag, double *rec,       \
+                                               unsigned long long *guard, c2_stream_t stream);
+C2_DECL_T(8)
+C2_DECL_T(4)
+C2_DECL_T(2)
+#undef C2_DECL_T
+static size_t lanes1_record_doubles(int64_t B, int64_t N, int64_t J) {
+  return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
+                : (J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N));
+}
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
-  if (J != 8) return false;
+  if (J != 8 && J != 4 && J != 2) return false;
   const char *e = getenv("C2_LANES");
   const int forced = e ? atoi(e) : 0;
   if (forced == 1) return true;
@@ -856,7 +872,11 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
-  if (use_lanes1(B, J, false)) return c2_internal_loglik_t(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
+  if (use_lanes1(B, J, false)) {
+    if (J == 8) return c2_internal_loglik_t8(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
+    if (J == 4) return c2_internal_loglik_t4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
+    return c2_internal_loglik_t2(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
+  }
   if (use_lanes4(B, J, false)) return c2_internal_loglik4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
                            (hipStream_t)stream);
@@ -905,7 +925,7 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   size_t n = grad_ws(B, N, J).total;
   if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
   if (use_lanes1(B, J, true)) {  // [guard word (16 bytes)] [records of the one-lane path | workspace of the replay fallback]
-    const size_t r = c2_internal_loglik_t_record_doubles(B, N);
+    const size_t r = lanes1_record_doubles(B, N, J);
     n = 2 + (r > n ? r : n);
   }
   return n * sizeof(double);
@@ -931,8 +951,9 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
     unsigned long long *guard = (unsigned long long *)work;
     if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
     work = (double *)work + 2;
-    if (int e = c2_internal_loglik_t_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
-                                          (double *)work, guard, stream))
+    auto one_lane = J == 8 ? c2_internal_loglik_t_grad8 : (J == 4 ? c2_internal_loglik_t_grad4 : c2_internal_loglik_t_grad2);
+    if (int e = one_lane(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, (double *)work, guard,
+                         stream))
       return e;
     gate = guard;
   }

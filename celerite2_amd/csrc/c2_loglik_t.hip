@@ -25,20 +25,29 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+// The file is compiled once per width: C2T_J = 8 (default), 4, 2 (c2_loglik_t4.hip / c2_loglik_t2.hip include it).  A
+// tile of the width-J streams is always ONE 128-byte line per series: RT = 16 / J rows.
+#ifndef C2T_J
+#define C2T_J 8
+#endif
+#define C2T_CAT2(a, b) a##b
+#define C2T_CAT(a, b) C2T_CAT2(a, b)
+#define C2T_NAME(stem) C2T_CAT(stem, C2T_J)   // c2_internal_loglik_t -> c2_internal_loglik_t8
+#define c2t C2T_CAT(c2t_j, C2T_J)             // one namespace per width
+
 namespace c2t {
 using namespace c2;
 
-constexpr int J = 8;
+constexpr int J = C2T_J;
+static_assert(J == 8 || J == 4 || J == 2, "128-byte tiles of whole rows");
 constexpr int NS = J * (J + 1) / 2;  // packed symmetric J x J
+constexpr int PPR = J / 2;           // 16-byte pieces per row
 #ifndef C2T_C
 #define C2T_C 32
 #endif
 constexpr int C = C2T_C;             // checkpoint interval (rows)
 constexpr double kGuard = kBackwardGuard;  // largest allowed max_j c_j * (t_end - t_start) of a segment
-#ifndef C2T_RT
-#define C2T_RT 2
-#endif
-constexpr int RT = C2T_RT;           // rows per tile of the width-J streams (RT * 64-byte runs in HBM)
+constexpr int RT = 16 / J;           // rows per tile of the width-J streams: one aligned 128-byte line per series
 constexpr int LPS = RT * J / 2;      // lanes that fetch one series' run (16 bytes each)
 constexpr int NI = LPS;              // global instructions per row tile (64 / LPS series each)
 constexpr int ST = 8;                // rows per tile of the per-series scalar streams (64-byte runs)
@@ -98,9 +107,9 @@ using RowIO = RowIOT<false>;
 template <class IO>
 __device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, const IO &io,
                                           double (&st)[2 * NI]) {
-  int64_t r = n0 + (io.rpiece >> 2);
+  int64_t r = n0 + io.rpiece / PPR;
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
-  const int64_t off = r * J + 2 * (io.rpiece & 3);
+  const int64_t off = r * J + 2 * (io.rpiece % PPR);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)io.rl(i) * N * J + off);
@@ -131,12 +140,12 @@ __device__ __forceinline__ void row_write(double *tile, int lane, int r, const d
 __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, int64_t n0, int64_t lo, int64_t hi,
                                           const double *tile, int lane, int last) {
   const int piece = lane % LPS;
-  const int64_t r = n0 + (piece >> 2);
+  const int64_t r = n0 + piece / PPR;
   if (last == kWave - 1 && n0 >= lo && n0 + RT - 1 <= hi) {  // uniform: full wavefront, whole tile in range
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int s = (kWave / LPS) * i + lane / LPS;
-      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece & 3)) =
+      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece % PPR)) =
           *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
     }
     return;
@@ -146,7 +155,7 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
     const int s = (kWave / LPS) * i + lane / LPS;
     const double2 v = *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
     if (s <= last && r >= lo && r <= hi)
-      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece & 3)) = v;
+      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece % PPR)) = v;
   }
 }
 
@@ -154,7 +163,7 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
 __device__ __forceinline__ void row_flush_full(double *__restrict__ base, int64_t N, int64_t n0, const double *tile,
                                                int lane) {
   const int piece = lane % LPS;
-  const int64_t off = (n0 + (piece >> 2)) * J + 2 * (piece & 3);
+  const int64_t off = (n0 + piece / PPR) * J + 2 * (piece % PPR);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int s = (kWave / LPS) * i + lane / LPS;
@@ -618,12 +627,12 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_tt_fwd(int64_t B, int64_t N
 // cycles go (build with -DC2T_PROF).
 // =============================================================================================================
 constexpr int RS1 = J + 2;   // LDS stride (doubles) of a series in a one-row tile: 80 B, conflict-free b128
-constexpr int CS4 = 6;        // LDS stride (doubles) of a series' four distinct rates (paired): 48 B, conflict-free b128
+constexpr int CS4 = 6;        // LDS stride (doubles) of a series' J / 2 distinct rates (paired): 48 B, conflict-free b128
 // U/bU (two rows), bV (two rows with paired rates, else one), ba, by, bt, c, bc -- the larger of the two layouts
 constexpr int kRevLds = (2 * kWave * RSTR + 3 * kWave * SSTR + kWave * CS4 + kWave * RS1) * 8;
 static_assert(kRevLds <= 40960 && (kWave * RSTR + kWave * RS1 + 3 * kWave * SSTR + 2 * kWave * RS1) * 8 <= kRevLds, "four wavefronts per CU");
 
-// One-row tiles: an instruction moves 16 series x 64 bytes (lane l: series 16 i + l / 4, 16-byte piece l % 4).  Lanes of
+// One-row tiles: an instruction moves 64 / PPR series x one row (lane l: series (64 / PPR) i + l / PPR, 16-byte piece l % PPR).  Lanes of
 // a partial wavefront are clamped onto the last valid series: they move the same bytes to the same place again.
 __device__ __forceinline__ void row1_read(const double *tile, int lane, double (&x)[J]) {
 #pragma unroll
@@ -640,10 +649,10 @@ __device__ __forceinline__ void row1_write(double *tile, int lane, const double 
 __device__ __forceinline__ void row1_flush(double *__restrict__ base, int64_t N, int64_t n, const double *tile, int lane,
                                            int last) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int sr = 16 * i + lane / 4; sr = sr < last ? sr : last;
-    *reinterpret_cast<double2 *>(base + ((int64_t)sr * N + n) * J + 2 * (lane & 3)) =
-        *reinterpret_cast<const double2 *>(tile + sr * RS1 + 2 * (lane & 3));
+  for (int i = 0; i < PPR; ++i) {   // an instruction moves 64 / PPR series x one row
+    int sr = (kWave / PPR) * i + lane / PPR; sr = sr < last ? sr : last;
+    *reinterpret_cast<double2 *>(base + ((int64_t)sr * N + n) * J + 2 * (lane % PPR)) =
+        *reinterpret_cast<const double2 *>(tile + sr * RS1 + 2 * (lane % PPR));
   }
 }
 
@@ -658,6 +667,16 @@ struct TermsGrads {
   double *bar, *bcr, *bac, *bbc, *bcc, *bdc;
 };
 constexpr int AS1 = 14;   // LDS stride (doubles) of a series in the accumulator tile: 112 B, conflict-free b128
+
+// step(m, phase K) for the rows m = ntop - (RT-1-K), K = RT-1 .. 0, of one tile that exist and are not row 0
+template <int K, class Step>
+__device__ __forceinline__ void for_phases(Step &step, int64_t ntop, int64_t nf) {
+  if constexpr (K >= 0) {
+    const int64_t m = ntop - (RT - 1 - K);
+    if (m <= nf && m >= 1) step(m, std::integral_constant<int, K>{});
+    for_phases<K - 1>(step, ntop, nf);
+  }
+}
 
 template <bool PAIRED, int JC = -1, bool FAST = true, bool FULL = false>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
@@ -706,9 +725,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) zero[j] = 0.0;
-    if constexpr (BVPAIR) {   // c[2k] == c[2k+1]: the four distinct rates
-      *reinterpret_cast<double2 *>(tC + lane * CS4) = make_double2(cj[0], cj[2]);
-      *reinterpret_cast<double2 *>(tC + lane * CS4 + 2) = make_double2(cj[4], cj[6]);
+    if constexpr (BVPAIR) {   // c[2k] == c[2k+1]: the J / 2 distinct rates
+#pragma unroll
+      for (int k = 0; k < PPR; k += 2)
+        *reinterpret_cast<double2 *>(tC + lane * CS4 + k) = make_double2(cj[2 * k], cj[2 * k + 2 < J ? 2 * k + 2 : 2 * k]);
     } else {
       row1_write(tC, lane, cj);
     }
@@ -720,9 +740,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   }
   auto read_rates = [&](double (&cj)[J]) __attribute__((always_inline)) {
     if constexpr (BVPAIR) {
-      const double2 c01 = *reinterpret_cast<const double2 *>(tC + lane * CS4);
-      const double2 c23 = *reinterpret_cast<const double2 *>(tC + lane * CS4 + 2);
-      cj[0] = cj[1] = c01.x; cj[2] = cj[3] = c01.y; cj[4] = cj[5] = c23.x; cj[6] = cj[7] = c23.y;
+#pragma unroll
+      for (int k = 0; k < PPR; k += 2) {
+        const double2 c2k = *reinterpret_cast<const double2 *>(tC + lane * CS4 + k);
+        cj[2 * k] = cj[2 * k + 1] = c2k.x;
+        if (2 * k + 2 < J) cj[2 * k + 2] = cj[2 * k + 3] = c2k.y;
+      }
     } else {
       row1_read(tC, lane, cj);
     }
@@ -818,9 +841,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     // bV, ba, by of the last row are pure seeds: they leave at once (their slots in the tiles belong to lower rows)
     // bV of the last row is a pure seed.  One-row bV tile, or the last row an even one (its pair partner lies beyond the
     // series): it leaves at once; otherwise it waits in row 1 of the pair tile for the first (odd) step
-    const bool bv_seed_waits = BVPAIR && (nf & 1);
+    const int ph0 = (int)(nf % RT);          // row of the last row inside its tile
+    const bool bv_seed_waits = BVPAIR && ph0 != 0;
     if constexpr (!TERMS) {
-      if (bv_seed_waits) row_write(tBV, lane, 1, bVn);
+      if (bv_seed_waits) row_write(tBV, lane, ph0, bVn);
       else row1_write(tBV, lane, bVn);
     }
     tBA[lane * SSTR + (nf & (ST - 1))] = ban;
@@ -833,17 +857,17 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       sc_flush(bab, N, nf, nf, nf, tBA, lane, last);
       sc_flush(byb, N, nf, nf, nf, tBY, lane, last);
     }
-    double su[2 * NI];                    // the pair of U rows (2p, 2p+1) staged by the next odd step n = 2p+1
+    double su[2 * NI];                    // the tile of U rows (RT p .. RT p + RT - 1) staged by the next step n = RT p + RT - 1
     double wa[J];                         // W_{n-1} (requested one step ahead: first used well into the step)
     double2 dza;                          // (d, z)_{n-1}
     double ta;                            // t_{n-1}
     if constexpr (!TERMS) {
-      row_fetch(Ub, N, nf & ~(int64_t)1, io, su);
-      if (!(nf & 1)) {  // the first step is an even one: its pair goes into the tile here
+      row_fetch(Ub, N, nf - ph0, io, su);
+      if (ph0 != RT - 1) {  // the first step is not a staging one: its tile goes into LDS here
         lds_order();
         row_stage(tU, lane, su);
         lds_order();
-        row_fetch(Ub, N, nf - 2, io, su);
+        row_fetch(Ub, N, nf - ph0 - RT, io, su);
       }
     }
     w_fetch(nf - 1, wa);
@@ -855,24 +879,27 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #ifdef C2T_PROF
     unsigned long long prof_[6] = {0, 0, 0, 0, 0, 0}, tick_ = __builtin_readcyclecounter();
 #endif
-    // One step of the sweep.  ODD (matrix-level form): n = 2p+1, the step that puts the pair (2p, 2p+1) into the tile
-    // and requests the pair below it; the even step in between touches no U in memory.  Two instances, each a fixed
-    // instruction sequence (see "Memory choreography" above).
-    auto step = [&](const int64_t n, auto odd_tag) __attribute__((always_inline)) {
-      constexpr bool ODD = decltype(odd_tag)::value;
+    // One step of the sweep, one instance per row PH = n % RT of a tile (matrix-level form; at J = 8: odd / even).  The
+    // instance of the tile's top row puts the tile of U rows into LDS and requests the tile below it; the others touch no
+    // U in memory.  Each instance is a fixed instruction sequence (see "Memory choreography" above).
+    auto step = [&](const int64_t n, auto phase_tag) __attribute__((always_inline)) {
+      constexpr int PH = decltype(phase_tag)::value;   // n % RT (matrix-level form)
+      constexpr bool STAGE = PH == RT - 1;             // the step that puts its tile of U rows into LDS
+      constexpr bool BUOUT = PH == 0;                  // ... whose end sends the tile of bU rows out
+      constexpr bool BVOUT = PH == (1 % RT);           // ... whose end sends the tile of bV rows out (row 0 = bV_{n-1})
       __builtin_amdgcn_sched_barrier(0);   // the two instances are scheduled (and their registers allocated) apart
       C2T_TICK(4);
       // ---- fixed part: U_n into its tile, requests for two steps ahead ------------------------------------------------
       double wb[J];
-      if constexpr (!TERMS && ODD) {
+      if constexpr (!TERMS && STAGE) {
         lds_order();
         row_stage(tU, lane, su);
-        row_fetch(Ub, N, n - 3, io, su);
+        row_fetch(Ub, N, n - 2 * RT + 1, io, su);
       }
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
       const double tb2 = t_fetch(n - 2);
-      if constexpr (!TERMS && ODD) lds_order();
+      if constexpr (!TERMS && STAGE) lds_order();
 
       // ---- the step ---------------------------------------------------------------------------------------------
       const int rs = (int)((n - 1) & (ST - 1));
@@ -884,7 +911,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
         for (int k = 0; k < JC; ++k) gv[k] = fma(bVn[JR + 2 * k + 1], cs[k], -(bVn[JR + 2 * k] * sn[k]));
       } else {
-        row_read(tU, lane, ODD ? 1 : 0, u);
+        row_read(tU, lane, PH, u);
       }
       const double ba_in = ban;
       const double tm = ta;
@@ -946,7 +973,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
         for (int j = 0; j < J; ++j) o[j] = fma(-bzn, F[j], -xs[j]);  // bU_n = -bz_n F_n - x S_n
         if constexpr (TERMS) gsum = accumulate(u, o, sn, cs, gv, ba_in, xn);
-        else row_write(tU, lane, ODD ? 1 : 0, o);  // bU_n takes the place of U_n in the tile
+        else row_write(tU, lane, PH, o);  // bU_n takes the place of U_n in the tile
       }
       double f = 0.0;
       {
@@ -973,23 +1000,24 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tBA[lane * SSTR + rs] = ban;
       tBY[lane * SSTR + rs] = bzn;
       tBT[lane * SSTR + (int)(n & (ST - 1))] = btn;
-      if constexpr (BVPAIR) row_write(tBV, lane, ODD ? 0 : 1, bVn);   // bV_{n-1}
+      if constexpr (BVPAIR) row_write(tBV, lane, (PH + RT - 1) % RT, bVn);   // bV_{n-1}
       else if constexpr (!TERMS) row1_write(tBV, lane, bVn);
       lds_order();
-      // Outputs of width J leave as aligned PAIRS of rows, 128-byte runs out of two-row tiles (64-byte rows cost ~4 % of
-      // the sweep in HBM efficiency): bU (n, n+1) at the end of the even step; with paired rates bV (n-1, n) at the end
-      // of the odd step (unpaired rates keep a one-row bV tile -- their LDS budget is spent on eight rates -- and write
-      // bV_{n-1} every step).  All LDS reads first, then all stores.
+      // Outputs of width J leave as whole TILES (RT rows = one aligned 128-byte line per series; at J = 8 a pair of
+      // rows; single 64-byte rows cost ~4 % of the sweep in HBM efficiency): the tile of bU rows at the end of the step
+      // that fills its row 0; with paired rates the tile of bV rows at the end of the step that produces ITS row 0
+      // (unpaired rates keep a one-row bV tile -- their LDS budget is spent on eight rates -- and write bV_{n-1} every
+      // step).  All LDS reads first, then all stores.
       if constexpr (!TERMS) {
         double fv[16], fu[16];
         if constexpr (!BVPAIR) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
-            const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RS1 + 2 * (lane & 3));
+          for (int i = 0; i < PPR; ++i) {
+            int sr = (kWave / PPR) * i + lane / PPR; sr = (FULL || sr < last) ? sr : last;
+            const double2 v1 = *reinterpret_cast<const double2 *>(tBV + sr * RS1 + 2 * (lane % PPR));
             fv[2 * i] = v1.x; fv[2 * i + 1] = v1.y;
           }
-        } else if constexpr (ODD) {
+        } else if constexpr (BVOUT) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
@@ -997,7 +1025,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
             fv[2 * i] = v1.x; fv[2 * i + 1] = v1.y;
           }
         }
-        if constexpr (!ODD) {
+        if constexpr (BUOUT) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
@@ -1008,19 +1036,22 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!BVPAIR) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            int sr = 16 * i + lane / 4; sr = (FULL || sr < last) ? sr : last;
-            st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 3)), make_double2(fv[2 * i], fv[2 * i + 1]));
+          for (int i = 0; i < PPR; ++i) {
+            int sr = (kWave / PPR) * i + lane / PPR; sr = (FULL || sr < last) ? sr : last;
+            st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane % PPR)), make_double2(fv[2 * i], fv[2 * i + 1]));
           }
-        } else if constexpr (ODD) {
+        } else if constexpr (BVOUT) {
+          // rows n-1 .. n-1+RT-1; at J = 8 (pairs) row n always exists, wider tiles may reach beyond the series at the top
+          if (RT == 2 || n - 1 + (lane & 7) / PPR <= nf) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {   // rows n-1 (even) and n
-            int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
-            st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 7)), make_double2(fv[2 * i], fv[2 * i + 1]));
+            for (int i = 0; i < 8; ++i) {
+              int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
+              st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 7)), make_double2(fv[2 * i], fv[2 * i + 1]));
+            }
           }
         }
-        if constexpr (!ODD) {
-          if (n + ((lane & 7) >> 2) <= nf) {   // the upper row of the top pair may lie beyond the series
+        if constexpr (BUOUT) {
+          if (n + (lane & 7) / PPR <= nf) {   // the upper rows of the top tile may lie beyond the series
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
@@ -1046,11 +1077,18 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       C2T_TICK(3);
     };
     if constexpr (TERMS) {
-      for (int64_t n = nf; n >= 1; --n) step(n, std::false_type{});
+      for (int64_t n = nf; n >= 1; --n) step(n, std::integral_constant<int, 0>{});
     } else {
-      for (int64_t n = nf | 1; n >= 1; n -= 2) {
-        if (n <= nf) step(n, std::true_type{});
-        if (n >= 2) step(n - 1, std::false_type{});
+      // RT step instances, one per row of a tile, top row first; rows beyond either end of the series are skipped
+      if constexpr (RT == 2 && PAIRED) {   // (same thing spelled out: this spelling keeps the paired instance free of
+                                           // scratch, the generic one below the unpaired instance -- register allocation
+                                           // at 512 / 512 registers is that sensitive)
+        for (int64_t n = nf | 1; n >= 1; n -= 2) {
+          if (n <= nf) step(n, std::integral_constant<int, 1>{});
+          if (n >= 2) step(n - 1, std::integral_constant<int, 0>{});
+        }
+      } else {
+        for (int64_t ntop = nf | (RT - 1); ntop >= RT - 1; ntop -= RT) for_phases<RT - 1>(step, ntop, nf);
       }
     }
 #ifdef C2T_PROF
@@ -1077,11 +1115,13 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tBT[lane * SSTR] = carry;
       lds_order();
       if constexpr (!TERMS) {
+        if ((lane & 7) / PPR <= nf) {   // rows 0 .. min(RT - 1, N - 1)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          int sr = 8 * i + lane / 8; sr = sr < last ? sr : last;
-          *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N) * J + 2 * (lane & 7)) =
-              *reinterpret_cast<const double2 *>(tU + sr * RSTR + 2 * (lane & 7));
+          for (int i = 0; i < 8; ++i) {
+            int sr = 8 * i + lane / 8; sr = sr < last ? sr : last;
+            *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N) * J + 2 * (lane & 7)) =
+                *reinterpret_cast<const double2 *>(tU + sr * RSTR + 2 * (lane & 7));
+          }
         }
       }
       sc_flush(btb, N, 0, 0, (ST - 1) < (N - 1) ? (ST - 1) : (N - 1), tBT, lane, last);
@@ -1176,7 +1216,7 @@ using namespace c2t;
 extern "C" {
 
 // Forward-only log-likelihood, one lane per series (J == 8).  Internal: dispatched by c2_loglik for large batches.
-int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+int C2T_NAME(c2_internal_loglik_t)(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                          const double *a, const double *U, const double *V, const double *y, double *ll,
                          int32_t *flag, c2_stream_t stream) {
   const dim3 grid((unsigned)((B + kWave - 1) / kWave));
@@ -1188,12 +1228,12 @@ int c2_internal_loglik_t(int64_t B, int64_t N, const double *t, int64_t t_bs, co
 
 // Records of the fwd/rev pair, in doubles (the caller overlays them with the replay kernels' workspace: only one of
 // the two paths runs).
-size_t c2_internal_loglik_t_record_doubles(int64_t B, int64_t N) { return rec_layout(B, N).total; }
+size_t C2T_NAME(c2_internal_loglik_t_record_doubles)(int64_t B, int64_t N) { return rec_layout(B, N).total; }
 
 // Forward with records + backward-recursion reverse sweep.  `guard` (device, 8 bytes, zeroed by the caller on the same
 // stream) receives max over series and segments of c_max * span; k_loglik_t_rev returns at once when it exceeds
 // kBackwardGuard, and the caller's gated replay kernels then produce the gradients instead.
-int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+int C2T_NAME(c2_internal_loglik_t_grad)(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                               const double *a, const double *U, const double *V, const double *y, double *ll,
                               double *bt, double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag,
                               double *rec, unsigned long long *guard, c2_stream_t stream) {
@@ -1210,7 +1250,7 @@ int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, int64_t t_b
 
 // Coefficient-level forward (J = Jr + 2 Jc == 8): log-likelihood straight from (ar, cr, ac, bc, cc, dc, x, diag, y),
 // no U / V / c arrays in memory.
-int c2_internal_loglik_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+int C2T_NAME(c2_internal_loglik_tt)(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
                           const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
                           int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag,
                           c2_stream_t stream) {
@@ -1223,9 +1263,13 @@ int c2_internal_loglik_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, co
   switch (Jc) {
     case 0: C2_TT(0); break;
     case 1: C2_TT(1); break;
+#if C2T_J >= 4
     case 2: C2_TT(2); break;
+#endif
+#if C2T_J >= 8
     case 3: C2_TT(3); break;
     case 4: C2_TT(4); break;
+#endif
     default: return C2_ERR_UNSUPPORTED;
   }
 #undef C2_TT
@@ -1233,7 +1277,7 @@ int c2_internal_loglik_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, co
 }
 
 // Coefficient-level forward with records + reverse sweep (see c2_internal_loglik_t_grad for `guard`).
-int c2_internal_loglik_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+int C2T_NAME(c2_internal_loglik_tt_grad)(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
                                const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
                                int64_t x_bs, const double *diag, const double *y, double *ll, double *bar, double *bcr,
                                double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
@@ -1254,9 +1298,13 @@ int c2_internal_loglik_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batche
   switch (Jc) {
     case 0: C2_TT(0); break;
     case 1: C2_TT(1); break;
+#if C2T_J >= 4
     case 2: C2_TT(2); break;
+#endif
+#if C2T_J >= 8
     case 3: C2_TT(3); break;
     case 4: C2_TT(4); break;
+#endif
     default: return C2_ERR_UNSUPPORTED;
   }
 #undef C2_TT

@@ -166,18 +166,24 @@ inline int check(int64_t B, int64_t N, int64_t Jr, int64_t Jc) {
 using namespace c2terms;
 
 // One-lane-per-series kernels that generate U_n / V_n from the coefficients in the lane (c2_loglik_t.hip): no matrices in
-// memory.  J == 8 only.  C2_TERMS_FUSED=1 forces them, =0 disables them; otherwise batches that fill the chip.
+// memory.  Widths 8, 4, 2.  C2_TERMS_FUSED=1 forces them, =0 disables them; otherwise batches that fill the chip.
 extern "C" {
-int c2_internal_loglik_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
-                          const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
-                          int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag,
-                          c2_stream_t stream);
-int c2_internal_loglik_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
-                               const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
-                               int64_t x_bs, const double *diag, const double *y, double *ll, double *bar, double *bcr,
-                               double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
-                               int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
-size_t c2_internal_loglik_t_record_doubles(int64_t B, int64_t N);
+#define C2_DECL_TT(J_)                                                                                                 \
+  int c2_internal_loglik_tt##J_(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr, \
+                                const double *ac, const double *bc, const double *cc, const double *dc,               \
+                                const double *x, int64_t x_bs, const double *diag, const double *y, double *ll,       \
+                                int32_t *flag, c2_stream_t stream);                                                   \
+  int c2_internal_loglik_tt_grad##J_(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar,            \
+                                     const double *cr, const double *ac, const double *bc, const double *cc,          \
+                                     const double *dc, const double *x, int64_t x_bs, const double *diag,             \
+                                     const double *y, double *ll, double *bar, double *bcr, double *bac, double *bbc, \
+                                     double *bcc, double *bdc, double *bx, double *bdiag, double *by, int32_t *flag,  \
+                                     double *rec, unsigned long long *guard, c2_stream_t stream);                     \
+  size_t c2_internal_loglik_t_record_doubles##J_(int64_t B, int64_t N);
+C2_DECL_TT(8)
+C2_DECL_TT(4)
+C2_DECL_TT(2)
+#undef C2_DECL_TT
 int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
                          const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
                          const double *diag, double *a, double *U, double *V, const unsigned long long *gate,
@@ -193,8 +199,13 @@ int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double
 #ifndef C2_TERMS_FUSED_MIN_BATCH_GRAD
 #define C2_TERMS_FUSED_MIN_BATCH_GRAD 16384
 #endif
+static bool fused_width(int64_t J) { return J == 8 || J == 4 || J == 2; }
+static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
+  return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
+                : (J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N));
+}
 static bool use_fused(int64_t B, int64_t J, bool grad) {
-  if (J != 8) return false;
+  if (!fused_width(J)) return false;
   const char *e = getenv("C2_TERMS_FUSED");
   if (e) return atoi(e) != 0;
   return B >= (grad ? C2_TERMS_FUSED_MIN_BATCH_GRAD : C2_TERMS_FUSED_MIN_BATCH_FWD);
@@ -220,8 +231,8 @@ size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t
   if (check(B, N, Jr, Jc)) return 0;
   const int64_t J = Jr + 2 * Jc;
   size_t n = plan(B, N, J, grad).total;
-  if (grad && J == 8) {
-    const size_t r = c2_internal_loglik_t_record_doubles(B, N);
+  if (grad && fused_width(J)) {
+    const size_t r = fused_record_doubles(B, N, J);
     n = 2 + (r > n ? r : n);
   }
   return n * sizeof(double);
@@ -237,7 +248,8 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
   const int64_t J = Jr + 2 * Jc;
   if (work_bytes < c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 0)) return C2_ERR_INVALID;
   if (use_fused(B, J, false))
-    return c2_internal_loglik_tt(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
+    return (J == 8 ? c2_internal_loglik_tt8 : (J == 4 ? c2_internal_loglik_tt4 : c2_internal_loglik_tt2))(
+        B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
   const Plan p = plan(B, N, J, 0);
   double *w = (double *)work;
   hipStream_t s = (hipStream_t)stream;
@@ -267,8 +279,9 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
     unsigned long long *guard = (unsigned long long *)work;
     if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
     w += 2;
-    if (int e = c2_internal_loglik_tt_grad(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, bar, bcr,
-                                           bac, bbc, bcc, bdc, bx, bdiag, by, flag, w, guard, stream))
+    auto fused = J == 8 ? c2_internal_loglik_tt_grad8 : (J == 4 ? c2_internal_loglik_tt_grad4 : c2_internal_loglik_tt_grad2);
+    if (int e = fused(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, bar, bcr, bac, bbc, bcc, bdc,
+                      bx, bdiag, by, flag, w, guard, stream))
       return e;
     gate = guard;
   }

@@ -132,15 +132,16 @@ def test_fuzz_general_matmul(ops, oracle, seed):
         close(getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd2), Zo)
 
 
-@pytest.mark.parametrize("seed", list(range(16)))
+@pytest.mark.parametrize("seed", list(range(40)))
 def test_fuzz_one_lane_kernels(ops, oracle, monkeypatch, seed):
-    """The one-lane-per-series kernels (width 8; c2_loglik_t.hip) forced on random shapes: ragged wavefronts, series
-    lengths around the pair (2), scalar-tile (8) and checkpoint (32) periods, paired / unpaired rates, shared grids,
+    """The one-lane-per-series kernels (widths 8, 4, 2; c2_loglik_t.hip) forced on random shapes: ragged wavefronts,
+    series lengths around the row-tile (2 / 4 / 8), scalar-tile (8) and checkpoint (32) periods, paired / unpaired rates, shared grids,
     an occasional failed series, and gaps that trip the stability gate (the gated replay kernels then answer)."""
     rng = np.random.default_rng(9000 + seed)
     B = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 190]))
-    N = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 34, 63, 64, 65, 66, 97, 130, 257]))
-    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), 8)
+    N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 66, 97, 130, 257]))
+    J = int(rng.choice([8, 8, 4, 4, 2]))      # the widths compiled for this mapping
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
     t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
     a = a + 0.5
     if rng.random() < 0.4:
@@ -170,11 +171,12 @@ def test_fuzz_one_lane_kernels(ops, oracle, monkeypatch, seed):
             assert bool(np.isnan(g.cpu().numpy()[~ok]).all())
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(30)))
 def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
     """Coefficient-level kernels (rows formed in the lane) against the composed chain on random term mixes and shapes."""
     rng = np.random.default_rng(9500 + seed)
-    Jc = int(rng.integers(0, 5)); Jr = 8 - 2 * Jc
+    J = int(rng.choice([8, 8, 4, 2]))
+    Jc = int(rng.integers(0, J // 2 + 1)); Jr = J - 2 * Jc
     B = int(rng.choice([1, 3, 64, 65, 130])); N = int(rng.choice([1, 2, 3, 9, 31, 32, 33, 65, 120]))
     ar = rng.uniform(0.5, 1.5, (B, Jr)); cr = rng.uniform(0.05, 0.5, (B, Jr))
     ac = rng.uniform(0.5, 2.0, (B, Jc)); cc = rng.uniform(0.02, 0.3, (B, Jc)); dc = rng.uniform(0.2, 3.0, (B, Jc))
@@ -193,5 +195,5 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
     for k, (gf, gc) in enumerate(zip(g_f, g_c)):
         if gc.numel():
             # two device paths with different summation orders; bdc / bx carry the factor max|x| (see test_gpu_terms.py)
-            floor = 1e-11 if k not in (5,) else max(1e-11, 1e-15 * N * xmax)
+            floor = 1e-11 if k not in (5,) else max(1e-11, 1e-14 * max(N, 4) * xmax)
             close(gf, gc.cpu().numpy(), tol=1e-9, floor=floor)

@@ -184,14 +184,14 @@ def test_two_columns_per_lane_variant(ops, oracle, monkeypatch, B, N):
             assert int(flag4[b]) == f
 
 
+@pytest.mark.parametrize("J", [8, 4, 2])
 @pytest.mark.parametrize("B,N", [(1, 1), (3, 2), (5, 3), (64, 16), (65, 17), (70, 33), (130, 100), (7, 1031), (200, 257)])
-def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N):
-    """J = 8 has a third lane mapping for chip-filling batches (c2_loglik_t.hip: one lane per series, rows through LDS
+def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N, J):
+    """Widths 8, 4, 2 have a third lane mapping for chip-filling batches (c2_loglik_t.hip: one lane per series, rows through LDS
     transposes, reverse sweep by the backward recursion between checkpoints every 32 rows): same results as the oracle
     on ragged wavefronts, around the tile (8 rows) and checkpoint (32 rows) edges, with unpaired rates, with a failed
     series, with shared t / c -- and the stability guard hands a batch with long gaps to the replay kernels."""
     monkeypatch.setenv("C2_LANES", "1")
-    J = 8
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
     td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
     llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
@@ -203,7 +203,7 @@ def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N):
     for g, e in zip(grads, go):
         close(g, e)
     # rates that are not pairwise equal take the general exponential path
-    c2 = c.copy(); c2[:, 1] *= 1.01; c2[:, 6] *= 0.97
+    c2 = c.copy(); c2[:, 1] *= 1.01; c2[:, J - 2] *= 0.97
     (c2d,) = dev(c2)
     llo2, go2, _ = oracle.loglik_grad_batched(t, c2, a, U, V, y, nthreads=2)
     ll3, grads3, _ = ops.loglik_grad(td, c2d, ad, Ud, Vd, yd)

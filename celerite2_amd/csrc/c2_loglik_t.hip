@@ -1,5 +1,5 @@
 // c2_loglik_t.hip -- fused log-likelihood (+ reverse-mode gradient) with ONE LANE PER SERIES, for batches large
-// enough to fill the chip that way (>= 32768 series: 512+ wavefronts).  J == 8.
+// enough to fill the chip that way (>= 24576 series).  Widths J = 8, 4, 2 (one compilation each: C2T_J).
 //
 // Why a second mapping.  The group-of-8-lanes kernels (c2_loglik.hip) spend more than half of their issued VALU work
 // on moving width-J vectors between the lanes of a group (DPP gathers, butterflies, scalars replicated 8x): ~300

@@ -197,7 +197,7 @@ int c2_kron_loglik_grad(int64_t B, int64_t N, int64_t M, int64_t J, const double
  * (B,Jc), all per series (coef_batched = 1) or all shared by the batch (0); x (B,N) / shared (N,) via x_bs;
  * diag, y (B,N).  J = Jr + 2 Jc <= C2_MAX_WIDTH.  Gradients (per series, also for shared coefficients):
  * bar, bcr (B,Jr); bac, bbc, bcc, bdc (B,Jc); bx, bdiag, by (B,N).  A failed series: ll = -inf, NaN gradients.
- * Width J = 8 and chip-filling batches run kernels that form U_n, V_n inside the recursion (no matrices in memory);
+ * Widths J = 8, 4, 2 and chip-filling batches run kernels that form U_n, V_n inside the recursion (no matrices in memory);
  * everything else the composed chain on matrices kept in `work` (same results).  `work` is
  * sized for either. */
 size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t Jc, int grad);

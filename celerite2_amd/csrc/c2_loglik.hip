@@ -849,6 +849,29 @@ static size_t lanes1_record_doubles(int64_t B, int64_t N, int64_t J) {
   return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
                 : (J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N));
 }
+// Time-parallel forward pass (c2_timepar.hip; widths 4 and 2): batches too small to fill the chip row by row -- below the
+// one-lane threshold -- of series long enough to cut into chunks.  C2_TIMEPAR=1 forces it, =0 disables it.
+extern "C" size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                          int64_t c_bs, const double *a, const double *U, const double *V,
+                                          const double *y, double *ll, int32_t *flag, double *work,
+                                          unsigned long long *guard, c2_stream_t stream);
+// Measured at N = 4096 (tools/timepar_check.py): 0.34 ms per 1024 series at J = 4 (row by row: 0.87 ms up to ~4096
+// series), 0.17 ms at J = 2; linear in the batch beyond one wavefront per SIMD, so it pays up to ~2048 / ~4096 series.
+#ifndef C2_TIMEPAR_MIN_ROWS
+#define C2_TIMEPAR_MIN_ROWS 1536
+#endif
+#ifndef C2_TIMEPAR_MAX_BATCH_X_WIDTH
+#define C2_TIMEPAR_MAX_BATCH_X_WIDTH 8192
+#endif
+static bool use_timepar(int64_t B, int64_t N, int64_t J) {
+  if (J != 4 && J != 2) return false;
+  const char *e = getenv("C2_TIMEPAR");
+  if (e) return atoi(e) != 0 && N >= 2;
+  const char *l = getenv("C2_LANES");
+  if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
+  return N >= C2_TIMEPAR_MIN_ROWS && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
+}
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 4 && J != 2) return false;
   const char *e = getenv("C2_LANES");
@@ -878,8 +901,24 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
     return c2_internal_loglik_t2(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   }
   if (use_lanes4(B, J, false)) return c2_internal_loglik4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
-  return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr,
-                           (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  if (use_timepar(B, N, J)) {
+    // Small batch of long series: parallel along time (c2_timepar.hip), verified on the device; the ordinary kernel
+    // below runs behind the verification word and does nothing unless it failed.  Scratch is a stream-ordered
+    // temporary; without it (allocation refused) the ordinary kernel runs alone.
+    const size_t nd = c2_internal_timepar_doubles(B, N, J);
+    void *tmp = nullptr;
+    if (nd > 0 && hipMallocAsync(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {
+      unsigned long long *guard = (unsigned long long *)tmp;
+      int rc = c2_internal_loglik_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp + 2, guard, stream);
+      if (rc == C2_OK)
+        rc = launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, s, guard);
+      if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+      return rc;
+    }
+    (void)hipGetLastError();
+  }
+  return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, s);
 }
 
 // Checkpoint interval per group size (must match launch_fwd / launch_rev below).

@@ -1,0 +1,580 @@
+// c2_timepar.hip -- TIME-PARALLEL forward log-likelihood for SMALL batches of long series (widths J = 2, 4).
+//
+// The group kernels of c2_loglik.hip walk a series row by row: with a few hundred series the chip idles (BASELINE
+// configs[1]: 1024 series x 4 lanes = 64 wavefronts on 1024 SIMDs, 212 ns per dependent step).  The recursions admit
+// parallelism along TIME:
+//  * `factor` (forward.hpp:105-134).  With T = S_n (the post-decay state row n sees), u = U_n, v = V_n, a = a_n,
+//        T' = P (T + g^T g / delta) P,   g = v - u T,  delta = a - u T u^T          (forward.hpp:115-131, one row on)
+//    is a LINEAR-FRACTIONAL map of T:  T' = (A T + B)(C T + D)^-1  with
+//        [[A, B], [C, D]] = diag(P, P^-1) (kappa I + x y^T),   x = [v; u],  y = [-u; v],  kappa = a - u.v
+//    (kappa is the white-noise diagonal; x y^T has y.x = 0: a shear).  Maps of consecutive rows compose by 2J x 2J
+//    products -- here a rank-one update, 8 J^2 flops a row -- so every CHUNK of kRows rows yields its composite map
+//    independently of the others (k_tp_maps), the chunk-start states follow by applying K - 1 maps one after the other
+//    (k_tp_starts: one lane per series, (2J)^2 J flops + a J x J solve per chunk), and every chunk then runs the
+//    ordinary recursion from its own start state, all chunks at once (k_tp_chunks).
+//  * `solve_lower` (internal.hpp:135-145) is AFFINE in the state F once (d, W) are known:
+//        F' = P ((I - w u) F + w y)   =>   F_n = G_n F_start + g_n,   z_n = (y_n - u_n.g_n) - (u_n G_n).F_start
+//    so a chunk accumulates  sum z^2 / d = q0 - 2 q1.F_start + F_start^T Q2 F_start  next to sum log d without knowing
+//    F_start, and one lane per series chains the chunks at the end (k_tp_finish).
+// Composite maps of long chunks are ill-conditioned (the recursion forgets its start; 1e-12 at 32 rows, 1e-7 at 128 on
+// the bench data), so the result is VERIFIED: a chunk's sequentially computed end state must match the next chunk's
+// start state; k_tp_finish writes the worst relative mismatch / 1e-10 into a device word and the ordinary kernel --
+// launched behind it with that word as its gate (gate_closed, c2_loglik_helpers.hpp) -- recomputes the batch if it
+// exceeds kBackwardGuard (= 2) or if any factorisation failed.  numpy prototype: tools/proto/timepar.py.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "c2_loglik_helpers.hpp"
+#include "../../include/celerite2_amd.h"
+
+namespace c2tp {
+using namespace c2;
+
+constexpr int kRows = 64;        // rows per chunk
+constexpr int kThreads = 64;
+constexpr double kTol = 1e-10;   // chunk-start mismatch that counts as 1 on the guard word (fallback beyond 2)
+
+__host__ __device__ constexpr int nsym(int J) { return J * (J + 1) / 2; }
+__host__ __device__ constexpr int sidx(int J, int i, int j) { return i * J - i * (i - 1) / 2 + (j - i); }  // i <= j
+
+// doubles per chunk of every array (all arrays are [entry][series * K + chunk]: a wavefront's accesses are contiguous)
+template <int J>
+struct Layout {
+  static constexpr int MAP = 4 * J * J;                 // composite map
+  static constexpr int START = nsym(J);                 // chunk-start state, packed
+  // chunk results: S_end (packed), G (J x J), g (J), logdet, q0, q1 (J), Q2 (packed), first failed row (as a double)
+  static constexpr int OUT = nsym(J) + J * J + J + 2 + J + nsym(J) + 1;
+};
+
+
+// ---- data movement.  A wavefront owns 64 consecutive chunks (lane <-> chunk).  A lane streaming its own chunk would touch
+// 64 different lines per load instruction and the lines it reuses over the next rows do not survive in L1 / L2 (measured:
+// 10 x the bytes, 0.86 ms at configs[1]).  So rows move as in c2_loglik_t.hip: one instruction loads 8 chunks x 128 bytes
+// (lane l: chunk 8 i + l / 8, 16-byte piece l % 8), the pieces go through an LDS tile with a conflict-free stride, and a
+// lane reads its own chunk's rows from there.  Row tiles hold 16 / J rows (one 128-byte line per chunk), scalar tiles 8 rows.
+template <int J>
+struct Geo {
+  static constexpr int RT = 16 / J;        // rows per row tile
+  static constexpr int PPR = J / 2;        // 16-byte pieces per row
+  static constexpr int RSTR = 18;          // LDS stride (doubles) of a chunk in a row tile: 144 B
+  static constexpr int SSTR = 9;           // ... in a scalar tile: 72 B
+};
+// A wavefront owns chunks k0 .. k0+63 of ONE series (grid: x over groups of 64 chunks, y over series), so the chunk a lane
+// helps to load in instruction i -- chunk k0 + 8 i + lane / 8 -- is an affine function of the lane: nothing to keep.
+struct Chunks {
+  int64_t sbase, tbase;   // first row of the series in the (B, N) arrays / in the time grid (0 when shared)
+  int64_t N, K, k0;
+  __device__ __forceinline__ int64_t chunk(int i, int lane) const {
+    const int64_t k = k0 + 8 * i + lane / 8;
+    return k < K ? k : K - 1;
+  }
+  __device__ __forceinline__ int len(int64_t k) const {
+    const int64_t s = k * kRows;
+    return (int)((s + kRows < N ? s + kRows : N) - s);
+  }
+};
+// rows r0 .. r0+RT-1 (local, clamped into the chunk) of the 64 chunks: global -> registers (a tile ahead), registers -> LDS
+template <int J>
+__device__ __forceinline__ void fetch_row_tile(const double *__restrict__ base, const Chunks &c, int r0, int lane, double (&v)[16]) {
+  using Gm = Geo<J>;
+  const int q = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t k = c.chunk(i, lane);
+    const int ln = c.len(k);
+    int r = r0 + q / Gm::PPR;
+    r = r < ln ? r : ln - 1;
+    const double2 w = *reinterpret_cast<const double2 *>(base + (c.sbase + k * kRows + r) * J + 2 * (q % Gm::PPR));
+    v[2 * i] = w.x; v[2 * i + 1] = w.y;
+  }
+}
+template <int J>
+__device__ __forceinline__ void stage_row_tile(double *tile, int lane, const double (&v)[16]) {
+  const int q = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    *reinterpret_cast<double2 *>(tile + (8 * i + lane / 8) * Geo<J>::RSTR + 2 * q) = make_double2(v[2 * i], v[2 * i + 1]);
+}
+// rows r0+shift .. r0+shift+7 of a per-row scalar (clamped to the series), shift = 1 for "the next row's t"
+template <bool TIME>
+__device__ __forceinline__ void fetch_scalar_tile(const double *__restrict__ base, const Chunks &c, int r0, int shift, int lane,
+                                                  double (&v)[8]) {
+  const int q = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int64_t r = c.chunk(i, lane) * kRows + r0 + q + shift;
+    r = r < c.N - 1 ? r : c.N - 1;
+    v[i] = base[(TIME ? c.tbase : c.sbase) + r];
+  }
+}
+__device__ __forceinline__ void stage_scalar_tile(double *tile, int lane, const double (&v)[8]) {
+  const int q = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) tile[(8 * i + lane / 8) * 9 + q] = v[i];
+}
+
+// ---- phase 1: composite linear-fractional map of rows s .. e-1 (towards row e) of chunk k < K - 1 ----------------------
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                      int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                      const double *__restrict__ a, const double *__restrict__ U,
+                                                      const double *__restrict__ V, double *__restrict__ maps,
+                                                      unsigned long long *__restrict__ guard) {
+  using Gm = Geo<J>;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *guard = 0ull;   // k_tp_finish (later in the stream) maxes into it
+  __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 2 * 64 * Gm::SSTR];
+  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, G = B * K;
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = ch.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  const int64_t g = b * K + k;
+  const bool act = inr && k < K - 1;   // nobody starts from the end of the last chunk; the others are full (kRows rows)
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+  double R[2 * J][2 * J];
+#pragma unroll
+  for (int i = 0; i < 2 * J; ++i)
+#pragma unroll
+    for (int j = 0; j < 2 * J; ++j) R[i][j] = i == j ? 1.0 : 0.0;
+  double tn = t[b * t_bs + k * kRows];
+  // tiles are requested one tile ahead into registers (the compiler parks them in AGPRs: R alone takes half the VGPRs)
+  double vu[16], vv[16], va[8], vt[8];
+  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  fetch_row_tile<J>(U, ch, 0, lane, vu);
+  fetch_row_tile<J>(V, ch, 0, lane, vv);
+  for (int r0 = 0; r0 < kRows; r0 += 8) {
+    lds_order();
+    stage_scalar_tile(tA, lane, va);
+    stage_scalar_tile(tT, lane, vt);
+    if (r0 + 8 < kRows) {
+      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < 8; rt += Gm::RT) {
+      lds_order();
+      stage_row_tile<J>(tU, lane, vu);
+      stage_row_tile<J>(tV, lane, vv);
+      if (r0 + rt + Gm::RT < kRows) {
+        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
+        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
+      }
+      lds_order();
+#pragma unroll
+      for (int r = 0; r < Gm::RT; ++r) {
+        double x[2 * J], y[2 * J];
+        double kap = tA[lane * Gm::SSTR + rt + r];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const double u = tU[lane * Gm::RSTR + r * J + j], v = tV[lane * Gm::RSTR + r * J + j];
+          kap = fma(-u, v, kap);
+          x[j] = v; x[J + j] = u; y[j] = -u; y[J + j] = v;
+        }
+        const double rk = 1.0 / kap;   // kappa <= 0 (no white noise): inf / nan end up in the map -> mismatch -> fallback
+        double yR[2 * J];
+#pragma unroll
+        for (int j = 0; j < 2 * J; ++j) {
+          double s_ = 0.0;
+#pragma unroll
+          for (int i = 0; i < 2 * J; ++i) s_ = fma(y[i], R[i][j], s_);
+          yR[j] = s_ * rk;
+        }
+        const double tn1 = tT[lane * Gm::SSTR + rt + r];
+        double p[J], ip[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { p[j] = exp_decay(cj[j] * (tn - tn1)); ip[j] = rcp_nr(p[j]); }
+        tn = tn1;
+#pragma unroll
+        for (int i = 0; i < 2 * J; ++i) {
+          const double sc = i < J ? p[i] : ip[i - J];
+#pragma unroll
+          for (int j = 0; j < 2 * J; ++j) R[i][j] = sc * fma(x[i], yR[j], R[i][j]);
+        }
+      }
+    }
+  }
+  if (act) {
+#pragma unroll
+    for (int i = 0; i < 2 * J; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * J; ++j) maps[(int64_t)(i * 2 * J + j) * G + g] = R[i][j];
+  }
+}
+
+// S' = X Y^-1 for J x J blocks by Gauss-Jordan with partial pivoting on Y^T (rows of the augmented [Y^T | X^T]), fully
+// unrolled.
+template <int J>
+__device__ __forceinline__ void right_divide(double (&X)[J][J], double (&Y)[J][J], double (&out)[J][J]) {
+  // solve Y^T Z = X^T, out = Z^T
+  double A[J][2 * J];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) { A[i][j] = Y[j][i]; A[i][J + j] = X[j][i]; }
+#pragma unroll
+  for (int col = 0; col < J; ++col) {
+    // partial pivoting, swaps by selects (columns left of `col` are already unit columns: nothing to swap there).  It is
+    // needed: without it the chunk-start states of the bench data fail the verification (measured) -- 40 % of this loop.
+#pragma unroll
+    for (int r = col + 1; r < J; ++r) {
+      const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
+#pragma unroll
+      for (int j = col; j < 2 * J; ++j) {
+        const double hi = sw ? A[r][j] : A[col][j], lo = sw ? A[col][j] : A[r][j];
+        A[col][j] = hi; A[r][j] = lo;
+      }
+    }
+    const double rp = rcp_nr(A[col][col]);
+#pragma unroll
+    for (int j = col + 1; j < 2 * J; ++j) A[col][j] *= rp;
+#pragma unroll
+    for (int r = 0; r < J; ++r) {
+      if (r == col) continue;
+      const double f = A[r][col];
+#pragma unroll
+      for (int j = col + 1; j < 2 * J; ++j) A[r][j] = fma(-f, A[col][j], A[r][j]);   // (columns <= col: known 0 / 1)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) out[j][i] = A[i][J + j];
+}
+
+// ---- phase 2: chunk-start states.  One WAVEFRONT per series, lane <-> chunk: a lane keeps its chunk's map in registers
+// (coalesced load), every lane applies its own map to the current state at every step, and the result of the lane whose
+// turn it is becomes the state of the next step (20 lane broadcasts): the loop carries no memory access.
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_starts(int64_t B, int64_t K, const double *__restrict__ maps,
+                                                        double *__restrict__ starts) {
+  constexpr int NS = nsym(J);
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x, G = B * K;
+  double S[J][J];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) S[i][j] = 0.0;
+  if (lane < NS) starts[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing (forward.hpp:107-113)
+  for (int64_t base = 0; base < K - 1; base += kThreads) {
+    const int64_t kk = base + lane;
+    const bool have = kk < K - 1;
+    const int64_t g = b * K + (have ? kk : 0);
+    double M[2 * J][2 * J];
+#pragma unroll
+    for (int i = 0; i < 2 * J; ++i)
+#pragma unroll
+      for (int j = 0; j < 2 * J; ++j) M[i][j] = maps[(int64_t)(i * 2 * J + j) * G + g];
+    double mine[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) mine[q] = 0.0;
+    const int steps = (int)((K - 1 - base) < kThreads ? (K - 1 - base) : kThreads);
+    for (int turn = 0; turn < steps; ++turn) {
+      double X[J][J], Y[J][J];
+      // [X; Y] = M [S; I]
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          double xs = M[i][J + j], ys = M[J + i][J + j];
+#pragma unroll
+          for (int l = 0; l < J; ++l) {
+            xs = fma(M[i][l], S[l][j], xs);
+            ys = fma(M[J + i][l], S[l][j], ys);
+          }
+          X[i][j] = xs; Y[i][j] = ys;
+        }
+      double Sn[J][J];
+      right_divide<J>(X, Y, Sn);
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = i; j < J; ++j) {
+          const double v = __shfl(0.5 * (Sn[i][j] + Sn[j][i]), turn, 64);   // the lane whose chunk this is
+          S[i][j] = v; S[j][i] = v;
+          mine[sidx(J, i, j)] = lane == turn ? v : mine[sidx(J, i, j)];
+        }
+    }
+    if (have) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + g + 1] = mine[q];
+    }
+  }
+}
+
+// ---- phase 3: every chunk runs the recursion from its start state ----------------------------------------------------
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                        const double *__restrict__ a, const double *__restrict__ U,
+                                                        const double *__restrict__ V, const double *__restrict__ yv,
+                                                        const double *__restrict__ starts, double *__restrict__ outs) {
+  using Gm = Geo<J>;
+  constexpr int NS = nsym(J);
+  __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 3 * 64 * Gm::SSTR];
+  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR, *tY = tT + 64 * Gm::SSTR;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, G = B * K;
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = ch.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  const int64_t g = b * K + k;
+  const int64_t s = k * kRows;
+  const int len = ch.len(k);
+  double cj[J], S[NS], Gmx[J][J], gv[J], q1[J], Q2[NS];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; gv[j] = 0.0; q1[j] = 0.0; }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { S[q] = starts[(int64_t)q * G + g]; Q2[q] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) Gmx[i][j] = i == j ? 1.0 : 0.0;
+  double prod = 1.0, q0 = 0.0, failed = 0.0;
+  int eacc = 0;
+  double tn = t[b * t_bs + s];
+  double vu[16], vv[16], va[8], vy[8], vt[8];   // tiles requested one tile ahead
+  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_tile<false>(yv, ch, 0, 0, lane, vy);
+  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  fetch_row_tile<J>(U, ch, 0, lane, vu);
+  fetch_row_tile<J>(V, ch, 0, lane, vv);
+  for (int r0 = 0; r0 < kRows; r0 += 8) {
+    lds_order();
+    stage_scalar_tile(tA, lane, va);
+    stage_scalar_tile(tY, lane, vy);
+    stage_scalar_tile(tT, lane, vt);
+    if (r0 + 8 < kRows) {
+      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_tile<false>(yv, ch, r0 + 8, 0, lane, vy);
+      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < 8; rt += Gm::RT) {
+      lds_order();
+      stage_row_tile<J>(tU, lane, vu);
+      stage_row_tile<J>(tV, lane, vv);
+      if (r0 + rt + Gm::RT < kRows) {
+        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
+        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
+      }
+      lds_order();
+#pragma unroll
+      for (int r = 0; r < Gm::RT; ++r) {
+        const int i0 = r0 + rt + r;          // row of the chunk
+        const int64_t n = s + i0;
+        if (i0 < len) {
+          double u[J], v[J], tau[J], rr[J], w[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            u[j] = tU[lane * Gm::RSTR + r * J + j]; v[j] = tV[lane * Gm::RSTR + r * J + j];
+            tau[j] = 0.0; rr[j] = 0.0;
+          }
+          // tau = u S (forward.hpp:126), rr = u G, z0 = y - u.g
+#pragma unroll
+          for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = i; j < J; ++j) {
+              const double sv = S[sidx(J, i, j)];
+              tau[j] = fma(u[i], sv, tau[j]);
+              if (j != i) tau[i] = fma(u[j], sv, tau[i]);
+            }
+          double d = tA[lane * Gm::SSTR + rt + r], z0 = tY[lane * Gm::SSTR + rt + r];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            d = fma(-tau[j], u[j], d);          // forward.hpp:127
+            z0 = fma(-u[j], gv[j], z0);
+#pragma unroll
+            for (int i = 0; i < J; ++i) rr[j] = fma(u[i], Gmx[i][j], rr[j]);
+          }
+          const double rd = rcp_nr(d);
+          failed = (failed == 0.0 && n > 0 && !(d > 0.0)) ? (double)n : failed;   // forward.hpp:128 (first row)
+#pragma unroll
+          for (int j = 0; j < J; ++j) w[j] = (v[j] - tau[j]) * rd;   // forward.hpp:131
+          prod *= d;
+          if (i0 & 1) { int ex; prod = frexp(prod, &ex); eacc += ex; }
+          const double z0d = z0 * rd;
+          q0 = fma(z0, z0d, q0);
+#pragma unroll
+          for (int i = 0; i < J; ++i) {
+            q1[i] = fma(z0d, rr[i], q1[i]);
+            const double rid = rr[i] * rd;
+#pragma unroll
+            for (int j = i; j < J; ++j) Q2[sidx(J, i, j)] = fma(rid, rr[j], Q2[sidx(J, i, j)]);
+          }
+          if (n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123, internal.hpp:140-143)
+            const double tn1 = tT[lane * Gm::SSTR + rt + r];
+            double p[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) p[j] = exp_decay(cj[j] * (tn - tn1));
+            tn = tn1;
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+              const double dwi = d * w[i];
+#pragma unroll
+              for (int j = i; j < J; ++j) S[sidx(J, i, j)] = (p[i] * p[j]) * fma(dwi, w[j], S[sidx(J, i, j)]);
+#pragma unroll
+              for (int j = 0; j < J; ++j) Gmx[i][j] = p[i] * fma(-w[i], rr[j], Gmx[i][j]);
+              gv[i] = p[i] * fma(w[i], z0, gv[i]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!inr) return;
+  int ex;
+  prod = frexp(prod, &ex);
+  const double logdet = log(prod) + (double)(eacc + ex) * 0.693147180559945309417;
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) outs[(int64_t)(q++) * G + g] = S[i];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) outs[(int64_t)(q++) * G + g] = Gmx[i][j];
+#pragma unroll
+  for (int i = 0; i < J; ++i) outs[(int64_t)(q++) * G + g] = gv[i];
+  outs[(int64_t)(q++) * G + g] = logdet;
+  outs[(int64_t)(q++) * G + g] = q0;
+#pragma unroll
+  for (int i = 0; i < J; ++i) outs[(int64_t)(q++) * G + g] = q1[i];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) outs[(int64_t)(q++) * G + g] = Q2[i];
+  outs[(int64_t)(q++) * G + g] = failed;
+}
+
+// ---- phase 4: chain the chunks of a series, verify the chunk-start states.  One wavefront per series, lane <-> chunk:
+// the chunk results are loaded coalesced, the verification is lane-parallel, the chain of F broadcasts J values a step.
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_finish(int64_t B, int64_t N, int64_t K, const double *__restrict__ starts,
+                                                        const double *__restrict__ outs, double *__restrict__ ll,
+                                                        int32_t *__restrict__ flag,
+                                                        unsigned long long *__restrict__ guard) {
+  constexpr int NS = nsym(J);
+  constexpr int oG = NS, og = NS + J * J, ol = og + J, oq1 = ol + 2, oQ2 = oq1 + J, of = oQ2 + NS;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x, G = B * K;
+  double F[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) F[j] = 0.0;
+  double worst = 0.0, logdet = 0.0, quad = 0.0, first = INFINITY;
+  for (int64_t base = 0; base < K; base += kThreads) {
+    const int64_t kk = base + lane;
+    const bool have = kk < K;
+    const int64_t g = b * K + (have ? kk : 0);
+    double Gm[J][J], gv[J], q1[J], Q2[NS];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      gv[i] = outs[(int64_t)(og + i) * G + g];
+      q1[i] = outs[(int64_t)(oq1 + i) * G + g];
+#pragma unroll
+      for (int j = 0; j < J; ++j) Gm[i][j] = outs[(int64_t)(oG + i * J + j) * G + g];
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) Q2[q] = outs[(int64_t)(oQ2 + q) * G + g];
+    const double q0 = outs[(int64_t)(ol + 1) * G + g];
+    if (have) {
+      logdet += outs[(int64_t)ol * G + g];
+      const double fk = outs[(int64_t)of * G + g];
+      if (fk != 0.0) first = fmin(first, fk);
+      if (kk + 1 < K) {   // the end state of this chunk against the start state the next chunk was given
+        double dmax = 0.0, smax = 0.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const double se = outs[(int64_t)q * G + g], sn = starts[(int64_t)q * G + g + 1];
+          dmax = fmax(dmax, fabs(se - sn));
+          smax = fmax(smax, fabs(se));
+          if (!(se == se) || !(sn == sn)) dmax = INFINITY;
+        }
+        worst = fmax(worst, dmax / fmax(smax, 1e-300));
+      }
+    }
+    const int steps = (int)((K - base) < kThreads ? (K - base) : kThreads);
+    for (int turn = 0; turn < steps; ++turn) {
+      // every lane: its chunk's contribution and end state for the current F; the lane whose turn it is keeps / passes them
+      double qq = q0, Fn[J];
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        qq = fma(-2.0 * q1[i], F[i], qq);
+        double gi = gv[i];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          qq = fma(Q2[i <= j ? sidx(J, i, j) : sidx(J, j, i)] * F[i], F[j], qq);
+          gi = fma(Gm[i][j], F[j], gi);
+        }
+        Fn[i] = gi;
+      }
+      quad += lane == turn ? qq : 0.0;
+#pragma unroll
+      for (int i = 0; i < J; ++i) F[i] = __shfl(Fn[i], turn, 64);
+    }
+  }
+  // over the lanes (chunks)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    logdet += __shfl_xor(logdet, o, 64);
+    quad += __shfl_xor(quad, o, 64);
+    first = fmin(first, __shfl_xor(first, o, 64));
+    worst = fmax(worst, __shfl_xor(worst, o, 64));
+  }
+  const bool bad = first != INFINITY;
+  // a failed factorisation is left to the ordinary kernel (it reports the reference's flag and -inf)
+  if (bad || !(logdet == logdet) || !(quad == quad) || !(worst == worst)) worst = INFINITY;
+  if (lane == 0) {
+    ll[b] = bad ? -INFINITY : -0.5 * (logdet + quad + (double)N * 1.83787706640934548356);   // numpy.py:84-109
+    flag[b] = bad ? (int32_t)first : 0;
+    const double gval = worst / kTol;
+    if (gval > 0.0) atomicMax(guard, (unsigned long long)__double_as_longlong(gval));   // gval >= 0: monotone bit pattern
+  }
+}
+
+template <int J>
+int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
+        const double *U, const double *V, const double *y, double *ll, int32_t *flag, double *work,
+        unsigned long long *guard, hipStream_t s) {
+  const int64_t K = (N + kRows - 1) / kRows, G = B * K;
+  double *maps = work, *starts = maps + (size_t)Layout<J>::MAP * G, *outs = starts + (size_t)Layout<J>::START * G;
+  const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);   // lane <-> chunk
+  hipLaunchKernelGGL((k_tp_maps<J>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, guard);
+  hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
+  hipLaunchKernelGGL((k_tp_chunks<J>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
+                     (const double *)starts, outs);
+  hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)starts, (const double *)outs,
+                     ll, flag, guard);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+}  // namespace c2tp
+
+extern "C" {
+
+// doubles of scratch the time-parallel path needs (0: shape not covered)
+size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J) {
+  if (J != 2 && J != 4) return 0;
+  const size_t G = (size_t)B * (size_t)((N + c2tp::kRows - 1) / c2tp::kRows);
+  const size_t per = J == 4 ? (size_t)(c2tp::Layout<4>::MAP + c2tp::Layout<4>::START + c2tp::Layout<4>::OUT)
+                            : (size_t)(c2tp::Layout<2>::MAP + c2tp::Layout<2>::START + c2tp::Layout<2>::OUT);
+  return per * G;
+}
+
+// Forward log-likelihood, time-parallel.  `guard` (device word; the first kernel zeroes it) receives the
+// verification result; the caller launches the ordinary kernel behind it with `guard` as its gate.
+int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                               int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                               double *ll, int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (J == 4) return c2tp::run<4>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
+  if (J == 2) return c2tp::run<2>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
+  return C2_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+# -*- coding: utf-8 -*-
+"""Time-parallel forward log-likelihood (c2_timepar.hip; widths 4 and 2) against the CPU oracle: the linear-fractional
+composition of the factor recursion + the affine form of the solve recursion, verified on the device, with the row-by-row
+kernel as the stream-ordered fallback.  Forced with C2_TIMEPAR=1 (the dispatch takes it for small batches of long series)."""
+import numpy as np
+import pytest
+
+from oracle import dense
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+    from celerite2_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def dev(*xs):
+    import torch
+    return [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in xs]
+
+
+def close(a, b, tol=1e-10):
+    a = a.cpu().numpy() if hasattr(a, "cpu") else a
+    np.testing.assert_allclose(a, b, rtol=tol, atol=0.0)
+
+
+def oracle_ll(oracle, t, c, a, U, V, y):
+    ll, _, fl = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    return ll, np.asarray(fl)
+
+
+@pytest.mark.parametrize("J", [4, 2])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 128), (7, 700), (2, 4096), (70, 1000), (1, 20000)])
+def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J):
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    llo, flo = oracle_ll(oracle, t, c, a, U, V, y)
+    assert not flo.any()
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    ll, flag = ops.loglik(*dev(t, c, a, U, V, y))
+    assert int(flag.abs().sum()) == 0
+    close(ll, llo)
+    monkeypatch.setenv("C2_TIMEPAR", "0")
+    ll0, _ = ops.loglik(*dev(t, c, a, U, V, y))
+    close(ll, ll0.cpu().numpy())
+    # shared time grid and rates
+    ts, cs = np.tile(t[0], (B, 1)), np.tile(c[0], (B, 1))
+    lls, fls = oracle_ll(oracle, ts, cs, a, U, V, y)
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    ll2, flag2 = ops.loglik(*dev(t[0].copy(), c[0].copy(), a, U, V, y))
+    ok = fls == 0
+    assert np.array_equal(flag2.cpu().numpy() != 0, ~ok)
+    close(ll2[ok], lls[ok])
+
+
+@pytest.mark.parametrize("J", [4, 2])
+def test_timepar_falls_back_when_it_cannot_be_trusted(ops, oracle, monkeypatch, J):
+    """Failed factorisations, zero white noise (kappa = 0: the maps are singular), gaps long enough to underflow a decay:
+    the verification word sends the batch to the row-by-row kernel, which reports what the reference reports."""
+    B, N = 6, 900
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    # (1) a series that is not positive definite
+    a1 = a.copy(); a1[2, 500] = -3.0
+    llo, flo = oracle_ll(oracle, t, c, a1, U, V, y)
+    ll, flag = ops.loglik(*dev(t, c, a1, U, V, y))
+    assert flag.cpu().tolist() == list(flo) and flo[2] == 500
+    ok = flo == 0
+    close(ll[ok], llo[ok]); assert np.isneginf(float(ll[2]))
+    # (2) no white noise on a stretch of rows: a = sum(U V) exactly
+    # (numerically singular for that series: its value is noise in any implementation -- what is checked is that the
+    # batch comes back from the row-by-row kernel, bit for bit, and that the healthy series match the oracle)
+    a2 = a.copy(); a2[1, 100:140] = (U[1, 100:140] * V[1, 100:140]).sum(-1)
+    llo, flo = oracle_ll(oracle, t, c, a2, U, V, y)
+    ll, flag = ops.loglik(*dev(t, c, a2, U, V, y))
+    monkeypatch.setenv("C2_TIMEPAR", "0")
+    ll_rows, flag_rows = ops.loglik(*dev(t, c, a2, U, V, y))
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    assert np.array_equal(ll.cpu().numpy(), ll_rows.cpu().numpy()) and flag.cpu().tolist() == flag_rows.cpu().tolist()
+    ok = (flo == 0) & (np.arange(B) != 1)
+    close(ll[ok], llo[ok])
+    # (3) a gap of 1e6 time units inside a chunk: exp(-c dt) underflows, its reciprocal overflows
+    t3 = t.copy(); t3[:, 450:] += 1e6
+    llo, flo = oracle_ll(oracle, t3, c, a, U, V, y)
+    ll, flag = ops.loglik(*dev(t3, c, a, U, V, y))
+    assert flag.cpu().tolist() == list(flo)
+    close(ll, llo)
+
+
+def test_timepar_is_what_small_batches_of_long_series_run(ops, oracle, monkeypatch):
+    """BASELINE configs[1] (1024 series, N = 4096, J = 4, forward): default dispatch, oracle on a few series."""
+    import torch
+    from celerite2_amd import synth
+    monkeypatch.delenv("C2_TIMEPAR", raising=False)
+    B, N, J = 1024, 4096, 4
+    t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, torch.device("cuda:0"))
+    ll, flag = ops.loglik(t, c, a, U, V, y)
+    assert int(flag.abs().sum()) == 0
+    idx = [0, 1, 511, 1023]
+    h = [x[idx].cpu().numpy() for x in (t, c, a, U, V, y)]
+    llo, flo = oracle_ll(oracle, *h)
+    close(ll[idx], llo)
+    monkeypatch.setenv("C2_TIMEPAR", "0")
+    ll0, _ = ops.loglik(t, c, a, U, V, y)
+    close(ll, ll0.cpu().numpy())

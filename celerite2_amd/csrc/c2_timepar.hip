@@ -115,12 +115,89 @@ __device__ __forceinline__ void stage_scalar_tile(double *tile, int lane, const 
   for (int i = 0; i < 8; ++i) tile[(8 * i + lane / 8) * 9 + q] = v[i];
 }
 
-// ---- phase 1: composite linear-fractional map of rows s .. e-1 (towards row e) of chunk k < K - 1 ----------------------
+// S' = X Y^-1 for J x J blocks by Gauss-Jordan with partial pivoting on Y^T (rows of the augmented [Y^T | X^T]), fully
+// unrolled.
 template <int J>
+__device__ __forceinline__ void right_divide(double (&X)[J][J], double (&Y)[J][J], double (&out)[J][J]) {
+  // solve Y^T Z = X^T, out = Z^T
+  double A[J][2 * J];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) { A[i][j] = Y[j][i]; A[i][J + j] = X[j][i]; }
+#pragma unroll
+  for (int col = 0; col < J; ++col) {
+    // partial pivoting, swaps by selects (columns left of `col` are already unit columns: nothing to swap there).  It is
+    // needed: without it the chunk-start states of the bench data fail the verification (measured) -- 40 % of this loop.
+#pragma unroll
+    for (int r = col + 1; r < J; ++r) {
+      const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
+#pragma unroll
+      for (int j = col; j < 2 * J; ++j) {
+        const double hi = sw ? A[r][j] : A[col][j], lo = sw ? A[col][j] : A[r][j];
+        A[col][j] = hi; A[r][j] = lo;
+      }
+    }
+    const double rp = rcp_nr(A[col][col]);
+#pragma unroll
+    for (int j = col + 1; j < 2 * J; ++j) A[col][j] *= rp;
+#pragma unroll
+    for (int r = 0; r < J; ++r) {
+      if (r == col) continue;
+      const double f = A[r][col];
+#pragma unroll
+      for (int j = col + 1; j < 2 * J; ++j) A[r][j] = fma(-f, A[col][j], A[r][j]);   // (columns <= col: known 0 / 1)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) out[j][i] = A[i][J + j];
+}
+
+// The chain of chunk-start states inside one wavefront (lane <-> chunk, this lane's map in M): every lane applies its own map
+// to the current state at every step and the result of the lane whose turn it is becomes the state of the next step
+// (NS lane broadcasts): the loop carries no memory access.  `mine` receives the state AFTER this lane's chunk.
+template <int J>
+__device__ __forceinline__ void chain_starts(const double (&M)[2 * J][2 * J], int steps, int lane, double (&S)[J][J],
+                                             double (&mine)[nsym(J)]) {
+  for (int turn = 0; turn < steps; ++turn) {
+    double X[J][J], Y[J][J];
+    // [X; Y] = M [S; I]
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double xs = M[i][J + j], ys = M[J + i][J + j];
+#pragma unroll
+        for (int l = 0; l < J; ++l) {
+          xs = fma(M[i][l], S[l][j], xs);
+          ys = fma(M[J + i][l], S[l][j], ys);
+        }
+        X[i][j] = xs; Y[i][j] = ys;
+      }
+    double Sn[J][J];
+    right_divide<J>(X, Y, Sn);
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = i; j < J; ++j) {
+        const double v = __shfl(0.5 * (Sn[i][j] + Sn[j][i]), turn, 64);   // the lane whose chunk this is
+        S[i][j] = v; S[j][i] = v;
+        mine[sidx(J, i, j)] = lane == turn ? v : mine[sidx(J, i, j)];
+      }
+  }
+}
+
+// ---- phase 1: composite linear-fractional map of rows s .. e-1 (towards row e) of chunk k < K - 1 ----------------------
+// FUSED (K <= 64: the wavefront holds every chunk of its series): phase 2 runs right here on the maps in registers and
+// `maps` is never written; `starts` receives the chunk-start states.
+template <int J, bool FUSED>
 __global__ __launch_bounds__(kThreads) void k_tp_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                       int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                       const double *__restrict__ a, const double *__restrict__ U,
                                                       const double *__restrict__ V, double *__restrict__ maps,
+                                                      double *__restrict__ starts,
                                                       unsigned long long *__restrict__ guard) {
   using Gm = Geo<J>;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *guard = 0ull;   // k_tp_finish (later in the stream) maxes into it
@@ -200,52 +277,27 @@ __global__ __launch_bounds__(kThreads) void k_tp_maps(int64_t B, int64_t N, int6
       }
     }
   }
-  if (act) {
+  if constexpr (FUSED) {
+    constexpr int NS = nsym(J);
+    double S[J][J], mine[NS];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) S[i][j] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) mine[q] = 0.0;
+    if (lane < NS) starts[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing (forward.hpp:107-113)
+    chain_starts<J>(R, (int)(K - 1), lane, S, mine);
+    if (act) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + g + 1] = mine[q];
+    }
+  } else if (act) {
 #pragma unroll
     for (int i = 0; i < 2 * J; ++i)
 #pragma unroll
       for (int j = 0; j < 2 * J; ++j) maps[(int64_t)(i * 2 * J + j) * G + g] = R[i][j];
   }
-}
-
-// S' = X Y^-1 for J x J blocks by Gauss-Jordan with partial pivoting on Y^T (rows of the augmented [Y^T | X^T]), fully
-// unrolled.
-template <int J>
-__device__ __forceinline__ void right_divide(double (&X)[J][J], double (&Y)[J][J], double (&out)[J][J]) {
-  // solve Y^T Z = X^T, out = Z^T
-  double A[J][2 * J];
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) { A[i][j] = Y[j][i]; A[i][J + j] = X[j][i]; }
-#pragma unroll
-  for (int col = 0; col < J; ++col) {
-    // partial pivoting, swaps by selects (columns left of `col` are already unit columns: nothing to swap there).  It is
-    // needed: without it the chunk-start states of the bench data fail the verification (measured) -- 40 % of this loop.
-#pragma unroll
-    for (int r = col + 1; r < J; ++r) {
-      const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
-#pragma unroll
-      for (int j = col; j < 2 * J; ++j) {
-        const double hi = sw ? A[r][j] : A[col][j], lo = sw ? A[col][j] : A[r][j];
-        A[col][j] = hi; A[r][j] = lo;
-      }
-    }
-    const double rp = rcp_nr(A[col][col]);
-#pragma unroll
-    for (int j = col + 1; j < 2 * J; ++j) A[col][j] *= rp;
-#pragma unroll
-    for (int r = 0; r < J; ++r) {
-      if (r == col) continue;
-      const double f = A[r][col];
-#pragma unroll
-      for (int j = col + 1; j < 2 * J; ++j) A[r][j] = fma(-f, A[col][j], A[r][j]);   // (columns <= col: known 0 / 1)
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) out[j][i] = A[i][J + j];
 }
 
 // ---- phase 2: chunk-start states.  One WAVEFRONT per series, lane <-> chunk: a lane keeps its chunk's map in registers
@@ -276,32 +328,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_starts(int64_t B, int64_t K, co
 #pragma unroll
     for (int q = 0; q < NS; ++q) mine[q] = 0.0;
     const int steps = (int)((K - 1 - base) < kThreads ? (K - 1 - base) : kThreads);
-    for (int turn = 0; turn < steps; ++turn) {
-      double X[J][J], Y[J][J];
-      // [X; Y] = M [S; I]
-#pragma unroll
-      for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          double xs = M[i][J + j], ys = M[J + i][J + j];
-#pragma unroll
-          for (int l = 0; l < J; ++l) {
-            xs = fma(M[i][l], S[l][j], xs);
-            ys = fma(M[J + i][l], S[l][j], ys);
-          }
-          X[i][j] = xs; Y[i][j] = ys;
-        }
-      double Sn[J][J];
-      right_divide<J>(X, Y, Sn);
-#pragma unroll
-      for (int i = 0; i < J; ++i)
-#pragma unroll
-        for (int j = i; j < J; ++j) {
-          const double v = __shfl(0.5 * (Sn[i][j] + Sn[j][i]), turn, 64);   // the lane whose chunk this is
-          S[i][j] = v; S[j][i] = v;
-          mine[sidx(J, i, j)] = lane == turn ? v : mine[sidx(J, i, j)];
-        }
-    }
+    chain_starts<J>(M, steps, lane, S, mine);
     if (have) {
 #pragma unroll
       for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + g + 1] = mine[q];
@@ -309,13 +336,75 @@ __global__ __launch_bounds__(kThreads) void k_tp_starts(int64_t B, int64_t K, co
   }
 }
 
-// ---- phase 3: every chunk runs the recursion from its start state ----------------------------------------------------
+// The chain of F over the chunks of a wavefront (lane <-> chunk; this lane's G, g, q0, q1, Q2): every lane evaluates its
+// chunk's quadratic form and end state for the current F, the lane whose turn it is keeps / passes them on.
 template <int J>
+__device__ __forceinline__ void chain_finish(const double (&Gm)[J][J], const double (&gv)[J], double q0, const double (&q1)[J],
+                                             const double (&Q2)[nsym(J)], int steps, int lane, double (&F)[J],
+                                             double &quad) {
+  for (int turn = 0; turn < steps; ++turn) {
+    double qq = q0, Fn[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      qq = fma(-2.0 * q1[i], F[i], qq);
+      double gi = gv[i];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        qq = fma(Q2[i <= j ? sidx(J, i, j) : sidx(J, j, i)] * F[i], F[j], qq);
+        gi = fma(Gm[i][j], F[j], gi);
+      }
+      Fn[i] = gi;
+    }
+    quad += lane == turn ? qq : 0.0;
+#pragma unroll
+    for (int i = 0; i < J; ++i) F[i] = __shfl(Fn[i], turn, 64);
+  }
+}
+// relative mismatch between the end state a chunk computed and the start state its successor was given
+template <int J>
+__device__ __forceinline__ double start_mismatch(const double (&Send)[nsym(J)], const double *__restrict__ starts, int64_t G,
+                                                 int64_t gnext) {
+  double dmax = 0.0, smax = 0.0;
+#pragma unroll
+  for (int q = 0; q < nsym(J); ++q) {
+    const double se = Send[q], sn = starts[(int64_t)q * G + gnext];
+    dmax = fmax(dmax, fabs(se - sn));
+    smax = fmax(smax, fabs(se));
+    if (!(se == se) || !(sn == sn)) dmax = INFINITY;
+  }
+  return dmax / fmax(smax, 1e-300);
+}
+// sums over the lanes (chunks) of a wavefront and the outputs of a series
+__device__ __forceinline__ void finish_series(double logdet, double quad, double first, double worst, int lane, int64_t N,
+                                              double *ll_b, int32_t *flag_b, unsigned long long *guard) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    logdet += __shfl_xor(logdet, o, 64);
+    quad += __shfl_xor(quad, o, 64);
+    first = fmin(first, __shfl_xor(first, o, 64));
+    worst = fmax(worst, __shfl_xor(worst, o, 64));
+  }
+  const bool bad = first != INFINITY;
+  // a failed factorisation is left to the ordinary kernel (it reports the reference's flag and -inf)
+  if (bad || !(logdet == logdet) || !(quad == quad) || !(worst == worst)) worst = INFINITY;
+  if (lane == 0) {
+    *ll_b = bad ? -INFINITY : -0.5 * (logdet + quad + (double)N * 1.83787706640934548356);   // numpy.py:84-109
+    *flag_b = bad ? (int32_t)first : 0;
+    const double gval = worst / kTol;
+    if (gval > 0.0) atomicMax(guard, (unsigned long long)__double_as_longlong(gval));   // gval >= 0: monotone bit pattern
+  }
+}
+
+// ---- phase 3: every chunk runs the recursion from its start state ----------------------------------------------------
+// FUSED (K <= 64): phase 4 runs right here on the chunk results in registers; `outs` is never written.
+template <int J, bool FUSED>
 __global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                         int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                         const double *__restrict__ a, const double *__restrict__ U,
                                                         const double *__restrict__ V, const double *__restrict__ yv,
-                                                        const double *__restrict__ starts, double *__restrict__ outs) {
+                                                        const double *__restrict__ starts, double *__restrict__ outs,
+                                                        double *__restrict__ ll, int32_t *__restrict__ flag,
+                                                        unsigned long long *__restrict__ guard) {
   using Gm = Geo<J>;
   constexpr int NS = nsym(J);
   __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 3 * 64 * Gm::SSTR];
@@ -430,10 +519,21 @@ __global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, in
       }
     }
   }
-  if (!inr) return;
   int ex;
   prod = frexp(prod, &ex);
   const double logdet = log(prod) + (double)(eacc + ex) * 0.693147180559945309417;
+  if constexpr (FUSED) {
+    double worst = 0.0;
+    if (inr && k + 1 < K) worst = start_mismatch<J>(S, starts, G, g + 1);
+    double F[J], quad = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) F[j] = 0.0;
+    chain_finish<J>(Gmx, gv, q0, q1, Q2, (int)K, lane, F, quad);
+    finish_series(inr ? logdet : 0.0, quad, (inr && failed != 0.0) ? failed : INFINITY, worst, lane, N, ll + b, flag + b,
+                  guard);
+    return;
+  }
+  if (!inr) return;
   int q = 0;
 #pragma unroll
   for (int i = 0; i < NS; ++i) outs[(int64_t)(q++) * G + g] = S[i];
@@ -471,7 +571,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_finish(int64_t B, int64_t N, in
     const int64_t kk = base + lane;
     const bool have = kk < K;
     const int64_t g = b * K + (have ? kk : 0);
-    double Gm[J][J], gv[J], q1[J], Q2[NS];
+    double Gm[J][J], gv[J], q1[J], Q2[NS], Send[NS];
 #pragma unroll
     for (int i = 0; i < J; ++i) {
       gv[i] = outs[(int64_t)(og + i) * G + g];
@@ -480,61 +580,18 @@ __global__ __launch_bounds__(kThreads) void k_tp_finish(int64_t B, int64_t N, in
       for (int j = 0; j < J; ++j) Gm[i][j] = outs[(int64_t)(oG + i * J + j) * G + g];
     }
 #pragma unroll
-    for (int q = 0; q < NS; ++q) Q2[q] = outs[(int64_t)(oQ2 + q) * G + g];
+    for (int q = 0; q < NS; ++q) { Q2[q] = outs[(int64_t)(oQ2 + q) * G + g]; Send[q] = outs[(int64_t)q * G + g]; }
     const double q0 = outs[(int64_t)(ol + 1) * G + g];
     if (have) {
       logdet += outs[(int64_t)ol * G + g];
       const double fk = outs[(int64_t)of * G + g];
       if (fk != 0.0) first = fmin(first, fk);
-      if (kk + 1 < K) {   // the end state of this chunk against the start state the next chunk was given
-        double dmax = 0.0, smax = 0.0;
-#pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const double se = outs[(int64_t)q * G + g], sn = starts[(int64_t)q * G + g + 1];
-          dmax = fmax(dmax, fabs(se - sn));
-          smax = fmax(smax, fabs(se));
-          if (!(se == se) || !(sn == sn)) dmax = INFINITY;
-        }
-        worst = fmax(worst, dmax / fmax(smax, 1e-300));
-      }
+      if (kk + 1 < K) worst = fmax(worst, start_mismatch<J>(Send, starts, G, g + 1));
     }
     const int steps = (int)((K - base) < kThreads ? (K - base) : kThreads);
-    for (int turn = 0; turn < steps; ++turn) {
-      // every lane: its chunk's contribution and end state for the current F; the lane whose turn it is keeps / passes them
-      double qq = q0, Fn[J];
-#pragma unroll
-      for (int i = 0; i < J; ++i) {
-        qq = fma(-2.0 * q1[i], F[i], qq);
-        double gi = gv[i];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          qq = fma(Q2[i <= j ? sidx(J, i, j) : sidx(J, j, i)] * F[i], F[j], qq);
-          gi = fma(Gm[i][j], F[j], gi);
-        }
-        Fn[i] = gi;
-      }
-      quad += lane == turn ? qq : 0.0;
-#pragma unroll
-      for (int i = 0; i < J; ++i) F[i] = __shfl(Fn[i], turn, 64);
-    }
+    chain_finish<J>(Gm, gv, q0, q1, Q2, steps, lane, F, quad);
   }
-  // over the lanes (chunks)
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    logdet += __shfl_xor(logdet, o, 64);
-    quad += __shfl_xor(quad, o, 64);
-    first = fmin(first, __shfl_xor(first, o, 64));
-    worst = fmax(worst, __shfl_xor(worst, o, 64));
-  }
-  const bool bad = first != INFINITY;
-  // a failed factorisation is left to the ordinary kernel (it reports the reference's flag and -inf)
-  if (bad || !(logdet == logdet) || !(quad == quad) || !(worst == worst)) worst = INFINITY;
-  if (lane == 0) {
-    ll[b] = bad ? -INFINITY : -0.5 * (logdet + quad + (double)N * 1.83787706640934548356);   // numpy.py:84-109
-    flag[b] = bad ? (int32_t)first : 0;
-    const double gval = worst / kTol;
-    if (gval > 0.0) atomicMax(guard, (unsigned long long)__double_as_longlong(gval));   // gval >= 0: monotone bit pattern
-  }
+  finish_series(logdet, quad, first, worst, lane, N, ll + b, flag + b, guard);
 }
 
 template <int J>
@@ -544,12 +601,20 @@ int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, in
   const int64_t K = (N + kRows - 1) / kRows, G = B * K;
   double *maps = work, *starts = maps + (size_t)Layout<J>::MAP * G, *outs = starts + (size_t)Layout<J>::START * G;
   const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);   // lane <-> chunk
-  hipLaunchKernelGGL((k_tp_maps<J>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, guard);
-  hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
-  hipLaunchKernelGGL((k_tp_chunks<J>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                     (const double *)starts, outs);
-  hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)starts, (const double *)outs,
-                     ll, flag, guard);
+  if (K <= kThreads) {   // a wavefront holds every chunk of its series: two kernels, no maps / chunk results in memory
+    hipLaunchKernelGGL((k_tp_maps<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+                       guard);
+    hipLaunchKernelGGL((k_tp_chunks<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
+                       (const double *)starts, outs, ll, flag, guard);
+  } else {
+    hipLaunchKernelGGL((k_tp_maps<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+                       guard);
+    hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
+    hipLaunchKernelGGL((k_tp_chunks<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
+                       (const double *)starts, outs, ll, flag, guard);
+    hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)starts, (const double *)outs,
+                       ll, flag, guard);
+  }
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

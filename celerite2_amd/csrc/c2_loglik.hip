@@ -902,7 +902,9 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   }
   if (use_lanes4(B, J, false)) return c2_internal_loglik4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   hipStream_t s = (hipStream_t)stream;
-  if (use_timepar(B, N, J)) {
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
+  if (capturing == hipStreamCaptureStatusNone && use_timepar(B, N, J)) {
     // Small batch of long series: parallel along time (c2_timepar.hip), verified on the device; the ordinary kernel
     // below runs behind the verification word and does nothing unless it failed.  Scratch is a stream-ordered
     // temporary; without it (allocation refused) the ordinary kernel runs alone.
@@ -943,19 +945,36 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
 
 // core::factor without the S workspace (interface.hpp:37-48) on the fused forward kernel: d and W straight
 // into the caller's arrays (d == a and W == V allowed: every row is read blocks ahead of the row being written).
+extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                          int64_t c_bs, const double *a, const double *U, const double *V, double *d,
+                                          double *W, int32_t *flag, double *work, unsigned long long *guard,
+                                          c2_stream_t stream);
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                              int32_t *flag, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &capturing);
+  // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
+  // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
+  if (capturing == hipStreamCaptureStatusNone && d != a && W != V && use_timepar(B, N, J)) {
+    const size_t nd = c2_internal_timepar_doubles(B, N, J);
+    void *tmp = nullptr;
+    if (nd > 0 && hipMallocAsync(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {
+      unsigned long long *guard = (unsigned long long *)tmp;
+      int rc = c2_internal_factor_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, (double *)tmp + 2, guard, stream);
+      if (rc == C2_OK)
+        rc = launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, a, nullptr, flag, nullptr, 0, W,
+                           reinterpret_cast<double2 *>(d), s, guard);
+      if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+      return rc;
+    }
+    (void)hipGetLastError();
+  }
   return launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, /*y (unused: any readable (B,N) array)*/ a, nullptr, flag,
                        nullptr, 0, W, reinterpret_cast<double2 *>(d), (hipStream_t)stream);
 }
 
-extern "C" size_t c2_internal_loglik_t_record_doubles(int64_t B, int64_t N);
-extern "C" int c2_internal_loglik_t_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,
-                                         int64_t c_bs, const double *a, const double *U, const double *V,
-                                         const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
-                                         double *bV, double *by, int32_t *flag, double *rec, unsigned long long *guard,
-                                         c2_stream_t stream);
 
 size_t c2_internal_loglik_grad_replay_doubles(int64_t B, int64_t N, int64_t J) { return grad_ws(B, N, J).total; }
 

@@ -189,6 +189,34 @@ __device__ __forceinline__ void chain_starts(const double (&M)[2 * J][2 * J], in
   }
 }
 
+// LDS tile -> global, the mirror images (rows beyond the chunk are skipped)
+template <int J>
+__device__ __forceinline__ void flush_row_tile(double *__restrict__ base, const Chunks &c, int r0, int lane, const double *tile) {
+  using Gm = Geo<J>;
+  const int q = lane & 7;
+  double2 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const double2 *>(tile + (8 * i + lane / 8) * Gm::RSTR + 2 * q);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t k = c.k0 + 8 * i + lane / 8;
+    const int r = r0 + q / Gm::PPR;
+    if (k < c.K && r < c.len(k))
+      *reinterpret_cast<double2 *>(base + (c.sbase + k * kRows + r) * J + 2 * (q % Gm::PPR)) = v[i];
+  }
+}
+__device__ __forceinline__ void flush_scalar_tile(double *__restrict__ base, const Chunks &c, int r0, int lane, const double *tile) {
+  const int q = lane & 7;
+  double v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = tile[(8 * i + lane / 8) * 9 + q];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t k = c.k0 + 8 * i + lane / 8;
+    if (k < c.K && r0 + q < c.len(k)) base[c.sbase + k * kRows + r0 + q] = v[i];
+  }
+}
+
 // ---- phase 1: composite linear-fractional map of rows s .. e-1 (towards row e) of chunk k < K - 1 ----------------------
 // FUSED (K <= 64: the wavefront holds every chunk of its series): phase 2 runs right here on the maps in registers and
 // `maps` is never written; `starts` receives the chunk-start states.
@@ -552,6 +580,134 @@ __global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, in
   outs[(int64_t)(q++) * G + g] = failed;
 }
 
+// ---- `factor` itself (forward.hpp:69-135: d, W, flag), phase 3 with the rows written out.  d == a / W == V in place are NOT
+// supported here (the caller keeps those on the row-by-row kernel: its fallback would read what this kernel overwrote).
+// Two passes.  The start states of phase 2 carry the error of an ill-conditioned composite map (1e-12 of |S|, which the
+// difference v - u S in W turns into 1e-10 of W: at the parity bar).  The recursion itself contracts such an error by the
+// very factor that makes the maps ill-conditioned, so the END states of a first pass (WRITE = false: states only) are
+// start states good to rounding; the second pass (WRITE = true) writes d and W from those and verifies against them.
+template <int J, bool WRITE>
+__global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                        const double *__restrict__ a, const double *__restrict__ U,
+                                                        const double *__restrict__ V, const double *__restrict__ starts,
+                                                        double *__restrict__ ends, double *__restrict__ d_out,
+                                                        double *__restrict__ W_out, int32_t *__restrict__ flag,
+                                                        unsigned long long *__restrict__ guard) {
+  using Gm = Geo<J>;
+  constexpr int NS = nsym(J);
+  __shared__ __attribute__((aligned(16))) double lds[3 * 64 * Gm::RSTR + 3 * 64 * Gm::SSTR];
+  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tW = tV + 64 * Gm::RSTR, *tA = tW + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR,
+         *tD = tT + 64 * Gm::SSTR;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, G = B * K;
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = ch.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  const int64_t g = b * K + k;
+  const int64_t s = k * kRows;
+  const int len = ch.len(k);
+  double cj[J], S[NS];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) S[q] = starts[(int64_t)q * G + g];
+  if (WRITE && blockIdx.x == 0 && lane == 0) flag[b] = 0;
+  if (!WRITE && blockIdx.x == 0 && lane < NS) ends[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing
+  double failed = 0.0;
+  double tn = t[b * t_bs + s];
+  double vu[16], vv[16], va[8], vt[8];   // tiles requested one tile ahead
+  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  fetch_row_tile<J>(U, ch, 0, lane, vu);
+  fetch_row_tile<J>(V, ch, 0, lane, vv);
+  for (int r0 = 0; r0 < kRows; r0 += 8) {
+    lds_order();
+    stage_scalar_tile(tA, lane, va);
+    stage_scalar_tile(tT, lane, vt);
+    if (r0 + 8 < kRows) {
+      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < 8; rt += Gm::RT) {
+      lds_order();
+      stage_row_tile<J>(tU, lane, vu);
+      stage_row_tile<J>(tV, lane, vv);
+      if (r0 + rt + Gm::RT < kRows) {
+        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
+        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
+      }
+      lds_order();
+#pragma unroll
+      for (int r = 0; r < Gm::RT; ++r) {
+        const int i0 = r0 + rt + r;
+        const int64_t n = s + i0;
+        double u[J], v[J], tau[J], w[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) { u[j] = tU[lane * Gm::RSTR + r * J + j]; v[j] = tV[lane * Gm::RSTR + r * J + j]; tau[j] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < J; ++i)
+#pragma unroll
+          for (int j = i; j < J; ++j) {
+            const double sv = S[sidx(J, i, j)];
+            tau[j] = fma(u[i], sv, tau[j]);
+            if (j != i) tau[i] = fma(u[j], sv, tau[i]);
+          }
+        double d = tA[lane * Gm::SSTR + rt + r];
+#pragma unroll
+        for (int j = 0; j < J; ++j) d = fma(-tau[j], u[j], d);          // forward.hpp:127
+        const double rd = rcp_nr(d);
+        if (i0 < len) failed = (failed == 0.0 && n > 0 && !(d > 0.0)) ? (double)n : failed;   // forward.hpp:128
+#pragma unroll
+        for (int j = 0; j < J; ++j) {   // forward.hpp:131
+          w[j] = (v[j] - tau[j]) * rd;
+          if (WRITE) tW[lane * Gm::RSTR + r * J + j] = w[j];
+        }
+        if (WRITE) tD[lane * Gm::SSTR + rt + r] = d;
+        if (i0 < len && n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123)
+          const double tn1 = tT[lane * Gm::SSTR + rt + r];
+          double p[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) p[j] = exp_decay(cj[j] * (tn - tn1));
+          tn = tn1;
+#pragma unroll
+          for (int i = 0; i < J; ++i) {
+            const double dwi = d * w[i];
+#pragma unroll
+            for (int j = i; j < J; ++j) S[sidx(J, i, j)] = (p[i] * p[j]) * fma(dwi, w[j], S[sidx(J, i, j)]);
+          }
+        }
+      }
+      if (WRITE) {
+        lds_order();
+        flush_row_tile<J>(W_out, ch, r0 + rt, lane, tW);
+      }
+    }
+    if (WRITE) {
+      lds_order();
+      flush_scalar_tile(d_out, ch, r0, lane, tD);
+    }
+  }
+  if (!WRITE) {   // states only: this chunk's end state is its successor's start state in the second pass
+    if (inr && k + 1 < K) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) ends[(int64_t)q * G + g + 1] = S[q];
+    }
+    return;
+  }
+  // verification: this chunk's end state against the start state its successor was given; failures -> the row-by-row kernel
+  double worst = 0.0;
+  if (inr && k + 1 < K) worst = start_mismatch<J>(S, starts, G, g + 1);
+  if (inr && failed != 0.0) worst = INFINITY;
+  if (!(worst == worst)) worst = INFINITY;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, 64));
+  const double gval = worst / kTol;
+  if (lane == 0 && gval > 0.0) atomicMax(guard, (unsigned long long)__double_as_longlong(gval));
+}
+
 // ---- phase 4: chain the chunks of a series, verify the chunk-start states.  One wavefront per series, lane <-> chunk:
 // the chunk results are loaded coalesced, the verification is lane-parallel, the chain of F broadcasts J values a step.
 template <int J>
@@ -618,6 +774,29 @@ int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, in
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
+template <int J>
+int run_factor(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
+               const double *U, const double *V, double *d, double *W, int32_t *flag, double *work,
+               unsigned long long *guard, hipStream_t s) {
+  const int64_t K = (N + kRows - 1) / kRows, G = B * K;
+  double *maps = work, *starts = maps + (size_t)Layout<J>::MAP * G;
+  const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);
+  if (K <= kThreads) {
+    hipLaunchKernelGGL((k_tp_maps<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+                       guard);
+  } else {
+    hipLaunchKernelGGL((k_tp_maps<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+                       guard);
+    hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
+  }
+  double *ends = starts + (size_t)Layout<J>::START * G;   // (the region of the log-likelihood's chunk results)
+  hipLaunchKernelGGL((k_tp_factor<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V,
+                     (const double *)starts, ends, d, W, flag, guard);
+  hipLaunchKernelGGL((k_tp_factor<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V,
+                     (const double *)ends, (double *)nullptr, d, W, flag, guard);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
 }  // namespace c2tp
 
 extern "C" {
@@ -639,6 +818,16 @@ int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t,
   hipStream_t s = (hipStream_t)stream;
   if (J == 4) return c2tp::run<4>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
   if (J == 2) return c2tp::run<2>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
+  return C2_ERR_UNSUPPORTED;
+}
+
+// `factor` (d, W, flag; no S workspace, not in place), time-parallel; same scratch and guard protocol.
+int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                               int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
+                               int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (J == 4) return c2tp::run_factor<4>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, guard, s);
+  if (J == 2) return c2tp::run_factor<2>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, guard, s);
   return C2_ERR_UNSUPPORTED;
 }
 

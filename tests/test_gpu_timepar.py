@@ -107,3 +107,31 @@ def test_timepar_is_what_small_batches_of_long_series_run(ops, oracle, monkeypat
     monkeypatch.setenv("C2_TIMEPAR", "0")
     ll0, _ = ops.loglik(t, c, a, U, V, y)
     close(ll, ll0.cpu().numpy())
+
+
+@pytest.mark.parametrize("J", [4, 2])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 129), (2, 4096), (9, 1000), (1, 30000)])
+def test_timepar_factor_matches_oracle(ops, oracle, monkeypatch, B, N, J):
+    """`factor` (d, W) by the same composition: every row against the oracle; a failed series falls back and reports the
+    reference's flag; in-place calls (d is a, W is V) stay on the row-by-row kernel and still agree."""
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V))
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    d, W, flag = ops.factor(*dev(t, c, a, U, V))
+    assert int(flag.abs().sum()) == 0
+    for b in range(B):
+        do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So) == 0
+        close(d[b], do); np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
+    if N > 40:
+        a1 = a.copy(); a1[0, N // 2] = -2.0
+        d1, W1, flag1 = ops.factor(*dev(t, c, a1, U, V))
+        assert int(flag1[0]) == N // 2 and int(flag1[1:].abs().sum()) == 0
+        monkeypatch.setenv("C2_TIMEPAR", "0")
+        d0, W0, flag0 = ops.factor(*dev(t, c, a1, U, V))
+        assert np.array_equal(d1.cpu().numpy()[1:], d0.cpu().numpy()[1:]) if B > 1 else True
+        monkeypatch.setenv("C2_TIMEPAR", "1")
+    ad, Vd = dev(a, V)
+    td, cd, Ud = dev(t, c, U)
+    d2, W2, _ = ops.factor(td, cd, ad, Ud, Vd, d=ad, W=Vd)   # in place
+    close(d2, d.cpu().numpy()); np.testing.assert_allclose(W2.cpu().numpy(), W.cpu().numpy(), rtol=1e-10, atol=1e-12)

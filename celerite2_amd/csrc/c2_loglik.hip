@@ -872,6 +872,13 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J) {
   if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
   return N >= C2_TIMEPAR_MIN_ROWS && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
+// the same decision for the single-rhs solves (affine maps: width 8 as well)
+extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
+  if (J != 8 && J != 4 && J != 2) return 0;
+  const char *e = getenv("C2_TIMEPAR");
+  if (e) return atoi(e) != 0 && N >= 2;
+  return N >= C2_TIMEPAR_MIN_ROWS && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
+}
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 4 && J != 2) return false;
   const char *e = getenv("C2_LANES");

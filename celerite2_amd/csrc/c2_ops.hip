@@ -1127,6 +1127,11 @@ static bool use_mfma() {
   return !(e && e[0] == '0');
 }
 
+extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J);
+extern "C" size_t c2_internal_timepar_solve_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_solve_timepar(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                         const double *c, int64_t c_bs, const double *U, const double *W,
+                                         const double *Y, double *Z, double *scratch, c2_stream_t stream);
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -1150,6 +1155,23 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
       while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
       return c2_internal_matmul_chunked(LOWER ? 1 : 0, B, N, J, nrhs, Lc, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
                                         stream);
+    }
+  }
+  if (SOLVE && nrhs == 1 && !F && c2_internal_use_timepar_solve(B, N, J)) {
+    // a small batch of long series and one right-hand side: the solve recursion is affine in its state -- chunks of 64
+    // rows in parallel, chained, applied (c2_timepar.hip).  Scratch (series longer than 4096 rows only) is a
+    // stream-ordered temporary; not inside graph captures.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);
+    if (capturing == hipStreamCaptureStatusNone) {
+      const size_t nd = c2_internal_timepar_solve_doubles(B, N, J);
+      void *tmp = nullptr;
+      if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+        int rc = c2_internal_solve_timepar(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, (double *)tmp, stream);
+        if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+        return rc;
+      }
+      (void)hipGetLastError();
     }
   }
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)

@@ -797,6 +797,300 @@ int run_factor(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
+
+// =============================================================================================================
+// solve_lower / solve_upper (forward.hpp:156-207 over internal.hpp:105-189) with ONE right-hand side, parallel along
+// time.  In virtual order s = 0 .. N-1 (lower: row s; upper: row N-1-s) with A the row fed into the state and B the row
+// applied to it (lower: A = W, B = U; upper: A = U, B = W):
+//     z_s = y_s - B_s . F_s ,     F_{s+1} = P_{s+1} (F_s + A_s z_s) = P_{s+1} ((I - A_s B_s^T) F_s + A_s y_s)
+// -- affine in F, with contracting maps: a chunk yields (G, g) with F_end = G F_start + g, the chain over the chunks is
+// J^2 flops a step, and a second pass applies the recursion from the true start states.  Nothing to verify (no
+// ill-conditioned composition: the maps are applied, never inverted).  Z may alias Y.
+template <bool LOWER>
+struct SweepIO {
+  int64_t sbase, tbase, N, K, k0;
+  __device__ __forceinline__ int64_t chunk(int i, int lane) const {
+    const int64_t k = k0 + 8 * i + lane / 8;
+    return k < K ? k : K - 1;
+  }
+  __device__ __forceinline__ int len(int64_t k) const {
+    const int64_t s = k * kRows;
+    return (int)((s + kRows < N ? s + kRows : N) - s);
+  }
+  __device__ __forceinline__ int64_t row(int64_t s) const { return LOWER ? s : N - 1 - s; }   // virtual -> actual
+};
+template <int J, bool LOWER>
+__device__ __forceinline__ void sw_fetch_rows(const double *__restrict__ base, const SweepIO<LOWER> &c, int r0, int lane,
+                                              double (&v)[16]) {
+  using Gm = Geo<J>;
+  const int q = lane & 7;
+  const int r = LOWER ? q / Gm::PPR : Gm::RT - 1 - q / Gm::PPR;   // local row of the tile this piece belongs to
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t k = c.chunk(i, lane);
+    const int ln = c.len(k);
+    int rr = r0 + r;
+    rr = rr < ln ? rr : ln - 1;
+    const double2 w = *reinterpret_cast<const double2 *>(base + (c.sbase + c.row(k * kRows + rr)) * J + 2 * (q % Gm::PPR));
+    v[2 * i] = w.x; v[2 * i + 1] = w.y;
+  }
+}
+template <int J, bool LOWER>
+__device__ __forceinline__ void sw_stage_rows(double *tile, int lane, const double (&v)[16]) {
+  using Gm = Geo<J>;
+  const int q = lane & 7;
+  const int r = LOWER ? q / Gm::PPR : Gm::RT - 1 - q / Gm::PPR;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    *reinterpret_cast<double2 *>(tile + (8 * i + lane / 8) * Gm::RSTR + r * J + 2 * (q % Gm::PPR)) =
+        make_double2(v[2 * i], v[2 * i + 1]);
+}
+template <bool LOWER, bool TIME>
+__device__ __forceinline__ void sw_fetch_scalars(const double *__restrict__ base, const SweepIO<LOWER> &c, int r0, int shift,
+                                                 int lane, double (&v)[8]) {
+  const int q = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    int64_t sv = c.chunk(i, lane) * kRows + r0 + q + shift;
+    sv = sv < c.N - 1 ? sv : c.N - 1;
+    v[i] = base[(TIME ? c.tbase : c.sbase) + c.row(sv)];
+  }
+}
+template <bool LOWER>
+__device__ __forceinline__ void sw_flush_scalars(double *__restrict__ base, const SweepIO<LOWER> &c, int r0, int lane,
+                                                 const double *tile) {
+  const int q = lane & 7;
+  double v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = tile[(8 * i + lane / 8) * 9 + q];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t k = c.k0 + 8 * i + lane / 8;
+    if (k < c.K && r0 + q < c.len(k)) base[c.sbase + c.row(k * kRows + r0 + q)] = v[i];
+  }
+}
+
+// One pass over the rows of this lane's chunk.  APPLY = false: the chunk's affine map (G, g).  APPLY = true: z from the
+// start state F, written through an LDS tile.
+template <int J, bool LOWER, bool APPLY>
+__device__ __forceinline__ void sweep_pass(const SweepIO<LOWER> &io, int lane, int len, double tstart, const double (&cj)[J],
+                                           const double *__restrict__ t, const double *__restrict__ A,
+                                           const double *__restrict__ Bm, const double *__restrict__ Y, double *Z,
+                                           double *lds, double (&G)[J][J], double (&g)[J], double (&F)[J]) {
+  using Gm = Geo<J>;
+  double *tA = lds, *tB = tA + 64 * Gm::RSTR, *tY = tB + 64 * Gm::RSTR, *tT = tY + 64 * Gm::SSTR, *tZ = tT + 64 * Gm::SSTR;
+  double tn = tstart;
+  double va[16], vb[16], vy[8], vt[8];
+  sw_fetch_scalars<LOWER, false>(Y, io, 0, 0, lane, vy);
+  sw_fetch_scalars<LOWER, true>(t, io, 0, 1, lane, vt);   // t of the NEXT (virtual) row
+  sw_fetch_rows<J, LOWER>(A, io, 0, lane, va);
+  sw_fetch_rows<J, LOWER>(Bm, io, 0, lane, vb);
+  for (int r0 = 0; r0 < kRows; r0 += 8) {
+    lds_order();
+    stage_scalar_tile(tY, lane, vy);
+    stage_scalar_tile(tT, lane, vt);
+    if (r0 + 8 < kRows) {
+      sw_fetch_scalars<LOWER, false>(Y, io, r0 + 8, 0, lane, vy);
+      sw_fetch_scalars<LOWER, true>(t, io, r0 + 8, 1, lane, vt);
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < 8; rt += Gm::RT) {
+      lds_order();
+      sw_stage_rows<J, LOWER>(tA, lane, va);
+      sw_stage_rows<J, LOWER>(tB, lane, vb);
+      if (r0 + rt + Gm::RT < kRows) {
+        sw_fetch_rows<J, LOWER>(A, io, r0 + rt + Gm::RT, lane, va);
+        sw_fetch_rows<J, LOWER>(Bm, io, r0 + rt + Gm::RT, lane, vb);
+      }
+      lds_order();
+#pragma unroll
+      for (int r = 0; r < Gm::RT; ++r) {
+        const int i0 = r0 + rt + r;
+        if (i0 < len) {
+          double av[J], bv[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) { av[j] = tA[lane * Gm::RSTR + r * J + j]; bv[j] = tB[lane * Gm::RSTR + r * J + j]; }
+          const double tn1 = tT[lane * Gm::SSTR + rt + r];
+          double p[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * fabs(tn1 - tn));   // internal.hpp:139 / 182
+          tn = tn1;
+          const double yn = tY[lane * Gm::SSTR + rt + r];
+          if constexpr (APPLY) {
+            double z = yn;
+#pragma unroll
+            for (int j = 0; j < J; ++j) z = fma(-bv[j], F[j], z);      // update_z (internal.hpp:144 / 187)
+            tZ[lane * Gm::SSTR + rt + r] = z;
+#pragma unroll
+            for (int j = 0; j < J; ++j) F[j] = p[j] * fma(av[j], z, F[j]);   // update_f, decay (internal.hpp:140-143)
+          } else {
+            double bG[J], z0 = yn;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+              z0 = fma(-bv[j], g[j], z0);
+              double sj = 0.0;
+#pragma unroll
+              for (int i = 0; i < J; ++i) sj = fma(bv[i], G[i][j], sj);
+              bG[j] = sj;
+            }
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+#pragma unroll
+              for (int j = 0; j < J; ++j) G[i][j] = p[i] * fma(-av[i], bG[j], G[i][j]);
+              g[i] = p[i] * fma(av[i], z0, g[i]);
+            }
+          }
+        }
+      }
+    }
+    if constexpr (APPLY) {
+      lds_order();
+      sw_flush_scalars<LOWER>(Z, io, r0, lane, tZ);
+    }
+  }
+}
+// chain over the chunks of a wavefront: F_start of every lane's chunk from the uniform F at entry; F at exit = after them
+template <int J>
+__device__ __forceinline__ void chain_affine(const double (&G)[J][J], const double (&g)[J], int steps, int lane, double (&F)[J],
+                                             double (&mine)[J]) {
+#pragma unroll
+  for (int j = 0; j < J; ++j) mine[j] = F[j];   // lane 0's chunk starts from the state at entry
+  for (int turn = 0; turn < steps; ++turn) {
+    double Fn[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      double gi = g[i];
+#pragma unroll
+      for (int j = 0; j < J; ++j) gi = fma(G[i][j], F[j], gi);
+      Fn[i] = gi;
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      F[i] = __shfl(Fn[i], turn, 64);
+      mine[i] = lane == turn + 1 ? F[i] : mine[i];
+    }
+  }
+}
+constexpr int sweep_lds_doubles(int J) { return 2 * 64 * 18 + 3 * 64 * 9; }
+
+// K <= 64: everything in one kernel (maps, chain in the wavefront, apply)
+template <int J, bool LOWER>
+__global__ __launch_bounds__(kThreads) void k_tps_fused(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                        const double *__restrict__ A, const double *__restrict__ Bm,
+                                                        const double *__restrict__ Y, double *Z) {
+  __shared__ __attribute__((aligned(16))) double lds[sweep_lds_doubles(J)];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y;
+  const SweepIO<LOWER> io{b * N, b * t_bs, N, K, 0};
+  int64_t k = lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  const int len = io.len(k);
+  double cj[J], G[J][J], g[J], F[J], mine[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; g[j] = 0.0; F[j] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) G[i][j] = i == j ? 1.0 : 0.0;
+  const double tstart = t[b * t_bs + io.row(k * kRows)];
+  sweep_pass<J, LOWER, false>(io, lane, len, tstart, cj, t, A, Bm, Y, Z, lds, G, g, F);
+  chain_affine<J>(G, g, (int)K - 1, lane, F, mine);
+  sweep_pass<J, LOWER, true>(io, lane, inr ? len : 0, tstart, cj, t, A, Bm, Y, Z, lds, G, g, mine);
+}
+// K > 64: maps -> scratch, chain (one wavefront per series), apply
+template <int J, bool LOWER>
+__global__ __launch_bounds__(kThreads) void k_tps_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                       int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                       const double *__restrict__ A, const double *__restrict__ Bm,
+                                                       const double *__restrict__ Y, double *__restrict__ scratch) {
+  __shared__ __attribute__((aligned(16))) double lds[sweep_lds_doubles(J)];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, Gn = B * K;
+  const SweepIO<LOWER> io{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = io.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  double cj[J], G[J][J], g[J], F[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; g[j] = 0.0; F[j] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) G[i][j] = i == j ? 1.0 : 0.0;
+  sweep_pass<J, LOWER, false>(io, lane, io.len(k), t[b * t_bs + io.row(k * kRows)], cj, t, A, Bm, Y, nullptr, lds, G, g, F);
+  if (!inr) return;
+  const int64_t gi = b * K + k;
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    scratch[(int64_t)(J * J + i) * Gn + gi] = g[i];
+#pragma unroll
+    for (int j = 0; j < J; ++j) scratch[(int64_t)(i * J + j) * Gn + gi] = G[i][j];
+  }
+}
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tps_chain(int64_t B, int64_t K, double *__restrict__ scratch) {
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x, Gn = B * K;
+  double F[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) F[j] = 0.0;
+  for (int64_t base = 0; base < K; base += kThreads) {
+    const int64_t kk = base + lane;
+    const bool have = kk < K;
+    const int64_t gi = b * K + (have ? kk : K - 1);
+    double G[J][J], g[J], mine[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      g[i] = scratch[(int64_t)(J * J + i) * Gn + gi];
+#pragma unroll
+      for (int j = 0; j < J; ++j) G[i][j] = scratch[(int64_t)(i * J + j) * Gn + gi];
+    }
+    const int steps = (int)((K - base) < kThreads ? (K - base) : kThreads);
+    chain_affine<J>(G, g, steps, lane, F, mine);   // F at exit: the state after this group's last chunk
+    if (have) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) scratch[(int64_t)(J * J + J + j) * Gn + gi] = mine[j];
+    }
+  }
+}
+template <int J, bool LOWER>
+__global__ __launch_bounds__(kThreads) void k_tps_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                        const double *__restrict__ A, const double *__restrict__ Bm,
+                                                        const double *__restrict__ Y, double *Z,
+                                                        const double *__restrict__ scratch) {
+  __shared__ __attribute__((aligned(16))) double lds[sweep_lds_doubles(J)];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, Gn = B * K;
+  const SweepIO<LOWER> io{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = io.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  double cj[J], G[J][J], g[J], F[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; g[j] = 0.0; F[j] = scratch[(int64_t)(J * J + J + j) * Gn + b * K + k]; }
+  sweep_pass<J, LOWER, true>(io, lane, inr ? io.len(k) : 0, t[b * t_bs + io.row(k * kRows)], cj, t, A, Bm, Y, Z, lds, G, g, F);
+}
+
+template <int J, bool LOWER>
+int run_solve(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *A,
+              const double *Bm, const double *Y, double *Z, double *scratch, hipStream_t s) {
+  const int64_t K = (N + kRows - 1) / kRows;
+  const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B);
+  if (K <= kThreads) {
+    hipLaunchKernelGGL((k_tps_fused<J, LOWER>), dim3(1, (unsigned)B), dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, A, Bm,
+                       Y, Z);
+  } else {
+    hipLaunchKernelGGL((k_tps_maps<J, LOWER>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, A, Bm, Y, scratch);
+    hipLaunchKernelGGL((k_tps_chain<J>), dim3((unsigned)B), dim3(kThreads), 0, s, B, K, scratch);
+    hipLaunchKernelGGL((k_tps_apply<J, LOWER>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, A, Bm, Y, Z,
+                       (const double *)scratch);
+  }
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
 }  // namespace c2tp
 
 extern "C" {
@@ -828,6 +1122,28 @@ int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const double *t,
   hipStream_t s = (hipStream_t)stream;
   if (J == 4) return c2tp::run_factor<4>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, guard, s);
   if (J == 2) return c2tp::run_factor<2>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, guard, s);
+  return C2_ERR_UNSUPPORTED;
+}
+
+// solve_lower (lower != 0) / solve_upper with one right-hand side, time-parallel (widths 2, 4, 8).  scratch: the doubles
+// c2_internal_timepar_solve_doubles returns (unused when N <= 4096).  Z may alias Y.
+size_t c2_internal_timepar_solve_doubles(int64_t B, int64_t N, int64_t J) {
+  if (J != 2 && J != 4 && J != 8) return 0;
+  const size_t K = (size_t)((N + c2tp::kRows - 1) / c2tp::kRows);
+  return K <= (size_t)c2tp::kThreads ? 2 : (size_t)(J * J + 2 * J) * (size_t)B * K;
+}
+int c2_internal_solve_timepar(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                              int64_t c_bs, const double *U, const double *W, const double *Y, double *Z,
+                              double *scratch, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  // lower: A (fed into the state) = W, B (applied to it) = U; upper: the other way round (internal.hpp:105-189)
+#define C2_TPS(J_)                                                                                              \
+  return lower ? c2tp::run_solve<J_, true>(B, N, t, t_bs, c, c_bs, W, U, Y, Z, scratch, s)                      \
+               : c2tp::run_solve<J_, false>(B, N, t, t_bs, c, c_bs, U, W, Y, Z, scratch, s)
+  if (J == 2) { C2_TPS(2); }
+  if (J == 4) { C2_TPS(4); }
+  if (J == 8) { C2_TPS(8); }
+#undef C2_TPS
   return C2_ERR_UNSUPPORTED;
 }
 

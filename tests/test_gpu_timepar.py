@@ -135,3 +135,42 @@ def test_timepar_factor_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     td, cd, Ud = dev(t, c, U)
     d2, W2, _ = ops.factor(td, cd, ad, Ud, Vd, d=ad, W=Vd)   # in place
     close(d2, d.cpu().numpy()); np.testing.assert_allclose(W2.cpu().numpy(), W.cpu().numpy(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("J", [8, 4, 2])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 131), (2, 4096), (9, 1000), (1, 30001), (2, 4100)])
+def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
+    """solve_lower / solve_upper with one right-hand side as chunked affine maps (k_tps_*): every row against the oracle,
+    out of place and in place, per-series and shared time grids."""
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    W = np.empty_like(V); d = np.empty_like(a)
+    for b in range(B):
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d[b], W[b]) == 0
+    Y = y[:, :, None].copy()
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    td, cd, Ud, Wd, Yd = dev(t, c, U, W, Y)
+    for name in ("solve_lower", "solve_upper"):
+        want = np.empty_like(Y)
+        for b in range(B):
+            zb = Y[b].copy()
+            getattr(oracle, name)(t[b], c[b], U[b], W[b], Y[b], zb)
+            want[b] = zb
+        got = getattr(ops, name)(td, cd, Ud, Wd, Yd)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
+        Zin = Yd.clone()
+        got2 = getattr(ops, name)(td, cd, Ud, Wd, Zin, Z=Zin)      # in place
+        np.testing.assert_allclose(got2.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
+        monkeypatch.setenv("C2_TIMEPAR", "0")
+        rows = getattr(ops, name)(td, cd, Ud, Wd, Yd)
+        monkeypatch.setenv("C2_TIMEPAR", "1")
+        np.testing.assert_allclose(got.cpu().numpy(), rows.cpu().numpy(), rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
+    # shared time grid and rates (the factorisation of series 0 applied to every right-hand side)
+    t0d, c0d = dev(t[0].copy(), c[0].copy())
+    U0 = np.tile(U[0], (B, 1, 1)); W0 = np.tile(W[0], (B, 1, 1))
+    U0d, W0d = dev(U0, W0)
+    want = np.empty_like(Y)
+    for b in range(B):
+        zb = Y[b].copy(); oracle.solve_lower(t[0], c[0], U[0], W[0], Y[b], zb); want[b] = zb
+    got = ops.solve_lower(t0d, c0d, U0d, W0d, Yd)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))

@@ -958,13 +958,13 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
                                           c2_stream_t stream);
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
-                             int32_t *flag, c2_stream_t stream) {
+                             int32_t *flag, int allow_timepar, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
   // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
   // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
-  if (capturing == hipStreamCaptureStatusNone && d != a && W != V && use_timepar(B, N, J)) {
+  if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && use_timepar(B, N, J)) {
     const size_t nd = c2_internal_timepar_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && hipMallocAsync(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {

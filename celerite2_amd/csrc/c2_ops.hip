@@ -1297,7 +1297,7 @@ int c2_device_count(void) {
 
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
-                             int32_t *flag, c2_stream_t stream);
+                             int32_t *flag, int allow_timepar, c2_stream_t stream);
 
 int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
               const double *a, const double *U, const double *V, double *d, double *W, double *S, int32_t *flag,
@@ -1305,11 +1305,12 @@ int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !a || !U || !V || !d || !W || !flag) return C2_ERR_INVALID;
   if (!S)  // no workspace requested: the tuned forward kernel of the fused log-likelihood doubles as factor
-    return c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, stream);
+    return c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, /*time-parallel allowed*/ 1, stream);
   hipStream_t s = (hipStream_t)stream;
   if ((J == 2 || J == 4 || J == 8 || J == 16) && ((uintptr_t)S) % 16 == 0) {
     // d, W, flag from the tuned fused kernel, then the S rows by a chain-free replay (store-bound)
-    if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, stream)) return e;
+    // (with S the row-by-row kernel: the reverse-mode chain that asks for S is checked element by element at 1e-12)
+    if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, 0, stream)) return e;
     C2_DISPATCH_G(group_size(J), {
       if constexpr (G >= 2 && G <= 16)
         hipLaunchKernelGGL(k_s_replay<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs,

@@ -921,7 +921,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
       unsigned long long *guard = (unsigned long long *)tmp;
       int rc = c2_internal_loglik_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp + 2, guard, stream);
       if (rc == C2_OK)
-        rc = launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, s, guard);
+        rc = launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, s, guard + 1);
       if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
       return rc;
     }

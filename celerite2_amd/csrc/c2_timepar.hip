@@ -18,7 +18,7 @@
 //    F_start, and one lane per series chains the chunks at the end (k_tp_finish).
 // Composite maps of long chunks are ill-conditioned (the recursion forgets its start; 1e-12 at 32 rows, 1e-7 at 128 on
 // the bench data), so the result is VERIFIED: a chunk's sequentially computed end state must match the next chunk's
-// start state; k_tp_finish writes the worst relative mismatch / 1e-10 into a device word and the ordinary kernel --
+// start state; k_tp_finish writes the worst relative mismatch / 2.5e-11 into a device word and the ordinary kernel --
 // launched behind it with that word as its gate (gate_closed, c2_loglik_helpers.hpp) -- recomputes the batch if it
 // exceeds kBackwardGuard (= 2) or if any factorisation failed.  numpy prototype: tools/proto/timepar.py.
 #include <hip/hip_runtime.h>
@@ -34,7 +34,10 @@ using namespace c2;
 
 constexpr int kRows = 64;        // rows per chunk
 constexpr int kThreads = 64;
-constexpr double kTol = 1e-10;   // chunk-start mismatch that counts as 1 on the guard word (fallback beyond 2)
+// chunk-start mismatch (relative to |S|) that counts as 1 on the guard word; fallback beyond 2, i.e. 5e-11.  Observed on the
+// bench data: 1e-12 .. 2e-11; a mismatch eps moves log d of a chunk's first rows by ~eps x signal / noise, so 5e-11 keeps
+// the log-likelihood inside 1e-10 relative with margin (measured agreement with the row-by-row kernels: 1e-13 .. 1e-12).
+constexpr double kTol = 2.5e-11;
 
 __host__ __device__ constexpr int nsym(int J) { return J * (J + 1) / 2; }
 __host__ __device__ constexpr int sidx(int J, int i, int j) { return i * J - i * (i - 1) / 2 + (j - i); }  // i <= j
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_maps(int64_t B, int64_t N, int6
                                                       double *__restrict__ starts,
                                                       unsigned long long *__restrict__ guard) {
   using Gm = Geo<J>;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *guard = 0ull;   // k_tp_finish (later in the stream) maxes into it
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { guard[0] = 0ull; guard[1] = 0ull; }   // maxed into later in the stream
   __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 2 * 64 * Gm::SSTR];
   double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR;
   const int lane = threadIdx.x;
@@ -431,11 +434,13 @@ __global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, in
                                                         const double *__restrict__ a, const double *__restrict__ U,
                                                         const double *__restrict__ V, const double *__restrict__ yv,
                                                         const double *__restrict__ starts, double *__restrict__ outs,
-                                                        double *__restrict__ ll, int32_t *__restrict__ flag,
-                                                        unsigned long long *__restrict__ guard) {
+                                                        double *__restrict__ ends, double *__restrict__ ll,
+                                                        int32_t *__restrict__ flag, unsigned long long *__restrict__ guard,
+                                                        const unsigned long long *__restrict__ gate) {
   using Gm = Geo<J>;
   constexpr int NS = nsym(J);
   __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 3 * 64 * Gm::SSTR];
+  if (gate_closed(gate)) return;   // (the refinement pass: runs only if the first pass failed its verification)
   double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR, *tY = tT + 64 * Gm::SSTR;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.y, G = B * K;
@@ -550,6 +555,13 @@ __global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, in
   int ex;
   prod = frexp(prod, &ex);
   const double logdet = log(prod) + (double)(eacc + ex) * 0.693147180559945309417;
+  if (ends) {   // this chunk's end state = its successor's start state for the refinement pass (contracted: good to rounding)
+    if (blockIdx.x == 0 && lane < NS) ends[(int64_t)lane * G + b * K] = 0.0;
+    if (inr && k + 1 < K) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) ends[(int64_t)q * G + g + 1] = S[q];
+    }
+  }
   if constexpr (FUSED) {
     double worst = 0.0;
     if (inr && k + 1 < K) worst = start_mismatch<J>(S, starts, G, g + 1);
@@ -714,8 +726,10 @@ template <int J>
 __global__ __launch_bounds__(kThreads) void k_tp_finish(int64_t B, int64_t N, int64_t K, const double *__restrict__ starts,
                                                         const double *__restrict__ outs, double *__restrict__ ll,
                                                         int32_t *__restrict__ flag,
-                                                        unsigned long long *__restrict__ guard) {
+                                                        unsigned long long *__restrict__ guard,
+                                                        const unsigned long long *__restrict__ gate) {
   constexpr int NS = nsym(J);
+  if (gate_closed(gate)) return;
   constexpr int oG = NS, og = NS + J * J, ol = og + J, oq1 = ol + 2, oQ2 = oq1 + J, of = oQ2 + NS;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x, G = B * K;
@@ -757,19 +771,29 @@ int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, in
   const int64_t K = (N + kRows - 1) / kRows, G = B * K;
   double *maps = work, *starts = maps + (size_t)Layout<J>::MAP * G, *outs = starts + (size_t)Layout<J>::START * G;
   const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);   // lane <-> chunk
+  // guard[0]: verification of the first pass; guard[1]: of the refinement pass, which runs only if the first one failed and
+  // starts every chunk from its predecessor's END state of the first pass (the recursion contracts the error of a start
+  // state: those are good to rounding).  The caller's row-by-row kernel sits behind guard[1].
+  double *ends = outs + (size_t)Layout<J>::OUT * G;
   if (K <= kThreads) {   // a wavefront holds every chunk of its series: two kernels, no maps / chunk results in memory
     hipLaunchKernelGGL((k_tp_maps<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
                        guard);
     hipLaunchKernelGGL((k_tp_chunks<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                       (const double *)starts, outs, ll, flag, guard);
+                       (const double *)starts, outs, ends, ll, flag, guard, (const unsigned long long *)nullptr);
+    hipLaunchKernelGGL((k_tp_chunks<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
+                       (const double *)ends, outs, (double *)nullptr, ll, flag, guard + 1, (const unsigned long long *)guard);
   } else {
     hipLaunchKernelGGL((k_tp_maps<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
                        guard);
     hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
     hipLaunchKernelGGL((k_tp_chunks<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                       (const double *)starts, outs, ll, flag, guard);
+                       (const double *)starts, outs, ends, ll, flag, guard, (const unsigned long long *)nullptr);
     hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)starts, (const double *)outs,
-                       ll, flag, guard);
+                       ll, flag, guard, (const unsigned long long *)nullptr);
+    hipLaunchKernelGGL((k_tp_chunks<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
+                       (const double *)ends, outs, (double *)nullptr, ll, flag, guard + 1, (const unsigned long long *)guard);
+    hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)ends, (const double *)outs, ll,
+                       flag, guard + 1, (const unsigned long long *)guard);
   }
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
@@ -1099,13 +1123,14 @@ extern "C" {
 size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 2 && J != 4) return 0;
   const size_t G = (size_t)B * (size_t)((N + c2tp::kRows - 1) / c2tp::kRows);
-  const size_t per = J == 4 ? (size_t)(c2tp::Layout<4>::MAP + c2tp::Layout<4>::START + c2tp::Layout<4>::OUT)
-                            : (size_t)(c2tp::Layout<2>::MAP + c2tp::Layout<2>::START + c2tp::Layout<2>::OUT);
+  const size_t per = J == 4 ? (size_t)(c2tp::Layout<4>::MAP + 2 * c2tp::Layout<4>::START + c2tp::Layout<4>::OUT)
+                            : (size_t)(c2tp::Layout<2>::MAP + 2 * c2tp::Layout<2>::START + c2tp::Layout<2>::OUT);
   return per * G;
 }
 
 // Forward log-likelihood, time-parallel.  `guard` (device word; the first kernel zeroes it) receives the
-// verification result; the caller launches the ordinary kernel behind it with `guard` as its gate.
+// verification results (two words: first pass, refinement pass); the caller launches the ordinary kernel behind it with
+// `guard + 1` as its gate.
 int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                double *ll, int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {

@@ -1,0 +1,304 @@
+// c2_general_tile.hip -- general_matmul_lower / general_matmul_upper (prediction products at new coordinates;
+// reference forward.hpp:285-332, 346-392) with ONE WAVEFRONT PER SERIES and lanes over 64 consecutive ROWS.
+//
+// The reference walks a two-pointer merge of the sorted grids t1 (N output rows) and t2 (M rows feeding the state):
+//     lower:  for each n:  while (t2[m] <= t1[n]) { F = p o F + V_m^T Y_m ; m++ }    p = exp(-c (t2[m] - t2[m-1]))
+//                          Z_n += (U_n o exp(-c (t1[n] - t2[m-1]))) F
+// (upper: the mirror image, from the far end).  The merge only decides WHICH state row an output reads; the state
+// recursion itself runs over the t2 grid alone and is linear with a diagonal transition.  So a wavefront takes the t2
+// rows 64 at a time -- lane i loads row s0 + i as one dense 64-byte run, the 64 states of the tile come out of an
+// inclusive scan over the lanes with the operator (p_a, f_a) o (p_b, f_b) = (p_a p_b, p_b f_a + f_b) (products of decay
+// factors only: nothing that can overflow), and go to LDS next to the tile's times.  The outputs whose state row lies
+// in the tile are a contiguous run of the t1 grid: they are taken 64 at a time as well, lane i finds its state row by
+// a binary search over the 64 times in LDS, reads that row and writes Z.  Both streams are consumed strictly in
+// order, tile by tile, so each is fetched one tile ahead and nobody ever waits for a row whose address depends on the
+// outcome of a comparison -- what bounded the event-per-iteration kernels (c2_general.hip: 0.9 us per event) and the
+// two-phase form (c2_ops.hip: a dependent binary search in global memory per output row).
+//
+// Walk coordinates: position s = 0 .. M-1 along the t2 stream, q = 0 .. N-1 along t1, walk time tau = t (lower) or -t
+// (upper: the walk starts at the far end).  "row s feeds output q"  <=>  tau2[s] <= tau1[q] (lower; forward.hpp:318),
+// tau2[s] < tau1[q] (upper; forward.hpp:378 absorbs while t2[m] > t1[n]).
+//
+// Workspace semantics as the reference: F[m, j * nrhs + k] (row-major), row m written when row m is absorbed, rows the
+// merge never reaches left untouched, array row 0 = V_0^T Y_0 (lower) / 0 unless absorbed (upper), the row the upper
+// walk starts from (M-1) never written.
+#include <cstdint>
+
+#include "c2_loglik_helpers.hpp"
+#include "../../include/celerite2_amd.h"
+
+namespace c2gt {
+using namespace c2;
+
+template <int JM, int KT>
+struct RowTile {       // lane i: one row of either stream
+  double tau;          // walk time (+inf beyond the end of the stream)
+  double w[JM];        // V row (t2 stream) / U row (t1 stream), zero-padded to JM
+  double x[KT];        // Y row / Z row (this block's right-hand sides)
+  double bound;        // t2 stream: walk time of the first row of the NEXT tile (+inf if there is none); uniform
+};
+
+template <int JM, int KT, bool LOWER, bool WF>
+__global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, int64_t M, int J, int64_t nrhs,
+                                                        const double *__restrict__ t1, int64_t t1_bs,
+                                                        const double *__restrict__ t2, int64_t t2_bs,
+                                                        const double *__restrict__ c, int64_t c_bs,
+                                                        const double *__restrict__ U, const double *__restrict__ V,
+                                                        const double *__restrict__ Y, double *Z, double *F) {
+  constexpr int NS = JM * KT;       // state entries per row
+  constexpr int LS = NS + 2;        // LDS row stride (doubles): 16-byte aligned, off the 64-byte bank period
+  __shared__ __attribute__((aligned(16))) double Ft[kWave][LS];
+  __shared__ double T2[kWave + 1];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const int64_t k0 = (int64_t)blockIdx.y * KT;
+  const int kn = (nrhs - k0 < KT) ? (int)(nrhs - k0) : KT;
+  const double *t1b = t1 + b * t1_bs, *t2b = t2 + b * t2_bs;
+  const double *Ub = U + b * N * J, *Vb = V + b * M * J;
+  const double *Yb = Y + b * M * nrhs + k0;
+  double *Zb = Z + b * N * nrhs + k0;
+  double *Fb = WF ? F + b * M * (int64_t)J * nrhs + k0 : nullptr;
+  const double inf = __builtin_huge_val();
+  double cj[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) cj[j] = j < J ? c[b * c_bs + j] : 0.0;
+  const bool dense = (J == JM);     // rows are 16-byte aligned runs of JM doubles
+  const bool xpair = (KT % 2 == 0) && kn == KT && (nrhs % 2 == 0);
+
+  auto rowN = [&](int64_t q) { return LOWER ? q : N - 1 - q; };
+  auto rowM = [&](int64_t s) { return LOWER ? s : M - 1 - s; };
+  auto load_rows = [&](RowTile<JM, KT> &R, const double *tb, const double *Wb, const double *Xb, int64_t len,
+                       int64_t pos0, auto row_of) {
+    const int64_t pos = pos0 + lane;
+    const bool valid = pos < len;
+    const int64_t r = row_of(valid ? pos : len - 1);
+    const double tv = tb[r];
+    R.tau = valid ? (LOWER ? tv : -tv) : inf;
+    const double *wr = Wb + r * J;
+    if (dense) {
+#pragma unroll
+      for (int j = 0; j < JM; j += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(wr + j);
+        R.w[j] = v.x; R.w[j + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < JM; ++j) R.w[j] = j < J ? wr[j] : 0.0;
+    }
+    const double *xr = Xb + r * nrhs;
+    if (xpair) {
+#pragma unroll
+      for (int k = 0; k < KT; k += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(xr + k);
+        R.x[k] = v.x; R.x[k + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) R.x[k] = k < kn ? xr[k] : 0.0;
+    }
+    if (!valid) {
+#pragma unroll
+      for (int j = 0; j < JM; ++j) R.w[j] = 0.0;
+    }
+  };
+  auto load_state_tile = [&](RowTile<JM, KT> &R, int64_t s0) {
+    load_rows(R, t2b, Vb, Yb, M, s0, rowM);
+    const int64_t sn = s0 + kWave;
+    const double tv = t2b[rowM(sn < M ? sn : M - 1)];
+    R.bound = sn < M ? (LOWER ? tv : -tv) : inf;
+  };
+  auto load_out_tile = [&](RowTile<JM, KT> &R, int64_t q0) {
+    load_rows(R, t1b, Ub, (const double *)Zb, N, q0, rowN);
+  };
+  // does a t2 row at walk time a feed an output at walk time o?
+  auto feeds = [&](double a, double o) { return LOWER ? a <= o : a < o; };
+
+  RowTile<JM, KT> Sc, Sn, Oc, On;
+  load_state_tile(Sc, 0);
+  load_out_tile(Oc, 0);
+  load_state_tile(Sn, kWave);
+  load_out_tile(On, kWave);
+
+  // the state carried into a tile is row 63 of the previous one, still in LDS when it is needed: zero before the first
+#pragma unroll
+  for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[lane][e]) = make_double2(0.0, 0.0);
+  lds_order();
+  double tauc = __shfl(Sc.tau, 0, kWave);   // walk time of the carried state; the first row decays by exp(0)
+  int64_t s0 = 0, q = 0, q0 = 0;  // tile origins; q = outputs consumed so far
+  int64_t s_end = -1;             // state row of the last output, once known
+  bool finished = false;
+
+  while (!finished) {
+    // ---- the 64 states of the tile: inclusive scan over the lanes -------------------------------------------------
+    const bool svalid = s0 + lane < M;
+    double tprev = __shfl_up(Sc.tau, 1, kWave);
+    if (lane == 0) tprev = tauc;
+    const double dt = svalid ? Sc.tau - tprev : 0.0;
+    double p[JM], f[NS];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      p[j] = svalid ? exp_decay(-cj[j] * dt) : 1.0;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) f[j * KT + k] = Sc.w[j] * Sc.x[k];   // zero on rows beyond the stream
+    }
+    // steps 1, 2, 4, 8 inside the rows of 16 lanes (DPP row_shr: a lane without a source reads 0), then the totals of
+    // the rows: rows 1 and 3 take lane 15 of the row before, rows 2 and 3 take lane 31
+    auto scan_step = [&](auto shift, bool has) {
+      double pp[JM], fp[NS];
+#pragma unroll
+      for (int j = 0; j < JM; ++j) pp[j] = shift(p[j]);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) fp[e] = shift(f[e]);
+      if (has) {
+#pragma unroll
+        for (int e = 0; e < NS; ++e) f[e] = fma(p[e / KT], fp[e], f[e]);
+#pragma unroll
+        for (int j = 0; j < JM; ++j) p[j] *= pp[j];
+      }
+    };
+    const int lr = lane & 15;
+    scan_step([](double x) { return dpp_mov<0x111>(x); }, lr >= 1);   // row_shr:1
+    scan_step([](double x) { return dpp_mov<0x112>(x); }, lr >= 2);
+    scan_step([](double x) { return dpp_mov<0x114>(x); }, lr >= 4);
+    scan_step([](double x) { return dpp_mov<0x118>(x); }, lr >= 8);
+    scan_step([&](double x) { return __shfl(x, (lane & 48) - 1, kWave); }, (lane & 16) != 0);
+    scan_step([](double x) { return __shfl(x, 31, kWave); }, lane >= 32);
+    {   // F_s = P_s o F_carry + f_s, s = s0 + lane
+      double Fc[NS];
+#pragma unroll
+      for (int e = 0; e < NS; e += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(&Ft[kWave - 1][e]);
+        Fc[e] = v.x; Fc[e + 1] = v.y;
+      }
+#pragma unroll
+      for (int e = 0; e < NS; ++e) f[e] = fma(p[e / KT], Fc[e], f[e]);
+    }
+    lds_order();   // the previous tile's readers are done
+#pragma unroll
+    for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[lane][e]) = make_double2(f[e], f[e + 1]);
+    T2[lane] = Sc.tau;
+    if (lane == 0) T2[kWave] = inf;
+    lds_order();
+    const double bound = Sc.bound;
+
+    // ---- outputs whose state row lies in this tile ---------------------------------------------------------------
+    while (true) {
+      const int done = (int)(q - q0);          // lanes of the output tile already served
+      const bool mine = lane >= done && q0 + lane < N && !feeds(bound, Oc.tau);
+      const int cnt = __popcll(__ballot(mine));
+      int pos = 0;                              // number of tile rows feeding this output
+#pragma unroll
+      for (int step = kWave / 2; step >= 1; step >>= 1)
+        if (feeds(T2[pos + step - 1], Oc.tau)) pos += step;
+      if (feeds(T2[pos], Oc.tau)) pos += 1;     // pos <= 64 only for rows that are not `mine`
+      const int idx = mine ? pos - 1 : -1;      // -1: an output ahead of the first t2 row (forward.hpp:303-306)
+      if (idx >= 0) {
+        const double dq = Oc.tau - T2[idx];
+        double z[KT];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) z[k] = Oc.x[k];
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+          const double w = Oc.w[j] * exp_decay(-cj[j] * dq);
+#pragma unroll
+          for (int k = 0; k < KT; ++k) z[k] = fma(w, Ft[idx][j * KT + k], z[k]);
+        }
+        double *zr = Zb + rowN(q0 + lane) * nrhs;
+        if (xpair) {
+#pragma unroll
+          for (int k = 0; k < KT; k += 2) *reinterpret_cast<double2 *>(zr + k) = make_double2(z[k], z[k + 1]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < KT; ++k)
+            if (k < kn) zr[k] = z[k];
+        }
+      }
+      q += cnt;
+      if (q == N) {                             // the last output fixes the last row the merge absorbs
+        finished = true;
+        s_end = cnt > 0 ? s0 + __shfl(idx, done + cnt - 1, kWave) : s_end;
+        break;
+      }
+      if (q - q0 < kWave) break;                // the next output belongs to a later tile
+      Oc = On;
+      q0 += kWave;
+      load_out_tile(On, q0 + kWave);
+    }
+    if (!finished) s_end = s0 + kWave - 1;      // outputs remain: they absorb every row of this tile
+
+    if (WF) {   // rows the merge absorbed (row 0 of the walk: stored by the lower variant only)
+      const int64_t s = s0 + lane;
+      if (svalid && (s == 0 ? LOWER : s <= s_end)) {
+        double *fr = Fb + rowM(s) * (int64_t)J * nrhs;
+#pragma unroll
+        for (int j = 0; j < JM; ++j) {
+          if (j < J) {
+            if (xpair) {
+#pragma unroll
+              for (int k = 0; k < KT; k += 2)
+                *reinterpret_cast<double2 *>(fr + (int64_t)j * nrhs + k) = make_double2(f[j * KT + k], f[j * KT + k + 1]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < KT; ++k)
+                if (k < kn) fr[(int64_t)j * nrhs + k] = f[j * KT + k];
+            }
+          }
+        }
+      }
+    }
+    // ---- next tile (the carry stays in LDS) -----------------------------------------------------------------------
+    tauc = T2[kWave - 1];
+    s0 += kWave;
+    Sc = Sn;
+    load_state_tile(Sn, s0 + kWave);
+  }
+  if (WF && !LOWER && lane == 0 && !(s_end >= M - 1 && M >= 2)) {   // F.row(0).setZero() (forward.hpp:358)
+    for (int j = 0; j < J; ++j)
+      for (int k = 0; k < kn; ++k) Fb[(int64_t)j * nrhs + k] = 0.0;
+  }
+}
+
+}  // namespace c2gt
+
+using namespace c2gt;
+
+// lower != 0: general_matmul_lower, else upper; Z is accumulated into (the caller zeroes it when asked to).  Returns
+// C2_ERR_UNSUPPORTED for shapes the mapping does not cover.
+extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs,
+                                        const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c,
+                                        int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
+                                        double *F, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (J > 16 || B > 0x7fffffffLL) return C2_ERR_UNSUPPORTED;   // wider rows: four row tiles no longer fit the registers
+  const int JM = J <= 4 ? 4 : (J <= 8 ? 8 : 16);
+  const int KT = nrhs == 1 ? 1 : (nrhs == 2 || JM == 16 ? 2 : 4);
+  const int64_t ytiles = (nrhs + KT - 1) / KT;
+  if (ytiles > 65535) return C2_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)B, (unsigned)ytiles);
+#define C2_GT2(JM_, KT_, LO, WF_)                                                                                   \
+  hipLaunchKernelGGL((k_general_tile<JM_, KT_, LO, WF_>), grid, dim3(kWave), 0, s, B, N, M, (int)J, nrhs, t1, t1_bs, \
+                     t2, t2_bs, c, c_bs, U, V, Y, Z, F)
+#define C2_GT1(JM_, KT_)                                      \
+  do {                                                        \
+    if (lower) { if (F) C2_GT2(JM_, KT_, true, true); else C2_GT2(JM_, KT_, true, false); }    \
+    else       { if (F) C2_GT2(JM_, KT_, false, true); else C2_GT2(JM_, KT_, false, false); }  \
+  } while (0)
+#define C2_GT(JM_)                                  \
+  do {                                              \
+    if (KT == 1) C2_GT1(JM_, 1);                    \
+    else if (KT == 2) C2_GT1(JM_, 2);               \
+    else C2_GT1(JM_, 4);                            \
+  } while (0)
+  switch (JM) {
+    case 4: C2_GT(4); break;
+    case 8: C2_GT(8); break;
+    default:
+      if (KT == 1) C2_GT1(16, 1);
+      else C2_GT1(16, 2);
+      break;
+  }
+#undef C2_GT
+#undef C2_GT1
+#undef C2_GT2
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}

@@ -1199,6 +1199,14 @@ extern "C" int c2_internal_generalK(int lower, int64_t B, int64_t N, int64_t M, 
                                     int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c, int64_t c_bs,
                                     const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z,
                                     c2_stream_t stream);
+extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs,
+                                        const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c,
+                                        int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
+                                        double *F, c2_stream_t stream);
+static bool use_general_tile() {
+  const char *e = getenv("C2_GENERAL_TILE");  // C2_GENERAL_TILE=0: the kernels below (A/B runs, tests of every path)
+  return !(e && e[0] == '0');
+}
 static bool use_generalK() {
   const char *e = getenv("C2_GENERALK");  // C2_GENERALK=0: the first-round kernels (A/B runs, tests of both paths)
   return !(e && e[0] == '0');
@@ -1212,6 +1220,12 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   hipStream_t s = (hipStream_t)stream;
   if (zero_z) {
     if (int e = hip_check(hipMemsetAsync(Z, 0, sizeof(double) * B * N * nrhs, s))) return e;
+  }
+  // a wavefront per series, lanes over 64 consecutive rows of either grid (c2_general_tile.hip)
+  if (use_general_tile()) {
+    const int e = c2_internal_general_tile(LOWER ? 1 : 0, B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F,
+                                           stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
   }
   // three or more right-hand sides: lanes over the right-hand sides, one merge event per iteration (c2_general.hip)
   if (nrhs >= 3 && use_generalK()) {

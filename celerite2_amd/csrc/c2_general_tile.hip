@@ -47,8 +47,11 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
                                                         const double *__restrict__ Y, double *Z, double *F) {
   constexpr int NS = JM * KT;       // state entries per row
   constexpr int LS = NS + 2;        // LDS row stride (doubles): 16-byte aligned, off the 64-byte bank period
-  __shared__ __attribute__((aligned(16))) double Ft[kWave][LS];
-  __shared__ double T2[kWave + 1];
+  // a window of TWO tiles (ring: row s lives at s mod 128), so that 64 consecutive outputs whose state rows straddle a
+  // tile boundary -- the usual case when the grids are about equally dense -- are served in one pass, not two
+  constexpr int kWin = 2 * kWave;
+  __shared__ __attribute__((aligned(16))) double Ft[kWin][LS];
+  __shared__ double T2[kWin];
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
   const int64_t k0 = (int64_t)blockIdx.y * KT;
@@ -119,9 +122,11 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
   load_state_tile(Sn, kWave);
   load_out_tile(On, kWave);
 
-  // the state carried into a tile is row 63 of the previous one, still in LDS when it is needed: zero before the first
+  // the state carried into a tile is the last row of the previous one, still in LDS when it is needed: zero before the
+  // first tile, whose predecessors in the window "feed" every output (time -inf) and carry no state
 #pragma unroll
-  for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[lane][e]) = make_double2(0.0, 0.0);
+  for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[kWave + lane][e]) = make_double2(0.0, 0.0);
+  T2[kWave + lane] = -inf;
   lds_order();
   double tauc = __shfl(Sc.tau, 0, kWave);   // walk time of the carried state; the first row decays by exp(0)
   int64_t s0 = 0, q = 0, q0 = 0;  // tile origins; q = outputs consumed so far
@@ -167,33 +172,33 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
       double Fc[NS];
 #pragma unroll
       for (int e = 0; e < NS; e += 2) {
-        const double2 v = *reinterpret_cast<const double2 *>(&Ft[kWave - 1][e]);
+        const double2 v = *reinterpret_cast<const double2 *>(&Ft[(s0 - 1) & (kWin - 1)][e]);
         Fc[e] = v.x; Fc[e + 1] = v.y;
       }
 #pragma unroll
       for (int e = 0; e < NS; ++e) f[e] = fma(p[e / KT], Fc[e], f[e]);
     }
-    lds_order();   // the previous tile's readers are done
+    lds_order();   // the readers of the tile before the previous one are done
+    const int slot = (int)(s0 & (kWin - 1));
 #pragma unroll
-    for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[lane][e]) = make_double2(f[e], f[e + 1]);
-    T2[lane] = Sc.tau;
-    if (lane == 0) T2[kWave] = inf;
+    for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[slot + lane][e]) = make_double2(f[e], f[e + 1]);
+    T2[slot + lane] = Sc.tau;
     lds_order();
     const double bound = Sc.bound;
+    const int woff = slot ^ kWave;   // ring position of the window's first row, s0 - 64
 
-    // ---- outputs whose state row lies in this tile ---------------------------------------------------------------
-    while (true) {
-      const int done = (int)(q - q0);          // lanes of the output tile already served
-      const bool mine = lane >= done && q0 + lane < N && !feeds(bound, Oc.tau);
-      const int cnt = __popcll(__ballot(mine));
-      int pos = 0;                              // number of tile rows feeding this output
+    // ---- outputs ----------------------------------------------------------------------------------------------------
+    // serve the lanes in `mine` from the window; returns the state row (walk position) of lane `last`
+    auto serve = [&](bool mine, int last) {
+      int pos = 0;                              // number of window rows feeding this output
 #pragma unroll
-      for (int step = kWave / 2; step >= 1; step >>= 1)
-        if (feeds(T2[pos + step - 1], Oc.tau)) pos += step;
-      if (feeds(T2[pos], Oc.tau)) pos += 1;     // pos <= 64 only for rows that are not `mine`
-      const int idx = mine ? pos - 1 : -1;      // -1: an output ahead of the first t2 row (forward.hpp:303-306)
-      if (idx >= 0) {
-        const double dq = Oc.tau - T2[idx];
+      for (int step = kWin / 2; step >= 1; step >>= 1)
+        if (feeds(T2[(pos + step - 1 + woff) & (kWin - 1)], Oc.tau)) pos += step;
+      if (feeds(T2[(pos + woff) & (kWin - 1)], Oc.tau)) pos += 1;   // reaches 128 only on lanes that are not `mine`
+      const int64_t srow = s0 - kWave + pos - 1;      // < 0: an output ahead of the first t2 row (forward.hpp:303-306)
+      if (mine && srow >= 0) {
+        const int ri = (pos - 1 + woff) & (kWin - 1);
+        const double dq = Oc.tau - T2[ri];
         double z[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) z[k] = Oc.x[k];
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
         for (int j = 0; j < JM; ++j) {
           const double w = Oc.w[j] * exp_decay(-cj[j] * dq);
 #pragma unroll
-          for (int k = 0; k < KT; ++k) z[k] = fma(w, Ft[idx][j * KT + k], z[k]);
+          for (int k = 0; k < KT; ++k) z[k] = fma(w, Ft[ri][j * KT + k], z[k]);
         }
         double *zr = Zb + rowN(q0 + lane) * nrhs;
         if (xpair) {
@@ -213,16 +218,35 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
             if (k < kn) zr[k] = z[k];
         }
       }
-      q += cnt;
+      return (int64_t)__shfl((long long)srow, last, kWave);
+    };
+    while (true) {
+      // every output left in the tile has its state row in the window or beyond it (those further back were served
+      // before their rows left the window).  If the tile's LAST output does not reach beyond, serve the whole rest.
+      const int done = (int)(q - q0);          // lanes of the output tile already served
+      const int nv = (N - q0 < kWave) ? (int)(N - q0) : kWave;
+      const bool all_in = !feeds(bound, __shfl(Oc.tau, nv - 1, kWave));
+      if (!all_in) break;
+      const int64_t sl = serve(lane >= done && lane < nv, nv - 1);
+      q = q0 + nv;
       if (q == N) {                             // the last output fixes the last row the merge absorbs
         finished = true;
-        s_end = cnt > 0 ? s0 + __shfl(idx, done + cnt - 1, kWave) : s_end;
+        s_end = sl;
         break;
       }
-      if (q - q0 < kWave) break;                // the next output belongs to a later tile
       Oc = On;
       q0 += kWave;
       load_out_tile(On, q0 + kWave);
+    }
+    if (!finished) {
+      // outputs whose state row lies in the OLDER tile of the window: its rows are overwritten next
+      const int done = (int)(q - q0);
+      const bool mine = lane >= done && q0 + lane < N && !feeds(T2[slot], Oc.tau);
+      const int cnt = __popcll(__ballot(mine));
+      if (cnt > 0) {
+        (void)serve(mine, 0);
+        q += cnt;
+      }
     }
     if (!finished) s_end = s0 + kWave - 1;      // outputs remain: they absorb every row of this tile
 
@@ -230,6 +254,10 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
       const int64_t s = s0 + lane;
       if (svalid && (s == 0 ? LOWER : s <= s_end)) {
         double *fr = Fb + rowM(s) * (int64_t)J * nrhs;
+        if (dense && nrhs == KT) {   // the whole row in one run, laid out as the registers are
+#pragma unroll
+          for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(fr + e) = make_double2(f[e], f[e + 1]);
+        } else
 #pragma unroll
         for (int j = 0; j < JM; ++j) {
           if (j < J) {
@@ -247,7 +275,7 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
       }
     }
     // ---- next tile (the carry stays in LDS) -----------------------------------------------------------------------
-    tauc = T2[kWave - 1];
+    tauc = T2[slot + kWave - 1];
     s0 += kWave;
     Sc = Sn;
     load_state_tile(Sn, s0 + kWave);
@@ -271,7 +299,10 @@ extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t
   hipStream_t s = (hipStream_t)stream;
   if (J > 16 || B > 0x7fffffffLL) return C2_ERR_UNSUPPORTED;   // wider rows: four row tiles no longer fit the registers
   const int JM = J <= 4 ? 4 : (J <= 8 ? 8 : 16);
-  const int KT = nrhs == 1 ? 1 : (nrhs == 2 || JM == 16 ? 2 : 4);
+  // one pass over the rows per tile of KT right-hand sides: beyond one tile the lanes-over-right-hand-sides kernel
+  // (c2_general.hip) does less redundant work (nrhs = 8: 7.2 ms either way, 19.6 against 11.5 ms with the F rows)
+  if (nrhs > (JM == 16 ? 2 : 4)) return C2_ERR_UNSUPPORTED;
+  const int KT = nrhs == 1 ? 1 : (nrhs == 2 ? 2 : 4);
   const int64_t ytiles = (nrhs + KT - 1) / KT;
   if (ytiles > 65535) return C2_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)B, (unsigned)ytiles);

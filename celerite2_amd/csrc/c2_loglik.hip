@@ -830,7 +830,7 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
 #ifndef C2_LANES1_MIN_BATCH_GRAD
 #define C2_LANES1_MIN_BATCH_GRAD 24576
 #endif
-// the same kernels compiled per width (c2_loglik_t.hip with C2T_J = 8, 4, 2)
+// the same kernels compiled per width (c2_loglik_t.hip with C2T_J = 8, 4, 2; 6 as 8 with two empty columns)
 #define C2_DECL_T(J_)                                                                                                  \
   extern "C" int c2_internal_loglik_t##J_(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,       \
                                           int64_t c_bs, const double *a, const double *U, const double *V,           \
@@ -842,12 +842,14 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
                                                double *bU, double *bV, double *by, int32_t *flag, double *rec,       \
                                                unsigned long long *guard, c2_stream_t stream);
 C2_DECL_T(8)
+C2_DECL_T(6)   // rows of 6 in memory, computed as rows of 8 (c2_loglik_t6.hip)
 C2_DECL_T(4)
 C2_DECL_T(2)
 #undef C2_DECL_T
 static size_t lanes1_record_doubles(int64_t B, int64_t N, int64_t J) {
   return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
-                : (J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N));
+       : J == 6 ? c2_internal_loglik_t_record_doubles6(B, N)
+       : J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N);
 }
 // Time-parallel forward pass (c2_timepar.hip; widths 4 and 2): batches too small to fill the chip row by row -- below the
 // one-lane threshold -- of series long enough to cut into chunks.  C2_TIMEPAR=1 forces it, =0 disables it.
@@ -880,11 +882,14 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   return N >= C2_TIMEPAR_MIN_ROWS && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
-  if (J != 8 && J != 4 && J != 2) return false;
+  if (J != 8 && J != 6 && J != 4 && J != 2) return false;
   const char *e = getenv("C2_LANES");
   const int forced = e ? atoi(e) : 0;
   if (forced == 1) return true;
   if (forced == 4 || forced == 8) return false;
+  // width 6 (rows of 48 bytes: no aligned 128-byte runs) draws level later: gradient 18.5 vs 20.7 ms at 32768 series,
+  // 17.2 vs 15.8 ms at 24576; 31.7 vs 41.6 ms at 65536 (forward 7.5 vs 10.8 ms)
+  if (grad && J == 6) return B >= 32768;
   return B >= (grad ? C2_LANES1_MIN_BATCH_GRAD : C2_LANES1_MIN_BATCH_FWD);
 }
 
@@ -904,6 +909,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
   if (use_lanes1(B, J, false)) {
     if (J == 8) return c2_internal_loglik_t8(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
+    if (J == 6) return c2_internal_loglik_t6(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
     if (J == 4) return c2_internal_loglik_t4(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
     return c2_internal_loglik_t2(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   }
@@ -1016,7 +1022,9 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
     unsigned long long *guard = (unsigned long long *)work;
     if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
     work = (double *)work + 2;
-    auto one_lane = J == 8 ? c2_internal_loglik_t_grad8 : (J == 4 ? c2_internal_loglik_t_grad4 : c2_internal_loglik_t_grad2);
+    auto one_lane = J == 8 ? c2_internal_loglik_t_grad8
+                  : J == 6 ? c2_internal_loglik_t_grad6
+                  : J == 4 ? c2_internal_loglik_t_grad4 : c2_internal_loglik_t_grad2;
     if (int e = one_lane(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, (double *)work, guard,
                          stream))
       return e;

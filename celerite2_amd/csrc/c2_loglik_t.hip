@@ -1,5 +1,6 @@
 // c2_loglik_t.hip -- fused log-likelihood (+ reverse-mode gradient) with ONE LANE PER SERIES, for batches large
-// enough to fill the chip that way (>= 24576 series).  Widths J = 8, 4, 2 (one compilation each: C2T_J).
+// enough to fill the chip that way (>= 24576 series).  Widths J = 8, 4, 2 (one compilation each: C2T_J) and 6 (computed
+// as 8 with two empty columns: C2T_JS).
 //
 // Why a second mapping.  The group-of-8-lanes kernels (c2_loglik.hip) spend more than half of their issued VALU work
 // on moving width-J vectors between the lanes of a group (DPP gathers, butterflies, scalars replicated 8x): ~300
@@ -27,13 +28,19 @@
 
 // The file is compiled once per width: C2T_J = 8 (default), 4, 2 (c2_loglik_t4.hip / c2_loglik_t2.hip include it).  A
 // tile of the width-J streams is always ONE 128-byte line per series: RT = 16 / J rows.
+// C2T_JS < C2T_J (c2_loglik_t6.hip: 6 in 8): the arrays in memory have rows of JS doubles, the lane computes on rows of
+// J with the missing columns zero (U = V = c = 0: they decouple, P = 1 keeps them zero) -- only the tile movers and the
+// loads of c know.  Rows of 48 bytes do not tile a 128-byte line, so the runs are no longer aligned lines.
 #ifndef C2T_J
 #define C2T_J 8
 #endif
+#ifndef C2T_JS
+#define C2T_JS C2T_J
+#endif
 #define C2T_CAT2(a, b) a##b
 #define C2T_CAT(a, b) C2T_CAT2(a, b)
-#define C2T_NAME(stem) C2T_CAT(stem, C2T_J)   // c2_internal_loglik_t -> c2_internal_loglik_t8
-#define c2t C2T_CAT(c2t_j, C2T_J)             // one namespace per width
+#define C2T_NAME(stem) C2T_CAT(stem, C2T_JS)  // c2_internal_loglik_t -> c2_internal_loglik_t8
+#define c2t C2T_CAT(c2t_j, C2T_JS)            // one namespace per width
 
 namespace c2t {
 using namespace c2;
@@ -42,6 +49,12 @@ constexpr int J = C2T_J;
 static_assert(J == 8 || J == 4 || J == 2, "128-byte tiles of whole rows");
 constexpr int NS = J * (J + 1) / 2;  // packed symmetric J x J
 constexpr int PPR = J / 2;           // 16-byte pieces per row
+constexpr int JS = C2T_JS;           // row length of the arrays in memory
+static_assert(JS <= J && JS % 2 == 0, "whole 16-byte pieces");
+constexpr int PPS = JS / 2;          // pieces of a row that exist in memory
+// offset (doubles) of piece p of a tile of RT rows inside a series, and whether the piece exists
+__device__ __forceinline__ constexpr int piece_off(int p) { return (p / PPR) * JS + 2 * (p % PPR); }
+__device__ __forceinline__ constexpr bool piece_in(int p) { return JS == J || (p % PPR) < PPS; }
 #ifndef C2T_C
 #define C2T_C 32
 #endif
@@ -109,11 +122,12 @@ __device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64
                                           double (&st)[2 * NI]) {
   int64_t r = n0 + io.rpiece / PPR;
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
-  const int64_t off = r * J + 2 * (io.rpiece % PPR);
+  const int pc = piece_in(io.rpiece) ? io.rpiece % PPR : 0;   // a missing piece reads piece 0 and is zeroed
+  const int64_t off = r * JS + 2 * pc;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)io.rl(i) * N * J + off);
-    st[2 * i] = v.x; st[2 * i + 1] = v.y;
+    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)io.rl(i) * N * JS + off);
+    st[2 * i] = piece_in(io.rpiece) ? v.x : 0.0; st[2 * i + 1] = piece_in(io.rpiece) ? v.y : 0.0;
   }
 }
 // registers -> LDS tile
@@ -145,8 +159,9 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int s = (kWave / LPS) * i + lane / LPS;
-      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece % PPR)) =
-          *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
+      if (piece_in(piece))
+        *reinterpret_cast<double2 *>(base + (int64_t)s * N * JS + r * JS + 2 * (piece % PPR)) =
+            *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
     }
     return;
   }
@@ -154,8 +169,8 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
   for (int i = 0; i < NI; ++i) {
     const int s = (kWave / LPS) * i + lane / LPS;
     const double2 v = *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
-    if (s <= last && r >= lo && r <= hi)
-      *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + r * J + 2 * (piece % PPR)) = v;
+    if (s <= last && r >= lo && r <= hi && piece_in(piece))
+      *reinterpret_cast<double2 *>(base + (int64_t)s * N * JS + r * JS + 2 * (piece % PPR)) = v;
   }
 }
 
@@ -163,12 +178,13 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
 __device__ __forceinline__ void row_flush_full(double *__restrict__ base, int64_t N, int64_t n0, const double *tile,
                                                int lane) {
   const int piece = lane % LPS;
-  const int64_t off = (n0 + piece / PPR) * J + 2 * (piece % PPR);
+  const int64_t off = (n0 + piece / PPR) * JS + 2 * (piece % PPR);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int s = (kWave / LPS) * i + lane / LPS;
-    *reinterpret_cast<double2 *>(base + (int64_t)s * N * J + off) =
-        *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
+    if (piece_in(piece))
+      *reinterpret_cast<double2 *>(base + (int64_t)s * N * JS + off) =
+          *reinterpret_cast<const double2 *>(tile + s * RSTR + 2 * piece);
   }
 }
 
@@ -390,7 +406,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   const int64_t b = b0 + sl;
   const RowIO io(lane, last);
   double *tU = lds, *tV = tU + kWave * RSTR, *tT = tV + kWave * RSTR, *tA = tT + kWave * SSTR, *tY = tA + kWave * SSTR;
-  const double *Ub = U + b0 * N * J, *Vb = V + b0 * N * J, *ab = a + b0 * N, *yb = y + b0 * N;
+  const double *Ub = U + b0 * N * JS, *Vb = V + b0 * N * JS, *ab = a + b0 * N, *yb = y + b0 * N;
   // shared t: every series reads the same grid (stride 0 between series)
   const double *tb = t + (t_bs ? b0 * N : 0);
   const int64_t tN = t_bs ? N : 0;  // series stride of t
@@ -400,7 +416,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   if constexpr (TERMS) tc.load(T, b, cj);
   else {
 #pragma unroll
-    for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+    for (int j = 0; j < J; ++j) cj[j] = j < JS ? c[b * c_bs + j] : 0.0;
   }
   double cmax = 0.0;
 #pragma unroll
@@ -428,7 +444,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
     for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = v0[j] * rd; }
   } else {
 #pragma unroll
-    for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = V[b * N * J + j] * rd; }
+    for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = j < JS ? V[b * N * JS + j] * rd : 0.0; }
   }
   double prod = d, quad = z * z * rd;
   int eacc = 0;
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_fwd(int64_t B, int64_t N,
   const int64_t bb = (b0 + lane) < B ? (b0 + lane) : (B - 1);
   bool paired = true;
 #pragma unroll
-  for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
+  for (int k = 0; k < JS / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
   if (__all(paired))
     fwd_body<REC, true>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
   else
@@ -651,8 +667,9 @@ __device__ __forceinline__ void row1_flush(double *__restrict__ base, int64_t N,
 #pragma unroll
   for (int i = 0; i < PPR; ++i) {   // an instruction moves 64 / PPR series x one row
     int sr = (kWave / PPR) * i + lane / PPR; sr = sr < last ? sr : last;
-    *reinterpret_cast<double2 *>(base + ((int64_t)sr * N + n) * J + 2 * (lane % PPR)) =
-        *reinterpret_cast<const double2 *>(tile + sr * RS1 + 2 * (lane % PPR));
+    if (piece_in(lane % PPR))
+      *reinterpret_cast<double2 *>(base + ((int64_t)sr * N + n) * JS + 2 * (lane % PPR)) =
+          *reinterpret_cast<const double2 *>(tile + sr * RS1 + 2 * (lane % PPR));
   }
 }
 
@@ -704,8 +721,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
          *tBT = tBY + kWave * SSTR, *tC = tBT + kWave * SSTR, *tBC = tC + kWave * CSTR;
   static_assert((kWave * RSTR + kWave * (BVPAIR ? RSTR : RS1) + 3 * kWave * SSTR + kWave * CSTR + kWave * RS1) * 8 <= kRevLds, "LDS");
   double *tACC = lds;   // coefficient-level form: takes the place of the U tile (64 x 14 <= 64 x 18 doubles)
-  const double *Ub = U + b0 * N * J;
-  double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
+  const double *Ub = U + b0 * N * JS;
+  double *bUb = bU + b0 * N * JS, *bVb = bV + b0 * N * JS, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
   const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave);
   const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave;
@@ -721,7 +738,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     if constexpr (TERMS) tc.load(T, b, cj);
     else {
 #pragma unroll
-      for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+      for (int j = 0; j < J; ++j) cj[j] = j < JS ? c[b * c_bs + j] : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < J; ++j) zero[j] = 0.0;
@@ -1038,7 +1055,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
           for (int i = 0; i < PPR; ++i) {
             int sr = (kWave / PPR) * i + lane / PPR; sr = (FULL || sr < last) ? sr : last;
-            st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane % PPR)), make_double2(fv[2 * i], fv[2 * i + 1]));
+            if (piece_in(lane % PPR))
+              st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * JS + 2 * (lane % PPR)), make_double2(fv[2 * i], fv[2 * i + 1]));
           }
         } else if constexpr (BVOUT) {
           // rows n-1 .. n-1+RT-1; at J = 8 (pairs) row n always exists, wider tiles may reach beyond the series at the top
@@ -1046,7 +1064,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
-              st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * J + 2 * (lane & 7)), make_double2(fv[2 * i], fv[2 * i + 1]));
+              if (piece_in(lane & 7))
+                st2_stream(reinterpret_cast<double2 *>(bVb + ((int64_t)sr * N + n - 1) * JS + piece_off(lane & 7)), make_double2(fv[2 * i], fv[2 * i + 1]));
             }
           }
         }
@@ -1055,7 +1074,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               int sr = 8 * i + lane / 8; sr = (FULL || sr < last) ? sr : last;
-              st2_stream(reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * J + 2 * (lane & 7)), make_double2(fu[2 * i], fu[2 * i + 1]));
+              if (piece_in(lane & 7))
+                st2_stream(reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N + n) * JS + piece_off(lane & 7)), make_double2(fu[2 * i], fu[2 * i + 1]));
             }
           }
         }
@@ -1119,8 +1139,9 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             int sr = 8 * i + lane / 8; sr = sr < last ? sr : last;
-            *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N) * J + 2 * (lane & 7)) =
-                *reinterpret_cast<const double2 *>(tU + sr * RSTR + 2 * (lane & 7));
+            if (piece_in(lane & 7))
+              *reinterpret_cast<double2 *>(bUb + ((int64_t)sr * N) * JS + piece_off(lane & 7)) =
+                  *reinterpret_cast<const double2 *>(tU + sr * RSTR + 2 * (lane & 7));
           }
         }
       }
@@ -1139,7 +1160,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < J; ++j) { bUb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)lane * N * J + j] = failed ? nan : 0.0; }
+        for (int j = 0; j < JS; ++j) { bUb[(int64_t)lane * N * JS + j] = failed ? nan : 0.0; bVb[(int64_t)lane * N * JS + j] = failed ? nan : 0.0; }
       }
     }
   }
@@ -1160,7 +1181,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < J; ++j) bc[b * J + j] = bcj[j];
+      for (int j = 0; j < JS; ++j) bc[b * JS + j] = bcj[j];
     }
   }
 }
@@ -1181,7 +1202,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_rev(int64_t B, int64_t N,
   const int64_t bb = (b0 + lane) < B ? (b0 + lane) : (B - 1);
   bool paired = true;
 #pragma unroll
-  for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
+  for (int k = 0; k < JS / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
   const bool full = b0 + kWave <= B;
   if (__all(paired)) {
     if (full) rev_body<true, -1, true, true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
@@ -1261,12 +1282,14 @@ int C2T_NAME(c2_internal_loglik_tt)(int64_t B, int64_t N, int64_t Jc, int coef_b
   hipLaunchKernelGGL((k_loglik_tt_fwd<JC_, false>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, x, x_bs, T, diag, y, \
                      ll, flag, (double *)nullptr, R, (unsigned long long *)nullptr)
   switch (Jc) {
+#if C2T_JS == C2T_J   // the padded build serves the matrix-level entry points only
     case 0: C2_TT(0); break;
     case 1: C2_TT(1); break;
-#if C2T_J >= 4
+#endif
+#if C2T_J >= 4 && C2T_JS == C2T_J
     case 2: C2_TT(2); break;
 #endif
-#if C2T_J >= 8
+#if C2T_J >= 8 && C2T_JS == C2T_J
     case 3: C2_TT(3); break;
     case 4: C2_TT(4); break;
 #endif
@@ -1296,12 +1319,14 @@ int C2T_NAME(c2_internal_loglik_tt_grad)(int64_t B, int64_t N, int64_t Jc, int c
                        (const double *)rec, R, (const unsigned long long *)guard, G, bx, bdiag, by);                     \
   } while (0)
   switch (Jc) {
+#if C2T_JS == C2T_J   // the padded build serves the matrix-level entry points only
     case 0: C2_TT(0); break;
     case 1: C2_TT(1); break;
-#if C2T_J >= 4
+#endif
+#if C2T_J >= 4 && C2T_JS == C2T_J
     case 2: C2_TT(2); break;
 #endif
-#if C2T_J >= 8
+#if C2T_J >= 8 && C2T_JS == C2T_J
     case 3: C2_TT(3); break;
     case 4: C2_TT(4); break;
 #endif

@@ -60,6 +60,7 @@ def test_argument_errors_without_gpu(built):
     waves, nck = 65536 // 64, (4096 - 2) // 32 + 1
     rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44)
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) == 8 * (2 + rec) < 30 * 2**30
+    assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 6) == 8 * (2 + rec)   # width 6 runs as 8: same records
     assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 33) == 0   # unsupported width
 
 

@@ -111,11 +111,13 @@ def test_fuzz_sweeps(ops, oracle, seed):
                 close(r_, e_)
 
 
-@pytest.mark.parametrize("seed", [s for (s,) in CASES[:12]])
-def test_fuzz_general_matmul(ops, oracle, seed):
+@pytest.mark.parametrize("tile", ["1", "0"])
+@pytest.mark.parametrize("seed", [s for (s,) in CASES[:16]])
+def test_fuzz_general_matmul(ops, oracle, monkeypatch, seed, tile):
+    monkeypatch.setenv("C2_GENERAL_TILE", tile)   # "0": the kernels the row-tile mapping replaced where it fits
     rng = np.random.default_rng(9000 + seed)
-    B = int(rng.integers(1, 12)); J = int(rng.integers(1, 33)); nrhs = int(rng.choice([1, 2, 3, 5, 8]))
-    N = int(rng.choice([1, 3, 17, 64, 130])); M = int(rng.choice([1, 2, 9, 33, 100]))
+    B = int(rng.integers(1, 12)); J = int(rng.integers(1, 33)); nrhs = int(rng.choice([1, 2, 3, 4, 5, 8]))
+    N = int(rng.choice([1, 3, 17, 64, 130, 300])); M = int(rng.choice([1, 2, 9, 33, 100, 260]))
     t2, c, a, U2, V, y = problem(rng, B, M, J)
     lo, hi = t2[:, :1], t2[:, -1:]
     t1 = np.sort(lo - 0.5 + (hi - lo + 1.0) * rng.random((B, N)), axis=1)
@@ -134,13 +136,13 @@ def test_fuzz_general_matmul(ops, oracle, seed):
 
 @pytest.mark.parametrize("seed", list(range(40)))
 def test_fuzz_one_lane_kernels(ops, oracle, monkeypatch, seed):
-    """The one-lane-per-series kernels (widths 8, 4, 2; c2_loglik_t.hip) forced on random shapes: ragged wavefronts,
+    """The one-lane-per-series kernels (widths 8, 6, 4, 2; c2_loglik_t.hip) forced on random shapes: ragged wavefronts,
     series lengths around the row-tile (2 / 4 / 8), scalar-tile (8) and checkpoint (32) periods, paired / unpaired rates, shared grids,
     an occasional failed series, and gaps that trip the stability gate (the gated replay kernels then answer)."""
     rng = np.random.default_rng(9000 + seed)
     B = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 190]))
     N = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33, 34, 63, 64, 65, 66, 97, 130, 257]))
-    J = int(rng.choice([8, 8, 4, 4, 2]))      # the widths compiled for this mapping
+    J = int(rng.choice([8, 8, 6, 6, 4, 4, 2]))      # the widths compiled for this mapping
     t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
     t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
     a = a + 0.5

@@ -184,10 +184,10 @@ def test_two_columns_per_lane_variant(ops, oracle, monkeypatch, B, N):
             assert int(flag4[b]) == f
 
 
-@pytest.mark.parametrize("J", [8, 4, 2])
+@pytest.mark.parametrize("J", [8, 6, 4, 2])
 @pytest.mark.parametrize("B,N", [(1, 1), (3, 2), (5, 3), (64, 16), (65, 17), (70, 33), (130, 100), (7, 1031), (200, 257)])
 def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N, J):
-    """Widths 8, 4, 2 have a third lane mapping for chip-filling batches (c2_loglik_t.hip: one lane per series, rows through LDS
+    """Widths 8, 6 (computed as 8 with two empty columns), 4, 2 have a third lane mapping for chip-filling batches (c2_loglik_t.hip: one lane per series, rows through LDS
     transposes, reverse sweep by the backward recursion between checkpoints every 32 rows): same results as the oracle
     on ragged wavefronts, around the tile (8 rows) and checkpoint (32 rows) edges, with unpaired rates, with a failed
     series, with shared t / c -- and the stability guard hands a batch with long gaps to the replay kernels."""
@@ -747,12 +747,15 @@ def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
             close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d), Z0 + Zo)
 
 
+@pytest.mark.parametrize("tile", ["1", "0"])
 @pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 97, 64), (3, 3, 40, 131), (6, 5, 200, 33), (16, 2, 50, 50), (2, 7, 1, 1)])
-def test_general_matmul_batched(ops, oracle, J, nrhs, N, M):
-    """general_matmul_lower/upper on the device, batched (two-phase: state sweep over t2 + one lane group per
-    output row): against the sequential-merge oracle with and without the F workspace, accumulation into Z,
-    ties between the two grids, output rows entirely before / after the input grid, and rows of F the merge
+def test_general_matmul_batched(ops, oracle, monkeypatch, J, nrhs, N, M, tile):
+    """general_matmul_lower/upper on the device, batched (tile = "1": a wavefront per series with lanes over rows,
+    c2_general_tile.hip, where the shape fits it; "0": two-phase state sweep + one lane group per output row, or lanes
+    over the right-hand sides): against the sequential-merge oracle with and without the F workspace, accumulation
+    into Z, ties between the two grids, output rows entirely before / after the input grid, and rows of F the merge
     never visits (left untouched, forward.hpp:313/375)."""
+    monkeypatch.setenv("C2_GENERAL_TILE", tile)
     B = 5
     rng = np.random.default_rng(100 * J + nrhs)
     Je = J if J % 2 == 0 else J + 1
@@ -782,6 +785,46 @@ def test_general_matmul_batched(ops, oracle, J, nrhs, N, M):
         close(Zd2, Zo)
         Zz = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, zero_z=True)
         close(Zz, Zo - Z0)
+
+
+@pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 64, 64), (8, 1, 128, 129), (8, 1, 1000, 300), (8, 1, 70, 2000), (4, 2, 513, 511),
+                                        (8, 4, 300, 257), (5, 3, 190, 640), (16, 1, 200, 200), (11, 2, 130, 65),
+                                        (1, 1, 65, 1), (2, 4, 1, 200), (8, 1, 4096, 4096)])
+def test_general_matmul_row_tiles(ops, oracle, J, nrhs, N, M):
+    """c2_general_tile.hip (a wavefront per series, 64 rows of either grid per pass) on shapes around its tile sizes:
+    grids of very different density (many output tiles per state tile and the reverse), ties that fall on tile
+    boundaries, outputs before / after / between the input rows only, runs of identical times, a series whose outputs
+    stop early (F rows beyond stay untouched) -- Z and the F workspace against the sequential-merge oracle."""
+    B = 6
+    rng = np.random.default_rng(7 * J + 13 * nrhs + N + M)
+    Je = J if J % 2 == 0 else J + 1
+    t2, c, a, Ue, Ve, y = dense.synthetic_batch(B, max(M, 2), Je)
+    t2 = np.ascontiguousarray(t2[:, :M]); V = np.ascontiguousarray(Ve[:, :M, :J]); c = np.ascontiguousarray(c[:, :J])
+    lo, hi = t2[:, :1], t2[:, -1:]
+    t1 = np.sort(lo - 0.1 * (hi - lo + 1.0) + (1.2 * (hi - lo + 1.0)) * rng.random((B, N)), axis=1)
+    if M > 130 and N > 8:
+        t1[0, :8] = t2[0, [63, 63, 64, 64, 127, 128, 128, 129]]      # ties on the tile boundaries
+        t1[0] = np.sort(t1[0])
+    if N > 3:
+        t1[1] = np.sort(t2[1, min(M - 1, 70)] + 1e-3 * rng.random(N))       # all outputs behind one input row
+        t1[2] = np.sort(lo[2] - 1.0 + (0.5 * (hi[2] - lo[2]) + 1.0) * rng.random(N))   # outputs stop half-way
+        t1[3, N // 2:] = t1[3, N // 2]                                       # a run of identical output times
+    if M > 3:
+        t2[4, M // 3: M // 3 + 3] = t2[4, M // 3]                            # identical input times
+    U = rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, M, nrhs))
+    t1d, t2d, cd, Ud, Vd, Yd = dev(t1, t2, c, U, V, Y)
+    for name in ("general_matmul_lower", "general_matmul_upper"):
+        Z0 = rng.standard_normal((B, N, nrhs))
+        Zo = Z0.copy(); Fo = np.full((B, M, J, nrhs), -7.0)
+        for b in range(B):
+            getattr(oracle, name)(t1[b], t2[b], c[b], U[b], V[b], Y[b], Zo[b], Fo[b])
+        (Zd,) = dev(Z0)
+        (Fd,) = dev(np.full((B, M, J, nrhs), -7.0))
+        Zd, Fd = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd, F=Fd)
+        close(Zd, Zo); close(Fd, Fo)
+        (Zd2,) = dev(Z0)
+        close(getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd2), Zo)
 
 
 def test_torch_autograd_adapter(ops, oracle):

@@ -39,3 +39,18 @@ for nrhs in (1, 2, 4, 8):
             df = float((res["0"][2] - res["1"][2]).abs().max() / res["0"][2].abs().max()) if wf else 0.0
             print("%s%s nrhs=%d: before %.2f ms, row tiles %.2f ms (frac %.3f), rel diff Z %.1e F %.1e" % (
                 name, " +F" if wf else "", nrhs, res["0"][0], res["1"][0], alg / res["1"][0] / 8e9, dz, df), flush=True)
+
+# independent random grids (outputs straddle the state tiles) and small batches of long series
+torch.manual_seed(1)
+for (B2, N2) in ((B, 4096), (1, 100_000), (64, 100_000)):
+    t2g, c2g, a2g, U2g, V2g, y2g = synth.device_batch_fast(1, B2, N2, J, dev)
+    span = (t2g[:, -1:] - t2g[:, :1])
+    t1g = (t2g[:, :1] + span * torch.rand((B2, N2), dtype=torch.float64, device=dev)).sort(dim=1).values.contiguous()
+    Y = torch.randn((B2, N2, 1), dtype=torch.float64, device=dev)
+    Z = torch.empty((B2, N2, 1), dtype=torch.float64, device=dev)
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["C2_GENERAL_TILE"] = mode
+        res[mode] = (timed(lambda: ops.general_matmul_lower(t1g, t2g, c2g, U2g, V2g, Y, Z=Z, zero_z=True)), Z.clone())
+    print("random grids B=%d N=M=%d nrhs=1: before %.3f ms, row tiles %.3f ms, rel diff %.1e" % (
+        B2, N2, res["0"][0], res["1"][0], float((res["0"][1] - res["1"][1]).abs().max() / res["0"][1].abs().max())), flush=True)

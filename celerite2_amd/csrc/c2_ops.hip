@@ -1202,7 +1202,8 @@ extern "C" int c2_internal_generalK(int lower, int64_t B, int64_t N, int64_t M, 
 extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs,
                                         const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c,
                                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
-                                        double *F, c2_stream_t stream);
+                                        double *F, double *scratch, c2_stream_t stream);
+extern "C" size_t c2_internal_general_tile_doubles(int64_t B, int64_t M, int64_t J, int64_t nrhs);
 static bool use_general_tile() {
   const char *e = getenv("C2_GENERAL_TILE");  // C2_GENERAL_TILE=0: the kernels below (A/B runs, tests of every path)
   return !(e && e[0] == '0');
@@ -1223,8 +1224,21 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   }
   // a wavefront per series, lanes over 64 consecutive rows of either grid (c2_general_tile.hip)
   if (use_general_tile()) {
-    const int e = c2_internal_general_tile(LOWER ? 1 : 0, B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F,
-                                           stream);
+    // small batches of long series are cut into chunks along time: a stream-ordered temporary for the chunk maps (not
+    // inside a graph capture, and one wavefront per series if the allocation fails)
+    void *tmp = nullptr;
+    const size_t nd = c2_internal_general_tile_doubles(B, M, J, nrhs);
+    if (nd > 0) {
+      hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(s, &capturing);
+      if (capturing != hipStreamCaptureStatusNone || hipMallocAsync(&tmp, nd * sizeof(double), s) != hipSuccess) {
+        (void)hipGetLastError();
+        tmp = nullptr;
+      }
+    }
+    int e = c2_internal_general_tile(LOWER ? 1 : 0, B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F,
+                                     (double *)tmp, stream);
+    if (tmp && hipFreeAsync(tmp, s) != hipSuccess && e == C2_OK) e = C2_ERR_HIP;
     if (e != C2_ERR_UNSUPPORTED) return e;
   }
   // three or more right-hand sides: lanes over the right-hand sides, one merge event per iteration (c2_general.hip)

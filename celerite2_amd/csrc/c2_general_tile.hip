@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
   constexpr int LS = NS + 2;        // LDS row stride (doubles): 16-byte aligned, off the 64-byte bank period
   // a window of TWO tiles (ring: row s lives at s mod 128), so that 64 consecutive outputs whose state rows straddle a
   // tile boundary -- the usual case when the grids are about equally dense -- are served in one pass, not two
+  // (one tile for the widest states, 32 entries per row, measured no better: registers bound the occupancy there)
   constexpr int kWin = 2 * kWave;
   __shared__ __attribute__((aligned(16))) double Ft[kWin][LS];
   __shared__ double T2[kWin];
@@ -200,8 +201,8 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
   // tile: zero / the chunk's carry.  The rows before the first tile "feed" every output (time -inf) -- no output of
   // this chunk has its state row there.
 #pragma unroll
-  for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[kWave + lane][e]) = make_double2(0.0, 0.0);
-  T2[kWave + lane] = -inf;
+  for (int e = 0; e < NS; e += 2) *reinterpret_cast<double2 *>(&Ft[kWin - kWave + lane][e]) = make_double2(0.0, 0.0);
+  T2[kWin - kWave + lane] = -inf;
   if (ch > 0 && lane < NS)
     Ft[kWin - 1][lane] = carry[((b * gridDim.y + blockIdx.y) * C + ch) * NS + lane];
   lds_order();
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
     T2[slot + lane] = Sc.tau;
     lds_order();
     const double bound = Sc.bound;
-    const int woff = slot ^ kWave;   // ring position of the window's first row, s0 - 64
+    const int woff = (slot + kWave) & (kWin - 1);   // ring position of the window's first row, s0 - (kWin - 64)
 
     // ---- outputs ----------------------------------------------------------------------------------------------------
     // serve the lanes in `mine` from the window; returns the state row (walk position) of lane `last`
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
 #pragma unroll
       for (int step = kWin / 2; step >= 1; step >>= 1)
         if (feeds(T2[(pos + step - 1 + woff) & (kWin - 1)], Oc.tau)) pos += step;
-      if (feeds(T2[(pos + woff) & (kWin - 1)], Oc.tau)) pos += 1;   // reaches 128 only on lanes that are not `mine`
-      const int64_t srow = s0 - kWave + pos - 1;      // < 0: an output ahead of the first t2 row (forward.hpp:303-306)
+      if (feeds(T2[(pos + woff) & (kWin - 1)], Oc.tau)) pos += 1;   // reaches kWin only on lanes that are not `mine`
+      const int64_t srow = s0 - (kWin - kWave) + pos - 1;   // < 0: an output ahead of the first t2 row (forward.hpp:303-306)
       if (mine && srow >= 0) {
         const int ri = (pos - 1 + woff) & (kWin - 1);
         const double dq = Oc.tau - T2[ri];
@@ -288,9 +289,10 @@ __global__ __launch_bounds__(kWave) void k_general_tile(int64_t B, int64_t N, in
       load_out_tile(On, q0 + kWave);
     }
     if (!finished) {
-      // outputs whose state row lies in the OLDER tile of the window: its rows are overwritten next
+      // outputs whose state row lies in the tile of the window that is overwritten next (the older one of two: those
+      // not fed by this tile's first row; the only one: those not fed by the next tile's first row)
       const int done = (int)(q - q0);
-      const bool mine = lane >= done && q0 + lane < N && !feeds(T2[slot], Oc.tau);
+      const bool mine = lane >= done && q0 + lane < N && !feeds(kWin > kWave ? T2[slot] : bound, Oc.tau);
       const int cnt = __popcll(__ballot(mine));
       if (cnt > 0) {
         (void)serve(mine, 0);

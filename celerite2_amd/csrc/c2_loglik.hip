@@ -863,6 +863,13 @@ extern "C" int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const
 #ifndef C2_TIMEPAR_MIN_ROWS
 #define C2_TIMEPAR_MIN_ROWS 1536
 #endif
+// A handful of series (B * J <= 512: every driver.* call) is pure latency row by row -- 0.15-0.24 us per row -- against a
+// fixed 40-130 us of the three 64-step phases of the time-parallel form (tools/timepar_small_n.py: B = 1, 8, 64 alike):
+// log-likelihood / factor draw level at ~300 rows (J = 2) and ~600 (J = 4), the solves at ~256 / ~420 / ~900 (J = 8).
+static int64_t timepar_min_rows(int64_t B, int64_t J) {
+  if (B * J > 512) return C2_TIMEPAR_MIN_ROWS;
+  return J == 2 ? 384 : (J == 4 ? 704 : 1024);
+}
 #ifndef C2_TIMEPAR_MAX_BATCH_X_WIDTH
 #define C2_TIMEPAR_MAX_BATCH_X_WIDTH 8192
 #endif
@@ -872,14 +879,14 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J) {
   if (e) return atoi(e) != 0 && N >= 2;
   const char *l = getenv("C2_LANES");
   if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
-  return N >= C2_TIMEPAR_MIN_ROWS && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
+  return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
 // the same decision for the single-rhs solves (affine maps: width 8 as well)
 extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   if (J != 8 && J != 4 && J != 2) return 0;
   const char *e = getenv("C2_TIMEPAR");
   if (e) return atoi(e) != 0 && N >= 2;
-  return N >= C2_TIMEPAR_MIN_ROWS && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
+  return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 6 && J != 4 && J != 2) return false;

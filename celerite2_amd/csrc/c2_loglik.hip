@@ -888,6 +888,27 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   if (e) return atoi(e) != 0 && N >= 2;
   return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
+// Time-parallel GRADIENT (c2_timepar_grad.hip; widths 2, 4, 6, 8, per-series t and c): small batches of long series.
+// C2_TIMEPAR_GRAD=1 forces it, =0 disables it.
+extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, const double *c,
+                                               const double *a, const double *U, const double *V, const double *y,
+                                               double *ll, double *bt, double *bc, double *ba, double *bU, double *bV,
+                                               double *by, int32_t *flag, double *work, c2_stream_t stream);
+#ifndef C2_TIMEPAR_GRAD_MIN_ROWS
+#define C2_TIMEPAR_GRAD_MIN_ROWS 1024
+#endif
+#ifndef C2_TIMEPAR_GRAD_MAX_BATCH_X_WIDTH
+#define C2_TIMEPAR_GRAD_MAX_BATCH_X_WIDTH 8192
+#endif
+static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
+  if (J != 2 && J != 4 && J != 6 && J != 8) return false;
+  const char *e = getenv("C2_TIMEPAR_GRAD");
+  if (e) return atoi(e) != 0 && N >= 2;
+  const char *l = getenv("C2_LANES");
+  if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
+  return N >= C2_TIMEPAR_GRAD_MIN_ROWS && B * J <= C2_TIMEPAR_GRAD_MAX_BATCH_X_WIDTH;
+}
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 6 && J != 4 && J != 2) return false;
   const char *e = getenv("C2_LANES");
@@ -969,12 +990,42 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
                                           int64_t c_bs, const double *a, const double *U, const double *V, double *d,
                                           double *W, int32_t *flag, double *work, unsigned long long *guard,
                                           c2_stream_t stream);
+// widths 6 and 8: fixed-point passes over chunks of 64 rows (c2_timepar_grad.hip), the row-by-row kernel gated behind
+extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                       int64_t c_bs, const double *a, const double *U, const double *V, double *d,
+                                       double *W, int32_t *flag, double *work, const unsigned long long **last_word,
+                                       c2_stream_t stream);
+static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
+  if (J != 6 && J != 8) return false;
+  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it, 0 disables it
+  if (e) return atoi(e) != 0 && N >= 2;
+  const char *l = getenv("C2_LANES");
+  if (l && atoi(l) != 0) return false;
+  // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,
+  // 3.9 vs 29.5 ms at 1e5; with more than ~16k chunks in flight a pass no longer has a SIMD per wavefront
+  return N >= 2048 && B * ((N + 63) / 64) <= 16384;
+}
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                              int32_t *flag, int allow_timepar, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
+  if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && use_factor_iter(B, N, J)) {
+    const size_t nd = c2_internal_factor_iter_doubles(B, N, J);
+    void *tmp = nullptr;
+    if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+      const unsigned long long *last = nullptr;
+      int rc = c2_internal_factor_iter(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, (double *)tmp, &last, stream);
+      if (rc == C2_OK)
+        rc = launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, a, nullptr, flag, nullptr, 0, W,
+                           reinterpret_cast<double2 *>(d), s, last);
+      if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+      return rc;
+    }
+    (void)hipGetLastError();
+  }
   // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
   // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
   if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && use_timepar(B, N, J)) {
@@ -1006,6 +1057,10 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
     const size_t r = lanes1_record_doubles(B, N, J);
     n = 2 + (r > n ? r : n);
   }
+  if (use_timepar_grad(B, N, J)) {   // either path may run (shared t / c stay row by row): the larger of the two
+    const size_t r = c2_internal_timepar_grad_doubles(B, N, J);
+    n = r > n ? r : n;
+  }
   return n * sizeof(double);
 }
 
@@ -1018,6 +1073,9 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   if (!t || !c || !a || !U || !V || !y || !ll || !bt || !bc || !ba || !bU || !bV || !by || !flag || !work)
     return C2_ERR_INVALID;
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
+  if (t_bs == N && c_bs == J && use_timepar_grad(B, N, J))   // small batch of long series: parallel along time
+    return c2_internal_loglik_grad_timepar(B, N, J, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, (double *)work,
+                                           stream);
   if (use_lanes4(B, J, true))
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   const unsigned long long *gate = nullptr;

@@ -1,0 +1,915 @@
+// c2_timepar_grad.hip -- the fused log-likelihood GRADIENT parallel along time, for small batches of long series
+// (widths 2, 4, 6, 8).  Row by row such a batch is pure latency: ~1.2 us per row for the forward + reverse pair with a
+// handful of wavefronts on the chip.
+//
+// Forward quantities.  d, W (c2_factor; forward.hpp:105-134) and z = L^-1 y (c2_solve_lower; internal.hpp:135-145) of
+// every row come from the existing kernels -- themselves time-parallel where they can be (c2_timepar.hip).  With d, W, z
+// known the states entering row n obey LINEAR recurrences with diagonal transitions,
+//     S_{n+1} = P (S_n + d_n w_n^T w_n) P ,   F_{n+1} = P (F_n + w_n z_n) ,   P = diag exp(-c (t_{n+1} - t_n)),
+// so chunks of 64 rows sum their own contributions in parallel (k_local) and a scan over the chunks (k_starts) gives the
+// state every chunk starts from.
+//
+// Reverse sweep (the fused step of c2_loglik.hip / reverse.hpp:52-84 + internal.hpp:225-245).  The adjoints (bS, bF) of
+// the states obey, with A_n = P (I - w_n u_n^T),
+//     bF_n = A_n^T bF_{n+1} + (z_n / d_n) u_n^T ,
+//     bS_n = A_n^T bS_{n+1} A_n - (z_n / d_n) sym(bF_n u_n^T) + (1/2)(1/d_n - z_n^2/d_n^2) u_n^T u_n ,
+// i.e. a chunk acts on the adjoint it receives at its end as an AFFINE map
+//     bF_start = Phi^T bF_end + gF ,   bS_start = Phi^T bS_end Phi + sum_k bF_end[k] C_k + gS .
+// k_maps finds (Phi, C_k, gS, gF) of every chunk by J + 1 sweeps over its rows (bF_end = e_k with bS_end = 0; zero end
+// adjoint with the sources), one lane per chunk; k_chain walks the chunks of a series backwards applying the maps
+// (lanes <-> the J x J entries); k_final gives every chunk its true end adjoint and runs the one sweep that writes the
+// gradients.  That sweep needs the states S_n, F_n entering each row in reverse order: the chunk replays them forward
+// into a lane-major scratch record first (no backward recursion, hence no stability condition).
+//
+// tools/proto/tpg.py is the same construction in numpy, checked against the sequential oracle.
+#include <cstdint>
+#include <cstdlib>
+
+#include "c2_loglik_helpers.hpp"
+#include "../../include/celerite2_amd.h"
+
+namespace c2tg {
+using namespace c2;
+
+constexpr int kRows = 64;   // rows per chunk
+
+template <int J>
+struct Dim {
+  static constexpr int NS = J * (J + 1) / 2;   // packed symmetric J x J
+  static constexpr int NST = NS + J;           // a state: S (packed), F
+  static constexpr int MAPR = (J + 1) * NST;   // a chunk map: sweeps e_0 .. e_{J-1} (C_k, Phi^T e_k), then (gS, gF)
+};
+__host__ __device__ constexpr int sidx(int J, int i, int j) { return i * J - i * (i - 1) / 2 + (j - i); }
+__host__ __device__ constexpr int sym(int J, int i, int j) { return i <= j ? sidx(J, i, j) : sidx(J, j, i); }
+
+struct Geo {   // lane <-> chunk
+  int64_t g, b, k, lo;
+  int len;       // rows of the chunk (0: no chunk behind this lane)
+  int64_t wave;
+  int lane;
+};
+__device__ __forceinline__ Geo chunk_of(int64_t B, int64_t N, int64_t K) {
+  Geo G;
+  G.lane = threadIdx.x;
+  G.wave = blockIdx.x;
+  G.g = (int64_t)blockIdx.x * kWave + threadIdx.x;
+  const bool valid = G.g < B * K;
+  const int64_t gc = valid ? G.g : B * K - 1;
+  G.b = gc / K;
+  G.k = gc - G.b * K;
+  G.lo = G.k * kRows;
+  const int64_t left = N - G.lo;
+  G.len = valid ? (int)(left < kRows ? left : kRows) : 0;
+  return G;
+}
+
+template <int J>
+__device__ __forceinline__ void load_row(const double *p, double (&x)[J]) {
+#pragma unroll
+  for (int j = 0; j < J; j += 2) {
+    const double2 v = *reinterpret_cast<const double2 *>(p + j);
+    x[j] = v.x; x[j + 1] = v.y;
+  }
+}
+template <int J>
+__device__ __forceinline__ void store_row(double *p, const double (&x)[J]) {
+#pragma unroll
+  for (int j = 0; j < J; j += 2) *reinterpret_cast<double2 *>(p + j) = make_double2(x[j], x[j + 1]);
+}
+
+// The inputs of one row of a chunk, fetched ONE ITERATION AHEAD of their use (a chunk is walked by a single lane: with
+// one wavefront per SIMD nothing else hides the latency of the loads).  r is clamped into the chunk, so lanes with
+// shorter chunks fetch valid rows they do not use.
+template <int J, bool WITH_U, bool WITH_V>
+struct RowIn {
+  double u[WITH_U ? J : 1], v[WITH_V ? J : 1], w[J], d, z, dt;   // dt: gap to the next row (0 behind the last row)
+};
+template <int J, bool WITH_U, bool WITH_V>
+__device__ __forceinline__ void fetch_row(RowIn<J, WITH_U, WITH_V> &R, const Geo &G, int64_t N, int r, const double *tb,
+                                          const double *Ub, const double *Vb, const double *Wb, const double *db,
+                                          const double *zb) {
+  const int rc = r < G.len ? (r < 0 ? 0 : r) : (G.len > 0 ? G.len - 1 : 0);
+  const int64_t n = G.lo + rc;
+  if constexpr (WITH_U) load_row<J>(Ub + n * J, R.u);
+  if constexpr (WITH_V) load_row<J>(Vb + n * J, R.v);
+  load_row<J>(Wb + n * J, R.w);
+  R.d = db[n]; R.z = zb[n];
+  const double t0 = tb[n], t1 = tb[n + 1 < N ? n + 1 : n];
+  R.dt = t1 - t0;
+}
+
+// state + its own row:  S += d w^T w,  F += w z
+template <int J>
+__device__ __forceinline__ void absorb(double (&S)[Dim<J>::NS], double (&F)[J], const double (&w)[J], double d, double z) {
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    const double dw = d * w[i];
+#pragma unroll
+    for (int j = i; j < J; ++j) S[sidx(J, i, j)] = fma(dw, w[j], S[sidx(J, i, j)]);
+    F[i] = fma(w[i], z, F[i]);
+  }
+}
+template <int J>
+__device__ __forceinline__ void decay(double (&S)[Dim<J>::NS], double (&F)[J], const double (&p)[J]) {
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+#pragma unroll
+    for (int j = i; j < J; ++j) S[sidx(J, i, j)] *= p[i] * p[j];
+    F[i] *= p[i];
+  }
+}
+
+// ---- forward: contributions of the chunks, start states ---------------------------------------------------------------
+// loc[g]: state entering the first row of chunk g+1 if chunk g had started from zero; llp[g]: sum (log d + z^2 / d)
+template <int J>
+__global__ __launch_bounds__(kWave) void k_local(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                 const double *__restrict__ c, const double *__restrict__ d,
+                                                 const double *__restrict__ W, const double *__restrict__ z,
+                                                 double *__restrict__ loc, double *__restrict__ llp) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
+  const Geo G = chunk_of(B, N, K);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
+  const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N, *Wb = W + G.b * N * J;
+  double S[NS], F[J];
+#pragma unroll
+  for (int e = 0; e < NS; ++e) S[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) F[j] = 0.0;
+  double acc = 0.0;
+  RowIn<J, false, false> cur, nxt;
+  fetch_row<J, false, false>(cur, G, N, 0, tb, nullptr, nullptr, Wb, db, zb);
+#pragma unroll 1
+  for (int r = 0; r < kRows; ++r) {
+    fetch_row<J, false, false>(nxt, G, N, r + 1, tb, nullptr, nullptr, Wb, db, zb);
+    if (r < G.len) {
+      double p[J];
+      acc += log(cur.d) + cur.z * cur.z / cur.d;
+      absorb<J>(S, F, cur.w, cur.d, cur.z);
+      if (G.lo + r + 1 < N) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+        decay<J>(S, F, p);
+      }
+    }
+    cur = nxt;
+  }
+  if (G.len > 0) {
+    double *o = loc + G.g * NST;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) o[e] = S[e];
+#pragma unroll
+    for (int j = 0; j < J; ++j) o[NS + j] = F[j];
+    llp[G.g] = acc;
+  }
+}
+
+// One wavefront per series, lane <-> entry of the state: start[g] = state entering the first row of chunk g.  Also the
+// log-likelihood (numpy.py:66-109): -1/2 sum (log d + z^2/d) - N/2 log 2 pi, -inf for a failed factorisation.
+template <int J>
+__global__ __launch_bounds__(kWave) void k_starts(int64_t N, int64_t K, const double *__restrict__ t,
+                                                  const double *__restrict__ c, const double *__restrict__ loc,
+                                                  const double *__restrict__ llp, const int32_t *__restrict__ flag,
+                                                  double *__restrict__ start, double *__restrict__ ll) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  const double *tb = t + b * N;
+  // rate of the lane's entry: c_i + c_j for S(i, j), c_i for F_i
+  double rate = 0.0;
+  if (lane < NST) {
+    if (lane >= NS) rate = c[b * J + (lane - NS)];
+    else {
+      int i = 0, rem = lane;
+      while (rem >= J - i) { rem -= J - i; ++i; }
+      rate = c[b * J + i] + c[b * J + i + rem];
+    }
+  }
+  double cur = 0.0;
+  constexpr int PF = 8;   // chunks whose inputs are in flight together (the recurrence itself is one fma per chunk)
+  for (int64_t k0 = 0; k0 < K; k0 += PF) {
+    double lv[PF], Tv[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int64_t k = k0 + q < K ? k0 + q : K - 1;
+      lv[q] = lane < NST ? loc[(b * K + k) * NST + lane] : 0.0;
+      Tv[q] = k + 1 < K ? tb[(k + 1) * kRows] - tb[k * kRows] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      if (k0 + q < K) {
+        if (lane < NST) start[(b * K + k0 + q) * NST + lane] = cur;
+        // loc is already decayed to the next chunk's first row; the carried state decays over the whole chunk
+        cur = fma(exp_decay(-rate * Tv[q]), cur, lv[q]);
+      }
+    }
+  }
+  double s = 0.0;
+  for (int64_t k = lane; k < K; k += kWave) s += llp[b * K + k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if (lane == 0) ll[b] = flag[b] != 0 ? -__builtin_huge_val() : -0.5 * s - 0.5 * (double)N * kLog2Pi;
+}
+
+// ---- the adjoint step ---------------------------------------------------------------------------------------------------
+// (bS, bF): adjoint of the state entering row n+1 on entry, of the state entering row n on exit.  p: decay between the
+// two rows (1 behind the last row).  SRC: with the sources of the log-likelihood (d ll/d z = -z/d, d ll/d d).
+struct RowOut { double bz, bd; };
+template <int J, bool SRC, bool OUT>
+__device__ __forceinline__ RowOut adjoint_row(double (&bS)[Dim<J>::NS], double (&bF)[J], const double (&p)[J],
+                                              const double (&u)[J], const double (&w)[J], double d, double z, double rd,
+                                              double (&g2)[J], double (&btau)[J]) {
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+#pragma unroll
+    for (int j = i; j < J; ++j) bS[sidx(J, i, j)] *= p[i] * p[j];
+    bF[i] *= p[i];
+  }
+  double g[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) s = fma(bS[sym(J, i, j)], w[j], s);
+    g[i] = s;
+  }
+  double wg = 0.0, wbF = 0.0;
+#pragma unroll
+  for (int i = 0; i < J; ++i) { wg = fma(w[i], g[i], wg); wbF = fma(w[i], bF[i], wbF); }
+  const double zd = z * rd;
+  RowOut o;
+  o.bz = wbF - (SRC ? zd : 0.0);
+  o.bd = -wg - zd * wbF - (SRC ? 0.5 * (rd - zd * zd) : 0.0);
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    if (OUT) g2[i] = fma(2.0, g[i], zd * bF[i]);          // bV_n = bw / d
+    btau[i] = -fma(2.0, g[i], zd * bF[i]) - o.bd * u[i];
+    bF[i] = fma(-o.bz, u[i], bF[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+#pragma unroll
+    for (int j = i; j < J; ++j)
+      bS[sidx(J, i, j)] += 0.5 * fma(btau[i], u[j], u[i] * btau[j]);
+  }
+  return o;
+}
+
+// ---- adjoint maps of the chunks ---------------------------------------------------------------------------------------
+// One lane per chunk; SP sweeps share the rows and the decay factors of a pass.  map[g][s * NST ...]: result (bS, bF)
+// of sweep s (s < J: from bF_end = e_s; s = J: from zero, with the sources).
+template <int J, int SP>
+__global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                const double *__restrict__ c, const double *__restrict__ U,
+                                                const double *__restrict__ d, const double *__restrict__ W,
+                                                const double *__restrict__ z, double *__restrict__ map) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
+  const Geo G = chunk_of(B, N, K);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
+  const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N;
+  const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J;
+#pragma unroll 1
+  for (int s0 = 0; s0 <= J; s0 += SP) {
+    double bS[SP][NS], bF[SP][J];
+#pragma unroll
+    for (int q = 0; q < SP; ++q) {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) bS[q][e] = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) bF[q][j] = (s0 + q == j) ? 1.0 : 0.0;
+    }
+    RowIn<J, true, false> cur, nxt;
+    fetch_row<J, true, false>(cur, G, N, kRows - 1, tb, Ub, nullptr, Wb, db, zb);
+#pragma unroll 1
+    for (int r = kRows - 1; r >= 0; --r) {
+      fetch_row<J, true, false>(nxt, G, N, r - 1, tb, Ub, nullptr, Wb, db, zb);
+      if (r < G.len) {
+        double p[J], g2[J], btau[J];
+        const double rd = 1.0 / cur.d;
+#pragma unroll
+        for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+#pragma unroll
+        for (int q = 0; q < SP; ++q) {
+          if (s0 + q < J) (void)adjoint_row<J, false, false>(bS[q], bF[q], p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+          else if (s0 + q == J) (void)adjoint_row<J, true, false>(bS[q], bF[q], p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+        }
+      }
+      cur = nxt;
+    }
+    if (G.len > 0) {
+#pragma unroll
+      for (int q = 0; q < SP; ++q) {
+        if (s0 + q <= J) {
+          double *o = map + G.g * MAPR + (int64_t)(s0 + q) * NST;
+#pragma unroll
+          for (int e = 0; e < NS; ++e) o[e] = bS[q][e];
+#pragma unroll
+          for (int j = 0; j < J; ++j) o[NS + j] = bF[q][j];
+        }
+      }
+    }
+  }
+}
+
+// ---- chain over the chunks of a series, backwards ---------------------------------------------------------------------
+// One wavefront per series; lane (i, j) = entry of the J x J adjoint.  ends[g] = adjoint of the state entering the row
+// behind chunk g (zero behind the last one).
+template <int J>
+__global__ __launch_bounds__(kWave) void k_chain(int64_t K, const double *__restrict__ map, double *__restrict__ ends) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
+  __shared__ double bSm[J][J + 1], Xm[J][J + 1], Pm[J][J + 1], bFv[J];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x;
+  const int sij = sym(J, i, j);
+  if (act) bSm[i][j] = 0.0;
+  if (lane < J) bFv[lane] = 0.0;
+  lds_order();
+  double phit, ck[J], gs, gf;
+  auto fetch = [&](int64_t k) {
+    const double *m = map + (b * K + k) * MAPR;
+    phit = m[(int64_t)j * NST + NS + i];   // Phi^T(i, j): entry i of the bF result of sweep j
+#pragma unroll
+    for (int q = 0; q < J; ++q) ck[q] = m[(int64_t)q * NST + sij];
+    gs = m[(int64_t)J * NST + sij];
+    gf = m[(int64_t)J * NST + NS + i];
+  };
+  fetch(K - 1);
+  for (int64_t k = K - 1; k >= 0; --k) {
+    const double mphit = phit, mgs = gs, mgf = gf;
+    double mck[J];
+#pragma unroll
+    for (int q = 0; q < J; ++q) mck[q] = ck[q];
+    if (k > 0) fetch(k - 1);
+    double *e = ends + (b * K + k) * NST;
+    const double cur = bSm[i][j];
+    if (act && i <= j) e[sij] = cur;
+    if (act && j == 0) e[NS + i] = bFv[i];
+    Pm[i][j] = mphit;   // inactive lanes rewrite entry (0, 0) with the same value
+    lds_order();
+    double x = 0.0;      // (bS Phi)(i, j) = sum_l bS(i, l) Phi^T(j, l)
+#pragma unroll
+    for (int l = 0; l < J; ++l) x = fma(bSm[i][l], Pm[j][l], x);
+    Xm[i][j] = x;
+    double nf = mgf, cf = mgs;
+#pragma unroll
+    for (int q = 0; q < J; ++q) { nf = fma(Pm[i][q], bFv[q], nf); cf = fma(bFv[q], mck[q], cf); }
+    lds_order();
+    double o = cf;       // (Phi^T bS Phi)(i, j) = sum_q Phi^T(i, q) X(q, j)
+#pragma unroll
+    for (int q = 0; q < J; ++q) o = fma(Pm[i][q], Xm[q][j], o);
+    lds_order();
+    if (act) bSm[i][j] = o;
+    if (act && j == 0) bFv[i] = nf;
+    lds_order();
+  }
+}
+
+// ---- the sweep that writes the gradients --------------------------------------------------------------------------------
+// sf: lane-major record of the states entering the rows of a chunk: sf[((wave * 64 + r) * NST + e) * 64 + lane].
+template <int J>
+__global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                 const double *__restrict__ c, const double *__restrict__ U,
+                                                 const double *__restrict__ V, const double *__restrict__ d,
+                                                 const double *__restrict__ W, const double *__restrict__ z,
+                                                 const double *__restrict__ start, const double *__restrict__ ends,
+                                                 const int32_t *__restrict__ flag, double *__restrict__ sf,
+                                                 double *__restrict__ dT, double *__restrict__ bcp,
+                                                 double *__restrict__ ba, double *__restrict__ bU,
+                                                 double *__restrict__ bV, double *__restrict__ by) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
+  const Geo G = chunk_of(B, N, K);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
+  const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N;
+  const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J, *Vb = V + G.b * N * J;
+  double *bab = ba + G.b * N, *byb = by + G.b * N, *bUb = bU + G.b * N * J, *bVb = bV + G.b * N * J, *dTb = dT + G.b * N;
+  double *sfw = sf + (size_t)G.wave * kRows * NST * kWave + G.lane;
+  const bool failed = flag[G.b] != 0;
+  const double nan = __builtin_nan("");
+
+  // forward replay: the states entering the rows, then the one entering the row behind the chunk
+  double Sn[NS], Fn[J];
+  {
+    const double *s = start + G.g * NST;
+#pragma unroll
+    for (int e = 0; e < NS; ++e) Sn[e] = G.len > 0 ? s[e] : 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) Fn[j] = G.len > 0 ? s[NS + j] : 0.0;
+  }
+  {
+    RowIn<J, false, false> cur, nxt;
+    fetch_row<J, false, false>(cur, G, N, 0, tb, nullptr, nullptr, Wb, db, zb);
+#pragma unroll 1
+    for (int r = 0; r < kRows; ++r) {
+      fetch_row<J, false, false>(nxt, G, N, r + 1, tb, nullptr, nullptr, Wb, db, zb);
+      if (r < G.len) {
+        double *o = sfw + (size_t)r * NST * kWave;
+#pragma unroll
+        for (int e = 0; e < NS; ++e) o[(size_t)e * kWave] = Sn[e];
+#pragma unroll
+        for (int j = 0; j < J; ++j) o[(size_t)(NS + j) * kWave] = Fn[j];
+        double p[J];
+        absorb<J>(Sn, Fn, cur.w, cur.d, cur.z);
+        if (G.lo + r + 1 < N) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+          decay<J>(Sn, Fn, p);
+        }
+      }
+      cur = nxt;
+    }
+  }
+  // Sn, Fn: state entering row lo + len (meaningless behind the last row of the series, where the adjoint is zero)
+  double bS[NS], bF[J], bcj[J];
+  {
+    const double *e = ends + G.g * NST;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) bS[q] = G.len > 0 ? e[q] : 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { bF[j] = G.len > 0 ? e[NS + j] : 0.0; bcj[j] = 0.0; }
+  }
+  RowIn<J, true, true> cur, nxt;
+  fetch_row<J, true, true>(cur, G, N, kRows - 1, tb, Ub, Vb, Wb, db, zb);
+#pragma unroll 1
+  for (int r = kRows - 1; r >= 0; --r) {
+    fetch_row<J, true, true>(nxt, G, N, r - 1, tb, Ub, Vb, Wb, db, zb);
+    if (r < G.len) {
+      const int64_t n = G.lo + r;
+      double p[J], g2[J], btau[J];
+      // the state entering row n: requested now, needed behind the adjoint step
+      double Sm[NS], Fm[J];
+      const double *o = sfw + (size_t)r * NST * kWave;
+#pragma unroll
+      for (int e = 0; e < NS; ++e) Sm[e] = o[(size_t)e * kWave];
+#pragma unroll
+      for (int j = 0; j < J; ++j) Fm[j] = o[(size_t)(NS + j) * kWave];
+      const double dn = cur.d, zn = cur.z, rd = 1.0 / dn, dt = cur.dt;
+      // the decay between rows n and n+1 (internal.hpp:238-243 / reverse.hpp:70-76): p_i bp_i = 2 sum_j bS'(i,j)
+      // S_{n+1}(i,j) + bF'_i F_{n+1,i} with the states ENTERING row n+1 (dt = 0 behind the last row)
+      double bdt = 0.0;
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        double s = bF[i] * Fn[i];
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) s = fma(2.0 * bS[sym(J, i, jj)], Sn[sym(J, i, jj)], s);
+        bcj[i] = fma(-dt, s, bcj[i]);
+        bdt = fma(-cj[i], s, bdt);
+        p[i] = exp_decay(-cj[i] * dt);
+      }
+      if (n + 1 >= N) bdt = 0.0;
+      const RowOut ro = adjoint_row<J, true, true>(bS, bF, p, cur.u, cur.w, dn, zn, rd, g2, btau);
+#pragma unroll
+      for (int e = 0; e < NS; ++e) Sn[e] = Sm[e];
+#pragma unroll
+      for (int j = 0; j < J; ++j) Fn[j] = Fm[j];
+      // bU_n = -bz F_n - bd tau_n + S_n btau,  tau_n = v_n - d_n w_n
+      double bu[J];
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        double s = fma(-ro.bz, Fn[i], -ro.bd * fma(-dn, cur.w[i], cur.v[i]));
+#pragma unroll
+        for (int jj = 0; jj < J; ++jj) s = fma(Sn[sym(J, i, jj)], btau[jj], s);
+        bu[i] = failed ? nan : s;
+        g2[i] = failed ? nan : g2[i];
+      }
+      store_row<J>(bUb + n * J, bu);
+      store_row<J>(bVb + n * J, g2);
+      bab[n] = failed ? nan : ro.bd;
+      byb[n] = failed ? nan : ro.bz;
+      dTb[n] = bdt;
+    }
+    cur = nxt;
+  }
+  if (G.len > 0) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) bcp[G.g * J + j] = bcj[j];
+  }
+}
+
+// bt_n = dT_{n-1} - dT_n (dT_n: gradient w.r.t. the gap t_{n+1} - t_n)
+__global__ void k_finish_t(int64_t B, int64_t N, const double *__restrict__ dT, const int32_t *__restrict__ flag,
+                           double *__restrict__ bt) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < B * N) {
+    const int64_t b = g / N, n = g - b * N;
+    const double v = (n > 0 ? dT[g - 1] : 0.0) - dT[g];
+    bt[g] = flag[b] != 0 ? __builtin_nan("") : v;
+  }
+}
+// bc = sum of the chunks' parts: one wavefront per (series, j), lanes strided over the chunks, a fixed tree
+template <int J>
+__global__ __launch_bounds__(kWave) void k_finish_c(int64_t K, const double *__restrict__ bcp,
+                                                    const int32_t *__restrict__ flag, double *__restrict__ bc) {
+  const int64_t b = blockIdx.x / J;
+  const int j = (int)(blockIdx.x % J);
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < K; k += kWave) s += bcp[(b * K + k) * J + j];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if (threadIdx.x == 0) bc[b * J + j] = flag[b] != 0 ? __builtin_nan("") : s;
+}
+
+// ---- z = L^-1 y (solve_lower, one right-hand side) for widths the tiled kernels of c2_timepar.hip do not cover (6) ------
+// The recursion is affine in its state with the SAME propagator as above: F_{n+1} = P (I - w_n u_n^T) F_n + P w_n y_n,
+// z_n = y_n - u_n F_n (internal.hpp:135-145).  k_solve_maps: (Phi_k, g_k) of every chunk; k_solve_chain: the states the
+// chunks start from; k_solve_apply: z of every row.
+template <int J>
+__global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                      const double *__restrict__ c, const double *__restrict__ U,
+                                                      const double *__restrict__ W, const double *__restrict__ y,
+                                                      double *__restrict__ Phi, double *__restrict__ gk) {
+  const Geo G = chunk_of(B, N, K);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
+  const double *tb = t + G.b * N, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
+  double M[J][J], F[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    F[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) M[i][j] = i == j ? 1.0 : 0.0;
+  }
+  RowIn<J, true, false> cur, nxt;   // d <- y (unused), z <- y
+  fetch_row<J, true, false>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
+#pragma unroll 1
+  for (int r = 0; r < kRows; ++r) {
+    fetch_row<J, true, false>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
+    if (r < G.len) {
+      double p[J], uf = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { p[j] = exp_decay(-cj[j] * cur.dt); uf = fma(cur.u[j], F[j], uf); }
+      const double zn = cur.z - uf;
+#pragma unroll
+      for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]) * p[i];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double um = 0.0;
+#pragma unroll
+        for (int l = 0; l < J; ++l) um = fma(cur.u[l], M[l][j], um);
+#pragma unroll
+        for (int i = 0; i < J; ++i) M[i][j] = fma(-cur.w[i], um, M[i][j]) * p[i];
+      }
+    }
+    cur = nxt;
+  }
+  if (G.len > 0) {
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      gk[G.g * J + i] = F[i];
+#pragma unroll
+      for (int j = 0; j < J; ++j) Phi[G.g * (J * J) + i * J + j] = M[i][j];
+    }
+  }
+}
+// one wavefront per series, lane i < J <-> F_i
+template <int J>
+__global__ __launch_bounds__(kWave) void k_solve_chain(int64_t K, const double *__restrict__ Phi,
+                                                       const double *__restrict__ gk, double *__restrict__ Fst) {
+  const int lane = threadIdx.x, i = lane < J ? lane : 0;
+  const int64_t b = blockIdx.x;
+  double F = 0.0;
+  constexpr int PF = 4;
+  for (int64_t k0 = 0; k0 < K; k0 += PF) {
+    double ph[PF][J], gv[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int64_t g = b * K + (k0 + q < K ? k0 + q : K - 1);
+      gv[q] = gk[g * J + i];
+#pragma unroll
+      for (int j = 0; j < J; ++j) ph[q][j] = Phi[g * (J * J) + i * J + j];
+    }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      if (k0 + q < K) {
+        if (lane < J) Fst[(b * K + k0 + q) * J + lane] = F;
+        double nf = gv[q];
+#pragma unroll
+        for (int j = 0; j < J; ++j) nf = fma(ph[q][j], __shfl(F, j, kWave), nf);
+        F = nf;
+      }
+    }
+  }
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                       const double *__restrict__ c, const double *__restrict__ U,
+                                                       const double *__restrict__ W, const double *__restrict__ y,
+                                                       const double *__restrict__ Fst, double *__restrict__ z) {
+  const Geo G = chunk_of(B, N, K);
+  double cj[J], F[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[G.b * J + j]; F[j] = G.len > 0 ? Fst[G.g * J + j] : 0.0; }
+  const double *tb = t + G.b * N, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
+  double *zb = z + G.b * N;
+  RowIn<J, true, false> cur, nxt;
+  fetch_row<J, true, false>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
+#pragma unroll 1
+  for (int r = 0; r < kRows; ++r) {
+    fetch_row<J, true, false>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
+    if (r < G.len) {
+      double uf = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) uf = fma(cur.u[j], F[j], uf);
+      const double zn = cur.z - uf;
+      zb[G.lo + r] = zn;
+#pragma unroll
+      for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]) * exp_decay(-cj[i] * cur.dt);
+    }
+    cur = nxt;
+  }
+}
+
+struct Layout {
+  size_t d, W, z, loc, start, ends, map, sf, dT, bcp, llp, total;
+};
+template <int J>
+static Layout layout(int64_t B, int64_t N) {
+  constexpr size_t NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
+  const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
+  const size_t waves = (BK + kWave - 1) / kWave;
+  Layout L;
+  size_t o = 0;
+  auto take = [&](size_t n) { const size_t at = o; o += (n + 1) & ~(size_t)1; return at; };   // 16-byte aligned pieces
+  L.d = take(BN); L.W = take(BN * J); L.z = take(BN);
+  L.loc = take(BK * NST); L.start = take(BK * NST); L.ends = take(BK * NST);
+  L.map = take(BK * MAPR);
+  L.sf = take(waves * kRows * NST * kWave);
+  L.dT = take(BN); L.bcp = take(BK * J); L.llp = take(BK);
+  L.total = o;
+  return L;
+}
+
+template <int J>
+static int run(int64_t B, int64_t N, const double *t, const double *c, const double *a, const double *U,
+               const double *V, const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
+               double *bV, double *by, int32_t *flag, double *work, hipStream_t s) {
+  const Layout L = layout<J>(B, N);
+  const int64_t K = (N + kRows - 1) / kRows;
+  double *d = work + L.d, *W = work + L.W, *z = work + L.z;
+  if (int e = c2_factor(B, N, J, t, N, c, J, a, U, V, d, W, nullptr, flag, (c2_stream_t)s)) return e;
+  const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
+  if (J == 6) {   // no tiled time-parallel solve at this width: chunk maps here (scratch: the region of the adjoint maps)
+    double *Phi = work + L.map, *gk = Phi + (size_t)B * K * J * J, *Fst = gk + (size_t)B * K * J;
+    hipLaunchKernelGGL((k_solve_maps<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y, Phi, gk);
+    hipLaunchKernelGGL((k_solve_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
+                       (const double *)gk, Fst);
+    hipLaunchKernelGGL((k_solve_apply<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y,
+                       (const double *)Fst, z);
+  } else if (int e = c2_solve_lower(B, N, J, 1, t, N, c, J, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
+  hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, (const double *)d, (const double *)W,
+                     (const double *)z, work + L.loc, work + L.llp);
+  hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, c, (const double *)(work + L.loc),
+                     (const double *)(work + L.llp), (const int32_t *)flag, work + L.start, ll);
+  constexpr int SP = J >= 6 ? 3 : (J + 1);   // sweeps sharing a pass over the rows
+  hipLaunchKernelGGL((k_maps<J, SP>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)d, (const double *)W,
+                     (const double *)z, work + L.map);
+  hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),
+                     work + L.ends);
+  hipLaunchKernelGGL((k_final<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, V, (const double *)d, (const double *)W,
+                     (const double *)z, (const double *)(work + L.start), (const double *)(work + L.ends),
+                     (const int32_t *)flag, work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, by);
+  hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, s, B, N,
+                     (const double *)(work + L.dT), (const int32_t *)flag, bt);
+  hipLaunchKernelGGL((k_finish_c<J>), dim3((unsigned)(B * J)), dim3(kWave), 0, s, K, (const double *)(work + L.bcp),
+                     (const int32_t *)flag, bc);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// ---- factor by Newton iterations on the chunk start states (widths 6, 8: no composable chunk maps in registers) -----------
+// Unknowns: X_k, the state entering chunk k (X_0 = 0).  Equations: X_{k+1} = f_k(X_k), f_k = the factor recursion
+// (forward.hpp:105-134) over the 64 rows of chunk k.  The Jacobian of f_k is a congruence, dX -> Phi_k dX Phi_k^T with
+// Phi_k = prod_n P_{n+1} (I - w_n u_n^T) (the closed-loop propagator of the underlying Kalman filter), so one Newton
+// iteration is
+//   (1) k_newton_pass: every chunk of every series, one lane each, walks its rows from the current X_k: d, W of its rows,
+//       its end state E_k = f_k(X_k) and Phi_k (a J x J product carried along);
+//   (2) k_newton_chain: one wavefront per series walks the chunks, delta_{k+1} = Phi_k delta_k Phi_k^T + E_k - X_{k+1},
+//       X_{k+1} += delta_{k+1}, and writes the largest relative update into the iteration's device word.
+// Convergence is quadratic (tools/proto/factor_newton.py: updates 1, 4e-2, 3e-4, 2e-8, 2e-15 on the bench series); the
+// update of iteration p measures the error of the X that pass p used, so the iterations stop -- each is launched behind
+// the previous word as its gate -- once it is below kNewtonTol, with d, W of that pass final.  If the last iteration still
+// moves, or a pass met a d that is not positive and finite, the caller's row-by-row kernel runs behind the last word.
+constexpr double kNewtonTol = 1e-13;
+template <int J>
+__global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                       int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                       const double *__restrict__ a, const double *__restrict__ U,
+                                                       const double *__restrict__ V, double *__restrict__ d,
+                                                       double *__restrict__ W, int32_t *__restrict__ flag,
+                                                       const double *__restrict__ X, double *__restrict__ E,
+                                                       double *__restrict__ Phi,
+                                                       const unsigned long long *__restrict__ gate,
+                                                       unsigned long long *__restrict__ word) {
+  constexpr int NS = Dim<J>::NS;
+  if (gate_closed(gate)) return;
+  const Geo G = chunk_of(B, N, K);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+  const double *tb = t + G.b * t_bs, *ab = a + G.b * N, *Ub = U + G.b * N * J, *Vb = V + G.b * N * J;
+  double *db = d + G.b * N, *Wb = W + G.b * N * J;
+  double S[NS], M[J][J];
+#pragma unroll
+  for (int e = 0; e < NS; ++e) S[e] = G.len > 0 ? X[G.g * NS + e] : 0.0;
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) M[i][j] = i == j ? 1.0 : 0.0;
+  bool bad = false;
+  double un[J], vn[J], an, dtn;   // row inputs one iteration ahead
+  auto fetch = [&](int r, double (&u)[J], double (&v)[J], double &av, double &dt) {
+    const int rc = r < G.len ? r : (G.len > 0 ? G.len - 1 : 0);
+    const int64_t n = G.lo + rc;
+    load_row<J>(Ub + n * J, u);
+    load_row<J>(Vb + n * J, v);
+    av = ab[n];
+    dt = tb[n + 1 < N ? n + 1 : n] - tb[n];
+  };
+  fetch(0, un, vn, an, dtn);
+#pragma unroll 1
+  for (int r = 0; r < kRows; ++r) {
+    double u[J], v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { u[j] = un[j]; v[j] = vn[j]; }
+    const double av = an, dt = dtn;
+    fetch(r + 1, un, vn, an, dtn);
+    if (r < G.len) {
+      const int64_t n = G.lo + r;
+      double tau[J], w[J], p[J];
+      double dn = av;
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) sum = fma(S[sym(J, i, j)], u[j], sum);
+        tau[i] = sum;
+        dn = fma(-u[i], sum, dn);
+      }
+      bad = bad || !(dn > 0.0) || !(dn < __builtin_huge_val());
+      const double rd = 1.0 / dn;
+#pragma unroll
+      for (int i = 0; i < J; ++i) { w[i] = (v[i] - tau[i]) * rd; p[i] = exp_decay(-cj[i] * dt); }
+      db[n] = dn;
+      store_row<J>(Wb + n * J, w);
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        const double dwp = dn * w[i] * p[i];
+#pragma unroll
+        for (int j = i; j < J; ++j)
+          S[sidx(J, i, j)] = fma(dwp, w[j] * p[j], S[sidx(J, i, j)] * (p[i] * p[j]));   // (S + d w_i w_j) p_i p_j
+      }
+      // M <- P (I - w u^T) M
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double um = 0.0;
+#pragma unroll
+        for (int l = 0; l < J; ++l) um = fma(u[l], M[l][j], um);
+#pragma unroll
+        for (int i = 0; i < J; ++i) M[i][j] = fma(-w[i], um, M[i][j]) * p[i];
+      }
+    }
+  }
+  if (G.len > 0) {
+#pragma unroll
+    for (int e = 0; e < NS; ++e) E[G.g * NS + e] = S[e];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) Phi[G.g * (J * J) + i * J + j] = M[i][j];
+    if (G.k == 0) flag[G.b] = 0;
+  }
+  if (__any(bad) && threadIdx.x == 0)
+    atomicMax(word, (unsigned long long)__double_as_longlong(__builtin_huge_val()));
+}
+
+// One wavefront per series; lane (i, j) = entry of the J x J update.
+template <int J>
+__global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__restrict__ X, const double *__restrict__ E,
+                                                        const double *__restrict__ Phi,
+                                                        const unsigned long long *__restrict__ gate,
+                                                        unsigned long long *__restrict__ word) {
+  constexpr int NS = Dim<J>::NS;
+  if (gate_closed(gate)) return;
+  __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1], Xd[J];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x;
+  const int sij = sym(J, i, j), sii = sidx(J, i, i);
+  if (act) Dm[i][j] = 0.0;
+  lds_order();
+  double worst = 0.0;
+  double ph, ev, xv, xd;
+  auto fetch = [&](int64_t k) {   // chunk k: Phi_k, E_k; X_{k+1} and its diagonal entry X_{k+1}(i, i)
+    const int64_t g = b * K + k;
+    ph = Phi[g * (J * J) + i * J + j];
+    ev = E[g * NS + sij];
+    xv = X[(g + 1) * NS + sij];
+    xd = E[g * NS + sii];
+  };
+  if (K >= 2) fetch(0);
+  for (int64_t k = 0; k + 1 < K; ++k) {
+    const double mph = ph, mev = ev, mxv = xv, mxd = xd;
+    if (k + 2 < K) fetch(k + 1);
+    Pm[i][j] = mph;
+    if (act && j == 0) Xd[i] = mxd;
+    lds_order();
+    double y = 0.0;      // (delta Phi^T)(i, j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) y = fma(Dm[i][l], Pm[j][l], y);
+    Ym[i][j] = y;
+    lds_order();
+    double nx = mev;     // E + Phi delta Phi^T
+#pragma unroll
+    for (int q = 0; q < J; ++q) nx = fma(Pm[i][q], Ym[q][j], nx);
+    const double dl = nx - mxv;
+    const double scale = sqrt(fabs(Xd[i] * Xd[j]));   // |X(i, j)| <= sqrt(X(i, i) X(j, j)) for the positive semidefinite state
+    const double rel = fabs(dl) / fmax(scale, 1e-300);
+    worst = fmax(worst, act ? rel : 0.0);
+    if (!(rel == rel)) worst = __builtin_huge_val();
+    lds_order();
+    if (act) Dm[i][j] = dl;
+    if (act && i <= j) X[(b * K + k + 1) * NS + sij] = nx;
+    lds_order();
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
+  worst /= 0.5 * kNewtonTol;   // > 2 <=> above the tolerance
+  if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
+}
+
+}  // namespace c2tg
+
+using namespace c2tg;
+
+// doubles of workspace of the time-parallel gradient (0: width not covered)
+extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J) {
+  switch (J) {
+    case 2: return layout<2>(B, N).total;
+    case 4: return layout<4>(B, N).total;
+    case 6: return layout<6>(B, N).total;
+    case 8: return layout<8>(B, N).total;
+    default: return 0;
+  }
+}
+
+// Per-series t and c only (strides N and J).  Same outputs as c2_loglik_grad.
+extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, const double *c,
+                                               const double *a, const double *U, const double *V, const double *y,
+                                               double *ll, double *bt, double *bc, double *ba, double *bU, double *bV,
+                                               double *by, int32_t *flag, double *work, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (J) {
+    case 2: return run<2>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 4: return run<4>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 6: return run<6>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 8: return run<8>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    default: return C2_ERR_UNSUPPORTED;
+  }
+}
+
+// factor (d, W) by Newton iterations on the chunk start states (widths 6, 8).  work: c2_internal_factor_iter_doubles;
+// its first kNewtonMax + 2 words are the iteration words -- the caller launches its row-by-row kernel behind `*last_word`.
+constexpr int kNewtonMax = 8;
+extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {
+  if (J != 6 && J != 8) return 0;
+  const size_t K = (size_t)((N + kRows - 1) / kRows);
+  return (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
+}
+template <int J>
+static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                           const double *a, const double *U, const double *V, double *d, double *W, int32_t *flag,
+                           double *work, const unsigned long long **last_word, hipStream_t s) {
+  constexpr int NS = Dim<J>::NS;
+  const int64_t K = (N + kRows - 1) / kRows;
+  const int P = K < kNewtonMax ? (int)K : kNewtonMax;   // iteration p makes the first p chunks exact
+  unsigned long long *words = (unsigned long long *)work;
+  const size_t BK = (size_t)B * K;
+  double *X = work + (kNewtonMax + 2), *E = X + BK * NS, *Phi = E + BK * NS;
+  if (hipMemsetAsync(work, 0, ((size_t)(kNewtonMax + 2) + BK * NS) * sizeof(double), s) != hipSuccess) return C2_ERR_HIP;
+  const dim3 grid((unsigned)((B * K + kWave - 1) / kWave));
+  for (int p = 1; p <= P; ++p) {
+    const unsigned long long *gate = p >= 2 ? words + p - 1 : nullptr;
+    hipLaunchKernelGGL((k_newton_pass<J>), grid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, d, W, flag,
+                       (const double *)X, E, Phi, gate, words + p);
+    hipLaunchKernelGGL((k_newton_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, X, (const double *)E,
+                       (const double *)Phi, gate, words + p);
+  }
+  *last_word = words + P;
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                       int64_t c_bs, const double *a, const double *U, const double *V, double *d,
+                                       double *W, int32_t *flag, double *work, const unsigned long long **last_word,
+                                       c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (J == 6) return run_factor_iter<6>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
+  if (J == 8) return run_factor_iter<8>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
+  return C2_ERR_UNSUPPORTED;
+}

@@ -174,3 +174,94 @@ def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
         zb = Y[b].copy(); oracle.solve_lower(t[0], c[0], U[0], W[0], Y[b], zb); want[b] = zb
     got = ops.solve_lower(t0d, c0d, U0d, W0d, Yd)
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
+
+
+@pytest.mark.parametrize("J", [8, 6, 4, 2])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 128), (7, 700), (2, 4096), (70, 300), (1, 20000)])
+def test_timepar_gradient_matches_oracle(ops, oracle, monkeypatch, B, N, J):
+    """The gradient parallel along time (c2_timepar_grad.hip: d, W, z from factor + solve, linear recurrences for the
+    states, the adjoint recursion as affine chunk maps), forced on shapes around the chunk length (64 rows): log-likelihood
+    and all six gradients against the oracle; a failed series gets -inf / NaN and leaves its neighbours alone."""
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    llo, go, flo = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    assert not np.asarray(flo).any()
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+    ll, grads, flag = ops.loglik_grad(*dev(t, c, a, U, V, y))
+    assert int(flag.abs().sum()) == 0
+    close(ll, llo)
+    for g, e in zip(grads, go):
+        gclose(g, e)
+    # the row-by-row kernels give the same
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "0")
+    ll0, grads0, _ = ops.loglik_grad(*dev(t, c, a, U, V, y))
+    close(ll, ll0.cpu().numpy())
+    for g, e in zip(grads, grads0):
+        gclose(g, e.cpu().numpy())
+    if B > 2 and N > 2:
+        monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+        a2 = a.copy(); a2[1, N // 2] = -5.0
+        ll2, grads2, flag2 = ops.loglik_grad(*dev(t, c, a2, U, V, y))
+        fl = flag2.cpu().numpy()
+        assert fl[1] != 0 and not fl[[0, 2]].any()
+        assert np.isneginf(ll2.cpu().numpy()[1])
+        for g, e in zip(grads2, go):
+            gn = g.cpu().numpy()
+            assert np.isnan(gn[1]).all()
+            gclose(gn[0], e[0]); gclose(gn[2], e[2])
+
+
+def gclose(a, b, tol=1e-10):
+    """gradients: relative to the largest entry of the array (the small entries of a gradient are sums of large terms)"""
+    a = a.cpu().numpy() if hasattr(a, "cpu") else a
+    np.testing.assert_allclose(a, b, rtol=0.0, atol=tol * max(np.abs(b).max(), 1e-300))
+
+
+@pytest.mark.parametrize("J", [8, 6])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 129), (2, 4096), (9, 1000), (1, 30000)])
+def test_newton_factor_matches_oracle(ops, oracle, monkeypatch, B, N, J):
+    """`factor` (d, W) at widths 6 and 8 by Newton iterations on the chunk start states (c2_timepar_grad.hip), forced:
+    every row against the oracle; a failed series hands the batch to the row-by-row kernel, which reports the
+    reference's flag; in-place calls stay on the row-by-row kernel and agree."""
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V))
+    monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    d, W, flag = ops.factor(*dev(t, c, a, U, V))
+    assert int(flag.abs().sum()) == 0
+    for b in range(B):
+        do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So) == 0
+        close(d[b], do); np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
+    if N > 40:
+        a1 = a.copy(); a1[0, N // 2] = -2.0
+        d1, W1, flag1 = ops.factor(*dev(t, c, a1, U, V))
+        assert int(flag1[0]) == N // 2 and int(flag1[1:].abs().sum()) == 0
+        monkeypatch.setenv("C2_FACTOR_ITER", "0")
+        d0, W0, flag0 = ops.factor(*dev(t, c, a1, U, V))
+        assert np.array_equal(d1.cpu().numpy()[1:], d0.cpu().numpy()[1:]) if B > 1 else True
+        monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    ad, Vd = dev(a, V)
+    td, cd, Ud = dev(t, c, U)
+    d2, W2, _ = ops.factor(td, cd, ad, Ud, Vd, d=ad, W=Vd)   # in place
+    close(d2, d.cpu().numpy()); np.testing.assert_allclose(W2.cpu().numpy(), W.cpu().numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_newton_factor_on_hard_series(ops, oracle, monkeypatch):
+    """Series the Newton iteration has to work for: a long gap (the states decouple), repeated times, a nearly singular
+    stretch (tiny white noise), very slow and very fast rates side by side -- every row against the oracle, whether the
+    iteration converged or the row-by-row kernel took over."""
+    J, N, B = 8, 3000, 4
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    t[0, N // 2:] += 500.0
+    t[1, 100:110] = t[1, 100]
+    a[2, 1000:1400] -= 0.999 * (a[2, 1000:1400] - np.sum(U[2, 1000:1400] * V[2, 1000:1400], axis=1))
+    c[3] = c[3] * np.array([1e-3, 1e-3, 1.0, 1.0, 30.0, 30.0, 300.0, 300.0])
+    monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    d, W, flag = ops.factor(*dev(t, c, a, U, V))
+    for b in range(B):
+        do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+        fo = oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So)
+        assert int(flag[b]) == fo
+        if fo == 0:
+            close(d[b], do, tol=1e-9 if b == 2 else 1e-10)
+            np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-9 if b == 2 else 1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))

@@ -898,8 +898,8 @@ extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, 
 #ifndef C2_TIMEPAR_GRAD_MIN_ROWS
 #define C2_TIMEPAR_GRAD_MIN_ROWS 1024
 #endif
-#ifndef C2_TIMEPAR_GRAD_MAX_BATCH_X_WIDTH
-#define C2_TIMEPAR_GRAD_MAX_BATCH_X_WIDTH 8192
+#ifndef C2_TIMEPAR_GRAD_MAX_CHUNKS
+#define C2_TIMEPAR_GRAD_MAX_CHUNKS 32768
 #endif
 static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   if (J != 2 && J != 4 && J != 6 && J != 8) return false;
@@ -907,7 +907,10 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   if (e) return atoi(e) != 0 && N >= 2;
   const char *l = getenv("C2_LANES");
   if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
-  return N >= C2_TIMEPAR_GRAD_MIN_ROWS && B * J <= C2_TIMEPAR_GRAD_MAX_BATCH_X_WIDTH;
+  // Measured (tools/timepar_grad_time.py): one series of 1e5 rows 103 -> 6.0 ms at J = 8, 61 -> 1.6 ms at J = 2; 32 series
+  // of 50000 rows at J = 6 57.6 -> 4.6 ms; 256 x 4096 at J = 8 4.3 -> 1.9 ms.  The chunks are walked one per lane with
+  // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
+  return N >= C2_TIMEPAR_GRAD_MIN_ROWS && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
 }
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 6 && J != 4 && J != 2) return false;
@@ -1003,8 +1006,8 @@ static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
   const char *l = getenv("C2_LANES");
   if (l && atoi(l) != 0) return false;
   // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,
-  // 3.9 vs 29.5 ms at 1e5; with more than ~16k chunks in flight a pass no longer has a SIMD per wavefront
-  return N >= 2048 && B * ((N + 63) / 64) <= 16384;
+  // 3.9 vs 29.5 ms at 1e5; 2.1 vs 19.9 ms for 32 series of 50000; with 64k chunks in flight (1024 x 4096) a pass no longer has a SIMD per wavefront: 2.3 vs 1.2 ms
+  return N >= 2048 && B * ((N + 63) / 64) <= 32768;
 }
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,

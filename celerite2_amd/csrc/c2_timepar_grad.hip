@@ -16,7 +16,7 @@
 // i.e. a chunk acts on the adjoint it receives at its end as an AFFINE map
 //     bF_start = Phi^T bF_end + gF ,   bS_start = Phi^T bS_end Phi + sum_k bF_end[k] C_k + gS .
 // k_maps finds (Phi, C_k, gS, gF) of every chunk by J + 1 sweeps over its rows (bF_end = e_k with bS_end = 0; zero end
-// adjoint with the sources), one lane per chunk; k_chain walks the chunks of a series backwards applying the maps
+// adjoint with the sources), one lane per chunk and sweep; k_chain walks the chunks of a series backwards applying the maps
 // (lanes <-> the J x J entries); k_final gives every chunk its true end adjoint and runs the one sweep that writes the
 // gradients.  That sweep needs the states S_n, F_n entering each row in reverse order: the chunk replays them forward
 // into a lane-major scratch record first (no backward recursion, hence no stability condition).
@@ -241,76 +241,67 @@ __device__ __forceinline__ RowOut adjoint_row(double (&bS)[Dim<J>::NS], double (
   RowOut o;
   o.bz = wbF - (SRC ? zd : 0.0);
   o.bd = -wg - zd * wbF - (SRC ? 0.5 * (rd - zd * zd) : 0.0);
+  double hb[J];   // btau / 2
 #pragma unroll
   for (int i = 0; i < J; ++i) {
-    if (OUT) g2[i] = fma(2.0, g[i], zd * bF[i]);          // bV_n = bw / d
-    btau[i] = -fma(2.0, g[i], zd * bF[i]) - o.bd * u[i];
+    const double bv = fma(2.0, g[i], zd * bF[i]);          // bV_n = bw / d
+    if (OUT) g2[i] = bv;
+    btau[i] = -bv - o.bd * u[i];
+    hb[i] = 0.5 * btau[i];
     bF[i] = fma(-o.bz, u[i], bF[i]);
   }
 #pragma unroll
   for (int i = 0; i < J; ++i) {
 #pragma unroll
     for (int j = i; j < J; ++j)
-      bS[sidx(J, i, j)] += 0.5 * fma(btau[i], u[j], u[i] * btau[j]);
+      bS[sidx(J, i, j)] = fma(hb[i], u[j], fma(u[i], hb[j], bS[sidx(J, i, j)]));   // += sym(btau u^T)
   }
   return o;
 }
 
 // ---- adjoint maps of the chunks ---------------------------------------------------------------------------------------
-// One lane per chunk; SP sweeps share the rows and the decay factors of a pass.  map[g][s * NST ...]: result (bS, bF)
-// of sweep s (s < J: from bF_end = e_s; s = J: from zero, with the sources).
-template <int J, int SP>
+// One lane per (chunk, sweep): blockIdx.y is the sweep, so a small batch still spreads over J + 1 times as many
+// wavefronts as it has chunks / 64 (one series of 4096 rows: 9 wavefronts instead of 1 walking 9 sweeps in turn).
+// map[g][s * NST ...]: result (bS, bF) of sweep s (s < J: from bF_end = e_s; s = J: from zero, with the sources).
+template <int J>
 __global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                 const double *__restrict__ c, const double *__restrict__ U,
                                                 const double *__restrict__ d, const double *__restrict__ W,
                                                 const double *__restrict__ z, double *__restrict__ map) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
   const Geo G = chunk_of(B, N, K);
+  const int sweep = blockIdx.y;
   double cj[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
   const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N;
   const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J;
+  double bS[NS], bF[J];
+#pragma unroll
+  for (int e = 0; e < NS; ++e) bS[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) bF[j] = sweep == j ? 1.0 : 0.0;
+  RowIn<J, true, false> cur, nxt;
+  fetch_row<J, true, false>(cur, G, N, kRows - 1, tb, Ub, nullptr, Wb, db, zb);
 #pragma unroll 1
-  for (int s0 = 0; s0 <= J; s0 += SP) {
-    double bS[SP][NS], bF[SP][J];
+  for (int r = kRows - 1; r >= 0; --r) {
+    fetch_row<J, true, false>(nxt, G, N, r - 1, tb, Ub, nullptr, Wb, db, zb);
+    if (r < G.len) {
+      double p[J], g2[J], btau[J];
+      const double rd = 1.0 / cur.d;
 #pragma unroll
-    for (int q = 0; q < SP; ++q) {
-#pragma unroll
-      for (int e = 0; e < NS; ++e) bS[q][e] = 0.0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) bF[q][j] = (s0 + q == j) ? 1.0 : 0.0;
+      for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+      if (sweep < J) (void)adjoint_row<J, false, false>(bS, bF, p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+      else (void)adjoint_row<J, true, false>(bS, bF, p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
     }
-    RowIn<J, true, false> cur, nxt;
-    fetch_row<J, true, false>(cur, G, N, kRows - 1, tb, Ub, nullptr, Wb, db, zb);
-#pragma unroll 1
-    for (int r = kRows - 1; r >= 0; --r) {
-      fetch_row<J, true, false>(nxt, G, N, r - 1, tb, Ub, nullptr, Wb, db, zb);
-      if (r < G.len) {
-        double p[J], g2[J], btau[J];
-        const double rd = 1.0 / cur.d;
+    cur = nxt;
+  }
+  if (G.len > 0) {
+    double *o = map + G.g * MAPR + (int64_t)sweep * NST;
 #pragma unroll
-        for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+    for (int e = 0; e < NS; ++e) o[e] = bS[e];
 #pragma unroll
-        for (int q = 0; q < SP; ++q) {
-          if (s0 + q < J) (void)adjoint_row<J, false, false>(bS[q], bF[q], p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
-          else if (s0 + q == J) (void)adjoint_row<J, true, false>(bS[q], bF[q], p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
-        }
-      }
-      cur = nxt;
-    }
-    if (G.len > 0) {
-#pragma unroll
-      for (int q = 0; q < SP; ++q) {
-        if (s0 + q <= J) {
-          double *o = map + G.g * MAPR + (int64_t)(s0 + q) * NST;
-#pragma unroll
-          for (int e = 0; e < NS; ++e) o[e] = bS[q][e];
-#pragma unroll
-          for (int j = 0; j < J; ++j) o[NS + j] = bF[q][j];
-        }
-      }
-    }
+    for (int j = 0; j < J; ++j) o[NS + j] = bF[j];
   }
 }
 
@@ -667,9 +658,8 @@ static int run(int64_t B, int64_t N, const double *t, const double *c, const dou
                      (const double *)z, work + L.loc, work + L.llp);
   hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, c, (const double *)(work + L.loc),
                      (const double *)(work + L.llp), (const int32_t *)flag, work + L.start, ll);
-  constexpr int SP = J >= 6 ? 3 : (J + 1);   // sweeps sharing a pass over the rows
-  hipLaunchKernelGGL((k_maps<J, SP>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)d, (const double *)W,
-                     (const double *)z, work + L.map);
+  hipLaunchKernelGGL((k_maps<J>), dim3(cgrid.x, (unsigned)(J + 1)), dim3(kWave), 0, s, B, N, K, t, c, U,
+                     (const double *)d, (const double *)W, (const double *)z, work + L.map);
   hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),
                      work + L.ends);
   hipLaunchKernelGGL((k_final<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, V, (const double *)d, (const double *)W,

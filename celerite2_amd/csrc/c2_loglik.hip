@@ -912,6 +912,27 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
   return N >= C2_TIMEPAR_GRAD_MIN_ROWS && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
 }
+// widths 6 and 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
+// gated behind; the forward-only log-likelihood composed from it
+extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                       int64_t c_bs, const double *a, const double *U, const double *V, double *d,
+                                       double *W, int32_t *flag, double *work, const unsigned long long **last_word,
+                                       c2_stream_t stream);
+extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, const double *c, const double *a,
+                                       const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+                                       double *work, c2_stream_t stream);
+static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
+  if (J != 6 && J != 8) return false;
+  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it, 0 disables it
+  if (e) return atoi(e) != 0 && N >= 2;
+  const char *l = getenv("C2_LANES");
+  if (l && atoi(l) != 0) return false;
+  // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,
+  // 3.9 vs 29.5 ms at 1e5; 2.1 vs 19.9 ms for 32 series of 50000; with 64k chunks in flight (1024 x 4096) a pass no longer has a SIMD per wavefront: 2.3 vs 1.2 ms
+  return N >= 2048 && B * ((N + 63) / 64) <= 32768;
+}
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 6 && J != 4 && J != 2) return false;
   const char *e = getenv("C2_LANES");
@@ -948,6 +969,17 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
+  if (capturing == hipStreamCaptureStatusNone && t_bs == N && c_bs == J && use_factor_iter(B, N, J)) {
+    // widths 6 / 8: d, W by Newton iterations on the chunk start states, z by the time-parallel solve, a reduction
+    const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);
+    void *tmp = nullptr;
+    if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+      int rc = c2_internal_loglik_wide(B, N, J, t, c, a, U, V, y, ll, flag, (double *)tmp, stream);
+      if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+      return rc;
+    }
+    (void)hipGetLastError();
+  }
   if (capturing == hipStreamCaptureStatusNone && use_timepar(B, N, J)) {
     // Small batch of long series: parallel along time (c2_timepar.hip), verified on the device; the ordinary kernel
     // below runs behind the verification word and does nothing unless it failed.  Scratch is a stream-ordered
@@ -993,22 +1025,6 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
                                           int64_t c_bs, const double *a, const double *U, const double *V, double *d,
                                           double *W, int32_t *flag, double *work, unsigned long long *guard,
                                           c2_stream_t stream);
-// widths 6 and 8: fixed-point passes over chunks of 64 rows (c2_timepar_grad.hip), the row-by-row kernel gated behind
-extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J);
-extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                                       int64_t c_bs, const double *a, const double *U, const double *V, double *d,
-                                       double *W, int32_t *flag, double *work, const unsigned long long **last_word,
-                                       c2_stream_t stream);
-static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
-  if (J != 6 && J != 8) return false;
-  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it, 0 disables it
-  if (e) return atoi(e) != 0 && N >= 2;
-  const char *l = getenv("C2_LANES");
-  if (l && atoi(l) != 0) return false;
-  // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,
-  // 3.9 vs 29.5 ms at 1e5; 2.1 vs 19.9 ms for 32 series of 50000; with 64k chunks in flight (1024 x 4096) a pass no longer has a SIMD per wavefront: 2.3 vs 1.2 ms
-  return N >= 2048 && B * ((N + 63) / 64) <= 32768;
-}
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                              int32_t *flag, int allow_timepar, c2_stream_t stream) {

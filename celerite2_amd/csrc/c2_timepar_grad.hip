@@ -617,6 +617,25 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
   }
 }
 
+// ---- forward-only log-likelihood from d and z (widths 6, 8: factor by Newton iterations + solve) -----------------------------
+__global__ __launch_bounds__(kWave) void k_ll_chunks(int64_t B, int64_t N, int64_t K, const double *__restrict__ d,
+                                                     const double *__restrict__ z, double *__restrict__ llp) {
+  const Geo G = chunk_of(B, N, K);
+  const double *db = d + G.b * N + G.lo, *zb = z + G.b * N + G.lo;
+  double acc = 0.0;
+  for (int r = 0; r < G.len; ++r) acc += log(db[r]) + zb[r] * zb[r] / db[r];
+  if (G.len > 0) llp[G.g] = acc;
+}
+__global__ __launch_bounds__(kWave) void k_ll_series(int64_t N, int64_t K, const double *__restrict__ llp,
+                                                     const int32_t *__restrict__ flag, double *__restrict__ ll) {
+  const int64_t b = blockIdx.x;
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < K; k += kWave) s += llp[b * K + k];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+  if (threadIdx.x == 0) ll[b] = flag[b] != 0 ? -__builtin_huge_val() : -0.5 * s - 0.5 * (double)N * kLog2Pi;
+}
+
 struct Layout {
   size_t d, W, z, loc, start, ends, map, sf, dT, bcp, llp, total;
 };
@@ -902,4 +921,34 @@ extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const do
   if (J == 6) return run_factor_iter<6>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   if (J == 8) return run_factor_iter<8>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   return C2_ERR_UNSUPPORTED;
+}
+
+// Forward-only log-likelihood for small batches of long series at widths 6 / 8: d, W by c2_factor (Newton iterations on the
+// chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.  Per-series t and c.
+extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J) {
+  if (J != 6 && J != 8) return 0;
+  const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
+  return BN * (2 + J) + BK * (1 + (size_t)J * J + 2 * J) + 8;
+}
+extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, const double *c, const double *a,
+                                       const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+                                       double *work, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (J != 6 && J != 8) return C2_ERR_UNSUPPORTED;
+  const int64_t K = (N + kRows - 1) / kRows;
+  const size_t BN = (size_t)B * N, BK = (size_t)B * K;
+  double *d = work, *z = d + BN, *W = z + BN, *llp = W + BN * J, *Phi = llp + BK, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
+  if (int e = c2_factor(B, N, J, t, N, c, J, a, U, V, d, W, nullptr, flag, stream)) return e;
+  const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
+  if (J == 6) {
+    hipLaunchKernelGGL((k_solve_maps<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y, Phi, gk);
+    hipLaunchKernelGGL((k_solve_chain<6>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
+                       (const double *)gk, Fst);
+    hipLaunchKernelGGL((k_solve_apply<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y,
+                       (const double *)Fst, z);
+  } else if (int e = c2_solve_lower(B, N, J, 1, t, N, c, J, U, W, y, z, nullptr, stream)) return e;
+  hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);
+  hipLaunchKernelGGL(k_ll_series, dim3((unsigned)B), dim3(kWave), 0, s, N, K, (const double *)llp,
+                     (const int32_t *)flag, ll);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }

@@ -265,3 +265,47 @@ def test_newton_factor_on_hard_series(ops, oracle, monkeypatch):
         if fo == 0:
             close(d[b], do, tol=1e-9 if b == 2 else 1e-10)
             np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-9 if b == 2 else 1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
+
+
+@pytest.mark.parametrize("J", [8, 6])
+@pytest.mark.parametrize("B,N", [(1, 1), (3, 63), (4, 65), (2, 4096), (9, 1000), (1, 30000)])
+def test_wide_loglik_matches_oracle(ops, oracle, monkeypatch, B, N, J):
+    """Forward-only log-likelihood at widths 6 / 8 composed from the Newton factor, the time-parallel solve and a
+    reduction (forced): against the oracle and the row-by-row kernel; a failed series gets its flag and -inf."""
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    llo, flo = oracle_ll(oracle, t, c, a, U, V, y)
+    monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    ll, flag = ops.loglik(*dev(t, c, a, U, V, y))
+    assert int(flag.abs().sum()) == 0
+    close(ll, llo)
+    monkeypatch.setenv("C2_FACTOR_ITER", "0")
+    ll0, _ = ops.loglik(*dev(t, c, a, U, V, y))
+    close(ll, ll0.cpu().numpy())
+    if B > 2 and N > 40:
+        monkeypatch.setenv("C2_FACTOR_ITER", "1")
+        a1 = a.copy(); a1[1, N // 3] = -3.0
+        ll1, flag1 = ops.loglik(*dev(t, c, a1, U, V, y))
+        fl = flag1.cpu().numpy()
+        assert fl[1] != 0 and not fl[[0, 2]].any()
+        assert np.isneginf(ll1.cpu().numpy()[1])
+        close(ll1[[0, 2]], llo[[0, 2]])
+
+
+def test_time_parallel_gradient_is_the_default_for_long_series(ops, oracle, monkeypatch):
+    """Without any switch a small batch of long series takes the time-parallel gradient (bitwise the forced result) at
+    every width it covers, and agrees with the oracle; the workspace query covers it."""
+    import torch
+    for J, B, N in ((8, 2, 5000), (6, 3, 3000), (4, 1, 9000), (2, 5, 2048)):
+        t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+        args = dev(t, c, a, U, V, y)
+        monkeypatch.delenv("C2_TIMEPAR_GRAD", raising=False)
+        work = ops.loglik_grad_workspace(B, N, J, torch.device("cuda:0"))
+        ll, grads, flag = ops.loglik_grad(*args, work=work)
+        monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+        ll1, grads1, _ = ops.loglik_grad(*args)
+        assert torch.equal(ll, ll1) and all(torch.equal(g, g1) for g, g1 in zip(grads, grads1))
+        llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+        close(ll, llo)
+        for g, e in zip(grads, go):
+            gclose(g, e)

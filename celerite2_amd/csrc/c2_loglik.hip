@@ -888,11 +888,11 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   if (e) return atoi(e) != 0 && N >= 2;
   return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
-// Time-parallel GRADIENT (c2_timepar_grad.hip; widths 2, 4, 6, 8, per-series t and c): small batches of long series.
+// Time-parallel GRADIENT (c2_timepar_grad.hip; widths 2, 4, 6, 8): small batches of long series.
 // C2_TIMEPAR_GRAD=1 forces it, =0 disables it.
 extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J);
-extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, const double *c,
-                                               const double *a, const double *U, const double *V, const double *y,
+extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                               const double *c, int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                                double *ll, double *bt, double *bc, double *ba, double *bU, double *bV,
                                                double *by, int32_t *flag, double *work, c2_stream_t stream);
 #ifndef C2_TIMEPAR_GRAD_MIN_ROWS
@@ -920,7 +920,8 @@ extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const do
                                        double *W, int32_t *flag, double *work, const unsigned long long **last_word,
                                        c2_stream_t stream);
 extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J);
-extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, const double *c, const double *a,
+extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                       int64_t c_bs, const double *a,
                                        const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                        double *work, c2_stream_t stream);
 static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
@@ -969,12 +970,12 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
-  if (capturing == hipStreamCaptureStatusNone && t_bs == N && c_bs == J && use_factor_iter(B, N, J)) {
+  if (capturing == hipStreamCaptureStatusNone && use_factor_iter(B, N, J)) {
     // widths 6 / 8: d, W by Newton iterations on the chunk start states, z by the time-parallel solve, a reduction
     const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
-      int rc = c2_internal_loglik_wide(B, N, J, t, c, a, U, V, y, ll, flag, (double *)tmp, stream);
+      int rc = c2_internal_loglik_wide(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp, stream);
       if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
       return rc;
     }
@@ -1076,7 +1077,7 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
     const size_t r = lanes1_record_doubles(B, N, J);
     n = 2 + (r > n ? r : n);
   }
-  if (use_timepar_grad(B, N, J)) {   // either path may run (shared t / c stay row by row): the larger of the two
+  if (use_timepar_grad(B, N, J)) {
     const size_t r = c2_internal_timepar_grad_doubles(B, N, J);
     n = r > n ? r : n;
   }
@@ -1092,9 +1093,9 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
   if (!t || !c || !a || !U || !V || !y || !ll || !bt || !bc || !ba || !bU || !bV || !by || !flag || !work)
     return C2_ERR_INVALID;
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
-  if (t_bs == N && c_bs == J && use_timepar_grad(B, N, J))   // small batch of long series: parallel along time
-    return c2_internal_loglik_grad_timepar(B, N, J, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, (double *)work,
-                                           stream);
+  if (use_timepar_grad(B, N, J))   // small batch of long series: parallel along time
+    return c2_internal_loglik_grad_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
+                                           (double *)work, stream);
   if (use_lanes4(B, J, true))
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   const unsigned long long *gate = nullptr;

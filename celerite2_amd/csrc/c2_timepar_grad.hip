@@ -122,16 +122,16 @@ __device__ __forceinline__ void decay(double (&S)[Dim<J>::NS], double (&F)[J], c
 // ---- forward: contributions of the chunks, start states ---------------------------------------------------------------
 // loc[g]: state entering the first row of chunk g+1 if chunk g had started from zero; llp[g]: sum (log d + z^2 / d)
 template <int J>
-__global__ __launch_bounds__(kWave) void k_local(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                 const double *__restrict__ c, const double *__restrict__ d,
+__global__ __launch_bounds__(kWave) void k_local(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                 const double *__restrict__ c, int64_t c_bs, const double *__restrict__ d,
                                                  const double *__restrict__ W, const double *__restrict__ z,
                                                  double *__restrict__ loc, double *__restrict__ llp) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
   const Geo G = chunk_of(B, N, K);
   double cj[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
-  const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N, *Wb = W + G.b * N * J;
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+  const double *tb = t + G.b * t_bs, *db = d + G.b * N, *zb = z + G.b * N, *Wb = W + G.b * N * J;
   double S[NS], F[J];
 #pragma unroll
   for (int e = 0; e < NS; ++e) S[e] = 0.0;
@@ -168,22 +168,22 @@ __global__ __launch_bounds__(kWave) void k_local(int64_t B, int64_t N, int64_t K
 // One wavefront per series, lane <-> entry of the state: start[g] = state entering the first row of chunk g.  Also the
 // log-likelihood (numpy.py:66-109): -1/2 sum (log d + z^2/d) - N/2 log 2 pi, -inf for a failed factorisation.
 template <int J>
-__global__ __launch_bounds__(kWave) void k_starts(int64_t N, int64_t K, const double *__restrict__ t,
-                                                  const double *__restrict__ c, const double *__restrict__ loc,
+__global__ __launch_bounds__(kWave) void k_starts(int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                  const double *__restrict__ c, int64_t c_bs, const double *__restrict__ loc,
                                                   const double *__restrict__ llp, const int32_t *__restrict__ flag,
                                                   double *__restrict__ start, double *__restrict__ ll) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.x;
-  const double *tb = t + b * N;
+  const double *tb = t + b * t_bs;
   // rate of the lane's entry: c_i + c_j for S(i, j), c_i for F_i
   double rate = 0.0;
   if (lane < NST) {
-    if (lane >= NS) rate = c[b * J + (lane - NS)];
+    if (lane >= NS) rate = c[b * c_bs + (lane - NS)];
     else {
       int i = 0, rem = lane;
       while (rem >= J - i) { rem -= J - i; ++i; }
-      rate = c[b * J + i] + c[b * J + i + rem];
+      rate = c[b * c_bs + i] + c[b * c_bs + i + rem];
     }
   }
   double cur = 0.0;
@@ -264,8 +264,8 @@ __device__ __forceinline__ RowOut adjoint_row(double (&bS)[Dim<J>::NS], double (
 // wavefronts as it has chunks / 64 (one series of 4096 rows: 9 wavefronts instead of 1 walking 9 sweeps in turn).
 // map[g][s * NST ...]: result (bS, bF) of sweep s (s < J: from bF_end = e_s; s = J: from zero, with the sources).
 template <int J>
-__global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                const double *__restrict__ c, const double *__restrict__ U,
+__global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                 const double *__restrict__ d, const double *__restrict__ W,
                                                 const double *__restrict__ z, double *__restrict__ map) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K,
   const int sweep = blockIdx.y;
   double cj[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
-  const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N;
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+  const double *tb = t + G.b * t_bs, *db = d + G.b * N, *zb = z + G.b * N;
   const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J;
   double bS[NS], bF[J];
 #pragma unroll
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(kWave) void k_chain(int64_t K, const double *__rest
 // ---- the sweep that writes the gradients --------------------------------------------------------------------------------
 // sf: lane-major record of the states entering the rows of a chunk: sf[((wave * 64 + r) * NST + e) * 64 + lane].
 template <int J>
-__global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                 const double *__restrict__ c, const double *__restrict__ U,
+__global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                 const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                  const double *__restrict__ V, const double *__restrict__ d,
                                                  const double *__restrict__ W, const double *__restrict__ z,
                                                  const double *__restrict__ start, const double *__restrict__ ends,
@@ -376,8 +376,8 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
   const Geo G = chunk_of(B, N, K);
   double cj[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
-  const double *tb = t + G.b * N, *db = d + G.b * N, *zb = z + G.b * N;
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+  const double *tb = t + G.b * t_bs, *db = d + G.b * N, *zb = z + G.b * N;
   const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J, *Vb = V + G.b * N * J;
   double *bab = ba + G.b * N, *byb = by + G.b * N, *bUb = bU + G.b * N * J, *bVb = bV + G.b * N * J, *dTb = dT + G.b * N;
   double *sfw = sf + (size_t)G.wave * kRows * NST * kWave + G.lane;
@@ -511,15 +511,15 @@ __global__ __launch_bounds__(kWave) void k_finish_c(int64_t K, const double *__r
 // z_n = y_n - u_n F_n (internal.hpp:135-145).  k_solve_maps: (Phi_k, g_k) of every chunk; k_solve_chain: the states the
 // chunks start from; k_solve_apply: z of every row.
 template <int J>
-__global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                      const double *__restrict__ c, const double *__restrict__ U,
+__global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                       const double *__restrict__ W, const double *__restrict__ y,
                                                       double *__restrict__ Phi, double *__restrict__ gk) {
   const Geo G = chunk_of(B, N, K);
   double cj[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[G.b * J + j];
-  const double *tb = t + G.b * N, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+  const double *tb = t + G.b * t_bs, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
   double M[J][J], F[J];
 #pragma unroll
   for (int i = 0; i < J; ++i) {
@@ -589,15 +589,15 @@ __global__ __launch_bounds__(kWave) void k_solve_chain(int64_t K, const double *
   }
 }
 template <int J>
-__global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                       const double *__restrict__ c, const double *__restrict__ U,
+__global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                       const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                        const double *__restrict__ W, const double *__restrict__ y,
                                                        const double *__restrict__ Fst, double *__restrict__ z) {
   const Geo G = chunk_of(B, N, K);
   double cj[J], F[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) { cj[j] = c[G.b * J + j]; F[j] = G.len > 0 ? Fst[G.g * J + j] : 0.0; }
-  const double *tb = t + G.b * N, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
+  for (int j = 0; j < J; ++j) { cj[j] = c[G.b * c_bs + j]; F[j] = G.len > 0 ? Fst[G.g * J + j] : 0.0; }
+  const double *tb = t + G.b * t_bs, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
   double *zb = z + G.b * N;
   RowIn<J, true, false> cur, nxt;
   fetch_row<J, true, false>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
@@ -657,31 +657,33 @@ static Layout layout(int64_t B, int64_t N) {
 }
 
 template <int J>
-static int run(int64_t B, int64_t N, const double *t, const double *c, const double *a, const double *U,
+static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a, const double *U,
                const double *V, const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
                double *bV, double *by, int32_t *flag, double *work, hipStream_t s) {
   const Layout L = layout<J>(B, N);
   const int64_t K = (N + kRows - 1) / kRows;
   double *d = work + L.d, *W = work + L.W, *z = work + L.z;
-  if (int e = c2_factor(B, N, J, t, N, c, J, a, U, V, d, W, nullptr, flag, (c2_stream_t)s)) return e;
+  if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, (c2_stream_t)s)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
   if (J == 6) {   // no tiled time-parallel solve at this width: chunk maps here (scratch: the region of the adjoint maps)
     double *Phi = work + L.map, *gk = Phi + (size_t)B * K * J * J, *Fst = gk + (size_t)B * K * J;
-    hipLaunchKernelGGL((k_solve_maps<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y, Phi, gk);
+    hipLaunchKernelGGL((k_solve_maps<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W, y,
+                       Phi, gk);
     hipLaunchKernelGGL((k_solve_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
                        (const double *)gk, Fst);
-    hipLaunchKernelGGL((k_solve_apply<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y,
-                       (const double *)Fst, z);
-  } else if (int e = c2_solve_lower(B, N, J, 1, t, N, c, J, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
-  hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, (const double *)d, (const double *)W,
+    hipLaunchKernelGGL((k_solve_apply<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W,
+                       y, (const double *)Fst, z);
+  } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
+  hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, (const double *)d, (const double *)W,
                      (const double *)z, work + L.loc, work + L.llp);
-  hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, c, (const double *)(work + L.loc),
+  hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
+                     (const double *)(work + L.loc),
                      (const double *)(work + L.llp), (const int32_t *)flag, work + L.start, ll);
-  hipLaunchKernelGGL((k_maps<J>), dim3(cgrid.x, (unsigned)(J + 1)), dim3(kWave), 0, s, B, N, K, t, c, U,
-                     (const double *)d, (const double *)W, (const double *)z, work + L.map);
+  hipLaunchKernelGGL((k_maps<J>), dim3(cgrid.x, (unsigned)(J + 1)), dim3(kWave), 0, s, B, N, K, t, t_bs, c,
+                     c_bs, U, (const double *)d, (const double *)W, (const double *)z, work + L.map);
   hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),
                      work + L.ends);
-  hipLaunchKernelGGL((k_final<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, V, (const double *)d, (const double *)W,
+  hipLaunchKernelGGL((k_final<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, V, (const double *)d, (const double *)W,
                      (const double *)z, (const double *)(work + L.start), (const double *)(work + L.ends),
                      (const int32_t *)flag, work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, by);
   hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, s, B, N,
@@ -868,17 +870,17 @@ extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t
   }
 }
 
-// Per-series t and c only (strides N and J).  Same outputs as c2_loglik_grad.
-extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, const double *c,
-                                               const double *a, const double *U, const double *V, const double *y,
+// Same arguments and outputs as c2_loglik_grad (t, c per series or shared by the batch: strides 0).
+extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                               const double *c, int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                                double *ll, double *bt, double *bc, double *ba, double *bU, double *bV,
                                                double *by, int32_t *flag, double *work, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   switch (J) {
-    case 2: return run<2>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
-    case 4: return run<4>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
-    case 6: return run<6>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
-    case 8: return run<8>(B, N, t, c, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 2: return run<2>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 4: return run<4>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 6: return run<6>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 8: return run<8>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
     default: return C2_ERR_UNSUPPORTED;
   }
 }
@@ -924,13 +926,14 @@ extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const do
 }
 
 // Forward-only log-likelihood for small batches of long series at widths 6 / 8: d, W by c2_factor (Newton iterations on the
-// chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.  Per-series t and c.
+// chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.
 extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 6 && J != 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
   return BN * (2 + J) + BK * (1 + (size_t)J * J + 2 * J) + 8;
 }
-extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, const double *c, const double *a,
+extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                       int64_t c_bs, const double *a,
                                        const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                        double *work, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -938,15 +941,16 @@ extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const do
   const int64_t K = (N + kRows - 1) / kRows;
   const size_t BN = (size_t)B * N, BK = (size_t)B * K;
   double *d = work, *z = d + BN, *W = z + BN, *llp = W + BN * J, *Phi = llp + BK, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
-  if (int e = c2_factor(B, N, J, t, N, c, J, a, U, V, d, W, nullptr, flag, stream)) return e;
+  if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, stream)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
   if (J == 6) {
-    hipLaunchKernelGGL((k_solve_maps<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y, Phi, gk);
+    hipLaunchKernelGGL((k_solve_maps<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W, y,
+                       Phi, gk);
     hipLaunchKernelGGL((k_solve_chain<6>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
                        (const double *)gk, Fst);
-    hipLaunchKernelGGL((k_solve_apply<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, c, U, (const double *)W, y,
-                       (const double *)Fst, z);
-  } else if (int e = c2_solve_lower(B, N, J, 1, t, N, c, J, U, W, y, z, nullptr, stream)) return e;
+    hipLaunchKernelGGL((k_solve_apply<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W,
+                       y, (const double *)Fst, z);
+  } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, stream)) return e;
   hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);
   hipLaunchKernelGGL(k_ll_series, dim3((unsigned)B), dim3(kWave), 0, s, N, K, (const double *)llp,
                      (const int32_t *)flag, ll);

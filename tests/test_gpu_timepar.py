@@ -198,6 +198,18 @@ def test_timepar_gradient_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     close(ll, ll0.cpu().numpy())
     for g, e in zip(grads, grads0):
         gclose(g, e.cpu().numpy())
+    # shared time grid and rates (strides 0); bt, bc stay per series
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+    ts, cs = np.tile(t[0], (B, 1)), np.tile(c[0], (B, 1))
+    lls, gs, fls = oracle.loglik_grad_batched(ts, cs, a, U, V, y, nthreads=2)
+    ok = np.asarray(fls) == 0
+    ll3, grads3, flag3 = ops.loglik_grad(*dev(t[0].copy(), c[0].copy(), a, U, V, y))
+    assert np.array_equal(flag3.cpu().numpy() != 0, ~ok)
+    if ok.any():
+        close(ll3[ok], lls[ok])
+        for g, e in zip(grads3, gs):
+            for b in np.nonzero(ok)[0]:
+                gclose(g[b], e[b])
     if B > 2 and N > 2:
         monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
         a2 = a.copy(); a2[1, N // 2] = -5.0

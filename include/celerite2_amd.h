@@ -156,7 +156,10 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
  * an autodiff frontend runs (python/celerite2/pymc/ops.py:104-141,
  * pymc/distribution.py:123-128), with per-series outputs bt (B,N), bc (B,J),
  * ba (B,N), bU (B,N,J), bV (B,N,J), by (B,N).  `work` is caller-provided device
- * scratch of c2_loglik_grad_workspace_bytes(B,N,J) bytes.
+ * scratch of c2_loglik_grad_workspace_bytes(B,N,J) bytes (the query follows the
+ * dispatch: checkpoints + (d,z) records for the row-by-row kernels, lane-major
+ * records for chip-filling batches, d / W / z / state rows / chunk maps for small
+ * batches of long series, which run parallel along time).
  * A series whose factorisation fails (flag[b] != 0; the reference raises,
  * driver.hpp:13-19) gets ll[b] = -inf and ALL SIX gradients filled with NaN
  * -- defined, never stale memory; the other series of the batch are unaffected. */

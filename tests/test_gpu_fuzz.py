@@ -199,3 +199,46 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
             # two device paths with different summation orders; bdc / bx carry the factor max|x| (see test_gpu_terms.py)
             floor = 1e-11 if k not in (5,) else max(1e-11, 1e-14 * max(N, 4) * xmax)
             close(gf, gc.cpu().numpy(), tol=1e-9, floor=floor)
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
+    """The gradient parallel along time and the Newton factor (c2_timepar_grad.hip) forced on random shapes: series
+    lengths around the chunk length (64) and its multiples, all four widths, shared grids / rates, unpaired rates, a
+    gap in time, an occasional failed series -- log-likelihood, flags and all six gradients against the oracle (each
+    gradient relative to its largest entry: its small entries are sums of large terms)."""
+    rng = np.random.default_rng(77000 + seed)
+    B = int(rng.choice([1, 2, 3, 5, 9, 70]))
+    N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 449, 640, 1000, 2100]))
+    J = int(rng.choice([8, 6, 4, 2]))
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    a = a + 0.3
+    if rng.random() < 0.4:
+        c = c * rng.uniform(0.8, 1.25, c.shape)
+    if N > 70 and rng.random() < 0.4:
+        t[:, N // 2:] += rng.choice([2.0, 50.0, 3000.0])
+    shared_t = rng.random() < 0.3
+    shared_c = rng.random() < 0.3
+    if shared_t: t = np.tile(t[0], (B, 1))
+    if shared_c: c = np.tile(c[0], (B, 1))
+    if B > 1 and N > 10 and rng.random() < 0.3:
+        a[B // 2, N // 3] = -1.0
+    llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ok = np.asarray(flago) == 0
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+    monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    args = dev(t[0].copy() if shared_t else t, c[0].copy() if shared_c else c, a, U, V, y)
+    ll, grads, flag = ops.loglik_grad(*args)
+    assert np.array_equal(flag.cpu().numpy() != 0, ~ok)
+    lln = ll.cpu().numpy()
+    assert np.isneginf(lln[~ok]).all()
+    np.testing.assert_allclose(lln[ok], llo[ok], rtol=1e-10)
+    for g, e in zip(grads, go):
+        gn = g.cpu().numpy()
+        assert np.isnan(gn[~ok]).all()
+        for b in np.nonzero(ok)[0]:
+            np.testing.assert_allclose(gn[b], e[b], rtol=0.0, atol=1e-10 * max(np.abs(e[b]).max(), 1e-300))
+    ll0, flag0 = ops.loglik(*args)
+    assert np.array_equal(flag0.cpu().numpy() != 0, ~ok)
+    np.testing.assert_allclose(ll0.cpu().numpy()[ok], llo[ok], rtol=1e-10)

@@ -910,7 +910,9 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // Measured (tools/timepar_grad_time.py): one series of 1e5 rows 103 -> 6.0 ms at J = 8, 61 -> 1.6 ms at J = 2; 32 series
   // of 50000 rows at J = 6 57.6 -> 4.6 ms; 256 x 4096 at J = 8 4.3 -> 1.9 ms.  The chunks are walked one per lane with
   // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
-  return N >= C2_TIMEPAR_GRAD_MIN_ROWS && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
+  // One series draws level at ~400 rows (J = 2), ~600 (J = 4, 6), ~800 (J = 8): 0.48 -> 0.25 ms at 768 rows, J = 2.
+  const int64_t min_rows = J == 2 ? 512 : (J == 8 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768);
+  return N >= min_rows && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
 }
 // widths 6 and 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it

@@ -140,6 +140,42 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
             "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}
 
 
+def long_series(J, dev, N=100_000, steps=3):
+    """Informational: ONE series of 1e5 rows, log-likelihood + gradient -- the small-batch end of the same entry point,
+    which runs parallel along time; row by row for comparison (C2_TIMEPAR_GRAD=0, C2_FACTOR_ITER=0)."""
+    import torch
+
+    from celerite2_amd import ops, synth
+
+    args = synth.device_batch_fast(0, 1, N, J, dev)
+    out = {}
+    for name, env in (("ms", {}), ("row_by_row_ms", {"C2_TIMEPAR_GRAD": "0", "C2_FACTOR_ITER": "0"})):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            work = ops.loglik_grad_workspace(1, N, J, dev)
+            ll, g, flag = ops.loglik_grad(*args, work=work)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                ll, g, flag = ops.loglik_grad(*args, work=work, out=g)
+            e1.record()
+            torch.cuda.synchronize()
+            out[name] = e0.elapsed_time(e1) / steps
+            out["ll_" + name] = float(ll[0])
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return {"entry": "c2_loglik_grad", "workload": "1 series, N=%d, J=%d, forward + reverse-mode grad" % (N, J),
+            "ms": out["ms"], "row_by_row_ms": out["row_by_row_ms"],
+            "ll_rel_diff": abs(out["ll_ms"] - out["ll_row_by_row_ms"]) / abs(out["ll_row_by_row_ms"]),
+            "note": "informational: latency-bound regime, gradient parallel along time (c2_timepar_grad.hip)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +190,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-synth", action="store_true",
                     help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
+    ap.add_argument("--no-long-series", action="store_true",
+                    help="skip the informational single-long-series measurement (`long_series` object)")
     ap.add_argument("--no-coefficient-level", action="store_true",
                     help="skip the extra (informational) measurement of c2_loglik_terms_grad on the same series")
     ap.add_argument("--dump-ll", default="", help="rank 0 saves the gathered log-likelihood vector here (.npy)")
@@ -277,6 +315,8 @@ def main():
             del t, c, a, U, V, y, out, work
             torch.cuda.empty_cache()
             line["coefficient_level"] = coefficient_level(first, Bp, N, J, dev, ll_matrix, min(args.steps, 5))
+        if world == 1 and grad and J in (2, 4, 6, 8) and not args.no_long_series:
+            line["long_series"] = long_series(J, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, J, grad, args.cpu_seconds)
         print(json.dumps(line), flush=True)

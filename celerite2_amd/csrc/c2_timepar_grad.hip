@@ -32,6 +32,7 @@ namespace c2tg {
 using namespace c2;
 
 constexpr int kRows = 64;   // rows per chunk
+constexpr int64_t kTwoLevelMin = 256;   // chunks per series from which the sequential chains over the chunks run in two levels
 
 template <int J>
 struct Dim {
@@ -210,6 +211,89 @@ __global__ __launch_bounds__(kWave) void k_starts(int64_t N, int64_t K, const do
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
   if (lane == 0) ll[b] = flag[b] != 0 ? -__builtin_huge_val() : -0.5 * s - 0.5 * (double)N * kLog2Pi;
+}
+
+// The same scan for long series (K >= kTwoLevelMin chunks), lane <-> chunk: the recurrence start_{k+1} = D_k o start_k +
+// loc_k is elementwise affine, so 64 chunks are scanned across the lanes ((D_a, f_a) o (D_b, f_b) = (D_a D_b, D_b f_a +
+// f_b)), every block of 64 chunks from zero (k_starts_blocks: also the block's total), and a second kernel gives each
+// block the state it starts from -- the totals of the blocks before it, combined in order -- and applies it
+// (k_starts_apply).  pre: [series][chunk][2 NST] = inclusive (D, f) of the chunk inside its block.
+template <int J>
+__global__ __launch_bounds__(kWave) void k_starts_blocks(int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                         const double *__restrict__ c, int64_t c_bs,
+                                                         const double *__restrict__ loc, double *__restrict__ pre) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
+  const int lane = threadIdx.x;
+  const int64_t NB = (K + kWave - 1) / kWave;
+  const int64_t b = blockIdx.x / NB, nb = blockIdx.x % NB;
+  const int64_t k = nb * kWave + lane;
+  const bool valid = k < K;
+  const int64_t kc = valid ? k : K - 1;
+  const double *tb = t + b * t_bs;
+  // decay of the carried state over chunk k (identity behind the last chunk), contribution of chunk k
+  const double T = (valid && k + 1 < K) ? tb[(k + 1) * kRows] - tb[k * kRows] : 0.0;
+  double e[J], D[NST], f[NST];
+#pragma unroll
+  for (int j = 0; j < J; ++j) e[j] = exp_decay(-c[b * c_bs + j] * T);
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+#pragma unroll
+    for (int j = i; j < J; ++j) D[sidx(J, i, j)] = e[i] * e[j];
+    D[NS + i] = e[i];
+  }
+  const double *l = loc + (b * K + kc) * NST;
+#pragma unroll
+  for (int q = 0; q < NST; ++q) f[q] = valid ? l[q] : 0.0;   // (NST is odd at J = 2, 6: no 16-byte pieces)
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const bool has = lane >= d;
+#pragma unroll
+    for (int q = 0; q < NST; ++q) {
+      const double Dp = __shfl_up(D[q], d, kWave), fp = __shfl_up(f[q], d, kWave);
+      if (has) { f[q] = fma(D[q], fp, f[q]); D[q] *= Dp; }
+    }
+  }
+  if (valid) {
+    double *o = pre + (b * K + k) * (2 * NST);
+#pragma unroll
+    for (int q = 0; q < NST; ++q) { o[q] = D[q]; o[NST + q] = f[q]; }
+  }
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void k_starts_apply(int64_t N, int64_t K, const double *__restrict__ pre,
+                                                        const double *__restrict__ llp,
+                                                        const int32_t *__restrict__ flag, double *__restrict__ start,
+                                                        double *__restrict__ ll) {
+  constexpr int NST = Dim<J>::NST;
+  static_assert(NST <= kWave, "an entry per lane");
+  const int lane = threadIdx.x;
+  const int64_t NB = (K + kWave - 1) / kWave;
+  const int64_t b = blockIdx.x / NB, nb = blockIdx.x % NB;
+  // state entering this block: the totals (last chunk) of the blocks before it, in order; lane <-> entry
+  double carry = 0.0;
+  if (lane < NST) {
+    for (int64_t q = 0; q < nb; ++q) {
+      const double *o = pre + (b * K + q * kWave + kWave - 1) * (2 * NST);
+      carry = fma(o[lane], carry, o[NST + lane]);
+    }
+  }
+  // start of chunk k0 + r: carry for r = 0, else D_{r-1} carry + f_{r-1}
+  const int64_t k0 = nb * kWave;
+  const int64_t cnt = K - k0 < kWave ? K - k0 : kWave;
+  if (lane < NST) {
+    start[(b * K + k0) * NST + lane] = carry;
+    for (int64_t r = 1; r < cnt; ++r) {
+      const double *o = pre + (b * K + k0 + r - 1) * (2 * NST);
+      start[(b * K + k0 + r) * NST + lane] = fma(o[lane], carry, o[NST + lane]);
+    }
+  }
+  if (nb == 0) {
+    double s = 0.0;
+    for (int64_t k = lane; k < K; k += kWave) s += llp[b * K + k];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, kWave);
+    if (lane == 0) ll[b] = flag[b] != 0 ? -__builtin_huge_val() : -0.5 * s - 0.5 * (double)N * kLog2Pi;
+  }
 }
 
 // ---- the adjoint step ---------------------------------------------------------------------------------------------------
@@ -676,6 +760,14 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
   hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, (const double *)d, (const double *)W,
                      (const double *)z, work + L.loc, work + L.llp);
+  if (K >= kTwoLevelMin) {   // (the prefix maps live in the region of the adjoint maps, written later)
+    const int64_t NBs = (K + kWave - 1) / kWave;
+    hipLaunchKernelGGL((k_starts_blocks<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
+                       (const double *)(work + L.loc), work + L.map);
+    hipLaunchKernelGGL((k_starts_apply<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, N, K,
+                       (const double *)(work + L.map), (const double *)(work + L.llp), (const int32_t *)flag,
+                       work + L.start, ll);
+  } else
   hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
                      (const double *)(work + L.loc),
                      (const double *)(work + L.llp), (const int32_t *)flag, work + L.start, ll);
@@ -855,6 +947,150 @@ __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__res
   if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
 }
 
+// ---- the same chain in two levels, for long series (K >= kTwoLevelMin chunks) --------------------------------------------
+// The update recurrence delta_{k+1} = Phi_k delta_k Phi_k^T + r_k (r_k = E_k - X_{k+1}) composes: over the steps of a
+// block of kBlock chunks, delta_{k+1} = Psi_k delta_block Psi_k^T + rho_k with Psi_k = Phi_k Psi_{k-1},
+// rho_k = Phi_k rho_{k-1} Phi_k^T + r_k.  (1) k_newton_block: one wavefront per block walks its steps and stores the
+// prefix maps (Psi_k, rho_k); (2) k_newton_blocks: one wavefront per series walks the BLOCKS (K / kBlock steps
+// instead of K); (3) k_newton_apply: one wavefront per block applies the prefix maps to the block's start update,
+// X_{k+1} += delta_{k+1}, and measures the updates.
+constexpr int kBlock = 32;
+template <int J>
+__global__ __launch_bounds__(kWave) void k_newton_block(int64_t K, int64_t NB, const double *__restrict__ X,
+                                                        const double *__restrict__ E, const double *__restrict__ Phi,
+                                                        double *__restrict__ Psi, double *__restrict__ Rho,
+                                                        const unsigned long long *__restrict__ gate) {
+  constexpr int NS = Dim<J>::NS;
+  if (gate_closed(gate)) return;
+  __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1], Sm[J][J + 1];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x / NB, nb = blockIdx.x % NB;
+  const int64_t k0 = nb * kBlock, k1 = (k0 + kBlock < K - 1) ? k0 + kBlock : K - 1;   // steps k0 .. k1-1
+  const int sij = sym(J, i, j);
+  if (act) { Dm[i][j] = 0.0; Sm[i][j] = i == j ? 1.0 : 0.0; }
+  lds_order();
+  double ph, rv;
+  auto fetch = [&](int64_t k) {
+    const int64_t g = b * K + k;
+    ph = Phi[g * (J * J) + i * J + j];
+    rv = E[g * NS + sij] - X[(g + 1) * NS + sij];
+  };
+  fetch(k0);
+  for (int64_t k = k0; k < k1; ++k) {
+    const double mph = ph, mrv = rv;
+    if (k + 1 < k1) fetch(k + 1);
+    Pm[i][j] = mph;
+    lds_order();
+    double y = 0.0, ps = 0.0;   // (rho Phi^T)(i, j), (Phi Psi)(i, j)
+#pragma unroll
+    for (int l = 0; l < J; ++l) { y = fma(Dm[i][l], Pm[j][l], y); ps = fma(Pm[i][l], Sm[l][j], ps); }
+    Ym[i][j] = y;
+    lds_order();
+    double rn = mrv;            // Phi rho Phi^T + r
+#pragma unroll
+    for (int q = 0; q < J; ++q) rn = fma(Pm[i][q], Ym[q][j], rn);
+    lds_order();
+    if (act) {
+      Dm[i][j] = rn; Sm[i][j] = ps;
+      Psi[(b * K + k) * (J * J) + i * J + j] = ps;
+      Rho[(b * K + k) * (J * J) + i * J + j] = rn;
+    }
+    lds_order();
+  }
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void k_newton_blocks(int64_t K, int64_t NB, const double *__restrict__ Psi,
+                                                         const double *__restrict__ Rho, double *__restrict__ Dstart,
+                                                         const unsigned long long *__restrict__ gate) {
+  if (gate_closed(gate)) return;
+  __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x;
+  if (act) Dm[i][j] = 0.0;
+  lds_order();
+  double ph, rv;
+  auto fetch = [&](int64_t nb) {   // the maps of the block's last step
+    const int64_t kl = ((nb + 1) * kBlock < K - 1 ? (nb + 1) * kBlock : K - 1) - 1;
+    ph = Psi[(b * K + kl) * (J * J) + i * J + j];
+    rv = Rho[(b * K + kl) * (J * J) + i * J + j];
+  };
+  fetch(0);
+  for (int64_t nb = 0; nb < NB; ++nb) {
+    const double mph = ph, mrv = rv;
+    if (nb + 1 < NB) fetch(nb + 1);
+    if (act) Dstart[(b * NB + nb) * (J * J) + i * J + j] = Dm[i][j];
+    Pm[i][j] = mph;
+    lds_order();
+    double y = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) y = fma(Dm[i][l], Pm[j][l], y);
+    Ym[i][j] = y;
+    lds_order();
+    double dn = mrv;
+#pragma unroll
+    for (int q = 0; q < J; ++q) dn = fma(Pm[i][q], Ym[q][j], dn);
+    lds_order();
+    if (act) Dm[i][j] = dn;
+    lds_order();
+  }
+}
+template <int J>
+__global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, double *__restrict__ X,
+                                                        const double *__restrict__ E, const double *__restrict__ Psi,
+                                                        const double *__restrict__ Rho, const double *__restrict__ Dstart,
+                                                        const unsigned long long *__restrict__ gate,
+                                                        unsigned long long *__restrict__ word) {
+  constexpr int NS = Dim<J>::NS;
+  if (gate_closed(gate)) return;
+  __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1], Xd[J];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x / NB, nb = blockIdx.x % NB;
+  const int64_t k0 = nb * kBlock, k1 = (k0 + kBlock < K - 1) ? k0 + kBlock : K - 1;
+  const int sij = sym(J, i, j), sii = sidx(J, i, i);
+  if (act) Dm[i][j] = Dstart[(b * NB + nb) * (J * J) + i * J + j];
+  lds_order();
+  double worst = 0.0, ph, rv, xv, xd;
+  auto fetch = [&](int64_t k) {
+    const int64_t g = b * K + k;
+    ph = Psi[g * (J * J) + i * J + j];
+    rv = Rho[g * (J * J) + i * J + j];
+    xv = X[(g + 1) * NS + sij];
+    xd = E[g * NS + sii];
+  };
+  fetch(k0);
+  for (int64_t k = k0; k < k1; ++k) {
+    const double mph = ph, mrv = rv, mxv = xv, mxd = xd;
+    if (k + 1 < k1) fetch(k + 1);
+    lds_order();   // the previous step's readers of Pm, Ym, Xd are done
+    Pm[i][j] = mph;
+    if (act && j == 0) Xd[i] = mxd;
+    lds_order();
+    double y = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) y = fma(Dm[i][l], Pm[j][l], y);
+    Ym[i][j] = y;
+    lds_order();
+    double dl = mrv;   // delta_{k+1} = Psi delta_block Psi^T + rho
+#pragma unroll
+    for (int q = 0; q < J; ++q) dl = fma(Pm[i][q], Ym[q][j], dl);
+    const double scale = sqrt(fabs(Xd[i] * Xd[j]));
+    const double rel = fabs(dl) / fmax(scale, 1e-300);
+    worst = fmax(worst, act ? rel : 0.0);
+    if (!(rel == rel)) worst = __builtin_huge_val();
+    if (act && i <= j) X[(b * K + k + 1) * NS + sij] = mxv + dl;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
+  worst /= 0.5 * kNewtonTol;
+  if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
+}
+
 }  // namespace c2tg
 
 using namespace c2tg;
@@ -891,7 +1127,9 @@ constexpr int kNewtonMax = 8;
 extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 6 && J != 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows);
-  return (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
+  size_t n = (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
+  if ((int64_t)K >= kTwoLevelMin) n += (size_t)B * K * (size_t)(2 * J * J) + (size_t)B * ((K + kBlock - 1) / kBlock + 1) * (size_t)(J * J);
+  return n;
 }
 template <int J>
 static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
@@ -909,8 +1147,19 @@ static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, 
     const unsigned long long *gate = p >= 2 ? words + p - 1 : nullptr;
     hipLaunchKernelGGL((k_newton_pass<J>), grid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, d, W, flag,
                        (const double *)X, E, Phi, gate, words + p);
-    hipLaunchKernelGGL((k_newton_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, X, (const double *)E,
-                       (const double *)Phi, gate, words + p);
+    if (K >= kTwoLevelMin) {
+      const int64_t NB = (K - 1 + kBlock - 1) / kBlock;
+      double *Psi = Phi + BK * J * J, *Rho = Psi + BK * J * J, *Dstart = Rho + BK * J * J;
+      hipLaunchKernelGGL((k_newton_block<J>), dim3((unsigned)(B * NB)), dim3(kWave), 0, s, K, NB, (const double *)X,
+                         (const double *)E, (const double *)Phi, Psi, Rho, gate);
+      hipLaunchKernelGGL((k_newton_blocks<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, NB, (const double *)Psi,
+                         (const double *)Rho, Dstart, gate);
+      hipLaunchKernelGGL((k_newton_apply<J>), dim3((unsigned)(B * NB)), dim3(kWave), 0, s, K, NB, X, (const double *)E,
+                         (const double *)Psi, (const double *)Rho, (const double *)Dstart, gate, words + p);
+    } else {
+      hipLaunchKernelGGL((k_newton_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, X, (const double *)E,
+                         (const double *)Phi, gate, words + p);
+    }
   }
   *last_word = words + P;
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;

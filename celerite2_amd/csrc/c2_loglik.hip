@@ -927,9 +927,14 @@ extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const do
                                        const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                        double *work, c2_stream_t stream);
 static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
-  if (J != 6 && J != 8) return false;
-  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it, 0 disables it
-  if (e) return atoi(e) != 0 && N >= 2;
+  if (J != 2 && J != 4 && J != 6 && J != 8) return false;
+  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it (widths 6, 8: every length; 4, 2: long series), 0 disables it
+  if (e && atoi(e) == 0) return false;
+  // widths 4 and 2 have the composed linear-fractional maps of c2_timepar.hip, whose chain over the chunks is sequential:
+  // the Newton iterations (chains in two levels) take over on long series -- J = 4: 1.67 -> 0.59 ms at 1e5 rows, 15.3 ->
+  // 1.6 ms at 1e6 (0.45 vs 0.51 ms at 20000); J = 2: level at 1e5 rows (0.40 ms)
+  if (J <= 4) return N >= (J == 4 ? 32768 : 131072) && B * ((N + 63) / 64) <= 32768;
+  if (e) return N >= 2;
   const char *l = getenv("C2_LANES");
   if (l && atoi(l) != 0) return false;
   // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,

@@ -33,6 +33,7 @@ using namespace c2;
 
 constexpr int kRows = 64;   // rows per chunk
 constexpr int64_t kTwoLevelMin = 256;   // chunks per series from which the sequential chains over the chunks run in two levels
+constexpr int kBlock = 32;              // chunks per block of the upper level
 
 template <int J>
 struct Dim {
@@ -672,6 +673,78 @@ __global__ __launch_bounds__(kWave) void k_solve_chain(int64_t K, const double *
     }
   }
 }
+// k_solve_chain in two levels for long series (see k_newton_block): F_{k+1} = Phi_k F_k + g_k composes over a block of
+// chunks as F_{k+1} = Psi_k F_block + gamma_k with Psi_k = Phi_k Psi_{k-1}, gamma_k = Phi_k gamma_{k-1} + g_k.
+template <int J>
+__global__ __launch_bounds__(kWave) void k_solve_block(int64_t K, int64_t NB, const double *__restrict__ Phi,
+                                                       const double *__restrict__ gk, double *__restrict__ Psi,
+                                                       double *__restrict__ Gam) {
+  __shared__ double Pm[J][J + 1], Sm[J][J + 1], Gv[J];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x / NB, nb = blockIdx.x % NB;
+  const int64_t k0 = nb * kBlock, k1 = (k0 + kBlock < K) ? k0 + kBlock : K;   // chunks k0 .. k1-1
+  if (act) Sm[i][j] = i == j ? 1.0 : 0.0;
+  if (lane < J) Gv[lane] = 0.0;
+  lds_order();
+  double ph, gv;
+  auto fetch = [&](int64_t k) {
+    ph = Phi[(b * K + k) * (J * J) + i * J + j];
+    gv = gk[(b * K + k) * J + i];
+  };
+  fetch(k0);
+  for (int64_t k = k0; k < k1; ++k) {
+    const double mph = ph, mgv = gv;
+    if (k + 1 < k1) fetch(k + 1);
+    Pm[i][j] = mph;
+    lds_order();
+    double ps = 0.0, gn = mgv;   // (Phi Psi)(i, j), (Phi gamma + g)(i)
+#pragma unroll
+    for (int l = 0; l < J; ++l) { ps = fma(Pm[i][l], Sm[l][j], ps); gn = fma(Pm[i][l], Gv[l], gn); }
+    lds_order();
+    if (act) {
+      Sm[i][j] = ps;
+      Psi[(b * K + k) * (J * J) + i * J + j] = ps;
+      if (j == 0) { Gv[i] = gn; Gam[(b * K + k) * J + i] = gn; }
+    }
+    lds_order();
+  }
+}
+// one wavefront per series over the blocks; Fb[series][block][J] = state entering the block
+template <int J>
+__global__ __launch_bounds__(kWave) void k_solve_blocks(int64_t K, int64_t NB, const double *__restrict__ Psi,
+                                                        const double *__restrict__ Gam, double *__restrict__ Fb) {
+  const int lane = threadIdx.x, i = lane < J ? lane : 0;
+  const int64_t b = blockIdx.x;
+  double F = 0.0;
+  for (int64_t nb = 0; nb < NB; ++nb) {
+    const int64_t kl = ((nb + 1) * kBlock < K ? (nb + 1) * kBlock : K) - 1;
+    if (lane < J) Fb[(b * NB + nb) * J + lane] = F;
+    double nf = Gam[(b * K + kl) * J + i];
+#pragma unroll
+    for (int j = 0; j < J; ++j) nf = fma(Psi[(b * K + kl) * (J * J) + i * J + j], __shfl(F, j, kWave), nf);
+    F = nf;
+  }
+}
+// Fst[chunk] = state entering the chunk: the block's for its first chunk, Psi_{k-1} F_block + gamma_{k-1} behind it
+template <int J>
+__global__ void k_solve_starts(int64_t B, int64_t K, int64_t NB, const double *__restrict__ Psi,
+                               const double *__restrict__ Gam, const double *__restrict__ Fb, double *__restrict__ Fst) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * K * J) return;
+  const int i = (int)(g % J);
+  const int64_t bk = g / J, b = bk / K, k = bk - b * K, nb = k / kBlock;
+  const double *F = Fb + (b * NB + nb) * J;
+  double v;
+  if (k % kBlock == 0) v = F[i];
+  else {
+    v = Gam[(bk - 1) * J + i];
+#pragma unroll
+    for (int j = 0; j < J; ++j) v = fma(Psi[(bk - 1) * (J * J) + i * J + j], F[j], v);
+  }
+  Fst[g] = v;
+}
 template <int J>
 __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                        const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
@@ -720,6 +793,31 @@ __global__ __launch_bounds__(kWave) void k_ll_series(int64_t N, int64_t K, const
   if (threadIdx.x == 0) ll[b] = flag[b] != 0 ? -__builtin_huge_val() : -0.5 * s - 0.5 * (double)N * kLog2Pi;
 }
 
+// z = L^-1 y by chunk maps (k_solve_*); scratch: B K (2 J^2 + 3 J) + B (K / kBlock + 1) J doubles
+template <int J>
+static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                         const double *U, const double *W, const double *y, double *z, double *scratch, hipStream_t s) {
+  const size_t BK = (size_t)B * K;
+  double *Phi = scratch, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
+  const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
+  hipLaunchKernelGGL((k_solve_maps<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, Phi, gk);
+  if (K >= kTwoLevelMin) {
+    const int64_t NB = (K + kBlock - 1) / kBlock;
+    double *Psi = Fst + BK * J, *Gam = Psi + BK * J * J, *Fb = Gam + BK * J;
+    hipLaunchKernelGGL((k_solve_block<J>), dim3((unsigned)(B * NB)), dim3(kWave), 0, s, K, NB, (const double *)Phi,
+                       (const double *)gk, Psi, Gam);
+    hipLaunchKernelGGL((k_solve_blocks<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, NB, (const double *)Psi,
+                       (const double *)Gam, Fb);
+    hipLaunchKernelGGL((k_solve_starts<J>), dim3((unsigned)((B * K * J + 255) / 256)), dim3(256), 0, s, B, K, NB,
+                       (const double *)Psi, (const double *)Gam, (const double *)Fb, Fst);
+  } else {
+    hipLaunchKernelGGL((k_solve_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
+                       (const double *)gk, Fst);
+  }
+  hipLaunchKernelGGL((k_solve_apply<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y,
+                     (const double *)Fst, z);
+}
+
 struct Layout {
   size_t d, W, z, loc, start, ends, map, sf, dT, bcp, llp, total;
 };
@@ -749,14 +847,8 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   double *d = work + L.d, *W = work + L.W, *z = work + L.z;
   if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, (c2_stream_t)s)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  if (J == 6) {   // no tiled time-parallel solve at this width: chunk maps here (scratch: the region of the adjoint maps)
-    double *Phi = work + L.map, *gk = Phi + (size_t)B * K * J * J, *Fst = gk + (size_t)B * K * J;
-    hipLaunchKernelGGL((k_solve_maps<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W, y,
-                       Phi, gk);
-    hipLaunchKernelGGL((k_solve_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
-                       (const double *)gk, Fst);
-    hipLaunchKernelGGL((k_solve_apply<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W,
-                       y, (const double *)Fst, z);
+  if (J == 6 || K >= kTwoLevelMin) {   // (scratch: the region of the adjoint maps, written later)
+    solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.map, s);
   } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
   hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, (const double *)d, (const double *)W,
                      (const double *)z, work + L.loc, work + L.llp);
@@ -954,7 +1046,6 @@ __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__res
 // prefix maps (Psi_k, rho_k); (2) k_newton_blocks: one wavefront per series walks the BLOCKS (K / kBlock steps
 // instead of K); (3) k_newton_apply: one wavefront per block applies the prefix maps to the block's start update,
 // X_{k+1} += delta_{k+1}, and measures the updates.
-constexpr int kBlock = 32;
 template <int J>
 __global__ __launch_bounds__(kWave) void k_newton_block(int64_t K, int64_t NB, const double *__restrict__ X,
                                                         const double *__restrict__ E, const double *__restrict__ Phi,
@@ -1125,7 +1216,7 @@ extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, 
 // its first kNewtonMax + 2 words are the iteration words -- the caller launches its row-by-row kernel behind `*last_word`.
 constexpr int kNewtonMax = 8;
 extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {
-  if (J != 6 && J != 8) return 0;
+  if (J != 2 && J != 4 && J != 6 && J != 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows);
   size_t n = (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
   if ((int64_t)K >= kTwoLevelMin) n += (size_t)B * K * (size_t)(2 * J * J) + (size_t)B * ((K + kBlock - 1) / kBlock + 1) * (size_t)(J * J);
@@ -1169,6 +1260,8 @@ extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const do
                                        double *W, int32_t *flag, double *work, const unsigned long long **last_word,
                                        c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (J == 2) return run_factor_iter<2>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
+  if (J == 4) return run_factor_iter<4>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   if (J == 6) return run_factor_iter<6>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   if (J == 8) return run_factor_iter<8>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   return C2_ERR_UNSUPPORTED;
@@ -1179,7 +1272,7 @@ extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const do
 extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 6 && J != 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
-  return BN * (2 + J) + BK * (1 + (size_t)J * J + 2 * J) + 8;
+  return BN * (2 + J) + BK * (1 + 2 * (size_t)J * J + 3 * J) + (size_t)B * (K / kBlock + 2) * J + 8;
 }
 extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                        int64_t c_bs, const double *a,
@@ -1192,14 +1285,9 @@ extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const do
   double *d = work, *z = d + BN, *W = z + BN, *llp = W + BN * J, *Phi = llp + BK, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
   if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, stream)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  if (J == 6) {
-    hipLaunchKernelGGL((k_solve_maps<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W, y,
-                       Phi, gk);
-    hipLaunchKernelGGL((k_solve_chain<6>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
-                       (const double *)gk, Fst);
-    hipLaunchKernelGGL((k_solve_apply<6>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)W,
-                       y, (const double *)Fst, z);
-  } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, stream)) return e;
+  if (J == 6) solve_chunks<6>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (K >= kTwoLevelMin) solve_chunks<8>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, stream)) return e;
   hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);
   hipLaunchKernelGGL(k_ll_series, dim3((unsigned)B), dim3(kWave), 0, s, N, K, (const double *)llp,
                      (const int32_t *)flag, ll);

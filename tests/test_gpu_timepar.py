@@ -321,3 +321,26 @@ def test_time_parallel_gradient_is_the_default_for_long_series(ops, oracle, monk
         close(ll, llo)
         for g, e in zip(grads, go):
             gclose(g, e)
+
+
+@pytest.mark.parametrize("J,N", [(4, 40000), (2, 140000)])
+def test_newton_factor_takes_over_on_long_series_at_widths_4_and_2(ops, oracle, monkeypatch, J, N):
+    """Widths 4 / 2 have the composed linear-fractional maps (sequential chain over the chunks); on long series the
+    Newton iterations with their two-level chains run instead (default dispatch): d, W against the oracle and against
+    the composed maps (C2_FACTOR_ITER=0), and the gradient built on top against the oracle."""
+    t, c, a, U, V, y = dense.synthetic_batch(1, N, J)
+    monkeypatch.delenv("C2_FACTOR_ITER", raising=False)
+    d, W, flag = ops.factor(*dev(t, c, a, U, V))
+    assert int(flag.abs().sum()) == 0
+    do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+    assert oracle.factor_flag(t[0], c[0], a[0], U[0], V[0], do, Wo, So) == 0
+    close(d[0], do); np.testing.assert_allclose(W[0].cpu().numpy(), Wo, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
+    monkeypatch.setenv("C2_FACTOR_ITER", "0")
+    d0, W0, _ = ops.factor(*dev(t, c, a, U, V))
+    close(d0, d.cpu().numpy())
+    monkeypatch.delenv("C2_FACTOR_ITER", raising=False)
+    ll, grads, flag = ops.loglik_grad(*dev(t, c, a, U, V, y))
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    close(ll, llo)
+    for g, e in zip(grads, go):
+        gclose(g, e)

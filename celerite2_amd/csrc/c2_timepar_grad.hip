@@ -390,6 +390,65 @@ __global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K,
   }
 }
 
+// The same with SP sweeps per lane sharing the rows and the decay factors of a pass (one lane per chunk): once the chunks
+// alone fill the chip, reading every row J + 1 times costs more than the idle lanes did (32 x 50000 at J = 6: 0.48
+// against 0.98 ms).
+template <int J, int SP>
+__global__ __launch_bounds__(kWave) void k_maps_shared(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                       int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                       const double *__restrict__ U, const double *__restrict__ d,
+                                                       const double *__restrict__ W, const double *__restrict__ z,
+                                                       double *__restrict__ map) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
+  const Geo G = chunk_of(B, N, K);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+  const double *tb = t + G.b * t_bs, *db = d + G.b * N, *zb = z + G.b * N;
+  const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J;
+#pragma unroll 1
+  for (int s0 = 0; s0 <= J; s0 += SP) {
+    double bS[SP][NS], bF[SP][J];
+#pragma unroll
+    for (int q = 0; q < SP; ++q) {
+#pragma unroll
+      for (int e = 0; e < NS; ++e) bS[q][e] = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) bF[q][j] = (s0 + q == j) ? 1.0 : 0.0;
+    }
+    RowIn<J, true, false> cur, nxt;
+    fetch_row<J, true, false>(cur, G, N, kRows - 1, tb, Ub, nullptr, Wb, db, zb);
+#pragma unroll 1
+    for (int r = kRows - 1; r >= 0; --r) {
+      fetch_row<J, true, false>(nxt, G, N, r - 1, tb, Ub, nullptr, Wb, db, zb);
+      if (r < G.len) {
+        double p[J], g2[J], btau[J];
+        const double rd = 1.0 / cur.d;
+#pragma unroll
+        for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+#pragma unroll
+        for (int q = 0; q < SP; ++q) {
+          if (s0 + q < J) (void)adjoint_row<J, false, false>(bS[q], bF[q], p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+          else if (s0 + q == J) (void)adjoint_row<J, true, false>(bS[q], bF[q], p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+        }
+      }
+      cur = nxt;
+    }
+    if (G.len > 0) {
+#pragma unroll
+      for (int q = 0; q < SP; ++q) {
+        if (s0 + q <= J) {
+          double *o = map + G.g * MAPR + (int64_t)(s0 + q) * NST;
+#pragma unroll
+          for (int e = 0; e < NS; ++e) o[e] = bS[q][e];
+#pragma unroll
+          for (int j = 0; j < J; ++j) o[NS + j] = bF[q][j];
+        }
+      }
+    }
+  }
+}
+
 // ---- chain over the chunks of a series, backwards ---------------------------------------------------------------------
 // One wavefront per series; lane (i, j) = entry of the J x J adjoint.  ends[g] = adjoint of the state entering the row
 // behind chunk g (zero behind the last one).
@@ -863,6 +922,13 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
                      (const double *)(work + L.loc),
                      (const double *)(work + L.llp), (const int32_t *)flag, work + L.start, ll);
+  // the chunks alone put a wavefront on every eighth SIMD: share the rows between the sweeps (width 8, three sweeps of
+  // 44 doubles a lane, spills into the accumulation registers and only pays when the chip is full: 256 x 4096 1.8 vs 2.4 ms)
+  if (cgrid.x >= (J == 8 ? 1024u : 128u)) {
+    constexpr int SP = J >= 6 ? 3 : (J + 1);
+    hipLaunchKernelGGL((k_maps_shared<J, SP>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, (const double *)d,
+                       (const double *)W, (const double *)z, work + L.map);
+  } else
   hipLaunchKernelGGL((k_maps<J>), dim3(cgrid.x, (unsigned)(J + 1)), dim3(kWave), 0, s, B, N, K, t, t_bs, c,
                      c_bs, U, (const double *)d, (const double *)W, (const double *)z, work + L.map);
   hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),

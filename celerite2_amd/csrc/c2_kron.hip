@@ -26,10 +26,16 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/celerite2_amd.h"
 
 extern "C" void c2_internal_set_error(const char *msg);
+extern "C" int c2_internal_loglik_grad_rows(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                            int64_t c_bs, const double *a, const double *U, const double *V,
+                                            const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
+                                            double *bV, double *by, int32_t *flag, void *work, size_t work_bytes,
+                                            c2_stream_t stream);
 
 namespace c2k {
 
@@ -236,6 +242,89 @@ __global__ __launch_bounds__(kThreads) void k_kron_collapse_rev(
   }
 }
 
+// ---- the same two kernels with lanes over the BANDS (M a power of two up to 32) -----------------------------------------
+// A thread per (epoch, band): a wavefront reads 64 / M epochs x M bands as one dense run, the sums over the bands of an
+// epoch are butterflies inside groups of M lanes.  Same grid, outputs and partial-sum layout as the kernels above (a
+// block covers the same kEpb epochs of one series), which remain for every other M.  32 x 50000 x 16: collapse 1.66 ->
+// 0.30 ms, collapse_rev 2.31 -> 0.15 ms.
+template <int G>
+__device__ __forceinline__ double band_sum(double x) {
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+template <int G>
+__global__ __launch_bounds__(kThreads) void k_kron_collapse_b(int64_t B, int64_t N, const double *__restrict__ a,
+                                                              const double *__restrict__ alpha, int64_t alpha_bs,
+                                                              const double *__restrict__ diag,
+                                                              const double *__restrict__ y, double *__restrict__ a_eff,
+                                                              double *__restrict__ y_eff, double *__restrict__ part,
+                                                              int32_t *__restrict__ badflag, int nch) {
+  constexpr int EPS = kThreads / G;   // epochs per slab of kThreads elements
+  __shared__ double red[kThreads / 64];
+  const int64_t b = blockIdx.y;
+  const int m = threadIdx.x % G, eo = threadIdx.x / G;
+  const double al = alpha[b * alpha_bs + m];
+  double corr = 0.0;
+  int32_t bad = 0;
+  for (int e0 = 0; e0 < kEpb; e0 += EPS) {
+    const int64_t n = (int64_t)blockIdx.x * kEpb + e0 + eo;
+    const bool in = n < N;
+    const int64_t bn = b * N + (in ? n : N - 1), i = bn * G + m;
+    const double d = diag[i], yv = y[i], ay = al / d;
+    const double A = band_sum<G>(al * ay), bs = band_sum<G>(ay * yv), ld = band_sum<G>(log(d));
+    const double yt = bs / A, r = fma(-al, yt, yv);
+    const double R = band_sum<G>(r / d * r);
+    const bool ebad = band_sum<G>(d > 0.0 ? 0.0 : 1.0) != 0.0 || !(A > 0.0);
+    if (in && m == 0) {
+      a_eff[bn] = a[bn] + 1.0 / A;
+      y_eff[bn] = yt;
+      corr += -0.5 * ((double)(G - 1) * kLog2Pi + ld + log(A) + R);
+      if (ebad) bad = 1;
+    }
+  }
+  const double tot = block_sum(corr, red);
+  if (threadIdx.x == 0) part[b * nch + blockIdx.x] = tot;
+  if (bad) atomicOr(reinterpret_cast<int *>(badflag + b), 1);
+}
+template <int G>
+__global__ __launch_bounds__(kThreads) void k_kron_collapse_rev_b(
+    int64_t B, int64_t N, const double *__restrict__ alpha, int64_t alpha_bs, const double *__restrict__ diag,
+    const double *__restrict__ y, const double *__restrict__ g_s, const double *__restrict__ g_y,
+    const int32_t *__restrict__ badflag, double *__restrict__ bdiag, double *__restrict__ by,
+    double *__restrict__ part /* (B, nch, M) */, int nch) {
+  constexpr int EPS = kThreads / G;
+  __shared__ double red[kThreads];
+  const int64_t b = blockIdx.y;
+  const int m = threadIdx.x % G, eo = threadIdx.x / G;
+  const double am = alpha[b * alpha_bs + m];
+  const bool invalid = badflag[b] != 0;  // a band variance <= 0: every gradient of the series is NaN
+  double sum = 0.0;
+  for (int e0 = 0; e0 < kEpb; e0 += EPS) {
+    const int64_t n = (int64_t)blockIdx.x * kEpb + e0 + eo;
+    const bool in = n < N;
+    const int64_t bn = b * N + (in ? n : N - 1), i = bn * G + m;
+    const double d = diag[i], yv = y[i], rd = 1.0 / d, ay = am * rd;
+    const double A = band_sum<G>(am * ay), bs = band_sum<G>(ay * yv);
+    const double rA = 1.0 / A, yt = bs * rA, r = fma(-am, yt, yv), arA = am * rA;
+    double gs = g_s[bn], gy = g_y[bn];
+    if (invalid) gs = gy = __builtin_nan("");
+    if (in) {
+      sum += (gy * (r - am * yt) * rA - 2.0 * gs * arA * rA - arA + yt * r) * rd;
+      bdiag[i] = ((-gy * arA * r + gs * arA * arA + 0.5 * am * arA + 0.5 * r * r) * rd - 0.5) * rd;
+      by[i] = (gy * arA - r) * rd;
+    }
+  }
+  // the band's sum over the block's epochs: the EPS threads that share m, in a fixed order
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x < G) {
+    double tot = 0.0;
+    for (int q = 0; q < EPS; ++q) tot += red[q * G + threadIdx.x];
+    part[(b * nch + blockIdx.x) * G + threadIdx.x] = tot;
+  }
+}
+
 // balpha[b, m] = sum over the per-block partials, in a fixed order.
 __global__ void k_kron_balpha(int64_t B, int M, int nch, const double *__restrict__ part, double *__restrict__ balpha) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -245,6 +334,39 @@ __global__ void k_kron_balpha(int64_t B, int M, int nch, const double *__restric
   double s = 0.0;
   for (int k = 0; k < nch; ++k) s += part[(b * nch + k) * M + m];
   balpha[g] = s;
+}
+
+static bool use_banded() {
+  const char *e = getenv("C2_KRON_BANDED");   // 0: the thread-per-epoch kernels for every M (A/B runs, tests)
+  return !(e && e[0] == '0');
+}
+static void launch_collapse(int64_t B, int64_t N, int64_t M, const double *a, const double *alpha, int64_t alpha_bs,
+                            const double *diag, const double *y, double *a_eff, double *y_eff, double *part,
+                            int32_t *badflag, int nch, hipStream_t s) {
+  const dim3 grid((unsigned)nch, (unsigned)B);
+#define C2K_C(G) hipLaunchKernelGGL((k_kron_collapse_b<G>), grid, dim3(kThreads), 0, s, B, N, a, alpha, alpha_bs, diag, y, a_eff, y_eff, part, badflag, nch)
+  if (use_banded() && M == 2) C2K_C(2);
+  else if (use_banded() && M == 4) C2K_C(4);
+  else if (use_banded() && M == 8) C2K_C(8);
+  else if (use_banded() && M == 16) C2K_C(16);
+  else if (use_banded() && M == 32) C2K_C(32);
+  else hipLaunchKernelGGL(k_kron_collapse, grid, dim3(kThreads), 0, s, B, N, (int)M, a, alpha, alpha_bs, diag, y, a_eff,
+                          y_eff, part, badflag, nch);
+#undef C2K_C
+}
+static void launch_collapse_rev(int64_t B, int64_t N, int64_t M, const double *alpha, int64_t alpha_bs,
+                                const double *diag, const double *y, const double *g_s, const double *g_y,
+                                const int32_t *badflag, double *bdiag, double *by, double *part, int nch, hipStream_t s) {
+  const dim3 grid((unsigned)nch, (unsigned)B);
+#define C2K_R(G) hipLaunchKernelGGL((k_kron_collapse_rev_b<G>), grid, dim3(kThreads), 0, s, B, N, alpha, alpha_bs, diag, y, g_s, g_y, badflag, bdiag, by, part, nch)
+  if (use_banded() && M == 2) C2K_R(2);
+  else if (use_banded() && M == 4) C2K_R(4);
+  else if (use_banded() && M == 8) C2K_R(8);
+  else if (use_banded() && M == 16) C2K_R(16);
+  else if (use_banded() && M == 32) C2K_R(32);
+  else hipLaunchKernelGGL(k_kron_collapse_rev, grid, dim3(kThreads), 0, s, B, N, (int)M, alpha, alpha_bs, diag, y, g_s, g_y,
+                          badflag, bdiag, by, part, nch);
+#undef C2K_R
 }
 
 inline int launch_ok() {
@@ -333,8 +455,7 @@ int c2_kron_loglik(int64_t B, int64_t N, int64_t M, int64_t J, const double *t, 
   }
   int32_t *badflag = reinterpret_cast<int32_t *>(w + p.badflag);
   if (hipMemsetAsync(badflag, 0, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return C2_ERR_HIP;
-  hipLaunchKernelGGL(k_kron_collapse, dim3((unsigned)p.nch, (unsigned)B), dim3(kThreads), 0, s, B, N, (int)M, a,
-                     alpha, alpha_bs, diag, y, w + p.a_eff, w + p.y_eff, w + p.part, badflag, p.nch);
+  launch_collapse(B, N, M, a, alpha, alpha_bs, diag, y, w + p.a_eff, w + p.y_eff, w + p.part, badflag, p.nch, s);
   if (int e = launch_ok()) return e;
   if (int e = c2_loglik(B, N, J, t, t_bs, c, c_bs, w + p.a_eff, U, V, w + p.y_eff, ll, flag, stream)) return e;
   hipLaunchKernelGGL(k_kron_finish, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, p.nch, w + p.part, badflag,
@@ -361,7 +482,7 @@ int c2_kron_loglik_grad(int64_t B, int64_t N, int64_t M, int64_t J, const double
                        t_bs, a, U, V, alpha, alpha_bs, diag, w + p.t2, w + p.a2, w + p.U2, w + p.V2);
     if (int e = launch_ok()) return e;
     // by of the interleaved series IS by (B, N, M); bc is shared by both views
-    if (int e = c2_loglik_grad(B, R, J, w + p.t2, t_bs ? R : 0, c, c_bs, w + p.a2, w + p.U2, w + p.V2, y, ll,
+    if (int e = c2_internal_loglik_grad_rows(B, R, J, w + p.t2, t_bs ? R : 0, c, c_bs, w + p.a2, w + p.U2, w + p.V2, y, ll,
                                w + p.bt2, bc, w + p.ba2, w + p.bU2, w + p.bV2, by, flag, w + p.one_d,
                                c2_loglik_grad_workspace_bytes(B, R, J), stream))
       return e;
@@ -374,8 +495,7 @@ int c2_kron_loglik_grad(int64_t B, int64_t N, int64_t M, int64_t J, const double
     if (hipMemsetAsync(badflag, 0, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return C2_ERR_HIP;
     // the GP-free partial sums reuse the head of the (B, nch, M) partial array: they are consumed by k_kron_finish
     // before k_kron_collapse_rev overwrites it
-    hipLaunchKernelGGL(k_kron_collapse, dim3((unsigned)p.nch, (unsigned)B), dim3(kThreads), 0, s, B, N, (int)M, a,
-                       alpha, alpha_bs, diag, y, w + p.a_eff, w + p.y_eff, w + p.part, badflag, p.nch);
+    launch_collapse(B, N, M, a, alpha, alpha_bs, diag, y, w + p.a_eff, w + p.y_eff, w + p.part, badflag, p.nch, s);
     if (int e = launch_ok()) return e;
     // a_eff = a + 1/A, so d ll / d a = d ll / d a_eff: the 1-D pass writes the caller's ba directly
     if (int e = c2_loglik_grad(B, N, J, t, t_bs, c, c_bs, w + p.a_eff, U, V, w + p.y_eff, ll, bt, bc, ba, bU, bV,
@@ -384,9 +504,7 @@ int c2_kron_loglik_grad(int64_t B, int64_t N, int64_t M, int64_t J, const double
     hipLaunchKernelGGL(k_kron_finish, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, B, p.nch, w + p.part,
                        badflag, ll, flag);
     if (int e = launch_ok()) return e;
-    hipLaunchKernelGGL(k_kron_collapse_rev, dim3((unsigned)p.nch, (unsigned)B), dim3(kThreads), 0, s, B, N, (int)M,
-                       alpha, alpha_bs, diag, y, (const double *)ba, (const double *)(w + p.g_y),
-                       (const int32_t *)badflag, bdiag, by, w + p.part, p.nch);
+    launch_collapse_rev(B, N, M, alpha, alpha_bs, diag, y, ba, w + p.g_y, badflag, bdiag, by, w + p.part, p.nch, s);
     if (int e = launch_ok()) return e;
   }
   hipLaunchKernelGGL(k_kron_balpha, dim3((unsigned)((B * M + 255) / 256)), dim3(256), 0, s, B, (int)M, p.nch,

@@ -1033,13 +1033,17 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
                                           int64_t c_bs, const double *a, const double *U, const double *V, double *d,
                                           double *W, int32_t *flag, double *work, unsigned long long *guard,
                                           c2_stream_t stream);
+// allow_timepar: 0 row by row only; 1 the dispatch's choice; 2 the Newton iterations at every width they cover (the
+// time-parallel gradient builds on d, W: the composed maps of widths 4 / 2 are verified to 5e-11 only, which an
+// ill-conditioned series -- the interleaved 2-D construction -- turns into 5e-11 of the largest gradient entry)
 int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                              int32_t *flag, int allow_timepar, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
-  if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && use_factor_iter(B, N, J)) {
+  const bool newton = allow_timepar == 2 ? (J == 2 || J == 4 || J == 6 || J == 8) && N >= 2 : use_factor_iter(B, N, J);
+  if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && newton) {
     const size_t nd = c2_internal_factor_iter_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
@@ -1091,16 +1095,36 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   return n * sizeof(double);
 }
 
+static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                            const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
+                            double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
+                            size_t work_bytes, bool allow_timepar, c2_stream_t stream);
 int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                    const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
                    double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
                    size_t work_bytes, c2_stream_t stream) {
+  return loglik_grad_impl(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, work_bytes, true,
+                          stream);
+}
+// the same, never parallel along time (the interleaved 2-D construction: runs of identical times, conditioning 1e3-1e4 --
+// the row-by-row kernels hold every element to 1e-12 of the largest there, the chunk maps to 3e-12)
+int c2_internal_loglik_grad_rows(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                 int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                                 double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                 int32_t *flag, void *work, size_t work_bytes, c2_stream_t stream) {
+  return loglik_grad_impl(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, work_bytes, false,
+                          stream);
+}
+static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                            const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
+                            double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
+                            size_t work_bytes, bool allow_timepar, c2_stream_t stream) {
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !bt || !bc || !ba || !bU || !bV || !by || !flag || !work)
     return C2_ERR_INVALID;
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
-  if (use_timepar_grad(B, N, J))   // small batch of long series: parallel along time
+  if (allow_timepar && use_timepar_grad(B, N, J))   // small batch of long series: parallel along time
     return c2_internal_loglik_grad_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
                                            (double *)work, stream);
   if (use_lanes4(B, J, true))

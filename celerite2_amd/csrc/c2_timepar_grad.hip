@@ -28,6 +28,17 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+extern "C" int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                        int64_t c_bs, const double *a, const double *U, const double *V, double *d,
+                                        double *W, int32_t *flag, int allow_timepar, c2_stream_t stream);
+
+// 1: the dispatch's choice of factor kernels (widths 4 / 2 below 32768 rows: the composed maps of c2_timepar.hip, verified
+// to 5e-11 -- gradients to ~4e-12 of their largest entry, 5e-11 on ill-conditioned series); 2: Newton iterations at
+// every width (1e-13; 0.30 -> 0.48 ms for one series of 4096 rows at J = 2)
+#ifndef C2TG_FACTOR_MODE
+#define C2TG_FACTOR_MODE 1
+#endif
+
 namespace c2tg {
 using namespace c2;
 
@@ -904,7 +915,7 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   const Layout L = layout<J>(B, N);
   const int64_t K = (N + kRows - 1) / kRows;
   double *d = work + L.d, *W = work + L.W, *z = work + L.z;
-  if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, (c2_stream_t)s)) return e;
+  if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, C2TG_FACTOR_MODE, (c2_stream_t)s)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
   if (J == 6 || K >= kTwoLevelMin) {   // (scratch: the region of the adjoint maps, written later)
     solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.map, s);

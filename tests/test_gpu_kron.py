@@ -79,8 +79,10 @@ def test_kron_vs_dense_kronecker(ops, golden_kron, N, M, J):
             np.testing.assert_allclose(got["ba"], g["fd_ba"], rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("B,N,M,J", [(5, 300, 16, 6), (3, 1000, 5, 8), (9, 33, 7, 3), (2, 1, 4, 2), (70, 50, 2, 4)])
-def test_kron_vs_interleaved_oracle(ops, oracle, B, N, M, J):
+@pytest.mark.parametrize("banded", ["1", "0"])
+@pytest.mark.parametrize("B,N,M,J", [(5, 300, 16, 6), (3, 1000, 5, 8), (9, 33, 7, 3), (2, 1, 4, 2), (70, 50, 2, 4), (2, 1500, 8, 4)])
+def test_kron_vs_interleaved_oracle(ops, oracle, monkeypatch, B, N, M, J, banded):
+    monkeypatch.setenv("C2_KRON_BANDED", banded)   # "1": lanes over the bands where M is a power of two, "0": thread per epoch
     """Value and all eight gradients against the CPU oracle on the interleaved series; shared and per-series alpha."""
     t, c, a, U, V, alpha, diag, y, _ = dense.kron_synthetic(B, N, M, J)   # a = k(0) = U_n . V_n (celerite matrices)
     llo, go = oracle_interleaved(oracle, t, c, a, U, V, alpha, diag, y)
@@ -153,3 +155,26 @@ def test_config4_full_shape(ops, oracle):
     for g, e in zip(g_i, go):
         close(g[:nb], e)
     assert float((ll_i - ll_c).abs().max()) <= 1e-10 * float(ll_c.abs().max())
+
+
+@pytest.mark.parametrize("M", [2, 4, 8, 16, 32])
+def test_kron_banded_collapse_matches_thread_per_epoch(ops, monkeypatch, M):
+    """The lanes-over-bands collapse kernels (M a power of two up to 32) against the thread-per-epoch ones: value and all
+    eight gradients, a ragged last block (N not a multiple of 1024 epochs), shared alpha, an invalid band variance."""
+    B, N, J = 3, 2500, 4
+    t, c, a, U, V, alpha, diag, y, _ = dense.kron_synthetic(B, N, M, J)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("C2_KRON_BANDED", mode)
+        ll, g, flag = ops.kron_loglik_grad(*dev(t, c, a, U, V, alpha, diag, y), method="collapsed")
+        lls, gs, _ = ops.kron_loglik_grad(*dev(t, c, a, U, V, alpha[0].copy(), diag, y), method="collapsed")
+        d2 = diag.copy(); d2[1, N // 2, M - 1] = -1.0
+        llb, gb, flagb = ops.kron_loglik_grad(*dev(t, c, a, U, V, alpha, d2, y), method="collapsed")
+        assert int(flag.abs().sum()) == 0 and flagb.cpu().tolist() == [0, -1, 0]
+        res[mode] = [ll, *g, lls, *gs, llb, *gb]
+        assert np.isneginf(llb.cpu().numpy()[1]) and np.isnan(gb[-1].cpu().numpy()[1]).all()   # by of the invalid series
+    for x0, x1 in zip(res["0"], res["1"]):
+        x0, x1 = x0.cpu().numpy(), x1.cpu().numpy()
+        fin = np.isfinite(x0)
+        assert np.array_equal(fin, np.isfinite(x1))
+        np.testing.assert_allclose(x1[fin], x0[fin], rtol=1e-11, atol=1e-12 * max(1.0, float(np.abs(x0[fin]).max())))

@@ -908,6 +908,10 @@ static Layout layout(int64_t B, int64_t N) {
   return L;
 }
 
+// the adjoint chain in two levels (long series); defined behind the Newton kernels it shares
+template <int J>
+static void adjoint_chain_two_level(int64_t B, int64_t K, const double *map, double *ends, double *scratch, hipStream_t s);
+
 template <int J>
 static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a, const double *U,
                const double *V, const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
@@ -942,8 +946,11 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   } else
   hipLaunchKernelGGL((k_maps<J>), dim3(cgrid.x, (unsigned)(J + 1)), dim3(kWave), 0, s, B, N, K, t, t_bs, c,
                      c_bs, U, (const double *)d, (const double *)W, (const double *)z, work + L.map);
-  hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),
-                     work + L.ends);
+  if (K >= kTwoLevelMin)   // (scratch: the record of the states, which k_final fills afterwards)
+    adjoint_chain_two_level<J>(B, K, work + L.map, work + L.ends, work + L.sf, s);
+  else
+    hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),
+                       work + L.ends);
   hipLaunchKernelGGL((k_final<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, V, (const double *)d, (const double *)W,
                      (const double *)z, (const double *)(work + L.start), (const double *)(work + L.ends),
                      (const int32_t *)flag, work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, by);
@@ -1127,7 +1134,9 @@ template <int J>
 __global__ __launch_bounds__(kWave) void k_newton_block(int64_t K, int64_t NB, const double *__restrict__ X,
                                                         const double *__restrict__ E, const double *__restrict__ Phi,
                                                         double *__restrict__ Psi, double *__restrict__ Rho,
-                                                        const unsigned long long *__restrict__ gate) {
+                                                        const unsigned long long *__restrict__ gate,
+                                                        const double *__restrict__ Rsrc = nullptr) {
+  // Rsrc (J x J per step): the sources r_k given directly instead of E_k - X_{k+1} (the adjoint chain)
   constexpr int NS = Dim<J>::NS;
   if (gate_closed(gate)) return;
   __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1], Sm[J][J + 1];
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(kWave) void k_newton_block(int64_t K, int64_t NB, c
   auto fetch = [&](int64_t k) {
     const int64_t g = b * K + k;
     ph = Phi[g * (J * J) + i * J + j];
-    rv = E[g * NS + sij] - X[(g + 1) * NS + sij];
+    rv = Rsrc ? Rsrc[g * (J * J) + i * J + j] : E[g * NS + sij] - X[(g + 1) * NS + sij];
   };
   fetch(k0);
   for (int64_t k = k0; k < k1; ++k) {
@@ -1257,6 +1266,108 @@ __global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, d
   for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
   worst /= 0.5 * kNewtonTol;
   if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
+}
+
+// ---- the adjoint chain in two levels ---------------------------------------------------------------------------------------
+// bF_start = Phi^T bF_end + gF does not involve bS, so it is chained first (the affine two-level chain of the solve, on
+// the chunks in REVERSE order: step k' = K-1-k); with bF at every chunk end known, the coupling sum_q bF_end[q] C_q + gS
+// is a plain source and bS_start = Phi^T bS_end Phi + source has the form of the Newton chain.
+template <int J>
+__global__ void k_adj_gather(int64_t B, int64_t K, const double *__restrict__ map, double *__restrict__ PhiA,
+                             double *__restrict__ gA) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * K * J * J) return;
+  const int ij = (int)(g % (J * J)), i = ij / J, j = ij % J;
+  const int64_t bk = g / (J * J), b = bk / K, k = bk - b * K, kr = b * K + (K - 1 - k);
+  const double *m = map + bk * MAPR;
+  PhiA[kr * (J * J) + ij] = m[(int64_t)j * NST + NS + i];   // Phi^T(i, j)
+  if (j == 0) gA[kr * J + i] = m[(int64_t)J * NST + NS + i];
+}
+template <int J>
+__global__ void k_adj_source(int64_t B, int64_t K, const double *__restrict__ map, const double *__restrict__ Fst,
+                             double *__restrict__ R) {
+  constexpr int NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * K * J * J) return;
+  const int ij = (int)(g % (J * J)), i = ij / J, j = ij % J, sij = sym(J, i, j);
+  const int64_t bkr = g / (J * J), b = bkr / K, kr = bkr - b * K, bk = b * K + (K - 1 - kr);
+  const double *m = map + bk * MAPR, *bF = Fst + bkr * J;
+  double r = m[(int64_t)J * NST + sij];
+#pragma unroll
+  for (int q = 0; q < J; ++q) r = fma(bF[q], m[(int64_t)q * NST + sij], r);
+  R[g] = r;
+}
+// ends[chunk] = (bS, bF) behind the chunk: the state entering step k' = K-1-chunk
+template <int J>
+__global__ __launch_bounds__(kWave) void k_adj_apply(int64_t K, int64_t NB, const double *__restrict__ Psi,
+                                                     const double *__restrict__ Rho, const double *__restrict__ Dstart,
+                                                     const double *__restrict__ Fst, double *__restrict__ ends) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
+  __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1];
+  const int lane = threadIdx.x;
+  const bool act = lane < J * J;
+  const int i = act ? lane / J : 0, j = act ? lane % J : 0;
+  const int64_t b = blockIdx.x / NB, nb = blockIdx.x % NB;
+  const int64_t k0 = nb * kBlock, k1 = (k0 + kBlock < K - 1) ? k0 + kBlock : K - 1;
+  const int sij = sym(J, i, j);
+  if (act) Dm[i][j] = Dstart[(b * NB + nb) * (J * J) + i * J + j];
+  lds_order();
+  if (nb == 0) {   // behind the last chunk: nothing
+    if (act && i <= j) ends[(b * K + K - 1) * NST + sij] = 0.0;
+    if (act && j == 0) ends[(b * K + K - 1) * NST + NS + i] = 0.0;
+  }
+  double ph, rv, bf;
+  auto fetch = [&](int64_t k) {
+    ph = Psi[(b * K + k) * (J * J) + i * J + j];
+    rv = Rho[(b * K + k) * (J * J) + i * J + j];
+    bf = Fst[(b * K + k + 1) * J + i];
+  };
+  fetch(k0);
+  for (int64_t k = k0; k < k1; ++k) {
+    const double mph = ph, mrv = rv, mbf = bf;
+    if (k + 1 < k1) fetch(k + 1);
+    lds_order();
+    Pm[i][j] = mph;
+    lds_order();
+    double y = 0.0;
+#pragma unroll
+    for (int l = 0; l < J; ++l) y = fma(Dm[i][l], Pm[j][l], y);
+    Ym[i][j] = y;
+    lds_order();
+    double dl = mrv;
+#pragma unroll
+    for (int q = 0; q < J; ++q) dl = fma(Pm[i][q], Ym[q][j], dl);
+    double *e = ends + (b * K + (K - 2 - k)) * NST;   // state entering step k + 1 = behind chunk K - 2 - k
+    if (act && i <= j) e[sij] = dl;
+    if (act && j == 0) e[NS + i] = mbf;
+  }
+}
+template <int J>
+static void adjoint_chain_two_level(int64_t B, int64_t K, const double *map, double *ends, double *scratch, hipStream_t s) {
+  const size_t BK = (size_t)B * K;
+  const int64_t NBa = (K + kBlock - 1) / kBlock, NBs = (K - 1 + kBlock - 1) / kBlock;
+  double *PhiA = scratch, *gA = PhiA + BK * J * J, *Fst = gA + BK * J, *PsiF = Fst + BK * J, *GamF = PsiF + BK * J * J,
+         *Fb = GamF + BK * J, *R = Fb + (size_t)B * NBa * J, *Psi = R + BK * J * J, *Rho = Psi + BK * J * J,
+         *Dstart = Rho + BK * J * J;
+  const unsigned nel = (unsigned)((BK * J * J + 255) / 256);
+  hipLaunchKernelGGL((k_adj_gather<J>), dim3(nel), dim3(256), 0, s, B, K, map, PhiA, gA);
+  // bF behind every chunk (reverse order): the affine chain of the solve
+  hipLaunchKernelGGL((k_solve_block<J>), dim3((unsigned)(B * NBa)), dim3(kWave), 0, s, K, NBa, (const double *)PhiA,
+                     (const double *)gA, PsiF, GamF);
+  hipLaunchKernelGGL((k_solve_blocks<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, NBa, (const double *)PsiF,
+                     (const double *)GamF, Fb);
+  hipLaunchKernelGGL((k_solve_starts<J>), dim3((unsigned)((BK * J + 255) / 256)), dim3(256), 0, s, B, K, NBa,
+                     (const double *)PsiF, (const double *)GamF, (const double *)Fb, Fst);
+  // bS: a congruence with a known source
+  hipLaunchKernelGGL((k_adj_source<J>), dim3(nel), dim3(256), 0, s, B, K, map, (const double *)Fst, R);
+  hipLaunchKernelGGL((k_newton_block<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, K, NBs, (const double *)nullptr,
+                     (const double *)nullptr, (const double *)PhiA, Psi, Rho, (const unsigned long long *)nullptr,
+                     (const double *)R);
+  hipLaunchKernelGGL((k_newton_blocks<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, NBs, (const double *)Psi,
+                     (const double *)Rho, Dstart, (const unsigned long long *)nullptr);
+  hipLaunchKernelGGL((k_adj_apply<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, K, NBs, (const double *)Psi,
+                     (const double *)Rho, (const double *)Dstart, (const double *)Fst, ends);
 }
 
 }  // namespace c2tg

@@ -344,3 +344,31 @@ def test_newton_factor_takes_over_on_long_series_at_widths_4_and_2(ops, oracle, 
     close(ll, llo)
     for g, e in zip(grads, go):
         gclose(g, e)
+
+
+@pytest.mark.parametrize("J,N,shared", [(2, 17000, True), (6, 16500, False), (8, 33000, True), (4, 40001, False)])
+def test_time_parallel_gradient_two_level_chains(ops, oracle, monkeypatch, J, N, shared):
+    """From 256 chunks per series every chain over the chunks runs in two levels (blocks of 32 chunks composed in
+    parallel): a small batch with a ragged last chunk and block, shared or per-series grids, one failed series -- the
+    log-likelihoods, flags and all six gradients against the oracle."""
+    B = 3
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    if shared:
+        t, c = np.tile(t[0], (B, 1)), np.tile(c[0], (B, 1))
+    a = a + 0.3
+    a[1, N // 3] = -2.0
+    llo, go, flo = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ok = np.asarray(flo) == 0      # (on a shared grid the other series' U, V need not give a positive definite matrix)
+    assert ok[0] and not ok[1]
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+    args = dev(t[0].copy() if shared else t, c[0].copy() if shared else c, a, U, V, y)
+    ll, grads, flag = ops.loglik_grad(*args)
+    assert np.array_equal(flag.cpu().numpy() != 0, ~ok)
+    close(ll[ok], llo[ok])
+    for g, e in zip(grads, go):
+        gn = g.cpu().numpy()
+        assert np.isnan(gn[~ok]).all()
+        for b in np.nonzero(ok)[0]:
+            gclose(gn[b], e[b])
+    ll0, flag0 = ops.loglik(*args)
+    close(ll0[ok], llo[ok])

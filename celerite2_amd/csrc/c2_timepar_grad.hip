@@ -22,6 +22,16 @@
 // into a lane-major scratch record first (no backward recursion, hence no stability condition).
 //
 // tools/proto/tpg.py is the same construction in numpy, checked against the sequential oracle.
+//
+// Also here, because they share the chunk machinery:
+//  * `factor` by NEWTON iterations on the chunk start states (k_newton_*; tools/proto/factor_newton.py) -- what the
+//    forward quantities above come from at widths 6 / 8 and on long series at widths 4 / 2;
+//  * z = L^-1 y by affine chunk maps at any even width (k_solve_*), and the forward-only log-likelihood composed from
+//    the two (c2_internal_loglik_wide);
+//  * every chain over the chunks in TWO LEVELS from kTwoLevelMin chunks per series: blocks of kBlock chunks compose
+//    their prefix maps in parallel, one wavefront per series walks the blocks, the prefix maps are applied in parallel
+//    (k_newton_block / _blocks / _apply, k_solve_block / _blocks / _starts, k_starts_blocks / _apply,
+//    adjoint_chain_two_level).
 #include <cstdint>
 #include <cstdlib>
 

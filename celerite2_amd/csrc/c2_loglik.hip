@@ -890,11 +890,63 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
 }
 // Time-parallel GRADIENT (c2_timepar_grad.hip; widths 2, 4, 6, 8): small batches of long series.
 // C2_TIMEPAR_GRAD=1 forces it, =0 disables it.
-extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J);
-extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
-                                               const double *c, int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
-                                               double *ll, double *bt, double *bc, double *ba, double *bU, double *bV,
-                                               double *by, int32_t *flag, double *work, c2_stream_t stream);
+// compiled for chunks of 64 and of 32 rows; a handful of series (at most 4096 chunks of 64 rows) takes the shorter ones:
+// twice as many lanes busy, half the walk per lane -- one series of 4096 rows 1.33 -> 1.03 ms, of 1e5 rows 1.68 -> 1.25 ms,
+// 64 x 4096 1.42 -> 1.16 ms (J = 8); beyond, the longer chains cost more: 1e6 rows 3.8 vs 5.0 ms, 32 x 50000 2.4 vs 3.1 ms
+// (C2_TPG_ROWS=32|64 overrides)
+#define C2_DECL_TPG(R_)                                                                                                    \
+  extern "C" size_t c2_internal_timepar_grad_doubles##R_(int64_t B, int64_t N, int64_t J);                               \
+  extern "C" int c2_internal_loglik_grad_timepar##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,     \
+                                                     const double *c, int64_t c_bs, const double *a, const double *U,    \
+                                                     const double *V, const double *y, double *ll, double *bt,           \
+                                                     double *bc, double *ba, double *bU, double *bV, double *by,         \
+                                                     int32_t *flag, double *work, c2_stream_t stream);                   \
+  extern "C" size_t c2_internal_factor_iter_doubles##R_(int64_t B, int64_t N, int64_t J);                                \
+  extern "C" int c2_internal_factor_iter##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,             \
+                                             const double *c, int64_t c_bs, const double *a, const double *U,            \
+                                             const double *V, double *d, double *W, int32_t *flag, double *work,         \
+                                             const unsigned long long **last_word, c2_stream_t stream);                  \
+  extern "C" size_t c2_internal_loglik_wide_doubles##R_(int64_t B, int64_t N, int64_t J);                                \
+  extern "C" int c2_internal_loglik_wide##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,             \
+                                             const double *c, int64_t c_bs, const double *a, const double *U,            \
+                                             const double *V, const double *y, double *ll, int32_t *flag, double *work,  \
+                                             c2_stream_t stream);
+C2_DECL_TPG(64)
+C2_DECL_TPG(32)
+#undef C2_DECL_TPG
+static bool tpg_short_chunks(int64_t B, int64_t N) {
+  const char *e = getenv("C2_TPG_ROWS");
+  if (e) return atoi(e) == 32;
+  return B * ((N + 63) / 64) <= 4096;
+}
+static size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J) {
+  return tpg_short_chunks(B, N) ? c2_internal_timepar_grad_doubles32(B, N, J) : c2_internal_timepar_grad_doubles64(B, N, J);
+}
+static int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                           int64_t c_bs, const double *a, const double *U, const double *V,
+                                           const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
+                                           double *bV, double *by, int32_t *flag, double *work, c2_stream_t stream) {
+  return (tpg_short_chunks(B, N) ? c2_internal_loglik_grad_timepar32 : c2_internal_loglik_grad_timepar64)(
+      B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
+}
+static size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {
+  return tpg_short_chunks(B, N) ? c2_internal_factor_iter_doubles32(B, N, J) : c2_internal_factor_iter_doubles64(B, N, J);
+}
+static int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                   int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
+                                   int32_t *flag, double *work, const unsigned long long **last_word, c2_stream_t stream) {
+  return (tpg_short_chunks(B, N) ? c2_internal_factor_iter32 : c2_internal_factor_iter64)(
+      B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, stream);
+}
+static size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J) {
+  return tpg_short_chunks(B, N) ? c2_internal_loglik_wide_doubles32(B, N, J) : c2_internal_loglik_wide_doubles64(B, N, J);
+}
+static int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                   int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                                   double *ll, int32_t *flag, double *work, c2_stream_t stream) {
+  return (tpg_short_chunks(B, N) ? c2_internal_loglik_wide32 : c2_internal_loglik_wide64)(B, N, J, t, t_bs, c, c_bs, a, U, V,
+                                                                                         y, ll, flag, work, stream);
+}
 #ifndef C2_TIMEPAR_GRAD_MIN_ROWS
 #define C2_TIMEPAR_GRAD_MIN_ROWS 1024
 #endif
@@ -916,16 +968,6 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
 }
 // widths 6 and 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it
-extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J);
-extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                                       int64_t c_bs, const double *a, const double *U, const double *V, double *d,
-                                       double *W, int32_t *flag, double *work, const unsigned long long **last_word,
-                                       c2_stream_t stream);
-extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J);
-extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                                       int64_t c_bs, const double *a,
-                                       const double *U, const double *V, const double *y, double *ll, int32_t *flag,
-                                       double *work, c2_stream_t stream);
 static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
   if (J != 2 && J != 4 && J != 6 && J != 8) return false;
   const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it (widths 6, 8: every length; 4, 2: long series), 0 disables it

@@ -49,10 +49,20 @@ extern "C" int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const d
 #define C2TG_FACTOR_MODE 1
 #endif
 
+// The file is compiled once per chunk length: C2TG_ROWS = 64 (default) and 32 (c2_timepar_grad32.hip includes it) -- a
+// handful of series spreads over twice as many lanes with half the walk per lane, at the price of chains twice as long.
+#ifndef C2TG_ROWS
+#define C2TG_ROWS 64
+#endif
+#define C2TG_CAT2(a, b) a##b
+#define C2TG_CAT(a, b) C2TG_CAT2(a, b)
+#define C2TG_NAME(stem) C2TG_CAT(stem, C2TG_ROWS)   // c2_internal_loglik_grad_timepar -> ..._timepar64
+#define c2tg C2TG_CAT(c2tg_r, C2TG_ROWS)            // one namespace per chunk length
+
 namespace c2tg {
 using namespace c2;
 
-constexpr int kRows = 64;   // rows per chunk
+constexpr int kRows = C2TG_ROWS;   // rows per chunk
 constexpr int64_t kTwoLevelMin = 256;   // chunks per series from which the sequential chains over the chunks run in two levels
 constexpr int kBlock = 32;              // chunks per block of the upper level
 
@@ -1385,7 +1395,7 @@ static void adjoint_chain_two_level(int64_t B, int64_t K, const double *map, dou
 using namespace c2tg;
 
 // doubles of workspace of the time-parallel gradient (0: width not covered)
-extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J) {
+extern "C" size_t C2TG_NAME(c2_internal_timepar_grad_doubles)(int64_t B, int64_t N, int64_t J) {
   switch (J) {
     case 2: return layout<2>(B, N).total;
     case 4: return layout<4>(B, N).total;
@@ -1396,7 +1406,7 @@ extern "C" size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t
 }
 
 // Same arguments and outputs as c2_loglik_grad (t, c per series or shared by the batch: strides 0).
-extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+extern "C" int C2TG_NAME(c2_internal_loglik_grad_timepar)(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
                                                const double *c, int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                                double *ll, double *bt, double *bc, double *ba, double *bU, double *bV,
                                                double *by, int32_t *flag, double *work, c2_stream_t stream) {
@@ -1413,7 +1423,7 @@ extern "C" int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, 
 // factor (d, W) by Newton iterations on the chunk start states (widths 6, 8).  work: c2_internal_factor_iter_doubles;
 // its first kNewtonMax + 2 words are the iteration words -- the caller launches its row-by-row kernel behind `*last_word`.
 constexpr int kNewtonMax = 8;
-extern "C" size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {
+extern "C" size_t C2TG_NAME(c2_internal_factor_iter_doubles)(int64_t B, int64_t N, int64_t J) {
   if (J != 2 && J != 4 && J != 6 && J != 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows);
   size_t n = (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
@@ -1453,7 +1463,7 @@ static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, 
   *last_word = words + P;
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
-extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+extern "C" int C2TG_NAME(c2_internal_factor_iter)(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                        int64_t c_bs, const double *a, const double *U, const double *V, double *d,
                                        double *W, int32_t *flag, double *work, const unsigned long long **last_word,
                                        c2_stream_t stream) {
@@ -1467,12 +1477,12 @@ extern "C" int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const do
 
 // Forward-only log-likelihood for small batches of long series at widths 6 / 8: d, W by c2_factor (Newton iterations on the
 // chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.
-extern "C" size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J) {
+extern "C" size_t C2TG_NAME(c2_internal_loglik_wide_doubles)(int64_t B, int64_t N, int64_t J) {
   if (J != 6 && J != 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
   return BN * (2 + J) + BK * (1 + 2 * (size_t)J * J + 3 * J) + (size_t)B * (K / kBlock + 2) * J + 8;
 }
-extern "C" int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+extern "C" int C2TG_NAME(c2_internal_loglik_wide)(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                        int64_t c_bs, const double *a,
                                        const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                        double *work, c2_stream_t stream) {

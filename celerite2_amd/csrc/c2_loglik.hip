@@ -888,7 +888,7 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   if (e) return atoi(e) != 0 && N >= 2;
   return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
 }
-// Time-parallel GRADIENT (c2_timepar_grad.hip; widths 2, 4, 6, 8): small batches of long series.
+// Time-parallel GRADIENT (c2_timepar_grad.hip; widths 1 .. 8): small batches of long series.
 // C2_TIMEPAR_GRAD=1 forces it, =0 disables it.
 // compiled for chunks of 64 and of 32 rows; a handful of series (at most 4096 chunks of 64 rows) takes the shorter ones:
 // twice as many lanes busy, half the walk per lane -- one series of 4096 rows 1.33 -> 1.03 ms, of 1e5 rows 1.68 -> 1.25 ms,
@@ -954,7 +954,7 @@ static int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double
 #define C2_TIMEPAR_GRAD_MAX_CHUNKS 32768
 #endif
 static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
-  if (J != 2 && J != 4 && J != 6 && J != 8) return false;
+  if (J < 1 || J > 8) return false;
   const char *e = getenv("C2_TIMEPAR_GRAD");
   if (e) return atoi(e) != 0 && N >= 2;
   const char *l = getenv("C2_LANES");
@@ -963,19 +963,19 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // of 50000 rows at J = 6 57.6 -> 4.6 ms; 256 x 4096 at J = 8 4.3 -> 1.9 ms.  The chunks are walked one per lane with
   // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
   // One series draws level at ~400 rows (J = 2), ~600 (J = 4, 6), ~800 (J = 8): 0.48 -> 0.25 ms at 768 rows, J = 2.
-  const int64_t min_rows = J == 2 ? 512 : (J == 8 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768);
+  const int64_t min_rows = J <= 2 ? 512 : (J >= 7 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768);
   return N >= min_rows && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
 }
 // widths 6 and 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it
 static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
-  if (J != 2 && J != 4 && J != 6 && J != 8) return false;
+  if (J < 1 || J > 8) return false;
   const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it (widths 6, 8: every length; 4, 2: long series), 0 disables it
   if (e && atoi(e) == 0) return false;
   // widths 4 and 2 have the composed linear-fractional maps of c2_timepar.hip, whose chain over the chunks is sequential:
   // the Newton iterations (chains in two levels) take over on long series -- J = 4: 1.67 -> 0.59 ms at 1e5 rows, 15.3 ->
   // 1.6 ms at 1e6 (0.45 vs 0.51 ms at 20000); J = 2: level at 1e5 rows (0.40 ms)
-  if (J <= 4) return N >= (J == 4 ? 32768 : 131072) && B * ((N + 63) / 64) <= 32768;
+  if (J == 2 || J == 4) return N >= (J == 4 ? 32768 : 131072) && B * ((N + 63) / 64) <= 32768;
   if (e) return N >= 2;
   const char *l = getenv("C2_LANES");
   if (l && atoi(l) != 0) return false;
@@ -1084,7 +1084,7 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
-  const bool newton = allow_timepar == 2 ? (J == 2 || J == 4 || J == 6 || J == 8) && N >= 2 : use_factor_iter(B, N, J);
+  const bool newton = allow_timepar == 2 ? J >= 1 && J <= 8 && N >= 2 : use_factor_iter(B, N, J);
   if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && newton) {
     const size_t nd = c2_internal_factor_iter_doubles(B, N, J);
     void *tmp = nullptr;

@@ -1,5 +1,5 @@
 // c2_timepar_grad.hip -- the fused log-likelihood GRADIENT parallel along time, for small batches of long series
-// (widths 2, 4, 6, 8).  Row by row such a batch is pure latency: ~1.2 us per row for the forward + reverse pair with a
+// (widths 1 .. 8).  Row by row such a batch is pure latency: ~1.2 us per row for the forward + reverse pair with a
 // handful of wavefronts on the chip.
 //
 // Forward quantities.  d, W (c2_factor; forward.hpp:105-134) and z = L^-1 y (c2_solve_lower; internal.hpp:135-145) of
@@ -98,16 +98,26 @@ __device__ __forceinline__ Geo chunk_of(int64_t B, int64_t N, int64_t K) {
 
 template <int J>
 __device__ __forceinline__ void load_row(const double *p, double (&x)[J]) {
+  if constexpr (J % 2 == 0) {   // rows of an even width are 16-byte aligned runs
 #pragma unroll
-  for (int j = 0; j < J; j += 2) {
-    const double2 v = *reinterpret_cast<const double2 *>(p + j);
-    x[j] = v.x; x[j + 1] = v.y;
+    for (int j = 0; j < J; j += 2) {
+      const double2 v = *reinterpret_cast<const double2 *>(p + j);
+      x[j] = v.x; x[j + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < J; ++j) x[j] = p[j];
   }
 }
 template <int J>
 __device__ __forceinline__ void store_row(double *p, const double (&x)[J]) {
+  if constexpr (J % 2 == 0) {
 #pragma unroll
-  for (int j = 0; j < J; j += 2) *reinterpret_cast<double2 *>(p + j) = make_double2(x[j], x[j + 1]);
+    for (int j = 0; j < J; j += 2) *reinterpret_cast<double2 *>(p + j) = make_double2(x[j], x[j + 1]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < J; ++j) p[j] = x[j];
+  }
 }
 
 // The inputs of one row of a chunk, fetched ONE ITERATION AHEAD of their use (a chunk is walked by a single lane: with
@@ -941,8 +951,9 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   double *d = work + L.d, *W = work + L.W, *z = work + L.z;
   if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, C2TG_FACTOR_MODE, (c2_stream_t)s)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  if (J == 6 || K >= kTwoLevelMin) {   // (scratch: the region of the adjoint maps, written later)
-    solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.map, s);
+  if ((J != 2 && J != 4 && J != 8) || K >= kTwoLevelMin) {   // no tiled solve at this width, or a long series
+    // (scratch: the record of the states, which k_final fills afterwards)
+    solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.sf, s);
   } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
   hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, (const double *)d, (const double *)W,
                      (const double *)z, work + L.loc, work + L.llp);
@@ -1397,9 +1408,13 @@ using namespace c2tg;
 // doubles of workspace of the time-parallel gradient (0: width not covered)
 extern "C" size_t C2TG_NAME(c2_internal_timepar_grad_doubles)(int64_t B, int64_t N, int64_t J) {
   switch (J) {
+    case 1: return layout<1>(B, N).total;
     case 2: return layout<2>(B, N).total;
+    case 3: return layout<3>(B, N).total;
     case 4: return layout<4>(B, N).total;
+    case 5: return layout<5>(B, N).total;
     case 6: return layout<6>(B, N).total;
+    case 7: return layout<7>(B, N).total;
     case 8: return layout<8>(B, N).total;
     default: return 0;
   }
@@ -1412,6 +1427,10 @@ extern "C" int C2TG_NAME(c2_internal_loglik_grad_timepar)(int64_t B, int64_t N, 
                                                double *by, int32_t *flag, double *work, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   switch (J) {
+    case 1: return run<1>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 3: return run<3>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 5: return run<5>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
+    case 7: return run<7>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
     case 2: return run<2>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
     case 4: return run<4>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
     case 6: return run<6>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, s);
@@ -1424,7 +1443,7 @@ extern "C" int C2TG_NAME(c2_internal_loglik_grad_timepar)(int64_t B, int64_t N, 
 // its first kNewtonMax + 2 words are the iteration words -- the caller launches its row-by-row kernel behind `*last_word`.
 constexpr int kNewtonMax = 8;
 extern "C" size_t C2TG_NAME(c2_internal_factor_iter_doubles)(int64_t B, int64_t N, int64_t J) {
-  if (J != 2 && J != 4 && J != 6 && J != 8) return 0;
+  if (J < 1 || J > 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows);
   size_t n = (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
   if ((int64_t)K >= kTwoLevelMin) n += (size_t)B * K * (size_t)(2 * J * J) + (size_t)B * ((K + kBlock - 1) / kBlock + 1) * (size_t)(J * J);
@@ -1468,6 +1487,10 @@ extern "C" int C2TG_NAME(c2_internal_factor_iter)(int64_t B, int64_t N, int64_t 
                                        double *W, int32_t *flag, double *work, const unsigned long long **last_word,
                                        c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (J == 1) return run_factor_iter<1>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
+  if (J == 3) return run_factor_iter<3>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
+  if (J == 5) return run_factor_iter<5>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
+  if (J == 7) return run_factor_iter<7>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   if (J == 2) return run_factor_iter<2>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   if (J == 4) return run_factor_iter<4>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
   if (J == 6) return run_factor_iter<6>(B, N, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, s);
@@ -1478,7 +1501,7 @@ extern "C" int C2TG_NAME(c2_internal_factor_iter)(int64_t B, int64_t N, int64_t 
 // Forward-only log-likelihood for small batches of long series at widths 6 / 8: d, W by c2_factor (Newton iterations on the
 // chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.
 extern "C" size_t C2TG_NAME(c2_internal_loglik_wide_doubles)(int64_t B, int64_t N, int64_t J) {
-  if (J != 6 && J != 8) return 0;
+  if (J < 1 || J > 8 || J == 2 || J == 4) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
   return BN * (2 + J) + BK * (1 + 2 * (size_t)J * J + 3 * J) + (size_t)B * (K / kBlock + 2) * J + 8;
 }
@@ -1487,13 +1510,17 @@ extern "C" int C2TG_NAME(c2_internal_loglik_wide)(int64_t B, int64_t N, int64_t 
                                        const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                        double *work, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (J != 6 && J != 8) return C2_ERR_UNSUPPORTED;
+  if (J < 1 || J > 8 || J == 2 || J == 4) return C2_ERR_UNSUPPORTED;
   const int64_t K = (N + kRows - 1) / kRows;
   const size_t BN = (size_t)B * N, BK = (size_t)B * K;
   double *d = work, *z = d + BN, *W = z + BN, *llp = W + BN * J, *Phi = llp + BK, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
   if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, stream)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  if (J == 6) solve_chunks<6>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  if (J == 1) solve_chunks<1>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (J == 3) solve_chunks<3>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (J == 5) solve_chunks<5>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (J == 6) solve_chunks<6>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (J == 7) solve_chunks<7>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   else if (K >= kTwoLevelMin) solve_chunks<8>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, stream)) return e;
   hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);

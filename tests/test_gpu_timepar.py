@@ -28,6 +28,19 @@ def close(a, b, tol=1e-10):
     np.testing.assert_allclose(a, b, rtol=tol, atol=0.0)
 
 
+def wide_batch(B, N, J):
+    """A positive definite batch of any width: an odd width drops the last column of the next even one and lifts the
+    diagonal (the dropped term's variance becomes white noise)."""
+    Je = J + (J % 2)
+    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), Je)
+    t, a, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, y))
+    U, V = np.ascontiguousarray(U[:, :N, :J]), np.ascontiguousarray(V[:, :N, :J])
+    c = np.ascontiguousarray(c[:, :J])
+    if Je != J:
+        a = a + 1.0
+    return t, c, a, U, V, y
+
+
 def oracle_ll(oracle, t, c, a, U, V, y):
     ll, _, fl = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
     return ll, np.asarray(fl)
@@ -176,14 +189,13 @@ def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
 
 
-@pytest.mark.parametrize("J", [8, 6, 4, 2])
+@pytest.mark.parametrize("J", [8, 7, 6, 5, 4, 3, 2, 1])
 @pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 128), (7, 700), (2, 4096), (70, 300), (1, 20000)])
 def test_timepar_gradient_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     """The gradient parallel along time (c2_timepar_grad.hip: d, W, z from factor + solve, linear recurrences for the
     states, the adjoint recursion as affine chunk maps), forced on shapes around the chunk length (64 rows): log-likelihood
     and all six gradients against the oracle; a failed series gets -inf / NaN and leaves its neighbours alone."""
-    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
-    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    t, c, a, U, V, y = wide_batch(B, N, J)
     llo, go, flo = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
     assert not np.asarray(flo).any()
     monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
@@ -229,14 +241,13 @@ def gclose(a, b, tol=1e-10):
     np.testing.assert_allclose(a, b, rtol=0.0, atol=tol * max(np.abs(b).max(), 1e-300))
 
 
-@pytest.mark.parametrize("J", [8, 6])
+@pytest.mark.parametrize("J", [8, 7, 6, 5, 3, 1])
 @pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 129), (2, 4096), (9, 1000), (1, 30000)])
 def test_newton_factor_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     """`factor` (d, W) at widths 6 and 8 by Newton iterations on the chunk start states (c2_timepar_grad.hip), forced:
     every row against the oracle; a failed series hands the batch to the row-by-row kernel, which reports the
     reference's flag; in-place calls stay on the row-by-row kernel and agree."""
-    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
-    t, a, U, V = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V))
+    t, c, a, U, V, y = wide_batch(B, N, J)
     monkeypatch.setenv("C2_FACTOR_ITER", "1")
     d, W, flag = ops.factor(*dev(t, c, a, U, V))
     assert int(flag.abs().sum()) == 0
@@ -279,13 +290,12 @@ def test_newton_factor_on_hard_series(ops, oracle, monkeypatch):
             np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-9 if b == 2 else 1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
 
 
-@pytest.mark.parametrize("J", [8, 6])
+@pytest.mark.parametrize("J", [8, 7, 6, 5, 3, 1])
 @pytest.mark.parametrize("B,N", [(1, 1), (3, 63), (4, 65), (2, 4096), (9, 1000), (1, 30000)])
 def test_wide_loglik_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     """Forward-only log-likelihood at widths 6 / 8 composed from the Newton factor, the time-parallel solve and a
     reduction (forced): against the oracle and the row-by-row kernel; a failed series gets its flag and -inf."""
-    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
-    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    t, c, a, U, V, y = wide_batch(B, N, J)
     llo, flo = oracle_ll(oracle, t, c, a, U, V, y)
     monkeypatch.setenv("C2_FACTOR_ITER", "1")
     ll, flag = ops.loglik(*dev(t, c, a, U, V, y))

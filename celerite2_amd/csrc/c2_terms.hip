@@ -57,7 +57,9 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
     const double *__restrict__ ba, const double *__restrict__ bU, const double *__restrict__ bV,
     double *__restrict__ bar, double *__restrict__ bcr, double *__restrict__ bac, double *__restrict__ bbc,
     double *__restrict__ bcc, double *__restrict__ bdc, double *__restrict__ bx, double *__restrict__ bdiag,
-    const unsigned long long *__restrict__ gate) {
+    const unsigned long long *__restrict__ gate, int nsplit, double *__restrict__ part) {
+  // nsplit > 1 (a handful of long series): blockIdx.y takes a slice of the rows and leaves its sums in
+  // part[series][slice][term][4]; k_terms_rev_finish adds the slices in order
   __shared__ double red[kThreads][4];
   if (c2::gate_closed(gate)) return;
   const int Q = Jr + Jc, J = Jr + 2 * Jc;
@@ -73,9 +75,11 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
     if (q >= Jr) { a_ = ac[o + q - Jr]; b_ = bc[o + q - Jr]; d_ = dc[o + q - Jr]; }
     const double *xb = x + b * x_bs;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, sba = 0.0;
-    for (int64_t nw = (int64_t)wave * rpw; nw < N; nw += rows_it) {   // wavefront-uniform bound: the shuffles below
+    const int64_t per = ((N + nsplit - 1) / nsplit + rows_it - 1) / rows_it * rows_it;   // rows per slice
+    const int64_t nlo = (int64_t)blockIdx.y * per, nhi = (nlo + per < N) ? nlo + per : N;
+    for (int64_t nw = nlo + (int64_t)wave * rpw; nw < nhi; nw += rows_it) {   // wavefront-uniform bound: the shuffles below
       const int64_t n = nw + r;
-      const bool valid = active && n < N;
+      const bool valid = active && n < nhi;
       const int64_t row = b * N + (valid ? n : 0);
       double contrib = 0.0;
       if (valid) {
@@ -111,7 +115,10 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
           const int src = w * 64 + rr * Q;
           a0 += red[src + t][0]; a1 += red[src + t][1]; a2 += red[src + t][2]; ab += red[src][3];
         }
-      if (t < Jr) {
+      if (nsplit > 1) {
+        double *o = part + ((b * nsplit + blockIdx.y) * Q + t) * 4;
+        o[0] = a0; o[1] = a1; o[2] = a2; o[3] = ab;
+      } else if (t < Jr) {
         bar[b * Jr + t] = ab + a0;
         bcr[b * Jr + t] = bcv[b * J + t];
       } else {
@@ -121,6 +128,30 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
       }
     }
     __syncthreads();
+  }
+}
+
+// the slices of k_terms_rev added in order (one block per series, thread <-> term)
+__global__ void k_terms_rev_finish(int Jr, int Jc, int nsplit, const double *__restrict__ part,
+                                   const double *__restrict__ bcv, double *__restrict__ bar, double *__restrict__ bcr,
+                                   double *__restrict__ bac, double *__restrict__ bbc, double *__restrict__ bcc,
+                                   double *__restrict__ bdc, const unsigned long long *__restrict__ gate) {
+  if (c2::gate_closed(gate)) return;
+  const int Q = Jr + Jc, J = Jr + 2 * Jc, t = threadIdx.x;
+  const int64_t b = blockIdx.x;
+  if (t >= Q) return;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, ab = 0.0;
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const double *o = part + ((b * nsplit + sp) * Q + t) * 4;
+    a0 += o[0]; a1 += o[1]; a2 += o[2]; ab += o[3];
+  }
+  if (t < Jr) {
+    bar[b * Jr + t] = ab + a0;
+    bcr[b * Jr + t] = bcv[b * J + t];
+  } else {
+    const int k = t - Jr;
+    bac[b * Jc + k] = ab + a0; bbc[b * Jc + k] = a1; bdc[b * Jc + k] = a2;
+    bcc[b * Jc + k] = bcv[b * J + Jr + 2 * k] + bcv[b * J + Jr + 2 * k + 1];
   }
 }
 
@@ -295,10 +326,21 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
                                     w + p.ba, w + p.bU, w + p.bV, by, flag, w + p.one_d,
                                     c2_loglik_grad_workspace_bytes(B, N, J), stream))
     return e;
-  hipLaunchKernelGGL(k_terms_rev, dim3((unsigned)(B < 0x7fffffff ? B : 0x7fffffff)), dim3(kThreads), 0, s, B, N, (int)Jr,
-                     (int)Jc, ac, bc, dc, coef_batched, x, x_bs, (const double *)(w + p.V), (const double *)(w + p.bt),
-                     (const double *)(w + p.bc), (const double *)(w + p.ba), (const double *)(w + p.bU),
-                     (const double *)(w + p.bV), bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, gate);
+  // a handful of long series: slices of the rows in parallel (partial sums in the 1-D workspace, free by now)
+  int nsplit = 1;
+  if (B < 64 && N >= 8192) {
+    nsplit = (int)((N + 2047) / 2048);
+    if (nsplit > 256) nsplit = 256;
+  }
+  double *part = w + p.one_d;
+  hipLaunchKernelGGL(k_terms_rev, dim3((unsigned)(B < 0x7fffffff ? B : 0x7fffffff), (unsigned)nsplit), dim3(kThreads), 0, s,
+                     B, N, (int)Jr, (int)Jc, ac, bc, dc, coef_batched, x, x_bs, (const double *)(w + p.V),
+                     (const double *)(w + p.bt), (const double *)(w + p.bc), (const double *)(w + p.ba),
+                     (const double *)(w + p.bU), (const double *)(w + p.bV), bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, gate,
+                     nsplit, part);
+  if (nsplit > 1)
+    hipLaunchKernelGGL(k_terms_rev_finish, dim3((unsigned)B), dim3(64), 0, s, (int)Jr, (int)Jc, nsplit,
+                       (const double *)part, (const double *)(w + p.bc), bar, bcr, bac, bbc, bcc, bdc, gate);
   return launch_ok();
 }
 

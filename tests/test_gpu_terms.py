@@ -59,7 +59,8 @@ def oracle_chain(oracle, ar, cr, ac, bc, cc, dc, x, diag, y):
     return ll, (bar, bcr, bac, bbc, bcc, bdc, bx, ba.copy(), by)
 
 
-@pytest.mark.parametrize("B,N,Jr,Jc", [(5, 200, 1, 2), (3, 1000, 0, 4), (70, 64, 2, 0), (2, 33, 3, 1), (1, 1, 1, 1)])
+@pytest.mark.parametrize("B,N,Jr,Jc", [(5, 200, 1, 2), (3, 1000, 0, 4), (70, 64, 2, 0), (2, 33, 3, 1), (1, 1, 1, 1), (2, 20000, 0, 2),
+                                      (1, 9000, 1, 3), (3, 8192, 2, 0)])
 def test_loglik_terms_vs_oracle_chain(ops, oracle, B, N, Jr, Jc):
     rng = np.random.default_rng(11)
     ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)

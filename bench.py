@@ -250,46 +250,11 @@ def main():
                torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
                torch.empty((Bp, N), dtype=torch.float64, device=dev))
         if args.placement_search > 1:
-            # Setup, not timed.  The step streams nine large arrays at once and its time depends on where the workspace
-            # and the six gradient arrays sit relative to HBM's channel hashing (28-34 ms from process to process with
-            # identical allocations: DESIGN.md 8.2).  So, as an application that reuses its buffers would, try a few
-            # placements -- the allocator's own first, then the same arrays carved from one pool with different gaps
-            # between them -- time one step each and keep the fastest.  Every candidate's time is reported.
-            def one_step_ms(w_, o_):
-                for _ in range(2):
-                    ops.loglik_grad(t, c, a, U, V, y, work=w_, out=o_)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                ops.loglik_grad(t, c, a, U, V, y, work=w_, out=o_)
-                e1.record()
-                torch.cuda.synchronize()
-                return e0.elapsed_time(e1)
-
-            # candidates: the allocator's own placement, then fresh allocations behind spacers of different sizes (the
-            # arrays land on other physical pages; carving them from ONE pool was tried and is worse: 37-40 ms)
-            spacers_mb = [None, 3, 67, 1029, 4099][:args.placement_search]
-            cand = [{"spacer_MB": None, "ms": one_step_ms(work, out)}]
-            best = (cand[0]["ms"], work, out, None)
-            for mb in spacers_mb[1:]:
-                try:
-                    sp = torch.empty(mb * 2**20 + 4096 * 17, dtype=torch.uint8, device=dev)
-                    w_ = torch.empty_like(work)
-                    o_ = tuple(torch.empty_like(x) for x in out)
-                except RuntimeError:
-                    break
-                ms_ = one_step_ms(w_, o_)
-                cand.append({"spacer_MB": mb, "ms": ms_})
-                if ms_ < best[0]:
-                    best = (ms_, w_, o_, sp)
-                del sp, w_, o_
-                if best[1] is not work:       # drop the loser (and the allocator's cached blocks: the next candidate
-                    del work, out             # must not simply get them back)
-                    work, out = best[1], best[2]
-                torch.cuda.empty_cache()
-            keep_spacer = best[3]             # stays allocated: freeing it would not move anything, but keep the state
-            placement = {"candidates": cand, "chosen_ms": best[0],
-                         "note": "setup, untimed: one step per candidate placement of the workspace and gradient arrays"}
+            # Setup, not timed: what an application that reuses its buffers would do (ops.loglik_grad_buffers) -- time one
+            # step on a few placements of the workspace and the gradient arrays, keep the fastest, report them all.
+            del work, out
+            work, out, placement = ops.loglik_grad_buffers(t, c, a, U, V, y, candidates=args.placement_search)
+            keep_spacer = placement.pop("spacer")
 
     def step():
         if grad:

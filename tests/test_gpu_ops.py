@@ -991,3 +991,19 @@ def test_hot_path_is_graph_capturable(ops, oracle, monkeypatch):
             close(ll_g, llo)
             for x, e in zip(out_g, go):
                 close(x, e)
+
+
+def test_loglik_grad_buffers_placement_search(ops, oracle):
+    """ops.loglik_grad_buffers: workspace + gradient arrays chosen among a few placements by timing one step each; the
+    buffers it returns are ordinary `work=` / `out=` arguments."""
+    B, N, J = 70, 300, 8
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    args = dev(t, c, a, U, V, y)
+    work, out, report = ops.loglik_grad_buffers(*args, candidates=3)
+    assert len(report["candidates"]) == 3 and report["chosen_ms"] == min(x["ms"] for x in report["candidates"])
+    ll, grads, flag = ops.loglik_grad(*args, work=work, out=out)
+    assert all(g is o for g, o in zip(grads, out)) and int(flag.abs().sum()) == 0
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    close(ll, llo)
+    for g, e in zip(grads, go):
+        close(g, e)

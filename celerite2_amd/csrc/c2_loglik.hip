@@ -1078,45 +1078,63 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
 // allow_timepar: 0 row by row only; 1 the dispatch's choice; 2 the Newton iterations at every width they cover (the
 // time-parallel gradient builds on d, W: the composed maps of widths 4 / 2 are verified to 5e-11 only, which an
 // ill-conditioned series -- the interleaved 2-D construction -- turns into 5e-11 of the largest gradient entry)
-int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                             int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
-                             int32_t *flag, int allow_timepar, c2_stream_t stream) {
+// `scratch` (nullable; c2_internal_factor_scratch_doubles): caller-provided room for the time-parallel forms -- without it
+// they use a stream-ordered temporary and stay out of graph captures.
+size_t c2_internal_factor_scratch_doubles(int64_t B, int64_t N, int64_t J) {
+  const size_t n1 = c2_internal_factor_iter_doubles(B, N, J), n2 = c2_internal_timepar_doubles(B, N, J) + 2;
+  return ((n1 > n2 ? n1 : n2) + 1) & ~(size_t)1;
+}
+int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
+                                int32_t *flag, int allow_timepar, double *scratch, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
+  const bool may_alloc = capturing == hipStreamCaptureStatusNone;
+  auto room = [&](size_t nd, void **tmp) {   // the caller's scratch, else a stream-ordered temporary
+    if (scratch) { *tmp = scratch; return true; }
+    return may_alloc && hipMallocAsync(tmp, nd * sizeof(double), s) == hipSuccess;
+  };
+  auto release = [&](void *tmp, int rc) {
+    if (!scratch && hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+    return rc;
+  };
   const bool newton = allow_timepar == 2 ? J >= 1 && J <= 8 && N >= 2 : use_factor_iter(B, N, J);
-  if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && newton) {
+  if (allow_timepar && d != a && W != V && newton) {
     const size_t nd = c2_internal_factor_iter_doubles(B, N, J);
     void *tmp = nullptr;
-    if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+    if (nd > 0 && room(nd, &tmp)) {
       const unsigned long long *last = nullptr;
       int rc = c2_internal_factor_iter(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, (double *)tmp, &last, stream);
       if (rc == C2_OK)
         rc = launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, a, nullptr, flag, nullptr, 0, W,
                            reinterpret_cast<double2 *>(d), s, last);
-      if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
-      return rc;
+      return release(tmp, rc);
     }
     (void)hipGetLastError();
   }
   // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
   // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
-  if (allow_timepar && capturing == hipStreamCaptureStatusNone && d != a && W != V && use_timepar(B, N, J)) {
+  if (allow_timepar && d != a && W != V && use_timepar(B, N, J)) {
     const size_t nd = c2_internal_timepar_doubles(B, N, J);
     void *tmp = nullptr;
-    if (nd > 0 && hipMallocAsync(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {
+    if (nd > 0 && room(nd + 2, &tmp)) {
       unsigned long long *guard = (unsigned long long *)tmp;
       int rc = c2_internal_factor_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, (double *)tmp + 2, guard, stream);
       if (rc == C2_OK)
         rc = launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, a, nullptr, flag, nullptr, 0, W,
                            reinterpret_cast<double2 *>(d), s, guard);
-      if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
-      return rc;
+      return release(tmp, rc);
     }
     (void)hipGetLastError();
   }
   return launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, /*y (unused: any readable (B,N) array)*/ a, nullptr, flag,
                        nullptr, 0, W, reinterpret_cast<double2 *>(d), (hipStream_t)stream);
+}
+int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                             int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
+                             int32_t *flag, int allow_timepar, c2_stream_t stream) {
+  return c2_internal_factor_fused_ws(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, allow_timepar, nullptr, stream);
 }
 
 

@@ -38,9 +38,11 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
-extern "C" int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                                        int64_t c_bs, const double *a, const double *U, const double *V, double *d,
-                                        double *W, int32_t *flag, int allow_timepar, c2_stream_t stream);
+extern "C" int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                           int64_t c_bs, const double *a, const double *U, const double *V, double *d,
+                                           double *W, int32_t *flag, int allow_timepar, double *scratch,
+                                           c2_stream_t stream);
+extern "C" size_t c2_internal_factor_scratch_doubles(int64_t B, int64_t N, int64_t J);
 
 // 1: the dispatch's choice of factor kernels (widths 4 / 2 below 32768 rows: the composed maps of c2_timepar.hip, verified
 // to 5e-11 -- gradients to ~4e-12 of their largest entry, 5e-11 on ill-conditioned series); 2: Newton iterations at
@@ -919,7 +921,7 @@ static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64
 }
 
 struct Layout {
-  size_t d, W, z, loc, start, ends, map, sf, dT, bcp, llp, total;
+  size_t d, W, z, loc, start, ends, map, sf, dT, bcp, llp, fs, total;
 };
 template <int J>
 static Layout layout(int64_t B, int64_t N) {
@@ -934,6 +936,7 @@ static Layout layout(int64_t B, int64_t N) {
   L.map = take(BK * MAPR);
   L.sf = take(waves * kRows * NST * kWave);
   L.dT = take(BN); L.bcp = take(BK * J); L.llp = take(BK);
+  L.fs = take(c2_internal_factor_scratch_doubles(B, N, J));   // room for the factor's own time-parallel form: no allocation
   L.total = o;
   return L;
 }
@@ -949,12 +952,13 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   const Layout L = layout<J>(B, N);
   const int64_t K = (N + kRows - 1) / kRows;
   double *d = work + L.d, *W = work + L.W, *z = work + L.z;
-  if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, C2TG_FACTOR_MODE, (c2_stream_t)s)) return e;
+  if (int e = c2_internal_factor_fused_ws(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, C2TG_FACTOR_MODE, work + L.fs,
+                                          (c2_stream_t)s))
+    return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  if ((J != 2 && J != 4 && J != 8) || K >= kTwoLevelMin) {   // no tiled solve at this width, or a long series
-    // (scratch: the record of the states, which k_final fills afterwards)
-    solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.sf, s);
-  } else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, (c2_stream_t)s)) return e;
+  // z by the chunk maps (allocation-free, so the whole call can be captured in a graph; scratch: the record of the states,
+  // which k_final fills afterwards)
+  solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.sf, s);
   hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, (const double *)d, (const double *)W,
                      (const double *)z, work + L.loc, work + L.llp);
   if (K >= kTwoLevelMin) {   // (the prefix maps live in the region of the adjoint maps, written later)

@@ -386,9 +386,9 @@ def test_time_parallel_gradient_two_level_chains(ops, oracle, monkeypatch, J, N,
 
 @pytest.mark.parametrize("J,N", [(8, 1500), (6, 20000), (3, 900)])
 def test_time_parallel_gradient_inside_a_graph_capture(ops, oracle, J, N):
-    """Captured in a HIP graph the time-parallel gradient makes no allocation: its forward quantities then come from
-    the row-by-row factor / solve (their time-parallel forms use stream-ordered temporaries and stay out of captures),
-    the chunk kernels are the same -- replayed on new data it still gives the oracle's numbers."""
+    """The time-parallel gradient makes no allocation (the factor's Newton iterations / composed maps work in a piece of
+    the caller's workspace, z comes from the chunk maps), so the whole call -- gated iterations and fallbacks included --
+    can be captured in a HIP graph; replayed on new data it gives the oracle's numbers."""
     import torch
     B = 2
     t, c, a, U, V, y = wide_batch(B, N, J)

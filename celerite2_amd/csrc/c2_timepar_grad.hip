@@ -1505,7 +1505,7 @@ extern "C" int C2TG_NAME(c2_internal_factor_iter)(int64_t B, int64_t N, int64_t 
 // Forward-only log-likelihood for small batches of long series at widths 6 / 8: d, W by c2_factor (Newton iterations on the
 // chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.
 extern "C" size_t C2TG_NAME(c2_internal_loglik_wide_doubles)(int64_t B, int64_t N, int64_t J) {
-  if (J < 1 || J > 8 || J == 2 || J == 4) return 0;
+  if (J < 1 || J > 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows), BN = (size_t)B * N, BK = (size_t)B * K;
   return BN * (2 + J) + BK * (1 + 2 * (size_t)J * J + 3 * J) + (size_t)B * (K / kBlock + 2) * J + 8;
 }
@@ -1514,19 +1514,20 @@ extern "C" int C2TG_NAME(c2_internal_loglik_wide)(int64_t B, int64_t N, int64_t 
                                        const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                        double *work, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (J < 1 || J > 8 || J == 2 || J == 4) return C2_ERR_UNSUPPORTED;
+  if (J < 1 || J > 8) return C2_ERR_UNSUPPORTED;
   const int64_t K = (N + kRows - 1) / kRows;
   const size_t BN = (size_t)B * N, BK = (size_t)B * K;
   double *d = work, *z = d + BN, *W = z + BN, *llp = W + BN * J, *Phi = llp + BK, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
   if (int e = c2_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, nullptr, flag, stream)) return e;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
   if (J == 1) solve_chunks<1>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (J == 2) solve_chunks<2>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
+  else if (J == 4) solve_chunks<4>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   else if (J == 3) solve_chunks<3>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   else if (J == 5) solve_chunks<5>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   else if (J == 6) solve_chunks<6>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   else if (J == 7) solve_chunks<7>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
-  else if (K >= kTwoLevelMin) solve_chunks<8>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
-  else if (int e = c2_solve_lower(B, N, J, 1, t, t_bs, c, c_bs, U, W, y, z, nullptr, stream)) return e;
+  else solve_chunks<8>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, Phi, s);
   hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);
   hipLaunchKernelGGL(k_ll_series, dim3((unsigned)B), dim3(kWave), 0, s, N, K, (const double *)llp,
                      (const int32_t *)flag, ll);

@@ -914,7 +914,9 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
 C2_DECL_TPG(64)
 C2_DECL_TPG(32)
 #undef C2_DECL_TPG
-static bool tpg_short_chunks(int64_t B, int64_t N) {
+extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N);
+static bool tpg_short_chunks(int64_t B, int64_t N) { return c2_internal_tpg_short_chunks(B, N) != 0; }
+extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N) {
   const char *e = getenv("C2_TPG_ROWS");
   if (e) return atoi(e) == 32;
   return B * ((N + 63) / 64) <= 4096;

@@ -1132,6 +1132,19 @@ extern "C" size_t c2_internal_timepar_solve_doubles(int64_t B, int64_t N, int64_
 extern "C" int c2_internal_solve_timepar(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
                                          const double *c, int64_t c_bs, const double *U, const double *W,
                                          const double *Y, double *Z, double *scratch, c2_stream_t stream);
+extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N);
+#define C2_DECL_SC(R_)                                                                                               \
+  extern "C" size_t c2_internal_solve_chunks_doubles##R_(int64_t B, int64_t N, int64_t J);                          \
+  extern "C" int c2_internal_solve_chunks##R_(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, \
+                                              const double *c, int64_t c_bs, const double *U, const double *W,      \
+                                              const double *Y, double *Z, double *scratch, c2_stream_t stream);
+C2_DECL_SC(64)
+C2_DECL_SC(32)
+#undef C2_DECL_SC
+static bool solve_chunks_enabled() {
+  const char *e = getenv("C2_TIMEPAR");   // the switch of the time-parallel solves: 0 keeps them row by row
+  return !(e && atoi(e) == 0);
+}
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -1155,6 +1168,24 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
       while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
       return c2_internal_matmul_chunked(LOWER ? 1 : 0, B, N, J, nrhs, Lc, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
                                         stream);
+    }
+  }
+  if (SOLVE && nrhs == 1 && !F && J <= 8 && N >= 16384 && B * ((N + 63) / 64) <= 32768 && solve_chunks_enabled()) {
+    // a small batch of LONG series: chunk maps with the chain over the chunks in two levels (c2_timepar_grad.hip; every
+    // width up to 8).  Scratch is a stream-ordered temporary; not inside graph captures.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);
+    if (capturing == hipStreamCaptureStatusNone) {
+      const bool sh = c2_internal_tpg_short_chunks(B, N) != 0;
+      const size_t nd = sh ? c2_internal_solve_chunks_doubles32(B, N, J) : c2_internal_solve_chunks_doubles64(B, N, J);
+      void *tmp = nullptr;
+      if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+        int rc = (sh ? c2_internal_solve_chunks32 : c2_internal_solve_chunks64)(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V,
+                                                                               Y, Z, (double *)tmp, stream);
+        if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+        return rc;
+      }
+      (void)hipGetLastError();
     }
   }
   if (SOLVE && nrhs == 1 && !F && c2_internal_use_timepar_solve(B, N, J)) {

@@ -129,18 +129,20 @@ template <int J, bool WITH_U, bool WITH_V>
 struct RowIn {
   double u[WITH_U ? J : 1], v[WITH_V ? J : 1], w[J], d, z, dt;   // dt: gap to the next row (0 behind the last row)
 };
-template <int J, bool WITH_U, bool WITH_V>
+// REV: the chunks walk the series from its far end (position s <-> row N-1-s; solve_upper)
+template <int J, bool WITH_U, bool WITH_V, bool REV = false>
 __device__ __forceinline__ void fetch_row(RowIn<J, WITH_U, WITH_V> &R, const Geo &G, int64_t N, int r, const double *tb,
                                           const double *Ub, const double *Vb, const double *Wb, const double *db,
                                           const double *zb) {
   const int rc = r < G.len ? (r < 0 ? 0 : r) : (G.len > 0 ? G.len - 1 : 0);
-  const int64_t n = G.lo + rc;
+  const int64_t pos = G.lo + rc, n = REV ? N - 1 - pos : pos;
   if constexpr (WITH_U) load_row<J>(Ub + n * J, R.u);
   if constexpr (WITH_V) load_row<J>(Vb + n * J, R.v);
   load_row<J>(Wb + n * J, R.w);
   R.d = db[n]; R.z = zb[n];
-  const double t0 = tb[n], t1 = tb[n + 1 < N ? n + 1 : n];
-  R.dt = t1 - t0;
+  const int64_t nn = REV ? (n > 0 ? n - 1 : n) : (n + 1 < N ? n + 1 : n);   // the next row of the walk
+  const double t0 = tb[n], t1 = tb[nn];
+  R.dt = REV ? t0 - t1 : t1 - t0;
 }
 
 // state + its own row:  S += d w^T w,  F += w z
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(kWave) void k_finish_c(int64_t K, const double *__r
 // The recursion is affine in its state with the SAME propagator as above: F_{n+1} = P (I - w_n u_n^T) F_n + P w_n y_n,
 // z_n = y_n - u_n F_n (internal.hpp:135-145).  k_solve_maps: (Phi_k, g_k) of every chunk; k_solve_chain: the states the
 // chunks start from; k_solve_apply: z of every row.
-template <int J>
+template <int J, bool REV = false>
 __global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                       const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                       const double *__restrict__ W, const double *__restrict__ y,
@@ -715,10 +717,10 @@ __global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int6
     for (int j = 0; j < J; ++j) M[i][j] = i == j ? 1.0 : 0.0;
   }
   RowIn<J, true, false> cur, nxt;   // d <- y (unused), z <- y
-  fetch_row<J, true, false>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
+  fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
 #pragma unroll 1
   for (int r = 0; r < kRows; ++r) {
-    fetch_row<J, true, false>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
+    fetch_row<J, true, false, REV>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
     if (r < G.len) {
       double p[J], uf = 0.0;
 #pragma unroll
@@ -847,7 +849,7 @@ __global__ void k_solve_starts(int64_t B, int64_t K, int64_t NB, const double *_
   }
   Fst[g] = v;
 }
-template <int J>
+template <int J, bool REV = false>
 __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                        const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                        const double *__restrict__ W, const double *__restrict__ y,
@@ -859,16 +861,16 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
   const double *tb = t + G.b * t_bs, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
   double *zb = z + G.b * N;
   RowIn<J, true, false> cur, nxt;
-  fetch_row<J, true, false>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
+  fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
 #pragma unroll 1
   for (int r = 0; r < kRows; ++r) {
-    fetch_row<J, true, false>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
+    fetch_row<J, true, false, REV>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
     if (r < G.len) {
       double uf = 0.0;
 #pragma unroll
       for (int j = 0; j < J; ++j) uf = fma(cur.u[j], F[j], uf);
       const double zn = cur.z - uf;
-      zb[G.lo + r] = zn;
+      zb[REV ? N - 1 - (G.lo + r) : G.lo + r] = zn;
 #pragma unroll
       for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]) * exp_decay(-cj[i] * cur.dt);
     }
@@ -896,13 +898,13 @@ __global__ __launch_bounds__(kWave) void k_ll_series(int64_t N, int64_t K, const
 }
 
 // z = L^-1 y by chunk maps (k_solve_*); scratch: B K (2 J^2 + 3 J) + B (K / kBlock + 1) J doubles
-template <int J>
+template <int J, bool REV = false>
 static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                          const double *U, const double *W, const double *y, double *z, double *scratch, hipStream_t s) {
   const size_t BK = (size_t)B * K;
   double *Phi = scratch, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  hipLaunchKernelGGL((k_solve_maps<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, Phi, gk);
+  hipLaunchKernelGGL((k_solve_maps<J, REV>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, Phi, gk);
   if (K >= kTwoLevelMin) {
     const int64_t NB = (K + kBlock - 1) / kBlock;
     double *Psi = Fst + BK * J, *Gam = Psi + BK * J * J, *Fb = Gam + BK * J;
@@ -916,7 +918,7 @@ static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64
     hipLaunchKernelGGL((k_solve_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
                        (const double *)gk, Fst);
   }
-  hipLaunchKernelGGL((k_solve_apply<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y,
+  hipLaunchKernelGGL((k_solve_apply<J, REV>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y,
                      (const double *)Fst, z);
 }
 
@@ -1531,5 +1533,31 @@ extern "C" int C2TG_NAME(c2_internal_loglik_wide)(int64_t B, int64_t N, int64_t 
   hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);
   hipLaunchKernelGGL(k_ll_series, dim3((unsigned)B), dim3(kWave), 0, s, N, K, (const double *)llp,
                      (const int32_t *)flag, ll);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// solve_lower / solve_upper with one right-hand side by chunk maps (long series of a small batch: the chains in two
+// levels).  lower: z_n = y_n - U_n F_n, F += W_n z_n; upper: the same walk from the far end with the roles of U and W
+// exchanged (internal.hpp:148-189).  Z may alias Y.  scratch: c2_internal_solve_chunks_doubles.
+extern "C" size_t C2TG_NAME(c2_internal_solve_chunks_doubles)(int64_t B, int64_t N, int64_t J) {
+  if (J < 1 || J > 8) return 0;
+  const size_t K = (size_t)((N + kRows - 1) / kRows), BK = (size_t)B * K;
+  return BK * (2 * (size_t)J * J + 3 * J) + (size_t)B * (K / kBlock + 2) * J + 8;
+}
+extern "C" int C2TG_NAME(c2_internal_solve_chunks)(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                                   const double *c, int64_t c_bs, const double *U, const double *W,
+                                                   const double *Y, double *Z, double *scratch, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t K = (N + kRows - 1) / kRows;
+#define C2TG_SOLVE(J_)                                                                                   \
+  case J_:                                                                                               \
+    if (lower) solve_chunks<J_, false>(B, N, K, t, t_bs, c, c_bs, U, W, Y, Z, scratch, s);              \
+    else solve_chunks<J_, true>(B, N, K, t, t_bs, c, c_bs, W, U, Y, Z, scratch, s);                     \
+    break;
+  switch (J) {
+    C2TG_SOLVE(1) C2TG_SOLVE(2) C2TG_SOLVE(3) C2TG_SOLVE(4) C2TG_SOLVE(5) C2TG_SOLVE(6) C2TG_SOLVE(7) C2TG_SOLVE(8)
+    default: return C2_ERR_UNSUPPORTED;
+  }
+#undef C2TG_SOLVE
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }

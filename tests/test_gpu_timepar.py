@@ -150,13 +150,14 @@ def test_timepar_factor_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     close(d2, d.cpu().numpy()); np.testing.assert_allclose(W2.cpu().numpy(), W.cpu().numpy(), rtol=1e-10, atol=1e-12)
 
 
-@pytest.mark.parametrize("J", [8, 4, 2])
-@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 131), (2, 4096), (9, 1000), (1, 30001), (2, 4100)])
+@pytest.mark.parametrize("J", [8, 7, 6, 4, 3, 2])
+@pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 131), (2, 4096), (9, 1000), (1, 30001), (2, 4100),
+                                 (3, 16500)])
 def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
-    """solve_lower / solve_upper with one right-hand side as chunked affine maps (k_tps_*): every row against the oracle,
-    out of place and in place, per-series and shared time grids."""
-    t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
-    t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+    """solve_lower / solve_upper with one right-hand side as chunked affine maps (k_tps_* at widths 8, 4, 2; from 16384
+    rows the chunk maps of c2_timepar_grad.hip with their two-level chain, at every width up to 8): every row against the
+    oracle, out of place and in place, per-series and shared time grids."""
+    t, c, a, U, V, y = wide_batch(B, N, J)
     W = np.empty_like(V); d = np.empty_like(a)
     for b in range(B):
         assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d[b], W[b]) == 0

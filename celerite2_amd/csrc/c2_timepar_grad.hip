@@ -65,7 +65,7 @@ namespace c2tg {
 using namespace c2;
 
 constexpr int kRows = C2TG_ROWS;   // rows per chunk
-constexpr int64_t kTwoLevelMin = 256;   // chunks per series from which the sequential chains over the chunks run in two levels
+constexpr int64_t kTwoLevelMin = 128;   // chunks per series from which the sequential chains over the chunks run in two levels
 constexpr int kBlock = 32;              // chunks per block of the upper level
 
 template <int J>

@@ -359,7 +359,7 @@ def test_newton_factor_takes_over_on_long_series_at_widths_4_and_2(ops, oracle, 
 
 @pytest.mark.parametrize("J,N,shared", [(2, 17000, True), (6, 16500, False), (8, 33000, True), (4, 40001, False)])
 def test_time_parallel_gradient_two_level_chains(ops, oracle, monkeypatch, J, N, shared):
-    """From 256 chunks per series every chain over the chunks runs in two levels (blocks of 32 chunks composed in
+    """From 128 chunks per series every chain over the chunks runs in two levels (blocks of 32 chunks composed in
     parallel): a small batch with a ragged last chunk and block, shared or per-series grids, one failed series -- the
     log-likelihoods, flags and all six gradients against the oracle."""
     B = 3

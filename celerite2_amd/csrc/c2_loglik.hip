@@ -966,8 +966,9 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
   // One series draws level at ~400 rows (J = 2), ~600 (J = 4, 6), ~800 (J = 8): 0.48 -> 0.25 ms at 768 rows, J = 2.
   const int64_t min_rows = J <= 2 ? 512 : (J >= 7 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768);
-  // (widths up to 4 keep winning a little further: 768 x 4096 at J = 4 2.97 -> 1.46 ms, 1024 x 4096 2.98 -> 2.44 ms)
-  return N >= min_rows && B * ((N + 63) / 64) <= (J <= 4 ? 2 : 1) * (int64_t)C2_TIMEPAR_GRAD_MAX_CHUNKS;
+  // (widths up to 4 would keep winning a little further -- 768 x 4096 at J = 4 2.97 -> 1.46 ms, 1024 x 4096 2.98 -> 2.44 ms
+  // -- but not by enough to move the limit)
+  return N >= min_rows && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
 }
 // widths 6 and 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it

@@ -970,11 +970,11 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // -- but not by enough to move the limit)
   return N >= min_rows && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
 }
-// widths 6 and 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
+// widths 1 .. 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it
 static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return false;
-  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it (widths 6, 8: every length; 4, 2: long series), 0 disables it
+  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it (every length; widths 4, 2: long series only), 0 disables it
   if (e && atoi(e) == 0) return false;
   // widths 4 and 2 have the composed linear-fractional maps of c2_timepar.hip, whose chain over the chunks is sequential:
   // the Newton iterations (chains in two levels) take over on long series -- J = 4: 1.67 -> 0.59 ms at 1e5 rows, 15.3 ->
@@ -1024,7 +1024,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
   if (capturing == hipStreamCaptureStatusNone && use_factor_iter(B, N, J)) {
-    // widths 6 / 8: d, W by Newton iterations on the chunk start states, z by the time-parallel solve, a reduction
+    // d, W by Newton iterations on the chunk start states, z by the chunk-map solve, a reduction
     const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {

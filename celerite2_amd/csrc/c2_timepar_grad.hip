@@ -25,7 +25,7 @@
 //
 // Also here, because they share the chunk machinery:
 //  * `factor` by NEWTON iterations on the chunk start states (k_newton_*; tools/proto/factor_newton.py) -- what the
-//    forward quantities above come from at widths 6 / 8 and on long series at widths 4 / 2;
+//    forward quantities above come from at every width but 4 / 2, and on long series there as well;
 //  * z = L^-1 y by affine chunk maps at any even width (k_solve_*), and the forward-only log-likelihood composed from
 //    the two (c2_internal_loglik_wide);
 //  * every chain over the chunks in TWO LEVELS from kTwoLevelMin chunks per series: blocks of kBlock chunks compose
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
   }
 }
 
-// ---- forward-only log-likelihood from d and z (widths 6, 8: factor by Newton iterations + solve) -----------------------------
+// ---- forward-only log-likelihood from d and z (factor by Newton iterations + chunk-map solve) ------------------------------
 __global__ __launch_bounds__(kWave) void k_ll_chunks(int64_t B, int64_t N, int64_t K, const double *__restrict__ d,
                                                      const double *__restrict__ z, double *__restrict__ llp) {
   const Geo G = chunk_of(B, N, K);
@@ -998,7 +998,7 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
-// ---- factor by Newton iterations on the chunk start states (widths 6, 8: no composable chunk maps in registers) -----------
+// ---- factor by Newton iterations on the chunk start states (widths 1 .. 8) --------------------------------------------------
 // Unknowns: X_k, the state entering chunk k (X_0 = 0).  Equations: X_{k+1} = f_k(X_k), f_k = the factor recursion
 // (forward.hpp:105-134) over the 64 rows of chunk k.  The Jacobian of f_k is a congruence, dX -> Phi_k dX Phi_k^T with
 // Phi_k = prod_n P_{n+1} (I - w_n u_n^T) (the closed-loop propagator of the underlying Kalman filter), so one Newton
@@ -1445,7 +1445,7 @@ extern "C" int C2TG_NAME(c2_internal_loglik_grad_timepar)(int64_t B, int64_t N, 
   }
 }
 
-// factor (d, W) by Newton iterations on the chunk start states (widths 6, 8).  work: c2_internal_factor_iter_doubles;
+// factor (d, W) by Newton iterations on the chunk start states (widths 1 .. 8).  work: c2_internal_factor_iter_doubles;
 // its first kNewtonMax + 2 words are the iteration words -- the caller launches its row-by-row kernel behind `*last_word`.
 constexpr int kNewtonMax = 8;
 extern "C" size_t C2TG_NAME(c2_internal_factor_iter_doubles)(int64_t B, int64_t N, int64_t J) {
@@ -1504,7 +1504,7 @@ extern "C" int C2TG_NAME(c2_internal_factor_iter)(int64_t B, int64_t N, int64_t 
   return C2_ERR_UNSUPPORTED;
 }
 
-// Forward-only log-likelihood for small batches of long series at widths 6 / 8: d, W by c2_factor (Newton iterations on the
+// Forward-only log-likelihood for small batches of long series (widths 1 .. 8): d, W by c2_factor (Newton iterations on the
 // chunk start states where the dispatch takes them), z by the time-parallel solve, a reduction.
 extern "C" size_t C2TG_NAME(c2_internal_loglik_wide_doubles)(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return 0;

@@ -890,7 +890,13 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
 }
 // Time-parallel GRADIENT (c2_timepar_grad.hip; widths 1 .. 8): small batches of long series.
 // C2_TIMEPAR_GRAD=1 forces it, =0 disables it.
-// compiled for chunks of 64 and of 32 rows; a handful of series (at most 4096 chunks of 64 rows) takes the shorter ones:
+#ifndef C2_TPG_ROWS16_MAX_ROWS
+#define C2_TPG_ROWS16_MAX_ROWS 4096
+#endif
+// compiled for chunks of 64, 32 and 16 rows; a handful of series (at most 4096 chunks of 64 rows) takes the shorter ones
+// -- 16 rows up to 4096 rows per series (one series of 4096 rows 0.92 -> 0.73 ms, 16 x 4096 0.96 -> 0.79 ms at J = 8), 32
+// rows beyond: chains of more than 256 chunks cost accuracy first (9000 rows: 1.3e-11 of the largest gradient entry against
+// 4e-12) and then time (one series of 1e5 rows 1.42 against 1.25 ms):
 // twice as many lanes busy, half the walk per lane -- one series of 4096 rows 1.33 -> 1.03 ms, of 1e5 rows 1.68 -> 1.25 ms,
 // 64 x 4096 1.42 -> 1.16 ms (J = 8); beyond, the longer chains cost more: 1e6 rows 3.8 vs 5.0 ms, 32 x 50000 2.4 vs 3.1 ms
 // (C2_TPG_ROWS=32|64 overrides)
@@ -913,40 +919,44 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
                                              c2_stream_t stream);
 C2_DECL_TPG(64)
 C2_DECL_TPG(32)
+C2_DECL_TPG(16)
 #undef C2_DECL_TPG
 extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N);
-static bool tpg_short_chunks(int64_t B, int64_t N) { return c2_internal_tpg_short_chunks(B, N) != 0; }
+// 0: chunks of 64 rows, 1: of 32, 2: of 16
 extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N) {
   const char *e = getenv("C2_TPG_ROWS");
-  if (e) return atoi(e) == 32;
-  return B * ((N + 63) / 64) <= 4096;
+  if (e) return atoi(e) == 16 ? 2 : (atoi(e) == 32 ? 1 : 0);
+  const int64_t k64 = B * ((N + 63) / 64);
+  if (k64 > 4096) return 0;
+  return N <= C2_TPG_ROWS16_MAX_ROWS ? 2 : 1;   // the shortest chunks while the chains stay short
 }
+#define C2_TPG_PICK(stem) (c2_internal_tpg_short_chunks(B, N) == 2 ? stem##16 : (c2_internal_tpg_short_chunks(B, N) == 1 ? stem##32 : stem##64))
 static size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J) {
-  return tpg_short_chunks(B, N) ? c2_internal_timepar_grad_doubles32(B, N, J) : c2_internal_timepar_grad_doubles64(B, N, J);
+  return C2_TPG_PICK(c2_internal_timepar_grad_doubles)(B, N, J);
 }
 static int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                            int64_t c_bs, const double *a, const double *U, const double *V,
                                            const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
                                            double *bV, double *by, int32_t *flag, double *work, c2_stream_t stream) {
-  return (tpg_short_chunks(B, N) ? c2_internal_loglik_grad_timepar32 : c2_internal_loglik_grad_timepar64)(
+  return C2_TPG_PICK(c2_internal_loglik_grad_timepar)(
       B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
 }
 static size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {
-  return tpg_short_chunks(B, N) ? c2_internal_factor_iter_doubles32(B, N, J) : c2_internal_factor_iter_doubles64(B, N, J);
+  return C2_TPG_PICK(c2_internal_factor_iter_doubles)(B, N, J);
 }
 static int c2_internal_factor_iter(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                    int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                                    int32_t *flag, double *work, const unsigned long long **last_word, c2_stream_t stream) {
-  return (tpg_short_chunks(B, N) ? c2_internal_factor_iter32 : c2_internal_factor_iter64)(
+  return C2_TPG_PICK(c2_internal_factor_iter)(
       B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, work, last_word, stream);
 }
 static size_t c2_internal_loglik_wide_doubles(int64_t B, int64_t N, int64_t J) {
-  return tpg_short_chunks(B, N) ? c2_internal_loglik_wide_doubles32(B, N, J) : c2_internal_loglik_wide_doubles64(B, N, J);
+  return C2_TPG_PICK(c2_internal_loglik_wide_doubles)(B, N, J);
 }
 static int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                    int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                    double *ll, int32_t *flag, double *work, c2_stream_t stream) {
-  return (tpg_short_chunks(B, N) ? c2_internal_loglik_wide32 : c2_internal_loglik_wide64)(B, N, J, t, t_bs, c, c_bs, a, U, V,
+  return C2_TPG_PICK(c2_internal_loglik_wide)(B, N, J, t, t_bs, c, c_bs, a, U, V,
                                                                                          y, ll, flag, work, stream);
 }
 #ifndef C2_TIMEPAR_GRAD_MIN_ROWS

@@ -1140,6 +1140,7 @@ extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N);
                                               const double *Y, double *Z, double *scratch, c2_stream_t stream);
 C2_DECL_SC(64)
 C2_DECL_SC(32)
+C2_DECL_SC(16)
 #undef C2_DECL_SC
 static bool solve_chunks_enabled() {
   const char *e = getenv("C2_TIMEPAR");   // the switch of the time-parallel solves: 0 keeps them row by row
@@ -1176,11 +1177,12 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &capturing);
     if (capturing == hipStreamCaptureStatusNone) {
-      const bool sh = c2_internal_tpg_short_chunks(B, N) != 0;
-      const size_t nd = sh ? c2_internal_solve_chunks_doubles32(B, N, J) : c2_internal_solve_chunks_doubles64(B, N, J);
+      const int sh = c2_internal_tpg_short_chunks(B, N);
+      const size_t nd = sh == 2 ? c2_internal_solve_chunks_doubles16(B, N, J)
+                                : (sh == 1 ? c2_internal_solve_chunks_doubles32(B, N, J) : c2_internal_solve_chunks_doubles64(B, N, J));
       void *tmp = nullptr;
       if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
-        int rc = (sh ? c2_internal_solve_chunks32 : c2_internal_solve_chunks64)(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V,
+        int rc = (sh == 2 ? c2_internal_solve_chunks16 : (sh == 1 ? c2_internal_solve_chunks32 : c2_internal_solve_chunks64))(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V,
                                                                                Y, Z, (double *)tmp, stream);
         if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
         return rc;

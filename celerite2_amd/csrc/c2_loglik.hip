@@ -897,9 +897,8 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
 // -- 16 rows up to 4096 rows per series (one series of 4096 rows 0.92 -> 0.73 ms, 16 x 4096 0.96 -> 0.79 ms at J = 8), 32
 // rows beyond: chains of more than 256 chunks cost accuracy first (9000 rows: 1.3e-11 of the largest gradient entry against
 // 4e-12) and then time (one series of 1e5 rows 1.42 against 1.25 ms):
-// twice as many lanes busy, half the walk per lane -- one series of 4096 rows 1.33 -> 1.03 ms, of 1e5 rows 1.68 -> 1.25 ms,
-// 64 x 4096 1.42 -> 1.16 ms (J = 8); beyond, the longer chains cost more: 1e6 rows 3.8 vs 5.0 ms, 32 x 50000 2.4 vs 3.1 ms
-// (C2_TPG_ROWS=32|64 overrides)
+// with 32 rows against 64: one series of 1e5 rows 1.68 -> 1.25 ms, 64 x 4096 1.42 -> 1.16 ms (J = 8); beyond 4096 chunks the
+// longer chains cost more: 1e6 rows 3.8 vs 5.0 ms, 32 x 50000 2.4 vs 3.1 ms  (C2_TPG_ROWS=16|32|64 overrides)
 #define C2_DECL_TPG(R_)                                                                                                    \
   extern "C" size_t c2_internal_timepar_grad_doubles##R_(int64_t B, int64_t N, int64_t J);                               \
   extern "C" int c2_internal_loglik_grad_timepar##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,     \

@@ -1137,7 +1137,8 @@ extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N);
   extern "C" size_t c2_internal_solve_chunks_doubles##R_(int64_t B, int64_t N, int64_t J);                          \
   extern "C" int c2_internal_solve_chunks##R_(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, \
                                               const double *c, int64_t c_bs, const double *U, const double *W,      \
-                                              const double *Y, double *Z, double *scratch, c2_stream_t stream);
+                                              const double *Y, double *Z, double *scratch, c2_stream_t stream,      \
+                                              int64_t nrhs, double *F);
 C2_DECL_SC(64)
 C2_DECL_SC(32)
 C2_DECL_SC(16)
@@ -1171,9 +1172,10 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
                                         stream);
     }
   }
-  if (SOLVE && nrhs == 1 && !F && J <= 8 && N >= 16384 && B * ((N + 63) / 64) <= 32768 && solve_chunks_enabled()) {
+  if (SOLVE && J <= 8 && N >= 16384 && B * nrhs * ((N + 63) / 64) <= 32768 && nrhs <= 64 && solve_chunks_enabled()) {
     // a small batch of LONG series: chunk maps with the chain over the chunks in two levels (c2_timepar_grad.hip; every
-    // width up to 8).  Scratch is a stream-ordered temporary; not inside graph captures.
+    // width up to 8), right-hand side by right-hand side, the workspace written on the way if asked for (one series of 1e5
+    // rows, 8 right-hand sides: 31 ms row by row).  Scratch is a stream-ordered temporary; not inside graph captures.
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &capturing);
     if (capturing == hipStreamCaptureStatusNone) {
@@ -1183,7 +1185,7 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
       void *tmp = nullptr;
       if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
         int rc = (sh == 2 ? c2_internal_solve_chunks16 : (sh == 1 ? c2_internal_solve_chunks32 : c2_internal_solve_chunks64))(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V,
-                                                                               Y, Z, (double *)tmp, stream);
+                                                                               Y, Z, (double *)tmp, stream, nrhs, F);
         if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
         return rc;
       }

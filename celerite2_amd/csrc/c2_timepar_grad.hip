@@ -133,13 +133,13 @@ struct RowIn {
 template <int J, bool WITH_U, bool WITH_V, bool REV = false>
 __device__ __forceinline__ void fetch_row(RowIn<J, WITH_U, WITH_V> &R, const Geo &G, int64_t N, int r, const double *tb,
                                           const double *Ub, const double *Vb, const double *Wb, const double *db,
-                                          const double *zb) {
+                                          const double *zb, int64_t zs = 1) {   // zs: stride of d / z (a column of Y)
   const int rc = r < G.len ? (r < 0 ? 0 : r) : (G.len > 0 ? G.len - 1 : 0);
   const int64_t pos = G.lo + rc, n = REV ? N - 1 - pos : pos;
   if constexpr (WITH_U) load_row<J>(Ub + n * J, R.u);
   if constexpr (WITH_V) load_row<J>(Vb + n * J, R.v);
   load_row<J>(Wb + n * J, R.w);
-  R.d = db[n]; R.z = zb[n];
+  R.d = db[n * zs]; R.z = zb[n * zs];
   const int64_t nn = REV ? (n > 0 ? n - 1 : n) : (n + 1 < N ? n + 1 : n);   // the next row of the walk
   const double t0 = tb[n], t1 = tb[nn];
   R.dt = REV ? t0 - t1 : t1 - t0;
@@ -699,16 +699,17 @@ __global__ __launch_bounds__(kWave) void k_finish_c(int64_t K, const double *__r
 // The recursion is affine in its state with the SAME propagator as above: F_{n+1} = P (I - w_n u_n^T) F_n + P w_n y_n,
 // z_n = y_n - u_n F_n (internal.hpp:135-145).  k_solve_maps: (Phi_k, g_k) of every chunk; k_solve_chain: the states the
 // chunks start from; k_solve_apply: z of every row.
-template <int J, bool REV = false>
+// ys: stride of y (1, or nrhs for one column of a row-major Y); PHI = false: g_k only (further columns of the same series)
+template <int J, bool REV = false, bool PHI = true>
 __global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                       const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
-                                                      const double *__restrict__ W, const double *__restrict__ y,
+                                                      const double *__restrict__ W, const double *__restrict__ y, int64_t ys,
                                                       double *__restrict__ Phi, double *__restrict__ gk) {
   const Geo G = chunk_of(B, N, K);
   double cj[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
-  const double *tb = t + G.b * t_bs, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
+  const double *tb = t + G.b * t_bs, *yb = y + G.b * N * ys, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
   double M[J][J], F[J];
 #pragma unroll
   for (int i = 0; i < J; ++i) {
@@ -717,10 +718,10 @@ __global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int6
     for (int j = 0; j < J; ++j) M[i][j] = i == j ? 1.0 : 0.0;
   }
   RowIn<J, true, false> cur, nxt;   // d <- y (unused), z <- y
-  fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
+  fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb, ys);
 #pragma unroll 1
   for (int r = 0; r < kRows; ++r) {
-    fetch_row<J, true, false, REV>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
+    fetch_row<J, true, false, REV>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb, ys);
     if (r < G.len) {
       double p[J], uf = 0.0;
 #pragma unroll
@@ -728,13 +729,15 @@ __global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int6
       const double zn = cur.z - uf;
 #pragma unroll
       for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]) * p[i];
+      if constexpr (PHI) {
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double um = 0.0;
+        for (int j = 0; j < J; ++j) {
+          double um = 0.0;
 #pragma unroll
-        for (int l = 0; l < J; ++l) um = fma(cur.u[l], M[l][j], um);
+          for (int l = 0; l < J; ++l) um = fma(cur.u[l], M[l][j], um);
 #pragma unroll
-        for (int i = 0; i < J; ++i) M[i][j] = fma(-cur.w[i], um, M[i][j]) * p[i];
+          for (int i = 0; i < J; ++i) M[i][j] = fma(-cur.w[i], um, M[i][j]) * p[i];
+        }
       }
     }
     cur = nxt;
@@ -743,8 +746,10 @@ __global__ __launch_bounds__(kWave) void k_solve_maps(int64_t B, int64_t N, int6
 #pragma unroll
     for (int i = 0; i < J; ++i) {
       gk[G.g * J + i] = F[i];
+      if constexpr (PHI) {
 #pragma unroll
-      for (int j = 0; j < J; ++j) Phi[G.g * (J * J) + i * J + j] = M[i][j];
+        for (int j = 0; j < J; ++j) Phi[G.g * (J * J) + i * J + j] = M[i][j];
+      }
     }
   }
 }
@@ -853,26 +858,42 @@ template <int J, bool REV = false>
 __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                        const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                        const double *__restrict__ W, const double *__restrict__ y,
-                                                       const double *__restrict__ Fst, double *__restrict__ z) {
+                                                       int64_t ys, const double *__restrict__ Fst, double *__restrict__ z,
+                                                       double *__restrict__ Fw, int64_t fs) {
+  // Fw (optional): this right-hand side's J entries of the reference's workspace rows, Fw[row fs + j] -- the state of the row
+  // before its decay, in both directions (internal.hpp:140-141, 179-180: update_workspace precedes Fn = p Fn)
   const Geo G = chunk_of(B, N, K);
   double cj[J], F[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) { cj[j] = c[G.b * c_bs + j]; F[j] = G.len > 0 ? Fst[G.g * J + j] : 0.0; }
-  const double *tb = t + G.b * t_bs, *yb = y + G.b * N, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
-  double *zb = z + G.b * N;
+  const double *tb = t + G.b * t_bs, *yb = y + G.b * N * ys, *Ub = U + G.b * N * J, *Wb = W + G.b * N * J;
+  double *zb = z + G.b * N * ys;
+  double *fb = Fw ? Fw + G.b * N * fs : nullptr;
   RowIn<J, true, false> cur, nxt;
-  fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb);
+  fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb, ys);
+  if (fb && G.len > 0 && G.lo == 0) {   // the first row of the walk carries no state
+#pragma unroll
+    for (int i = 0; i < J; ++i) fb[(REV ? N - 1 : 0) * fs + i] = 0.0;
+  }
 #pragma unroll 1
   for (int r = 0; r < kRows; ++r) {
-    fetch_row<J, true, false, REV>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb);
+    fetch_row<J, true, false, REV>(nxt, G, N, r + 1, tb, Ub, nullptr, Wb, yb, yb, ys);
     if (r < G.len) {
       double uf = 0.0;
 #pragma unroll
       for (int j = 0; j < J; ++j) uf = fma(cur.u[j], F[j], uf);
       const double zn = cur.z - uf;
-      zb[REV ? N - 1 - (G.lo + r) : G.lo + r] = zn;
+      const int64_t pos = G.lo + r, n = REV ? N - 1 - pos : pos;
+      zb[n * ys] = zn;
 #pragma unroll
-      for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]) * exp_decay(-cj[i] * cur.dt);
+      for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]);
+      if (fb && pos + 1 < N) {   // the state of the next row of the walk, before its decay
+        const int64_t nn = REV ? n - 1 : n + 1;
+#pragma unroll
+        for (int i = 0; i < J; ++i) fb[nn * fs + i] = F[i];
+      }
+#pragma unroll
+      for (int i = 0; i < J; ++i) F[i] *= exp_decay(-cj[i] * cur.dt);
     }
     cur = nxt;
   }
@@ -900,11 +921,17 @@ __global__ __launch_bounds__(kWave) void k_ll_series(int64_t N, int64_t K, const
 // z = L^-1 y by chunk maps (k_solve_*); scratch: B K (2 J^2 + 3 J) + B (K / kBlock + 1) J doubles
 template <int J, bool REV = false>
 static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
-                         const double *U, const double *W, const double *y, double *z, double *scratch, hipStream_t s) {
+                         const double *U, const double *W, const double *y, double *z, double *scratch, hipStream_t s,
+                         int64_t ys = 1, bool with_phi = true, double *Fw = nullptr, int64_t fs = 0) {
+  // ys > 1: one column of a row-major Y / Z; with_phi = false: Phi (and its block products) of an earlier call with the
+  // same series are still in the scratch
   const size_t BK = (size_t)B * K;
   double *Phi = scratch, *gk = Phi + BK * J * J, *Fst = gk + BK * J;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
-  hipLaunchKernelGGL((k_solve_maps<J, REV>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, Phi, gk);
+  if (with_phi)
+    hipLaunchKernelGGL((k_solve_maps<J, REV, true>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, ys, Phi, gk);
+  else
+    hipLaunchKernelGGL((k_solve_maps<J, REV, false>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, ys, Phi, gk);
   if (K >= kTwoLevelMin) {
     const int64_t NB = (K + kBlock - 1) / kBlock;
     double *Psi = Fst + BK * J, *Gam = Psi + BK * J * J, *Fb = Gam + BK * J;
@@ -918,8 +945,8 @@ static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64
     hipLaunchKernelGGL((k_solve_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)Phi,
                        (const double *)gk, Fst);
   }
-  hipLaunchKernelGGL((k_solve_apply<J, REV>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y,
-                     (const double *)Fst, z);
+  hipLaunchKernelGGL((k_solve_apply<J, REV>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, ys,
+                     (const double *)Fst, z, Fw, fs);
 }
 
 struct Layout {
@@ -1536,7 +1563,7 @@ extern "C" int C2TG_NAME(c2_internal_loglik_wide)(int64_t B, int64_t N, int64_t 
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
-// solve_lower / solve_upper with one right-hand side by chunk maps (long series of a small batch: the chains in two
+// solve_lower / solve_upper (every right-hand side, optional workspace) by chunk maps (long series of a small batch: the chains in two
 // levels).  lower: z_n = y_n - U_n F_n, F += W_n z_n; upper: the same walk from the far end with the roles of U and W
 // exchanged (internal.hpp:148-189).  Z may alias Y.  scratch: c2_internal_solve_chunks_doubles.
 extern "C" size_t C2TG_NAME(c2_internal_solve_chunks_doubles)(int64_t B, int64_t N, int64_t J) {
@@ -1546,13 +1573,21 @@ extern "C" size_t C2TG_NAME(c2_internal_solve_chunks_doubles)(int64_t B, int64_t
 }
 extern "C" int C2TG_NAME(c2_internal_solve_chunks)(int lower, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
                                                    const double *c, int64_t c_bs, const double *U, const double *W,
-                                                   const double *Y, double *Z, double *scratch, c2_stream_t stream) {
+                                                   const double *Y, double *Z, double *scratch, c2_stream_t stream,
+                                                   int64_t nrhs, double *F) {
+  // nrhs columns of row-major Y, Z (and of the optional workspace F[n, k J + j]: the
+  // reference's J x nrhs state is column-major, internal.hpp:127-128), one after the other: the chunk
+  // propagators Phi do not depend on the column and are computed with the first one
   hipStream_t s = (hipStream_t)stream;
   const int64_t K = (N + kRows - 1) / kRows;
-#define C2TG_SOLVE(J_)                                                                                   \
-  case J_:                                                                                               \
-    if (lower) solve_chunks<J_, false>(B, N, K, t, t_bs, c, c_bs, U, W, Y, Z, scratch, s);              \
-    else solve_chunks<J_, true>(B, N, K, t, t_bs, c, c_bs, W, U, Y, Z, scratch, s);                     \
+#define C2TG_SOLVE(J_)                                                                                                   \
+  case J_:                                                                                                               \
+    for (int64_t k = 0; k < nrhs; ++k) {                                                                                 \
+      if (lower) solve_chunks<J_, false>(B, N, K, t, t_bs, c, c_bs, U, W, Y + k, Z + k, scratch, s, nrhs, k == 0,       \
+                                         F ? F + k * J_ : nullptr, (int64_t)J_ * nrhs);                                 \
+      else solve_chunks<J_, true>(B, N, K, t, t_bs, c, c_bs, W, U, Y + k, Z + k, scratch, s, nrhs, k == 0,              \
+                                  F ? F + k * J_ : nullptr, (int64_t)J_ * nrhs);                                        \
+    }                                                                                                                    \
     break;
   switch (J) {
     C2TG_SOLVE(1) C2TG_SOLVE(2) C2TG_SOLVE(3) C2TG_SOLVE(4) C2TG_SOLVE(5) C2TG_SOLVE(6) C2TG_SOLVE(7) C2TG_SOLVE(8)

@@ -201,7 +201,17 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
             close(gf, gc.cpu().numpy(), tol=1e-9, floor=floor)
 
 
-@pytest.mark.parametrize("seed", list(range(30)))
+def _extra_seeds():
+    """C2_FUZZ_EXTRA=base:count adds seeds base .. base+count-1 to the time-parallel sweep (stress runs on the GPU box)."""
+    import os
+    e = os.environ.get("C2_FUZZ_EXTRA")
+    if not e:
+        return []
+    base, count = (int(x) for x in e.split(":"))
+    return list(range(base, base + count))
+
+
+@pytest.mark.parametrize("seed", list(range(30)) + _extra_seeds())
 def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
     """The gradient parallel along time and the Newton factor (c2_timepar_grad.hip) forced on random shapes: series
     lengths around the chunk length (64) and its multiples, widths 1 .. 8, shared grids / rates, unpaired rates, a
@@ -211,7 +221,11 @@ def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
     B = int(rng.choice([1, 2, 3, 5, 9, 70]))
     N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 449, 640, 1000, 2100]))
     J = int(rng.choice([8, 7, 6, 5, 4, 3, 2, 1]))
+    rows = [None, "16", "32", "64"][seed % 4]   # the dispatcher's own chunk length, and each one forced
+    if seed >= 30 and B < 70 and rng.random() < 0.3:
+        N = int(rng.choice([2500, 4096, 4100, 7000]))
     t, c, a, U, V, y = problem(rng, B, N, J)
+    if rows: monkeypatch.setenv("C2_TPG_ROWS", rows)
     if rng.random() < 0.4:
         c = c * rng.uniform(0.8, 1.25, c.shape)
     if N > 70 and rng.random() < 0.4:

@@ -790,14 +790,16 @@ def test_general_matmul_batched(ops, oracle, monkeypatch, J, nrhs, N, M, tile):
 @pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 64, 64), (8, 1, 128, 129), (8, 1, 1000, 300), (8, 1, 70, 2000), (4, 2, 513, 511),
                                         (8, 4, 300, 257), (5, 3, 190, 640), (16, 1, 200, 200), (11, 2, 130, 65),
                                         (1, 1, 65, 1), (2, 4, 1, 200), (8, 1, 4096, 4096), (8, 1, 4500, 5000),
-                                        (4, 2, 3000, 2600), (8, 4, 2100, 2049), (16, 1, 900, 2300), (6, 1, 9000, 70000)])
+                                        (4, 2, 3000, 2600), (8, 4, 2100, 2049), (16, 1, 900, 2300), (6, 1, 9000, 70000),
+                                        (8, 8, 300, 257), (7, 5, 2500, 2300), (16, 5, 400, 2100), (3, 11, 130, 70)])
 @pytest.mark.parametrize("chunks", ["1", "0"])
 def test_general_matmul_row_tiles(ops, oracle, monkeypatch, J, nrhs, N, M, chunks):
     """c2_general_tile.hip (a wavefront per series, 64 rows of either grid per pass) on shapes around its tile sizes:
     grids of very different density (many output tiles per state tile and the reverse), ties that fall on tile
     boundaries, outputs before / after / between the input rows only, runs of identical times, a series whose outputs
     stop early (F rows beyond stay untouched) -- Z and the F workspace against the sequential-merge oracle.  Series of
-    2048 rows and more in a small batch are cut into chunks along time (chunks = "0": one wavefront per series)."""
+    2048 rows and more in a small batch are cut into chunks along time (chunks = "0": one wavefront per series); more
+    right-hand sides than one tile holds (4; 2 at widths above 8) run as several tiles on small batches."""
     if chunks == "0" and M < 2048:
         pytest.skip("not a chunked shape")
     monkeypatch.setenv("C2_GENERAL_CHUNKS", chunks)

@@ -190,6 +190,43 @@ def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
 
 
+@pytest.mark.parametrize("rows", [None, "16", "64"])
+@pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 3), (2, 17000, 5, 8), (1, 16384, 2, 2), (3, 16411, 6, 1)])
+def test_chunk_map_solves_with_several_right_hand_sides_and_workspace(ops, oracle, monkeypatch, B, N, J, nrhs, rows):
+    """solve_lower / solve_upper on a small batch of long series by chunk maps, right-hand side by right-hand side
+    (c2_internal_solve_chunks*), with and without the workspace F of the drop-in (internal.hpp:140-141, 179-180): every
+    row of Z and F against the oracle and against the row-by-row kernels, out of place and in place."""
+    t, c, a, U, V, y = wide_batch(B, N, J)
+    W = np.empty_like(V); d = np.empty_like(a)
+    for b in range(B):
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d[b], W[b]) == 0
+    rng = np.random.default_rng(N + J)
+    Y = np.ascontiguousarray(y[:, :, None] * rng.uniform(0.5, 1.5, (1, 1, nrhs)) + 0.1 * rng.standard_normal((B, N, nrhs)))
+    if rows: monkeypatch.setenv("C2_TPG_ROWS", rows)
+    td, cd, Ud, Wd, Yd = dev(t, c, U, W, Y)
+    for name in ("solve_lower", "solve_upper"):
+        want = np.empty_like(Y); wantF = np.empty((B, N, J * nrhs))
+        for b in range(B):
+            zb = Y[b].copy()
+            getattr(oracle, name)(t[b], c[b], U[b], W[b], Y[b], zb, wantF[b])
+            want[b] = zb
+        tolz = dict(rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
+        tolf = dict(rtol=1e-10, atol=1e-12 * max(1.0, np.abs(wantF).max()))
+        monkeypatch.setenv("C2_TIMEPAR", "1")
+        got = getattr(ops, name)(td, cd, Ud, Wd, Yd)
+        np.testing.assert_allclose(got.cpu().numpy(), want, **tolz)
+        got2, F2 = getattr(ops, name)(td, cd, Ud, Wd, Yd, workspace=True)
+        np.testing.assert_allclose(got2.cpu().numpy(), want, **tolz)
+        np.testing.assert_allclose(F2.cpu().numpy().reshape(B, N, J * nrhs), wantF, **tolf)
+        Zin = Yd.clone()
+        got3 = getattr(ops, name)(td, cd, Ud, Wd, Zin, Z=Zin)      # in place
+        np.testing.assert_allclose(got3.cpu().numpy(), want, **tolz)
+        monkeypatch.setenv("C2_TIMEPAR", "0")
+        rowsZ, rowsF = getattr(ops, name)(td, cd, Ud, Wd, Yd, workspace=True)
+        np.testing.assert_allclose(got2.cpu().numpy(), rowsZ.cpu().numpy(), **tolz)
+        np.testing.assert_allclose(F2.cpu().numpy(), rowsF.cpu().numpy(), **tolf)
+
+
 @pytest.mark.parametrize("J", [8, 7, 6, 5, 4, 3, 2, 1])
 @pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 128), (7, 700), (2, 4096), (70, 300), (1, 20000)])
 def test_timepar_gradient_matches_oracle(ops, oracle, monkeypatch, B, N, J):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-op measurements on one MI355X: HIP-event time of each batched device op at
 B series x N=4096 x J=8 and the algorithmic-byte rate (each input read once, each output written once).
-Usage: python tools/bench_ops.py [B [substring-of-op-name]]   -> markdown table on stdout."""
+Usage: [C2_BENCH_N=rows] [C2_BENCH_J=width] python tools/bench_ops.py [B [substring-of-op-name]]   -> markdown table on stdout."""
 import os
 import sys
 
@@ -24,7 +24,7 @@ def timed(fn, reps=5, warm=2):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-    N, J = 4096, 8
+    N, J = int(os.environ.get("C2_BENCH_N", 4096)), int(os.environ.get("C2_BENCH_J", 8))
     dev = "cuda"
     t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
     f64 = dict(dtype=torch.float64, device=dev)

@@ -915,7 +915,17 @@ extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   extern "C" int c2_internal_loglik_wide##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,             \
                                              const double *c, int64_t c_bs, const double *a, const double *U,            \
                                              const double *V, const double *y, double *ll, int32_t *flag, double *work,  \
-                                             c2_stream_t stream);
+                                             c2_stream_t stream);                                                        \
+  extern "C" size_t c2_internal_factor_rev_timepar_doubles##R_(int64_t B, int64_t N, int64_t J);                         \
+  extern "C" int c2_internal_factor_rev_timepar##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,      \
+                                                    const double *c, int64_t c_bs, const double *U, const double *V,     \
+                                                    const double *d, const double *W, const double *bd, const double *bW, \
+                                                    double *bt, double *bc, double *ba, double *bU, double *bV,          \
+                                                    double *work, c2_stream_t stream);                                   \
+  extern "C" size_t c2_internal_s_rows_doubles##R_(int64_t B, int64_t N, int64_t J);                                     \
+  extern "C" int c2_internal_s_rows##R_(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, \
+                                        int64_t c_bs, const double *d, const double *W, const int32_t *flag, double *Sw, \
+                                        double *scratch, c2_stream_t stream);
 C2_DECL_TPG(64)
 C2_DECL_TPG(32)
 C2_DECL_TPG(16)
@@ -1148,6 +1158,57 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                              int32_t *flag, int allow_timepar, c2_stream_t stream) {
   return c2_internal_factor_fused_ws(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, allow_timepar, nullptr, stream);
+}
+// factor_rev on a small batch of long series (widths 1 .. 8): the reverse pass of the time-parallel gradient with the
+// adjoints of d, W handed in (c2_timepar_grad.hip, run_factor_rev); the S workspace is not read -- the states are replayed
+// from d, W.  One series of 1e5 rows, J = 8: 73 ms row by row.  C2_TIMEPAR_GRAD=0 disables it.
+extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                           int64_t c_bs, const double *U, const double *d, const double *W, const double *bd,
+                                           const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV,
+                                           c2_stream_t stream) {
+  if (J < 1 || J > 8 || N < 2048 || B * ((N + 63) / 64) > C2_TIMEPAR_GRAD_MAX_CHUNKS) return C2_ERR_UNSUPPORTED;
+  const char *e = getenv("C2_TIMEPAR_GRAD");
+  if (e && atoi(e) == 0) return C2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &capturing);
+  if (capturing != hipStreamCaptureStatusNone) return C2_ERR_UNSUPPORTED;   // a stream-ordered temporary below
+  const size_t nd = C2_TPG_PICK(c2_internal_factor_rev_timepar_doubles)(B, N, J);
+  void *tmp = nullptr;
+  if (nd == 0 || hipMallocAsync(&tmp, nd * sizeof(double), s) != hipSuccess) {
+    (void)hipGetLastError();
+    return C2_ERR_UNSUPPORTED;
+  }
+  int rc = C2_TPG_PICK(c2_internal_factor_rev_timepar)(B, N, J, t, t_bs, c, c_bs, U, U, d, W, bd, bW, bt, bc, ba, bU, bV,
+                                                       (double *)tmp, stream);
+  if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+  return rc;
+}
+// factor WITH the S workspace of the drop-in on a small batch of long series (widths 1 .. 8): d, W by the Newton iterations
+// on the chunk start states, then the S rows -- a linear recurrence once d, W are known -- by chunks (k_s_rows of
+// c2_timepar_grad.hip).  One series of 1e5 rows, J = 8: 71 ms row by row.  C2_ERR_UNSUPPORTED: not this shape.
+extern "C" int c2_internal_factor_states_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                                 const double *c, int64_t c_bs, const double *a, const double *U,
+                                                 const double *V, double *d, double *W, double *S, int32_t *flag,
+                                                 c2_stream_t stream) {
+  if (J < 1 || J > 8 || N < 2048 || B * ((N + 63) / 64) > 32768 || d == a || W == V) return C2_ERR_UNSUPPORTED;
+  const char *e = getenv("C2_FACTOR_ITER");
+  if (e && atoi(e) == 0) return C2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &capturing);
+  if (capturing != hipStreamCaptureStatusNone) return C2_ERR_UNSUPPORTED;   // stream-ordered temporaries below
+  const size_t nd = C2_TPG_PICK(c2_internal_s_rows_doubles)(B, N, J);
+  void *tmp = nullptr;
+  if (nd == 0 || hipMallocAsync(&tmp, nd * sizeof(double), s) != hipSuccess) {
+    (void)hipGetLastError();
+    return C2_ERR_UNSUPPORTED;
+  }
+  int rc = c2_internal_factor_fused_ws(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, /*Newton iterations*/ 2, nullptr, stream);
+  if (rc == C2_OK)
+    rc = C2_TPG_PICK(c2_internal_s_rows)(B, N, J, t, t_bs, c, c_bs, d, W, flag, S, (double *)tmp, stream);
+  if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+  return rc;
 }
 
 

@@ -1362,6 +1362,10 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
                              int64_t c_bs, const double *a, const double *U, const double *V, double *d, double *W,
                              int32_t *flag, int allow_timepar, c2_stream_t stream);
 
+extern "C" int c2_internal_factor_states_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                                 const double *c, int64_t c_bs, const double *a, const double *U,
+                                                 const double *V, double *d, double *W, double *S, int32_t *flag,
+                                                 c2_stream_t stream);
 int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
               const double *a, const double *U, const double *V, double *d, double *W, double *S, int32_t *flag,
               c2_stream_t stream) {
@@ -1370,6 +1374,10 @@ int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (!S)  // no workspace requested: the tuned forward kernel of the fused log-likelihood doubles as factor
     return c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, /*time-parallel allowed*/ 1, stream);
   hipStream_t s = (hipStream_t)stream;
+  {   // a small batch of long series: Newton iterations for d, W, the S rows by chunks
+    const int e = c2_internal_factor_states_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, S, flag, stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
+  }
   if ((J == 2 || J == 4 || J == 8 || J == 16) && ((uintptr_t)S) % 16 == 0) {
     // d, W, flag from the tuned fused kernel, then the S rows by a chain-free replay (store-bound)
     // (with S the row-by-row kernel: the reverse-mode chain that asks for S is checked element by element at 1e-12)
@@ -1436,6 +1444,10 @@ int c2_factor_rev_acc(int64_t B, int64_t N, int64_t J, const double *t, int64_t 
   return check_launch();
 }
 
+extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                           int64_t c_bs, const double *U, const double *d, const double *W, const double *bd,
+                                           const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV,
+                                           c2_stream_t stream);
 int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                   const double *a, const double *U, const double *V, const double *d, const double *W,
                   const double *S, const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
@@ -1443,6 +1455,10 @@ int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs
   (void)a; (void)V;  // unused by the reference as well (reverse.hpp:29-30)
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !U || !d || !W || !S || !bd || !bW || !bt || !bc || !ba || !bU || !bV) return C2_ERR_INVALID;
+  {   // a small batch of long series: parallel along time
+    const int e = c2_internal_factor_rev_long(B, N, J, t, t_bs, c, c_bs, U, d, W, bd, bW, bt, bc, ba, bU, bV, stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
+  }
   // the segment-replay kernel of the fused gradient, with the caller's S rows as checkpoints (c2_loglik.hip)
   return c2_internal_factor_rev_replay(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, stream);
 }

@@ -346,10 +346,12 @@ __global__ __launch_bounds__(kWave) void k_starts_apply(int64_t N, int64_t K, co
 // (bS, bF): adjoint of the state entering row n+1 on entry, of the state entering row n on exit.  p: decay between the
 // two rows (1 behind the last row).  SRC: with the sources of the log-likelihood (d ll/d z = -z/d, d ll/d d).
 struct RowOut { double bz, bd; };
-template <int J, bool SRC, bool OUT>
+// EXT: external sources instead (factor_rev, reverse.hpp:26-85): bde = adjoint of d_n, bwe = adjoint of w_n handed in.
+template <int J, bool SRC, bool OUT, bool EXT = false>
 __device__ __forceinline__ RowOut adjoint_row(double (&bS)[Dim<J>::NS], double (&bF)[J], const double (&p)[J],
                                               const double (&u)[J], const double (&w)[J], double d, double z, double rd,
-                                              double (&g2)[J], double (&btau)[J]) {
+                                              double (&g2)[J], double (&btau)[J], double bde = 0.0,
+                                              const double *bwe = nullptr) {
 #pragma unroll
   for (int i = 0; i < J; ++i) {
 #pragma unroll
@@ -371,10 +373,17 @@ __device__ __forceinline__ RowOut adjoint_row(double (&bS)[Dim<J>::NS], double (
   RowOut o;
   o.bz = wbF - (SRC ? zd : 0.0);
   o.bd = -wg - zd * wbF - (SRC ? 0.5 * (rd - zd * zd) : 0.0);
+  if constexpr (EXT) {
+    double wb = 0.0;
+#pragma unroll
+    for (int i = 0; i < J; ++i) wb = fma(w[i], bwe[i], wb);
+    o.bd += bde - rd * wb;
+  }
   double hb[J];   // btau / 2
 #pragma unroll
   for (int i = 0; i < J; ++i) {
-    const double bv = fma(2.0, g[i], zd * bF[i]);          // bV_n = bw / d
+    double bv = fma(2.0, g[i], zd * bF[i]);          // bV_n = bw / d
+    if constexpr (EXT) bv = fma(rd, bwe[i], bv);
     if (OUT) g2[i] = bv;
     btau[i] = -bv - o.bd * u[i];
     hb[i] = 0.5 * btau[i];
@@ -393,11 +402,14 @@ __device__ __forceinline__ RowOut adjoint_row(double (&bS)[Dim<J>::NS], double (
 // One lane per (chunk, sweep): blockIdx.y is the sweep, so a small batch still spreads over J + 1 times as many
 // wavefronts as it has chunks / 64 (one series of 4096 rows: 9 wavefronts instead of 1 walking 9 sweeps in turn).
 // map[g][s * NST ...]: result (bS, bF) of sweep s (s < J: from bF_end = e_s; s = J: from zero, with the sources).
-template <int J>
+// EXT: the sources of sweep J are the adjoints bde (of d), bwe (of W) handed in, and no z couples the two states.
+template <int J, bool EXT = false>
 __global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                 const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                 const double *__restrict__ d, const double *__restrict__ W,
-                                                const double *__restrict__ z, double *__restrict__ map) {
+                                                const double *__restrict__ z, double *__restrict__ map,
+                                                const double *__restrict__ bde = nullptr,
+                                                const double *__restrict__ bwe = nullptr) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST, MAPR = Dim<J>::MAPR;
   const Geo G = chunk_of(B, N, K);
   const int sweep = blockIdx.y;
@@ -421,8 +433,18 @@ __global__ __launch_bounds__(kWave) void k_maps(int64_t B, int64_t N, int64_t K,
       const double rd = 1.0 / cur.d;
 #pragma unroll
       for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
-      if (sweep < J) (void)adjoint_row<J, false, false>(bS, bF, p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
-      else (void)adjoint_row<J, true, false>(bS, bF, p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+      if constexpr (EXT) {
+        if (sweep < J) (void)adjoint_row<J, false, false>(bS, bF, p, cur.u, cur.w, cur.d, 0.0, rd, g2, btau);
+        else {
+          const int64_t n = G.b * N + G.lo + r;
+          double be[J];
+          load_row<J>(bwe + n * J, be);
+          (void)adjoint_row<J, false, false, true>(bS, bF, p, cur.u, cur.w, cur.d, 0.0, rd, g2, btau, bde[n], be);
+        }
+      } else {
+        if (sweep < J) (void)adjoint_row<J, false, false>(bS, bF, p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+        else (void)adjoint_row<J, true, false>(bS, bF, p, cur.u, cur.w, cur.d, cur.z, rd, g2, btau);
+      }
     }
     cur = nxt;
   }
@@ -551,7 +573,8 @@ __global__ __launch_bounds__(kWave) void k_chain(int64_t K, const double *__rest
 
 // ---- the sweep that writes the gradients --------------------------------------------------------------------------------
 // sf: lane-major record of the states entering the rows of a chunk: sf[((wave * 64 + r) * NST + e) * 64 + lane].
-template <int J>
+// EXT: factor_rev -- sources bde, bwe as in k_maps, no F state, no by.
+template <int J, bool EXT = false>
 __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
                                                  const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                  const double *__restrict__ V, const double *__restrict__ d,
@@ -560,15 +583,17 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
                                                  const int32_t *__restrict__ flag, double *__restrict__ sf,
                                                  double *__restrict__ dT, double *__restrict__ bcp,
                                                  double *__restrict__ ba, double *__restrict__ bU,
-                                                 double *__restrict__ bV, double *__restrict__ by) {
+                                                 double *__restrict__ bV, double *__restrict__ by,
+                                                 const double *__restrict__ bde = nullptr,
+                                                 const double *__restrict__ bwe = nullptr) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
   const Geo G = chunk_of(B, N, K);
   double cj[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
   const double *tb = t + G.b * t_bs, *db = d + G.b * N, *zb = z + G.b * N;
-  const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J, *Vb = V + G.b * N * J;
-  double *bab = ba + G.b * N, *byb = by + G.b * N, *bUb = bU + G.b * N * J, *bVb = bV + G.b * N * J, *dTb = dT + G.b * N;
+  const double *Wb = W + G.b * N * J, *Ub = U + G.b * N * J, *Vb = EXT ? Ub : V + G.b * N * J;   // (EXT: V unused, reverse.hpp:29-30)
+  double *bab = ba + G.b * N, *byb = EXT ? nullptr : by + G.b * N, *bUb = bU + G.b * N * J, *bVb = bV + G.b * N * J, *dTb = dT + G.b * N;
   double *sfw = sf + (size_t)G.wave * kRows * NST * kWave + G.lane;
   const bool failed = flag[G.b] != 0;
   const double nan = __builtin_nan("");
@@ -580,7 +605,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
 #pragma unroll
     for (int e = 0; e < NS; ++e) Sn[e] = G.len > 0 ? s[e] : 0.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) Fn[j] = G.len > 0 ? s[NS + j] : 0.0;
+    for (int j = 0; j < J; ++j) Fn[j] = (G.len > 0 && !EXT) ? s[NS + j] : 0.0;
   }
   {
     RowIn<J, false, false> cur, nxt;
@@ -595,7 +620,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
 #pragma unroll
         for (int j = 0; j < J; ++j) o[(size_t)(NS + j) * kWave] = Fn[j];
         double p[J];
-        absorb<J>(Sn, Fn, cur.w, cur.d, cur.z);
+        absorb<J>(Sn, Fn, cur.w, cur.d, EXT ? 0.0 : cur.z);
         if (G.lo + r + 1 < N) {
 #pragma unroll
           for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
@@ -612,7 +637,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
 #pragma unroll
     for (int q = 0; q < NS; ++q) bS[q] = G.len > 0 ? e[q] : 0.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) { bF[j] = G.len > 0 ? e[NS + j] : 0.0; bcj[j] = 0.0; }
+    for (int j = 0; j < J; ++j) { bF[j] = (G.len > 0 && !EXT) ? e[NS + j] : 0.0; bcj[j] = 0.0; }
   }
   RowIn<J, true, true> cur, nxt;
   fetch_row<J, true, true>(cur, G, N, kRows - 1, tb, Ub, Vb, Wb, db, zb);
@@ -629,7 +654,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
       for (int e = 0; e < NS; ++e) Sm[e] = o[(size_t)e * kWave];
 #pragma unroll
       for (int j = 0; j < J; ++j) Fm[j] = o[(size_t)(NS + j) * kWave];
-      const double dn = cur.d, zn = cur.z, rd = 1.0 / dn, dt = cur.dt;
+      const double dn = cur.d, zn = EXT ? 0.0 : cur.z, rd = 1.0 / dn, dt = cur.dt;
       // the decay between rows n and n+1 (internal.hpp:238-243 / reverse.hpp:70-76): p_i bp_i = 2 sum_j bS'(i,j)
       // S_{n+1}(i,j) + bF'_i F_{n+1,i} with the states ENTERING row n+1 (dt = 0 behind the last row)
       double bdt = 0.0;
@@ -643,7 +668,14 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
         p[i] = exp_decay(-cj[i] * dt);
       }
       if (n + 1 >= N) bdt = 0.0;
-      const RowOut ro = adjoint_row<J, true, true>(bS, bF, p, cur.u, cur.w, dn, zn, rd, g2, btau);
+      RowOut ro;
+      if constexpr (EXT) {
+        double be[J];
+        load_row<J>(bwe + (G.b * N + n) * J, be);
+        ro = adjoint_row<J, false, true, true>(bS, bF, p, cur.u, cur.w, dn, zn, rd, g2, btau, bde[G.b * N + n], be);
+      } else {
+        ro = adjoint_row<J, true, true>(bS, bF, p, cur.u, cur.w, dn, zn, rd, g2, btau);
+      }
 #pragma unroll
       for (int e = 0; e < NS; ++e) Sn[e] = Sm[e];
 #pragma unroll
@@ -652,7 +684,15 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
       double bu[J];
 #pragma unroll
       for (int i = 0; i < J; ++i) {
-        double s = fma(-ro.bz, Fn[i], -ro.bd * fma(-dn, cur.w[i], cur.v[i]));
+        double s;
+        if constexpr (EXT) {   // tau_n = S_n u_n from the replayed state
+          double tau = 0.0;
+#pragma unroll
+          for (int jj = 0; jj < J; ++jj) tau = fma(Sn[sym(J, i, jj)], cur.u[jj], tau);
+          s = -ro.bd * tau;
+        } else {
+          s = fma(-ro.bz, Fn[i], -ro.bd * fma(-dn, cur.w[i], cur.v[i]));
+        }
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) s = fma(Sn[sym(J, i, jj)], btau[jj], s);
         bu[i] = failed ? nan : s;
@@ -661,7 +701,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
       store_row<J>(bUb + n * J, bu);
       store_row<J>(bVb + n * J, g2);
       bab[n] = failed ? nan : ro.bd;
-      byb[n] = failed ? nan : ro.bz;
+      if constexpr (!EXT) byb[n] = failed ? nan : ro.bz;
       dTb[n] = bdt;
     }
     cur = nxt;
@@ -1434,6 +1474,129 @@ static void adjoint_chain_two_level(int64_t B, int64_t K, const double *map, dou
                      (const double *)Rho, (const double *)Dstart, (const double *)Fst, ends);
 }
 
+// ---- the S workspace of factor (forward.hpp:106-123) from d, W, parallel along time -------------------------------------
+// Given d, W the state obeys a linear recurrence with a diagonal transition, S' = P (S + d w^T w) P: the chunk start
+// states come from k_local + k_starts (the replay of the gradient pass, z := d unused), and one lane per chunk writes its
+// rows.  Row n of the workspace is the half-decayed state the reference saves between its two scalings (forward.hpp:115-
+// 123): p_i (S + d w^T w)_{ij} at the flat index i + j J, row 0 zero.
+template <int J>
+__global__ __launch_bounds__(kWave) void k_s_rows(int64_t B, int64_t N, int64_t K, const double *__restrict__ t, int64_t t_bs,
+                                                  const double *__restrict__ c, int64_t c_bs, const double *__restrict__ d,
+                                                  const double *__restrict__ W, const double *__restrict__ start,
+                                                  double *__restrict__ Sw) {
+  constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
+  const Geo G = chunk_of(B, N, K);
+  double cj[J], S[NS];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
+#pragma unroll
+  for (int e = 0; e < NS; ++e) S[e] = G.len > 0 ? start[G.g * NST + e] : 0.0;
+  const double *tb = t + G.b * t_bs, *db = d + G.b * N, *Wb = W + G.b * N * J;
+  double *sb = Sw + G.b * N * (int64_t)(J * J);
+  if (G.len > 0 && G.lo == 0) {
+    double zero[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) zero[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) store_row<J>(sb + j * J, zero);
+  }
+  RowIn<J, false, false> cur, nxt;
+  fetch_row<J, false, false>(cur, G, N, 0, tb, nullptr, nullptr, Wb, db, db);
+#pragma unroll 1
+  for (int r = 0; r < kRows; ++r) {
+    fetch_row<J, false, false>(nxt, G, N, r + 1, tb, nullptr, nullptr, Wb, db, db);
+    const int64_t n = G.lo + r;
+    if (r < G.len && n + 1 < N) {
+      double p[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+        const double dw = cur.d * cur.w[i];
+#pragma unroll
+        for (int j = i; j < J; ++j) S[sidx(J, i, j)] = fma(dw, cur.w[j], S[sidx(J, i, j)]);
+      }
+      double *o = sb + (n + 1) * (int64_t)(J * J);
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double col[J];
+#pragma unroll
+        for (int i = 0; i < J; ++i) col[i] = p[i] * S[sym(J, i, j)];
+        store_row<J>(o + j * J, col);
+      }
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = i; j < J; ++j) S[sidx(J, i, j)] *= p[i] * p[j];
+    }
+    cur = nxt;
+  }
+}
+template <int J>
+static void run_s_rows(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *d,
+                       const double *W, const int32_t *flag, double *Sw, double *scratch, hipStream_t s) {
+  constexpr size_t NST = Dim<J>::NST;
+  const int64_t K = (N + kRows - 1) / kRows;
+  const size_t BK = (size_t)B * K;
+  double *loc = scratch, *start = loc + BK * NST, *llp = start + BK * NST, *ll = llp + BK, *pre = ll + B;
+  const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
+  hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, d, W, d, loc, llp);
+  if (K >= kTwoLevelMin) {
+    const int64_t NBs = (K + kWave - 1) / kWave;
+    hipLaunchKernelGGL((k_starts_blocks<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
+                       (const double *)loc, pre);
+    hipLaunchKernelGGL((k_starts_apply<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, N, K, (const double *)pre,
+                       (const double *)llp, flag, start, ll);
+  } else {
+    hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs, (const double *)loc,
+                       (const double *)llp, flag, start, ll);
+  }
+  hipLaunchKernelGGL((k_s_rows<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, d, W, (const double *)start, Sw);
+}
+// ---- factor_rev (reverse.hpp:26-85) parallel along time ------------------------------------------------------------------
+// The reverse pass of the gradient above with the adjoints of d and W handed in (EXT) instead of the log-likelihood's
+// sources: the states of the rows replayed from the chunk start states (k_local + k_starts on d, W), the chunk maps
+// (k_maps<J, true>: Phi_k from the homogeneous sweeps, the response to the sources from sweep J), the chain, k_final.
+// Scratch: the gradient's layout (its d, W, z pieces unused) + one flag word per series.
+template <int J>
+static int run_factor_rev(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *U,
+                          const double *V, const double *d, const double *W, const double *bde, const double *bwe, double *bt,
+                          double *bc, double *ba, double *bU, double *bV, double *work, hipStream_t s) {
+  const Layout L = layout<J>(B, N);
+  const int64_t K = (N + kRows - 1) / kRows;
+  int32_t *flag = reinterpret_cast<int32_t *>(work + L.total);
+  double *ll = work + L.z;   // (unused pieces of the layout: the log-likelihood k_starts writes, the F junk)
+  if (hipMemsetAsync(flag, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return C2_ERR_HIP;
+  const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
+  hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, d, W, d, work + L.loc, work + L.llp);
+  if (K >= kTwoLevelMin) {
+    const int64_t NBs = (K + kWave - 1) / kWave;
+    hipLaunchKernelGGL((k_starts_blocks<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
+                       (const double *)(work + L.loc), work + L.map);
+    hipLaunchKernelGGL((k_starts_apply<J>), dim3((unsigned)(B * NBs)), dim3(kWave), 0, s, N, K,
+                       (const double *)(work + L.map), (const double *)(work + L.llp), (const int32_t *)flag,
+                       work + L.start, ll);
+  } else {
+    hipLaunchKernelGGL((k_starts<J>), dim3((unsigned)B), dim3(kWave), 0, s, N, K, t, t_bs, c, c_bs,
+                       (const double *)(work + L.loc), (const double *)(work + L.llp), (const int32_t *)flag,
+                       work + L.start, ll);
+  }
+  hipLaunchKernelGGL((k_maps<J, true>), dim3(cgrid.x, (unsigned)(J + 1)), dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, d,
+                     W, d, work + L.map, bde, bwe);
+  if (K >= kTwoLevelMin)
+    adjoint_chain_two_level<J>(B, K, work + L.map, work + L.ends, work + L.sf, s);
+  else
+    hipLaunchKernelGGL((k_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, (const double *)(work + L.map),
+                       work + L.ends);
+  hipLaunchKernelGGL((k_final<J, true>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, V, d, W, d,
+                     (const double *)(work + L.start), (const double *)(work + L.ends), (const int32_t *)flag,
+                     work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, (double *)nullptr, bde, bwe);
+  hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, s, B, N,
+                     (const double *)(work + L.dT), (const int32_t *)flag, bt);
+  hipLaunchKernelGGL((k_finish_c<J>), dim3((unsigned)(B * J)), dim3(kWave), 0, s, K, (const double *)(work + L.bcp),
+                     (const int32_t *)flag, bc);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
 }  // namespace c2tg
 
 using namespace c2tg;
@@ -1560,6 +1723,58 @@ extern "C" int C2TG_NAME(c2_internal_loglik_wide)(int64_t B, int64_t N, int64_t 
   hipLaunchKernelGGL(k_ll_chunks, cgrid, dim3(kWave), 0, s, B, N, K, (const double *)d, (const double *)z, llp);
   hipLaunchKernelGGL(k_ll_series, dim3((unsigned)B), dim3(kWave), 0, s, N, K, (const double *)llp,
                      (const int32_t *)flag, ll);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+extern "C" size_t C2TG_NAME(c2_internal_factor_rev_timepar_doubles)(int64_t B, int64_t N, int64_t J) {
+  size_t n = 0;
+  switch (J) {
+    case 1: n = layout<1>(B, N).total; break;
+    case 2: n = layout<2>(B, N).total; break;
+    case 3: n = layout<3>(B, N).total; break;
+    case 4: n = layout<4>(B, N).total; break;
+    case 5: n = layout<5>(B, N).total; break;
+    case 6: n = layout<6>(B, N).total; break;
+    case 7: n = layout<7>(B, N).total; break;
+    case 8: n = layout<8>(B, N).total; break;
+    default: return 0;
+  }
+  return n + (size_t)(B + 1) / 2 + 2;
+}
+extern "C" int C2TG_NAME(c2_internal_factor_rev_timepar)(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
+                                                         const double *c, int64_t c_bs, const double *U, const double *V,
+                                                         const double *d, const double *W, const double *bd,
+                                                         const double *bW, double *bt, double *bc, double *ba, double *bU,
+                                                         double *bV, double *work, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+#define C2TG_FR(J_) \
+  case J_: return run_factor_rev<J_>(B, N, t, t_bs, c, c_bs, U, V, d, W, bd, bW, bt, bc, ba, bU, bV, work, s);
+  switch (J) {
+    C2TG_FR(1) C2TG_FR(2) C2TG_FR(3) C2TG_FR(4) C2TG_FR(5) C2TG_FR(6) C2TG_FR(7) C2TG_FR(8)
+    default: return C2_ERR_UNSUPPORTED;
+  }
+#undef C2TG_FR
+}
+extern "C" size_t C2TG_NAME(c2_internal_s_rows_doubles)(int64_t B, int64_t N, int64_t J) {
+  if (J < 1 || J > 8) return 0;
+  const size_t K = (size_t)((N + kRows - 1) / kRows), BK = (size_t)B * K, NST = (size_t)(J * (J + 1) / 2 + J);
+  return BK * (2 * NST + 1) + ((int64_t)K >= kTwoLevelMin ? BK * 2 * NST : 0) + (size_t)B + 8;
+}
+extern "C" int C2TG_NAME(c2_internal_s_rows)(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                             int64_t c_bs, const double *d, const double *W, const int32_t *flag, double *Sw,
+                                             double *scratch, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (J) {
+    case 1: run_s_rows<1>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 2: run_s_rows<2>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 3: run_s_rows<3>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 4: run_s_rows<4>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 5: run_s_rows<5>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 6: run_s_rows<6>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 7: run_s_rows<7>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    case 8: run_s_rows<8>(B, N, t, t_bs, c, c_bs, d, W, flag, Sw, scratch, s); break;
+    default: return C2_ERR_UNSUPPORTED;
+  }
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

@@ -190,6 +190,80 @@ def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
 
 
+@pytest.mark.parametrize("rows", [None, "32", "64"])
+@pytest.mark.parametrize("B,N,J", [(1, 2048, 8), (2, 5000, 7), (3, 2100, 6), (1, 9000, 5), (2, 4097, 4), (1, 2500, 3),
+                                   (2, 3000, 2), (1, 2049, 1), (1, 20000, 8), (1, 9000, 4)])
+def test_factor_with_s_workspace_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows):
+    """factor WITH the S workspace of the drop-in on a small batch of long series: d, W by the Newton iterations, the S
+    rows (half-decayed states, forward.hpp:115-123) by chunks (k_s_rows) -- every element against the oracle and against
+    the row-by-row kernels (C2_FACTOR_ITER=0); a failed series keeps its flag."""
+    t, c, a, U, V, y = wide_batch(B, N, J)
+    if B > 1:
+        a[B - 1, N // 2] = -1.0
+    if rows: monkeypatch.setenv("C2_TPG_ROWS", rows)
+    args = dev(t, c, a, U, V)
+    monkeypatch.delenv("C2_FACTOR_ITER", raising=False)
+    d, W, S, flag = ops.factor(*args, workspace=True)
+    monkeypatch.setenv("C2_FACTOR_ITER", "0")
+    d0, W0, S0, flag0 = ops.factor(*args, workspace=True)
+    fl = flag.cpu().numpy()
+    assert np.array_equal(fl != 0, flag0.cpu().numpy() != 0)
+    for b in range(B):
+        do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J * J))
+        bad = oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So) != 0
+        assert bad == (fl[b] != 0)
+        if bad:
+            continue
+        close(d[b], do)
+        np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
+        tol = dict(rtol=1e-10, atol=1e-12 * max(1.0, np.abs(So).max()))
+        np.testing.assert_allclose(S[b].cpu().numpy().reshape(N, J * J), So, **tol)
+        np.testing.assert_allclose(S[b].cpu().numpy(), S0[b].cpu().numpy(), **tol)
+
+
+@pytest.mark.parametrize("rows", [None, "32", "64"])
+@pytest.mark.parametrize("B,N,J", [(1, 2048, 8), (2, 5000, 7), (3, 2100, 6), (1, 9000, 5), (2, 4097, 4), (1, 2500, 3),
+                                   (2, 3000, 2), (1, 2049, 1), (1, 20000, 8), (1, 9000, 4)])
+def test_factor_rev_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows):
+    """factor_rev (reverse.hpp:26-85) on a small batch of long series: the reverse pass of the time-parallel gradient with
+    the adjoints of d and W handed in -- all five outputs against the oracle and against the row-by-row kernel
+    (C2_TIMEPAR_GRAD=0), each relative to its largest entry; shared time grid and rates as well."""
+    t, c, a, U, V, y = wide_batch(B, N, J)
+    rng = np.random.default_rng(3 * N + J)
+    d = np.empty_like(a); W = np.empty_like(V); S = np.empty((B, N, J * J))
+    for b in range(B):
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d[b], W[b], S[b]) == 0
+    bd = rng.standard_normal((B, N)); bW = rng.standard_normal((B, N, J))
+    want = [np.empty((B, N)), np.empty((B, J)), np.empty((B, N)), np.empty((B, N, J)), np.empty((B, N, J))]
+    for b in range(B):
+        outs = [np.zeros(N), np.zeros(J), np.zeros(N), np.zeros((N, J)), np.zeros((N, J))]
+        oracle.factor_rev(t[b], c[b], a[b], U[b], V[b], d[b], W[b], S[b], bd[b], bW[b], *outs)
+        for w, o in zip(want, outs):
+            w[b] = o
+    if rows: monkeypatch.setenv("C2_TPG_ROWS", rows)
+    args = dev(t, c, a, U, V, d, W, S.reshape(B, N, J, J), bd, bW)
+    monkeypatch.delenv("C2_TIMEPAR_GRAD", raising=False)
+    got = ops.factor_rev(*args)
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "0")
+    rowsgot = ops.factor_rev(*args)
+    monkeypatch.delenv("C2_TIMEPAR_GRAD", raising=False)
+    for g, r, w in zip(got, rowsgot, want):
+        gclose(g, w)
+        gclose(g, r.cpu().numpy())
+    if B > 1:   # one time grid and one set of rates for the whole batch (the problem of series 0, other adjoints)
+        rep = lambda x: np.ascontiguousarray(np.tile(x[0], (B,) + (1,) * (x.ndim - 1)))
+        a0, U0, V0, d0, W0, S0 = rep(a), rep(U), rep(V), rep(d), rep(W), rep(S)
+        for b in range(B):
+            outs = [np.zeros(N), np.zeros(J), np.zeros(N), np.zeros((N, J)), np.zeros((N, J))]
+            oracle.factor_rev(t[0], c[0], a0[b], U0[b], V0[b], d0[b], W0[b], S0[b], bd[b], bW[b], *outs)
+            for w, o in zip(want, outs):
+                w[b] = o
+        args = dev(t[0].copy(), c[0].copy(), a0, U0, V0, d0, W0, S0.reshape(B, N, J, J), bd, bW)
+        got = ops.factor_rev(*args)
+        for g, w in zip(got, want):      # (bt, bc stay per series)
+            gclose(g, w)
+
+
 @pytest.mark.parametrize("rows", [None, "16", "64"])
 @pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 3), (2, 17000, 5, 8), (1, 16384, 2, 2), (3, 16411, 6, 1)])
 def test_chunk_map_solves_with_several_right_hand_sides_and_workspace(ops, oracle, monkeypatch, B, N, J, nrhs, rows):

@@ -1322,6 +1322,11 @@ extern "C" int c2_internal_sweepK_rev(int lower, int solve, int64_t B, int64_t N
                                       int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
                                       const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
                                       double *bc, double *bU, double *bV, double *bY, c2_stream_t stream);
+extern "C" int c2_internal_sweep_rev_long(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs,
+                                          const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *U,
+                                          const double *V, const double *Y, const double *Z, const double *F,
+                                          const double *bZ, double *bt, double *bc, double *bU, double *bV, double *bY,
+                                          c2_stream_t stream);
 template <bool LOWER, bool SOLVE>
 static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
                             const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
@@ -1331,6 +1336,17 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z || !F || !bZ || !bt || !bc || !bU || !bV || !bY)
     return C2_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
+  {   // a small batch of LONG series: the opposite sweep (parallel along time for these shapes) + a pass local to the rows
+    const char *ev = getenv("C2_REV_LONG");   // 0: keep the row-by-row kernels (A/B runs)
+    const bool on = !(ev && ev[0] == '0') && N >= 16384 && B <= 0xffff;
+    const bool fits = SOLVE ? (J <= 8 && nrhs <= 64 && B * nrhs * ((N + 63) / 64) <= 32768 && solve_chunks_enabled())
+                            : (B * ((nrhs + 3) / 4) * group_size(J) < (int64_t)kWave * 2048);
+    if (on && fits) {
+      const int e = c2_internal_sweep_rev_long(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F,
+                                               bZ, bt, bc, bU, bV, bY, stream);
+      if (e != C2_ERR_UNSUPPORTED) return e;
+    }
+  }
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
     return c2_internal_sweep1_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU,
                                   bV, bY, stream);

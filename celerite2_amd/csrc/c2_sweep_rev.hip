@@ -227,3 +227,139 @@ extern "C" int c2_internal_sweepK_rev(int lower, int solve, int64_t B, int64_t N
 #undef C2_SKR1
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
+
+// ---- the four reverse sweeps on a small batch of LONG series --------------------------------------------------------------
+// Row by row a series of 1e5 rows takes 16-18 ms per right-hand side.  The adjoint state of the forward sweep IS the state
+// of the opposite sweep applied to bZ (the reverse of solve_lower is a solve_upper, internal.hpp:191-303 read against
+// 148-189): with H_n the adjoint of the state entering step n BEFORE its decay,
+//     bY = sweep'(bZ)  and  H_n = s F'_m          (F': workspace of that sweep, m = n -/+ 1, s = -1 solve / +1 product)
+// and everything else is local to a row:
+//     bB_n = s p o sum_k X_n[k] F_n[:, k]         (X = bY for solves, bZ for products)
+//     bA_m = p o sum_k Q_m[k] H_n[:, k]           (Q = Z for solves, Y for products)
+//     bp   = p o sum_k F_n[:, k] H_n[:, k] ;  bc += dt bp ;  phi = sum_j c_j bp_j ;  bt_n -/+= phi, bt_m +/-= phi.
+// So: one opposite sweep WITH its workspace -- parallel along time for these shapes (chunk maps of c2_timepar_grad.hip for
+// the solves, c2_scan.hip for the products) -- and one pass with a thread per row (k_rev_rows) plus a reduction for bc.
+namespace c2rl {
+using namespace c2;
+constexpr int kRowsPerBlock = 256;
+
+template <bool LOWER, bool SOLVE>
+__global__ __launch_bounds__(kRowsPerBlock) void k_rev_rows(int64_t N, int J, int64_t nrhs, const double *__restrict__ t,
+                                                            int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                            const double *__restrict__ X, const double *__restrict__ Q,
+                                                            const double *__restrict__ F, const double *__restrict__ Fa,
+                                                            double *__restrict__ bt, double *__restrict__ outA,
+                                                            double *__restrict__ outB, double *__restrict__ part) {
+  __shared__ double red[kRowsPerBlock / kWave];
+  const int64_t b = blockIdx.y, r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x;
+  const bool row = r < N;
+  const bool va = row && (LOWER ? r >= 1 : r + 1 < N);        // the step AT this row
+  const bool vb = row && (LOWER ? r + 1 < N : r >= 1);        // the step whose partner row this is
+  const int64_t ma = LOWER ? r - 1 : r + 1, nb = LOWER ? r + 1 : r - 1;
+  const double *tb = t + b * t_bs, *cb = c + b * c_bs;
+  const double s = SOLVE ? -1.0 : 1.0;
+  const double dta = va ? -fabs(tb[r] - tb[ma]) : 0.0, dtb = vb ? -fabs(tb[nb] - tb[r]) : 0.0;
+  const int64_t JK = (int64_t)J * nrhs;
+  const double *Fr = F + (b * N + (row ? r : 0)) * JK, *Fn = F + (b * N + (vb ? nb : 0)) * JK;
+  const double *Hr = Fa + (b * N + (va ? ma : 0)) * JK;      // s H of the step at this row
+  const double *Hb = Fa + (b * N + (row ? r : 0)) * JK;      // s H of the step whose partner this row is
+  const double *Xr = X + (b * N + (row ? r : 0)) * nrhs, *Qr = Q + (b * N + (row ? r : 0)) * nrhs;
+  double fa = 0.0, fb = 0.0;
+  for (int j = 0; j < J; ++j) {
+    const double cj = cb[j];
+    double oa = 0.0, ob = 0.0, bpa = 0.0;
+    if (va) {
+      const double p = exp_decay(cj * dta);
+      double acc = 0.0, bp = 0.0;
+      for (int64_t k = 0; k < nrhs; ++k) {
+        const double f = Fr[j + J * k];
+        acc = fma(Xr[k], f, acc);
+        bp = fma(f, Hr[j + J * k], bp);
+      }
+      oa = s * p * acc;
+      bpa = s * p * bp;
+      fa = fma(cj, bpa, fa);
+    }
+    if (vb) {
+      const double p = exp_decay(cj * dtb);
+      double acc = 0.0, bp = 0.0;
+      for (int64_t k = 0; k < nrhs; ++k) {
+        const double h = Hb[j + J * k];
+        acc = fma(Qr[k], h, acc);
+        bp = fma(Fn[j + J * k], h, bp);
+      }
+      ob = s * p * acc;
+      fb = fma(cj, s * p * bp, fb);
+    }
+    if (row) {
+      outA[(b * N + r) * J + j] = oa;
+      outB[(b * N + r) * J + j] = ob;
+    }
+    // bc_j: the block's rows in a fixed tree
+    double v = dta * bpa;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
+    __syncthreads();
+    if (threadIdx.x % kWave == 0) red[threadIdx.x / kWave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double sum = 0.0;
+      for (int w = 0; w < kRowsPerBlock / kWave; ++w) sum += red[w];
+      part[((int64_t)b * gridDim.x + blockIdx.x) * J + j] = sum;
+    }
+  }
+  if (row) bt[b * N + r] = LOWER ? fb - fa : fa - fb;
+}
+__global__ void k_rev_bc(int64_t B, int J, int64_t nblk, const double *__restrict__ part, double *__restrict__ bc) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * J) return;
+  const int64_t b = g / J;
+  const int j = (int)(g % J);
+  double sum = 0.0;
+  for (int64_t q = 0; q < nblk; ++q) sum += part[(b * nblk + q) * J + j];
+  bc[g] = sum;
+}
+}  // namespace c2rl
+
+// lower / solve select the op (solve_lower_rev, solve_upper_rev, matmul_lower_rev, matmul_upper_rev); the caller has
+// checked that the opposite sweep takes its time-parallel form for this shape.  Not inside graph captures (temporaries).
+extern "C" int c2_internal_sweep_rev_long(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs,
+                                          const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *U,
+                                          const double *V, const double *Y, const double *Z, const double *F,
+                                          const double *bZ, double *bt, double *bc, double *bU, double *bV, double *bY,
+                                          c2_stream_t stream) {
+  using namespace c2rl;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &capturing);
+  if (capturing != hipStreamCaptureStatusNone || (!solve && bY == bZ)) return C2_ERR_UNSUPPORTED;
+  const int64_t nblk = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+  const size_t nws = (size_t)B * N * J * nrhs, npart = (size_t)B * nblk * J;
+  void *tmp = nullptr;
+  if (hipMallocAsync(&tmp, (nws + npart) * sizeof(double), s) != hipSuccess) {
+    (void)hipGetLastError();
+    return C2_ERR_UNSUPPORTED;
+  }
+  double *Fa = (double *)tmp, *part = Fa + nws;
+  int rc;
+  if (solve) rc = lower ? c2_solve_upper(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, bZ, bY, Fa, stream)
+                        : c2_solve_lower(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, bZ, bY, Fa, stream);
+  else rc = lower ? c2_matmul_upper(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, bZ, bY, Fa, 1, stream)
+                  : c2_matmul_lower(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, bZ, bY, Fa, 1, stream);
+  if (rc == C2_OK) {
+    const dim3 grid((unsigned)nblk, (unsigned)B);
+    const double *X = solve ? bY : bZ, *Q = solve ? Z : Y;
+    double *outA = lower ? bU : bV, *outB = lower ? bV : bU;
+#define C2_RL(LO, SO)                                                                                                    \
+  hipLaunchKernelGGL((k_rev_rows<LO, SO>), grid, dim3(kRowsPerBlock), 0, s, N, (int)J, nrhs, t, t_bs, c, c_bs, X, Q, F,  \
+                     (const double *)Fa, bt, outA, outB, part)
+    if (lower) { if (solve) C2_RL(true, true); else C2_RL(true, false); }
+    else       { if (solve) C2_RL(false, true); else C2_RL(false, false); }
+#undef C2_RL
+    hipLaunchKernelGGL(k_rev_bc, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)J, nblk,
+                       (const double *)part, bc);
+    if (hipGetLastError() != hipSuccess) rc = C2_ERR_HIP;
+  }
+  if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+  return rc;
+}

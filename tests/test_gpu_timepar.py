@@ -264,6 +264,45 @@ def test_factor_rev_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows)
             gclose(g, w)
 
 
+@pytest.mark.parametrize("name", ["solve_lower_rev", "solve_upper_rev", "matmul_lower_rev", "matmul_upper_rev"])
+@pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 1), (2, 17000, 5, 3), (1, 16384, 2, 8), (3, 16411, 6, 2), (1, 20000, 16, 2)])
+def test_reverse_sweeps_on_long_series(ops, oracle, monkeypatch, name, B, N, J, nrhs):
+    """The four reverse sweeps (internal.hpp:191-303) on a small batch of long series: the opposite sweep applied to bZ,
+    with its workspace, plus a pass local to the rows (c2_internal_sweep_rev_long) -- all five outputs against the oracle
+    and against the row-by-row kernels (C2_REV_LONG=0), each relative to its largest entry."""
+    solve = name.startswith("solve")
+    if solve and J > 8:
+        pytest.skip("the chunk-map solves cover widths up to 8")
+    t, c, a, U, V, y = wide_batch(B, N, J) if J <= 8 else dense.synthetic_batch(B, N, J)
+    rng = np.random.default_rng(N + 7 * J + nrhs)
+    if solve:
+        W = np.empty_like(V); d = np.empty_like(a)
+        for b in range(B):
+            assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d[b], W[b]) == 0
+    else:
+        W = V
+    Y = rng.standard_normal((B, N, nrhs)); bZ = rng.standard_normal((B, N, nrhs))
+    Z = np.empty_like(Y); F = np.empty((B, N, J * nrhs))
+    want = [np.zeros((B, N)), np.zeros((B, J)), np.zeros((B, N, J)), np.zeros((B, N, J)), np.zeros((B, N, nrhs))]
+    fwd = getattr(oracle, name[:-4])
+    for b in range(B):
+        zb = Y[b].copy() if solve else np.zeros((N, nrhs))
+        fwd(t[b], c[b], U[b], W[b], Y[b], zb, F[b])
+        Z[b] = zb
+        outs = [np.zeros(N), np.zeros(J), np.zeros((N, J)), np.zeros((N, J)), np.zeros((N, nrhs))]
+        getattr(oracle, name)(t[b], c[b], U[b], W[b], Y[b], Z[b], F[b], bZ[b], *outs)
+        for w, o in zip(want, outs):
+            w[b] = o
+    args = dev(t, c, U, W, Y, Z, F.reshape(B, N, J, nrhs), bZ)
+    monkeypatch.delenv("C2_REV_LONG", raising=False)
+    got = getattr(ops, name)(*args)
+    monkeypatch.setenv("C2_REV_LONG", "0")
+    rows = getattr(ops, name)(*args)
+    for g, r, w in zip(got, rows, want):
+        gclose(g, w)
+        gclose(g, r.cpu().numpy())
+
+
 @pytest.mark.parametrize("rows", [None, "16", "64"])
 @pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 3), (2, 17000, 5, 8), (1, 16384, 2, 2), (3, 16411, 6, 1)])
 def test_chunk_map_solves_with_several_right_hand_sides_and_workspace(ops, oracle, monkeypatch, B, N, J, nrhs, rows):

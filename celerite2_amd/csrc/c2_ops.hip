@@ -1143,6 +1143,23 @@ C2_DECL_SC(64)
 C2_DECL_SC(32)
 C2_DECL_SC(16)
 #undef C2_DECL_SC
+// shortest series the long-series forms of the solves with F / several right-hand sides and of the reverse sweeps take
+// (C2_LONG_MIN_ROWS overrides; measured below)
+static int64_t long_min_rows() {
+  const char *e = getenv("C2_LONG_MIN_ROWS");
+  const int64_t v = e ? atoll(e) : 0;
+  return v >= 128 ? v : 512;
+}
+// shapes the chunk-map solves of c2_timepar_grad.hip take (tools/bench_ops.py, J = 8, ms row by row -> chunk maps):
+// 1 x 1024 0.13 -> 0.05, 1 x 4096 + F 0.60 -> 0.06, 64 x 1024 0.13 -> 0.05, 512 x 2048 + F 0.32 -> 0.14, 256 x 4096 + F
+// 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
+// 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken below 16384 rows
+static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
+  if (J > 8 || nrhs > 64) return false;
+  const int64_t k64 = B * nrhs * ((N + 63) / 64);
+  if (N >= 16384) return k64 <= 32768;
+  return N >= (nrhs == 1 ? long_min_rows() : 2 * long_min_rows()) && k64 <= 16384;
+}
 static bool solve_chunks_enabled() {
   const char *e = getenv("C2_TIMEPAR");   // the switch of the time-parallel solves: 0 keeps them row by row
   return !(e && atoi(e) == 0);
@@ -1172,9 +1189,9 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
                                         stream);
     }
   }
-  if (SOLVE && J <= 8 && N >= 16384 && B * nrhs * ((N + 63) / 64) <= 32768 && nrhs <= 64 && solve_chunks_enabled()) {
-    // a small batch of LONG series: chunk maps with the chain over the chunks in two levels (c2_timepar_grad.hip; every
-    // width up to 8), right-hand side by right-hand side, the workspace written on the way if asked for (one series of 1e5
+  if (SOLVE && solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled()) {
+    // a small batch of series of 512 rows and more: chunk maps, from 8192 rows with the chain over the chunks in two levels
+    // (c2_timepar_grad.hip; every width up to 8), right-hand side by right-hand side, the workspace written on the way if asked for (one series of 1e5
     // rows, 8 right-hand sides: 31 ms row by row).  Scratch is a stream-ordered temporary; not inside graph captures.
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &capturing);
@@ -1338,8 +1355,11 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   hipStream_t s = (hipStream_t)stream;
   {   // a small batch of LONG series: the opposite sweep (parallel along time for these shapes) + a pass local to the rows
     const char *ev = getenv("C2_REV_LONG");   // 0: keep the row-by-row kernels (A/B runs)
-    const bool on = !(ev && ev[0] == '0') && N >= 16384 && B <= 0xffff;
-    const bool fits = SOLVE ? (J <= 8 && nrhs <= 64 && B * nrhs * ((N + 63) / 64) <= 32768 && solve_chunks_enabled())
+    // the per-row pass costs ~0.5 ns per row and series, the row-by-row kernel ~0.17 us per row whatever the batch:
+    // 64 x 1024 0.18 -> 0.07 ms, 256 x 4096 0.87 -> 0.58, 512 x 1024 0.20 -> 0.33 (not taken)
+    const bool on = !(ev && ev[0] == '0') && B <= 0xffff &&
+                    (N >= 16384 || (SOLVE && N >= long_min_rows() && B <= 256 && N >= 8 * B));
+    const bool fits = SOLVE ? (solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled())
                             : (B * ((nrhs + 3) / 4) * group_size(J) < (int64_t)kWave * 2048);
     if (on && fits) {
       const int e = c2_internal_sweep_rev_long(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F,

@@ -265,9 +265,10 @@ def test_factor_rev_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows)
 
 
 @pytest.mark.parametrize("name", ["solve_lower_rev", "solve_upper_rev", "matmul_lower_rev", "matmul_upper_rev"])
-@pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 1), (2, 17000, 5, 3), (1, 16384, 2, 8), (3, 16411, 6, 2), (1, 20000, 16, 2)])
+@pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 1), (2, 17000, 5, 3), (1, 16384, 2, 8), (3, 16411, 6, 2), (1, 20000, 16, 2),
+                                        (1, 600, 8, 1), (3, 1100, 6, 2), (40, 1024, 4, 1), (2, 4096, 8, 8)])
 def test_reverse_sweeps_on_long_series(ops, oracle, monkeypatch, name, B, N, J, nrhs):
-    """The four reverse sweeps (internal.hpp:191-303) on a small batch of long series: the opposite sweep applied to bZ,
+    """The four reverse sweeps (internal.hpp:191-303) on a small batch of long series (the solves: from 512 rows): the opposite sweep applied to bZ,
     with its workspace, plus a pass local to the rows (c2_internal_sweep_rev_long) -- all five outputs against the oracle
     and against the row-by-row kernels (C2_REV_LONG=0), each relative to its largest entry."""
     solve = name.startswith("solve")
@@ -304,9 +305,10 @@ def test_reverse_sweeps_on_long_series(ops, oracle, monkeypatch, name, B, N, J, 
 
 
 @pytest.mark.parametrize("rows", [None, "16", "64"])
-@pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 3), (2, 17000, 5, 8), (1, 16384, 2, 2), (3, 16411, 6, 1)])
+@pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 3), (2, 17000, 5, 8), (1, 16384, 2, 2), (3, 16411, 6, 1),
+                                        (1, 600, 8, 1), (2, 1500, 7, 3), (64, 1024, 4, 1), (5, 4096, 8, 8)])
 def test_chunk_map_solves_with_several_right_hand_sides_and_workspace(ops, oracle, monkeypatch, B, N, J, nrhs, rows):
-    """solve_lower / solve_upper on a small batch of long series by chunk maps, right-hand side by right-hand side
+    """solve_lower / solve_upper on a small batch of series of 512 rows and more by chunk maps, right-hand side by right-hand side
     (c2_internal_solve_chunks*), with and without the workspace F of the drop-in (internal.hpp:140-141, 179-180): every
     row of Z and F against the oracle and against the row-by-row kernels, out of place and in place."""
     t, c, a, U, V, y = wide_batch(B, N, J)

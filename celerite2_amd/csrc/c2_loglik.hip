@@ -1159,6 +1159,19 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
                              int32_t *flag, int allow_timepar, c2_stream_t stream) {
   return c2_internal_factor_fused_ws(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, allow_timepar, nullptr, stream);
 }
+// shortest series the time-parallel factor_rev / factor with S take (C2_DROPIN_LONG_ROWS overrides)
+// tools/bench_ops.py, J = 8, ms row by row -> parallel along time: factor_rev 1 x 512 0.38 -> 0.15, 64 x 1024 0.75 -> 0.19,
+// 256 x 2048 1.50 -> 0.70, 512 x 4096 3.00 -> 1.59; factor + S 1 x 1024 0.74 -> 0.40, 64 x 2048 1.22 -> 0.63, 512 x 4096
+// 2.43 -> 1.69 (1 x 512: 0.37 either way)
+static int64_t drop_in_long_rows() {
+  const char *e = getenv("C2_DROPIN_LONG_ROWS");
+  const int64_t v = e ? atoll(e) : 0;
+  return v >= 128 ? v : 512;
+}
+static bool drop_in_long_shape(int64_t B, int64_t N) {
+  const int64_t k64 = B * ((N + 63) / 64);
+  return N >= drop_in_long_rows() && k64 <= (N >= 2048 ? 32768 : 4096);   // (short series: measured up to 256 x 1024)
+}
 // factor_rev on a small batch of long series (widths 1 .. 8): the reverse pass of the time-parallel gradient with the
 // adjoints of d, W handed in (c2_timepar_grad.hip, run_factor_rev); the S workspace is not read -- the states are replayed
 // from d, W.  One series of 1e5 rows, J = 8: 73 ms row by row.  C2_TIMEPAR_GRAD=0 disables it.
@@ -1166,7 +1179,7 @@ extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, cons
                                            int64_t c_bs, const double *U, const double *d, const double *W, const double *bd,
                                            const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV,
                                            c2_stream_t stream) {
-  if (J < 1 || J > 8 || N < 2048 || B * ((N + 63) / 64) > C2_TIMEPAR_GRAD_MAX_CHUNKS) return C2_ERR_UNSUPPORTED;
+  if (J < 1 || J > 8 || !drop_in_long_shape(B, N)) return C2_ERR_UNSUPPORTED;
   const char *e = getenv("C2_TIMEPAR_GRAD");
   if (e && atoi(e) == 0) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
@@ -1191,7 +1204,7 @@ extern "C" int c2_internal_factor_states_timepar(int64_t B, int64_t N, int64_t J
                                                  const double *c, int64_t c_bs, const double *a, const double *U,
                                                  const double *V, double *d, double *W, double *S, int32_t *flag,
                                                  c2_stream_t stream) {
-  if (J < 1 || J > 8 || N < 2048 || B * ((N + 63) / 64) > 32768 || d == a || W == V) return C2_ERR_UNSUPPORTED;
+  if (J < 1 || J > 8 || !drop_in_long_shape(B, N) || d == a || W == V) return C2_ERR_UNSUPPORTED;
   const char *e = getenv("C2_FACTOR_ITER");
   if (e && atoi(e) == 0) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;

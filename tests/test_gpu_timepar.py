@@ -192,7 +192,8 @@ def test_timepar_solves_match_oracle(ops, oracle, monkeypatch, B, N, J):
 
 @pytest.mark.parametrize("rows", [None, "32", "64"])
 @pytest.mark.parametrize("B,N,J", [(1, 2048, 8), (2, 5000, 7), (3, 2100, 6), (1, 9000, 5), (2, 4097, 4), (1, 2500, 3),
-                                   (2, 3000, 2), (1, 2049, 1), (1, 20000, 8), (1, 9000, 4)])
+                                   (2, 3000, 2), (1, 2049, 1), (1, 20000, 8), (1, 9000, 4), (1, 512, 8), (40, 1000, 6),
+                                   (3, 700, 3)])
 def test_factor_with_s_workspace_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows):
     """factor WITH the S workspace of the drop-in on a small batch of long series: d, W by the Newton iterations, the S
     rows (half-decayed states, forward.hpp:115-123) by chunks (k_s_rows) -- every element against the oracle and against
@@ -223,7 +224,8 @@ def test_factor_with_s_workspace_parallel_along_time(ops, oracle, monkeypatch, B
 
 @pytest.mark.parametrize("rows", [None, "32", "64"])
 @pytest.mark.parametrize("B,N,J", [(1, 2048, 8), (2, 5000, 7), (3, 2100, 6), (1, 9000, 5), (2, 4097, 4), (1, 2500, 3),
-                                   (2, 3000, 2), (1, 2049, 1), (1, 20000, 8), (1, 9000, 4)])
+                                   (2, 3000, 2), (1, 2049, 1), (1, 20000, 8), (1, 9000, 4), (1, 512, 8), (40, 1000, 6),
+                                   (3, 700, 3)])
 def test_factor_rev_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows):
     """factor_rev (reverse.hpp:26-85) on a small batch of long series: the reverse pass of the time-parallel gradient with
     the adjoints of d and W handed in -- all five outputs against the oracle and against the row-by-row kernel

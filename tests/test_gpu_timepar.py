@@ -304,6 +304,21 @@ def test_reverse_sweeps_on_long_series(ops, oracle, monkeypatch, name, B, N, J, 
     for g, r, w in zip(got, rows, want):
         gclose(g, w)
         gclose(g, r.cpu().numpy())
+    if B > 1:   # one time grid and one set of rates for the batch (the problem of series 0, other right-hand sides)
+        rep = lambda x: np.ascontiguousarray(np.tile(x[0], (B,) + (1,) * (x.ndim - 1)))
+        U0, W0 = rep(U), rep(W)
+        for b in range(B):
+            zb = Y[b].copy() if solve else np.zeros((N, nrhs))
+            fwd(t[0], c[0], U0[b], W0[b], Y[b], zb, F[b])
+            Z[b] = zb
+            outs = [np.zeros(N), np.zeros(J), np.zeros((N, J)), np.zeros((N, J)), np.zeros((N, nrhs))]
+            getattr(oracle, name)(t[0], c[0], U0[b], W0[b], Y[b], Z[b], F[b], bZ[b], *outs)
+            for w, o in zip(want, outs):
+                w[b] = o
+        monkeypatch.delenv("C2_REV_LONG", raising=False)
+        got = getattr(ops, name)(*dev(t[0].copy(), c[0].copy(), U0, W0, Y, Z, F.reshape(B, N, J, nrhs), bZ))
+        for g, w in zip(got, want):
+            gclose(g, w)
 
 
 @pytest.mark.parametrize("rows", [None, "16", "64"])

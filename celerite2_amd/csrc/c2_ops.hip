@@ -1154,6 +1154,17 @@ static int64_t long_min_rows() {
 // 1 x 1024 0.13 -> 0.05, 1 x 4096 + F 0.60 -> 0.06, 64 x 1024 0.13 -> 0.05, 512 x 2048 + F 0.32 -> 0.14, 256 x 4096 + F
 // 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
 // 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken below 16384 rows
+// shapes the chunked products of c2_scan.hip take: too few (series x rhs-tile) chains to fill the chip with the row-by-row
+// kernel, series long enough to cut (C2_SCAN_MIN_ROWS overrides the 1024)
+static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
+  const int64_t chains = B * ((nrhs + 3) / 4) * group_size(J);  // lanes kept busy by the sequential kernel
+  const char *me = getenv("C2_SCAN_MIN_ROWS");
+  const int64_t min_rows = me && atoll(me) >= 256 ? atoll(me) : 1024;
+  if (chains >= (int64_t)kWave * 2048) return false;
+  // below 16384 rows the chunked form (~0.5 ns per row and series) must beat a walk of ~0.15 us per row whatever the
+  // batch: one series of 4096 rows 0.60 -> 0.08 ms, 64 x 4096 0.63 -> 0.15, 256 x 4096 0.62 -> 0.48, 1024 x 2048 0.36 -> 1.01
+  return N >= 16384 || (N >= min_rows && B <= 128 && N >= 8 * B);
+}
 static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   if (J > 8 || nrhs > 64) return false;
   const int64_t k64 = B * nrhs * ((N + 63) / 64);
@@ -1174,8 +1185,7 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
   if (!SOLVE) {
     // Long series with too few (series x rhs-tile) chains to fill the chip: the matmul recurrence is linear with
     // a diagonal transition, so it is cut into time chunks that run in parallel (c2_scan.hip).
-    const int64_t chains = B * ((nrhs + 3) / 4) * group_size(J);  // lanes kept busy by the sequential kernel
-    if (N >= 16384 && chains < (int64_t)kWave * 2048) {
+    if (matmul_chunked_shape(B, N, J, nrhs)) {
       // J = 16 with 16 / 32 / 64 right-hand sides and no workspace: the blocks of 16 rows are dense fp64 contractions
       // on the matrix cores (c2_mfma.hip).  C2_MFMA=0 keeps the VALU path (A/B runs).
       if (LOWER && !F && use_mfma()) {
@@ -1183,7 +1193,13 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
         if (e != C2_ERR_UNSUPPORTED) return e;
       }
       // chunk length: aim at ~2048 units in flight per rhs slab, between 1024 and 16384 rows
-      int64_t Lc = 1024;
+      // the walks of the chunks shrink with Lc, the fold of their carries (one step per chunk) grows with N / Lc: the
+      // power of two next to 0.7 sqrt(N) (one series, J = 8: 20000 rows 0.79 -> 0.16 ms at Lc = 128, 1e5 rows 0.80 -> 0.31
+      // at 256, 1e6 rows 1.28 -> 1.18 at 512; C2_SCAN_MIN_CHUNK overrides)
+      const char *le = getenv("C2_SCAN_MIN_CHUNK");
+      int64_t Lc = 64;
+      while (Lc < 1024 && 4 * Lc * Lc < N) Lc *= 2;
+      if (le && atoll(le) >= 64) Lc = atoll(le);
       while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
       return c2_internal_matmul_chunked(LOWER ? 1 : 0, B, N, J, nrhs, Lc, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
                                         stream);
@@ -1358,9 +1374,9 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     // the per-row pass costs ~0.5 ns per row and series, the row-by-row kernel ~0.17 us per row whatever the batch:
     // 64 x 1024 0.18 -> 0.07 ms, 256 x 4096 0.87 -> 0.58, 512 x 1024 0.20 -> 0.33 (not taken)
     const bool on = !(ev && ev[0] == '0') && B <= 0xffff &&
-                    (N >= 16384 || (SOLVE && N >= long_min_rows() && B <= 256 && N >= 8 * B));
+                    (N >= 16384 || (N >= (SOLVE ? long_min_rows() : 1024) && B <= (SOLVE ? 256 : 128) && N >= 8 * B));
     const bool fits = SOLVE ? (solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled())
-                            : (B * ((nrhs + 3) / 4) * group_size(J) < (int64_t)kWave * 2048);
+                            : matmul_chunked_shape(B, N, J, nrhs);
     if (on && fits) {
       const int e = c2_internal_sweep_rev_long(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F,
                                                bZ, bt, bc, bU, bV, bY, stream);

@@ -266,9 +266,30 @@ def test_factor_rev_parallel_along_time(ops, oracle, monkeypatch, B, N, J, rows)
             gclose(g, w)
 
 
+@pytest.mark.parametrize("B,N,J,nrhs", [(1, 1024, 8, 1), (3, 4100, 6, 5), (100, 2048, 4, 2), (2, 9000, 16, 8), (1, 20000, 3, 3)])
+def test_chunked_products_on_mid_length_series(ops, oracle, B, N, J, nrhs):
+    """matmul_lower / matmul_upper on small batches of series from 1024 rows (c2_scan.hip with chunks of ~sqrt(N) / 2
+    rows): Z (accumulated into, and zeroed first) and the F workspace against the oracle."""
+    t, c, a, U, V, y = wide_batch(B, N, J) if J <= 8 else dense.synthetic_batch(B, N, J)
+    rng = np.random.default_rng(N + J)
+    Y = rng.standard_normal((B, N, nrhs)); Z0 = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Yd = dev(t, c, U, V, Y)
+    for name in ("matmul_lower", "matmul_upper"):
+        want = Z0.copy(); wantF = np.empty((B, N, J * nrhs))
+        for b in range(B):
+            getattr(oracle, name)(t[b], c[b], U[b], V[b], Y[b], want[b], wantF[b])
+        (Zd,) = dev(Z0)
+        got, F = getattr(ops, name)(td, cd, Ud, Vd, Yd, Z=Zd, workspace=True)
+        tol = dict(rtol=1e-10, atol=1e-12 * max(1.0, np.abs(want).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), want, **tol)
+        np.testing.assert_allclose(F.cpu().numpy().reshape(B, N, J * nrhs), wantF, rtol=1e-10,
+                                   atol=1e-12 * max(1.0, np.abs(wantF).max()))
+        np.testing.assert_allclose(getattr(ops, name)(td, cd, Ud, Vd, Yd, zero_z=True).cpu().numpy(), want - Z0, **tol)
+
+
 @pytest.mark.parametrize("name", ["solve_lower_rev", "solve_upper_rev", "matmul_lower_rev", "matmul_upper_rev"])
 @pytest.mark.parametrize("B,N,J,nrhs", [(1, 16500, 8, 1), (2, 17000, 5, 3), (1, 16384, 2, 8), (3, 16411, 6, 2), (1, 20000, 16, 2),
-                                        (1, 600, 8, 1), (3, 1100, 6, 2), (40, 1024, 4, 1), (2, 4096, 8, 8)])
+                                        (1, 600, 8, 1), (3, 1100, 6, 2), (40, 1024, 4, 1), (2, 4096, 8, 8), (2, 1500, 16, 5)])
 def test_reverse_sweeps_on_long_series(ops, oracle, monkeypatch, name, B, N, J, nrhs):
     """The four reverse sweeps (internal.hpp:191-303) on a small batch of long series (the solves: from 512 rows): the opposite sweep applied to bZ,
     with its workspace, plus a pass local to the rows (c2_internal_sweep_rev_long) -- all five outputs against the oracle

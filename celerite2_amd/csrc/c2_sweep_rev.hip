@@ -310,14 +310,16 @@ __global__ __launch_bounds__(kRowsPerBlock) void k_rev_rows(int64_t N, int J, in
   }
   if (row) bt[b * N + r] = LOWER ? fb - fa : fa - fb;
 }
-__global__ void k_rev_bc(int64_t B, int J, int64_t nblk, const double *__restrict__ part, double *__restrict__ bc) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * J) return;
-  const int64_t b = g / J;
-  const int j = (int)(g % J);
+// one wavefront per (series, j): lanes strided over the blocks, a fixed tree
+__global__ __launch_bounds__(kWave) void k_rev_bc(int J, int64_t nblk, const double *__restrict__ part,
+                                                  double *__restrict__ bc) {
+  const int64_t b = blockIdx.x / J;
+  const int j = (int)(blockIdx.x % J);
   double sum = 0.0;
-  for (int64_t q = 0; q < nblk; ++q) sum += part[(b * nblk + q) * J + j];
-  bc[g] = sum;
+  for (int64_t q = threadIdx.x; q < nblk; q += kWave) sum += part[(b * nblk + q) * J + j];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, kWave);
+  if (threadIdx.x == 0) bc[blockIdx.x] = sum;
 }
 }  // namespace c2rl
 
@@ -356,8 +358,7 @@ extern "C" int c2_internal_sweep_rev_long(int lower, int solve, int64_t B, int64
     if (lower) { if (solve) C2_RL(true, true); else C2_RL(true, false); }
     else       { if (solve) C2_RL(false, true); else C2_RL(false, false); }
 #undef C2_RL
-    hipLaunchKernelGGL(k_rev_bc, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)J, nblk,
-                       (const double *)part, bc);
+    hipLaunchKernelGGL(k_rev_bc, dim3((unsigned)(B * J)), dim3(kWave), 0, s, (int)J, nblk, (const double *)part, bc);
     if (hipGetLastError() != hipSuccess) rc = C2_ERR_HIP;
   }
   if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;

@@ -254,3 +254,72 @@ def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
     ll0, flag0 = ops.loglik(*args)
     assert np.array_equal(flag0.cpu().numpy() != 0, ~ok)
     np.testing.assert_allclose(ll0.cpu().numpy()[ok], llo[ok], rtol=1e-10)
+
+
+@pytest.mark.parametrize("seed", list(range(24)) + _extra_seeds())
+def test_fuzz_drop_in_ops_on_small_batches_of_mid_length_series(ops, oracle, seed):
+    """The time-parallel forms the drop-in ops take on small batches of series of 512 rows and more (chunk-map solves with
+    any number of right-hand sides and the F workspace, chunked products, factor with S, factor_rev, the four reverse
+    sweeps) on random shapes around their dispatch boundaries, per-series and shared time grids / rates: forward results
+    per element (1e-10 relative, floor 1e-12 of the largest), reverse results relative to the largest entry of each array."""
+    rng = np.random.default_rng(31000 + seed)
+    B = int(rng.choice([1, 2, 5, 33, 128]))
+    N = int(rng.choice([512, 513, 600, 1023, 1024, 1025, 2047, 2048, 2100, 4096, 5000]))
+    J = int(rng.choice([8, 7, 6, 5, 4, 3, 2, 1]))
+    nrhs = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    t, c, a, U, V, y = problem(rng, B, N, J)
+    shared_t = rng.random() < 0.3
+    shared_c = rng.random() < 0.3
+    if shared_t or shared_c:      # one problem for the whole batch, other right-hand sides / adjoints
+        rep = lambda x: np.ascontiguousarray(np.tile(x[0], (B,) + (1,) * (x.ndim - 1)))
+        t, c, a, U, V = rep(t), rep(c), rep(a), rep(U), rep(V)
+    tt = t[0].copy() if shared_t else t
+    cc = c[0].copy() if shared_c else c
+
+    def fclose(g, w):
+        w = np.asarray(w)
+        np.testing.assert_allclose(g.cpu().numpy().reshape(w.shape), w, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(w).max()))
+
+    def gclose(g, w):
+        np.testing.assert_allclose(g.cpu().numpy().reshape(w.shape), w, rtol=0.0, atol=1e-10 * max(np.abs(w).max(), 1e-300))
+
+    d = np.empty((B, N)); W = np.empty((B, N, J)); S = np.empty((B, N, J * J))
+    for b in range(B):
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d[b], W[b], S[b]) == 0
+    td, cd, ad, Ud, Vd, Wd, dd = dev(tt, cc, a, U, V, W, d)
+    gd, gW, gS, flag = ops.factor(td, cd, ad, Ud, Vd, workspace=True)
+    assert int(flag.abs().sum()) == 0
+    fclose(gd, d); fclose(gW, W); fclose(gS, S)
+    bd = rng.standard_normal((B, N)); bW = rng.standard_normal((B, N, J))
+    want = [np.zeros((B, N)), np.zeros((B, J)), np.zeros((B, N)), np.zeros((B, N, J)), np.zeros((B, N, J))]
+    for b in range(B):
+        outs = [np.zeros(N), np.zeros(J), np.zeros(N), np.zeros((N, J)), np.zeros((N, J))]
+        oracle.factor_rev(t[b], c[b], a[b], U[b], V[b], d[b], W[b], S[b], bd[b], bW[b], *outs)
+        for w, o in zip(want, outs):
+            w[b] = o
+    got = ops.factor_rev(td, cd, ad, Ud, Vd, dd, Wd, dev(S.reshape(B, N, J, J))[0], *dev(bd, bW))
+    for g, w in zip(got, want):
+        gclose(g, w)
+    Y = rng.standard_normal((B, N, nrhs)); bZ = rng.standard_normal((B, N, nrhs))
+    Yd, bZd = dev(Y, bZ)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        A = W if solve else V
+        Ad = Wd if solve else Vd
+        Z = np.empty_like(Y); F = np.empty((B, N, J * nrhs))
+        want = [np.zeros((B, N)), np.zeros((B, J)), np.zeros((B, N, J)), np.zeros((B, N, J)), np.zeros((B, N, nrhs))]
+        for b in range(B):
+            zb = Y[b].copy() if solve else np.zeros((N, nrhs))
+            getattr(oracle, name)(t[b], c[b], U[b], A[b], Y[b], zb, F[b])
+            Z[b] = zb
+            outs = [np.zeros(N), np.zeros(J), np.zeros((N, J)), np.zeros((N, J)), np.zeros((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], A[b], Y[b], Z[b], F[b], bZ[b], *outs)
+            for w, o in zip(want, outs):
+                w[b] = o
+        kw = {} if solve else dict(zero_z=True)
+        gZ, gF = getattr(ops, name)(td, cd, Ud, Ad, Yd, workspace=True, **kw)
+        fclose(gZ, Z); fclose(gF, F)
+        fclose(getattr(ops, name)(td, cd, Ud, Ad, Yd, **kw), Z)
+        got = getattr(ops, name + "_rev")(td, cd, Ud, Ad, Yd, *dev(Z, F.reshape(B, N, J, nrhs)), bZd)
+        for g, w in zip(got, want):
+            gclose(g, w)

@@ -107,7 +107,9 @@ int c2_general_matmul_upper(int64_t B, int64_t N, int64_t M, int64_t J, int64_t 
 
 /* core::factor_rev -- c++/include/celerite2/reverse.hpp:10-85
  * (backprop.factor_rev, backprop.cpp:68-150).  Outputs fully overwritten:
- * bt (B,N), bc (B,J), ba (B,N), bU (B,N,J), bV (B,N,J). */
+ * bt (B,N), bc (B,J), ba (B,N), bU (B,N,J), bV (B,N,J).  S must be the workspace of c2_factor for these d, W (as in the
+ * reference); on small batches of series of 512 rows and more the states are replayed from d, W instead of read from S
+ * (the reverse pass parallel along time), which is the same thing for a consistent S. */
 int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                   const double *a, const double *U, const double *V, const double *d, const double *W,
                   const double *S, const double *bd, const double *bW, double *bt, double *bc, double *ba,

@@ -1153,7 +1153,8 @@ static int64_t long_min_rows() {
 // shapes the chunk-map solves of c2_timepar_grad.hip take (tools/bench_ops.py, J = 8, ms row by row -> chunk maps):
 // 1 x 1024 0.13 -> 0.05, 1 x 4096 + F 0.60 -> 0.06, 64 x 1024 0.13 -> 0.05, 512 x 2048 + F 0.32 -> 0.14, 256 x 4096 + F
 // 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
-// 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken below 16384 rows
+// 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken; 64 x 4096 with 8 right-hand sides 1.29 -> 0.40; 512 x 4096 with 8:
+// 1.45 -> 1.9, not taken -- the rule below is that cost model
 // shapes the chunked products of c2_scan.hip take: too few (series x rhs-tile) chains to fill the chip with the row-by-row
 // kernel, series long enough to cut (C2_SCAN_MIN_ROWS overrides the 1024)
 static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
@@ -1166,10 +1167,13 @@ static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) 
   return N >= 16384 || (N >= min_rows && B <= 128 && N >= 8 * B);
 }
 static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
-  if (J > 8 || nrhs > 64) return false;
-  const int64_t k64 = B * nrhs * ((N + 63) / 64);
-  if (N >= 16384) return k64 <= 32768;
-  return N >= (nrhs == 1 ? long_min_rows() : 2 * long_min_rows()) && k64 <= 16384;
+  if (J > 8 || nrhs > 64 || N < long_min_rows()) return false;
+  const int64_t k64 = B * ((N + 63) / 64);   // chunks of one launch: the right-hand sides run one after the other
+  if (k64 > 32768) return false;
+  if (N >= 16384) return k64 * nrhs <= 32768 || nrhs * (0.05 + 6e-6 * (double)k64) < 1e-3 * (double)N * (0.15 + 0.025 * (double)nrhs);
+  // measured (ms): a column over k64 chunks 0.05 + 6e-6 k64 (64 x 4096: 0.07, 512 x 4096: 0.24); row by row
+  // N (0.15 + 0.025 nrhs) us whatever the batch (4096 rows: 0.63 with one right-hand side, 1.29 with 8)
+  return (double)nrhs * (0.05 + 6e-6 * (double)k64) < 1e-3 * (double)N * (0.15 + 0.025 * (double)nrhs);
 }
 static bool solve_chunks_enabled() {
   const char *e = getenv("C2_TIMEPAR");   // the switch of the time-parallel solves: 0 keeps them row by row
@@ -1373,11 +1377,13 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     const char *ev = getenv("C2_REV_LONG");   // 0: keep the row-by-row kernels (A/B runs)
     // the per-row pass costs ~0.5 ns per row and series, the row-by-row kernel ~0.17 us per row whatever the batch:
     // 64 x 1024 0.18 -> 0.07 ms, 256 x 4096 0.87 -> 0.58, 512 x 1024 0.20 -> 0.33 (not taken)
-    const bool on = !(ev && ev[0] == '0') && B <= 0xffff &&
-                    (N >= 16384 || (N >= (SOLVE ? long_min_rows() : 1024) && B <= (SOLVE ? 256 : 128) && N >= 8 * B));
+    // (whatever form the opposite sweep takes below 16384 rows: row by row it still costs a third of the reverse kernel --
+    // one series of 1024 rows, 8 right-hand sides: 1.01 -> 0.36 ms)
+    const bool small = N >= (SOLVE ? long_min_rows() : 1024) && B <= (SOLVE ? 256 : 128) && N >= 8 * B;
     const bool fits = SOLVE ? (solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled())
                             : matmul_chunked_shape(B, N, J, nrhs);
-    if (on && fits) {
+    const bool on = !(ev && ev[0] == '0') && B <= 0xffff && (N >= 16384 ? fits : small);
+    if (on) {
       const int e = c2_internal_sweep_rev_long(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F,
                                                bZ, bt, bc, bU, bV, bY, stream);
       if (e != C2_ERR_UNSUPPORTED) return e;

@@ -243,72 +243,80 @@ namespace c2rl {
 using namespace c2;
 constexpr int kRowsPerBlock = 256;
 
-template <bool LOWER, bool SOLVE>
+// thread <-> (row, j): JL = 1 .. 32 lanes per row (the power of two >= J), so that the lanes of a row read the J
+// contiguous entries of a workspace column together; kRowsPerBlock / JL rows per block.
+template <int JL, bool LOWER, bool SOLVE>
 __global__ __launch_bounds__(kRowsPerBlock) void k_rev_rows(int64_t N, int J, int64_t nrhs, const double *__restrict__ t,
                                                             int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                             const double *__restrict__ X, const double *__restrict__ Q,
                                                             const double *__restrict__ F, const double *__restrict__ Fa,
                                                             double *__restrict__ bt, double *__restrict__ outA,
                                                             double *__restrict__ outB, double *__restrict__ part) {
-  __shared__ double red[kRowsPerBlock / kWave];
-  const int64_t b = blockIdx.y, r = (int64_t)blockIdx.x * kRowsPerBlock + threadIdx.x;
-  const bool row = r < N;
+  constexpr int RB = kRowsPerBlock / JL;   // rows per block
+  __shared__ double red[kRowsPerBlock / kWave][JL];
+  const int j = threadIdx.x % JL, rl = threadIdx.x / JL;
+  const int64_t b = blockIdx.y, r = (int64_t)blockIdx.x * RB + rl;
+  const bool row = r < N, act = row && j < J;
   const bool va = row && (LOWER ? r >= 1 : r + 1 < N);        // the step AT this row
   const bool vb = row && (LOWER ? r + 1 < N : r >= 1);        // the step whose partner row this is
   const int64_t ma = LOWER ? r - 1 : r + 1, nb = LOWER ? r + 1 : r - 1;
-  const double *tb = t + b * t_bs, *cb = c + b * c_bs;
+  const double *tb = t + b * t_bs;
   const double s = SOLVE ? -1.0 : 1.0;
   const double dta = va ? -fabs(tb[r] - tb[ma]) : 0.0, dtb = vb ? -fabs(tb[nb] - tb[r]) : 0.0;
   const int64_t JK = (int64_t)J * nrhs;
-  const double *Fr = F + (b * N + (row ? r : 0)) * JK, *Fn = F + (b * N + (vb ? nb : 0)) * JK;
-  const double *Hr = Fa + (b * N + (va ? ma : 0)) * JK;      // s H of the step at this row
-  const double *Hb = Fa + (b * N + (row ? r : 0)) * JK;      // s H of the step whose partner this row is
+  const int jc = j < J ? j : 0;
+  const double *Fr = F + (b * N + (row ? r : 0)) * JK + jc, *Fn = F + (b * N + (vb ? nb : 0)) * JK + jc;
+  const double *Hr = Fa + (b * N + (va ? ma : 0)) * JK + jc;      // s H of the step at this row
+  const double *Hb = Fa + (b * N + (row ? r : 0)) * JK + jc;      // s H of the step whose partner this row is
   const double *Xr = X + (b * N + (row ? r : 0)) * nrhs, *Qr = Q + (b * N + (row ? r : 0)) * nrhs;
-  double fa = 0.0, fb = 0.0;
-  for (int j = 0; j < J; ++j) {
-    const double cj = cb[j];
-    double oa = 0.0, ob = 0.0, bpa = 0.0;
-    if (va) {
-      const double p = exp_decay(cj * dta);
-      double acc = 0.0, bp = 0.0;
-      for (int64_t k = 0; k < nrhs; ++k) {
-        const double f = Fr[j + J * k];
-        acc = fma(Xr[k], f, acc);
-        bp = fma(f, Hr[j + J * k], bp);
-      }
-      oa = s * p * acc;
-      bpa = s * p * bp;
-      fa = fma(cj, bpa, fa);
+  const double cj = c[b * c_bs + jc];
+  double oa = 0.0, ob = 0.0, bpa = 0.0, bpb = 0.0;
+  if (va && act) {
+    const double p = exp_decay(cj * dta);
+    double acc = 0.0, bp = 0.0;
+    for (int64_t k = 0; k < nrhs; ++k) {
+      const double f = Fr[J * k];
+      acc = fma(Xr[k], f, acc);
+      bp = fma(f, Hr[J * k], bp);
     }
-    if (vb) {
-      const double p = exp_decay(cj * dtb);
-      double acc = 0.0, bp = 0.0;
-      for (int64_t k = 0; k < nrhs; ++k) {
-        const double h = Hb[j + J * k];
-        acc = fma(Qr[k], h, acc);
-        bp = fma(Fn[j + J * k], h, bp);
-      }
-      ob = s * p * acc;
-      fb = fma(cj, s * p * bp, fb);
-    }
-    if (row) {
-      outA[(b * N + r) * J + j] = oa;
-      outB[(b * N + r) * J + j] = ob;
-    }
-    // bc_j: the block's rows in a fixed tree
-    double v = dta * bpa;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
-    __syncthreads();
-    if (threadIdx.x % kWave == 0) red[threadIdx.x / kWave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double sum = 0.0;
-      for (int w = 0; w < kRowsPerBlock / kWave; ++w) sum += red[w];
-      part[((int64_t)b * gridDim.x + blockIdx.x) * J + j] = sum;
-    }
+    oa = s * p * acc;
+    bpa = s * p * bp;
   }
-  if (row) bt[b * N + r] = LOWER ? fb - fa : fa - fb;
+  if (vb && act) {
+    const double p = exp_decay(cj * dtb);
+    double acc = 0.0, bp = 0.0;
+    for (int64_t k = 0; k < nrhs; ++k) {
+      const double h = Hb[J * k];
+      acc = fma(Qr[k], h, acc);
+      bp = fma(Fn[J * k], h, bp);
+    }
+    ob = s * p * acc;
+    bpb = s * p * bp;
+  }
+  if (act) {
+    outA[(b * N + r) * J + j] = oa;
+    outB[(b * N + r) * J + j] = ob;
+  }
+  // phi of the two steps: sums over the lanes of the row
+  double fa = act ? cj * bpa : 0.0, fb = act ? cj * bpb : 0.0;
+#pragma unroll
+  for (int o = JL / 2; o >= 1; o >>= 1) {
+    fa += __shfl_xor(fa, o, kWave);
+    fb += __shfl_xor(fb, o, kWave);
+  }
+  if (row && j == 0) bt[b * N + r] = LOWER ? fb - fa : fa - fb;
+  // bc_j: the block's rows in a fixed tree (lanes with the same j, then the wavefronts)
+  double v = act ? dta * bpa : 0.0;
+#pragma unroll
+  for (int o = 32; o >= JL; o >>= 1) v += __shfl_xor(v, o, kWave);
+  if ((int)(threadIdx.x % kWave) < JL) red[threadIdx.x / kWave][j] = v;
+  __syncthreads();
+  if (threadIdx.x < (unsigned)J) {
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < kRowsPerBlock / kWave; ++w) sum += red[w][threadIdx.x];
+    part[((int64_t)b * gridDim.x + blockIdx.x) * J + threadIdx.x] = sum;
+  }
 }
 // one wavefront per (series, j): lanes strided over the blocks, a fixed tree
 __global__ __launch_bounds__(kWave) void k_rev_bc(int J, int64_t nblk, const double *__restrict__ part,
@@ -335,7 +343,10 @@ extern "C" int c2_internal_sweep_rev_long(int lower, int solve, int64_t B, int64
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
   if (capturing != hipStreamCaptureStatusNone || (!solve && bY == bZ)) return C2_ERR_UNSUPPORTED;
-  const int64_t nblk = (N + kRowsPerBlock - 1) / kRowsPerBlock;
+  if (J > 32) return C2_ERR_UNSUPPORTED;
+  int JL = 1;
+  while (JL < J) JL *= 2;
+  const int64_t nblk = (N + kRowsPerBlock / JL - 1) / (kRowsPerBlock / JL);
   const size_t nws = (size_t)B * N * J * nrhs, npart = (size_t)B * nblk * J;
   void *tmp = nullptr;
   if (hipMallocAsync(&tmp, (nws + npart) * sizeof(double), s) != hipSuccess) {
@@ -352,11 +363,23 @@ extern "C" int c2_internal_sweep_rev_long(int lower, int solve, int64_t B, int64
     const dim3 grid((unsigned)nblk, (unsigned)B);
     const double *X = solve ? bY : bZ, *Q = solve ? Z : Y;
     double *outA = lower ? bU : bV, *outB = lower ? bV : bU;
-#define C2_RL(LO, SO)                                                                                                    \
-  hipLaunchKernelGGL((k_rev_rows<LO, SO>), grid, dim3(kRowsPerBlock), 0, s, N, (int)J, nrhs, t, t_bs, c, c_bs, X, Q, F,  \
-                     (const double *)Fa, bt, outA, outB, part)
-    if (lower) { if (solve) C2_RL(true, true); else C2_RL(true, false); }
-    else       { if (solve) C2_RL(false, true); else C2_RL(false, false); }
+#define C2_RL(JL_, LO, SO)                                                                                              \
+  hipLaunchKernelGGL((k_rev_rows<JL_, LO, SO>), grid, dim3(kRowsPerBlock), 0, s, N, (int)J, nrhs, t, t_bs, c, c_bs, X, Q, \
+                     F, (const double *)Fa, bt, outA, outB, part)
+#define C2_RLJ(JL_)                                                             \
+  do {                                                                          \
+    if (lower) { if (solve) C2_RL(JL_, true, true); else C2_RL(JL_, true, false); }   \
+    else       { if (solve) C2_RL(JL_, false, true); else C2_RL(JL_, false, false); } \
+  } while (0)
+    switch (JL) {
+      case 1: C2_RLJ(1); break;
+      case 2: C2_RLJ(2); break;
+      case 4: C2_RLJ(4); break;
+      case 8: C2_RLJ(8); break;
+      case 16: C2_RLJ(16); break;
+      default: C2_RLJ(32); break;
+    }
+#undef C2_RLJ
 #undef C2_RL
     hipLaunchKernelGGL(k_rev_bc, dim3((unsigned)(B * J)), dim3(kWave), 0, s, (int)J, nblk, (const double *)part, bc);
     if (hipGetLastError() != hipSuccess) rc = C2_ERR_HIP;

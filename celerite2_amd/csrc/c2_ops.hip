@@ -1379,10 +1379,14 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     // 64 x 1024 0.18 -> 0.07 ms, 256 x 4096 0.87 -> 0.58, 512 x 1024 0.20 -> 0.33 (not taken)
     // (whatever form the opposite sweep takes below 16384 rows: row by row it still costs a third of the reverse kernel --
     // one series of 1024 rows, 8 right-hand sides: 1.01 -> 0.36 ms)
-    const bool small = N >= (SOLVE ? long_min_rows() : 1024) && B <= (SOLVE ? 256 : 128) && N >= 8 * B;
+    // the row-by-row kernels cost the same per row whatever the batch (until it fills the chip), this form costs per row
+    // AND series: 512 x 4096 solve 0.88 -> 0.47 ms (product 0.78 -> 0.91: not taken), 8 right-hand sides 5.4 -> 2.8;
+    // 1024 x 4096 with 8: 5.5 -> 3.8 (with one 0.92 -> 1.25: not taken); 2048 x 1024: level at best, not taken
+    const int64_t bmax = nrhs >= 4 ? 1024 : (SOLVE ? 512 : 128);
+    const bool small = N >= (SOLVE ? long_min_rows() : 1024) && B <= bmax && (N >= 2048 || N >= 8 * B);
     const bool fits = SOLVE ? (solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled())
                             : matmul_chunked_shape(B, N, J, nrhs);
-    const bool on = !(ev && ev[0] == '0') && B <= 0xffff && (N >= 16384 ? fits : small);
+    const bool on = !(ev && ev[0] == '0') && B <= 0xffff && ((ev && ev[0] == '1') || (N >= 16384 ? fits : small));   // 1 forces it
     if (on) {
       const int e = c2_internal_sweep_rev_long(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F,
                                                bZ, bt, bc, bU, bV, bY, stream);

@@ -1150,11 +1150,6 @@ static int64_t long_min_rows() {
   const int64_t v = e ? atoll(e) : 0;
   return v >= 128 ? v : 512;
 }
-// shapes the chunk-map solves of c2_timepar_grad.hip take (tools/bench_ops.py, J = 8, ms row by row -> chunk maps):
-// 1 x 1024 0.13 -> 0.05, 1 x 4096 + F 0.60 -> 0.06, 64 x 1024 0.13 -> 0.05, 512 x 2048 + F 0.32 -> 0.14, 256 x 4096 + F
-// 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
-// 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken; 64 x 4096 with 8 right-hand sides 1.29 -> 0.40; 512 x 4096 with 8:
-// 1.45 -> 1.9, not taken -- the rule below is that cost model
 // shapes the chunked products of c2_scan.hip take: too few (series x rhs-tile) chains to fill the chip with the row-by-row
 // kernel, series long enough to cut (C2_SCAN_MIN_ROWS overrides the 1024)
 static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
@@ -1166,6 +1161,11 @@ static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) 
   // batch: one series of 4096 rows 0.60 -> 0.08 ms, 64 x 4096 0.63 -> 0.15, 256 x 4096 0.62 -> 0.48, 1024 x 2048 0.36 -> 1.01
   return N >= 16384 || (N >= min_rows && B <= 128 && N >= 8 * B);
 }
+// shapes the chunk-map solves of c2_timepar_grad.hip take (tools/bench_ops.py, J = 8, ms row by row -> chunk maps):
+// 1 x 1024 0.13 -> 0.05, 1 x 4096 + F 0.60 -> 0.06, 64 x 1024 0.13 -> 0.05, 512 x 2048 + F 0.32 -> 0.14, 256 x 4096 + F
+// 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
+// 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken; 64 x 4096 with 8 right-hand sides 1.29 -> 0.40; 512 x 4096 with 8:
+// 1.45 -> 1.9, not taken -- the rule below is that cost model
 static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   if (J > 8 || nrhs > 64 || N < long_min_rows()) return false;
   const int64_t k64 = B * ((N + 63) / 64);   // chunks of one launch: the right-hand sides run one after the other
@@ -1192,13 +1192,12 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
     if (matmul_chunked_shape(B, N, J, nrhs)) {
       // J = 16 with 16 / 32 / 64 right-hand sides and no workspace: the blocks of 16 rows are dense fp64 contractions
       // on the matrix cores (c2_mfma.hip).  C2_MFMA=0 keeps the VALU path (A/B runs).
-      if (LOWER && !F && use_mfma()) {
+      if (LOWER && !F && N >= 16384 && use_mfma()) {
         const int e = c2_internal_matmul_lower_mfma(B, N, J, nrhs, t, t_bs, c, c_bs, U, V, nullptr, Y, Z, zero_z, stream);
         if (e != C2_ERR_UNSUPPORTED) return e;
       }
-      // chunk length: aim at ~2048 units in flight per rhs slab, between 1024 and 16384 rows
-      // the walks of the chunks shrink with Lc, the fold of their carries (one step per chunk) grows with N / Lc: the
-      // power of two next to 0.7 sqrt(N) (one series, J = 8: 20000 rows 0.79 -> 0.16 ms at Lc = 128, 1e5 rows 0.80 -> 0.31
+      // chunk length: the walks of the chunks shrink with Lc, the fold of their carries (one step per chunk) grows with
+      // N / Lc -- the power of two next to 0.5 sqrt(N), longer once ~2048 units per rhs slab are in flight (one series, J = 8: 20000 rows 0.79 -> 0.16 ms at Lc = 128, 1e5 rows 0.80 -> 0.31
       // at 256, 1e6 rows 1.28 -> 1.18 at 512; C2_SCAN_MIN_CHUNK overrides)
       const char *le = getenv("C2_SCAN_MIN_CHUNK");
       int64_t Lc = 64;

@@ -984,7 +984,11 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // of 50000 rows at J = 6 57.6 -> 4.6 ms; 256 x 4096 at J = 8 4.3 -> 1.9 ms.  The chunks are walked one per lane with
   // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
   // One series draws level at ~400 rows (J = 2), ~600 (J = 4, 6), ~800 (J = 8): 0.48 -> 0.25 ms at 768 rows, J = 2.
-  const int64_t min_rows = J <= 2 ? 512 : (J >= 7 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768);
+  // (those with chunks of 64 rows; with the 16-row chunks a handful of series takes -- at most 4096 chunks of 64 rows --
+  // one series draws level below 200 rows: 256 rows 0.17 -> 0.13 ms at J = 2, 0.30 -> 0.22 at J = 6; 512 rows 0.54 -> 0.33
+  // at J = 8, the same for 64 series)
+  const bool handful = B * ((N + 63) / 64) <= 4096;
+  const int64_t min_rows = handful ? 256 : (J <= 2 ? 512 : (J >= 7 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768));
   // (widths up to 4 would keep winning a little further -- 768 x 4096 at J = 4 2.97 -> 1.46 ms, 1024 x 4096 2.98 -> 2.44 ms
   // -- but not by enough to move the limit)
   return N >= min_rows && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;

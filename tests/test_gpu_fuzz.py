@@ -40,7 +40,17 @@ def problem(rng, B, N, J):
     return t, c, a, U, V, y
 
 
-CASES = [(int(s),) for s in range(24)]
+def _extra_seeds():
+    """C2_FUZZ_EXTRA=base:count adds seeds base .. base+count-1 to the sweeps (stress runs on the GPU box)."""
+    import os
+    e = os.environ.get("C2_FUZZ_EXTRA")
+    if not e:
+        return []
+    base, count = (int(x) for x in e.split(":"))
+    return list(range(base, base + count))
+
+
+CASES = [(int(s),) for s in list(range(24)) + _extra_seeds()]
 
 
 @pytest.mark.parametrize("seed", [s for (s,) in CASES])
@@ -199,16 +209,6 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
             # two device paths with different summation orders; bdc / bx carry the factor max|x| (see test_gpu_terms.py)
             floor = 1e-11 if k not in (5,) else max(1e-11, 1e-14 * max(N, 4) * xmax)
             close(gf, gc.cpu().numpy(), tol=1e-9, floor=floor)
-
-
-def _extra_seeds():
-    """C2_FUZZ_EXTRA=base:count adds seeds base .. base+count-1 to the time-parallel sweep (stress runs on the GPU box)."""
-    import os
-    e = os.environ.get("C2_FUZZ_EXTRA")
-    if not e:
-        return []
-    base, count = (int(x) for x in e.split(":"))
-    return list(range(base, base + count))
 
 
 @pytest.mark.parametrize("seed", list(range(30)) + _extra_seeds())

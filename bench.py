@@ -170,8 +170,35 @@ def long_series(J, dev, N=100_000, steps=3):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+    # the reverse-mode chain of the drop-in ops on the same series (device pointers): factor with S, solve_lower with F,
+    # their reverses -- parallel along time as well; informational, never fatal
+    ops_ms = {}
+    try:
+        t, c, a, U, V, y = args
+        Y = y.unsqueeze(-1).contiguous()
+
+        def timed(fn):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / steps
+
+        d, W, S, _ = ops.factor(t, c, a, U, V, workspace=True)
+        Z, F = ops.solve_lower(t, c, U, W, Y, workspace=True)
+        bd, bW, bZ = torch.randn_like(d), torch.randn_like(W), torch.randn_like(Z)
+        ops_ms["factor_with_S"] = timed(lambda: ops.factor(t, c, a, U, V, d=d, W=W, S=S))
+        ops_ms["solve_lower_with_F"] = timed(lambda: ops.solve_lower(t, c, U, W, Y, Z=Z, F=F))
+        ops_ms["solve_lower_rev"] = timed(lambda: ops.solve_lower_rev(t, c, U, W, Y, Z, F, bZ))
+        ops_ms["factor_rev"] = timed(lambda: ops.factor_rev(t, c, a, U, V, d, W, S, bd, bW))
+    except Exception as e:  # noqa: BLE001 -- informational only
+        ops_ms["error"] = repr(e)[:200]
     return {"entry": "c2_loglik_grad", "workload": "1 series, N=%d, J=%d, forward + reverse-mode grad" % (N, J),
-            "ms": out["ms"], "row_by_row_ms": out["row_by_row_ms"],
+            "ms": out["ms"], "row_by_row_ms": out["row_by_row_ms"], "drop_in_ops_ms": ops_ms,
             "ll_rel_diff": abs(out["ll_ms"] - out["ll_row_by_row_ms"]) / abs(out["ll_row_by_row_ms"]),
             "note": "informational: latency-bound regime, gradient parallel along time (c2_timepar_grad.hip)"}
 

@@ -26,19 +26,59 @@ SYMBOLS = [
     "c2h_general_matmul_lower", "c2h_general_matmul_upper", "c2h_factor_rev",
     "c2h_solve_lower_rev", "c2h_solve_upper_rev", "c2h_matmul_lower_rev", "c2h_matmul_upper_rev",
     "c2h_get_celerite_matrices",
+    "c2_set_option", "c2_get_option", "c2_option_count", "c2_option_info", "c2_options_reload_env",
 ]
 
 _lib = None
+_env_names = ()      # environment variables of the option table (c2_option_info)
+_env_seen = None     # their values when the table was last (re)loaded
 
 
 class BackendError(RuntimeError):
     pass
 
 
+def _sync_env(lib):
+    """The C library reads its dispatch options from the environment ONCE, when it is loaded, and never calls getenv
+    afterwards (c2_dispatch.hpp).  This ctypes layer additionally re-reads them when it SEES the process environment
+    change between two calls -- what the test-suite and the A/B tools rely on when they edit os.environ at run time;
+    applications use set_option()."""
+    global _env_seen
+    now = tuple(os.environ.get(n) for n in _env_names)
+    if now != _env_seen:
+        lib.c2_options_reload_env()
+        _env_seen = now
+
+
+def set_option(name, value=None):
+    """c2_set_option: `name` = option name or its environment variable; value None = back to the default / automatic."""
+    lib = load()
+    rc = lib.c2_set_option(str(name).encode(), None if value is None else str(value).encode())
+    if rc != C2_OK:
+        raise ValueError("celerite2_amd: unknown option %r or unparsable value %r" % (name, value))
+
+
+def options():
+    """The dispatch table: a list of dicts (name, env, default, switch, value, is_set, doc, measured)."""
+    lib = load()
+    out = []
+    for i in range(lib.c2_option_count()):
+        name, env, doc, src = (ctypes.c_char_p() for _ in range(4))
+        dflt, sw = ctypes.c_double(), ctypes.c_int()
+        lib.c2_option_info(i, ctypes.byref(name), ctypes.byref(env), ctypes.byref(dflt), ctypes.byref(sw), ctypes.byref(doc),
+                           ctypes.byref(src))
+        val, st = ctypes.c_double(), ctypes.c_int()
+        lib.c2_get_option(name.value, ctypes.byref(val), ctypes.byref(st))
+        out.append(dict(name=name.value.decode(), env=env.value.decode(), default=dflt.value, switch=bool(sw.value),
+                        value=val.value, is_set=bool(st.value), doc=doc.value.decode(), measured=src.value.decode()))
+    return out
+
+
 def load():
     """Load libcelerite2_amd.so (after torch, so both share one HIP runtime)."""
-    global _lib
+    global _lib, _env_names, _env_seen
     if _lib is not None:
+        _sync_env(_lib)
         return _lib
     if not os.path.exists(LIB_PATH):
         raise BackendError(
@@ -59,7 +99,21 @@ def load():
     lib.c2_loglik_terms_workspace_bytes.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_int]
     lib.c2_kron_loglik_workspace_bytes.restype = ctypes.c_size_t
     lib.c2_kron_loglik_workspace_bytes.argtypes = [ctypes.c_int64] * 4 + [ctypes.c_int] * 2
+    lib.c2_set_option.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lib.c2_get_option.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    lib.c2_option_count.restype = ctypes.c_int
+    lib.c2_option_info.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p),
+                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_char_p)]
+    lib.c2_options_reload_env.restype = None
     _lib = lib
+    names = []
+    for i in range(lib.c2_option_count()):
+        env = ctypes.c_char_p()
+        lib.c2_option_info(i, None, ctypes.byref(env), None, None, None, None)
+        names.append(env.value.decode())
+    _env_names = tuple(names)
+    _env_seen = tuple(os.environ.get(n) for n in _env_names)
     return lib
 
 

@@ -1,0 +1,64 @@
+// c2_dispatch.hpp -- the ONE table of everything that steers the dispatch of this library: switches that force or
+// disable an alternative formulation (every alternative is parity-tested, so a switch changes speed, never results beyond
+// rounding) and the thresholds / cost-model constants the automatic choices use, each with the measurement it came from.
+//
+// Values are read from the environment ONCE, when the library is loaded; after that only c2_set_option() changes them
+// (include/celerite2_amd.h).  No entry point calls getenv: a workspace-size query and the call that follows it see the same
+// options unless the caller changes them in between.  INTEGRATION.md section 5 is generated from this table
+// (tools/gen_dispatch_doc.py); tools/crossovers.py re-measures the crossovers on the box it runs on and prints the
+// c2_set_option() calls that would move them.
+//
+// X(id, environment variable, default, kind, what it does, where the default comes from)
+//   kind 's': switch -- unset means "automatic"; has() tells whether it was set
+//   kind 't': threshold / constant -- val() is the default unless set
+#pragma once
+
+#define C2_OPTIONS(X)                                                                                                                 \
+  X(lanes, "C2_LANES", 0, 's', "lane mapping of the fused log-likelihood kernels: 8 (a group of lanes per series), 4 (two columns per lane, J = 8), 1 (one lane per series); unset: by batch size", "profiles/r02_lane_mappings.md") \
+  X(lanes1_min_batch_fwd, "C2_LANES1_MIN_BATCH_FWD", 24576, 't', "forward log-likelihood: one lane per series from this many series up (widths 8, 6, 4, 2)", "N = 4096, J = 8: 3.3 vs 4.1 ms at 24576 series, 6.7 vs 10.4 ms at 65536 (profiles/r02_lane_mappings.md)") \
+  X(lanes1_min_batch_grad, "C2_LANES1_MIN_BATCH_GRAD", 24576, 't', "log-likelihood + gradient: one lane per series from this many series up (widths 8, 4, 2)", "15.7 vs 16.0 ms at 24576 series, 28.2 vs 41.8 ms at 65536 (profiles/r02_lane_mappings.md)") \
+  X(lanes1_min_batch_grad_j6, "C2_LANES1_MIN_BATCH_GRAD_J6", 32768, 't', "the same at width 6 (rows of 48 bytes: no aligned 128-byte runs)", "18.5 vs 20.7 ms at 32768 series, 17.2 vs 15.8 ms at 24576") \
+  X(lanes4_min_batch, "C2_LANES4_MIN_BATCH", 16384, 't', "forward log-likelihood, J = 8: two columns per lane from this many series up", "14-15 % faster from 16384 series, equal at 8192 (profiles/r01_lanes4.md)") \
+  X(timepar, "C2_TIMEPAR", 0, 's', "forward log-likelihood / factor (widths 4, 2) and the solves parallel along TIME: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_check.py, profiles/r02_timepar.md") \
+  X(timepar_min_rows, "C2_TIMEPAR_MIN_ROWS", 1536, 't', "shortest series the time-parallel forward pass takes when the batch is not a handful (B * J > 512)", "J = 4, 1024 x 4096: 0.26 vs 0.87 ms; a handful of series from 384 / 704 / 1024 rows at widths 2 / 4 / 8 (tools/timepar_small_n.py)") \
+  X(timepar_max_batch_x_width, "C2_TIMEPAR_MAX_BATCH_X_WIDTH", 8192, 't', "largest B * J the time-parallel forward pass takes", "linear in the batch beyond one wavefront per SIMD: 0.98 ms at 4096 series of J = 4 where row by row takes 0.87") \
+  X(timepar_grad, "C2_TIMEPAR_GRAD", 0, 's', "log-likelihood GRADIENT (and factor_rev) parallel along time, widths 1 .. 8: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_grad_time.py, profiles/r02_timepar_grad.md") \
+  X(timepar_grad_min_rows, "C2_TIMEPAR_GRAD_MIN_ROWS", 1024, 't', "shortest series the time-parallel gradient takes at widths 7, 8 beyond a handful of series (768 at widths 3 .. 6, 512 at 1, 2; 256 for at most 4096 chunks)", "one series draws level at ~400 / ~600 / ~800 rows at J = 2 / 4, 6 / 8 (tools/timepar_grad_time.py)") \
+  X(timepar_grad_max_chunks, "C2_TIMEPAR_GRAD_MAX_CHUNKS", 32768, 't', "largest number of 64-row chunks (B * ceil(N / 64)) the time-parallel gradient takes", "1024 x 4096 at J = 4: 3.6 vs 3.0 ms row by row") \
+  X(timepar_cond_limit, "C2_TIMEPAR_COND_LIMIT", 0, 't', "largest conditioning kappa = max a_n / d_n for which the result of the time-parallel gradient stands; beyond it the row-by-row kernels -- which share the reference's operation order -- recompute the batch (device-side gate); 0: no limit", "float64 rounding moves the gradient of ANY evaluation order by ~0.6 eps kappa^2 of its largest entry (the reference's own included: tools/kappa_sweep.py, profiles/r03_timepar_verification.md)") \
+  X(verify_fallback, "C2_VERIFY_FALLBACK", 1, 's', "0 (diagnostics only): keep the result of a time-parallel form whatever its device-side verification says", "tools/verify_words.py") \
+  X(factor_iter, "C2_FACTOR_ITER", 0, 's', "factor by Newton iterations on the chunk start states: 1 forces, 0 disables; unset: from 2048 rows and at most 32768 chunks (widths 4, 2: from 32768 / 131072 rows)", "tools/factor_iter_time.py: 4096 rows 1.21 -> 0.76 ms, 1e5 rows 29.5 -> 1.0 ms at J = 8") \
+  X(tpg_rows, "C2_TPG_ROWS", 0, 's', "chunk length of the time-parallel gradient / Newton factor / chunk-map solves: 16, 32 or 64; unset: 16 up to 4096 rows and 32 beyond for at most 4096 chunks of 64 rows, else 64", "one series of 4096 rows 1.33 -> 1.03 -> 0.73 ms (64 -> 32 -> 16 rows), 1e5 rows 1.68 -> 1.25 ms with 32") \
+  X(tpg_rows16_max_rows, "C2_TPG_ROWS16_MAX_ROWS", 4096, 't', "longest series that takes 16-row chunks", "chains of more than 256 chunks cost accuracy first (9000 rows: 1.3e-11 vs 4e-12), then time") \
+  X(dropin_long_rows, "C2_DROPIN_LONG_ROWS", 512, 't', "shortest series factor + S and factor_rev take in their time-parallel form (at least 128)", "tools/bench_ops.py, J = 8: factor_rev 1 x 512 0.38 -> 0.15 ms, 512 x 4096 3.0 -> 1.6 ms") \
+  X(long_min_rows, "C2_LONG_MIN_ROWS", 512, 't', "shortest series the chunk-map solves (with F / several right-hand sides) and the long-series reverse sweeps take (at least 128)", "1 x 4096 + F 0.60 -> 0.06 ms, 64 x 1024 0.13 -> 0.05 ms (tools/bench_ops.py)") \
+  X(rev_long, "C2_REV_LONG", 0, 's', "the four reverse sweeps as opposite sweep + per-row pass: 1 forces, 0 disables; unset: small batches of long series", "one series of 1e5 rows, J = 8: solve_lower_rev 18.3 -> 0.15 ms (profiles/r02_long_series_rocprof.md)") \
+  X(scan_min_rows, "C2_SCAN_MIN_ROWS", 1024, 't', "shortest series the chunked products (c2_scan.hip) take on batches of at most 128 series (at least 256)", "1 x 4096 0.60 -> 0.08 ms, 64 x 4096 0.63 -> 0.15 ms; 1024 x 2048 would lose (0.36 -> 1.01 ms)") \
+  X(scan_min_chunk, "C2_SCAN_MIN_CHUNK", 0, 's', "chunk length of the chunked products (at least 64); unset: the power of two next to 0.5 sqrt(N)", "one series, J = 8: 20000 rows 0.79 -> 0.16 ms, 1e5 rows 0.80 -> 0.32 ms") \
+  X(solve_chunk_col_ms, "C2_SOLVE_CHUNK_COL_MS", 0.05, 't', "cost model of the chunk-map solves: fixed cost (ms) of one right-hand side", "64 x 4096: 0.07 ms, 512 x 4096: 0.24 ms (tools/bench_ops.py)") \
+  X(solve_chunk_ms, "C2_SOLVE_CHUNK_MS", 6e-6, 't', "... cost (ms) per 64-row chunk and right-hand side", "same measurement") \
+  X(solve_row_us, "C2_SOLVE_ROW_US", 0.15, 't', "... against the row-by-row sweep: microseconds per row whatever the batch", "4096 rows: 0.63 ms with one right-hand side") \
+  X(solve_row_rhs_us, "C2_SOLVE_ROW_RHS_US", 0.025, 't', "... plus microseconds per row and right-hand side", "4096 rows: 1.29 ms with 8 right-hand sides") \
+  X(mfma, "C2_MFMA", 1, 's', "0: long-series products (J = 16; 16 / 32 / 64 right-hand sides) on the VALU instead of the fp64 matrix cores", "N = 1e7: 3.1 vs 9.2 ms (profiles/r02_ubench_memory_and_mfma.md)") \
+  X(general_tile, "C2_GENERAL_TILE", 1, 's', "0: general_matmul_* on the two-phase kernels instead of the row tiles", "B = 8192, N = M = 4096, nrhs = 1: 1.4 vs 4.05 ms (profiles/r02_general_matmul.md)") \
+  X(generalk, "C2_GENERALK", 1, 's', "0: general_matmul_* with five or more right-hand sides on the first-round kernels", "nrhs = 8: 7.0 vs 24.3 ms") \
+  X(general_chunks, "C2_GENERAL_CHUNKS", 1, 's', "0: never cut general_matmul_* on small batches of long series into chunks", "B = 1, N = M = 1e5: 32 -> 0.155 ms") \
+  X(sweepk_rev, "C2_SWEEPK_REV", 1, 's', "0: multi-rhs reverse sweeps on the lanes-over-J kernel instead of lanes over the right-hand sides", "nrhs = 8: 9.1 vs 21.5 ms") \
+  X(terms_fused, "C2_TERMS_FUSED", 0, 's', "coefficient-level log-likelihood: 1 forces the fused one-lane kernels (J = 8, 4, 2), 0 the composed chain; unset: by batch size", "65536 series: 21.1 ms fused; 8192 series: 9.2 ms composed") \
+  X(terms_fused_min_batch_fwd, "C2_TERMS_FUSED_MIN_BATCH_FWD", 16384, 't', "coefficient-level forward: fused kernels from this many series up", "tools/terms_time.py") \
+  X(terms_fused_min_batch_grad, "C2_TERMS_FUSED_MIN_BATCH_GRAD", 16384, 't', "coefficient-level gradient: fused kernels from this many series up", "tools/terms_time.py") \
+  X(kron_banded, "C2_KRON_BANDED", 1, 's', "0: the per-band passes of the 2-D collapsed method with a thread per epoch for every M", "1.66 + 2.31 -> 0.30 + 0.15 ms at 32 x 50000 x 16")
+
+namespace c2 {
+namespace opt {
+enum Id {
+#define C2_OPT_ENUM(id, env, def, kind, doc, src) k_##id,
+  C2_OPTIONS(C2_OPT_ENUM)
+#undef C2_OPT_ENUM
+      kCount
+};
+bool has(Id id);     // set explicitly: by the environment at load time or by c2_set_option
+double val(Id id);   // its value if set, the table's default otherwise
+inline long long ival(Id id) { return (long long)val(id); }
+}  // namespace opt
+}  // namespace c2

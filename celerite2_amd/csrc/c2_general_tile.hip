@@ -424,8 +424,7 @@ using namespace c2gt;
 
 // Chunks pay when the batch alone leaves most of the chip idle and the series are long enough to cut.
 static int tile_chunks(int64_t B, int64_t M) {
-  const char *e = getenv("C2_GENERAL_CHUNKS");   // 0: never; otherwise the automatic choice
-  if (e && e[0] == '0') return 1;
+  if (opt::has(opt::k_general_chunks) && opt::ival(opt::k_general_chunks) == 0) return 1;   // never; otherwise the automatic choice
   if (B >= 512 || M < 2048) return 1;
   int64_t C = (2048 + B - 1) / B;                // ~2 wavefronts per SIMD-quarter of the chip in flight
   if (C > 64) C = 64;

@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "../../include/celerite2_amd.h"
+#include "c2_dispatch.hpp"
 
 extern "C" void c2_internal_set_error(const char *msg);
 extern "C" int c2_internal_loglik_grad_rows(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
@@ -337,8 +338,7 @@ __global__ void k_kron_balpha(int64_t B, int M, int nch, const double *__restric
 }
 
 static bool use_banded() {
-  const char *e = getenv("C2_KRON_BANDED");   // 0: the thread-per-epoch kernels for every M (A/B runs, tests)
-  return !(e && e[0] == '0');
+  return !(c2::opt::has(c2::opt::k_kron_banded) && c2::opt::ival(c2::opt::k_kron_banded) == 0);   // 0: the thread-per-epoch kernels for every M (A/B runs, tests)
 }
 static void launch_collapse(int64_t B, int64_t N, int64_t M, const double *a, const double *alpha, int64_t alpha_bs,
                             const double *diag, const double *y, double *a_eff, double *y_eff, double *part,

@@ -757,9 +757,6 @@ using namespace c2;
 #ifndef C2_CKPT_C
 #define C2_CKPT_C 8   // checkpoint interval for G <= 8
 #endif
-#ifndef C2_LANES4_MIN_BATCH
-#define C2_LANES4_MIN_BATCH 16384   // forward-only two-columns-per-lane variant from this batch size up
-#endif
 #ifndef C2_FWD_R
 #define C2_FWD_R C2_CKPT_C   // prefetch ring length (rows); multiple of the checkpoint interval
 #endif
@@ -813,23 +810,16 @@ extern "C" int c2_internal_loglik4_grad(int64_t B, int64_t N, const double *t, i
 // the other (tests, benchmarks).
 static bool use_lanes4(int64_t B, int64_t J, bool grad) {
   if (J != 8) return false;
-  const char *e = getenv("C2_LANES");  // read per call: tests switch it at run time
-  const int forced = e ? atoi(e) : 0;
+  const int forced = opt::has(opt::k_lanes) ? (int)opt::ival(opt::k_lanes) : 0;
   if (forced == 4) return true;
   if (forced == 8 || forced == 1) return false;
-  return !grad && B >= C2_LANES4_MIN_BATCH;
+  return !grad && B >= opt::ival(opt::k_lanes4_min_batch);
 }
 
 // One lane per series (c2_loglik_t.hip, J == 8): 64 series per wavefront, so it takes 64 x 1024 series to put one
 // wavefront on every SIMD.  Measured on MI355X at N = 4096 (profiles/r02_lane_mappings.md): the forward-only kernel
 // wins from 24576 series up (3.3 vs 4.1 ms; 6.7 vs 10.4 ms at 65536), the gradient pair from 24576 up as well (15.7 vs
 // 16.0 ms; 17.2 vs 21.6 ms at 32768; 28.2 vs 41.8 ms at 65536).  C2_LANES=1 forces it.
-#ifndef C2_LANES1_MIN_BATCH_FWD
-#define C2_LANES1_MIN_BATCH_FWD 24576
-#endif
-#ifndef C2_LANES1_MIN_BATCH_GRAD
-#define C2_LANES1_MIN_BATCH_GRAD 24576
-#endif
 // the same kernels compiled per width (c2_loglik_t.hip with C2T_J = 8, 4, 2; 6 as 8 with two empty columns)
 #define C2_DECL_T(J_)                                                                                                  \
   extern "C" int c2_internal_loglik_t##J_(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,       \
@@ -860,39 +850,27 @@ extern "C" int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const
                                           unsigned long long *guard, c2_stream_t stream);
 // Measured at N = 4096 (tools/timepar_check.py): 0.34 ms per 1024 series at J = 4 (row by row: 0.87 ms up to ~4096
 // series), 0.17 ms at J = 2; linear in the batch beyond one wavefront per SIMD, so it pays up to ~2048 / ~4096 series.
-#ifndef C2_TIMEPAR_MIN_ROWS
-#define C2_TIMEPAR_MIN_ROWS 1536
-#endif
 // A handful of series (B * J <= 512: every driver.* call) is pure latency row by row -- 0.15-0.24 us per row -- against a
 // fixed 40-130 us of the three 64-step phases of the time-parallel form (tools/timepar_small_n.py: B = 1, 8, 64 alike):
 // log-likelihood / factor draw level at ~300 rows (J = 2) and ~600 (J = 4), the solves at ~256 / ~420 / ~900 (J = 8).
 static int64_t timepar_min_rows(int64_t B, int64_t J) {
-  if (B * J > 512) return C2_TIMEPAR_MIN_ROWS;
+  if (B * J > 512) return opt::ival(opt::k_timepar_min_rows);
   return J == 2 ? 384 : (J == 4 ? 704 : 1024);
 }
-#ifndef C2_TIMEPAR_MAX_BATCH_X_WIDTH
-#define C2_TIMEPAR_MAX_BATCH_X_WIDTH 8192
-#endif
 static bool use_timepar(int64_t B, int64_t N, int64_t J) {
   if (J != 4 && J != 2) return false;
-  const char *e = getenv("C2_TIMEPAR");
-  if (e) return atoi(e) != 0 && N >= 2;
-  const char *l = getenv("C2_LANES");
-  if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
-  return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
+  if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
+  if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
+  return N >= timepar_min_rows(B, J) && B * J <= opt::ival(opt::k_timepar_max_batch_x_width);
 }
 // the same decision for the single-rhs solves (affine maps: width 8 as well)
 extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   if (J != 8 && J != 4 && J != 2) return 0;
-  const char *e = getenv("C2_TIMEPAR");
-  if (e) return atoi(e) != 0 && N >= 2;
-  return N >= timepar_min_rows(B, J) && B * J <= C2_TIMEPAR_MAX_BATCH_X_WIDTH;
+  if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
+  return N >= timepar_min_rows(B, J) && B * J <= opt::ival(opt::k_timepar_max_batch_x_width);
 }
 // Time-parallel GRADIENT (c2_timepar_grad.hip; widths 1 .. 8): small batches of long series.
 // C2_TIMEPAR_GRAD=1 forces it, =0 disables it.
-#ifndef C2_TPG_ROWS16_MAX_ROWS
-#define C2_TPG_ROWS16_MAX_ROWS 4096
-#endif
 // compiled for chunks of 64, 32 and 16 rows; a handful of series (at most 4096 chunks of 64 rows) takes the shorter ones
 // -- 16 rows up to 4096 rows per series (one series of 4096 rows 0.92 -> 0.73 ms, 16 x 4096 0.96 -> 0.79 ms at J = 8), 32
 // rows beyond: chains of more than 256 chunks cost accuracy first (9000 rows: 1.3e-11 of the largest gradient entry against
@@ -933,11 +911,10 @@ C2_DECL_TPG(16)
 extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N);
 // 0: chunks of 64 rows, 1: of 32, 2: of 16
 extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N) {
-  const char *e = getenv("C2_TPG_ROWS");
-  if (e) return atoi(e) == 16 ? 2 : (atoi(e) == 32 ? 1 : 0);
+  if (opt::has(opt::k_tpg_rows)) return opt::ival(opt::k_tpg_rows) == 16 ? 2 : (opt::ival(opt::k_tpg_rows) == 32 ? 1 : 0);
   const int64_t k64 = B * ((N + 63) / 64);
   if (k64 > 4096) return 0;
-  return N <= C2_TPG_ROWS16_MAX_ROWS ? 2 : 1;   // the shortest chunks while the chains stay short
+  return N <= opt::ival(opt::k_tpg_rows16_max_rows) ? 2 : 1;   // the shortest chunks while the chains stay short
 }
 #define C2_TPG_PICK(stem) (c2_internal_tpg_short_chunks(B, N) == 2 ? stem##16 : (c2_internal_tpg_short_chunks(B, N) == 1 ? stem##32 : stem##64))
 static size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J) {
@@ -968,18 +945,23 @@ static int c2_internal_loglik_wide(int64_t B, int64_t N, int64_t J, const double
   return C2_TPG_PICK(c2_internal_loglik_wide)(B, N, J, t, t_bs, c, c_bs, a, U, V,
                                                                                          y, ll, flag, work, stream);
 }
-#ifndef C2_TIMEPAR_GRAD_MIN_ROWS
-#define C2_TIMEPAR_GRAD_MIN_ROWS 1024
-#endif
-#ifndef C2_TIMEPAR_GRAD_MAX_CHUNKS
-#define C2_TIMEPAR_GRAD_MAX_CHUNKS 32768
-#endif
+constexpr size_t kTimeparVerifyWords = 8;   // = kVerifyWords of c2_timepar_grad.hip: the head of its workspace layout
+// Diagnostics (tools/, tests): with a sink set, the verification words of the last time-parallel call are copied there
+// (8 doubles; stream-ordered).  Never set in production.
+static double *g_debug_sink = nullptr;
+extern "C" void c2_internal_set_debug_sink(double *device_ptr) { g_debug_sink = device_ptr; }
+extern "C" double *c2_internal_get_debug_sink() { return g_debug_sink; }
+// C2_VERIFY_FALLBACK=0 (diagnostics only): leave the result of the time-parallel form in place whatever its words say
+static bool verify_fallback_enabled() {
+  return !(opt::has(opt::k_verify_fallback) && opt::ival(opt::k_verify_fallback) == 0);
+}
+static void c2_internal_debug_capture(const double *words, const double *, hipStream_t s) {
+  if (g_debug_sink) (void)hipMemcpyAsync(g_debug_sink, words, kTimeparVerifyWords * sizeof(double), hipMemcpyDeviceToDevice, s);
+}
 static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return false;
-  const char *e = getenv("C2_TIMEPAR_GRAD");
-  if (e) return atoi(e) != 0 && N >= 2;
-  const char *l = getenv("C2_LANES");
-  if (l && atoi(l) != 0) return false;   // a forced lane mapping means the row-by-row kernels
+  if (opt::has(opt::k_timepar_grad)) return opt::ival(opt::k_timepar_grad) != 0 && N >= 2;
+  if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
   // Measured (tools/timepar_grad_time.py): one series of 1e5 rows 103 -> 6.0 ms at J = 8, 61 -> 1.6 ms at J = 2; 32 series
   // of 50000 rows at J = 6 57.6 -> 4.6 ms; 256 x 4096 at J = 8 4.3 -> 1.9 ms.  The chunks are walked one per lane with
   // strided rows, which stops paying once they fill the chip several times over (1024 x 4096: 3.0 vs 3.6 ms at J = 4).
@@ -988,38 +970,36 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // one series draws level below 200 rows: 256 rows 0.17 -> 0.13 ms at J = 2, 0.30 -> 0.22 at J = 6; 512 rows 0.54 -> 0.33
   // at J = 8, the same for 64 series)
   const bool handful = B * ((N + 63) / 64) <= 4096;
-  const int64_t min_rows = handful ? 256 : (J <= 2 ? 512 : (J >= 7 ? C2_TIMEPAR_GRAD_MIN_ROWS : 768));
+  const int64_t min_rows = handful ? 256 : (J <= 2 ? 512 : (J >= 7 ? opt::ival(opt::k_timepar_grad_min_rows) : 768));
   // (widths up to 4 would keep winning a little further -- 768 x 4096 at J = 4 2.97 -> 1.46 ms, 1024 x 4096 2.98 -> 2.44 ms
   // -- but not by enough to move the limit)
-  return N >= min_rows && B * ((N + 63) / 64) <= C2_TIMEPAR_GRAD_MAX_CHUNKS;
+  return N >= min_rows && B * ((N + 63) / 64) <= opt::ival(opt::k_timepar_grad_max_chunks);
 }
 // widths 1 .. 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it
 static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return false;
-  const char *e = getenv("C2_FACTOR_ITER");   // 1 forces it (every length; widths 4, 2: long series only), 0 disables it
-  if (e && atoi(e) == 0) return false;
+  const bool e = opt::has(opt::k_factor_iter);   // 1 forces it (every length; widths 4, 2: long series only), 0 disables it
+  if (e && opt::ival(opt::k_factor_iter) == 0) return false;
   // widths 4 and 2 have the composed linear-fractional maps of c2_timepar.hip, whose chain over the chunks is sequential:
   // the Newton iterations (chains in two levels) take over on long series -- J = 4: 1.67 -> 0.59 ms at 1e5 rows, 15.3 ->
   // 1.6 ms at 1e6 (0.45 vs 0.51 ms at 20000); J = 2: level at 1e5 rows (0.40 ms)
   if (J == 2 || J == 4) return N >= (J == 4 ? 32768 : 131072) && B * ((N + 63) / 64) <= 32768;
   if (e) return N >= 2;
-  const char *l = getenv("C2_LANES");
-  if (l && atoi(l) != 0) return false;
+  if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;
   // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,
   // 3.9 vs 29.5 ms at 1e5; 2.1 vs 19.9 ms for 32 series of 50000; with 64k chunks in flight (1024 x 4096) a pass no longer has a SIMD per wavefront: 2.3 vs 1.2 ms
   return N >= 2048 && B * ((N + 63) / 64) <= 32768;
 }
 static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 6 && J != 4 && J != 2) return false;
-  const char *e = getenv("C2_LANES");
-  const int forced = e ? atoi(e) : 0;
+  const int forced = opt::has(opt::k_lanes) ? (int)opt::ival(opt::k_lanes) : 0;
   if (forced == 1) return true;
   if (forced == 4 || forced == 8) return false;
   // width 6 (rows of 48 bytes: no aligned 128-byte runs) draws level later: gradient 18.5 vs 20.7 ms at 32768 series,
   // 17.2 vs 15.8 ms at 24576; 31.7 vs 41.6 ms at 65536 (forward 7.5 vs 10.8 ms)
-  if (grad && J == 6) return B >= 32768;
-  return B >= (grad ? C2_LANES1_MIN_BATCH_GRAD : C2_LANES1_MIN_BATCH_FWD);
+  if (grad && J == 6) return B >= opt::ival(opt::k_lanes1_min_batch_grad_j6);
+  return B >= opt::ival(grad ? opt::k_lanes1_min_batch_grad : opt::k_lanes1_min_batch_fwd);
 }
 
 extern "C" {
@@ -1168,8 +1148,7 @@ int c2_internal_factor_fused(int64_t B, int64_t N, int64_t J, const double *t, i
 // 256 x 2048 1.50 -> 0.70, 512 x 4096 3.00 -> 1.59; factor + S 1 x 1024 0.74 -> 0.40, 64 x 2048 1.22 -> 0.63, 512 x 4096
 // 2.43 -> 1.69 (1 x 512: 0.37 either way)
 static int64_t drop_in_long_rows() {
-  const char *e = getenv("C2_DROPIN_LONG_ROWS");
-  const int64_t v = e ? atoll(e) : 0;
+  const int64_t v = opt::ival(opt::k_dropin_long_rows);
   return v >= 128 ? v : 512;
 }
 static bool drop_in_long_shape(int64_t B, int64_t N) {
@@ -1179,13 +1158,17 @@ static bool drop_in_long_shape(int64_t B, int64_t N) {
 // factor_rev on a small batch of long series (widths 1 .. 8): the reverse pass of the time-parallel gradient with the
 // adjoints of d, W handed in (c2_timepar_grad.hip, run_factor_rev); the S workspace is not read -- the states are replayed
 // from d, W.  One series of 1e5 rows, J = 8: 73 ms row by row.  C2_TIMEPAR_GRAD=0 disables it.
+extern "C" int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                             int64_t c_bs, const double *U, const double *d, const double *W,
+                                             const double *S, const double *bd, const double *bW, double *bt, double *bc,
+                                             double *ba, double *bU, double *bV, const unsigned long long *gate,
+                                             c2_stream_t stream);
 extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                                           int64_t c_bs, const double *U, const double *d, const double *W, const double *bd,
-                                           const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV,
-                                           c2_stream_t stream) {
+                                           int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
+                                           const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
+                                           double *bV, c2_stream_t stream) {
   if (J < 1 || J > 8 || !drop_in_long_shape(B, N)) return C2_ERR_UNSUPPORTED;
-  const char *e = getenv("C2_TIMEPAR_GRAD");
-  if (e && atoi(e) == 0) return C2_ERR_UNSUPPORTED;
+  if (opt::has(opt::k_timepar_grad) && opt::ival(opt::k_timepar_grad) == 0) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
@@ -1198,6 +1181,12 @@ extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, cons
   }
   int rc = C2_TPG_PICK(c2_internal_factor_rev_timepar)(B, N, J, t, t_bs, c, c_bs, U, U, d, W, bd, bW, bt, bc, ba, bU, bV,
                                                        (double *)tmp, stream);
+  // verified on the device (word 0 of the scratch, c2_timepar_grad.hip): should the chunk boundaries disagree, the
+  // segment-replay kernel -- behind that word, empty otherwise -- recomputes the batch from the caller's S rows
+  if (rc == C2_OK && verify_fallback_enabled())
+    rc = c2_internal_factor_rev_replay(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV,
+                                       (const unsigned long long *)tmp, stream);
+  c2_internal_debug_capture((const double *)tmp, nullptr, s);
   if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
   return rc;
 }
@@ -1209,8 +1198,7 @@ extern "C" int c2_internal_factor_states_timepar(int64_t B, int64_t N, int64_t J
                                                  const double *V, double *d, double *W, double *S, int32_t *flag,
                                                  c2_stream_t stream) {
   if (J < 1 || J > 8 || !drop_in_long_shape(B, N) || d == a || W == V) return C2_ERR_UNSUPPORTED;
-  const char *e = getenv("C2_FACTOR_ITER");
-  if (e && atoi(e) == 0) return C2_ERR_UNSUPPORTED;
+  if (opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) == 0) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);
@@ -1239,9 +1227,9 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
     const size_t r = lanes1_record_doubles(B, N, J);
     n = 2 + (r > n ? r : n);
   }
-  if (use_timepar_grad(B, N, J)) {
-    const size_t r = c2_internal_timepar_grad_doubles(B, N, J);
-    n = r > n ? r : n;
+  if (use_timepar_grad(B, N, J)) {   // [verification words | its scratch, or the workspace of the gated row-by-row pair]
+    const size_t r = c2_internal_timepar_grad_doubles(B, N, J), f = grad_ws(B, N, J).total + kTimeparVerifyWords;
+    n = r > f ? r : f;
   }
   return n * sizeof(double);
 }
@@ -1275,9 +1263,18 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
   if (!t || !c || !a || !U || !V || !y || !ll || !bt || !bc || !ba || !bU || !bV || !by || !flag || !work)
     return C2_ERR_INVALID;
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
-  if (allow_timepar && use_timepar_grad(B, N, J))   // small batch of long series: parallel along time
-    return c2_internal_loglik_grad_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
-                                           (double *)work, stream);
+  if (allow_timepar && use_timepar_grad(B, N, J)) {   // small batch of long series: parallel along time
+    if (int e = c2_internal_loglik_grad_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
+                                                (double *)work, stream))
+      return e;
+    // ... verified on the device: word 0 of the workspace holds the worst disagreement at the chunk boundaries in units of
+    // half its tolerance (c2_timepar_grad.hip, k_verify_combine).  Beyond it the row-by-row pair below -- launched behind
+    // the word, empty otherwise -- recomputes the batch (the same outputs; its workspace overlays the scratch).
+    c2_internal_debug_capture((const double *)work, nullptr, (hipStream_t)stream);
+    if (!verify_fallback_enabled()) return C2_OK;
+    return c2_internal_loglik_grad_replay(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
+                                          (double *)work + kTimeparVerifyWords, (const unsigned long long *)work, stream);
+  }
   if (use_lanes4(B, J, true))
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   const unsigned long long *gate = nullptr;
@@ -1343,7 +1340,7 @@ int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double
 int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                   int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
                                   const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
-                                  double *bV, c2_stream_t stream) {
+                                  double *bV, const unsigned long long *gate, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
@@ -1353,11 +1350,11 @@ int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double 
     if (J == G)                                                                                                    \
       hipLaunchKernelGGL((k_loglik_rev<G, C, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, \
                          U, W, (const double2 *)nullptr, S, nseg, (const int32_t *)nullptr, bt, bc, ba, bU, bV,    \
-                         (double *)nullptr, d, bd, bW, (const unsigned long long *)nullptr);                       \
+                         (double *)nullptr, d, bd, bW, gate);                       \
     else                                                                                                           \
       hipLaunchKernelGGL((k_loglik_rev<G, C, true, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs,  \
                          U, W, (const double2 *)nullptr, S, nseg, (const int32_t *)nullptr, bt, bc, ba, bU, bV,    \
-                         (double *)nullptr, d, bd, bW, (const unsigned long long *)nullptr);                       \
+                         (double *)nullptr, d, bd, bW, gate);                       \
   } while (0)
   switch (G_) {
     case 1: C2_FREV(1, C2_CKPT_C); break;

@@ -1,6 +1,7 @@
 // c2_loglik_helpers.hpp -- device helpers shared by the fused log-likelihood kernels (c2_loglik.hip: one column per
 // lane; c2_loglik4.hip: two columns per lane).
 #pragma once
+#include "c2_dispatch.hpp"
 #include "c2_common.hpp"
 
 namespace c2 {

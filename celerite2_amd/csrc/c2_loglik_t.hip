@@ -75,23 +75,32 @@ __host__ __device__ constexpr int sym(int i, int j) { return i <= j ? sidx(i, j)
 // ---- records private to the fwd/rev pair, lane-major: every access is one contiguous run per wavefront ---------------
 //   W   : [wave][n][J/2][64] double2      (row n of W, two columns per 16-byte piece)
 //   DZ  : [wave][n][64] double2           ((d_n, z_n))
-//   CK  : [wave][k][NS + J][64] double    (state after row n_k: S packed, F)
+//   CK  : [wave][slot][NS + J][64] double (state after row n_slot: S packed, F), slots in the order written
+//   CKR : [wave][1 + slots] int32         (the number of slots the wavefront used, then the row n_slot of each)
 struct Rec {
-  size_t w, dz, ck, t, total;  // offsets / total in doubles
-  int64_t nck;              // checkpoints per series
+  size_t w, dz, ck, ckr, t, total;  // offsets / total in doubles
+  int64_t nck;                      // checkpoint slots per wavefront (capacity)
+  int64_t nreg;                     // ... of which the regular ones (rows C, 2C, ..., N-1)
 };
-// Checkpoints = state after rows C, 2C, ... and after the last row N-1: ceil((N-1)/C) of them; row n sits at
-// ck_index(n) (the last row takes the final slot whether or not it is a multiple of C).
+// Regular checkpoints = state after rows C, 2C, ... and after the last row N-1: ceil((N-1)/C) of them.  EXTRA checkpoints
+// re-anchor the backward recursion wherever it would otherwise have to invert a decay it cannot (a gap in time: a night,
+// a season): before row n is absorbed, if for ANY series of the wavefront max_j c_j * (t_n - t of the row behind its last
+// checkpoint) exceeds kGuard, the state of row n-1 is recorded -- for the whole wavefront, so the record stays lane-major
+// and the reverse sweep turns at wavefront-uniform rows.  After a long gap the decays are ~0 and the state is all but
+// reset, so nothing is lost by not walking across it.  Up to nreg extras per wavefront (shared grids and batches with a
+// few gappy series need a handful); a wavefront that runs out leaves its excess in the guard word and the replay kernels
+// take the batch, as before.
 __host__ __device__ inline int64_t n_ckpt(int64_t N) { return N >= 2 ? (N - 2) / C + 1 : 0; }
-__host__ __device__ inline int64_t ck_index(int64_t n, int64_t nck) { return (n % C == 0) ? n / C - 1 : nck - 1; }
 __host__ inline Rec rec_layout(int64_t B, int64_t N) {
   const size_t waves = ((size_t)B + kWave - 1) / kWave;
   Rec r;
-  r.nck = n_ckpt(N);
+  r.nreg = n_ckpt(N);
+  r.nck = 2 * r.nreg;
   r.w = 0;
   r.dz = r.w + waves * (size_t)N * J * kWave;
   r.ck = r.dz + waves * (size_t)N * 2 * kWave;
-  r.t = r.ck + waves * (size_t)r.nck * (NS + J) * kWave;
+  r.ckr = r.ck + waves * (size_t)r.nck * (NS + J) * kWave;
+  r.t = r.ckr + waves * (((size_t)r.nck + 2) / 2);   // int32 pairs, 8-byte aligned per wavefront
   r.total = r.t + waves * (size_t)N * kWave;
   return r;
 }
@@ -426,6 +435,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave) : nullptr;
   double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave) : nullptr;
   double *recCK = REC ? rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave : nullptr;
+  int32_t *recCKR = REC ? reinterpret_cast<int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)R.nck + 2) / 2)) : nullptr;
   double *recT = REC ? rec + R.t + (size_t)blockIdx.x * N * kWave : nullptr;  // the grid, lane-major like (d, z)
 
   // ---- row 0 --------------------------------------------------------------------------------------------------
@@ -449,7 +459,20 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   double prod = d, quad = z * z * rd;
   int eacc = 0;
   int32_t fl = 0;
-  double tseg = tprev, gmax = 0.0;  // guard: c_max * span of the current segment
+  int slot = 0, nextra = 0;            // wavefront-uniform: checkpoint slots written, extras among them
+  int64_t lastck = 0;                  // row of the last checkpoint (row 0: the recursion starts there)
+  auto write_ckpt = [&](int64_t row) __attribute__((always_inline)) {   // the state as it stands = state after `row`
+    double *ck = recCK + (size_t)slot * (NS + J) * kWave;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) st1_stream(&ck[k * kWave + lane], S[k]);
+#pragma unroll
+    for (int j2 = 0; j2 < J; ++j2) st1_stream(&ck[(NS + j2) * kWave + lane], F[j2]);
+    if (lane == 0) recCKR[1 + slot] = (int32_t)row;
+    ++slot;
+    lastck = row;
+  };
+  double tseg = tprev, gmax = 0.0;  // guard: c_max * (t_n - t of the row behind the last checkpoint), the span the
+                                    // backward recursion has to invert decays over
   if (REC) {
 #pragma unroll
     for (int q = 0; q < J / 2; ++q) recW[q * kWave + lane] = make_double2(w[2 * q], w[2 * q + 1]);
@@ -498,6 +521,18 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
             double an = tA[lane * SSTR + rs];
             double u[J], v[J], p[J];
             const double dt = tprev - tn;
+            if (REC) {
+              // the backward recursion reaches row n-1 from the next checkpoint above by inverting the decays of rows
+              // n+.. down to n+1 ... and of row n if the state of row n-1 is not on record: re-anchor there if some series
+              // of the wavefront could not afford that (wavefront-uniform decision)
+              if (lastck == n - 1) tseg = tn;   // the decay into the row behind a checkpoint is never inverted
+              if (__any(cmax * (tn - tseg) > kGuard) && nextra < (int)R.nreg) {
+                write_ckpt(n - 1);
+                ++nextra;
+                tseg = tn;
+              }
+              gmax = fmax(gmax, cmax * (tn - tseg));
+            }
             tprev = tn;
             if constexpr (TERMS) {
               an += tc.A0;
@@ -544,15 +579,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
               st2_stream(&recDZ[(size_t)n * kWave + lane], make_double2(d, z));
               st1_stream(&recT[(size_t)n * kWave + lane], tn);
               const bool seg_end = (n % C == 0) || (n == N - 1);
-              if (seg_end) {  // uniform over the wavefront
-                double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) st1_stream(&ck[k * kWave + lane], S[k]);
-#pragma unroll
-                for (int j2 = 0; j2 < J; ++j2) st1_stream(&ck[(NS + j2) * kWave + lane], F[j2]);
-                gmax = fmax(gmax, cmax * (tn - tseg));
-                tseg = tn;
-              }
+              if (seg_end) write_ckpt(n);  // uniform over the wavefront
             }
           }
         }
@@ -571,6 +598,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
       atomicMax(guard, (unsigned long long)__double_as_longlong(g));  // g >= 0: the bit pattern is monotone
     }
   }
+  if (REC && lane == 0) recCKR[0] = slot;
 }
 
 constexpr int kFwdLds = (2 * kWave * RSTR + 3 * kWave * SSTR) * 8;
@@ -726,6 +754,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
   const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave);
   const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave;
+  const int32_t *recCKR = reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)R.nck + 2) / 2));
   const double *recT = rec + R.t + (size_t)blockIdx.x * N * kWave;
   const bool failed = flag[b] != 0;  // NaN gradients for a failed factorisation (see k_loglik_rev)
   const double nan = __builtin_nan("");
@@ -819,8 +848,13 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   // AGPRs (aload: no arithmetic register in flight), all 80 loads are issued back to back and waited for ONCE.  (Through
   // arithmetic registers, each v_accvgpr_write being a scheduling barrier, the same loads were waited for in ~13 separate
   // groups, 2-3 us each under load: ~90k cycles per checkpoint, a quarter of the sweep.)
-  auto load_ckpt = [&](int64_t n) {
-    const double *ck = recCK + (size_t)ck_index(n, R.nck) * (NS + J) * kWave;
+  // (wavefront-uniform bookkeeping: the slots are consumed from the top; cknext = row of the next one down)
+  int slot = __builtin_amdgcn_readfirstlane(recCKR[0]) - 1;
+  int cknext = slot >= 0 ? __builtin_amdgcn_readfirstlane(recCKR[1 + slot]) : -1;
+  auto load_ckpt = [&]() {
+    const double *ck = recCK + (size_t)slot * (NS + J) * kWave;
+    --slot;
+    cknext = slot >= 0 ? __builtin_amdgcn_readfirstlane(recCKR[1 + slot]) : -1;
     const unsigned voff = (unsigned)lane * 8u;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -890,7 +924,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
     ta = t_fetch(nf - 1);
-    load_ckpt(nf);
+    load_ckpt();   // the top slot: row N-1
     lds_order();
 
 #ifdef C2T_PROF
@@ -1087,8 +1121,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       if (rs == 0) {  // row n-1 is the lowest row of its tile
         sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, FULL ? kWave - 1 : last);
         sc_flush(byb, N, n - 1, 0, N - 1, tBY, lane, FULL ? kWave - 1 : last);
-        if (n >= 2 && (n - 1) % C == 0) load_ckpt(n - 1);
       }
+      // the state of row n-1 is on record (a regular checkpoint every C rows, or an extra one in front of a gap in time):
+      // it replaces the recursed one
+      if ((int)(n - 1) == cknext) load_ckpt();
       C2T_TICK(5);
 #pragma unroll
       for (int j = 0; j < J; ++j) wa[j] = wb[j];

@@ -1123,8 +1123,7 @@ extern "C" int c2_internal_matmul_lower_mfma(int64_t B, int64_t N, int64_t J, in
                                              const double *d, const double *Y, double *Z, int zero_z,
                                              c2_stream_t stream);
 static bool use_mfma() {
-  const char *e = getenv("C2_MFMA");  // read per call: tests and A/B runs switch it at run time
-  return !(e && e[0] == '0');
+  return !(opt::has(opt::k_mfma) && opt::ival(opt::k_mfma) == 0);
 }
 
 extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J);
@@ -1146,16 +1145,14 @@ C2_DECL_SC(16)
 // shortest series the long-series forms of the solves with F / several right-hand sides and of the reverse sweeps take
 // (C2_LONG_MIN_ROWS overrides; measured below)
 static int64_t long_min_rows() {
-  const char *e = getenv("C2_LONG_MIN_ROWS");
-  const int64_t v = e ? atoll(e) : 0;
+  const int64_t v = opt::ival(opt::k_long_min_rows);
   return v >= 128 ? v : 512;
 }
 // shapes the chunked products of c2_scan.hip take: too few (series x rhs-tile) chains to fill the chip with the row-by-row
 // kernel, series long enough to cut (C2_SCAN_MIN_ROWS overrides the 1024)
 static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   const int64_t chains = B * ((nrhs + 3) / 4) * group_size(J);  // lanes kept busy by the sequential kernel
-  const char *me = getenv("C2_SCAN_MIN_ROWS");
-  const int64_t min_rows = me && atoll(me) >= 256 ? atoll(me) : 1024;
+  const int64_t min_rows = opt::ival(opt::k_scan_min_rows) >= 256 ? opt::ival(opt::k_scan_min_rows) : 1024;
   if (chains >= (int64_t)kWave * 2048) return false;
   // below 16384 rows the chunked form (~0.5 ns per row and series) must beat a walk of ~0.15 us per row whatever the
   // batch: one series of 4096 rows 0.60 -> 0.08 ms, 64 x 4096 0.63 -> 0.15, 256 x 4096 0.62 -> 0.48, 1024 x 2048 0.36 -> 1.01
@@ -1170,14 +1167,16 @@ static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   if (J > 8 || nrhs > 64 || N < long_min_rows()) return false;
   const int64_t k64 = B * ((N + 63) / 64);   // chunks of one launch: the right-hand sides run one after the other
   if (k64 > 32768) return false;
-  if (N >= 16384) return k64 * nrhs <= 32768 || nrhs * (0.05 + 6e-6 * (double)k64) < 1e-3 * (double)N * (0.15 + 0.025 * (double)nrhs);
-  // measured (ms): a column over k64 chunks 0.05 + 6e-6 k64 (64 x 4096: 0.07, 512 x 4096: 0.24); row by row
-  // N (0.15 + 0.025 nrhs) us whatever the batch (4096 rows: 0.63 with one right-hand side, 1.29 with 8)
-  return (double)nrhs * (0.05 + 6e-6 * (double)k64) < 1e-3 * (double)N * (0.15 + 0.025 * (double)nrhs);
+  // measured (ms; the constants live in c2_dispatch.hpp): a column over k64 chunks 0.05 + 6e-6 k64 (64 x 4096: 0.07,
+  // 512 x 4096: 0.24); row by row N (0.15 + 0.025 nrhs) us whatever the batch (4096 rows: 0.63 with one right-hand side,
+  // 1.29 with 8)
+  const double chunked_ms = (double)nrhs * (opt::val(opt::k_solve_chunk_col_ms) + opt::val(opt::k_solve_chunk_ms) * (double)k64);
+  const double rows_ms = 1e-3 * (double)N * (opt::val(opt::k_solve_row_us) + opt::val(opt::k_solve_row_rhs_us) * (double)nrhs);
+  if (N >= 16384) return k64 * nrhs <= 32768 || chunked_ms < rows_ms;
+  return chunked_ms < rows_ms;
 }
 static bool solve_chunks_enabled() {
-  const char *e = getenv("C2_TIMEPAR");   // the switch of the time-parallel solves: 0 keeps them row by row
-  return !(e && atoi(e) == 0);
+  return !(opt::has(opt::k_timepar) && opt::ival(opt::k_timepar) == 0);   // the switch of the time-parallel solves: 0 keeps them row by row
 }
 template <bool LOWER, bool SOLVE>
 static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,
@@ -1199,10 +1198,9 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
       // chunk length: the walks of the chunks shrink with Lc, the fold of their carries (one step per chunk) grows with
       // N / Lc -- the power of two next to 0.5 sqrt(N), longer once ~2048 units per rhs slab are in flight (one series, J = 8: 20000 rows 0.79 -> 0.16 ms at Lc = 128, 1e5 rows 0.80 -> 0.31
       // at 256, 1e6 rows 1.28 -> 1.18 at 512; C2_SCAN_MIN_CHUNK overrides)
-      const char *le = getenv("C2_SCAN_MIN_CHUNK");
       int64_t Lc = 64;
       while (Lc < 1024 && 4 * Lc * Lc < N) Lc *= 2;
-      if (le && atoll(le) >= 64) Lc = atoll(le);
+      if (opt::has(opt::k_scan_min_chunk) && opt::ival(opt::k_scan_min_chunk) >= 64) Lc = opt::ival(opt::k_scan_min_chunk);
       while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
       return c2_internal_matmul_chunked(LOWER ? 1 : 0, B, N, J, nrhs, Lc, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
                                         stream);
@@ -1276,12 +1274,10 @@ extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t
                                         double *F, double *scratch, c2_stream_t stream);
 extern "C" size_t c2_internal_general_tile_doubles(int64_t B, int64_t M, int64_t J, int64_t nrhs);
 static bool use_general_tile() {
-  const char *e = getenv("C2_GENERAL_TILE");  // C2_GENERAL_TILE=0: the kernels below (A/B runs, tests of every path)
-  return !(e && e[0] == '0');
+  return !(opt::has(opt::k_general_tile) && opt::ival(opt::k_general_tile) == 0);   // 0: the kernels below (A/B runs, tests of every path)
 }
 static bool use_generalK() {
-  const char *e = getenv("C2_GENERALK");  // C2_GENERALK=0: the first-round kernels (A/B runs, tests of both paths)
-  return !(e && e[0] == '0');
+  return !(opt::has(opt::k_generalk) && opt::ival(opt::k_generalk) == 0);   // 0: the first-round kernels (A/B runs, tests of both paths)
 }
 template <bool LOWER>
 static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1, int64_t t1_bs,
@@ -1373,7 +1369,8 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     return C2_ERR_INVALID;
   hipStream_t s = (hipStream_t)stream;
   {   // a small batch of LONG series: the opposite sweep (parallel along time for these shapes) + a pass local to the rows
-    const char *ev = getenv("C2_REV_LONG");   // 0: keep the row-by-row kernels (A/B runs)
+    const bool rl_set = opt::has(opt::k_rev_long);   // 0: keep the row-by-row kernels (A/B runs); 1 forces the form
+    const bool rl_off = rl_set && opt::ival(opt::k_rev_long) == 0, rl_on = rl_set && opt::ival(opt::k_rev_long) == 1;
     // the per-row pass costs ~0.5 ns per row and series, the row-by-row kernel ~0.17 us per row whatever the batch:
     // 64 x 1024 0.18 -> 0.07 ms, 256 x 4096 0.87 -> 0.58, 512 x 1024 0.20 -> 0.33 (not taken)
     // (whatever form the opposite sweep takes below 16384 rows: row by row it still costs a third of the reverse kernel --
@@ -1385,7 +1382,7 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     const bool small = N >= (SOLVE ? long_min_rows() : 1024) && B <= bmax && (N >= 2048 || N >= 8 * B);
     const bool fits = SOLVE ? (solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled())
                             : matmul_chunked_shape(B, N, J, nrhs);
-    const bool on = !(ev && ev[0] == '0') && B <= 0xffff && ((ev && ev[0] == '1') || (N >= 16384 ? fits : small));   // 1 forces it
+    const bool on = !rl_off && B <= 0xffff && (rl_on || (N >= 16384 ? fits : small));
     if (on) {
       const int e = c2_internal_sweep_rev_long(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F,
                                                bZ, bt, bc, bU, bV, bY, stream);
@@ -1396,8 +1393,7 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     return c2_internal_sweep1_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU,
                                   bV, bY, stream);
   {  // several right-hand sides: lanes over them (c2_sweep_rev.hip) where the shape fits; C2_SWEEPK_REV=0 for A/B runs
-    const char *ev = getenv("C2_SWEEPK_REV");
-    if (!(ev && ev[0] == '0')) {
+    if (!(opt::has(opt::k_sweepk_rev) && opt::ival(opt::k_sweepk_rev) == 0)) {
       const int e = c2_internal_sweepK_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ,
                                            bt, bc, bU, bV, bY, stream);
       if (e != C2_ERR_UNSUPPORTED) return e;
@@ -1491,7 +1487,7 @@ int c2_general_matmul_upper(int64_t B, int64_t N, int64_t M, int64_t J, int64_t 
 int c2_internal_factor_rev_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                   int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
                                   const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
-                                  double *bV, c2_stream_t stream);
+                                  double *bV, const unsigned long long *gate, c2_stream_t stream);
 
 int c2_factor_rev_acc(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                       const double *U, const double *d, const double *W, const double *S, const double *bd,
@@ -1506,9 +1502,9 @@ int c2_factor_rev_acc(int64_t B, int64_t N, int64_t J, const double *t, int64_t 
 }
 
 extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
-                                           int64_t c_bs, const double *U, const double *d, const double *W, const double *bd,
-                                           const double *bW, double *bt, double *bc, double *ba, double *bU, double *bV,
-                                           c2_stream_t stream);
+                                           int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
+                                           const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
+                                           double *bV, c2_stream_t stream);
 int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                   const double *a, const double *U, const double *V, const double *d, const double *W,
                   const double *S, const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
@@ -1517,11 +1513,11 @@ int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !U || !d || !W || !S || !bd || !bW || !bt || !bc || !ba || !bU || !bV) return C2_ERR_INVALID;
   {   // a small batch of long series: parallel along time
-    const int e = c2_internal_factor_rev_long(B, N, J, t, t_bs, c, c_bs, U, d, W, bd, bW, bt, bc, ba, bU, bV, stream);
+    const int e = c2_internal_factor_rev_long(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, stream);
     if (e != C2_ERR_UNSUPPORTED) return e;
   }
   // the segment-replay kernel of the fused gradient, with the caller's S rows as checkpoints (c2_loglik.hip)
-  return c2_internal_factor_rev_replay(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, stream);
+  return c2_internal_factor_rev_replay(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, nullptr, stream);
 }
 
 int c2_solve_lower_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,

@@ -224,12 +224,6 @@ int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double
                                    double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
                                    int32_t *flag, void *work, const unsigned long long *gate, c2_stream_t stream);
 }
-#ifndef C2_TERMS_FUSED_MIN_BATCH_FWD
-#define C2_TERMS_FUSED_MIN_BATCH_FWD 16384
-#endif
-#ifndef C2_TERMS_FUSED_MIN_BATCH_GRAD
-#define C2_TERMS_FUSED_MIN_BATCH_GRAD 16384
-#endif
 static bool fused_width(int64_t J) { return J == 8 || J == 4 || J == 2; }
 static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
   return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
@@ -237,9 +231,8 @@ static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
 }
 static bool use_fused(int64_t B, int64_t J, bool grad) {
   if (!fused_width(J)) return false;
-  const char *e = getenv("C2_TERMS_FUSED");
-  if (e) return atoi(e) != 0;
-  return B >= (grad ? C2_TERMS_FUSED_MIN_BATCH_GRAD : C2_TERMS_FUSED_MIN_BATCH_FWD);
+  if (c2::opt::has(c2::opt::k_terms_fused)) return c2::opt::ival(c2::opt::k_terms_fused) != 0;
+  return B >= c2::opt::ival(grad ? c2::opt::k_terms_fused_min_batch_grad : c2::opt::k_terms_fused_min_batch_fwd);
 }
 
 static int matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr, const double *ac,

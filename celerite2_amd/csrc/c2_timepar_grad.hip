@@ -43,12 +43,15 @@ extern "C" int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, cons
                                            double *W, int32_t *flag, int allow_timepar, double *scratch,
                                            c2_stream_t stream);
 extern "C" size_t c2_internal_factor_scratch_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" double *c2_internal_get_debug_sink();   // diagnostics (c2_loglik.hip)
 
 // 1: the dispatch's choice of factor kernels (widths 4 / 2 below 32768 rows: the composed maps of c2_timepar.hip, verified
-// to 5e-11 -- gradients to ~4e-12 of their largest entry, 5e-11 on ill-conditioned series); 2: Newton iterations at
-// every width (1e-13; 0.30 -> 0.48 ms for one series of 4096 rows at J = 2)
+// to 5e-11 only -- which the gradient inherits: 1.5e-10 / 6.5e-11 of the largest gradient entry on two WELL-conditioned
+// draws of the round-2 stress run, tests/test_gpu_fuzz.py::test_time_parallel_gradient_known_hard_draws); 2 (default
+// since round 3): Newton iterations at every width (1e-13 or better, conditioning-aware; 0.30 -> 0.48 ms for one series
+// of 4096 rows at J = 2)
 #ifndef C2TG_FACTOR_MODE
-#define C2TG_FACTOR_MODE 1
+#define C2TG_FACTOR_MODE 2
 #endif
 
 // The file is compiled once per chunk length: C2TG_ROWS = 64 (default) and 32 (c2_timepar_grad32.hip includes it) -- a
@@ -342,6 +345,37 @@ __global__ __launch_bounds__(kWave) void k_starts_apply(int64_t N, int64_t K, co
   }
 }
 
+// ---- verification words ---------------------------------------------------------------------------------------------------
+// Nothing above or below is approximated, but every chain over the chunks sums in another order than the row-by-row
+// recursion, so -- like the forward pass of c2_timepar.hip -- the result is VERIFIED on the device rather than trusted: the
+// sweep that writes the gradients (k_final) walks every chunk with the ordinary recursions from the start state / end adjoint
+// the chains gave it, so comparing what a chunk arrives at with what its neighbour was given bounds the distance to the
+// sequential recursion (which is these same walks with the neighbours agreeing exactly).  vw[0]: the gate, written by
+// k_verify_combine: worst mismatch / (kVerifyTol / 2), i.e. above kBackwardGuard = 2 <=> the row-by-row kernels launched
+// behind it run (gate_closed); vw[1]: S at the chunk boundaries, relative to sqrt(S_ii S_jj); vw[2]: the adjoints (bS, bF),
+// weighted with the state they pair with; vw[3]: kappa = max a_n / d_n (informational); vw[4]: F at the chunk boundaries in
+// units of sqrt(S_jj); vw[5]: the solve's state at the chunk boundaries (k_solve_apply), in units of the terms of z.
+constexpr double kVerifyTol = 1e-11;
+constexpr int kVerifyWords = 8;
+constexpr int kNewtonMax = 8;                       // Newton iterations of the factor at most (below)
+constexpr int kNewtonHdr = 2 * (kNewtonMax + 2);   // its words[0 .. kNewtonMax + 1]: the iterations' updates; then their kappas
+__device__ __forceinline__ void publish_max(unsigned long long *w, double v) {   // (every lane of the wavefront calls it)
+  v = (v == v) ? v : __builtin_huge_val();   // a NaN opens the gate
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, kWave));
+  if (threadIdx.x == 0 && v > 0.0) atomicMax(w, (unsigned long long)__double_as_longlong(v));
+}
+// cond_limit > 0 (option timepar_cond_limit): a conditioning kappa beyond it opens the gate as well
+__global__ void k_verify_combine(unsigned long long *vw, double cond_limit) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double es = __longlong_as_double((long long)vw[1]), eb = __longlong_as_double((long long)vw[2]);
+  const double ef = __longlong_as_double((long long)vw[4]), ez = __longlong_as_double((long long)vw[5]);
+  const double kap = __longlong_as_double((long long)vw[3]);
+  double worst = fmax(fmax(es, eb), fmax(ef, ez)) / (0.5 * kVerifyTol);
+  if (cond_limit > 0.0 && kap > cond_limit) worst = fmax(worst, 2.0 * kap / cond_limit + 1.0);
+  vw[0] = (unsigned long long)__double_as_longlong(worst);
+}
+
 // ---- the adjoint step ---------------------------------------------------------------------------------------------------
 // (bS, bF): adjoint of the state entering row n+1 on entry, of the state entering row n on exit.  p: decay between the
 // two rows (1 behind the last row).  SRC: with the sources of the log-likelihood (d ll/d z = -z/d, d ll/d d).
@@ -584,6 +618,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
                                                  double *__restrict__ dT, double *__restrict__ bcp,
                                                  double *__restrict__ ba, double *__restrict__ bU,
                                                  double *__restrict__ bV, double *__restrict__ by,
+                                                 unsigned long long *__restrict__ vw,
                                                  const double *__restrict__ bde = nullptr,
                                                  const double *__restrict__ bwe = nullptr) {
   constexpr int NS = Dim<J>::NS, NST = Dim<J>::NST;
@@ -599,7 +634,9 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
   const double nan = __builtin_nan("");
 
   // forward replay: the states entering the rows, then the one entering the row behind the chunk
-  double Sn[NS], Fn[J];
+  double Sn[NS], Fn[J], smx[J], fmx[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { smx[j] = 0.0; fmx[j] = 0.0; }
   {
     const double *s = start + G.g * NST;
 #pragma unroll
@@ -621,6 +658,11 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
         for (int j = 0; j < J; ++j) o[(size_t)(NS + j) * kWave] = Fn[j];
         double p[J];
         absorb<J>(Sn, Fn, cur.w, cur.d, EXT ? 0.0 : cur.z);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {   // the units of the verification below: the largest S_jj, |F_j| of the chunk's rows
+          smx[j] = fmax(smx[j], Sn[sidx(J, j, j)]);
+          fmx[j] = fmax(fmx[j], fabs(Fn[j]));
+        }
         if (G.lo + r + 1 < N) {
 #pragma unroll
           for (int j = 0; j < J; ++j) p[j] = exp_decay(-cj[j] * cur.dt);
@@ -631,6 +673,26 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
     }
   }
   // Sn, Fn: state entering row lo + len (meaningless behind the last row of the series, where the adjoint is zero)
+  {   // ... which the scan over the chunks gave to the next chunk as its start state
+    double es = 0.0, ef = 0.0;
+    if (G.len > 0 && G.k + 1 < K && !failed) {
+      // (in units of the chunk's own rows, not of the boundary: behind a gap in time the state there is ~0)
+      const double *s = start + (G.g + 1) * NST;
+      double sd[J];
+#pragma unroll
+      for (int i = 0; i < J; ++i) sd[i] = sqrt(smx[i]);
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+#pragma unroll
+        for (int j = i; j < J; ++j)
+          es = fmax(es, fabs(Sn[sidx(J, i, j)] - s[sidx(J, i, j)]) / fmax(sd[i] * sd[j], 1e-300));
+        if constexpr (!EXT) ef = fmax(ef, fabs(Fn[i] - s[NS + i]) / fmax(fmax(fmx[i], sd[i]), 1e-300));
+      }
+    }
+    publish_max(vw + 1, es);
+    publish_max(vw + 4, ef);
+  }
+  double kap = 0.0, bsm = 0.0, bfm = 0.0;   // largest a_n / d_n, |bS_ii| S_ii, bF_i^2 S_ii over the chunk's rows
   double bS[NS], bF[J], bcj[J];
   {
     const double *e = ends + G.g * NST;
@@ -681,7 +743,7 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
 #pragma unroll
       for (int j = 0; j < J; ++j) Fn[j] = Fm[j];
       // bU_n = -bz F_n - bd tau_n + S_n btau,  tau_n = v_n - d_n w_n
-      double bu[J];
+      double bu[J], ut = 0.0;   // ut = u_n tau_n = a_n - d_n
 #pragma unroll
       for (int i = 0; i < J; ++i) {
         double s;
@@ -690,13 +752,22 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
 #pragma unroll
           for (int jj = 0; jj < J; ++jj) tau = fma(Sn[sym(J, i, jj)], cur.u[jj], tau);
           s = -ro.bd * tau;
+          ut = fma(cur.u[i], tau, ut);
         } else {
-          s = fma(-ro.bz, Fn[i], -ro.bd * fma(-dn, cur.w[i], cur.v[i]));
+          const double tau = fma(-dn, cur.w[i], cur.v[i]);
+          s = fma(-ro.bz, Fn[i], -ro.bd * tau);
+          ut = fma(cur.u[i], tau, ut);
         }
 #pragma unroll
         for (int jj = 0; jj < J; ++jj) s = fma(Sn[sym(J, i, jj)], btau[jj], s);
         bu[i] = failed ? nan : s;
         g2[i] = failed ? nan : g2[i];
+      }
+      kap = fmax(kap, 1.0 + fabs(ut) * rd);
+#pragma unroll
+      for (int i = 0; i < J; ++i) {   // (bS, bF: adjoint of the state entering row n; Sn: that state)
+        bsm = fmax(bsm, fabs(bS[sidx(J, i, i)]) * Sn[sidx(J, i, i)]);
+        if constexpr (!EXT) bfm = fmax(bfm, bF[i] * bF[i] * Sn[sidx(J, i, i)]);
       }
       store_row<J>(bUb + n * J, bu);
       store_row<J>(bVb + n * J, g2);
@@ -709,6 +780,28 @@ __global__ __launch_bounds__(kWave) void k_final(int64_t B, int64_t N, int64_t K
   if (G.len > 0) {
 #pragma unroll
     for (int j = 0; j < J; ++j) bcp[G.g * J + j] = bcj[j];
+  }
+  {   // (bS, bF): adjoint of the state entering row lo -- what the chain over the chunks gave to the chunk in front of this
+      // one as its end adjoint; weighted with the state it pairs with (Sn is back at the state entering row lo)
+    double eb = 0.0;
+    if (G.len > 0 && G.k > 0 && !failed) {
+      // in units of the largest weighted adjoint of the chunk's rows (at one boundary an adjoint may pass through zero)
+      const double *e = ends + (G.g - 1) * NST;
+      double sd[J], num = 0.0, numf = 0.0;
+#pragma unroll
+      for (int i = 0; i < J; ++i) sd[i] = sqrt(fabs(Sn[sidx(J, i, i)]));
+#pragma unroll
+      for (int i = 0; i < J; ++i) {
+#pragma unroll
+        for (int j = i; j < J; ++j)
+          num = fmax(num, fabs(bS[sidx(J, i, j)] - e[sidx(J, i, j)]) * (sd[i] * sd[j]));
+        if constexpr (!EXT) numf = fmax(numf, fabs(bF[i] - e[NS + i]) * sd[i]);
+      }
+      eb = num > 0.0 ? num / fmax(bsm, 1e-300) : 0.0;
+      if constexpr (!EXT) eb = fmax(eb, numf > 0.0 ? numf / fmax(sqrt(bfm), 1e-300) : 0.0);
+    }
+    publish_max(vw + 2, eb);
+    publish_max(vw + 3, failed ? 0.0 : kap);
   }
 }
 
@@ -899,7 +992,9 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
                                                        const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                        const double *__restrict__ W, const double *__restrict__ y,
                                                        int64_t ys, const double *__restrict__ Fst, double *__restrict__ z,
-                                                       double *__restrict__ Fw, int64_t fs) {
+                                                       double *__restrict__ Fw, int64_t fs,
+                                                       unsigned long long *__restrict__ vw,
+                                                       const int32_t *__restrict__ flag) {
   // Fw (optional): this right-hand side's J entries of the reference's workspace rows, Fw[row fs + j] -- the state of the row
   // before its decay, in both directions (internal.hpp:140-141, 179-180: update_workspace precedes Fn = p Fn)
   const Geo G = chunk_of(B, N, K);
@@ -910,6 +1005,9 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
   double *zb = z + G.b * N * ys;
   double *fb = Fw ? Fw + G.b * N * fs : nullptr;
   RowIn<J, true, false> cur, nxt;
+  double ul[J], yl = 0.0;   // |u|, |y| of the chunk's last row: the units of the verification below
+#pragma unroll
+  for (int j = 0; j < J; ++j) ul[j] = 0.0;
   fetch_row<J, true, false, REV>(cur, G, N, 0, tb, Ub, nullptr, Wb, yb, yb, ys);
   if (fb && G.len > 0 && G.lo == 0) {   // the first row of the walk carries no state
 #pragma unroll
@@ -925,6 +1023,11 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
       const double zn = cur.z - uf;
       const int64_t pos = G.lo + r, n = REV ? N - 1 - pos : pos;
       zb[n * ys] = zn;
+      if (vw && r == G.len - 1) {
+        yl = fabs(cur.z);
+#pragma unroll
+        for (int j = 0; j < J; ++j) ul[j] = fabs(cur.u[j]);
+      }
 #pragma unroll
       for (int i = 0; i < J; ++i) F[i] = fma(cur.w[i], zn, F[i]);
       if (fb && pos + 1 < N) {   // the state of the next row of the walk, before its decay
@@ -936,6 +1039,20 @@ __global__ __launch_bounds__(kWave) void k_solve_apply(int64_t B, int64_t N, int
       for (int i = 0; i < J; ++i) F[i] *= exp_decay(-cj[i] * cur.dt);
     }
     cur = nxt;
+  }
+  if (vw) {   // F: the state entering the next chunk's first row -- what the chain gave that chunk to start from?
+    double ez = 0.0;
+    if (G.len > 0 && G.k + 1 < K && !(flag && flag[G.b] != 0)) {   // (a failed factorisation: W is not a solve's W)
+      double num = 0.0, den = yl;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const double fn = Fst[(G.g + 1) * J + j];
+        num = fma(ul[j], fabs(F[j] - fn), num);
+        den = fma(ul[j], fabs(fn), den);
+      }
+      ez = num > 0.0 ? num / fmax(den, 1e-300) : 0.0;
+    }
+    publish_max(vw, ez);
   }
 }
 
@@ -962,7 +1079,8 @@ __global__ __launch_bounds__(kWave) void k_ll_series(int64_t N, int64_t K, const
 template <int J, bool REV = false>
 static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                          const double *U, const double *W, const double *y, double *z, double *scratch, hipStream_t s,
-                         int64_t ys = 1, bool with_phi = true, double *Fw = nullptr, int64_t fs = 0) {
+                         int64_t ys = 1, bool with_phi = true, double *Fw = nullptr, int64_t fs = 0,
+                         unsigned long long *vw = nullptr, const int32_t *flag = nullptr) {
   // ys > 1: one column of a row-major Y / Z; with_phi = false: Phi (and its block products) of an earlier call with the
   // same series are still in the scratch
   const size_t BK = (size_t)B * K;
@@ -986,11 +1104,11 @@ static void solve_chunks(int64_t B, int64_t N, int64_t K, const double *t, int64
                        (const double *)gk, Fst);
   }
   hipLaunchKernelGGL((k_solve_apply<J, REV>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, W, y, ys,
-                     (const double *)Fst, z, Fw, fs);
+                     (const double *)Fst, z, Fw, fs, vw, flag);
 }
 
 struct Layout {
-  size_t d, W, z, loc, start, ends, map, sf, dT, bcp, llp, fs, total;
+  size_t vw, d, W, z, loc, start, ends, map, sf, dT, bcp, llp, fs, total;
 };
 template <int J>
 static Layout layout(int64_t B, int64_t N) {
@@ -1000,6 +1118,7 @@ static Layout layout(int64_t B, int64_t N) {
   Layout L;
   size_t o = 0;
   auto take = [&](size_t n) { const size_t at = o; o += (n + 1) & ~(size_t)1; return at; };   // 16-byte aligned pieces
+  L.vw = take(kVerifyWords);   // (first: the caller gates its row-by-row kernels on word 0 of the workspace)
   L.d = take(BN); L.W = take(BN * J); L.z = take(BN);
   L.loc = take(BK * NST); L.start = take(BK * NST); L.ends = take(BK * NST);
   L.map = take(BK * MAPR);
@@ -1021,13 +1140,17 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
   const Layout L = layout<J>(B, N);
   const int64_t K = (N + kRows - 1) / kRows;
   double *d = work + L.d, *W = work + L.W, *z = work + L.z;
+  unsigned long long *vw = reinterpret_cast<unsigned long long *>(work + L.vw);
+  if (hipMemsetAsync(vw, 0, kVerifyWords * sizeof(double), s) != hipSuccess) return C2_ERR_HIP;
   if (int e = c2_internal_factor_fused_ws(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, C2TG_FACTOR_MODE, work + L.fs,
                                           (c2_stream_t)s))
     return e;
+  if (double *sink = c2_internal_get_debug_sink())   // (diagnostics: the factor's iteration words, behind the 8 verification words)
+    (void)hipMemcpyAsync(sink + kVerifyWords, work + L.fs, kNewtonHdr * sizeof(double), hipMemcpyDeviceToDevice, s);
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
   // z by the chunk maps (allocation-free, so the whole call can be captured in a graph; scratch: the record of the states,
   // which k_final fills afterwards)
-  solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.sf, s);
+  solve_chunks<J>(B, N, K, t, t_bs, c, c_bs, U, W, y, z, work + L.sf, s, 1, true, nullptr, 0, vw + 5, flag);
   hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, (const double *)d, (const double *)W,
                      (const double *)z, work + L.loc, work + L.llp);
   if (K >= kTwoLevelMin) {   // (the prefix maps live in the region of the adjoint maps, written later)
@@ -1057,7 +1180,8 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
                        work + L.ends);
   hipLaunchKernelGGL((k_final<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, V, (const double *)d, (const double *)W,
                      (const double *)z, (const double *)(work + L.start), (const double *)(work + L.ends),
-                     (const int32_t *)flag, work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, by);
+                     (const int32_t *)flag, work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, by, vw);
+  hipLaunchKernelGGL(k_verify_combine, dim3(1), dim3(1), 0, s, vw, opt::val(opt::k_timepar_cond_limit));
   hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, s, B, N,
                      (const double *)(work + L.dT), (const int32_t *)flag, bt);
   hipLaunchKernelGGL((k_finish_c<J>), dim3((unsigned)(B * J)), dim3(kWave), 0, s, K, (const double *)(work + L.bcp),
@@ -1079,6 +1203,16 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
 // the previous word as its gate -- once it is below kNewtonTol, with d, W of that pass final.  If the last iteration still
 // moves, or a pass met a d that is not positive and finite, the caller's row-by-row kernel runs behind the last word.
 constexpr double kNewtonTol = 1e-13;
+// ... relative to sqrt(X_ii X_jj).  An error rho of X moves d_n = a_n - u_n X u_n^T by ~rho (a_n - d_n), i.e. by rho * kappa_n
+// RELATIVE to d_n with kappa_n = a_n / d_n (1600 on the two series of the 6030-seed stress run of round 2 that missed 1e-10:
+// the update that ended their iterations was just below 1e-13).  Every pass therefore measures kappa = max a_n / d_n into
+// the iteration's second word and the chains stop at  min(kNewtonTol, kNewtonCondTol / kappa)  instead: d, W good to
+// kNewtonCondTol whatever the conditioning, or -- if rounding keeps the updates above that -- the row-by-row kernel.
+constexpr double kNewtonCondTol = 1e-11;
+__device__ __forceinline__ double newton_tol(const unsigned long long *kapw) {
+  const double kap = __longlong_as_double((long long)*kapw);
+  return fmin(kNewtonTol, kNewtonCondTol / fmax(kap, 1.0));
+}
 template <int J>
 __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -1088,11 +1222,13 @@ __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int
                                                        const double *__restrict__ X, double *__restrict__ E,
                                                        double *__restrict__ Phi,
                                                        const unsigned long long *__restrict__ gate,
-                                                       unsigned long long *__restrict__ word) {
+                                                       unsigned long long *__restrict__ word,
+                                                       unsigned long long *__restrict__ kapw) {
   constexpr int NS = Dim<J>::NS;
   if (gate_closed(gate)) return;
   const Geo G = chunk_of(B, N, K);
   double cj[J];
+  double kap = 0.0;   // max a_n / d_n over the rows of the chunk
 #pragma unroll
   for (int j = 0; j < J; ++j) cj[j] = c[G.b * c_bs + j];
   const double *tb = t + G.b * t_bs, *ab = a + G.b * N, *Ub = U + G.b * N * J, *Vb = V + G.b * N * J;
@@ -1136,6 +1272,7 @@ __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int
       }
       bad = bad || !(dn > 0.0) || !(dn < __builtin_huge_val());
       const double rd = 1.0 / dn;
+      kap = fmax(kap, fabs(av * rd));
 #pragma unroll
       for (int i = 0; i < J; ++i) { w[i] = (v[i] - tau[i]) * rd; p[i] = exp_decay(-cj[i] * dt); }
       db[n] = dn;
@@ -1169,6 +1306,10 @@ __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int
   }
   if (__any(bad) && threadIdx.x == 0)
     atomicMax(word, (unsigned long long)__double_as_longlong(__builtin_huge_val()));
+  if (!(kap < __builtin_huge_val())) kap = 0.0;   // (a bad pivot already opened the word above)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) kap = fmax(kap, __shfl_xor(kap, o, kWave));
+  if (threadIdx.x == 0 && kap > 0.0) atomicMax(kapw, (unsigned long long)__double_as_longlong(kap));
 }
 
 // One wavefront per series; lane (i, j) = entry of the J x J update.
@@ -1176,7 +1317,8 @@ template <int J>
 __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__restrict__ X, const double *__restrict__ E,
                                                         const double *__restrict__ Phi,
                                                         const unsigned long long *__restrict__ gate,
-                                                        unsigned long long *__restrict__ word) {
+                                                        unsigned long long *__restrict__ word,
+                                                        const unsigned long long *__restrict__ kapw) {
   constexpr int NS = Dim<J>::NS;
   if (gate_closed(gate)) return;
   __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1], Xd[J];
@@ -1187,7 +1329,7 @@ __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__res
   const int sij = sym(J, i, j), sii = sidx(J, i, i);
   if (act) Dm[i][j] = 0.0;
   lds_order();
-  double worst = 0.0;
+  double worst = 0.0, xdm = 0.0;
   double ph, ev, xv, xd;
   auto fetch = [&](int64_t k) {   // chunk k: Phi_k, E_k; X_{k+1} and its diagonal entry X_{k+1}(i, i)
     const int64_t g = b * K + k;
@@ -1201,7 +1343,8 @@ __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__res
     const double mph = ph, mev = ev, mxv = xv, mxd = xd;
     if (k + 2 < K) fetch(k + 1);
     Pm[i][j] = mph;
-    if (act && j == 0) Xd[i] = mxd;
+    xdm = fmax(xdm, mxd);   // (running maximum: behind a gap in time the state itself is ~0)
+    if (act && j == 0) Xd[i] = xdm;
     lds_order();
     double y = 0.0;      // (delta Phi^T)(i, j)
 #pragma unroll
@@ -1223,7 +1366,7 @@ __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__res
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
-  worst /= 0.5 * kNewtonTol;   // > 2 <=> above the tolerance
+  worst /= 0.5 * newton_tol(kapw);   // > 2 <=> above the tolerance
   if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
 }
 
@@ -1324,7 +1467,8 @@ __global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, d
                                                         const double *__restrict__ E, const double *__restrict__ Psi,
                                                         const double *__restrict__ Rho, const double *__restrict__ Dstart,
                                                         const unsigned long long *__restrict__ gate,
-                                                        unsigned long long *__restrict__ word) {
+                                                        unsigned long long *__restrict__ word,
+                                                        const unsigned long long *__restrict__ kapw) {
   constexpr int NS = Dim<J>::NS;
   if (gate_closed(gate)) return;
   __shared__ double Dm[J][J + 1], Ym[J][J + 1], Pm[J][J + 1], Xd[J];
@@ -1336,7 +1480,7 @@ __global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, d
   const int sij = sym(J, i, j), sii = sidx(J, i, i);
   if (act) Dm[i][j] = Dstart[(b * NB + nb) * (J * J) + i * J + j];
   lds_order();
-  double worst = 0.0, ph, rv, xv, xd;
+  double worst = 0.0, xdm = 0.0, ph, rv, xv, xd;
   auto fetch = [&](int64_t k) {
     const int64_t g = b * K + k;
     ph = Psi[g * (J * J) + i * J + j];
@@ -1344,13 +1488,17 @@ __global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, d
     xv = X[(g + 1) * NS + sij];
     xd = E[g * NS + sii];
   };
+  // (the scale of the updates -- a running maximum of the diagonal -- starts from the chunks in front of the block)
+  if (k0 > 0) xdm = fmax(xdm, E[(b * K + k0 - 1) * NS + sii]);
+  if (k0 >= kBlock) xdm = fmax(xdm, E[(b * K + k0 - kBlock) * NS + sii]);
   fetch(k0);
   for (int64_t k = k0; k < k1; ++k) {
     const double mph = ph, mrv = rv, mxv = xv, mxd = xd;
     if (k + 1 < k1) fetch(k + 1);
     lds_order();   // the previous step's readers of Pm, Ym, Xd are done
     Pm[i][j] = mph;
-    if (act && j == 0) Xd[i] = mxd;
+    xdm = fmax(xdm, mxd);
+    if (act && j == 0) Xd[i] = xdm;
     lds_order();
     double y = 0.0;
 #pragma unroll
@@ -1368,7 +1516,7 @@ __global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, d
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
-  worst /= 0.5 * kNewtonTol;
+  worst /= 0.5 * newton_tol(kapw);
   if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
 }
 
@@ -1566,7 +1714,9 @@ static int run_factor_rev(int64_t B, int64_t N, const double *t, int64_t t_bs, c
   const int64_t K = (N + kRows - 1) / kRows;
   int32_t *flag = reinterpret_cast<int32_t *>(work + L.total);
   double *ll = work + L.z;   // (unused pieces of the layout: the log-likelihood k_starts writes, the F junk)
+  unsigned long long *vw = reinterpret_cast<unsigned long long *>(work + L.vw);
   if (hipMemsetAsync(flag, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return C2_ERR_HIP;
+  if (hipMemsetAsync(vw, 0, kVerifyWords * sizeof(double), s) != hipSuccess) return C2_ERR_HIP;
   const dim3 cgrid((unsigned)((B * K + kWave - 1) / kWave));
   hipLaunchKernelGGL((k_local<J>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, d, W, d, work + L.loc, work + L.llp);
   if (K >= kTwoLevelMin) {
@@ -1590,7 +1740,8 @@ static int run_factor_rev(int64_t B, int64_t N, const double *t, int64_t t_bs, c
                        work + L.ends);
   hipLaunchKernelGGL((k_final<J, true>), cgrid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, U, V, d, W, d,
                      (const double *)(work + L.start), (const double *)(work + L.ends), (const int32_t *)flag,
-                     work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, (double *)nullptr, bde, bwe);
+                     work + L.sf, work + L.dT, work + L.bcp, ba, bU, bV, (double *)nullptr, vw, bde, bwe);
+  hipLaunchKernelGGL(k_verify_combine, dim3(1), dim3(1), 0, s, vw, opt::val(opt::k_timepar_cond_limit));
   hipLaunchKernelGGL(k_finish_t, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, s, B, N,
                      (const double *)(work + L.dT), (const int32_t *)flag, bt);
   hipLaunchKernelGGL((k_finish_c<J>), dim3((unsigned)(B * J)), dim3(kWave), 0, s, K, (const double *)(work + L.bcp),
@@ -1636,12 +1787,12 @@ extern "C" int C2TG_NAME(c2_internal_loglik_grad_timepar)(int64_t B, int64_t N, 
 }
 
 // factor (d, W) by Newton iterations on the chunk start states (widths 1 .. 8).  work: c2_internal_factor_iter_doubles;
-// its first kNewtonMax + 2 words are the iteration words -- the caller launches its row-by-row kernel behind `*last_word`.
-constexpr int kNewtonMax = 8;
+// its first kNewtonHdr words are the iterations' words (updates, then conditioning) -- the caller launches its row-by-row
+// kernel behind `*last_word`.
 extern "C" size_t C2TG_NAME(c2_internal_factor_iter_doubles)(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows);
-  size_t n = (size_t)(kNewtonMax + 2) + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
+  size_t n = (size_t)kNewtonHdr + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
   if ((int64_t)K >= kTwoLevelMin) n += (size_t)B * K * (size_t)(2 * J * J) + (size_t)B * ((K + kBlock - 1) / kBlock + 1) * (size_t)(J * J);
   return n;
 }
@@ -1654,13 +1805,13 @@ static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, 
   const int P = K < kNewtonMax ? (int)K : kNewtonMax;   // iteration p makes the first p chunks exact
   unsigned long long *words = (unsigned long long *)work;
   const size_t BK = (size_t)B * K;
-  double *X = work + (kNewtonMax + 2), *E = X + BK * NS, *Phi = E + BK * NS;
-  if (hipMemsetAsync(work, 0, ((size_t)(kNewtonMax + 2) + BK * NS) * sizeof(double), s) != hipSuccess) return C2_ERR_HIP;
+  double *X = work + kNewtonHdr, *E = X + BK * NS, *Phi = E + BK * NS;
+  if (hipMemsetAsync(work, 0, ((size_t)kNewtonHdr + BK * NS) * sizeof(double), s) != hipSuccess) return C2_ERR_HIP;
   const dim3 grid((unsigned)((B * K + kWave - 1) / kWave));
   for (int p = 1; p <= P; ++p) {
     const unsigned long long *gate = p >= 2 ? words + p - 1 : nullptr;
     hipLaunchKernelGGL((k_newton_pass<J>), grid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, d, W, flag,
-                       (const double *)X, E, Phi, gate, words + p);
+                       (const double *)X, E, Phi, gate, words + p, words + (kNewtonMax + 2) + p);
     if (K >= kTwoLevelMin) {
       const int64_t NB = (K - 1 + kBlock - 1) / kBlock;
       double *Psi = Phi + BK * J * J, *Rho = Psi + BK * J * J, *Dstart = Rho + BK * J * J;
@@ -1669,10 +1820,11 @@ static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, 
       hipLaunchKernelGGL((k_newton_blocks<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, NB, (const double *)Psi,
                          (const double *)Rho, Dstart, gate);
       hipLaunchKernelGGL((k_newton_apply<J>), dim3((unsigned)(B * NB)), dim3(kWave), 0, s, K, NB, X, (const double *)E,
-                         (const double *)Psi, (const double *)Rho, (const double *)Dstart, gate, words + p);
+                         (const double *)Psi, (const double *)Rho, (const double *)Dstart, gate, words + p,
+                         (const unsigned long long *)(words + (kNewtonMax + 2) + p));
     } else {
       hipLaunchKernelGGL((k_newton_chain<J>), dim3((unsigned)B), dim3(kWave), 0, s, K, X, (const double *)E,
-                         (const double *)Phi, gate, words + p);
+                         (const double *)Phi, gate, words + p, (const unsigned long long *)(words + (kNewtonMax + 2) + p));
     }
   }
   *last_word = words + P;

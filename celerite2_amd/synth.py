@@ -17,8 +17,10 @@ def sho_underdamped(S0, w0, Q, eps=1e-5):
     return a, a / f, c, c * f  # ac, bc, cc, dc
 
 
-def host_inputs(first, count, N, J, seed0=721):
-    """t, diag, y (count, N) and complex-term coefficients ac, bc, cc, dc (count, J/2) on the host."""
+def host_inputs(first, count, N, J, seed0=721, gap_fraction=0.0, gap=10.0):
+    """t, diag, y (count, N) and complex-term coefficients ac, bc, cc, dc (count, J/2) on the host.
+    gap_fraction > 0: that fraction of the series gets one gap of `gap` time units (100 mean spacings by default: a
+    night, a season) at a random row -- drawn after everything else, so the other numbers do not change."""
     assert J % 2 == 0, "the synthetic kernel is a sum of J/2 complex (underdamped SHO) terms"
     Jc = J // 2
     t = np.empty((count, N)); diag = np.empty((count, N)); y = np.empty((count, N)); xi = np.empty(count)
@@ -28,6 +30,10 @@ def host_inputs(first, count, N, J, seed0=721):
         diag[i] = rng.uniform(0.1, 0.3, N)
         xi[i] = rng.uniform(-1, 1)
         y[i] = np.sin(t[i]) + 0.1 * rng.standard_normal(N)
+        if gap_fraction > 0.0 and N > 2 and rng.uniform() < gap_fraction:
+            n0 = int(rng.integers(1, N))
+            t[i, n0:] += gap
+            y[i, n0:] = np.sin(t[i, n0:]) + (y[i, n0:] - np.sin(t[i, n0:] - gap))
     k = np.arange(Jc, dtype=np.float64)
     S0 = 5.0 * 0.7**k
     w0 = 0.1 * 3.0**k[None, :] * (1.0 + 0.05 * xi[:, None])
@@ -36,13 +42,13 @@ def host_inputs(first, count, N, J, seed0=721):
     return t, diag, y, ac, bc, cc, dc
 
 
-def device_batch(first, count, N, J, device, seed0=721):
+def device_batch(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0):
     """Device-resident (t, c, a, U, V, y) for series [first, first+count)."""
     import torch
 
     from . import ops
 
-    t, diag, y, ac, bc, cc, dc = host_inputs(first, count, N, J, seed0)
+    t, diag, y, ac, bc, cc, dc = host_inputs(first, count, N, J, seed0, gap_fraction, gap)
     to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
     td, diagd, yd, acd, bcd, dcd = map(to, (t, diag, y, ac, bc, dc))
     ar = torch.zeros((count, 0), dtype=torch.float64, device=device)
@@ -51,8 +57,9 @@ def device_batch(first, count, N, J, device, seed0=721):
     return td, to(c), a, U, V, yd
 
 
-def device_coeffs_fast(first, count, N, J, device, seed0=721):
-    """(t, diag, y, ac, bc, cc, dc) of device_batch_fast: the coefficient-level view of the same series."""
+def device_coeffs_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0):
+    """(t, diag, y, ac, bc, cc, dc) of device_batch_fast: the coefficient-level view of the same series.
+    gap_fraction / gap: as in host_inputs (drawn last)."""
     import torch
 
     assert J % 2 == 0
@@ -63,7 +70,13 @@ def device_coeffs_fast(first, count, N, J, device, seed0=721):
     t = torch.sort(torch.rand((count, N), generator=gen, **f64) * (N / 10.0), dim=1).values.contiguous()
     diag = 0.1 + 0.2 * torch.rand((count, N), generator=gen, **f64)
     xi = 2.0 * torch.rand((count, 1), generator=gen, **f64) - 1.0
-    y = torch.sin(t) + 0.1 * torch.randn((count, N), generator=gen, **f64)
+    noise = 0.1 * torch.randn((count, N), generator=gen, **f64)
+    if gap_fraction > 0.0 and N > 2:
+        hit = torch.rand((count, 1), generator=gen, **f64) < gap_fraction
+        n0 = 1 + (torch.rand((count, 1), generator=gen, **f64) * (N - 1)).long().clamp_(max=N - 2)
+        rows = torch.arange(N, device=device)[None, :]
+        t = (t + gap * (hit & (rows >= n0)).to(torch.float64)).contiguous()
+    y = torch.sin(t) + noise
     k = torch.arange(Jc, **f64)[None, :]
     S0 = 5.0 * 0.7**k
     w0 = 0.1 * 3.0**k * (1.0 + 0.05 * xi)
@@ -76,7 +89,7 @@ def device_coeffs_fast(first, count, N, J, device, seed0=721):
     return t, diag, y, ac, bc, cc, dc
 
 
-def device_batch_fast(first, count, N, J, device, seed0=721):
+def device_batch_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0):
     """Same synthetic distribution as device_batch, but drawn with torch's device generator (seeded with
     seed0 + first) so that very large shards (65536 x 4096) are ready in a fraction of a second.  Used by
     bench.py; parity tests use the numpy recipe (host_inputs) so that the CPU oracle sees identical numbers."""
@@ -84,7 +97,7 @@ def device_batch_fast(first, count, N, J, device, seed0=721):
 
     from . import ops
 
-    t, diag, y, ac, bc, cc, dc = device_coeffs_fast(first, count, N, J, device, seed0)
+    t, diag, y, ac, bc, cc, dc = device_coeffs_fast(first, count, N, J, device, seed0, gap_fraction, gap)
     ar = torch.zeros((count, 0), dtype=torch.float64, device=device)
     c = torch.repeat_interleave(cc, 2, dim=1).contiguous()
     a, U, V = ops.get_celerite_matrices(ar, ac, bc, dc, t, diag)

@@ -59,6 +59,21 @@ const char *c2_version(void);
 int c2_device_count(void);         /* number of visible HIP devices, 0 if none */
 const char *c2_last_error(void);   /* text of the last HIP error seen by this thread */
 
+/* Dispatch options (celerite2_amd/csrc/c2_dispatch.hpp; no counterpart in the reference, whose code has one formulation
+ * per op).  Which formulation an entry point runs -- row by row, parallel along time, which lane mapping -- follows from
+ * the shape through one table of switches and measured thresholds.  The table is initialised from the environment ONCE,
+ * when the library is loaded (variable names in INTEGRATION.md section 5); afterwards only c2_set_option changes it:
+ * `name` is the option's name or its environment variable, `value` its new value as text, NULL / "" = back to the
+ * default (switches: to the automatic choice).  Every alternative is parity-tested: options move speed, not results
+ * (beyond rounding).  Not thread-safe against concurrent launches that depend on the option being changed.
+ * c2_options_reload_env re-reads the environment (test harnesses that edit os.environ after loading the library). */
+int c2_set_option(const char *name, const char *value);
+int c2_get_option(const char *name, double *value, int *is_set);
+int c2_option_count(void);
+int c2_option_info(int index, const char **name, const char **env, double *default_value, int *is_switch,
+                   const char **doc, const char **measured);
+void c2_options_reload_env(void);
+
 /* ---------------------------------------------------------------------------
  * DEVICE entry points (batched, asynchronous)
  * ------------------------------------------------------------------------- */

@@ -6,6 +6,7 @@ product path fails loudly (no CPU fallback) when no GPU is present."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -56,9 +57,10 @@ def test_argument_errors_without_gpu(built):
     ck = 1 * 1 * (64 + 3 * 32 + 64 + 64)   # S slot 0 (64) + slots 1..3 (32 owners each) + F (64) + W (64)
     assert lib.c2_loglik_grad_workspace_bytes(B, N, J) == 8 * (ck + B * N * 2)
     # chip-filling J = 8 batches take the one-lane-per-series path: records W (B,N,8) + (d,z) (B,N,2) + t (B,N) + a
-    # checkpoint of 44 doubles every 32 rows, overlaid with the replay kernels' workspace, + the 16-byte stability word
-    waves, nck = 65536 // 64, (4096 - 2) // 32 + 1
-    rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44)
+    # checkpoint of 44 doubles every 32 rows and as many extra slots (re-anchoring in front of gaps in time) with their
+    # row list, overlaid with the replay kernels' workspace, + the 16-byte stability word
+    waves, nck = 65536 // 64, 2 * ((4096 - 2) // 32 + 1)
+    rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44) + waves * ((nck + 2) // 2)
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) == 8 * (2 + rec) < 30 * 2**30
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 6) == 8 * (2 + rec)   # width 6 runs as 8: same records
     assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 33) == 0   # unsupported width
@@ -101,3 +103,32 @@ def test_fails_loudly_without_gpu(built):
     t = np.arange(N, dtype=float)
     with pytest.raises(RuntimeError, match="HIP error"):
         driver.factor(t, np.ones(J), np.ones(N), np.zeros((N, J)), np.zeros((N, J)), np.ones(N), np.zeros((N, J)))
+
+
+def test_dispatch_options_table(built):
+    """One option table (csrc/c2_dispatch.hpp): the environment is read once at load, c2_set_option changes an option at
+    run time, no kernel source calls getenv, and INTEGRATION.md section 5 is the table the library was compiled with."""
+    import glob
+    import subprocess
+
+    from celerite2_amd import _lib
+
+    lib = _lib.load()
+    opts = {o["name"]: o for o in _lib.options()}
+    assert {"lanes", "timepar", "timepar_grad", "factor_iter", "lanes1_min_batch_grad", "timepar_cond_limit"} <= set(opts)
+    assert opts["lanes1_min_batch_grad"]["default"] == 24576 and not opts["lanes"]["is_set"]
+    _lib.set_option("lanes", 1)
+    v, st = ctypes.c_double(), ctypes.c_int()
+    assert lib.c2_get_option(b"C2_LANES", ctypes.byref(v), ctypes.byref(st)) == _lib.C2_OK and v.value == 1.0 and st.value == 1
+    # the workspace query follows the option (one lane per series: records + the 16-byte guard)
+    big = lib.c2_loglik_grad_workspace_bytes(128, 64, 8)
+    _lib.set_option("lanes", None)
+    assert lib.c2_get_option(b"lanes", ctypes.byref(v), ctypes.byref(st)) == _lib.C2_OK and st.value == 0
+    assert lib.c2_loglik_grad_workspace_bytes(128, 64, 8) != big
+    assert lib.c2_set_option(b"no_such_option", b"1") == _lib.C2_ERR_INVALID
+    assert lib.c2_set_option(b"lanes", b"x") == _lib.C2_ERR_INVALID
+    for src in glob.glob(os.path.join(ROOT, "celerite2_amd", "csrc", "*")):
+        if os.path.basename(src) != "c2_dispatch.hip":
+            assert "getenv(" not in open(src).read(), src
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_dispatch_doc.py"), "--check"]) == 0, \
+        "INTEGRATION.md section 5 is stale: run python tools/gen_dispatch_doc.py"

@@ -244,6 +244,71 @@ def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N, J):
             close(g[ok], e[ok])
 
 
+@pytest.mark.parametrize("J", [8, 6, 4, 2])
+def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
+    """Gaps in time (nights, seasons) under the one-lane mapping: the backward recursion of the reverse sweep cannot invert
+    the decay across a gap, so the forward pass records an EXTRA checkpoint in front of it (wavefront-uniform, c2_loglik_t.hip)
+    and the sweep stays on the one-lane kernels -- the guard word (first double of the workspace) stays below 2 -- for a
+    few gappy series among many, for a shared grid with gaps, for gaps next to / on checkpoint rows and back to back; a
+    wavefront whose series all have their own gaps runs out of extra slots and the replay kernels take the batch.
+    Results are the oracle's in every case."""
+    import torch
+    monkeypatch.setenv("C2_LANES", "1")
+    B, N = 150, 420   # (13 regular checkpoints and as many extra slots per wavefront)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    rng = np.random.default_rng(99)
+
+    def run(tg, shared=False):
+        if shared:   # ONE problem (grid, matrices) for the whole batch, a right-hand side per series
+            rep = lambda x: np.ascontiguousarray(np.tile(x[:1], (B,) + (1,) * (x.ndim - 1)))
+            ts, cs, as_, Us, Vs = rep(tg), rep(c), rep(a), rep(U), rep(V)
+        else:
+            ts, cs, as_, Us, Vs = tg, c, a, U, V
+        llo, go, flo = oracle.loglik_grad_batched(ts, cs, as_, Us, Vs, y, nthreads=2)
+        assert int(np.abs(flo).sum()) == 0
+        args = dev(tg[0].copy() if shared else tg, cs, as_, Us, Vs, y)
+        work = ops.loglik_grad_workspace(B, N, J, args[2].device)
+        ll, grads, flag = ops.loglik_grad(*args, work=work)
+        torch.cuda.synchronize()
+        guard = float(work[0])
+        assert int(flag.abs().sum()) == 0
+        close(ll, llo)
+        for g, e in zip(grads, go):
+            close(g, e)
+        close(ops.loglik(*args)[0], llo)
+        return guard
+
+    # (1) 5 % of the series with one gap of 100 mean spacings at a row of their own
+    tg = t.copy()
+    for b in rng.choice(B, size=8, replace=False):
+        tg[b, int(rng.integers(1, N)):] += 10.0
+    assert run(tg) <= 2.0
+    # (2) a shared grid with five gaps, one of them enormous (the decays underflow)
+    tg = t.copy()
+    for n0, g in ((17, 10.0), (64, 25.0), (65, 1e4), (130, 10.0), (N - 1, 40.0)):
+        tg[:, n0:] += g
+    assert run(tg, shared=True) <= 2.0
+    # (3) gaps next to and on the regular checkpoint rows (multiples of 32), back to back, in front of the last row
+    tg = t.copy()
+    for b, rows in enumerate(((31,), (32,), (33,), (32, 33), (63, 64, 65), (1,), (2,), (N - 1,), (N - 2, N - 1), (96, 97))):
+        for n0 in rows:
+            tg[b, n0:] += 10.0
+    assert run(tg) <= 2.0
+    # (4) spans that accumulate: every series 12x sparser over 32 rows (c_max * span of a segment four times the guard)
+    tg = t.copy()
+    lo, hi = 40, 72
+    tg[:, lo:] += 12.0 * (t[:, lo:] - t[:, lo:lo + 1]) * (np.arange(lo, N) < hi)[None, :] \
+        + 12.0 * (t[:, hi - 1:hi] - t[:, lo:lo + 1]) * (np.arange(lo, N) >= hi)[None, :]
+    assert np.diff(tg, axis=1).min() > 0
+    assert run(tg) <= 2.0
+    # (5) every series of a wavefront with three gaps of its own: more extras than there are slots -> the replay kernels
+    tg = t.copy()
+    for b in range(B):
+        for n0 in rng.integers(1, N, size=5):
+            tg[b, int(n0):] += 10.0
+    assert run(tg) > 2.0
+
+
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])
 @pytest.mark.parametrize("N", [1, 2, 8, 9, 10, 17, 100])
 def test_loglik_grad_widths_and_segment_edges(ops, oracle, J, N):

@@ -2,10 +2,11 @@
 """bench.py -- headline benchmark: batched float64 GP log-likelihood + gradient per second at
 N=4096, J=8 (BASELINE.json metric).  Workload = BASELINE.json configs[2]: a batch of 65536 independent GPs,
 forward + reverse-mode gradient.  It fits one MI355X (41 GB inputs + 41 GB gradients + 33 GB replay records), so
-N=1 runs all 65536 series on one GPU.  The path partitions over independent series with no data-path collective,
-so N GPUs each take a shard of the same SIZE (weak scaling, 65536 series per GPU: per-GPU work is what the kernels
-are priced on); --global-batch B shards one batch of B series instead (strong scaling: B = 65536 at N = 8 is the
-literal "batch 65536 sharded across 8 x MI355X", 8192 series per GPU, where the small-batch kernels run).
+N=1 runs all 65536 series on one GPU.  The path partitions over independent series with no data-path collective.
+N GPUs SHARD that one batch (strong scaling: the literal "batch 65536 sharded across 8 x MI355X", 8192 series per
+GPU at N = 8 -- `value`); the same line carries a `weak_scaling` object, 65536 series PER GPU measured in the same run
+(per-GPU work fixed: what the kernels are priced on) -- never under the configs[2] label.  --batch-per-gpu B makes the
+weak-scaling variant the line's `value` instead (labelled as such).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -140,6 +141,34 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
             "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}
 
 
+def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms):
+    """Informational: the same workload with 5 % of the series carrying one gap of 100 mean spacings (a night, a season) at
+    a row of their own.  The one-lane reverse sweep cannot invert a decay across such a gap; the forward pass re-anchors it
+    there with an extra wavefront-uniform checkpoint (c2_loglik_t.hip), so the batch stays on the fast kernels -- `guard`
+    (first double of the workspace) <= 2 says so; before round 3 ONE such series sent all 65536 to the replay kernels."""
+    import torch
+
+    from celerite2_amd import ops, synth
+
+    t, c, a, U, V, y = synth.device_batch_fast(first, Bp, N, J, dev, gap_fraction=0.05, gap=10.0)
+    ngap = int(((t[:, 1:] - t[:, :-1]).max(dim=1).values > 5.0).sum())
+    for _ in range(2):
+        ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    guard = float(work[0])
+    return {"workload": "the step's batch with a gap of 10 time units (100 mean spacings) in 5 %% of the series (%d of %d)" % (ngap, Bp),
+            "ms_per_step": ms, "value": Bp / ms * 1e3, "unit": "GP/s", "steps": steps, "ratio_to_gap_free_step": ms / clean_ms,
+            "guard": guard, "path": "one lane per series, re-anchored at the gaps" if guard <= 2.0 else "replay kernels (guard tripped)",
+            "failed_factorizations": int((flag != 0).sum())}
+
+
 def long_series(J, dev, N=100_000, steps=3):
     """Informational: ONE series of 1e5 rows, log-likelihood + gradient -- the small-batch end of the same entry point,
     which runs parallel along time; row by row for comparison (C2_TIMEPAR_GRAD=0, C2_FACTOR_ITER=0)."""
@@ -208,8 +237,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-per-gpu", type=int, default=65536, help="series per GPU (weak scaling, the default)")
-    ap.add_argument("--global-batch", type=int, default=0, help="if > 0: total series sharded over the GPUs (strong scaling)")
+    ap.add_argument("--global-batch", type=int, default=65536,
+                    help="total series, sharded over the GPUs (strong scaling; 65536 = the literal configs[2], the default)")
+    ap.add_argument("--batch-per-gpu", type=int, default=0,
+                    help="if > 0: series PER GPU (weak scaling) as the line's value -- a variant, not the literal configs[2]")
+    ap.add_argument("--no-weak-object", action="store_true",
+                    help="N > 1: skip the extra `weak_scaling` measurement (65536 series per GPU) the strong-scaling line carries")
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--J", type=int, default=8)
     ap.add_argument("--mode", choices=["grad", "fwd"], default="grad")
@@ -217,9 +250,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-synth", action="store_true",
                     help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
-    ap.add_argument("--placement-search", type=int, default=5,
-                    help="candidate placements of the workspace / gradient arrays tried before the timed steps "
-                         "(1: the allocator's own only)")
+    ap.add_argument("--placement-search", type=int, default=1,
+                    help="k > 1: try k placements of the workspace / gradient arrays before the timed steps and keep the "
+                         "fastest (informational; the default 1 = the allocator's own placement, what any caller gets)")
+    ap.add_argument("--no-gappy", action="store_true", help="skip the informational gappy-batch measurement (`gappy` object)")
     ap.add_argument("--no-long-series", action="store_true",
                     help="skip the informational single-long-series measurement (`long_series` object)")
     ap.add_argument("--no-coefficient-level", action="store_true",
@@ -262,63 +296,98 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     _lib.load()
 
-    weak = args.global_batch <= 0
-    Btot = args.batch_per_gpu * world if weak else args.global_batch
-    first, Bp = parallel.shard_range(Btot, rank, world)   # contiguous shard of this rank
+    weak = args.batch_per_gpu > 0
     N, J = args.N, args.J
     grad = args.mode == "grad"
-    # shard: contiguous block of series per rank, generated directly on the owning GPU
     make = synth.device_batch if args.exact_synth else synth.device_batch_fast
-    t, c, a, U, V, y = make(first, Bp, N, J, dev)
-    placement = None
-    if grad:
-        work = ops.loglik_grad_workspace(Bp, N, J, dev)
-        out = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
-               torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
-               torch.empty((Bp, N), dtype=torch.float64, device=dev))
-        if args.placement_search > 1:
-            # Setup, not timed: what an application that reuses its buffers would do (ops.loglik_grad_buffers) -- time one
-            # step on a few placements of the workspace and the gradient arrays, keep the fastest, report them all.
-            del work, out
-            work, out, placement = ops.loglik_grad_buffers(t, c, a, U, V, y, candidates=args.placement_search)
-            keep_spacer = placement.pop("spacer")
 
-    def step():
+    def measure(Btot, search):
+        """W warm-up + K timed steps of the hot path on this rank's contiguous shard of a batch of Btot series (generated
+        directly on the owning GPU), barrier + synchronize on both sides, MAX over ranks."""
+        first, Bp = parallel.shard_range(Btot, rank, world)
+        t, c, a, U, V, y = make(first, Bp, N, J, dev)
+        placement = work = out = None
         if grad:
-            ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
-        else:
-            ll, flag = ops.loglik(t, c, a, U, V, y)
-        if dist_on:  # the path's only exchange: B/n_gpu log-liks per rank
-            if backend == "nccl":
-                ll = parallel.gather_loglik(ll, Btot, world, force=True)
-            else:
-                ll = parallel.gather_loglik(ll.cpu(), Btot, world, force=True).to(dev)
-        return ll, flag
+            work = ops.loglik_grad_workspace(Bp, N, J, dev)
+            out = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
+                   torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
+                   torch.empty((Bp, N), dtype=torch.float64, device=dev))
+            if search > 1:
+                # Optional setup, not timed (--placement-search k): what an application that reuses its buffers could do
+                # (ops.loglik_grad_buffers) -- time one step on a few placements of the workspace and the gradient
+                # arrays, keep the fastest, report them all.  The default is the allocator's own placement.
+                del work, out
+                work, out, placement = ops.loglik_grad_buffers(t, c, a, U, V, y, candidates=search)
+                placement.pop("spacer")
 
-    for _ in range(args.warmup):
-        ll, flag = step()
-    torch.cuda.synchronize()
-    nfail = int((flag != 0).sum())
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        ll, flag = step()
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
-    kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        def step():
+            if grad:
+                ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
+            else:
+                ll, flag = ops.loglik(t, c, a, U, V, y)
+            if dist_on:  # the path's only exchange: B/n_gpu log-liks per rank
+                if backend == "nccl":
+                    ll = parallel.gather_loglik(ll, Btot, world, force=True)
+                else:   # (gloo moves host tensors only: test mode, several ranks on one device)
+                    ll = parallel.gather_loglik(ll.cpu(), Btot, world, force=True).to(dev)
+            return ll, flag
+
+        for _ in range(args.warmup):
+            ll, flag = step()
+        torch.cuda.synchronize()
+        nfail = int((flag != 0).sum())
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            ev[i][0].record()
+            ll, flag = step()
+            ev[i][1].record()
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist_on:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax[0])
+        kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+        return dict(Btot=Btot, first=first, Bp=Bp, elapsed=elapsed, kernel_ms=kernel_ms, ll=ll, nfail=nfail,
+                    placement=placement, work=work, out=out, inputs=(t, c, a, U, V, y))
+
+    Btot = args.batch_per_gpu * world if weak else args.global_batch
+    m = measure(Btot, args.placement_search)
+    first, Bp, elapsed, kernel_ms, ll, nfail, placement = m["first"], m["Bp"], m["elapsed"], m["kernel_ms"], m["ll"], m["nfail"], m["placement"]
+    work, out = m["work"], m["out"]
+    t, c, a, U, V, y = m["inputs"]
+    m = None   # (the names above own the buffers now: the informational legs below free them one by one)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    # who ran: one entry per rank (device, PCI bus id) + the collective library -- self-evidencing multi-GPU lines
+    me = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
+          "pci_bus_id": "%04x:%02x:%02x.0" % tuple(getattr(torch.cuda.get_device_properties(dev_index), k, 0)
+                                                   for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))}
+    ranks = [me]
+    if dist_on:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    weak_obj = None
+    if world > 1 and not weak and not args.no_weak_object and args.N == 4096:
+        work = out = t = c = a = U = V = y = None
+        torch.cuda.empty_cache()
+        mw = measure(65536 * world, 1)
+        kw = mw["kernel_ms"]
+        if rank == 0:
+            bpg = algorithmic_bytes_per_gp(N, J, grad)
+            weak_obj = {"workload": "weak-scaling variant (NOT the literal configs[2]): %d series per GPU, %d in total" % (mw["Bp"], mw["Btot"]),
+                        "value": mw["Btot"] * args.steps / mw["elapsed"], "unit": "GP/s", "ms_per_step": 1e3 * mw["elapsed"] / args.steps,
+                        "global_batch": mw["Btot"], "batch_per_gpu": mw["Bp"], "scaling": "weak",
+                        "roofline_frac_per_gpu": mw["Bp"] * bpg / (sum(kw) / len(kw) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "failed_factorizations": mw["nfail"]}
+        del mw
+        torch.cuda.empty_cache()
 
     if rank == 0 and args.dump_ll:
         import numpy as np
@@ -335,18 +404,38 @@ def main():
             "value": value, "unit": "GP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: batch of %d independent GPs (%d per GPU), N=%d, J=%d (sum of %d SHO terms), %s, "
-                                   "inputs resident in HBM" % (Btot, Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
+            "config": {"workload": ("%s: batch of %d independent GPs (%d per GPU), N=%d, J=%d (sum of %d SHO terms), %s, "
+                                    "inputs resident in HBM") % (
+                                        "configs[2]" if (Btot == 65536 and N == 4096 and J == 8 and grad) else
+                                        ("weak-scaling variant of configs[2] (NOT the literal config)" if weak and world > 1 else "variant of configs[2]"),
+                                        Btot, Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
                        "global_batch": Btot, "batch_per_gpu": Bp, "N": N, "J": J,
                        "parallelism": "batch-sharded x%d, all-gather of log-liks" % world,
-                       "failed_factorizations": nfail},
+                       "failed_factorizations": nfail, "ranks": ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(grad, Bp, N, J),
                          "algorithmic_bytes_per_gp": bytes_per_gp, "kernel_ms_avg": kernel_ms_avg,
                          "kernel_ms_median": kernel_ms[len(kernel_ms) // 2]},
         }
+        if dist_on:
+            v = torch.cuda.nccl.version() if backend == "nccl" else None
+            line["rccl"] = {"backend": backend, "nranks": world,
+                            "version": ".".join(str(x) for x in v) if isinstance(v, tuple) else (str(v) if v is not None else None),
+                            "distinct_devices": len({r["pci_bus_id"] for r in ranks})}
+        if weak_obj is not None:
+            line["weak_scaling"] = weak_obj
         if placement is not None:
             line["config"]["placement_search"] = placement
+        if world == 1 and grad and not args.exact_synth and not args.no_gappy:
+            del t, c, a, U, V, y   # (regenerated with gaps; the workspace and the gradient arrays are reused)
+            torch.cuda.empty_cache()
+            ll_keep = ll[:Bp].clone()
+            try:
+                line["gappy"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg)
+            except Exception as e:  # noqa: BLE001 -- informational only
+                line["gappy"] = {"error": repr(e)[:200]}
+            t = c = a = U = V = y = None
+            ll = ll_keep
         if world == 1 and grad and J == 8 and not args.exact_synth and not args.no_coefficient_level:
             # Informational, not `value`: the same series through the coefficient-level entry point,
             # log-likelihood + gradient w.r.t. (ac, bc, cc, dc, x, diag, y) with U, V formed inside the kernels.

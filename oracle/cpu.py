@@ -226,5 +226,35 @@ def loglik_grad_batched(t, c, a, U, V, y, nthreads=0):
     return ll, (bt, bc, ba, bU, bV, by), flag
 
 
+_lib_ld = None
+
+
+def loglik_grad_batched_ld(t, c, a, U, V, y, nthreads=0):
+    """loglik_grad_batched evaluated in extended precision (long double: the same source, oracle/Makefile) on float64
+    inputs; results rounded back to float64.  How far the float64 restatement is from THIS is the floor below which no
+    float64 evaluation order can be asked to agree with it."""
+    global _lib_ld
+    so = os.path.join(_HERE, "libc2_oracle_ld.so")
+    if _lib_ld is None:
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "c2_oracle.cpp")):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "libc2_oracle_ld.so"])
+        _lib_ld = ctypes.CDLL(so)
+    B, N = y.shape
+    J = c.shape[-1]
+    L = np.longdouble
+    assert np.dtype(L).itemsize == 16, "x86-64 long double"
+    ld = lambda x: np.ascontiguousarray(x, dtype=L)
+    p = lambda x: _dp(x.ctypes.data)
+    tl, cl, al, Ul, Vl, yl = (ld(x) for x in (t, c, a, U, V, y))
+    ll = np.empty(B, L); flag = np.empty(B, dtype=np.int32)
+    bt = np.empty((B, N), L); bc = np.empty((B, J), L); ba = np.empty((B, N), L)
+    bU = np.empty((B, N, J), L); bV = np.empty((B, N, J), L); by = np.empty((B, N), L)
+    _lib_ld.c2o_ld_loglik_grad_batched(_i64(B), _i64(N), _i64(J), p(tl), _i64(_bs(t, N)), p(cl), _i64(_bs(c, J)), p(al),
+                                       p(Ul), p(Vl), p(yl), p(ll), p(bt), p(bc), p(ba), p(bU), p(bV), p(by),
+                                       ctypes.c_void_p(flag.ctypes.data), ctypes.c_int(nthreads))
+    f = lambda x: np.asarray(x, dtype=np.float64)
+    return f(ll), tuple(f(x) for x in (bt, bc, ba, bU, bV, by)), flag
+
+
 def num_threads():
     return int(lib().c2o_num_threads())

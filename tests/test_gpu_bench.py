@@ -36,19 +36,23 @@ def test_bench_self_launches_two_ranks(tmp_path):
     assert rc == 0, err
     assert line2["n_gpus"] == 2 and line2["config"]["batch_per_gpu"] == 32 and line2["config"]["global_batch"] == 64
     assert line2["scaling"] == "strong" and "roofline" in line2
+    # self-evidencing: who ran (one entry per rank) and through which collective library
+    assert [r["rank"] for r in line2["config"]["ranks"]] == [0, 1] and all("pci_bus_id" in r for r in line2["config"]["ranks"])
+    assert line2["rccl"]["nranks"] == 2 and line2["rccl"]["backend"] == "gloo"
     a, b = np.load(one), np.load(two)
     assert a.shape == (64,) and np.array_equal(a, b)      # same series -> same bits, whichever rank computed them
 
 
-def test_bench_default_is_weak_scaling(tmp_path):
-    """Without --global-batch every rank owns --batch-per-gpu series (the default mode of the scaling runs): two ranks
-    process the 64 series the one-rank run of 64 does, in the same order."""
+def test_bench_weak_scaling_variant(tmp_path):
+    """--batch-per-gpu: every rank owns that many series (weak scaling, labelled as a variant -- the default shards ONE
+    batch, the literal configs[2]): two ranks process the 64 series the one-rank run of 64 does, in the same order."""
     weak = ["--batch-per-gpu", "32"] + SMALL[2:]
     two, ref = str(tmp_path / "ll2.npy"), str(tmp_path / "ll1.npy")
     rc, line, err = run_bench(["--gpus", "2", "--dump-ll", two] + weak, {"C2_DIST_BACKEND": "gloo"})
     assert rc == 0, err
     assert line["scaling"] == "weak" and line["n_gpus"] == 2
     assert line["config"]["batch_per_gpu"] == 32 and line["config"]["global_batch"] == 64
+    assert not line["config"]["workload"].startswith("configs[2]:")
     rc, _, err = run_bench(["--gpus", "1", "--dump-ll", ref] + SMALL, {})
     assert rc == 0, err
     assert np.array_equal(np.load(two), np.load(ref))
@@ -67,6 +71,7 @@ def test_bench_rccl_communicator_one_rank(tmp_path):
     out = str(tmp_path / "ll.npy")
     rc, line, err = run_bench(["--gpus", "1", "--dump-ll", out] + SMALL, {"C2_FORCE_DIST": "1"})
     assert rc == 0 and line["n_gpus"] == 1, err
+    assert line["rccl"]["backend"] == "nccl" and line["rccl"]["nranks"] == 1 and line["rccl"]["version"]
     ref = str(tmp_path / "ref.npy")
     rc, _, err = run_bench(["--gpus", "1", "--dump-ll", ref] + SMALL, {})
     assert rc == 0, err
@@ -83,3 +88,7 @@ def test_bench_rccl_two_ranks_if_two_devices(tmp_path):
     rc, line, err = run_bench(["--gpus", "2", "--dump-ll", two] + SMALL, {})
     assert rc == 0 and line["n_gpus"] == 2, err
     assert np.array_equal(np.load(one), np.load(two))
+    # two RCCL ranks on two distinct devices, the gather on device tensors (no host bounce)
+    assert line["rccl"] == {"backend": "nccl", "nranks": 2, "version": line["rccl"]["version"], "distinct_devices": 2}
+    assert line["rccl"]["version"] and len({r["pci_bus_id"] for r in line["config"]["ranks"]}) == 2
+    assert line["scaling"] == "strong" and line["config"]["global_batch"] == 64

@@ -211,12 +211,8 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
             close(gf, gc.cpu().numpy(), tol=1e-9, floor=floor)
 
 
-@pytest.mark.parametrize("seed", list(range(30)) + _extra_seeds())
-def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
-    """The gradient parallel along time and the Newton factor (c2_timepar_grad.hip) forced on random shapes: series
-    lengths around the chunk length (64) and its multiples, widths 1 .. 8, shared grids / rates, unpaired rates, a
-    gap in time, an occasional failed series -- log-likelihood, flags and all six gradients against the oracle (each
-    gradient relative to its largest entry: its small entries are sums of large terms)."""
+def _tpg_draw(seed):
+    """The draw of seed `seed` of the time-parallel-gradient sweep (tools/verify_words.py draws the same)."""
     rng = np.random.default_rng(77000 + seed)
     B = int(rng.choice([1, 2, 3, 5, 9, 70]))
     N = int(rng.choice([1, 2, 3, 63, 64, 65, 127, 128, 129, 200, 449, 640, 1000, 2100]))
@@ -225,7 +221,6 @@ def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
     if seed >= 30 and B < 70 and rng.random() < 0.3:
         N = int(rng.choice([2500, 4096, 4100, 7000]))
     t, c, a, U, V, y = problem(rng, B, N, J)
-    if rows: monkeypatch.setenv("C2_TPG_ROWS", rows)
     if rng.random() < 0.4:
         c = c * rng.uniform(0.8, 1.25, c.shape)
     if N > 70 and rng.random() < 0.4:
@@ -236,24 +231,73 @@ def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
     if shared_c: c = np.tile(c[0], (B, 1))
     if B > 1 and N > 10 and rng.random() < 0.3:
         a[B // 2, N // 3] = -1.0
+    return rows, t, c, a, U, V, y, shared_t, shared_c
+
+
+def _tpg_check(ops, oracle, monkeypatch, seed, forced=True):
+    """Criterion of the time-parallel gradient (also stated in DESIGN.md section 5 and at c2_loglik_grad): every gradient
+    array of every series agrees with the float64 oracle to 1e-10 of the array's LARGEST entry (chunked sums reorder the
+    additions: small entries are sums of large terms) -- plus four times the distance of that oracle itself from the
+    same recursion evaluated in extended precision (oracle.loglik_grad_batched_ld).  That second term is the rounding
+    error of the REFERENCE's operation order on the draw: ~0.5 eps kappa^2 with kappa = max a_n / d_n, e.g. 1e-10 at
+    kappa = 1500 -- no float64 evaluation in another order can be asked to agree with the oracle more closely than the
+    oracle agrees with the exact result; on well-conditioned draws it vanishes (1e-14) and the criterion is 1e-10."""
+    rows, t, c, a, U, V, y, shared_t, shared_c = _tpg_draw(seed)
+    if rows: monkeypatch.setenv("C2_TPG_ROWS", rows)
     llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
-    ok = np.asarray(flago) == 0
-    monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
-    monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    llx, gx, flagx = oracle.loglik_grad_batched_ld(t, c, a, U, V, y, nthreads=2)
+    ok = (np.asarray(flago) == 0) & (np.asarray(flagx) == 0)
+    if forced:
+        monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+        monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    else:
+        monkeypatch.setenv("C2_TIMEPAR_GRAD", "0")
+        monkeypatch.setenv("C2_FACTOR_ITER", "0")
     args = dev(t[0].copy() if shared_t else t, c[0].copy() if shared_c else c, a, U, V, y)
     ll, grads, flag = ops.loglik_grad(*args)
-    assert np.array_equal(flag.cpu().numpy() != 0, ~ok)
+    failed = flag.cpu().numpy() != 0
+    assert np.array_equal(failed, np.asarray(flago) != 0)
     lln = ll.cpu().numpy()
-    assert np.isneginf(lln[~ok]).all()
-    np.testing.assert_allclose(lln[ok], llo[ok], rtol=1e-10)
-    for g, e in zip(grads, go):
+    assert np.isneginf(lln[failed]).all()
+    np.testing.assert_array_less(np.abs(lln[ok] - llo[ok]), 1e-10 * np.abs(llo[ok]) + 4.0 * np.abs(llo[ok] - llx[ok]) + 1e-300)
+    worst = 0.0
+    for g, e, x in zip(grads, go, gx):
         gn = g.cpu().numpy()
-        assert np.isnan(gn[~ok]).all()
+        assert np.isnan(gn[failed]).all()
         for b in np.nonzero(ok)[0]:
-            np.testing.assert_allclose(gn[b], e[b], rtol=0.0, atol=1e-10 * max(np.abs(e[b]).max(), 1e-300))
+            floor = float(np.abs(e[b] - x[b]).max())
+            np.testing.assert_allclose(gn[b], e[b], rtol=0.0, atol=1e-10 * max(np.abs(e[b]).max(), 1e-300) + 4.0 * floor)
+            worst = max(worst, float(np.abs(gn[b] - e[b]).max() / max(np.abs(e[b]).max(), 1e-300)))
     ll0, flag0 = ops.loglik(*args)
-    assert np.array_equal(flag0.cpu().numpy() != 0, ~ok)
-    np.testing.assert_allclose(ll0.cpu().numpy()[ok], llo[ok], rtol=1e-10)
+    assert np.array_equal(flag0.cpu().numpy() != 0, failed)
+    np.testing.assert_array_less(np.abs(ll0.cpu().numpy()[ok] - llo[ok]), 1e-10 * np.abs(llo[ok]) + 4.0 * np.abs(llo[ok] - llx[ok]) + 1e-300)
+    return worst
+
+
+@pytest.mark.parametrize("seed", list(range(30)) + _extra_seeds())
+def test_fuzz_time_parallel_gradient(ops, oracle, monkeypatch, seed):
+    """The gradient parallel along time and the Newton factor (c2_timepar_grad.hip) forced on random shapes: series
+    lengths around the chunk length (64) and its multiples, widths 1 .. 8, shared grids / rates, unpaired rates, a
+    gap in time, an occasional failed series -- log-likelihood, flags and all six gradients against the oracle under the
+    criterion of _tpg_check."""
+    _tpg_check(ops, oracle, monkeypatch, seed)
+
+
+# The draws of the 6030- and 9000-seed stress runs (rounds 2 and 3; tools/verify_words.py) that are furthest from the oracle,
+# as fixed cases.  8021, 6286 (J = 2, kappa = 2.6): 1.5e-10 / 6.5e-11 while the factor of widths 4 / 2 came from the composed
+# maps of c2_timepar.hip (verified to 5e-11 only) -- 6e-14 / 2e-14 since the gradient takes the Newton factor at every
+# width.  6564 (kappa = 1500), 1896 / 2731 (a batch of marginally positive-definite series), 2107: ill-conditioned -- the
+# float64 oracle itself is 1e-10 / 2.7e-9 / 5e-11 from the extended-precision result, the row-by-row kernels land at the
+# same distance (tools/kappa_sweep.py).  7570: a cancelling sum (bc of a single rate).
+HARD_DRAWS = [6564, 8021, 6286, 7570, 1896, 2731, 2107]
+
+
+@pytest.mark.parametrize("seed", HARD_DRAWS)
+def test_time_parallel_gradient_known_hard_draws(ops, oracle, monkeypatch, seed):
+    worst = _tpg_check(ops, oracle, monkeypatch, seed)
+    if seed in (8021, 6286):   # well-conditioned: the plain 1e-10 with three orders to spare
+        assert worst < 1e-12
+    _tpg_check(ops, oracle, monkeypatch, seed, forced=False)   # the row-by-row kernels under the same criterion
 
 
 @pytest.mark.parametrize("seed", list(range(24)) + _extra_seeds())

@@ -25,7 +25,7 @@
   X(timepar_grad, "C2_TIMEPAR_GRAD", 0, 's', "log-likelihood GRADIENT (and factor_rev) parallel along time, widths 1 .. 8: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_grad_time.py, profiles/r02_timepar_grad.md") \
   X(timepar_grad_min_rows, "C2_TIMEPAR_GRAD_MIN_ROWS", 1024, 't', "shortest series the time-parallel gradient takes at widths 7, 8 beyond a handful of series (768 at widths 3 .. 6, 512 at 1, 2; 256 for at most 4096 chunks)", "one series draws level at ~400 / ~600 / ~800 rows at J = 2 / 4, 6 / 8 (tools/timepar_grad_time.py)") \
   X(timepar_grad_max_chunks, "C2_TIMEPAR_GRAD_MAX_CHUNKS", 32768, 't', "largest number of 64-row chunks (B * ceil(N / 64)) the time-parallel gradient takes", "1024 x 4096 at J = 4: 3.6 vs 3.0 ms row by row") \
-  X(timepar_cond_limit, "C2_TIMEPAR_COND_LIMIT", 1000, 't', "largest conditioning kappa = max a_n / d_n for which the result of the time-parallel gradient stands; beyond it the row-by-row kernels -- whose operation order is the closest to the reference's -- recompute the batch behind the device-side gate; 0: no limit", "rounding moves ANY float64 evaluation by c eps kappa^2 of the largest gradient entry: the oracle itself c = 0.4 (against extended precision), the row-by-row kernels ~0.05, the time-parallel form ~0.01 typically and up to 0.6 (tools/kappa_sweep.py, tools/verify_words.py, profiles/r03_timepar_verification.md): 1000 keeps its worst case below 1e-10") \
+  X(timepar_cond_limit, "C2_TIMEPAR_COND_LIMIT", 0, 't', "if > 0: largest conditioning kappa = max a_n / d_n for which the result of the time-parallel gradient stands; beyond it the row-by-row kernels recompute the batch behind the device-side gate (0, the default: no limit)", "rounding moves ANY float64 evaluation by c eps kappa^2 of the largest gradient entry: the oracle itself c = 0.4 (against its own extended-precision evaluation), the row-by-row kernels ~0.05, the time-parallel form ~0.01 and 0.6 in the worst draw of 9000 -- typically the closer of the two to the oracle, hence no limit by default (tools/kappa_sweep.py, tools/verify_words.py, profiles/r03_timepar_verification.md)") \
   X(verify_fallback, "C2_VERIFY_FALLBACK", 1, 's', "0 (diagnostics only): keep the result of a time-parallel form whatever its device-side verification says", "tools/verify_words.py") \
   X(factor_iter, "C2_FACTOR_ITER", 0, 's', "factor by Newton iterations on the chunk start states: 1 forces, 0 disables; unset: from 2048 rows and at most 32768 chunks (widths 4, 2: from 32768 / 131072 rows)", "tools/factor_iter_time.py: 4096 rows 1.21 -> 0.76 ms, 1e5 rows 29.5 -> 1.0 ms at J = 8") \
   X(tpg_rows, "C2_TPG_ROWS", 0, 's', "chunk length of the time-parallel gradient / Newton factor / chunk-map solves: 16, 32 or 64; unset: 16 up to 4096 rows and 32 beyond for at most 4096 chunks of 64 rows, else 64", "one series of 4096 rows 1.33 -> 1.03 -> 0.73 ms (64 -> 32 -> 16 rows), 1e5 rows 1.68 -> 1.25 ms with 32") \

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(kWave) void k_starts_apply(int64_t N, int64_t K, co
 // behind it run (gate_closed); vw[1]: S at the chunk boundaries, relative to sqrt(S_ii S_jj); vw[2]: the adjoints (bS, bF),
 // weighted with the state they pair with; vw[3]: kappa = max a_n / d_n (informational); vw[4]: F at the chunk boundaries in
 // units of sqrt(S_jj); vw[5]: the solve's state at the chunk boundaries (k_solve_apply), in units of the terms of z.
-constexpr double kVerifyTol = 1e-11;
+constexpr double kVerifyTol = 2e-12;   // (largest mismatch over 8528 stress draws: 9e-14, profiles/r03_timepar_verification.md)
 constexpr int kVerifyWords = 8;
 constexpr int kNewtonMax = 8;                       // Newton iterations of the factor at most (below)
 constexpr int kNewtonHdr = 2 * (kNewtonMax + 2);   // its words[0 .. kNewtonMax + 1]: the iterations' updates; then their kappas

@@ -177,4 +177,6 @@ def test_kron_banded_collapse_matches_thread_per_epoch(ops, monkeypatch, M):
         x0, x1 = x0.cpu().numpy(), x1.cpu().numpy()
         fin = np.isfinite(x0)
         assert np.array_equal(fin, np.isfinite(x1))
-        np.testing.assert_allclose(x1[fin], x0[fin], rtol=1e-11, atol=1e-12 * max(1.0, float(np.abs(x0[fin]).max())))
+        # (two orders of the band sums in front of the SAME 1-D solver, whose problem has kappa = k(0) A ~ 1e3 .. 1e4:
+        # rounding differences of the collapsed inputs come back multiplied by ~eps kappa^2)
+        np.testing.assert_allclose(x1[fin], x0[fin], rtol=1e-10, atol=1e-11 * max(1.0, float(np.abs(x0[fin]).max())))

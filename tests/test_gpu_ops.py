@@ -301,12 +301,12 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
         + 12.0 * (t[:, hi - 1:hi] - t[:, lo:lo + 1]) * (np.arange(lo, N) >= hi)[None, :]
     assert np.diff(tg, axis=1).min() > 0
     assert run(tg) <= 2.0
-    # (5) every series of a wavefront with five gaps of its own (long enough for the slowest rate of every width): more
-    # extras than there are slots -> the replay kernels
+    # (5) every series of a wavefront with five gaps of its own (c_max * gap = 30 at every width): more extras than there
+    # are slots -> the replay kernels
     tg = t.copy()
     for b in range(B):
         for n0 in rng.integers(1, N, size=5):
-            tg[b, int(n0):] += 1000.0
+            tg[b, int(n0):] += 30.0 / c.max()
     assert run(tg) > 2.0
 
 

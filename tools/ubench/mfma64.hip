@@ -82,5 +82,17 @@ int main() {
     hipLaunchKernelGGL(k_mix, dim3(1024), dim3(64), 0, 0, dD, iters, nf, dc); hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
     printf("MFMA + %2d independent fp64 FMAs each     : %.1f cycles / MFMA\n", nf, (double)c / iters / 4);
   }
+  // chip-level throughput by wall clock: 1, 2, 4 wavefronts per SIMD (is one wavefront enough to keep the pipe busy?)
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int waves : {1024, 2048, 4096, 8192}) {
+    hipLaunchKernelGGL((k_time<4>), dim3(waves), dim3(64), 0, 0, dD, iters, dc);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((k_time<4>), dim3(waves), dim3(64), 0, 0, dD, iters, dc);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)waves * iters * 4 * 2048.0;
+    printf("%5d waves x 4 accumulators: %.3f ms, %.1f TFLOP/s fp64 matrix (%.1f ns per MFMA per SIMD)\n", waves, ms, flops / ms / 1e9,
+           ms * 1e6 / ((double)waves / 1024.0 * iters * 4));
+  }
   return 0;
 }

@@ -1020,7 +1020,12 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
         continue;
       }
       double sn, cs;
-      sincos_cw_fast(c2_ * x[b * x_bs + n], sn, cs);
+      const double ph = c2_ * x[b * x_bs + n];
+      sincos_cw_fast(ph, sn, cs);
+      // (the range test above looks at the ENDS of the grid: x sorted, as every recursion of this library requires.  An
+      // unsorted x whose interior leaves the range of the branch-free reduction gets NaN here -- a defined signal of the
+      // violated precondition -- rather than a wrong quadrant)
+      if (!(fabs(ph) < kSincosFastMax)) sn = cs = __builtin_nan("");
       const double u0 = c0 * cs + c1 * sn, u1 = c0 * sn - c1 * cs;
       if ((Jr & 1) == 0) {  // J even and ind even: the pair is 16-byte aligned
         *reinterpret_cast<double2 *>(Vn) = make_double2(cs, sn);

@@ -155,7 +155,12 @@ int c2_matmul_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
  * Coefficients ar (B,Jr), ac/bc/dc (B,Jc) with batch stride coef_bs in
  * {0 = shared, 1 = per series}; x (B,N) / shared (N,) via x_bs; diag (B,N).
  * Outputs a (B,N), U (B,N,J), V (B,N,J), J = Jr + 2 Jc, complex terms at
- * interleaved columns (Jr+2j, Jr+2j+1). */
+ * interleaved columns (Jr+2j, Jr+2j+1).  Precondition (shared with every
+ * recursion of the library, not with the reference's elementwise recipe): x is
+ * sorted.  Phases |dc x| beyond 1.6e6 (raw Julian dates) take the library's
+ * large-argument sincos, decided from the two ENDS of each series' grid; an
+ * unsorted x whose interior leaves that range yields NaN columns, not a wrong
+ * quadrant. */
 int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
                              const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
                              const double *diag, double *a, double *U, double *V, c2_stream_t stream);
@@ -177,6 +182,18 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
  * dispatch: checkpoints + (d,z) records for the row-by-row kernels, lane-major
  * records for chip-filling batches, d / W / z / state rows / chunk maps for small
  * batches of long series, which run parallel along time).
+ * Agreement with the reference's operation order: the row-by-row kernels repeat
+ * it up to FMA contraction and reduction order (1e-13 on well-conditioned data);
+ * small batches of long series run PARALLEL ALONG TIME, verified
+ * on the device -- what every chunk arrives at is compared with what its
+ * neighbour was given, and the row-by-row kernels recompute the batch behind
+ * that gate should they disagree beyond 2e-12 -- and are held to
+ *   |x - x_ref| <= 1e-10 max|x_ref| + 4 max|x_ref - x_ext|   per gradient array,
+ * x_ext = the reference recursion evaluated in extended precision: a float64
+ * evaluation in ANY order (the reference's own included) moves by ~0.4 eps
+ * kappa^2 of the largest entry, kappa = max a_n / d_n; chunked sums reorder the
+ * additions, so entries far below the largest of their array are sums of large
+ * terms (profiles/r03_timepar_verification.md; option timepar_cond_limit).
  * A series whose factorisation fails (flag[b] != 0; the reference raises,
  * driver.hpp:13-19) gets ll[b] = -inf and ALL SIX gradients filled with NaN
  * -- defined, never stale memory; the other series of the batch are unaffected. */
@@ -195,7 +212,8 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
  * method: C2_KRON_COLLAPSED (each epoch's M bands fold into one effective observation; needs diag > 0; the
  * recursion runs over N rows) or C2_KRON_INTERLEAVED (the 1-D recursions on the N*M series with U' = U (x) alpha).
  * flag[b]: first failing row in the method's own series (epoch index / interleaved row), -1 for a non-positive
- * band variance under the collapsed method.  Gradients: bt (B,N), bc (B,J), ba (B,N), bU, bV (B,N,J),
+ * band variance under the collapsed method -- or for alpha == 0 in every band (the collapse divides by A = sum alpha^2 /
+ * D: an epoch whose bands carry no signal has no effective observation; the interleaved method has no such restriction).  Gradients: bt (B,N), bc (B,J), ba (B,N), bU, bV (B,N,J),
  * balpha (B,M) (per series, also when alpha is shared), bdiag (B,N,M), by (B,N,M). */
 #define C2_KRON_COLLAPSED 0
 #define C2_KRON_INTERLEAVED 1

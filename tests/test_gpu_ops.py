@@ -258,7 +258,7 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
     rng = np.random.default_rng(99)
 
-    def run(tg, shared=False):
+    def run(tg, shared=False, floor=FLOOR):
         if shared:   # ONE problem (grid, matrices) for the whole batch, a right-hand side per series
             rep = lambda x: np.ascontiguousarray(np.tile(x[:1], (B,) + (1,) * (x.ndim - 1)))
             ts, cs, as_, Us, Vs = rep(tg), rep(c), rep(a), rep(U), rep(V)
@@ -274,7 +274,7 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
         assert int(flag.abs().sum()) == 0
         close(ll, llo)
         for g, e in zip(grads, go):
-            close(g, e)
+            close(g, e, floor=floor)
         close(ops.loglik(*args)[0], llo)
         return guard
 
@@ -307,7 +307,9 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
     for b in range(B):
         for n0 in rng.integers(1, N, size=5):
             tg[b, int(n0):] += 30.0 / c.max()
-    assert run(tg) > 2.0
+    # (750 gaps: bt next to a gap is the difference of two gap gradients -- one element in 63000 lands at 2.2e-12 of the
+    # largest, on the replay kernels that passed the single-gap cases of the round-2 suite unchanged)
+    assert run(tg, floor=4e-12) > 2.0
 
 
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])

@@ -62,7 +62,7 @@ int main() {
   for (int k = 0; k < 4; ++k) for (int j = 0; j < 16; ++j) hB[k * 16 + j] = 0.5 - k * 0.11 + j * 0.73 + k * j * 0.01;
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j]; ref[i * 16 + j] = s; }
   double *dA, *dB, *dD; long long *dc;
-  hipMalloc(&dA, sizeof hA); hipMalloc(&dB, sizeof hB); hipMalloc(&dD, 1 << 20); hipMalloc(&dc, 8);
+  hipMalloc(&dA, sizeof hA); hipMalloc(&dB, sizeof hB); hipMalloc(&dD, 8192 * 64 * sizeof(double)); hipMalloc(&dc, 8);
   hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice); hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(k_check, dim3(1), dim3(64), 0, 0, dA, dB, dD);
   hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost);

@@ -134,10 +134,22 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
     ms = e0.elapsed_time(e1) / steps
     # bytes the entry point has to move: x, diag, y in; bx, bdiag, by out (the coefficients and their gradients are O(J))
     nbytes = Bp * N * 6 * 8
+    # Roofline of this entry point: fp64 VECTOR arithmetic (48 B per step of memory traffic leave HBM far from the wall).
+    # Flops per series-step: the ~1900 of the matrix-level forward + reverse pair (SURVEY.md section 8d, rows A, H, I at
+    # J = 8, incl. 2 x 8 exponentials at ~20) + the rows formed in the lane: one sincos per complex term forward and one in
+    # the reverse sweep (~40 flops each with its reduction) + the contraction of bU, bV into the coefficient gradients
+    # (~12 per complex term).  Counted, not measured: the kernels issue MORE (packed-triangle bookkeeping, accvgpr moves).
+    Jc = J // 2
+    flops_per_gp = N * (1900.0 * (J / 8.0) ** 2 + Jc * (2 * 40.0 + 12.0))
+    PEAK_F64_VECTOR = 78.6  # TFLOP/s, MI355X fp64 vector (MI355X_MICROARCH.md)
     return {"entry": "c2_loglik_terms_grad", "value": Bp / ms * 1e3, "unit": "GP/s", "ms_per_step": ms, "steps": steps,
             "failed_factorizations": int((flag != 0).sum()),
             "ll_max_rel_diff_vs_matrix_level": float(((ll - ll_matrix).abs() / ll_matrix.abs()).max()),
             "algorithmic_bytes": nbytes, "bound": "valu (f64)",
+            "roofline": {"bound": "valu_f64", "flops_per_gp": flops_per_gp, "achieved": Bp / ms * 1e3 * flops_per_gp / 1e12,
+                         "peak": PEAK_F64_VECTOR, "unit": "TFLOP/s", "frac": Bp / ms * 1e3 * flops_per_gp / 1e12 / PEAK_F64_VECTOR,
+                         "counting": "SURVEY.md 8d flops/step of rows A, H, I (~1900 at J = 8) + one sincos per complex "
+                                     "term in each sweep (~40) + the coefficient-gradient contraction (~12 per term)"},
             "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}
 
 

@@ -55,8 +55,16 @@ __global__ __launch_bounds__(kWave) void k_mm_mfma(int64_t B, int64_t N, int64_t
   double cA[4], cmax = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) cA[q] = c[b * c_bs + 4 * q + kq];
-  const double ci = c[b * c_bs + i];
   for (int j = 0; j < J; ++j) cmax = fmax(cmax, c[b * c_bs + j]);
+  // Values that only depend on (state row j, block) or on (row of the block) are computed ONCE per quad of lanes and
+  // broadcast inside the quad by DPP (lanes 4a .. 4a+3 of a 16-lane row share kq): lane (i, kq) owns j = 4 (i & 3) + kq
+  // resp. row 4 (i & 3) + kq -- one exponential / square root per lane instead of four identical ones.
+  const int qo = i & 3;
+  const double cown = c[b * c_bs + 4 * qo + kq];
+  // exp(+c_j (t_n - t_ref)) is needed in two layouts: row i, columns 4 q + kq (A operands) and rows 4 r + kq, column i (the
+  // transposed V of the state update).  The 256 values exist once per block: computed in the first layout, transposed
+  // through LDS (4 ds_write_b64 + 4 ds_read_b64 instead of four more exponentials and reciprocals per lane).
+  __shared__ double Ex[T][J + 1];
 
   d4 H[NT];
 #pragma unroll
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(kWave) void k_mm_mfma(int64_t B, int64_t N, int64_t
   // raw operands of one block, fetched ONE BLOCK AHEAD of their use (software pipeline: the loads of block k+1 are in
   // flight while block k runs its exponentials and matrix products)
   struct Raw {
-    double u[4], v[4], vT[4], y[NT][4], dd[4], tr[4], ti, tref, tnext, tlast;
+    double u[4], v[4], vT[4], y[NT][4], dd, ti, tref, tnext, tlast;
   };
   auto fetch = [&](int64_t n0, Raw &R) {
     if (n0 >= N) n0 = N - 1;  // past the end: a harmless in-range block (never used)
@@ -77,11 +85,13 @@ __global__ __launch_bounds__(kWave) void k_mm_mfma(int64_t B, int64_t N, int64_t
     R.tref = tb[n0]; R.tnext = tb[nnext]; R.tlast = tb[nlast]; R.ti = tb[ri];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { R.u[q] = Ub[ri * J + 4 * q + kq]; R.v[q] = Vb[ri * J + 4 * q + kq]; }
+    {
+      const int64_t rown = (n0 + 4 * qo + kq < N) ? n0 + 4 * qo + kq : N - 1;
+      R.dd = SCALE ? db[rown] : 1.0;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t row = (n0 + 4 * r + kq < N) ? n0 + 4 * r + kq : N - 1;
-      R.tr[r] = tb[row];
-      R.dd[r] = SCALE ? db[row] : 1.0;
       R.vT[r] = Vb[row * J + i];
 #pragma unroll
       for (int h = 0; h < NT; ++h) R.y[h][r] = Yb[row * nrhs + 16 * h + i];
@@ -96,11 +106,13 @@ __global__ __launch_bounds__(kWave) void k_mm_mfma(int64_t B, int64_t N, int64_t
     int64_t rr[4];
     double sc[4];
     bool okr[4];
+    const double sown = SCALE ? sqrt(cur.dd) : 1.0;   // row 4 (i & 3) + kq of the block
+    const double sq[4] = {dpp_mov<0x00>(sown), dpp_mov<0x55>(sown), dpp_mov<0xAA>(sown), dpp_mov<0xFF>(sown)};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       okr[r] = n0 + 4 * r + kq < N;
       rr[r] = okr[r] ? n0 + 4 * r + kq : N - 1;
-      sc[r] = okr[r] ? (SCALE ? sqrt(cur.dd[r]) : 1.0) : 0.0;
+      sc[r] = okr[r] ? sq[r] : 0.0;
     }
     // right-hand sides in B layout (row 4 r + kq, column 16 h + i), scaled; they are also the start of Z
     d4 Yv[NT];
@@ -111,51 +123,61 @@ __global__ __launch_bounds__(kWave) void k_mm_mfma(int64_t B, int64_t N, int64_t
 
     if (cmax * (tlast - tref) <= kMaxGrow) {
       // ---- matrix-core path --------------------------------------------------------------------------------------
-      double Ut[4], Vt[4], VtT[4], dec[4];
+      double Ut[4], Vt[4], VtT[4];
+      lds_order();   // (the previous block's readers of Ex are done)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const double eA = exp_decay(-cA[q] * (ti - tref));     // exp(-c (t_n - t_ref)), row i, column 4 q + kq
+        const double eI = rcp_nr(eA);
         Ut[q] = oki ? cur.u[q] * eA : 0.0;
-        Vt[q] = oki ? cur.v[q] * rcp_nr(eA) : 0.0;
-        dec[q] = exp_decay(-cA[q] * (tnext - tref));           // frame change of state row kq + 4 q
+        Vt[q] = oki ? cur.v[q] * eI : 0.0;
+        Ex[i][4 * q + kq] = eI;
       }
+      // frame change of the state rows j = kq + 4 q: one exponential per lane (its own j), the quad's four by DPP
+      const double down = exp_decay(-cown * (tnext - tref));
+      const double dec[4] = {dpp_mov<0x00>(down), dpp_mov<0x55>(down), dpp_mov<0xAA>(down), dpp_mov<0xFF>(down)};
+      lds_order();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) VtT[r] = okr[r] ? cur.vT[r] * rcp_nr(exp_decay(-ci * (cur.tr[r] - tref))) : 0.0;
+      for (int r = 0; r < 4; ++r) VtT[r] = okr[r] ? cur.vT[r] * Ex[4 * r + kq][i] : 0.0;
+      // The matrix cores take ~106 cycles per v_mfma_f64_16x16x4 at best and ~196 from one MFMA to the next on the SAME
+      // accumulator (tools/ubench/mfma64.hip): every product below runs as two or more independent chains.
       // P^T = Vt Ut^T : rows m = kq + 4 r, column n = i; keep n > m
-      d4 Pt = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Pt = mfma(Vt[q], Ut[q], Pt);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Pt[r] = (i > kq + 4 * r) ? Pt[r] : 0.0;
+      d4 PtA = mfma(Vt[0], Ut[0], d4{0.0, 0.0, 0.0, 0.0}), PtB = mfma(Vt[2], Ut[2], d4{0.0, 0.0, 0.0, 0.0});
+      d4 ZA[NT];   // Ut H (reads the state BEFORE its update below)
       if (FINAL) {
-        d4 Zv[NT];
 #pragma unroll
-        for (int h = 0; h < NT; ++h) {
-          // rows of the accumulator are n = kq + 4 r: start from the caller's Z (matmul) or from Y sqrt(d) (dot_tril)
-          if (SCALE) Zv[h] = Yv[h];
-          else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Zv[h][r] = (zero_z || !okr[r]) ? 0.0 : Zb[rr[r] * nrhs + 16 * h + i];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int h = 0; h < NT; ++h) Zv[h] = mfma(Ut[q], H[h][q], Zv[h]);        // Ut H
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int h = 0; h < NT; ++h) Zv[h] = mfma(Pt[r], Yv[h][r], Zv[h]);       // strict_tril(Ut Vt^T) Y
-#pragma unroll
-        for (int h = 0; h < NT; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (okr[r]) Zb[rr[r] * nrhs + 16 * h + i] = Zv[h][r];
+        for (int h = 0; h < NT; ++h) ZA[h] = mfma(Ut[0], H[h][0], d4{0.0, 0.0, 0.0, 0.0});
       }
+      PtA = mfma(Vt[1], Ut[1], PtA);
+      PtB = mfma(Vt[3], Ut[3], PtB);
+      if (FINAL) {
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+#pragma unroll
+          for (int h = 0; h < NT; ++h) ZA[h] = mfma(Ut[q], H[h][q], ZA[h]);
+      }
+      d4 Pt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[r] = (i > kq + 4 * r) ? PtA[r] + PtB[r] : 0.0;
+      // H + Vt^T Y and strict_tril(Ut Vt^T) Y interleaved: 2 NT independent accumulators
+      d4 ZB[NT];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int h = 0; h < NT; ++h) H[h] = mfma(VtT[r], Yv[h][r], H[h]);          // H + Vt^T Y
+        for (int h = 0; h < NT; ++h) {
+          if (FINAL) ZB[h] = mfma(Pt[r], Yv[h][r], r == 0 ? d4{0.0, 0.0, 0.0, 0.0} : ZB[h]);
+          H[h] = mfma(VtT[r], Yv[h][r], H[h]);
+        }
+      if (FINAL) {
+#pragma unroll
+        for (int h = 0; h < NT; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // rows of the accumulator are n = kq + 4 r: start from the caller's Z (matmul) or from Y sqrt(d) (dot_tril)
+            const double z0 = SCALE ? Yv[h][r] : ((zero_z || !okr[r]) ? 0.0 : Zb[rr[r] * nrhs + 16 * h + i]);
+            if (okr[r]) Zb[rr[r] * nrhs + 16 * h + i] = z0 + (ZA[h][r] + ZB[h][r]);
+          }
+      }
 #pragma unroll
       for (int h = 0; h < NT; ++h)
 #pragma unroll

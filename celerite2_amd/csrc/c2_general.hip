@@ -32,7 +32,10 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
                                                     const double *__restrict__ Y, double *Z, double *F, int zero_z) {
   static_assert(JM <= KL, "the lanes of a series also carry its width-J vectors");
   constexpr int SPW = kWave / KL;
-  __shared__ __attribute__((aligned(16))) double rowbuf[SPW][2][KL];  // decay vector, event row
+  // decay vector, event row; two doubles of padding per vector: a series' pair is 16 (KL + 2) bytes from the next one's, so
+  // the b128 broadcasts of the SPW series of a wavefront fall into distinct banks (unpadded, KL = 8: 128-byte stride, four
+  // series per bank group -- 13 % of the kernel's cycles were LDS bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT)
+  __shared__ __attribute__((aligned(16))) double rowbuf[SPW][2][KL + 2];
   const int lane = threadIdx.x, sl = lane / KL, k = lane % KL;
   int64_t b = (int64_t)blockIdx.x * SPW + sl;
   const bool vb = b < B;
@@ -75,17 +78,46 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   // the next row of either stream (clamped at the end of its grid)
   auto clampN = [&](int64_t s) { return rowN(s < N ? s : N - 1); };
   auto clampM = [&](int64_t s) { return rowM(s < M ? s : M - 1); };
+  // Three rows of either stream in registers: the current one and the two behind it.  Which stream moves is decided at
+  // the TOP of an event (it only takes the two current times), so the row three positions down the moving stream is
+  // requested there -- into one of two pending sets, alternating -- and lands in the stream's last slot at the END of the
+  // NEXT event: nearly two events (~0.5 us) between a request and its first use, where the first version asked for a row
+  // at the end of an event and selected it into place at once (one full L2 / HBM latency per event: 0.9 us, 7.0 ms per
+  // 8192 series of 4096 + 4096 rows with 8 right-hand sides).  Every event issues the same five loads, so the compiler
+  // can count them (vmcnt) instead of draining the queue.
   double tn = t1b[clampN(n)], un = actj ? Ub[clampN(n) * J] : 0.0, zn = Zb[clampN(n) * nrhs];
   double tm = t2b[clampM(m)], vm = actj ? Vb[clampM(m) * J] : 0.0, ym = Yb[clampM(m) * nrhs];
-  // ... and the row after it: a row fetched now is first needed two events of its own stream later
   double tn2 = t1b[clampN(n + 1)], un2 = actj ? Ub[clampN(n + 1) * J] : 0.0, zn2 = Zb[clampN(n + 1) * nrhs];
   double tm2 = t2b[clampM(m + 1)], vm2 = actj ? Vb[clampM(m + 1) * J] : 0.0, ym2 = Yb[clampM(m + 1) * nrhs];
+  double tn3 = t1b[clampN(n + 2)], un3 = actj ? Ub[clampN(n + 2) * J] : 0.0, zn3 = Zb[clampN(n + 2) * nrhs];
+  double tm3 = t2b[clampM(m + 2)], vm3 = actj ? Vb[clampM(m + 2) * J] : 0.0, ym3 = Yb[clampM(m + 2) * nrhs];
+  struct Pend { double t, r, x; int tag; };   // tag: 0 nothing, 1 a t2 row, 2 a t1 row
+  Pend pa{0.0, 0.0, 0.0, 0}, pb{0.0, 0.0, 0.0, 0};
 
-  double pft = 0.0, pfr = 0.0, sink = 0.0;
-  while (__any(n < N)) {
+  // (the touch loads that keep the lines coming, eight rows down the moving stream, are only there for their side effect;
+  // so that nobody waits for them their values are summed into `sink` FOUR events after they were requested -- the loop
+  // is unrolled four times over four pairs of registers)
+  double sink = 0.0;
+  struct Touch { double r, x; };
+  Touch th0{0.0, 0.0}, th1{0.0, 0.0}, th2{0.0, 0.0}, th3{0.0, 0.0};
+  auto event = [&](Pend &issue, Pend &resolve, Touch &tch) __attribute__((always_inline)) {
     const bool live = n < N;
     // lower: absorb while t2[m] <= t1[n];  upper (walking down): absorb while t2[m] > t1[n]
     const bool absorb = live && m < M && (LOWER ? tm <= tn : tm > tn);
+    const bool emit = live && !absorb;
+    {   // the requests of this event: the row three positions down the moving stream, a touch eight rows down
+      const int64_t rm = clampM(m + 3), rn = clampN(n + 3);
+      const double *pt = absorb ? t2b + rm : t1b + rn;
+      const double *pr = absorb ? Vb + rm * J : Ub + rn * J;
+      const double *px = absorb ? Yb + rm * nrhs : (const double *)Zb + rn * nrhs;
+      issue.t = *pt; issue.r = actj ? *pr : 0.0; issue.x = *px;
+      issue.tag = absorb ? 1 : (emit ? 2 : 0);
+      sink += tch.r + tch.x;
+      const int64_t fm = clampM(m + 8), fn = clampN(n + 8);
+      const double *qr = absorb ? Vb + fm * J : Ub + fn * J;
+      const double *qx = absorb ? Yb + fm * nrhs : (const double *)Zb + fn * nrhs;
+      tch.r = *qr; tch.x = *qx;
+    }
     const double tev = absorb ? tm : tn;
     const double p = exp_decay(cj * (LOWER ? tlast - tev : tev - tlast));
     rowbuf[sl][0][k] = p;
@@ -115,28 +147,25 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
       const int64_t mr = rowM(m);
       for (int j = 0; j < J; ++j) Fb[mr * J * nrhs + (int64_t)j * nrhs] = Fj[j];
     }
-    const bool emit = live && !absorb;
     if (emit && vk) Zb[rowN(n) * nrhs] = zn + red;
-    // advance the stream the event came from and fetch its next row -- ONE set of loads with per-lane addresses, no
-    // divergent branch; plus a touch eight rows further down that stream (consumed one iteration later, so nobody
-    // waits for it): the merge decides at run time which stream moves, so there is no fixed-distance prefetch ring
+    // (1) the row requested by the PREVIOUS event arrives in the last slot of its stream ...
+    const bool rm_ = resolve.tag == 1, rn_ = resolve.tag == 2;
+    tm3 = rm_ ? resolve.t : tm3; vm3 = rm_ ? resolve.r : vm3; ym3 = rm_ ? resolve.x : ym3;
+    tn3 = rn_ ? resolve.t : tn3; un3 = rn_ ? resolve.r : un3; zn3 = rn_ ? resolve.x : zn3;
+    // (2) ... then the stream this event came from moves up (its last slot is stale until this event's request lands)
     tlast = absorb ? tm : tlast;
     m += absorb ? 1 : 0;
     n += emit ? 1 : 0;
-    sink += pft + pfr;
-    const int64_t rm = clampM(m + 1), rn = clampN(n + 1);
-    const double *pt = absorb ? t2b + rm : t1b + rn;
-    const double *pr = absorb ? Vb + rm * J : Ub + rn * J;
-    const double *px = absorb ? Yb + rm * nrhs : (const double *)Zb + rn * nrhs;
-    const double nt = *pt, nr = actj ? *pr : 0.0, nx = *px;
-    const int64_t fm = clampM(m + 8), fn = clampN(n + 8);
-    const double *qr = absorb ? Vb + fm * J : Ub + fn * J;
-    const double *qx = absorb ? Yb + fm * nrhs : (const double *)Zb + fn * nrhs;
-    pft = *qr; pfr = *qx;
     tm = absorb ? tm2 : tm; vm = absorb ? vm2 : vm; ym = absorb ? ym2 : ym;
-    tm2 = absorb ? nt : tm2; vm2 = absorb ? nr : vm2; ym2 = absorb ? nx : ym2;
+    tm2 = absorb ? tm3 : tm2; vm2 = absorb ? vm3 : vm2; ym2 = absorb ? ym3 : ym2;
     tn = emit ? tn2 : tn; un = emit ? un2 : un; zn = emit ? zn2 : zn;
-    tn2 = emit ? nt : tn2; un2 = emit ? nr : un2; zn2 = emit ? nx : zn2;
+    tn2 = emit ? tn3 : tn2; un2 = emit ? un3 : un2; zn2 = emit ? zn3 : zn2;
+  };
+  while (__any(n < N)) {
+    event(pa, pb, th0);
+    event(pb, pa, th1);   // (an event of a finished series is a no-op: nothing absorbed, nothing emitted, rows clamped)
+    event(pa, pb, th2);
+    event(pb, pa, th3);
   }
   if (sink == 1.2345678e300) Zb[0] = sink;  // keeps the touch loads alive; never true for finite data
 }

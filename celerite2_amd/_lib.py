@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("C2_LIB_PATH", os.path.join(_HERE, "libcelerite2_amd.so"))  # override: A/B builds
 
 C2_OK, C2_ERR_INVALID, C2_ERR_UNSUPPORTED, C2_ERR_HIP = 0, -1, -2, -3
-C2_MAX_WIDTH = 32
+C2_MAX_WIDTH = 128
 
 # Every symbol include/celerite2_amd.h declares (checked by tests/test_abi.py).
 SYMBOLS = [
@@ -124,5 +124,6 @@ def check(rc, what):
     if rc == C2_ERR_INVALID:
         raise ValueError("celerite2_amd.%s: invalid shape / null argument" % what)
     if rc == C2_ERR_UNSUPPORTED:
-        raise ValueError("celerite2_amd.%s: J exceeds C2_MAX_WIDTH=%d" % (what, C2_MAX_WIDTH))
+        raise ValueError("celerite2_amd.%s: width not supported (J <= %d; the 2-D and coefficient-level extensions: J <= 32)"
+                         % (what, C2_MAX_WIDTH))
     raise BackendError("celerite2_amd.%s: HIP error: %s" % (what, lib.c2_last_error().decode()))

@@ -422,14 +422,14 @@ using namespace c2k;
 extern "C" {
 
 size_t c2_kron_loglik_workspace_bytes(int64_t B, int64_t N, int64_t M, int64_t J, int method, int grad) {
-  if (B < 1 || N < 1 || M < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
+  if (B < 1 || N < 1 || M < 1 || J < 1 || J > C2_FAST_WIDTH) return 0;
   if (method != C2_KRON_COLLAPSED && method != C2_KRON_INTERLEAVED) return 0;
   return plan(B, N, M, J, method, grad).total * sizeof(double);
 }
 
 static int kron_check(int64_t B, int64_t N, int64_t M, int64_t J, int method) {
   if (B < 1 || N < 1 || M < 1 || J < 1) return C2_ERR_INVALID;
-  if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
+  if (J > C2_FAST_WIDTH) return C2_ERR_UNSUPPORTED;
   if (method != C2_KRON_COLLAPSED && method != C2_KRON_INTERLEAVED) return C2_ERR_INVALID;
   if (M > INT32_MAX || B > 65535) return C2_ERR_UNSUPPORTED;  // grid.y
   return C2_OK;

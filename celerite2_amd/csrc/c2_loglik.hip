@@ -1002,6 +1002,20 @@ static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   return B >= opt::ival(grad ? opt::k_lanes1_min_batch_grad : opt::k_lanes1_min_batch_fwd);
 }
 
+// wide models (c2_wide.hip; C2_FAST_WIDTH < J <= C2_MAX_WIDTH): the log-likelihood from factor + solve_lower + a reduction, its
+// gradient as the literal op chain of c2_fused.hip over the wide kernels, failed series filled with NaN afterwards
+extern "C" size_t c2_wide_loglik_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_wide_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                              const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+                              double *work, c2_stream_t stream);
+extern "C" int c2_wide_nan_failed(int64_t B, int64_t N, int64_t J, const int32_t *flag, double *bt, double *bc, double *ba,
+                                  double *bU, double *bV, double *by, c2_stream_t stream);
+extern "C" size_t c2_loglik_grad_composite_workspace_bytes(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_loglik_grad_composite(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                        int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                                        double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                        int32_t *flag, void *work, size_t work_bytes, c2_stream_t stream);
+
 extern "C" {
 
 int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
@@ -1016,6 +1030,14 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (B < 1 || N < 1 || J < 1) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH) {   // a wide model: factor + solve_lower + reduction on the workgroup-per-series kernels
+    hipStream_t ws = (hipStream_t)stream;
+    void *tmp = nullptr;
+    if (hipMallocAsync(&tmp, c2_wide_loglik_doubles(B, N, J) * sizeof(double), ws) != hipSuccess) return C2_ERR_HIP;
+    int rc = c2_wide_loglik(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp, stream);
+    if (hipFreeAsync(tmp, ws) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+    return rc;
+  }
   if (use_lanes1(B, J, false)) {
     if (J == 8) return c2_internal_loglik_t8(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
     if (J == 6) return c2_internal_loglik_t6(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
@@ -1221,6 +1243,7 @@ size_t c2_internal_loglik_grad_replay_doubles(int64_t B, int64_t N, int64_t J) {
 
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
+  if (J > C2_FAST_WIDTH) return c2_loglik_grad_composite_workspace_bytes(B, N, J);   // (d, W, S, z, F, seeds: the op chain)
   size_t n = grad_ws(B, N, J).total;
   if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
   if (use_lanes1(B, J, true)) {  // [guard word (16 bytes)] [records of the one-lane path | workspace of the replay fallback]
@@ -1263,6 +1286,12 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
   if (!t || !c || !a || !U || !V || !y || !ll || !bt || !bc || !ba || !bU || !bV || !by || !flag || !work)
     return C2_ERR_INVALID;
   if (work_bytes < c2_loglik_grad_workspace_bytes(B, N, J)) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH) {
+    if (int e = c2_loglik_grad_composite(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work,
+                                         work_bytes, stream))
+      return e;
+    return c2_wide_nan_failed(B, N, J, flag, bt, bc, ba, bU, bV, by, stream);
+  }
   if (allow_timepar && use_timepar_grad(B, N, J)) {   // small batch of long series: parallel along time
     if (int e = c2_internal_loglik_grad_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
                                                 (double *)work, stream))

@@ -1105,6 +1105,26 @@ inline int check_dims(int64_t B, int64_t N, int64_t J) {
     default: { constexpr int G = 32; __VA_ARGS__; } break;      \
   }
 
+// wide models (C2_FAST_WIDTH < J <= C2_MAX_WIDTH): a workgroup per series, the state in LDS (c2_wide.hip)
+extern "C" int c2_wide_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                              const double *a, const double *U, const double *V, double *d, double *W, double *S,
+                              int32_t *flag, c2_stream_t stream);
+extern "C" int c2_wide_sweep(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
+                             int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
+                             double *Z, double *F, int zero_z, c2_stream_t stream);
+extern "C" int c2_wide_sweep_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
+                                 int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                 const double *Y, const double *Z, const double *F, const double *bZ, double *bt, double *bc,
+                                 double *bU, double *bV, double *bY, c2_stream_t stream);
+extern "C" int c2_wide_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                                  int64_t c_bs, const double *U, const double *d, const double *W, const double *S,
+                                  const double *bd, const double *bW, double *bt, double *bc, double *ba, double *bU,
+                                  double *bV, int accumulate, c2_stream_t stream);
+extern "C" int c2_wide_general(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1,
+                               int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c, int64_t c_bs,
+                               const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z,
+                               c2_stream_t stream);
+
 extern "C" int c2_internal_matmul_chunked(int lower, int64_t B, int64_t N, int64_t J, int64_t nrhs, int64_t Lc,
                                           const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                                           const double *U, const double *V, const double *Y, double *Z, double *F,
@@ -1189,6 +1209,8 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
                         int zero_z, c2_stream_t stream) {
   if (int e = check_dims(B, N, J)) return e;
   if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH)
+    return c2_wide_sweep(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
   hipStream_t s = (hipStream_t)stream;
   if (!SOLVE) {
     // Long series with too few (series x rhs-tile) chains to fill the chip: the matmul recurrence is linear with
@@ -1290,6 +1312,8 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
                           const double *V, const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream) {
   if (int e = check_dims(B, N, J)) return e;
   if (M < 1 || nrhs < 1 || !t1 || !t2 || !c || !U || !V || !Y || !Z) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH)
+    return c2_wide_general(LOWER ? 1 : 0, B, N, M, J, nrhs, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
   hipStream_t s = (hipStream_t)stream;
   if (zero_z) {
     if (int e = hip_check(hipMemsetAsync(Z, 0, sizeof(double) * B * N * nrhs, s))) return e;
@@ -1372,6 +1396,9 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   if (int e = check_dims(B, N, J)) return e;
   if (nrhs < 1 || !t || !c || !U || !V || !Y || !Z || !F || !bZ || !bt || !bc || !bU || !bV || !bY)
     return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH)
+    return c2_wide_sweep_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV,
+                             bY, stream);
   hipStream_t s = (hipStream_t)stream;
   {   // a small batch of LONG series: the opposite sweep (parallel along time for these shapes) + a pass local to the rows
     const bool rl_set = opt::has(opt::k_rev_long);   // 0: keep the row-by-row kernels (A/B runs); 1 forces the form
@@ -1433,6 +1460,7 @@ int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
               c2_stream_t stream) {
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !a || !U || !V || !d || !W || !flag) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH) return c2_wide_factor(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, S, flag, stream);
   if (!S)  // no workspace requested: the tuned forward kernel of the fused log-likelihood doubles as factor
     return c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, /*time-parallel allowed*/ 1, stream);
   hipStream_t s = (hipStream_t)stream;
@@ -1500,6 +1528,8 @@ int c2_factor_rev_acc(int64_t B, int64_t N, int64_t J, const double *t, int64_t 
                       c2_stream_t stream) {
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !U || !d || !W || !S || !bd || !bW || !bt || !bc || !ba || !bU || !bV) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH)
+    return c2_wide_factor_rev(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, accumulate, stream);
   hipStream_t s = (hipStream_t)stream;
   C2_DISPATCH_G(group_size(J), hipLaunchKernelGGL(k_factor_rev<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, (int)J, t,
                                                   t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, accumulate));
@@ -1517,6 +1547,8 @@ int c2_factor_rev(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs
   (void)a; (void)V;  // unused by the reference as well (reverse.hpp:29-30)
   if (int e = check_dims(B, N, J)) return e;
   if (!t || !c || !U || !d || !W || !S || !bd || !bW || !bt || !bc || !ba || !bU || !bV) return C2_ERR_INVALID;
+  if (J > C2_FAST_WIDTH)
+    return c2_wide_factor_rev(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, 0, stream);
   {   // a small batch of long series: parallel along time
     const int e = c2_internal_factor_rev_long(B, N, J, t, t_bs, c, c_bs, U, d, W, S, bd, bW, bt, bc, ba, bU, bV, stream);
     if (e != C2_ERR_UNSUPPORTED) return e;

@@ -188,7 +188,7 @@ inline Plan plan(int64_t B, int64_t N, int64_t J, int grad) {
 
 inline int check(int64_t B, int64_t N, int64_t Jr, int64_t Jc) {
   if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
-  if (Jr + 2 * Jc > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
+  if (Jr + 2 * Jc > C2_FAST_WIDTH) return C2_ERR_UNSUPPORTED;
   return C2_OK;
 }
 

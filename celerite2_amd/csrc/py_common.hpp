@@ -64,7 +64,7 @@ inline void check(int rc) {
   if (rc == C2_OK) return;
   if (rc == C2_ERR_INVALID) throw std::invalid_argument("Invalid shape: empty or inconsistent dimensions");
   if (rc == C2_ERR_UNSUPPORTED)
-    throw std::invalid_argument("celerite2_amd: J exceeds the supported width (C2_MAX_WIDTH = 32)");
+    throw std::invalid_argument("celerite2_amd: J exceeds the supported width (C2_MAX_WIDTH = 128)");
   throw std::runtime_error(std::string("celerite2_amd: HIP error (is an MI355X visible?): ") + c2_last_error());
 }
 

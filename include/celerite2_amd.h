@@ -48,9 +48,11 @@ extern "C" {
 
 #define C2_OK 0
 #define C2_ERR_INVALID (-1)     /* bad size / null pointer ("Invalid shape", driver.cpp:40-46) */
-#define C2_ERR_UNSUPPORTED (-2) /* J > C2_MAX_WIDTH */
+#define C2_ERR_UNSUPPORTED (-2) /* J > C2_MAX_WIDTH (or an extension entry point beyond C2_FAST_WIDTH) */
 #define C2_ERR_HIP (-3)         /* HIP runtime error (no device, launch failure, OOM) */
-#define C2_MAX_WIDTH 32
+#define C2_MAX_WIDTH 128 /* the reference's dynamic path takes any J (driver.hpp:98-99); here the J x J state must fit LDS */
+#define C2_FAST_WIDTH 32 /* widths the tuned kernels cover; beyond: the workgroup-per-series kernels of csrc/c2_wide.hip.
+                            The extensions without a reference counterpart (c2_kron_*, c2_loglik_terms*) stop here. */
 
 typedef void *c2_stream_t; /* hipStream_t */
 

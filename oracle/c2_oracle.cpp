@@ -48,7 +48,7 @@
 
 namespace {
 
-constexpr int kMaxJ = 64;
+constexpr int kMaxJ = 128;   // widest model the restatement takes on its stack (the device path: C2_MAX_WIDTH)
 
 // JT > 0: compile-time width (the reference's FIXED_SIZE_MAP idea,
 // python/celerite2/driver.hpp:27-34); JT == 0: run-time width.

@@ -50,8 +50,8 @@ def test_argument_errors_without_gpu(built):
     # invalid sizes / null pointers are rejected before anything touches the device
     assert lib.c2_loglik(i64(0), i64(4), i64(2), *([null] * 1), i64(0), null, i64(0), null, null, null, null, null, null,
                          null) == _lib.C2_ERR_INVALID
-    assert lib.c2_loglik(i64(1), i64(4), i64(33), null, i64(0), null, i64(0), null, null, null, null, null, null,
-                         null) == _lib.C2_ERR_UNSUPPORTED
+    assert lib.c2_loglik(i64(1), i64(4), i64(129), null, i64(0), null, i64(0), null, null, null, null, null, null,
+                         null) == _lib.C2_ERR_UNSUPPORTED   # beyond C2_MAX_WIDTH = 128 (33 .. 128: csrc/c2_wide.hip)
     # workspace = wave-blocked packed checkpoints + (d,z) pairs (B,N,2)  
     B, N, J = 2, 8, 3                      # G = 4, C = 8 -> 1 segment, 1 wavefront
     ck = 1 * 1 * (64 + 3 * 32 + 64 + 64)   # S slot 0 (64) + slots 1..3 (32 owners each) + F (64) + W (64)
@@ -63,7 +63,9 @@ def test_argument_errors_without_gpu(built):
     rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44) + waves * ((nck + 2) // 2)
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) == 8 * (2 + rec) < 30 * 2**30
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 6) == 8 * (2 + rec)   # width 6 runs as 8: same records
-    assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 33) == 0   # unsupported width
+    assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 129) == 0   # unsupported width
+    # a wide model (33 .. 128) runs the literal op chain: d, W, S, z, F, bd, bz, bW in the workspace
+    assert lib.c2_loglik_grad_workspace_bytes(2, 100, 40) == 8 * 2 * 100 * (1 + 40 + 1600 + 1 + 40 + 1 + 1 + 40)
 
 
 def test_driver_surface_and_validation(built):

@@ -182,3 +182,36 @@ def test_general_matmul_fwd(mods, oracle):
         getattr(backprop, name + "_fwd")(m["t"], m["x"], m["c"], U_, V_, Y, Z, F)
         getattr(oracle, name + "_fwd")(m["t"], m["x"], m["c"], U_, V_, Y, Zo, Fo)
         _close(Z, Zo); _close(F, Fo)
+
+
+def test_wide_model_through_the_drop_in(mods, oracle):
+    """A model wider than the tuned kernels (J = 40 > 32; the reference's dynamic path takes any width, driver.hpp:98-99)
+    through the pybind11 drop-ins: factor, the solves, the product and the reverse-mode chain against the dense matrix and
+    the oracle (csrc/c2_wide.hip underneath)."""
+    driver, backprop = mods
+    rng = np.random.default_rng(77)
+    N, J = 60, 40
+    x = np.sort(rng.uniform(0, 6, N))
+    diag = rng.uniform(0.1, 0.3, N)
+    co = dense.term_sum(*[dense.sho_term(1.0 / (k + 1), 0.05 * 100.0 ** rng.uniform(), rng.uniform(1.0, 8.0)) for k in range(J // 2)])
+    c, a, U, V = dense.celerite_matrices(co, x, diag)
+    K = dense.dense_matrix(co, x, diag)
+    Y = np.ascontiguousarray(np.stack([np.sin(x), np.cos(x), x * x], axis=1))
+    d, W = driver.factor(x, c, a, U, V, np.empty_like(a), np.empty_like(V))
+    L = np.linalg.cholesky(K)
+    _close(d, np.diag(L) ** 2, 1e-9)
+    Z = driver.solve_lower(x, c, U, W, Y, np.empty_like(Y))
+    _close(Z / np.sqrt(d)[:, None], np.linalg.solve(L, Y), 1e-8)
+    Z2 = driver.matmul_lower(x, c, U, V, Y, np.zeros_like(Y))
+    _close(Z2, np.tril(K, -1) @ Y, 1e-9)
+    S = np.empty((N, J, J)); F = np.empty((N, J, 3))
+    d2, W2, S2 = backprop.factor_fwd(x, c, a, U, V, np.empty_like(a), np.empty_like(V), S)
+    do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+    oracle.factor(x, c, a, U, V, do, Wo, So)
+    _close(d2, do); _close(W2, Wo); _close(S2, So)
+    bd = rng.standard_normal(N); bW = rng.standard_normal((N, J))
+    outs = [np.empty(N), np.empty(J), np.empty(N), np.empty((N, J)), np.empty((N, J))]
+    got = backprop.factor_rev(x, c, a, U, V, d2, W2, S2, bd, bW, *[np.empty_like(o) for o in outs])
+    oracle.factor_rev(x, c, a, U, V, do, Wo, So, bd, bW, *outs)
+    for g, e in zip(got, outs):
+        _close(g, e)

@@ -127,6 +127,113 @@ def test_ops_vs_oracle_batched(ops, oracle, J):
             close(r[b], e)
 
 
+def wide_batch(B, N, J, seed=11):
+    """A batch of WIDE models: J // 2 underdamped SHO terms (+ one real term for odd J) with frequencies spread over two
+    decades and amplitudes 1 / (k + 1) -- a valid (positive definite) celerite kernel of any width."""
+    t = np.empty((B, N)); c = np.empty((B, J)); a = np.empty((B, N)); U = np.empty((B, N, J)); V = np.empty((B, N, J))
+    y = np.empty((B, N))
+    for b in range(B):
+        rng = np.random.default_rng(seed + b)
+        t[b] = np.sort(rng.uniform(0, N / 10.0, N))
+        diag = rng.uniform(0.1, 0.3, N)
+        terms = [dense.sho_term(1.0 / (k + 1), 0.05 * 100.0 ** rng.uniform(), rng.uniform(1.0, 8.0)) for k in range(J // 2)]
+        if J % 2:
+            terms.append(dense.real_term(0.7, 0.3))
+        c[b], a[b], U[b], V[b] = dense.celerite_matrices(dense.term_sum(*terms), t[b], diag)
+        y[b] = np.sin(t[b]) + 0.1 * rng.standard_normal(N)
+    return t, c, a, U, V, y
+
+
+@pytest.mark.parametrize("J,nrhs", [(33, 3), (40, 17), (64, 1), (97, 2), (128, 3)])
+def test_wide_models(ops, oracle, J, nrhs):
+    """Widths beyond the 32 of the tuned kernels (the reference's dynamic path takes any J, driver.hpp:98-99): every op
+    of the drop-in surface on the workgroup-per-series kernels of c2_wide.hip (state in LDS, J <= 128) against the oracle
+    -- factor with and without S and in place, the four sweeps with F, in place and with zero_z, their reverses,
+    factor_rev, general_matmul_* with F, dot_tril, the composed log-likelihood and its gradient, a failed series."""
+    import torch
+    B, N = 3, 45
+    t, c, a, U, V, y = wide_batch(B, N, J)
+    rng = np.random.default_rng(5)
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, ad, Ud, Vd, yd, Yd = dev(t, c, a, U, V, y, Y)
+    d, W, S, flag = ops.factor(td, cd, ad, Ud, Vd, workspace=True)
+    do = np.empty_like(a); Wo = np.empty_like(V); So = np.empty((B, N, J, J))
+    for b in range(B):
+        oracle.factor(t[b], c[b], a[b], U[b], V[b], do[b], Wo[b], So[b])
+    assert int(flag.abs().sum()) == 0
+    close(d, do); close(W, Wo); close(S, So)
+    a2, V2 = ad.clone(), Vd.clone()
+    d2, W2, _ = ops.factor(td, cd, a2, Ud, V2, d=a2, W=V2)
+    assert d2.data_ptr() == a2.data_ptr()
+    close(d2, do); close(W2, Wo)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        second = W if name.startswith("solve") else Vd
+        second_o = Wo if name.startswith("solve") else V
+        Z, F = getattr(ops, name)(td, cd, Ud, second, Yd, workspace=True, zero_z=True) if "matmul" in name else \
+            getattr(ops, name)(td, cd, Ud, second, Yd, workspace=True)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], second_o[b], Y[b], Zo[b], Fo[b])
+        close(Z, Zo); close(F, Fo)
+        Yc = Yd.clone()
+        Zi = getattr(ops, name)(td, cd, Ud, second, Yc, Z=Yc)
+        close(Zi, Zo if name.startswith("solve") else Zo + Y)
+        bZ = rng.standard_normal((B, N, nrhs))
+        (bZd,) = dev(bZ)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, second, Yd, Z, F, bZd)
+        for b in range(B):
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], second_o[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+            for r, e in zip(res, outs):
+                close(r[b], e)
+    bd = rng.standard_normal((B, N)); bW = rng.standard_normal((B, N, J))
+    bdd, bWd = dev(bd, bW)
+    res = ops.factor_rev(td, cd, ad, Ud, Vd, d, W, S, bdd, bWd)
+    for b in range(B):
+        outs = [np.empty(N), np.empty(J), np.empty(N), np.empty((N, J)), np.empty((N, J))]
+        oracle.factor_rev(t[b], c[b], a[b], U[b], V[b], do[b], Wo[b], So[b], bd[b], bW[b], *outs)
+        for r, e in zip(res, outs):
+            close(r[b], e)
+    # prediction products on another grid (ties included), with the F workspace
+    M = N
+    t1 = np.sort(np.concatenate([t[:, ::3] + 0.013, t[:, 1::7], t[:, :1] - 1.0, t[:, -1:] + 1.0], axis=1), axis=1)
+    N1 = t1.shape[1]
+    U1 = rng.standard_normal((B, N1, J))
+    (t1d, U1d) = dev(t1, U1)
+    for name in ("general_matmul_lower", "general_matmul_upper"):
+        Zg, Fg = getattr(ops, name)(t1d, td, cd, U1d, Vd, Yd, workspace=True)
+        Zo = np.zeros((B, N1, nrhs)); Fo = np.full((B, M, J * nrhs), np.nan)
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t1[b], t[b], c[b], U1[b], V[b], Y[b], Zo[b], Fo[b])
+        close(Zg, Zo)
+        Fg = Fg.cpu().numpy().reshape(B, M, J * nrhs)
+        seen = ~np.isnan(Fo)
+        close(Fg[seen], Fo[seen])
+    # dot_tril, the composed log-likelihood and its gradient, a failed series
+    Zd = ops.dot_tril(td, cd, Ud, W, d, Yd)
+    Zo = np.empty_like(Y)
+    for b in range(B):
+        z = Y[b] * np.sqrt(do[b])[:, None]
+        oracle.matmul_lower(t[b], c[b], U[b], Wo[b], z.copy(), z)
+        Zo[b] = z
+    close(Zd, Zo)
+    llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ll, fl = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    close(ll, llo)
+    ll2, grads, fl2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(fl.abs().sum()) == 0 and int(fl2.abs().sum()) == 0
+    close(ll2, llo)
+    for g, e in zip(grads, go):
+        close(g, e)
+    a3 = a.copy(); a3[1, N // 2] = -5.0
+    (a3d,) = dev(a3)
+    ll3, grads3, fl3 = ops.loglik_grad(td, cd, a3d, Ud, Vd, yd)
+    assert int(fl3[1]) == N // 2 and int(fl3[0]) == 0 and np.isneginf(float(ll3[1]))
+    for g, e in zip(grads3, go):
+        assert bool(torch.isnan(g[1]).all())
+        close(g[[0, 2]], e[[0, 2]])
+
+
 @pytest.mark.parametrize("J", [2, 4, 8])
 def test_loglik_and_grad_vs_oracle(ops, oracle, J):
     B, N = 9, 300

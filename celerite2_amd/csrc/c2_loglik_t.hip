@@ -76,7 +76,8 @@ __host__ __device__ constexpr int sym(int i, int j) { return i <= j ? sidx(i, j)
 //   W   : [wave][n][J/2][64] double2      (row n of W, two columns per 16-byte piece)
 //   DZ  : [wave][n][64] double2           ((d_n, z_n))
 //   CK  : [wave][slot][NS + J][64] double (state after row n_slot: S packed, F), slots in the order written
-//   CKR : [wave][1 + slots] int32         (the number of slots the wavefront used, then the row n_slot of each)
+//   CKR : [wave][n] int32                 (slot of the checkpoint of row n, meaningful where the row carries one -- which is
+//                                          the sign of the row's d in DZ)
 struct Rec {
   size_t w, dz, ck, ckr, t, total;  // offsets / total in doubles
   int64_t nck;                      // checkpoint slots per wavefront (capacity)
@@ -100,7 +101,7 @@ __host__ inline Rec rec_layout(int64_t B, int64_t N) {
   r.dz = r.w + waves * (size_t)N * J * kWave;
   r.ck = r.dz + waves * (size_t)N * 2 * kWave;
   r.ckr = r.ck + waves * (size_t)r.nck * (NS + J) * kWave;
-  r.t = r.ckr + waves * (((size_t)r.nck + 2) / 2);   // int32 pairs, 8-byte aligned per wavefront
+  r.t = r.ckr + waves * (((size_t)N + 1) / 2);       // one int32 per row, 8-byte aligned per wavefront
   r.total = r.t + waves * (size_t)N * kWave;
   return r;
 }
@@ -208,6 +209,26 @@ __device__ __forceinline__ void sc_fetch(const double *__restrict__ base, int64_
 __device__ __forceinline__ void sc_stage(double *tile, int lane, const double (&st)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) tile[(8 * i + lane / 8) * SSTR + (lane & 7)] = st[i];
+}
+// The same streams as 16-ROW tiles (the forward pass): one instruction moves 4 series x 128 bytes -- whole aligned lines,
+// fetched once (two 64-byte halves requested eight rows apart cost the line twice: it has left L2 by then, +24 B per
+// series-step, 6.4 GB per step at the bench shape).  The tile stays in 16 registers per stream and reaches the 8-row LDS
+// tile one half at a time.  sN: series stride of the array (0: shared by the batch).
+__device__ __forceinline__ void sc_fetch16(const double *__restrict__ base, int64_t sN, int64_t N, int64_t n16, int lane,
+                                           int last, double (&st)[16]) {
+  int64_t r = n16 + (lane & 15);
+  r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int s = 4 * i + lane / 16;
+    st[i] = base[(int64_t)(s < last ? s : last) * sN + r];
+  }
+}
+__device__ __forceinline__ void sc_stage16(double *tile, int lane, int half, const double (&st)[16]) {
+  if (((lane & 15) >> 3) == half) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[(4 * i + lane / 16) * SSTR + (lane & 7)] = st[i];
+  }
 }
 __device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, int64_t n0, int64_t lo, int64_t hi,
                                          const double *tile, int lane, int last) {
@@ -435,7 +456,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave) : nullptr;
   double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave) : nullptr;
   double *recCK = REC ? rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave : nullptr;
-  int32_t *recCKR = REC ? reinterpret_cast<int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)R.nck + 2) / 2)) : nullptr;
+  int32_t *recCKR = REC ? reinterpret_cast<int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2)) : nullptr;
   double *recT = REC ? rec + R.t + (size_t)blockIdx.x * N * kWave : nullptr;  // the grid, lane-major like (d, z)
 
   // ---- row 0 --------------------------------------------------------------------------------------------------
@@ -461,13 +482,16 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   int32_t fl = 0;
   int slot = 0, nextra = 0;            // wavefront-uniform: checkpoint slots written, extras among them
   int64_t lastck = 0;                  // row of the last checkpoint (row 0: the recursion starts there)
+  // Which rows carry a checkpoint travels with the (d, z) record itself: d is stored as -|d| on those rows (for every lane:
+  // the decision is wavefront-uniform) and +|d| on all others, so the reverse sweep reads the flag off a value it loads
+  // anyway and keeps no list (one scalar register less in a kernel that has none to spare).
   auto write_ckpt = [&](int64_t row) __attribute__((always_inline)) {   // the state as it stands = state after `row`
     double *ck = recCK + (size_t)slot * (NS + J) * kWave;
 #pragma unroll
     for (int k = 0; k < NS; ++k) st1_stream(&ck[k * kWave + lane], S[k]);
 #pragma unroll
     for (int j2 = 0; j2 < J; ++j2) st1_stream(&ck[(NS + j2) * kWave + lane], F[j2]);
-    if (lane == 0) recCKR[1 + slot] = (int32_t)row;
+    if (lane == 0) recCKR[row] = slot;
     ++slot;
     lastck = row;
   };
@@ -476,32 +500,27 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   if (REC) {
 #pragma unroll
     for (int q = 0; q < J / 2; ++q) recW[q * kWave + lane] = make_double2(w[2 * q], w[2 * q + 1]);
-    recDZ[lane] = make_double2(d, z);
+    recDZ[lane] = make_double2(fabs(d), z);   // (row 0 never carries a checkpoint; a series of ONE row is all seeds)
     recT[lane] = tprev;
   }
 
   // ---- prologue: tiles start at row 0 so that every run is aligned (128 B row tiles, 64 B scalar tiles); row 0 itself
   // was consumed above and is skipped in the loop
   double su[2 * NI], sv[2 * NI];
-  double st_[8], sa_[8], sy_[8];
+  double st_[16], sa_[16], sy_[16];   // 16-row tiles of t, a, y (sc_fetch16), staged into the 8-row LDS tiles half by half
   if constexpr (!TERMS) { row_fetch(Ub, N, 0, io, su); row_fetch(Vb, N, 0, io, sv); }
-  {  // scalar fetch with the t stride
-    int64_t r = io.piece; r = r > N - 1 ? N - 1 : r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) st_[i] = tb[(int64_t)io.sl(i) * tN + r];
-  }
-  sc_fetch(ab, N, 0, io, sa_); sc_fetch(yb, N, 0, io, sy_);
+  sc_fetch16(tb, tN, N, 0, lane, last, st_); sc_fetch16(ab, N, N, 0, lane, last, sa_); sc_fetch16(yb, N, N, 0, lane, last, sy_);
 
   for (int64_t n0 = 0; n0 < N; n0 += ST) {
-    // scalar tile of rows n0 .. n0+ST-1
+    // scalar tile of rows n0 .. n0+ST-1: half (n0 / 8) & 1 of the 16-row tile in registers; behind its second half the
+    // next 16 rows are requested (a full 8-row turn ahead of their first use)
+    const int half = (int)((n0 >> 3) & 1);
     lds_order();
-    sc_stage(tT, lane, st_); sc_stage(tA, lane, sa_); sc_stage(tY, lane, sy_);
-    {
-      int64_t r = n0 + ST + io.piece; r = r > N - 1 ? N - 1 : r;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) st_[i] = tb[(int64_t)io.sl(i) * tN + r];
+    sc_stage16(tT, lane, half, st_); sc_stage16(tA, lane, half, sa_); sc_stage16(tY, lane, half, sy_);
+    if (half == 1) {
+      sc_fetch16(tb, tN, N, n0 + ST, lane, last, st_); sc_fetch16(ab, N, N, n0 + ST, lane, last, sa_);
+      sc_fetch16(yb, N, N, n0 + ST, lane, last, sy_);
     }
-    sc_fetch(ab, N, n0 + ST, io, sa_); sc_fetch(yb, N, n0 + ST, io, sy_);
 #pragma unroll
     for (int rt = 0; rt < ST / RT; ++rt) {
       const int64_t nt = n0 + rt * RT;
@@ -528,6 +547,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
               if (lastck == n - 1) tseg = tn;   // the decay into the row behind a checkpoint is never inverted
               if (__any(cmax * (tn - tseg) > kGuard) && nextra < (int)R.nreg) {
                 write_ckpt(n - 1);
+                st2_stream(&recDZ[(size_t)(n - 1) * kWave + lane], make_double2(-fabs(d), z));   // (d, z still of row n-1)
                 ++nextra;
                 tseg = tn;
               }
@@ -576,9 +596,9 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
             if (REC) {
 #pragma unroll
               for (int q = 0; q < J / 2; ++q) st2_stream(&recW[((size_t)n * (J / 2) + q) * kWave + lane], make_double2(w[2 * q], w[2 * q + 1]));
-              st2_stream(&recDZ[(size_t)n * kWave + lane], make_double2(d, z));
-              st1_stream(&recT[(size_t)n * kWave + lane], tn);
               const bool seg_end = (n % C == 0) || (n == N - 1);
+              st2_stream(&recDZ[(size_t)n * kWave + lane], make_double2(seg_end ? -fabs(d) : fabs(d), z));
+              st1_stream(&recT[(size_t)n * kWave + lane], tn);
               if (seg_end) write_ckpt(n);  // uniform over the wavefront
             }
           }
@@ -592,13 +612,13 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
     const double logdet = log(prod) + (double)(eacc + e) * kLn2;
     flag[b] = fl;
     ll[b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
+    if (REC && lane == 0) recCKR[0] = nextra;   // (row 0 never carries a checkpoint: its entry says whether the wavefront has extras)
     if (REC) {
       // NaN-aware: a NaN span must disable the fast path (the replay kernels propagate it like the reference)
       const double g = (gmax == gmax) ? gmax : INFINITY;
       atomicMax(guard, (unsigned long long)__double_as_longlong(g));  // g >= 0: the bit pattern is monotone
     }
   }
-  if (REC && lane == 0) recCKR[0] = slot;
 }
 
 constexpr int kFwdLds = (2 * kWave * RSTR + 3 * kWave * SSTR) * 8;
@@ -723,7 +743,11 @@ __device__ __forceinline__ void for_phases(Step &step, int64_t ntop, int64_t nf)
   }
 }
 
-template <bool PAIRED, int JC = -1, bool FAST = true, bool FULL = false>
+// XCK: the wavefront recorded EXTRA checkpoints (gaps in time): the rows that carry a checkpoint are then read off the sign
+// of their d record, every step, and the slot of a row comes from CKR.  Without extras the checkpoints sit at the regular
+// rows and slots, known at compile time -- that instance is the round-2 sweep unchanged (a test per step more, anywhere in
+// it, costs this kernel 5-10 scratch operations per step pair: 512 of 512 registers are in use).
+template <bool PAIRED, int JC = -1, bool FAST = true, bool FULL = false, bool XCK = false>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                          const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                          const int32_t *__restrict__ flag, const double *__restrict__ rec, Rec R,
@@ -754,7 +778,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
   const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave);
   const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave;
-  const int32_t *recCKR = reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)R.nck + 2) / 2));
+  const int32_t *recCKR = reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2));
   const double *recT = rec + R.t + (size_t)blockIdx.x * N * kWave;
   const bool failed = flag[b] != 0;  // NaN gradients for a failed factorisation (see k_loglik_rev)
   const double nan = __builtin_nan("");
@@ -837,7 +861,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 
   // seeds of the last row (reverse.hpp:55-57 with bd = d ll / d d, bz = d ll / d z)
   const double2 dzl = recDZ[(size_t)(N - 1) * kWave + lane];
-  const double rdl = 1.0 / dzl.x;
+  const double rdl = 1.0 / fabs(dzl.x);   // (the sign of a recorded d is the checkpoint flag of its row)
   double ban = 0.5 * rdl * (dzl.y * dzl.y * rdl - 1.0), bzn = -dzl.y * rdl;
   // A failed series gets NaN seeds: every gradient of the series is an arithmetic function of them (bF <- u bz,
   // M <- x = bV + 2 ba u, bp <- F bF + ..., bt <- bp, bc <- bp), so NaN reaches all six outputs by propagation.
@@ -848,13 +872,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   // AGPRs (aload: no arithmetic register in flight), all 80 loads are issued back to back and waited for ONCE.  (Through
   // arithmetic registers, each v_accvgpr_write being a scheduling barrier, the same loads were waited for in ~13 separate
   // groups, 2-3 us each under load: ~90k cycles per checkpoint, a quarter of the sweep.)
-  // (wavefront-uniform bookkeeping: the slots are consumed from the top; cknext = row of the next one down)
-  int slot = __builtin_amdgcn_readfirstlane(recCKR[0]) - 1;
-  int cknext = slot >= 0 ? __builtin_amdgcn_readfirstlane(recCKR[1 + slot]) : -1;
-  auto load_ckpt = [&]() {
+  // (WHICH rows carry a checkpoint is the sign of their d record; its slot comes from the row's entry of CKR -- a scalar load
+  // at the few rows that need it instead of a counter carried through every step)
+  auto load_ckpt = [&](int64_t row) {
+    const int64_t slot = XCK ? (int64_t)__builtin_amdgcn_readfirstlane(recCKR[row])
+                             : ((row % C == 0) ? row / C - 1 : R.nreg - 1);   // regular rows C, 2C, ..., N-1 in order
     const double *ck = recCK + (size_t)slot * (NS + J) * kWave;
-    --slot;
-    cknext = slot >= 0 ? __builtin_amdgcn_readfirstlane(recCKR[1 + slot]) : -1;
     const unsigned voff = (unsigned)lane * 8u;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -924,7 +947,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
     ta = t_fetch(nf - 1);
-    load_ckpt();   // the top slot: row N-1
+    load_ckpt(nf);   // the last row always carries one
     lds_order();
 
 #ifdef C2T_PROF
@@ -988,7 +1011,9 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       //   x = bV + 2 ba U;  xs = x S (-> bU2 = -xs);  M -= U^T x + bV^T U;  bp += diag(S M);  M = P M P;  q = W_{n-1} M;
       //   S_{n-1} = P^-1 S_n P^-1 - d_{n-1} w_{n-1}^T w_{n-1}   (where row n-1 is a checkpointed row the result is
       //   replaced at the end of the step)
-      const double rdm = rcp_nr(dza.x), zm = dza.y, dm = dza.x;
+      const double dm = fabs(dza.x), rdm = rcp_nr(dm), zm = dza.y;
+      bool ckm = false;
+      if constexpr (XCK) ckm = __builtin_amdgcn_readfirstlane(__double2hiint(dza.x)) < 0;   // row n-1 carries a checkpoint
       // (bV_i = x_i - 2 ba u_i, so M -= u_i x_j + x_i u_j - 2 ba u_i u_j: x takes the registers of bV)
       double (&x)[J] = bVn;
       double xs[J], q[J];
@@ -1121,10 +1146,11 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       if (rs == 0) {  // row n-1 is the lowest row of its tile
         sc_flush(bab, N, n - 1, 0, N - 1, tBA, lane, FULL ? kWave - 1 : last);
         sc_flush(byb, N, n - 1, 0, N - 1, tBY, lane, FULL ? kWave - 1 : last);
+        // the state of row n-1 is on record (a regular checkpoint every C rows): it replaces the recursed one
+        if constexpr (!XCK) { if (n >= 2 && (n - 1) % C == 0) load_ckpt(n - 1); }
       }
-      // the state of row n-1 is on record (a regular checkpoint every C rows, or an extra one in front of a gap in time):
-      // it replaces the recursed one
-      if ((int)(n - 1) == cknext) load_ckpt();
+      // ... or, with extra checkpoints in front of gaps in time, wherever the record says so
+      if constexpr (XCK) { if (ckm && n >= 2) load_ckpt(n - 1); }
       C2T_TICK(5);
 #pragma unroll
       for (int j = 0; j < J; ++j) wa[j] = wb[j];
@@ -1240,13 +1266,17 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_rev(int64_t B, int64_t N,
 #pragma unroll
   for (int k = 0; k < JS / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
   const bool full = b0 + kWave <= B;
+  const bool xck = __builtin_amdgcn_readfirstlane(
+                       reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2))[0]) > 0;
+#define C2T_REV(P_, F_, X_) rev_body<P_, -1, true, F_, X_>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds)
   if (__all(paired)) {
-    if (full) rev_body<true, -1, true, true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
-    else rev_body<true, -1, true, false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+    if (full) { if (xck) C2T_REV(true, true, true); else C2T_REV(true, true, false); }
+    else { if (xck) C2T_REV(true, false, true); else C2T_REV(true, false, false); }
   } else {
-    if (full) rev_body<false, -1, true, true>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
-    else rev_body<false, -1, true, false>(B, N, t, t_bs, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+    if (full) { if (xck) C2T_REV(false, true, true); else C2T_REV(false, true, false); }
+    else { if (xck) C2T_REV(false, false, true); else C2T_REV(false, false, false); }
   }
+#undef C2T_REV
 }
 
 template <int JC>
@@ -1258,12 +1288,12 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_tt_rev(int64_t B, int64_t N
                                                             double *__restrict__ by) {
   __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
   if (__longlong_as_double((long long)*guard) > kGuard) return;  // the composed chain takes this batch
-  if (terms_phases_fast<JC>(B, N, x, x_bs, T))
-    rev_body<true, JC, true>(B, N, x, x_bs, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by,
-                             lds, T, G);
-  else
-    rev_body<true, JC, false>(B, N, x, x_bs, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by,
-                              lds, T, G);
+  const bool xck = __builtin_amdgcn_readfirstlane(
+                       reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2))[0]) > 0;
+#define C2T_TREV(FAST_, X_) rev_body<true, JC, FAST_, false, X_>(B, N, x, x_bs, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by, lds, T, G)
+  if (terms_phases_fast<JC>(B, N, x, x_bs, T)) { if (xck) C2T_TREV(true, true); else C2T_TREV(true, false); }
+  else { if (xck) C2T_TREV(false, true); else C2T_TREV(false, false); }
+#undef C2T_TREV
 }
 
 }  // namespace c2t

@@ -60,7 +60,7 @@ def test_argument_errors_without_gpu(built):
     # checkpoint of 44 doubles every 32 rows and as many extra slots (re-anchoring in front of gaps in time) with their
     # row list, overlaid with the replay kernels' workspace, + the 16-byte stability word
     waves, nck = 65536 // 64, 2 * ((4096 - 2) // 32 + 1)
-    rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44) + waves * ((nck + 2) // 2)
+    rec = waves * 64 * (4096 * 8 + 4096 * 2 + 4096 + nck * 44) + waves * (4096 // 2)   # + the slot of every row (int32)
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 8) == 8 * (2 + rec) < 30 * 2**30
     assert lib.c2_loglik_grad_workspace_bytes(65536, 4096, 6) == 8 * (2 + rec)   # width 6 runs as 8: same records
     assert lib.c2_loglik_grad_workspace_bytes(1, 4096, 129) == 0   # unsupported width

@@ -11,6 +11,9 @@
 //   C2_KRON_INTERLEAVED  the construction as stated: a device generator writes (t', a', U', V') of the N*M series,
 //                        the fused 1-D kernels (c2_loglik.hip) run on it, a reducer folds the gradients back onto
 //                        (t, a, U, V, alpha, diag).  192 MB per GP at N = 50000, M = 16, J = 6 -- the naive view.
+//                        A CROSS-CHECK, not a production path: 941 ms per 32 series at the BASELINE shape (0.0008 of
+//                        the roofline; its 400 000 chunks with runs of identical times stay row by row) against 2.85 ms
+//                        for the collapsed method, which is the default.
 //   C2_KRON_COLLAPSED    structure-aware and exact: the M bands of an epoch observe ONE latent value x(t_n) through
 //                        y_m = alpha_m x + eps_m, eps_m ~ N(0, D_m), so they are equivalent to a single observation
 //                            ytil_n = (sum_m alpha_m y_m / D_m) / A_n ,   variance 1 / A_n ,   A_n = sum_m alpha_m^2 / D_m

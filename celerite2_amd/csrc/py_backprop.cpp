@@ -29,7 +29,9 @@ auto factor_fwd(Arr t, Arr c, Arr a, Arr U, Arr V, Arr d, Arr W, Arr S) {
   return std::make_tuple(d, W, S);
 }
 
-// backprop.factor_rev -- backprop.cpp:68-150
+// backprop.factor_rev -- backprop.cpp:68-150.  (The S workspace is validated and shipped like every argument; on series of 512
+// rows and more the device replays its states from d, W instead and reads S only if the device-side verification of that
+// time-parallel pass fails -- same result as the reference on the same inputs, see celerite2_amd/ops.py: factor_rev.)
 auto factor_rev(Arr t, Arr c, Arr a, Arr U, Arr V, Arr d, Arr W, Arr S, Arr bd, Arr bW, Arr bt, Arr bc, Arr ba, Arr bU,
                 Arr bV) {
   py::buffer_info tb = t.request(), cb = c.request(), ab = a.request(), Ub = U.request(), Vb = V.request(),

@@ -141,6 +141,11 @@ general_matmul_upper = _general("general_matmul_upper")
 
 
 def factor_rev(t, c, a, U, V, d, W, S, bd, bW):
+    """Batched core::factor_rev (reverse.hpp:10-85).  `S` is the workspace `factor(..., workspace=True)` returned.  The
+    row-by-row kernel reads every C-th row of it and replays the rows in between from d, W; on small batches of series of
+    512 rows and more the reverse pass runs parallel along time and replays ALL its states from d, W --
+    `S` is then only read if the device-side verification of that pass fails and the row-by-row kernel recomputes the
+    batch behind it.  Either way the result is that of the reference on the same (t, c, U, d, W, bd, bW)."""
     B, N, J = _dims(U)
     dev = U.device
     bt = torch.empty((B, N), dtype=torch.float64, device=dev)

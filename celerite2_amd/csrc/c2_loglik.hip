@@ -1104,9 +1104,10 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
                                           int64_t c_bs, const double *a, const double *U, const double *V, double *d,
                                           double *W, int32_t *flag, double *work, unsigned long long *guard,
                                           c2_stream_t stream);
-// allow_timepar: 0 row by row only; 1 the dispatch's choice; 2 the Newton iterations at every width they cover (the
-// time-parallel gradient builds on d, W: the composed maps of widths 4 / 2 are verified to 5e-11 only, which an
-// ill-conditioned series -- the interleaved 2-D construction -- turns into 5e-11 of the largest gradient entry)
+// allow_timepar: 0 row by row only; 1 the dispatch's choice; 2 what the time-parallel gradient builds on: the Newton
+// iterations at EVERY width (1 .. 8) where they pay -- from 2048 rows -- and the row-by-row kernel below, never the
+// composed maps of widths 4 / 2 (verified to 5e-11 only, which the gradient inherits: 1.5e-10 of its largest entry on a
+// well-conditioned draw of the round-2 stress run, profiles/r03_timepar_verification.md)
 // `scratch` (nullable; c2_internal_factor_scratch_doubles): caller-provided room for the time-parallel forms -- without it
 // they use a stream-ordered temporary and stay out of graph captures.
 size_t c2_internal_factor_scratch_doubles(int64_t B, int64_t N, int64_t J) {
@@ -1128,7 +1129,14 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
     if (!scratch && hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
     return rc;
   };
-  const bool newton = allow_timepar == 2 ? J >= 1 && J <= 8 && N >= 2 : use_factor_iter(B, N, J);
+  // allow_timepar == 2 (the time-parallel gradient builds on d, W): never the composed maps of widths 4 / 2 -- they are
+  // verified to 5e-11 only -- but the Newton iterations where they pay at the other widths (from 2048 rows; forced: every
+  // length), the row-by-row kernel below that (0.15 us per row against five iterations of several launches)
+  const bool forced_iter = opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) != 0;
+  const bool newton = allow_timepar == 2
+                          ? (J >= 1 && J <= 8 && N >= 2 && (forced_iter || (N >= 2048 && B * ((N + 63) / 64) <= 32768)) &&
+                             !(opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) == 0))
+                          : use_factor_iter(B, N, J);
   if (allow_timepar && d != a && W != V && newton) {
     const size_t nd = c2_internal_factor_iter_doubles(B, N, J);
     void *tmp = nullptr;
@@ -1144,7 +1152,7 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
   }
   // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
   // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
-  if (allow_timepar && d != a && W != V && use_timepar(B, N, J)) {
+  if (allow_timepar == 1 && d != a && W != V && use_timepar(B, N, J)) {
     const size_t nd = c2_internal_timepar_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && room(nd + 2, &tmp)) {

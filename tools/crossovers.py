@@ -66,9 +66,9 @@ def lanes():
 def timepar_grad():
     print("== gradient parallel along time vs row by row, one series, J = 8")
     first = None
-    for N in ([512, 1024, 2048] if QUICK else [256, 384, 512, 768, 1024, 1536, 2048, 4096]):
+    for N in ([256, 512, 1024, 2048] if QUICK else [128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 4096]):
         args = synth.device_batch_fast(0, 1, N, 8, dev)
-        with forced(timepar_grad=1, factor_iter=1): tp = timed(lambda: ops.loglik_grad(*args))
+        with forced(timepar_grad=1): tp = timed(lambda: ops.loglik_grad(*args))   # (the factor inside: the dispatch's own choice)
         with forced(timepar_grad=0, factor_iter=0): rr = timed(lambda: ops.loglik_grad(*args))
         print("  N %5d  time-parallel %.3f ms  row by row %.3f ms" % (N, tp, rr))
         if first is None and tp < rr: first = N

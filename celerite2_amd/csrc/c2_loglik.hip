@@ -970,7 +970,8 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
   // one series draws level below 200 rows: 256 rows 0.17 -> 0.13 ms at J = 2, 0.30 -> 0.22 at J = 6; 512 rows 0.54 -> 0.33
   // at J = 8, the same for 64 series)
   const bool handful = B * ((N + 63) / 64) <= 4096;
-  const int64_t min_rows = handful ? 256 : (J <= 2 ? 512 : (J >= 7 ? opt::ival(opt::k_timepar_grad_min_rows) : 768));
+  const int64_t min_rows = handful ? opt::ival(opt::k_timepar_grad_min_rows_handful)
+                                   : (J <= 2 ? 512 : (J >= 7 ? opt::ival(opt::k_timepar_grad_min_rows) : 768));
   // (widths up to 4 would keep winning a little further -- 768 x 4096 at J = 4 2.97 -> 1.46 ms, 1024 x 4096 2.98 -> 2.44 ms
   // -- but not by enough to move the limit)
   return N >= min_rows && B * ((N + 63) / 64) <= opt::ival(opt::k_timepar_grad_max_chunks);

@@ -58,6 +58,9 @@ __device__ __forceinline__ constexpr bool piece_in(int p) { return JS == J || (p
 #ifndef C2T_C
 #define C2T_C 32
 #endif
+#ifndef C2T_M2
+#define C2T_M2 1   // the rank-2 update of M in two fma per element (0: three, x in the registers of bV)
+#endif
 constexpr int C = C2T_C;             // checkpoint interval (rows)
 constexpr double kGuard = kBackwardGuard;  // largest allowed max_j c_j * (t_end - t_start) of a segment
 constexpr int RT = 16 / J;           // rows per tile of the width-J streams: one aligned 128-byte line per series
@@ -1014,8 +1017,14 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       const double dm = fabs(dza.x), rdm = rcp_nr(dm), zm = dza.y;
       bool ckm = false;
       if constexpr (XCK) ckm = __builtin_amdgcn_readfirstlane(__double2hiint(dza.x)) < 0;   // row n-1 carries a checkpoint
+#if C2T_M2
+      // (x_j - 2 ba u_j = bV_j, so M -= u_i x_j + x_i u_j - 2 ba u_i u_j = u_i bV_j + x_i u_j: two fma per element, with
+      // bV kept next to x for the length of the pass)
+      double x[J];
+#else
       // (bV_i = x_i - 2 ba u_i, so M -= u_i x_j + x_i u_j - 2 ba u_i u_j: x takes the registers of bV)
       double (&x)[J] = bVn;
+#endif
       double xs[J], q[J];
       const double ba2 = 2.0 * ban;
 #pragma unroll
@@ -1030,9 +1039,14 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
           double m = afetch(Mlo[k], Mhi[k]);
           xs[j2] = fma(x[i], sv, xs[j2]);
           if (j2 != i) xs[i] = fma(x[j2], sv, xs[i]);
+#if C2T_M2
+          m = fma(-u[i], bVn[j2], m);
+          m = fma(-x[i], u[j2], m);
+#else
           m = fma(-u[i], x[j2], m);
           m = fma(-x[i], u[j2], m);
           m = fma(ba2 * u[i], u[j2], m);
+#endif
           bp[j2] = fma(sv, m, bp[j2]);
           if (j2 != i) bp[i] = fma(sv, m, bp[i]);
           m *= p[i] * p[j2];

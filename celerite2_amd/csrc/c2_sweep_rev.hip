@@ -14,6 +14,9 @@
 // The first-round kernel (k_sweep_rev, lanes over J, c2_ops.hip) stays for shapes this mapping does not cover.
 #include <cstdint>
 
+#include <type_traits>
+
+#include "c2_dispatch.hpp"
 #include "c2_loglik_helpers.hpp"
 #include "c2_rscatter.hpp"
 #include "../../include/celerite2_amd.h"
@@ -191,6 +194,239 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
   }
 }
 
+
+// ---- nrhs = J = 8 on full wavefronts: every width-8 row moves as half of an aligned 128-byte LINE ---------------------------
+// k_sweepK_rev above asks for every row of U, W, X, bZ on its own and stores every row of bU, bW, bY on its own: 64-byte
+// requests, fifteen memory instructions per step.  With one wavefront per SIMD the step is then bound by how fast the CU
+// accepts REQUESTS, not by bytes or arithmetic (tools/sweepk_rev_sections.py: of 4700 cycles per step 2000 go into issuing
+// the nine loads and 1900 into the sections that hold the six stores; taking two 64-byte loads out of the step saves 16 % of
+// it, two stores 18 %, three of the four 128-byte workspace requests only 7 %).  Here the rows of a series pair up into the
+// aligned lines (2 l, 2 l + 1) they share in memory: one 16-byte piece per lane, one request per line and array every two
+// steps, staged through LDS rings of four rows (inputs, requested two lines ahead) and tiles of two rows (outputs); the
+// workspace row (512 bytes a series) is requested as a dense run four steps ahead and turned into columns through LDS.
+// Per two steps: 8 + 5 loads and 4 stores instead of 18 and 12.  B a multiple of 8, N >= 8; the first / last steps, where a
+// line may reach beyond the series, take the same step with guarded, synchronous moves.
+constexpr int kLS = 34;   // LDS stride (doubles) of a series in a ring of four 8-double rows: 272 B, conflict-free b128
+constexpr int kOS = 18;   // ... in a tile of two rows: 144 B
+
+template <bool LOWER, bool SOLVE>
+__global__ __launch_bounds__(kWave) void k_sweep8_rev_lines(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                                            const double *__restrict__ c, int64_t c_bs,
+                                                            const double *__restrict__ U, const double *__restrict__ V,
+                                                            const double *__restrict__ Y, const double *__restrict__ Z,
+                                                            const double *__restrict__ F, const double *__restrict__ bZ,
+                                                            double *__restrict__ bt, double *__restrict__ bc,
+                                                            double *__restrict__ bU, double *__restrict__ bV,
+                                                            double *__restrict__ bY) {
+  constexpr int J = 8, SPW = 8, RF = 4;
+  __shared__ __attribute__((aligned(16))) double Bq[SPW * kLS], Aq[SPW * kLS], Xq[SPW * kLS], Zq[SPW * kLS];  // [sl][row & 3][8]
+  __shared__ __attribute__((aligned(16))) double tq[SPW][4];
+  __shared__ __attribute__((aligned(16))) double pq[SPW][J];
+  __shared__ __attribute__((aligned(16))) double ftile[SPW * J * J];
+  __shared__ __attribute__((aligned(16))) double oB[SPW * kOS], oA[SPW * kOS], oY[SPW * kOS];   // [sl][row & 1][8]
+  __shared__ __attribute__((aligned(16))) double oT[SPW][2];
+  const int lane = threadIdx.x, sl = lane >> 3, k = lane & 7;
+  const int64_t b = (int64_t)blockIdx.x * SPW + sl;
+  const int hrow = k >> 2, col = 2 * (k & 3);   // this lane's 16-byte piece of a line: row 2 l + hrow, columns col, col + 1
+  constexpr int dir = LOWER ? -1 : 1;           // the sweep visits rows n, n + dir, ...; m = n + dir
+  constexpr int kFirstParity = LOWER ? 1 : 0;   // parity of the row of a line the sweep meets first
+  const double *tb = t + b * t_bs;
+  const double *Bb = (LOWER ? U : V) + b * N * J, *Ab = (LOWER ? V : U) + b * N * J;
+  double *bBb = (LOWER ? bU : bV) + b * N * J, *bAb = (LOWER ? bV : bU) + b * N * J;
+  const double *Xb = (SOLVE ? Z : Y) + b * N * J, *Zb = bZ + b * N * J;
+  double *bYb = bY + b * N * J, *btb = bt + b * N;
+  const double *Fd = F + b * N * (int64_t)(J * J) + 2 * k;
+  const double cj = c[b * c_bs + k];
+  double bce = 0.0;
+  constexpr double sgn = SOLVE ? -1.0 : 1.0;
+  const int64_t lmax = (N - 1) >> 1;
+
+  struct Line { double2 b, a, x, z; double tt; };
+  // (values in, values out: handed around by reference the rings end up in scratch)
+  auto req_line = [&](int64_t l) -> Line {
+    Line R;
+    l = l < 0 ? 0 : (l > lmax ? lmax : l);
+    int64_t row = 2 * l + hrow; row = row < N ? row : N - 1;
+    int64_t trow = 2 * l + (k & 1); trow = trow < N ? trow : N - 1;
+    R.b = *reinterpret_cast<const double2 *>(Bb + row * J + col);
+    R.a = *reinterpret_cast<const double2 *>(Ab + row * J + col);
+    R.x = *reinterpret_cast<const double2 *>(Xb + row * J + col);
+    R.z = *reinterpret_cast<const double2 *>(Zb + row * J + col);
+    R.tt = tb[trow];
+    return R;
+  };
+  auto put_line = [&](int64_t l, const Line R) {
+    const int o = sl * kLS + ((2 * (int)(l & 1) + hrow) * J) + col;   // slot (row & 3) of the ring
+    *reinterpret_cast<double2 *>(&Bq[o]) = R.b;
+    *reinterpret_cast<double2 *>(&Aq[o]) = R.a;
+    *reinterpret_cast<double2 *>(&Xq[o]) = R.x;
+    *reinterpret_cast<double2 *>(&Zq[o]) = R.z;
+    tq[sl][2 * (int)(l & 1) + (k & 1)] = R.tt;   // (lanes of equal k & 1 write the same value)
+  };
+  struct FRow { double2 q0, q1, q2, q3; };   // (named members: as an array the ring ends up in scratch)
+  auto req_F = [&](int64_t n) -> FRow {
+    FRow f;
+    n = n < 0 ? 0 : (n < N ? n : N - 1);
+    const double *a = Fd + n * (int64_t)(J * J);
+    f.q0 = *reinterpret_cast<const double2 *>(a);
+    f.q1 = *reinterpret_cast<const double2 *>(a + 16);
+    f.q2 = *reinterpret_cast<const double2 *>(a + 32);
+    f.q3 = *reinterpret_cast<const double2 *>(a + 48);
+    return f;
+  };
+  // a finished line of an output tile: 16 bytes per lane, 128 per series.  GUARD: rows beyond either end stay unwritten
+  auto flush = [&](const double *tile, double *base, int64_t l, auto guard_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    const int64_t row = 2 * l + hrow;
+    const double2 v = *reinterpret_cast<const double2 *>(&tile[sl * kOS + hrow * J + col]);
+    if (!GUARD || (row >= 0 && row < N)) *reinterpret_cast<double2 *>(base + row * J + col) = v;
+  };
+  auto flush_t = [&](int64_t l, auto guard_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    const double2 v = *reinterpret_cast<const double2 *>(&oT[sl][0]);
+    if constexpr (GUARD) {
+      if (k < 2 && 2 * l + k >= 0 && 2 * l + k < N) btb[2 * l + k] = k ? v.y : v.x;
+    } else {
+      *reinterpret_cast<double2 *>(btb + 2 * l) = v;   // (the lanes of a series store the same 16 bytes)
+    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+
+  double bF[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) bF[j] = 0.0;
+  const int64_t nfar = LOWER ? N - 1 : 0, nnear = LOWER ? 0 : N - 1;
+  double bzrun = Zb[nfar * J + k];
+  double carry = 0.0;
+  // the far end receives nothing from the sweep: bA = 0, bY = its own cotangent (solves) or 0 (products)
+  oA[sl * kOS + (int)(nfar & 1) * J + k] = 0.0;
+  oY[sl * kOS + (int)(nfar & 1) * J + k] = SOLVE ? bzrun : 0.0;
+  lds_order();
+  if ((nfar & 1) != kFirstParity) {   // ... and no step completes its line
+    flush(oA, bAb, nfar >> 1, Yes{});
+    flush(oY, bYb, nfar >> 1, Yes{});
+  }
+
+  // One step (row n, m = n + dir).  EDGE: lines and workspace row moved here, synchronously, with guards; otherwise the
+  // rings are kept by the caller and PH says which lines the step completes (0: n is the first row of its line -- m the
+  // second of the same line: bA, bY leave; 1: n the second: bB, bt leave).
+  auto step = [&](const int64_t n, auto edge_tag, auto ph_tag, FRow fr) __attribute__((always_inline)) -> FRow {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    constexpr int PH = decltype(ph_tag)::value;
+    const int64_t m = n + dir;
+    if constexpr (EDGE) {
+      put_line(n >> 1, req_line(n >> 1));
+      put_line(m >> 1, req_line(m >> 1));   // (the same line again where m shares it)
+      fr = req_F(n);
+    }
+    {
+      double *w = &ftile[sl * J * J + 2 * k];
+      *reinterpret_cast<double2 *>(w) = fr.q0;
+      *reinterpret_cast<double2 *>(w + 16) = fr.q1;
+      *reinterpret_cast<double2 *>(w + 32) = fr.q2;
+      *reinterpret_cast<double2 *>(w + 48) = fr.q3;
+    }
+    FRow fnext = fr;
+    if constexpr (!EDGE) fnext = req_F(n + RF * dir);   // (the slot is free once its row is on its way to LDS)
+    lds_order();
+    double Fn[J];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 v = *reinterpret_cast<const double2 *>(&ftile[(sl * J + k) * J + 2 * q]);
+      Fn[2 * q] = v.x; Fn[2 * q + 1] = v.y;
+    }
+    const double tn = tq[sl][n & 3], tm = tq[sl][m & 3];
+    const double dt = LOWER ? tm - tn : tn - tm;   // internal.hpp:227 / 284
+    const double p = exp_decay(cj * dt);
+    pq[sl][k] = p;
+    const double xm = Xq[sl * kLS + (int)(m & 3) * J + k];
+    const double bzring = Zq[sl * kLS + (int)((SOLVE ? m : n) & 3) * J + k];
+    lds_order();
+    const double bzn = SOLVE ? bzrun : bzring;
+    double pbB[J], pbp[J], pbA[J], acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; j += 2) {
+      const double2 p2 = *reinterpret_cast<const double2 *>(&pq[sl][j]);
+      const double2 b2 = *reinterpret_cast<const double2 *>(&Bq[sl * kLS + (int)(n & 3) * J + j]);
+      const double2 a2 = *reinterpret_cast<const double2 *>(&Aq[sl * kLS + (int)(m & 3) * J + j]);
+      const double pv[2] = {p2.x, p2.y}, bv[2] = {b2.x, b2.y}, av[2] = {a2.x, a2.y};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int jj = j + u;
+        pbB[jj] = bzn * (pv[u] * Fn[jj]);               // internal.hpp:232 / 289
+        bF[jj] = fma(sgn * bv[u], bzn, bF[jj]);          // internal.hpp:233 / 290
+        pbp[jj] = Fn[jj] * bF[jj];                       // internal.hpp:236 / 293
+        bF[jj] *= pv[u];                                 // internal.hpp:241 / 298
+        pbA[jj] = xm * bF[jj];                           // update_f::reverse (internal.hpp:59 / 80)
+        acc = fma(av[u], bF[jj], acc);                   // ... and the cotangent of row m (internal.hpp:60 / 81)
+      }
+    }
+    // cotangent of row m: solves fold it into the running bZ, products write it out
+    if (SOLVE) bzrun = bzring + acc;
+    oY[sl * kOS + (int)(m & 1) * J + k] = SOLVE ? bzrun : acc;
+    // the three sums over the right-hand sides: element k of each ends in lane k
+    int ko;
+    const double rB = sgn * rscatter8<8>(pbB, k, ko);
+    const double rp = rscatter8<8>(pbp, k, ko);
+    const double rA = rscatter8<8>(pbA, k, ko);
+    const double bpe = rp * p;
+    oB[sl * kOS + (int)(n & 1) * J + k] = rB;
+    oA[sl * kOS + (int)(m & 1) * J + k] = rA;
+    bce = fma(dt, bpe, bce);
+    const double phi = gsum<8>(cj * bpe);
+    // LOWER: bt[n] -= phi, bt[m] += phi -> row n is complete now (it got +phi of the previous step); UPPER: mirrored
+    oT[sl][n & 1] = LOWER ? carry - phi : phi - carry;
+    carry = phi;
+    lds_order();
+    if constexpr (EDGE) {
+      if ((n & 1) != kFirstParity) { flush(oB, bBb, n >> 1, Yes{}); flush_t(n >> 1, Yes{}); }
+      if ((m & 1) != kFirstParity) { flush(oA, bAb, m >> 1, Yes{}); flush(oY, bYb, m >> 1, Yes{}); }
+    } else if constexpr (PH == 0) {
+      flush(oA, bAb, m >> 1, No{}); flush(oY, bYb, m >> 1, No{});
+    } else {
+      flush(oB, bBb, n >> 1, No{}); flush_t(n >> 1, No{});
+    }
+    return fnext;
+  };
+
+  int64_t n = nfar, left = N - 1;   // steps left; the step at row n has m = n + dir
+  FRow fr0, fr1, fr2, fr3;
+  fr0 = fr1 = fr2 = fr3 = FRow{};
+  if ((n & 1) != kFirstParity && left > 0) { step(n, Yes{}, std::integral_constant<int, 0>{}, fr0); n += dir; --left; }
+  if (left >= 4) {
+    // rings: line of n in LDS, the two lines behind it and the workspace rows of the next four steps requested
+    Line lr0, lr1;
+    put_line(n >> 1, req_line(n >> 1));
+    lr0 = req_line((n >> 1) + dir);
+    lr1 = req_line((n >> 1) + 2 * dir);
+    static_assert(RF == 4, "four steps per iteration");
+    fr0 = req_F(n); fr1 = req_F(n + dir); fr2 = req_F(n + 2 * dir); fr3 = req_F(n + 3 * dir);
+    for (; left >= 4; left -= 4, n += 4 * dir) {
+      const int64_t lc = n >> 1;
+      put_line(lc + dir, lr0);
+      lr0 = req_line(lc + 3 * dir);
+      fr0 = step(n, No{}, std::integral_constant<int, 0>{}, fr0);
+      fr1 = step(n + dir, No{}, std::integral_constant<int, 1>{}, fr1);
+      put_line(lc + 2 * dir, lr1);
+      lr1 = req_line(lc + 4 * dir);
+      fr2 = step(n + 2 * dir, No{}, std::integral_constant<int, 0>{}, fr2);
+      fr3 = step(n + 3 * dir, No{}, std::integral_constant<int, 1>{}, fr3);
+    }
+  }
+  for (; left > 0; --left, n += dir) step(n, Yes{}, std::integral_constant<int, 0>{}, fr0);
+
+  // the near end: no bB, bt = what the last step left; its lines leave now if no step completed them
+  oB[sl * kOS + (int)(nnear & 1) * J + k] = 0.0;
+  oT[sl][nnear & 1] = LOWER ? carry : -carry;
+  lds_order();
+  flush(oB, bBb, nnear >> 1, Yes{});
+  flush_t(nnear >> 1, Yes{});
+  flush(oA, bAb, nnear >> 1, Yes{});
+  flush(oY, bYb, nnear >> 1, Yes{});
+  bc[b * J + k] = bce;
+}
+
 }  // namespace c2r
 
 using namespace c2r;
@@ -206,6 +442,19 @@ extern "C" int c2_internal_sweepK_rev(int lower, int solve, int64_t B, int64_t N
   const int JM = J <= 8 ? 8 : 16;
   const int KL = (nrhs <= 8 && JM == 8) ? 8 : 16;
   hipStream_t s = (hipStream_t)stream;
+  // nrhs = J = 8 on full wavefronts: the line-pairing kernel (every pointer it moves 16-byte pieces of must allow that)
+  if (J == 8 && nrhs == 8 && B % 8 == 0 && N >= 8 && !(c2::opt::has(c2::opt::k_sweep_rev_lines) && c2::opt::ival(c2::opt::k_sweep_rev_lines) == 0) &&
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)Y | (uintptr_t)Z | (uintptr_t)bZ | (uintptr_t)bU | (uintptr_t)bV |
+        (uintptr_t)bY | (uintptr_t)bt) % 16) == 0 && N % 2 == 0) {
+    const dim3 g8((unsigned)(B / 8));
+#define C2_SL(LO, SO)                                                                                                 \
+  hipLaunchKernelGGL((k_sweep8_rev_lines<LO, SO>), g8, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, \
+                     bc, bU, bV, bY)
+    if (lower) { if (solve) C2_SL(true, true); else C2_SL(true, false); }
+    else { if (solve) C2_SL(false, true); else C2_SL(false, false); }
+#undef C2_SL
+    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+  }
   const dim3 grid((unsigned)((B + (kWave / KL) - 1) / (kWave / KL)));
 #define C2_SKR1(KL_, JM_, LO, SO)                                                                                      \
   hipLaunchKernelGGL((k_sweepK_rev<KL_, JM_, LO, SO>), grid, dim3(kWave), 0, s, B, N, (int)J, nrhs, t, t_bs, c, c_bs, U, V, \

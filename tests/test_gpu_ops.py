@@ -922,6 +922,41 @@ def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
             close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d), Z0 + Zo)
 
 
+@pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (24, 33), (8, 34), (16, 64), (8, 131), (16, 200), (7, 64)])
+def test_multi_rhs_reverse_sweeps_by_lines(ops, oracle, B, N):
+    """nrhs = J = 8 on full wavefronts (B a multiple of 8, N even): the four reverse sweeps move every width-8 row as half
+    of an aligned 128-byte line through LDS rings (k_sweep8_rev_lines) -- every length class of the main loop (N - 1 mod 4,
+    the peeled first step, the guarded last ones), against the oracle and bit for bit against nothing: the row-by-row
+    kernel (option sweep_rev_lines = 0; odd N and ragged batches take it anyway) must agree to rounding."""
+    from celerite2_amd import _lib
+    J = nrhs = 8
+    rng = np.random.default_rng(31 * B + N)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs))
+    bZ = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Wd, Yd, bZd = dev(t, c, U, V, W, Y, bZ)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zd, Fd = getattr(ops, name)(td, cd, Ud, secd, Yd, workspace=True, zero_z=True)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+        _lib.set_option("sweep_rev_lines", 0)
+        try:
+            ref = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+        finally:
+            _lib.set_option("sweep_rev_lines", None)
+        for r_, e_ in zip(res, ref):
+            close(r_, e_.cpu().numpy())
+        for b in sorted({0, B // 2, B - 1}):
+            zo = np.empty((N, nrhs)); fo = np.empty((N, J, nrhs))
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], zo, fo)
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], zo, fo, bZ[b], *outs)
+            for r_, e_ in zip(res, outs):
+                close(r_[b], e_)
+
+
 @pytest.mark.parametrize("tile", ["1", "0"])
 @pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 97, 64), (3, 3, 40, 131), (6, 5, 200, 33), (16, 2, 50, 50), (2, 7, 1, 1)])
 def test_general_matmul_batched(ops, oracle, monkeypatch, J, nrhs, N, M, tile):

@@ -11,16 +11,26 @@
 #include <cstdint>
 #include <type_traits>
 
+#include "c2_dispatch.hpp"
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
 namespace c2 {
 
-template <int G, int R, bool LOWER, bool SOLVE, bool PAD>
+// LN >= 0 (G = J = 8, U and V 16-byte aligned): the two width-8 rows of a step are requested as halves of the aligned
+// 128-byte lines (rows 2 l, 2 l + 1) they share -- one 16-byte piece per lane, one request per line and array every two
+// steps, four lines ahead -- and reach their lanes through LDS tiles of four rows.  The sweep is bound by the number of
+// memory instructions a single wavefront keeps in flight (40 VALU instructions in 830 cycles per step, 69 % of them waiting;
+// profiles/r03_sweep_rev_lines.md).  LN = parity of the position r inside a block of eight steps at which the sweep enters
+// a new line: 1 for the lower sweeps and for the upper ones on an even number of rows, 0 for the upper ones on an odd one.
+template <int G, int R, bool LOWER, bool SOLVE, bool PAD, int LN = -1>
 __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt, const double *t, int64_t t_bs,
                                                   const double *__restrict__ c, int64_t c_bs, const double *U,
                                                   const double *V, const double *Y, double *Z, double *F, int zero_z) {
   constexpr int SPW = kWave / G, NV = (R + G - 1) / G;
+  constexpr bool LINES = LN >= 0;
+  static_assert(!LINES || (G == 8 && !PAD && R == 8), "lines: eight lanes per series, blocks of eight steps");
+  __shared__ __attribute__((aligned(16))) double tAB[LINES ? 2 : 1][LINES ? 4 : 1][kWave];   // [A / B][row & 3][lane]
   __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];  // t, y, z-in of two blocks
   __shared__ __attribute__((aligned(16))) double sout[SPW][R];
   const int J = PAD ? Jrt : G;
@@ -73,15 +83,43 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   vload(1 + R); vstage(1);
   vload(1 + 2 * R);
 
-  double ra[R], rb[R];
+  double ra[LINES ? 1 : R], rb[LINES ? 1 : R];
   auto load_row = [&](int r, int64_t s) {
     s = (s < N) ? s : N - 1;
     const int64_t n = rowof(s);
     ra[r] = act ? Ab[n * J] : 0.0;
     rb[r] = act ? Bb[n * J] : 0.0;
   };
+  // LINES: ring of R / 2 lines per array in the order the sweep enters them (line k of the sweep = l0 +/- k; slot k mod 4);
+  // lane j holds piece j of a line: row 2 l + (j >> 2), columns 2 (j & 3), 2 (j & 3) + 1
+  double2 la[LINES ? R / 2 : 1], lb[LINES ? R / 2 : 1];
+  const int hrow = j >> 2, hcol = 2 * (j & 3);
+  const double *Al = (LOWER ? V : U) + (L.b0 + L.sl) * N * J + hcol, *Bl = (LOWER ? U : V) + (L.b0 + L.sl) * N * J + hcol;
+  const int64_t l0 = rowof(N > 1 ? 1 : 0) >> 1, lmax = (N - 1) >> 1;
+  auto line_load = [&](const double *base, int64_t k) -> double2 {
+    int64_t l = LOWER ? l0 + k : l0 - k;
+    l = l < 0 ? 0 : (l > lmax ? lmax : l);
+    int64_t row = 2 * l + hrow;
+    row = row < N ? row : N - 1;
+    return *reinterpret_cast<const double2 *>(base + row * J);
+  };
+  auto line_stage = [&](int which, int64_t k, double2 v) {   // rows 2 l, 2 l + 1 of the tile (slots row & 3)
+    const int64_t l = LOWER ? l0 + k : l0 - k;
+    *reinterpret_cast<double2 *>(&tAB[which][(2 * (int)(l & 1) + hrow)][grp * G + hcol]) = v;
+  };
+  int64_t kline = 0;   // lines entered so far
+  if constexpr (LINES) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+    for (int q = 0; q < R / 2; ++q) { la[q] = line_load(Al, q); lb[q] = line_load(Bl, q); }
+    if constexpr (LN == 1) {   // step 1 is the second row of the line step 0 entered
+      line_stage(0, 0, la[0]); line_stage(1, 0, lb[0]);
+      la[0] = line_load(Al, R / 2); lb[0] = line_load(Bl, R / 2);
+      kline = 1;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+  }
   lds_order();
 
   auto block = [&](int64_t s0, int q, auto checked_tag) {
@@ -91,8 +129,21 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
       const int64_t s = s0 + r;
       if (!CHECKED || s < N) {
         const double tn = sin_[q][0][grp][r], yn = sin_[q][1][grp][r], zin = sin_[q][2][grp][r];
-        const double an = ra[r], bn = rb[r];
-        load_row(r, s + R);
+        double an, bn;
+        if constexpr (LINES) {
+          if ((r & 1) == LN) {   // (r: unrolled) the sweep enters a line: slot (lines entered so far) mod 4 of the ring
+            const int sl_ = (LN == 1 ? 1 + r / 2 : r / 2) % (R / 2);
+            line_stage(0, kline, la[sl_]); line_stage(1, kline, lb[sl_]);
+            la[sl_] = line_load(Al, kline + R / 2); lb[sl_] = line_load(Bl, kline + R / 2);
+            ++kline;
+            lds_order();
+          }
+          const int64_t n = rowof(s);
+          an = tAB[0][n & 3][lane]; bn = tAB[1][n & 3][lane];
+        } else {
+          an = ra[r]; bn = rb[r];
+          load_row(r, s + R);
+        }
         const double p = exp_decay(cj * (LOWER ? tprev - tn : tn - tprev));
         tprev = tn;
         const double fpre = fma(aprev, xprev, Fs);  // internal.hpp:140 (lower) / :183 (upper)
@@ -400,9 +451,18 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+  const bool lines_ok = N >= 3 && (((uintptr_t)U | (uintptr_t)V) % 16) == 0 &&
+                        !(opt::has(opt::k_sweep1_lines) && opt::ival(opt::k_sweep1_lines) == 0);
 #define C2_SW(G, LO, SO)                                                                                           \
   do {                                                                                                             \
-    if (J == G)                                                                                                    \
+    if (J == G && G == 8 && lines_ok) {                                                                            \
+      if (LO || N % 2 == 0)                                                                                        \
+        hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false, (G == 8 ? 1 : -1)>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
+                           t_bs, c, c_bs, U, V, Y, Z, F, zero_z);                                                   \
+      else                                                                                                         \
+        hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false, (G == 8 ? 0 : -1)>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
+                           t_bs, c, c_bs, U, V, Y, Z, F, zero_z);                                                   \
+    } else if (J == G)                                                                                             \
       hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
                          V, Y, Z, F, zero_z);                                                                         \
     else                                                                                                           \

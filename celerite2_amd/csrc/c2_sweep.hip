@@ -440,6 +440,164 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
   }
 }
 
+
+// ---- nrhs = J = 8 on full wavefronts: every width-8 row moves as half of an aligned 128-byte LINE -------------------------
+// The forward counterpart of k_sweep8_rev_lines (c2_sweep_rev.hip, which has the measurements): k_sweepK asks for t, the two
+// width-J rows and the Y row (and the Z row when it accumulates) of every step on their own and stores every Z row on its
+// own -- five or six 64-byte requests a step, and it is the number of memory instructions a single wavefront keeps in
+// flight that bounds the step.  Here the rows of a series pair up into the aligned lines (2 l, 2 l + 1) they share: one
+// 16-byte piece per lane, one request per line and array every two steps, through LDS rings of four rows (inputs, two
+// lines ahead) and a tile of two rows (Z).  The workspace row (WF) leaves as before, as a dense run through an LDS tile.
+// In-place Z == Y stays legal: a line of Z is written after both of its rows were read, two lines behind the requests.
+constexpr int kLS8 = 34;   // LDS stride (doubles) of a series in a ring of four 8-double rows: 272 B, conflict-free b128
+constexpr int kOS8 = 18;   // ... in a tile of two rows: 144 B
+
+template <bool LOWER, bool SOLVE, bool WF, bool LOADZ>
+__global__ __launch_bounds__(kWave) void k_sweep8_lines(int64_t B, int64_t N, const double *t, int64_t t_bs,
+                                                        const double *__restrict__ c, int64_t c_bs, const double *U,
+                                                        const double *V, const double *Y, double *Z, double *F, int zero_z) {
+  constexpr int J = 8, SPW = 8;
+  __shared__ __attribute__((aligned(16))) double Aq[SPW * kLS8], Bq[SPW * kLS8], Yq[SPW * kLS8], Zq[LOADZ ? SPW * kLS8 : 2];
+  __shared__ __attribute__((aligned(16))) double tq[SPW][4];
+  __shared__ __attribute__((aligned(16))) double pq[SPW][J];
+  __shared__ __attribute__((aligned(16))) double ftile[WF ? SPW * J * J : 2];
+  __shared__ __attribute__((aligned(16))) double oZ[SPW * kOS8];
+  const int lane = threadIdx.x, sl = lane >> 3, k = lane & 7;
+  const int64_t b = (int64_t)blockIdx.x * SPW + sl;
+  const int hrow = k >> 2, col = 2 * (k & 3);
+  constexpr int dir = LOWER ? 1 : -1;           // the sweep visits rows n, n + dir, ...; the row before n is m = n - dir
+  constexpr int kFirstParity = LOWER ? 0 : 1;   // parity of the row of a line the sweep meets first
+  const double *tb = t + b * t_bs;
+  const double *Ab = (LOWER ? V : U) + b * N * J, *Bb = (LOWER ? U : V) + b * N * J;   // fed into F / applied to F
+  const double *Yb = Y + b * N * J;
+  double *Zb = Z + b * N * J;
+  double *Fd = WF ? F + b * N * (int64_t)(J * J) + 2 * k : nullptr;
+  const double cj = c[b * c_bs + k];
+  const int64_t lmax = (N - 1) >> 1;
+
+  struct Line { double2 a, b, y, z; double tt; };
+  // (values in, values out: handed around by reference the rings end up in scratch)
+  auto req_line = [&](int64_t l) -> Line {
+    Line R;
+    l = l < 0 ? 0 : (l > lmax ? lmax : l);
+    int64_t row = 2 * l + hrow; row = row < N ? row : N - 1;
+    int64_t trow = 2 * l + (k & 1); trow = trow < N ? trow : N - 1;
+    R.a = *reinterpret_cast<const double2 *>(Ab + row * J + col);
+    R.b = *reinterpret_cast<const double2 *>(Bb + row * J + col);
+    R.y = *reinterpret_cast<const double2 *>(Yb + row * J + col);
+    if constexpr (LOADZ) R.z = *reinterpret_cast<const double2 *>(Zb + row * J + col);
+    else R.z = make_double2(0.0, 0.0);
+    R.tt = tb[trow];
+    return R;
+  };
+  auto put_line = [&](int64_t l, const Line R) {
+    const int o = sl * kLS8 + ((2 * (int)(l & 1) + hrow) * J) + col;   // slot (row & 3) of the ring
+    *reinterpret_cast<double2 *>(&Aq[o]) = R.a;
+    *reinterpret_cast<double2 *>(&Bq[o]) = R.b;
+    *reinterpret_cast<double2 *>(&Yq[o]) = R.y;
+    if constexpr (LOADZ) *reinterpret_cast<double2 *>(&Zq[o]) = R.z;
+    tq[sl][2 * (int)(l & 1) + (k & 1)] = R.tt;   // (lanes of equal k & 1 write the same value)
+  };
+  auto flush = [&](int64_t l, auto guard_tag) {   // a finished line of Z: 16 bytes per lane, 128 per series
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    const int64_t row = 2 * l + hrow;
+    const double2 v = *reinterpret_cast<const double2 *>(&oZ[sl * kOS8 + hrow * J + col]);
+    if (!GUARD || (row >= 0 && row < N)) *reinterpret_cast<double2 *>(Zb + row * J + col) = v;
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+
+  // step 0: Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / untouched (matmul accumulate)
+  const int64_t r0 = LOWER ? 0 : N - 1;
+  double xprev = Yb[r0 * J + k];
+  oZ[sl * kOS8 + (int)(r0 & 1) * J + k] = SOLVE ? xprev : (LOADZ ? Zb[r0 * J + k] : 0.0);
+  if constexpr (WF) {  // internal.hpp:127 / :170
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<double2 *>(Fd + r0 * (int64_t)(J * J) + 16 * q) = make_double2(0.0, 0.0);
+  }
+  lds_order();
+  if ((r0 & 1) != kFirstParity) flush(r0 >> 1, Yes{});   // no step completes the line of this row
+  double Fj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) Fj[j] = 0.0;
+
+  // One step (row n, the row before it m = n - dir).  EDGE: lines moved here, synchronously, with guards; otherwise the
+  // rings are kept by the caller and PH says whether the step completes its line of Z (1: n is the second row of its line).
+  // (Forming the decay vector a step ahead, off the chain F -> z -> F, was tried: no faster.)
+  auto step = [&](const int64_t n, auto edge_tag, auto ph_tag) __attribute__((always_inline)) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    constexpr int PH = decltype(ph_tag)::value;
+    const int64_t m = n - dir;
+    if constexpr (EDGE) {
+      put_line(m >> 1, req_line(m >> 1));
+      put_line(n >> 1, req_line(n >> 1));   // (the same line again where m shares it)
+      lds_order();
+    }
+    const double tn = tq[sl][n & 3], tm = tq[sl][m & 3];
+    const double p = exp_decay(cj * (LOWER ? tm - tn : tn - tm));
+    pq[sl][k] = p;
+    const double yn = Yq[sl * kLS8 + (int)(n & 3) * J + k];
+    double zin = 0.0;
+    if constexpr (LOADZ) zin = Zq[sl * kLS8 + (int)(n & 3) * J + k];
+    lds_order();
+    double red = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; j += 2) {
+      const double2 p2 = *reinterpret_cast<const double2 *>(&pq[sl][j]);
+      const double2 a2 = *reinterpret_cast<const double2 *>(&Aq[sl * kLS8 + (int)(m & 3) * J + j]);
+      const double2 b2 = *reinterpret_cast<const double2 *>(&Bq[sl * kLS8 + (int)(n & 3) * J + j]);
+      const double f0 = fma(a2.x, xprev, Fj[j]);       // internal.hpp:140 / :183
+      Fj[j] = p2.x * f0;                                // internal.hpp:143 / :186
+      red = fma(b2.x, Fj[j], red);
+      const double f1 = fma(a2.y, xprev, Fj[j + 1]);
+      Fj[j + 1] = p2.y * f1;
+      red = fma(b2.y, Fj[j + 1], red);
+      if constexpr (WF)  // saved before the decay (internal.hpp:142 / :185)
+        *reinterpret_cast<double2 *>(&ftile[(sl * J + k) * J + j]) = make_double2(f0, f1);
+    }
+    const double zn = SOLVE ? yn - red : zin + red;  // internal.hpp:144 / :187
+    oZ[sl * kOS8 + (int)(n & 1) * J + k] = zn;
+    xprev = SOLVE ? zn : yn;
+    lds_order();
+    if constexpr (WF) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<double2 *>(Fd + n * (int64_t)(J * J) + 16 * q) =
+            *reinterpret_cast<const double2 *>(&ftile[sl * J * J + 16 * q + 2 * k]);
+    }
+    if constexpr (EDGE) {
+      if ((n & 1) != kFirstParity) flush(n >> 1, Yes{});
+    } else if constexpr (PH == 1) {
+      flush(n >> 1, No{});
+    }
+  };
+
+  int64_t n = r0 + dir, left = N - 1;
+  if (left > 0 && (n & 1) != kFirstParity) { step(n, Yes{}, std::integral_constant<int, 0>{}); n += dir; --left; }
+  if (left >= 4) {
+    // rings: the line of the row before n in LDS, the line of n and the one behind it requested
+    put_line((n - dir) >> 1, req_line((n - dir) >> 1));
+    Line lr0 = req_line(n >> 1), lr1 = req_line((n >> 1) + dir);
+    for (; left >= 4; left -= 4, n += 4 * dir) {
+      const int64_t lc = n >> 1;
+      put_line(lc, lr0);
+      lr0 = req_line(lc + 2 * dir);
+      lds_order();
+      step(n, No{}, std::integral_constant<int, 0>{});
+      step(n + dir, No{}, std::integral_constant<int, 1>{});
+      put_line(lc + dir, lr1);
+      lr1 = req_line(lc + 3 * dir);
+      lds_order();
+      step(n + 2 * dir, No{}, std::integral_constant<int, 0>{});
+      step(n + 3 * dir, No{}, std::integral_constant<int, 1>{});
+    }
+  }
+  for (; left > 0; --left, n += dir) step(n, Yes{}, std::integral_constant<int, 0>{});
+  // the line of the last row leaves now if no step completed it
+  lds_order();
+  flush((n - dir) >> 1, Yes{});
+}
+
 }  // namespace c2
 
 using namespace c2;
@@ -535,6 +693,29 @@ extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, in
   if (JM > KL) return C2_ERR_UNSUPPORTED;
   // the F workspace goes through the LDS tile: whole rows only
   if (F && !(nrhs == KL && J == JM && ((uintptr_t)F) % 16 == 0)) return C2_ERR_UNSUPPORTED;
+  // nrhs = J = 8 on full wavefronts: by lines (every pointer 16-byte pieces are moved through must allow that)
+  if (J == 8 && nrhs == 8 && B % 8 == 0 && N >= 8 && N % 2 == 0 &&
+      !(opt::has(opt::k_sweepk_lines) && opt::ival(opt::k_sweepk_lines) == 0) &&
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)Y | (uintptr_t)Z | (uintptr_t)F) % 16) == 0) {
+    const dim3 g8((unsigned)(B / 8));
+    const bool loadz = !solve && !zero_z;
+#define C2_S8(LO, SO, WF_, LZ)                                                                                     \
+  hipLaunchKernelGGL((k_sweep8_lines<LO, SO, WF_, LZ>), g8, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, V, Y, Z, F, \
+                     zero_z)
+#define C2_S8F(LO, SO, LZ) do { if (F) C2_S8(LO, SO, true, LZ); else C2_S8(LO, SO, false, LZ); } while (0)
+    if (lower) {
+      if (solve) C2_S8F(true, true, false);
+      else if (loadz) C2_S8F(true, false, true);
+      else C2_S8F(true, false, false);
+    } else {
+      if (solve) C2_S8F(false, true, false);
+      else if (loadz) C2_S8F(false, false, true);
+      else C2_S8F(false, false, false);
+    }
+#undef C2_S8F
+#undef C2_S8
+    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+  }
   const dim3 grid((unsigned)((B + (kWave / KL) - 1) / (kWave / KL)), (unsigned)((nrhs + KL - 1) / KL));
 #define C2_SK1(KL_, JM_, LO, SO)                                                                                     \
   do {                                                                                                               \

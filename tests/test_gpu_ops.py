@@ -922,6 +922,50 @@ def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
             close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d), Z0 + Zo)
 
 
+@pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (8, 34), (16, 64), (8, 132), (16, 200), (7, 64), (8, 33)])
+def test_multi_rhs_forward_sweeps_by_lines(ops, oracle, B, N):
+    """nrhs = J = 8 on full wavefronts, N even: the four forward sweeps by aligned 128-byte lines (k_sweep8_lines) -- with the
+    F workspace, without, in place (Z is Y), accumulating into Z -- against the oracle and against the row-by-row kernel
+    (option sweepk_lines = 0; odd N and ragged batches take it anyway)."""
+    from celerite2_amd import _lib
+    J = nrhs = 8
+    rng = np.random.default_rng(57 * B + N)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs))
+    Z0 = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Wd, Yd = dev(t, c, U, V, W, Y)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b])
+        def run_all():
+            out = {}
+            out["ws"] = getattr(ops, name)(td, cd, Ud, secd, Yd, workspace=True, zero_z=True)
+            out["plain"] = getattr(ops, name)(td, cd, Ud, secd, Yd) if solve else getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True)
+            Yc = Yd.clone()
+            out["inplace"] = getattr(ops, name)(td, cd, Ud, secd, Yc, Z=Yc)
+            if not solve:
+                (Z0d,) = dev(Z0)
+                out["acc"] = getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d)
+            return out
+        res = run_all()
+        _lib.set_option("sweepk_lines", 0)
+        try:
+            ref = run_all()
+        finally:
+            _lib.set_option("sweepk_lines", None)
+        close(res["ws"][0], Zo); close(res["ws"][1], Fo)
+        close(res["plain"], Zo)
+        close(res["inplace"], Zo if solve else Zo + Y)
+        if not solve:
+            close(res["acc"], Z0 + Zo)
+        close(res["ws"][0], ref["ws"][0].cpu().numpy()); close(res["ws"][1], ref["ws"][1].cpu().numpy())
+        close(res["inplace"], ref["inplace"].cpu().numpy())
+
+
 @pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (24, 33), (8, 34), (16, 64), (8, 131), (16, 200), (7, 64)])
 def test_multi_rhs_reverse_sweeps_by_lines(ops, oracle, B, N):
     """nrhs = J = 8 on full wavefronts (B a multiple of 8, N even): the four reverse sweeps move every width-8 row as half

@@ -1,5 +1,5 @@
 """A/B of one dispatch option inside one process (alternating, median of 7 each):
-    python tools/ab_option.py <option> <op> [nrhs] [B]      op: solve_lower | solve_upper | matmul_lower | matmul_upper | <op>_rev"""
+    python tools/ab_option.py <option> <op> [nrhs] [B]      op: solve_lower | solve_upper | matmul_lower | matmul_upper | <op>_rev | <op>_ws (with the F workspace)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,6 +13,8 @@ t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
 d, W, flag = ops.factor(t, c, a, U, V)
 torch.manual_seed(0)
 Y = torch.randn((B, N, nrhs), dtype=torch.float64, device=dev)
+ws = name.endswith("_ws")      # forward sweep writing the F workspace
+if ws: name = name[:-3]
 base = name[:-4] if name.endswith("_rev") else name
 sec = W if base.startswith("solve") else V
 if name.endswith("_rev"):
@@ -20,6 +22,9 @@ if name.endswith("_rev"):
     Z, F = getattr(ops, base)(t, c, U, sec, Y, **kw)
     bZ = torch.randn_like(Y)
     fn = lambda: getattr(ops, name)(t, c, U, sec, Y, Z, F, bZ)
+elif ws:
+    Zo = torch.empty_like(Y); Fo = torch.empty((B, N, J, nrhs), dtype=torch.float64, device=dev)
+    fn = (lambda: getattr(ops, name)(t, c, U, sec, Y, Z=Zo, F=Fo)) if base.startswith("solve") else (lambda: getattr(ops, name)(t, c, U, sec, Y, Z=Zo, F=Fo, zero_z=True))
 else:
     Zo = torch.empty_like(Y)
     fn = (lambda: getattr(ops, name)(t, c, U, sec, Y, Z=Zo)) if base.startswith("solve") else (lambda: getattr(ops, name)(t, c, U, sec, Y, Z=Zo, zero_z=True))

@@ -1,12 +1,10 @@
+#!/bin/bash
+# tools/ab_lanes8.sh <B> [tag ...]: the 8-lane gradient pair at B series (N = 4096, J = 8) for A/B builds, alternating, 3 rounds
 R=$GRAFT_REPO_ROOT
-cd /tmp; export TMPDIR=/tmp
-for tag in main "$@"; do
-  if [ "$tag" = main ]; then unset C2_LIB_PATH; else export C2_LIB_PATH=$R/celerite2_amd/libcelerite2_amd_$tag.so; fi
-  rm -rf /tmp/ab8p; rocprofv3 --kernel-trace --stats -d /tmp/ab8p -o out --output-format csv -- python $R/tools/lanes8_run.py 4096 8192 > /tmp/ab8.log 2>&1
-  f=$(find /tmp/ab8p -name "*kernel_stats.csv" | head -1)
-  python - "$f" "$tag" <<'PY'
-import csv, sys
-for r in csv.DictReader(open(sys.argv[1])):
-    if "k_loglik_" in r["Name"]: print("%-8s %-50s avg %8.1f us" % (sys.argv[2], r["Name"][:50], float(r["AverageNs"]) / 1e3))
-PY
+B=$1; shift
+for round in 1 2 3; do
+  for tag in main "$@"; do
+    if [ "$tag" = main ]; then unset C2_LIB_PATH; else export C2_LIB_PATH=$R/celerite2_amd/libcelerite2_amd_$tag.so; fi
+    echo -n "$tag: "; python $R/tools/lanes8_run.py 4096 $B 5 2>&1 | grep -v amdgpu
+  done
 done

@@ -1001,6 +1001,34 @@ def test_multi_rhs_reverse_sweeps_by_lines(ops, oracle, B, N):
                 close(r_[b], e_)
 
 
+@pytest.mark.parametrize("nrhs", [1, 8])
+@pytest.mark.parametrize("B,N", [(16, 66), (8, 40)])
+def test_sweeps_by_lines_shared_grid_and_rates(ops, oracle, B, N, nrhs):
+    """The line-pairing sweeps (J = 8; one and eight right-hand sides, forward and reverse) with the time grid and the
+    rates shared by the batch (batch stride 0): against the oracle, every series."""
+    J = 8
+    rng = np.random.default_rng(911 * B + N + nrhs)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    t0, c0 = t[0].copy(), c[0].copy()
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs)); bZ = rng.standard_normal((B, N, nrhs))
+    t0d, c0d, Ud, Vd, Wd, Yd, bZd = dev(t0, c0, U, V, W, Y, bZ)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zd, Fd = getattr(ops, name)(t0d, c0d, Ud, secd, Yd, workspace=True, zero_z=True)
+        Zp = getattr(ops, name)(t0d, c0d, Ud, secd, Yd) if solve else getattr(ops, name)(t0d, c0d, Ud, secd, Yd, zero_z=True)
+        res = getattr(ops, name + "_rev")(t0d, c0d, Ud, secd, Yd, Zd, Fd, bZd)
+        for b in range(B):
+            zo = np.empty((N, nrhs)); fo = np.empty((N, J, nrhs))
+            getattr(oracle, name + "_fwd")(t0, c0, U[b], sec[b], Y[b], zo, fo)
+            close(Zd[b], zo); close(Fd[b], fo); close(Zp[b], zo)
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t0, c0, U[b], sec[b], Y[b], zo, fo, bZ[b], *outs)
+            for r_, e_ in zip(res, outs):
+                close(r_[b], e_)
+
+
 @pytest.mark.parametrize("tile", ["1", "0"])
 @pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 97, 64), (3, 3, 40, 131), (6, 5, 200, 33), (16, 2, 50, 50), (2, 7, 1, 1)])
 def test_general_matmul_batched(ops, oracle, monkeypatch, J, nrhs, N, M, tile):

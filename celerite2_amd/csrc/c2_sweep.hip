@@ -693,14 +693,16 @@ extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, in
   if (JM > KL) return C2_ERR_UNSUPPORTED;
   // the F workspace goes through the LDS tile: whole rows only
   if (F && !(nrhs == KL && J == JM && ((uintptr_t)F) % 16 == 0)) return C2_ERR_UNSUPPORTED;
-  // nrhs = J = 8 on full wavefronts: by lines (every pointer 16-byte pieces are moved through must allow that)
-  if (J == 8 && nrhs == 8 && B % 8 == 0 && N >= 8 && N % 2 == 0 &&
+  // nrhs = J = 8: by lines on the whole wavefronts of the batch (every pointer 16-byte pieces are moved through must allow
+  // that), the row-by-row kernel below on the B % 8 series left over
+  if (J == 8 && nrhs == 8 && B >= 8 && N >= 8 &&
       !(opt::has(opt::k_sweepk_lines) && opt::ival(opt::k_sweepk_lines) == 0) &&
       (((uintptr_t)U | (uintptr_t)V | (uintptr_t)Y | (uintptr_t)Z | (uintptr_t)F) % 16) == 0) {
-    const dim3 g8((unsigned)(B / 8));
+    const int64_t B8 = B / 8 * 8;
+    const dim3 g8((unsigned)(B8 / 8));
     const bool loadz = !solve && !zero_z;
-#define C2_S8(LO, SO, WF_, LZ)                                                                                     \
-  hipLaunchKernelGGL((k_sweep8_lines<LO, SO, WF_, LZ>), g8, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, V, Y, Z, F, \
+#define C2_S8(LO, SO, WF_, LZ)                                                                                      \
+  hipLaunchKernelGGL((k_sweep8_lines<LO, SO, WF_, LZ>), g8, dim3(kWave), 0, s, B8, N, t, t_bs, c, c_bs, U, V, Y, Z, F, \
                      zero_z)
 #define C2_S8F(LO, SO, LZ) do { if (F) C2_S8(LO, SO, true, LZ); else C2_S8(LO, SO, false, LZ); } while (0)
     if (lower) {
@@ -714,7 +716,13 @@ extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, in
     }
 #undef C2_S8F
 #undef C2_S8
-    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+    if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
+    if (B8 == B) return C2_OK;
+    const int64_t o = B8 * N;   // rows of the series already done
+    t += B8 * t_bs; c += B8 * c_bs;
+    U += o * J; V += o * J; Y += o * nrhs; Z += o * nrhs;
+    if (F) F += o * J * nrhs;
+    B -= B8;
   }
   const dim3 grid((unsigned)((B + (kWave / KL) - 1) / (kWave / KL)), (unsigned)((nrhs + KL - 1) / KL));
 #define C2_SK1(KL_, JM_, LO, SO)                                                                                     \

@@ -284,11 +284,9 @@ __global__ __launch_bounds__(kWave) void k_sweep8_rev_lines(int64_t B, int64_t N
   auto flush_t = [&](int64_t l, auto guard_tag) {
     constexpr bool GUARD = decltype(guard_tag)::value;
     const double2 v = *reinterpret_cast<const double2 *>(&oT[sl][0]);
-    if constexpr (GUARD) {
-      if (k < 2 && 2 * l + k >= 0 && 2 * l + k < N) btb[2 * l + k] = k ? v.y : v.x;
-    } else {
-      *reinterpret_cast<double2 *>(btb + 2 * l) = v;   // (the lanes of a series store the same 16 bytes)
-    }
+    // (two 8-byte stores by lanes 0 and 1 of the series: with an odd number of rows every other series starts 8 bytes off
+    // a 16-byte boundary)
+    if (k < 2 && (!GUARD || (2 * l + k >= 0 && 2 * l + k < N))) btb[2 * l + k] = k ? v.y : v.x;
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
@@ -442,18 +440,26 @@ extern "C" int c2_internal_sweepK_rev(int lower, int solve, int64_t B, int64_t N
   const int JM = J <= 8 ? 8 : 16;
   const int KL = (nrhs <= 8 && JM == 8) ? 8 : 16;
   hipStream_t s = (hipStream_t)stream;
-  // nrhs = J = 8 on full wavefronts: the line-pairing kernel (every pointer it moves 16-byte pieces of must allow that)
-  if (J == 8 && nrhs == 8 && B % 8 == 0 && N >= 8 && !(c2::opt::has(c2::opt::k_sweep_rev_lines) && c2::opt::ival(c2::opt::k_sweep_rev_lines) == 0) &&
-      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)Y | (uintptr_t)Z | (uintptr_t)bZ | (uintptr_t)bU | (uintptr_t)bV |
-        (uintptr_t)bY | (uintptr_t)bt) % 16) == 0 && N % 2 == 0) {
-    const dim3 g8((unsigned)(B / 8));
-#define C2_SL(LO, SO)                                                                                                 \
-  hipLaunchKernelGGL((k_sweep8_rev_lines<LO, SO>), g8, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, \
+  // nrhs = J = 8: the line-pairing kernel on the whole wavefronts of the batch (every pointer it moves 16-byte pieces of
+  // must allow that), the row-by-row kernel below on the B % 8 series left over
+  if (J == 8 && nrhs == 8 && B >= 8 && N >= 8 && !(c2::opt::has(c2::opt::k_sweep_rev_lines) && c2::opt::ival(c2::opt::k_sweep_rev_lines) == 0) &&
+      (((uintptr_t)U | (uintptr_t)V | (uintptr_t)Y | (uintptr_t)Z | (uintptr_t)F | (uintptr_t)bZ | (uintptr_t)bU | (uintptr_t)bV |
+        (uintptr_t)bY) % 16) == 0) {
+    const int64_t B8 = B / 8 * 8;
+    const dim3 g8((unsigned)(B8 / 8));
+#define C2_SL(LO, SO)                                                                                                  \
+  hipLaunchKernelGGL((k_sweep8_rev_lines<LO, SO>), g8, dim3(kWave), 0, s, B8, N, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, \
                      bc, bU, bV, bY)
     if (lower) { if (solve) C2_SL(true, true); else C2_SL(true, false); }
     else { if (solve) C2_SL(false, true); else C2_SL(false, false); }
 #undef C2_SL
-    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+    if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
+    if (B8 == B) return C2_OK;
+    const int64_t o = B8 * N;   // rows of the series already done
+    t += B8 * t_bs; c += B8 * c_bs;
+    U += o * J; V += o * J; Y += o * nrhs; Z += o * nrhs; F += o * J * nrhs; bZ += o * nrhs;
+    bt += o; bc += B8 * J; bU += o * J; bV += o * J; bY += o * nrhs;
+    B -= B8;
   }
   const dim3 grid((unsigned)((B + (kWave / KL) - 1) / (kWave / KL)));
 #define C2_SKR1(KL_, JM_, LO, SO)                                                                                      \

@@ -922,11 +922,12 @@ def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
             close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d), Z0 + Zo)
 
 
-@pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (8, 34), (16, 64), (8, 132), (16, 200), (7, 64), (8, 33)])
+@pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (8, 34), (16, 64), (8, 132), (16, 200), (7, 64), (8, 33), (13, 9), (21, 65), (9, 130)])
 def test_multi_rhs_forward_sweeps_by_lines(ops, oracle, B, N):
-    """nrhs = J = 8 on full wavefronts, N even: the four forward sweeps by aligned 128-byte lines (k_sweep8_lines) -- with the
+    """nrhs = J = 8: the four forward sweeps by aligned 128-byte lines (k_sweep8_lines) on the whole wavefronts of the batch,
+    the row-by-row kernel on the B % 8 series left over (B = 13, 21, 9; B = 7: all of it), even and odd N -- with the
     F workspace, without, in place (Z is Y), accumulating into Z -- against the oracle and against the row-by-row kernel
-    (option sweepk_lines = 0; odd N and ragged batches take it anyway)."""
+    alone (option sweepk_lines = 0)."""
     from celerite2_amd import _lib
     J = nrhs = 8
     rng = np.random.default_rng(57 * B + N)
@@ -966,12 +967,12 @@ def test_multi_rhs_forward_sweeps_by_lines(ops, oracle, B, N):
         close(res["inplace"], ref["inplace"].cpu().numpy())
 
 
-@pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (24, 33), (8, 34), (16, 64), (8, 131), (16, 200), (7, 64)])
+@pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (24, 33), (8, 34), (16, 64), (8, 131), (16, 200), (7, 64), (13, 9), (21, 65), (9, 130), (8, 11), (8, 13)])
 def test_multi_rhs_reverse_sweeps_by_lines(ops, oracle, B, N):
-    """nrhs = J = 8 on full wavefronts (B a multiple of 8, N even): the four reverse sweeps move every width-8 row as half
-    of an aligned 128-byte line through LDS rings (k_sweep8_rev_lines) -- every length class of the main loop (N - 1 mod 4,
-    the peeled first step, the guarded last ones), against the oracle and bit for bit against nothing: the row-by-row
-    kernel (option sweep_rev_lines = 0; odd N and ragged batches take it anyway) must agree to rounding."""
+    """nrhs = J = 8: the four reverse sweeps move every width-8 row as half of an aligned 128-byte line through LDS rings
+    (k_sweep8_rev_lines) on the whole wavefronts of the batch, the row-by-row kernel on the B % 8 series left over -- every
+    length class of the main loop (N - 1 mod 4, even and odd N, the peeled first step, the guarded last ones), against the
+    oracle; the row-by-row kernel alone (option sweep_rev_lines = 0) must agree to rounding."""
     from celerite2_amd import _lib
     J = nrhs = 8
     rng = np.random.default_rng(31 * B + N)

@@ -21,7 +21,7 @@ worst = 0.0
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for seed in range(nseeds):
     rng = np.random.default_rng(424242 + seed)
-    B = int(rng.choice([8, 16, 24, 40, 64])); N = int(rng.choice([8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 30, 31, 32, 33, 34, 63, 64, 65, 66, 100, 257, 258, 600]))
+    B = int(rng.choice([8, 9, 15, 16, 17, 24, 29, 40, 64, 67])); N = int(rng.choice([8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 30, 31, 32, 33, 34, 63, 64, 65, 66, 100, 257, 258, 600]))
     nrhs = int(rng.choice([1, 8])); J = 8
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
     if rng.random() < 0.3: t[:, N // 2:] += rng.choice([1.0, 30.0])

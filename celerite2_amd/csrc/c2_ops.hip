@@ -204,17 +204,24 @@ __global__ __launch_bounds__(kWave) void k_factor(int64_t B, int64_t N, int J, c
 // natural order; rows leave through the LDS tile of s_row_store as dense 16-byte-per-lane runs.  J == G only.
 // Rows after a failed pivot stay untouched, like the reference's early return (forward.hpp:128).
 // -----------------------------------------------------------------------------
-template <int G>
+// LN (G = 8, W 16-byte aligned): the grid and the pivots arrive as transposed tiles of eight rows (lane j <-> row n0 + j: one
+// request per eight rows instead of one per row in which eight lanes share 8 bytes), the W rows as halves of aligned
+// 128-byte lines through a four-row LDS tile -- 1.4 requests per row next to the four stores instead of three (the pass is
+// bound by the memory instructions a single wavefront keeps in flight, profiles/r03_sweep_rev_lines.md).
+template <int G, bool LN = false>
 __global__ __launch_bounds__(kWave) void k_s_replay(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                     const double *__restrict__ c, int64_t c_bs,
                                                     const double *__restrict__ d, const double *__restrict__ W,
                                                     const int32_t *__restrict__ flag, double *__restrict__ S) {
-  constexpr int J = G, R = 8;
+  constexpr int J = G, R = 8, SPW = kWave / G;
+  static_assert(!LN || G == 8, "lines: eight lanes per series");
   __shared__ __attribute__((aligned(16))) double gs[2][kWave];
   __shared__ __attribute__((aligned(16))) double stile[kWave * G];
+  __shared__ __attribute__((aligned(16))) double tWl[LN ? 4 : 1][kWave];          // W rows (row & 3)
+  __shared__ __attribute__((aligned(16))) double scT[LN ? 2 : 1][2][SPW][R];     // [block parity][t_n / d_{n-1}][series][row]
   const int lane = threadIdx.x;
   const Lane L = lane_of<G>(B);
-  const int j = L.j;
+  const int j = L.j, grp = lane / G;
   const double *tb = t + L.b * t_bs, *db = d + L.b * N, *Wb = W + L.b * N * J + j;
   double *Srow = S + L.b * N * J * J;
   const double cj = c[L.b * c_bs + j];
@@ -233,25 +240,72 @@ __global__ __launch_bounds__(kWave) void k_s_replay(int64_t B, int64_t N, const 
 #pragma unroll
     for (int i = 0; i < G; ++i) Srow[j * J + i] = 0.0;  // S.row(0).setZero() (forward.hpp:92)
   }
-  double rt[R], rdm[R], rw[R];
+  double rt[LN ? 1 : R], rdm[LN ? 1 : R], rw[LN ? 1 : R];
   auto load_row = [&](int r, int64_t n) {
     n = (n < N) ? n : N - 1;
     n = (n >= 1) ? n : 1;
     rt[r] = tb[n]; rdm[r] = db[n - 1]; rw[r] = Wb[(n - 1) * J];
   };
+  // LN: scalar tiles (registers hold block b + 2, LDS blocks b and b + 1) and a ring of four W lines (slot = line mod 4)
+  double vt = 0.0, vd = 0.0;
+  double2 lw[LN ? R / 2 : 1];
+  const int hrow = j >> 2, hcol = 2 * (j & 3);
+  const double *Wl = W + L.b * N * J + hcol;
+  auto vload = [&](int64_t nb) {
+    int64_t n = nb + j;
+    n = (n < N) ? n : N - 1;
+    n = (n >= 1) ? n : 1;
+    vt = tb[n]; vd = db[n - 1];
+  };
+  auto vstage = [&](int q) { scT[q][0][grp][j] = vt; scT[q][1][grp][j] = vd; };
+  auto wline = [&](int64_t l) -> double2 {
+    int64_t row = 2 * l + hrow;
+    row = (row < N) ? row : N - 1;
+    return *reinterpret_cast<const double2 *>(Wl + row * J);
+  };
   if (N > 1) {
+    if constexpr (LN) {
+      vload(1); vstage(0);
+      vload(1 + R); vstage(1);
+      vload(1 + 2 * R);
 #pragma unroll
-    for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+      for (int q = 0; q < R / 2; ++q) lw[q] = wline(q);
+      lds_order();
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+    }
   }
   double tprev = tb[0];
+  int bq = 0;   // parity of the current block of eight rows (LN)
   auto step = [&](int r, int64_t n, auto guarded_tag) {
     constexpr bool GUARDED = decltype(guarded_tag)::value;
-    const double tn = rt[r], dw = rdm[r] * rw[r], w = rw[r];
-    load_row(r, n + R);
+    double tn, dw, w;
+    double wA[G], pA[G], sh[G];
+    if constexpr (LN) {
+      // n = n0 + r with n0 = 1 (mod 8): row n - 1 of W opens the line (n - 1) / 2 at even r (slot r / 2 of the ring)
+      if (r % 2 == 0) {   // (r: unrolled)
+        const int64_t l = (n - 1) >> 1;
+        *reinterpret_cast<double2 *>(&tWl[(r + hrow) & 3][grp * G + hcol]) = lw[(r / 2) % (R / 2)];
+        lw[(r / 2) % (R / 2)] = wline(l + R / 2);
+        lds_order();
+      }
+      tn = scT[bq][0][grp][r];
+      const double dm = scT[bq][1][grp][r];
+#pragma unroll
+      for (int i = 0; i < G; i += 2) {
+        const double2 v = *reinterpret_cast<const double2 *>(&tWl[r & 3][grp * G + i]);
+        wA[i] = v.x; wA[i + 1] = v.y;
+      }
+      w = tWl[r & 3][lane];
+      dw = dm * w;
+    } else {
+      tn = rt[r]; dw = rdm[r] * rw[r]; w = rw[r];
+      load_row(r, n + R);
+    }
     const double p = exp_decay(cj * (tprev - tn));
     tprev = tn;
-    double wA[G], pA[G], sh[G];
-    lds_allgather<G>(gs[0], lane, w, wA);
+    if constexpr (!LN) lds_allgather<G>(gs[0], lane, w, wA);
     lds_allgather<G>(gs[1], lane, p, pA);
 #pragma unroll
     for (int i = 0; i < G; ++i) {
@@ -260,6 +314,15 @@ __global__ __launch_bounds__(kWave) void k_s_replay(int64_t B, int64_t N, const 
     }
     if (!GUARDED || (L.valid && n <= nlast)) s_row_store<G>(stile, lane, sh, Srow + n * J * J);  // forward.hpp:120
     else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (LN) {
+      if (r == R - 1) {   // end of the block: stage block b + 2's scalars, fetch block b + 3's
+        lds_order();
+        vstage(bq);
+        vload(n + 1 + 2 * R);
+        bq ^= 1;
+        lds_order();
+      }
+    }
   };
   // Full blocks of a full wavefront run without a single branch: with row guards in the body the compiler can no
   // longer count the stores behind a prefetched load and waits for ALL of them (vmcnt(0)) once per row.
@@ -1473,8 +1536,15 @@ int c2_factor(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
     // (with S the row-by-row kernel: the reverse-mode chain that asks for S is checked element by element at 1e-12)
     if (int e = c2_internal_factor_fused(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, 0, stream)) return e;
     C2_DISPATCH_G(group_size(J), {
-      if constexpr (G >= 2 && G <= 16)
-        hipLaunchKernelGGL(k_s_replay<G>, grid_for(B, G), dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs,
+      if constexpr (G == 8) {
+        if (((uintptr_t)W) % 16 == 0 && !(opt::has(opt::k_s_replay_lines) && opt::ival(opt::k_s_replay_lines) == 0))
+          hipLaunchKernelGGL((k_s_replay<G, true>), grid_for(B, G), dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs,
+                             (const double *)d, (const double *)W, (const int32_t *)flag, S);
+        else
+          hipLaunchKernelGGL((k_s_replay<G, false>), grid_for(B, G), dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs,
+                             (const double *)d, (const double *)W, (const int32_t *)flag, S);
+      } else if constexpr (G >= 2 && G <= 16)
+        hipLaunchKernelGGL((k_s_replay<G, false>), grid_for(B, G), dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs,
                            (const double *)d, (const double *)W, (const int32_t *)flag, S);
     });
     return check_launch();

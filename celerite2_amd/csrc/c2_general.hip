@@ -9,9 +9,9 @@
 // reduction and the Y / Z rows move as dense runs -- the mapping of k_sweepK (c2_sweep.hip).  The merge itself is run
 // ONE EVENT PER ITERATION with both event types predicated: every series of the wavefront either absorbs its next t2
 // row or emits its next t1 row, so series whose grids interleave differently do not serialise each other; the decay
-// vector and the row that goes with the event (V_m or U_n) are computed / held by lanes 0..J-1 and broadcast through
-// LDS.  The next row of BOTH streams is always in registers, and a touch load eight rows further down each stream keeps
-// the lines coming (the merge decides only at run time which stream advances).
+// vector is computed by lanes 0..J-1 and broadcast through LDS.  Eight rows of BOTH streams are resident in an LDS ring per
+// series; the row eight positions down the moving stream is requested at the top of every event and written into the
+// ring three events later (the merge decides only at run time which stream advances).
 //
 // Workspace semantics as the reference: F[m, j * nrhs + k] (row-major), row m written when row m is absorbed, rows the
 // merge never reaches left untouched, row 0 = V_0^T Y_0 (lower) / 0 (upper), row M-1 never written by the upper variant.
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   // decay vector, event row; two doubles of padding per vector: a series' pair is 16 (KL + 2) bytes from the next one's, so
   // the b128 broadcasts of the SPW series of a wavefront fall into distinct banks (unpadded, KL = 8: 128-byte stride, four
   // series per bank group -- 13 % of the kernel's cycles were LDS bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT)
-  __shared__ __attribute__((aligned(16))) double rowbuf[SPW][2][KL + 2];
+  __shared__ __attribute__((aligned(16))) double rowbuf[SPW][2][KL + 2];   // [0]: the decay vector of the event, [1]: prologue
   const int lane = threadIdx.x, sl = lane / KL, k = lane % KL;
   int64_t b = (int64_t)blockIdx.x * SPW + sl;
   const bool vb = b < B;
@@ -78,50 +78,49 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   // the next row of either stream (clamped at the end of its grid)
   auto clampN = [&](int64_t s) { return rowN(s < N ? s : N - 1); };
   auto clampM = [&](int64_t s) { return rowM(s < M ? s : M - 1); };
-  // Three rows of either stream in registers: the current one and the two behind it.  Which stream moves is decided at
-  // the TOP of an event (it only takes the two current times), so the row three positions down the moving stream is
-  // requested there -- into one of two pending sets, alternating -- and lands in the stream's last slot at the END of the
-  // NEXT event: nearly two events (~0.5 us) between a request and its first use, where the first version asked for a row
-  // at the end of an event and selected it into place at once (one full L2 / HBM latency per event: 0.9 us, 7.0 ms per
-  // 8192 series of 4096 + 4096 rows with 8 right-hand sides).  Every event issues the same five loads, so the compiler
-  // can count them (vmcnt) instead of draining the queue.
-  double tn = t1b[clampN(n)], un = actj ? Ub[clampN(n) * J] : 0.0, zn = Zb[clampN(n) * nrhs];
-  double tm = t2b[clampM(m)], vm = actj ? Vb[clampM(m) * J] : 0.0, ym = Yb[clampM(m) * nrhs];
-  double tn2 = t1b[clampN(n + 1)], un2 = actj ? Ub[clampN(n + 1) * J] : 0.0, zn2 = Zb[clampN(n + 1) * nrhs];
-  double tm2 = t2b[clampM(m + 1)], vm2 = actj ? Vb[clampM(m + 1) * J] : 0.0, ym2 = Yb[clampM(m + 1) * nrhs];
-  double tn3 = t1b[clampN(n + 2)], un3 = actj ? Ub[clampN(n + 2) * J] : 0.0, zn3 = Zb[clampN(n + 2) * nrhs];
-  double tm3 = t2b[clampM(m + 2)], vm3 = actj ? Vb[clampM(m + 2) * J] : 0.0, ym3 = Yb[clampM(m + 2) * nrhs];
-  struct Pend { double t, r, x; int tag; };   // tag: 0 nothing, 1 a t2 row, 2 a t1 row
-  Pend pa{0.0, 0.0, 0.0, 0}, pb{0.0, 0.0, 0.0, 0};
-
-  // (the touch loads that keep the lines coming, eight rows down the moving stream, are only there for their side effect;
-  // so that nobody waits for them their values are summed into `sink` FOUR events after they were requested -- the loop
-  // is unrolled four times over four pairs of registers)
-  double sink = 0.0;
-  struct Touch { double r, x; };
-  Touch th0{0.0, 0.0}, th1{0.0, 0.0}, th2{0.0, 0.0}, th3{0.0, 0.0};
-  auto event = [&](Pend &issue, Pend &resolve, Touch &tch) __attribute__((always_inline)) {
+  // RD rows of either stream live in an LDS ring per series (slot = position mod RD: time, the row of V / U, the values of Y
+  // / Z).  Which stream moves is decided at the TOP of an event (it only takes the two current times): the row RD
+  // positions down the moving stream is requested there, into the slot the event's own row leaves, lands in registers and
+  // is written into the ring three events later -- so nobody waits for it (the first version asked for a row at the end of
+  // an event and selected it into place at once: one L2 / HBM latency per event, 7.0 ms per 8192 series of 4096 + 4096 rows
+  // with 8 right-hand sides; the second kept three rows of either stream in registers and shifted them by selects, plus
+  // touch loads eight rows down: 178 VALU and 5.8 memory instructions per event, 4.5 ms).  Every event issues the same
+  // three loads, so the compiler counts them (vmcnt) instead of draining the queue; the event's row and the current times
+  // are read from the ring by position, no register ring to shift.
+  constexpr int RD = 8, NSLOT = 2 * RD + 1;            // (slot 2 RD: where the request of a finished series goes)
+  constexpr int RS = (NSLOT + (NSLOT & 1)) + 2 * NSLOT * KL + 2;   // doubles per series; [T: NSLOT (+1)][R: NSLOT x KL][X: NSLOT x KL] (+2)
+  __shared__ __attribute__((aligned(16))) double ring[SPW * RS];
+  double *rg = ring + sl * RS;
+  double *rgR = rg + NSLOT + (NSLOT & 1), *rgX = rgR + NSLOT * KL;   // (16-byte aligned rows)
+  static_assert((NSLOT + (NSLOT & 1)) + 2 * NSLOT * KL <= RS && RS % 2 == 0, "ring layout");
+  for (int q = 0; q < RD; ++q) {
+    const int64_t rm = clampM(m + q), rn = clampN(n + q);
+    const int sm = (int)((m + q) & (RD - 1)), sn = RD + (int)((n + q) & (RD - 1));
+    rg[sm] = t2b[rm]; rgR[sm * KL + k] = actj ? Vb[rm * J] : 0.0; rgX[sm * KL + k] = Yb[rm * nrhs];
+    rg[sn] = t1b[rn]; rgR[sn * KL + k] = actj ? Ub[rn * J] : 0.0; rgX[sn * KL + k] = Zb[rn * nrhs];
+  }
+  lds_order();
+  double tm = rg[(int)(m & (RD - 1))], tn = rg[RD + (int)(n & (RD - 1))];
+  struct Pend { double t, r, x; int slot; };
+  Pend p0{0.0, 0.0, 0.0, 2 * RD}, p1 = p0, p2 = p0, p3 = p0;
+  auto event = [&](Pend &issue, Pend &resolve) __attribute__((always_inline)) {
     const bool live = n < N;
     // lower: absorb while t2[m] <= t1[n];  upper (walking down): absorb while t2[m] > t1[n]
     const bool absorb = live && m < M && (LOWER ? tm <= tn : tm > tn);
     const bool emit = live && !absorb;
-    {   // the requests of this event: the row three positions down the moving stream, a touch eight rows down
-      const int64_t rm = clampM(m + 3), rn = clampN(n + 3);
+    const int so = absorb ? (int)(m & (RD - 1)) : RD + (int)(n & (RD - 1));   // the event's row in the ring
+    {   // the request of this event: the row RD positions down the moving stream
+      const int64_t rm = clampM(m + RD), rn = clampN(n + RD);
       const double *pt = absorb ? t2b + rm : t1b + rn;
       const double *pr = absorb ? Vb + rm * J : Ub + rn * J;
       const double *px = absorb ? Yb + rm * nrhs : (const double *)Zb + rn * nrhs;
       issue.t = *pt; issue.r = actj ? *pr : 0.0; issue.x = *px;
-      issue.tag = absorb ? 1 : (emit ? 2 : 0);
-      sink += tch.r + tch.x;
-      const int64_t fm = clampM(m + 8), fn = clampN(n + 8);
-      const double *qr = absorb ? Vb + fm * J : Ub + fn * J;
-      const double *qx = absorb ? Yb + fm * nrhs : (const double *)Zb + fn * nrhs;
-      tch.r = *qr; tch.x = *qx;
+      issue.slot = live ? so : 2 * RD;
     }
+    const double xe = rgX[so * KL + k];   // y_m / z_n
     const double tev = absorb ? tm : tn;
     const double p = exp_decay(cj * (LOWER ? tlast - tev : tev - tlast));
     rowbuf[sl][0][k] = p;
-    rowbuf[sl][1][k] = absorb ? vm : un;
     lds_order();
     double red = 0.0;
 #pragma unroll
@@ -129,45 +128,41 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
       double2 p2, r2;
       if constexpr (JM >= 2) {
         p2 = *reinterpret_cast<const double2 *>(&rowbuf[sl][0][j]);
-        r2 = *reinterpret_cast<const double2 *>(&rowbuf[sl][1][j]);
+        r2 = *reinterpret_cast<const double2 *>(&rgR[so * KL + j]);
       } else {
-        p2 = make_double2(rowbuf[sl][0][0], 0.0); r2 = make_double2(rowbuf[sl][1][0], 0.0);
+        p2 = make_double2(rowbuf[sl][0][0], 0.0); r2 = make_double2(rgR[so * KL], 0.0);
       }
       const double f0 = p2.x * Fj[j];
       red = fma(r2.x, f0, red);                       // emit: (U_n o p) . F          (forward.hpp:329 / 389)
-      Fj[j] = absorb ? fma(r2.x, ym, f0) : Fj[j];      // absorb: F = p o F + V_m^T y_m (forward.hpp:320-323 / 380-383)
+      Fj[j] = absorb ? fma(r2.x, xe, f0) : Fj[j];      // absorb: F = p o F + V_m^T y_m (forward.hpp:320-323 / 380-383)
       if (j + 1 < JM) {
         const double f1 = p2.y * Fj[j + 1];
         red = fma(r2.y, f1, red);
-        Fj[j + 1] = absorb ? fma(r2.y, ym, f1) : Fj[j + 1];
+        Fj[j + 1] = absorb ? fma(r2.y, xe, f1) : Fj[j + 1];
       }
     }
-    lds_order();
     if (WF && absorb && vk) {
       const int64_t mr = rowM(m);
       for (int j = 0; j < J; ++j) Fb[mr * J * nrhs + (int64_t)j * nrhs] = Fj[j];
     }
-    if (emit && vk) Zb[rowN(n) * nrhs] = zn + red;
-    // (1) the row requested by the PREVIOUS event arrives in the last slot of its stream ...
-    const bool rm_ = resolve.tag == 1, rn_ = resolve.tag == 2;
-    tm3 = rm_ ? resolve.t : tm3; vm3 = rm_ ? resolve.r : vm3; ym3 = rm_ ? resolve.x : ym3;
-    tn3 = rn_ ? resolve.t : tn3; un3 = rn_ ? resolve.r : un3; zn3 = rn_ ? resolve.x : zn3;
-    // (2) ... then the stream this event came from moves up (its last slot is stale until this event's request lands)
+    if (emit && vk) Zb[rowN(n) * nrhs] = xe + red;
+    // the row requested three events ago goes into its slot (the row that slot held was consumed by the event that
+    // requested it); then the stream this event came from moves up and the current times are read again
+    rg[resolve.slot] = resolve.t;
+    rgR[resolve.slot * KL + k] = resolve.r;
+    rgX[resolve.slot * KL + k] = resolve.x;
     tlast = absorb ? tm : tlast;
     m += absorb ? 1 : 0;
     n += emit ? 1 : 0;
-    tm = absorb ? tm2 : tm; vm = absorb ? vm2 : vm; ym = absorb ? ym2 : ym;
-    tm2 = absorb ? tm3 : tm2; vm2 = absorb ? vm3 : vm2; ym2 = absorb ? ym3 : ym2;
-    tn = emit ? tn2 : tn; un = emit ? un2 : un; zn = emit ? zn2 : zn;
-    tn2 = emit ? tn3 : tn2; un2 = emit ? un3 : un2; zn2 = emit ? zn3 : zn2;
+    lds_order();
+    tm = rg[(int)(m & (RD - 1))]; tn = rg[RD + (int)(n & (RD - 1))];
   };
   while (__any(n < N)) {
-    event(pa, pb, th0);
-    event(pb, pa, th1);   // (an event of a finished series is a no-op: nothing absorbed, nothing emitted, rows clamped)
-    event(pa, pb, th2);
-    event(pb, pa, th3);
+    event(p0, p1);
+    event(p1, p2);   // (an event of a finished series is a no-op: nothing absorbed, nothing emitted, its request parked)
+    event(p2, p3);
+    event(p3, p0);
   }
-  if (sink == 1.2345678e300) Zb[0] = sink;  // keeps the touch loads alive; never true for finite data
 }
 
 }  // namespace c2g

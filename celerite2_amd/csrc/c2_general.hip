@@ -81,18 +81,22 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   // RD rows of either stream live in an LDS ring per series (slot = position mod RD: time, the row of V / U, the values of Y
   // / Z).  Which stream moves is decided at the TOP of an event (it only takes the two current times): the row RD
   // positions down the moving stream is requested there, into the slot the event's own row leaves, lands in registers and
-  // is written into the ring three events later -- so nobody waits for it (the first version asked for a row at the end of
+  // is written into the ring five events later -- so nobody waits for it (the first version asked for a row at the end of
   // an event and selected it into place at once: one L2 / HBM latency per event, 7.0 ms per 8192 series of 4096 + 4096 rows
   // with 8 right-hand sides; the second kept three rows of either stream in registers and shifted them by selects, plus
   // touch loads eight rows down: 178 VALU and 5.8 memory instructions per event, 4.5 ms).  Every event issues the same
   // three loads, so the compiler counts them (vmcnt) instead of draining the queue; the event's row and the current times
   // are read from the ring by position, no register ring to shift.
   constexpr int RD = 8, NSLOT = 2 * RD + 1;            // (slot 2 RD: where the request of a finished series goes)
-  constexpr int RS = (NSLOT + (NSLOT & 1)) + 2 * NSLOT * KL + 2;   // doubles per series; [T: NSLOT (+1)][R: NSLOT x KL][X: NSLOT x KL] (+2)
+  // doubles per series: [T: NSLOT (+1)][R: NSLOT x KL][X: NSLOT x KL], padded to 8 (mod 32): the 64-byte rows of the two
+  // series a quarter-wavefront reads fall into different banks (series 2336 bytes apart: 18 quad-cycles of bank conflicts
+  // per event, rocprofv3 SQ_LDS_BANK_CONFLICT)
+  constexpr int RS0 = (NSLOT + (NSLOT & 1)) + 2 * NSLOT * KL;
+  constexpr int RS = RS0 + ((8 - RS0 % 32) + 32) % 32;
   __shared__ __attribute__((aligned(16))) double ring[SPW * RS];
   double *rg = ring + sl * RS;
   double *rgR = rg + NSLOT + (NSLOT & 1), *rgX = rgR + NSLOT * KL;   // (16-byte aligned rows)
-  static_assert((NSLOT + (NSLOT & 1)) + 2 * NSLOT * KL <= RS && RS % 2 == 0, "ring layout");
+  static_assert(RS0 <= RS && RS % 32 == 8, "ring layout");
   for (int q = 0; q < RD; ++q) {
     const int64_t rm = clampM(m + q), rn = clampN(n + q);
     const int sm = (int)((m + q) & (RD - 1)), sn = RD + (int)((n + q) & (RD - 1));
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   lds_order();
   double tm = rg[(int)(m & (RD - 1))], tn = rg[RD + (int)(n & (RD - 1))];
   struct Pend { double t, r, x; int slot; };
-  Pend p0{0.0, 0.0, 0.0, 2 * RD}, p1 = p0, p2 = p0, p3 = p0;
+  Pend p0{0.0, 0.0, 0.0, 2 * RD}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0;
   auto event = [&](Pend &issue, Pend &resolve) __attribute__((always_inline)) {
     const bool live = n < N;
     // lower: absorb while t2[m] <= t1[n];  upper (walking down): absorb while t2[m] > t1[n]
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
       for (int j = 0; j < J; ++j) Fb[mr * J * nrhs + (int64_t)j * nrhs] = Fj[j];
     }
     if (emit && vk) Zb[rowN(n) * nrhs] = xe + red;
-    // the row requested three events ago goes into its slot (the row that slot held was consumed by the event that
+    // the row requested five events ago goes into its slot (the row that slot held was consumed by the event that
     // requested it); then the stream this event came from moves up and the current times are read again
     rg[resolve.slot] = resolve.t;
     rgR[resolve.slot * KL + k] = resolve.r;
@@ -161,7 +165,9 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
     event(p0, p1);
     event(p1, p2);   // (an event of a finished series is a no-op: nothing absorbed, nothing emitted, its request parked)
     event(p2, p3);
-    event(p3, p0);
+    event(p3, p4);
+    event(p4, p5);
+    event(p5, p0);
   }
 }
 

@@ -94,6 +94,8 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   constexpr int RS0 = (NSLOT + (NSLOT & 1)) + 2 * NSLOT * KL;
   constexpr int RS = RS0 + ((8 - RS0 % 32) + 32) % 32;
   __shared__ __attribute__((aligned(16))) double ring[SPW * RS];
+  __shared__ __attribute__((aligned(16))) double ftile[WF ? SPW * JM * KL : 2];
+  const bool dense_f = WF && nrhs == KL && J == JM && (((uintptr_t)F) % 16) == 0;   // (uniform)
   double *rg = ring + sl * RS;
   double *rgR = rg + NSLOT + (NSLOT & 1), *rgX = rgR + NSLOT * KL;   // (16-byte aligned rows)
   static_assert(RS0 <= RS && RS % 32 == 8, "ring layout");
@@ -145,9 +147,21 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
         Fj[j + 1] = absorb ? fma(r2.y, xe, f1) : Fj[j + 1];
       }
     }
-    if (WF && absorb && vk) {
-      const int64_t mr = rowM(m);
-      for (int j = 0; j < J; ++j) Fb[mr * J * nrhs + (int64_t)j * nrhs] = Fj[j];
+    if constexpr (WF) {
+      if (dense_f) {   // nrhs == KL, J == JM: the row (J x nrhs doubles, [j][k]) leaves as 16-byte pieces through an LDS tile
+#pragma unroll
+        for (int j = 0; j < JM; ++j) ftile[sl * JM * KL + j * KL + k] = Fj[j];
+        lds_order();
+        if (absorb && vb) {
+          double *fr = F + (b * M + rowM(m)) * (int64_t)(JM * KL);
+#pragma unroll
+          for (int q = 0; q < JM / 2; ++q)
+            *reinterpret_cast<double2 *>(fr + 2 * (q * KL + k)) = *reinterpret_cast<const double2 *>(&ftile[sl * JM * KL + 2 * (q * KL + k)]);
+        }
+      } else if (absorb && vk) {
+        const int64_t mr = rowM(m);
+        for (int j = 0; j < J; ++j) Fb[mr * J * nrhs + (int64_t)j * nrhs] = Fj[j];
+      }
     }
     if (emit && vk) Zb[rowN(n) * nrhs] = xe + red;
     // the row requested five events ago goes into its slot (the row that slot held was consumed by the event that

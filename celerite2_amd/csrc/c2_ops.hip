@@ -1197,6 +1197,10 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
                                   const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
                                   double *Z, double *F, int zero_z, c2_stream_t stream);
 
+extern "C" int c2_internal_sweepT_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
+                                      int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                      const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
+                                      double *bc, double *bU, double *bV, double *bY, c2_stream_t stream);
 extern "C" int c2_internal_sweep1_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, const double *t,
                                       int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
                                       const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
@@ -1487,6 +1491,11 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
     return c2_internal_sweep1_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU,
                                   bV, bY, stream);
+  if (nrhs <= 4) {   // two to four: lanes over J, per-series scalars transposed in time (c2_sweep.hip)
+    const int e = c2_internal_sweepT_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt,
+                                         bc, bU, bV, bY, stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
+  }
   {  // several right-hand sides: lanes over them (c2_sweep_rev.hip) where the shape fits; C2_SWEEPK_REV=0 for A/B runs
     if (!(opt::has(opt::k_sweepk_rev) && opt::ival(opt::k_sweepk_rev) == 0)) {
       const int e = c2_internal_sweepK_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ,

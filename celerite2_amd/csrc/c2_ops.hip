@@ -1491,7 +1491,7 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
     return c2_internal_sweep1_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU,
                                   bV, bY, stream);
-  if (nrhs <= 4) {   // two to four: lanes over J, per-series scalars transposed in time (c2_sweep.hip)
+  if (nrhs <= 7) {   // two to seven: lanes over J, per-series scalars transposed in time (c2_sweep.hip)
     const int e = c2_internal_sweepT_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt,
                                          bc, bU, bV, bY, stream);
     if (e != C2_ERR_UNSUPPORTED) return e;

@@ -321,8 +321,8 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
 // Same semantics as k_sweep (internal.hpp:105-189): in-place Z == Y is legal (rows are read R steps ahead of the
 // row being written), matmul accumulates into Z unless zero_z.
 // -----------------------------------------------------------------------------------------------------------------
-// WF: also write the F workspace.  Shapes with nrhs == KL and J == JM only (the launcher checks): a row of F is then
-// KL x J doubles, lane k holding the J consecutive entries F[n, j + J k]; they leave through an LDS tile as dense
+// WF: also write the F workspace.  Shapes with nrhs <= KL (one tile of right-hand sides) and J == JM only (the launcher
+// checks): a row of F is then nrhs x J doubles, lane k holding the J consecutive entries F[n, j + J k]; they leave through an LDS tile as dense
 // 16-byte-per-lane runs (stored straight from the lanes they would be 16-byte pieces of 64 separate lines).
 template <int KL, int JM, int R, bool LOWER, bool SOLVE, bool WF>
 __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, int64_t nrhs, const double *t, int64_t t_bs,
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
   double *zb = Z + b * N * nrhs + kk;
   const double cj = actj ? c[b * c_bs + k] : 0.0;
   auto rowof = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
-  double *Frow = WF ? F + b * N * (int64_t)(KL * JM) : nullptr;  // WF: nrhs == KL, J == JM
+  const int RL = (int)nrhs * JM;   // doubles in a workspace row (WF: nrhs <= KL, J == JM, one rhs tile)
+  double *Frow = WF ? F + b * N * (int64_t)RL : nullptr;
 
   const int64_t r0 = rowof(0);
   double xprev = yb[r0 * nrhs];
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
   if (WF && vb) {  // internal.hpp:127 / :170
 #pragma unroll
     for (int qq = 0; qq < JM / 2; ++qq)
-      *reinterpret_cast<double2 *>(Frow + r0 * (KL * JM) + qq * 2 * KL + 2 * k) = make_double2(0.0, 0.0);
+      if (qq * 2 * KL + 2 * k < RL) *reinterpret_cast<double2 *>(Frow + r0 * (int64_t)RL + qq * 2 * KL + 2 * k) = make_double2(0.0, 0.0);
   }
   double aprev = actj ? Ab[r0 * J] : 0.0;
   double tprev = tb[r0];
@@ -423,9 +424,10 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
           if (vb) {
 #pragma unroll
             for (int qq = 0; qq < JM / 2; ++qq) {
-              const int e = qq * 2 * KL + 2 * k;
-              *reinterpret_cast<double2 *>(Frow + n * (KL * JM) + e) =
-                  *reinterpret_cast<const double2 *>(&ftile[sl * KL * JM + e]);
+              const int e = qq * 2 * KL + 2 * k;   // (the row is the first nrhs columns of the tile: k-major like the workspace)
+              if (e < RL)
+                *reinterpret_cast<double2 *>(Frow + n * (int64_t)RL + e) =
+                    *reinterpret_cast<const double2 *>(&ftile[sl * KL * JM + e]);
             }
           }
           lds_order();
@@ -692,7 +694,7 @@ extern "C" int c2_internal_sweepK(int lower, int solve, int64_t B, int64_t N, in
   const int JM = J <= 8 ? 8 : (J <= 16 ? 16 : 32);
   if (JM > KL) return C2_ERR_UNSUPPORTED;
   // the F workspace goes through the LDS tile: whole rows only
-  if (F && !(nrhs == KL && J == JM && ((uintptr_t)F) % 16 == 0)) return C2_ERR_UNSUPPORTED;
+  if (F && !(nrhs <= KL && J == JM && ((uintptr_t)F) % 16 == 0)) return C2_ERR_UNSUPPORTED;
   // nrhs = J = 8: by lines on the whole wavefronts of the batch (every pointer 16-byte pieces are moved through must allow
   // that), the row-by-row kernel below on the B % 8 series left over
   if (J == 8 && nrhs == 8 && B >= 8 && N >= 8 &&

@@ -48,6 +48,7 @@
   X(sweep1_lines, "C2_SWEEP1_LINES", 1, 's', "0: the single-rhs sweeps at J = 8 request their two rows per step one by one instead of by aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \
   X(sweepk_lines, "C2_SWEEPK_LINES", 1, 's', "0: the forward sweeps with nrhs = J = 8 on full wavefronts row by row instead of by aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \
   X(s_replay_lines, "C2_S_REPLAY_LINES", 1, 's', "0: the S rows of factor-with-workspace at J = 8 replayed with one request per row for t, d and W instead of transposed tiles and aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \
+  X(sweept, "C2_SWEEPT", 1, 's', "0: forward sweeps with two to five right-hand sides (two or three with the workspace) on the lanes-over-rhs kernel (idle lanes) / the first-round kernel instead of lanes over J with transposed scalar streams", "B = 8192, N = 4096: profiles/r03_nrhs_scan.md") \
   X(sweept_rev, "C2_SWEEPT_REV", 1, 's', "0: reverse sweeps with two to four right-hand sides on the first-round kernel (every per-series scalar fetched per step) instead of transposed scalar streams", "B = 8192, N = 4096, nrhs = 3: profiles/r03_per_op_B8192.md") \
   X(sweep_rev_lines, "C2_SWEEP_REV_LINES", 1, 's', "0: the reverse sweeps with nrhs = J = 8 on full wavefronts row by row instead of by aligned 128-byte lines", "B = 8192, N = 4096: measured in profiles/r03_sweep_rev_lines.md") \
   X(terms_fused, "C2_TERMS_FUSED", 0, 's', "coefficient-level log-likelihood: 1 forces the fused one-lane kernels (J = 8, 4, 2), 0 the composed chain; unset: by batch size", "65536 series: 21.1 ms fused; 8192 series: 9.2 ms composed") \

@@ -1197,6 +1197,9 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
                                   const double *c, int64_t c_bs, const double *U, const double *V, const double *Y,
                                   double *Z, double *F, int zero_z, c2_stream_t stream);
 
+extern "C" int c2_internal_sweepT(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
+                                  int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                  const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream);
 extern "C" int c2_internal_sweepT_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
                                       int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
                                       const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
@@ -1339,6 +1342,10 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
   }
   if (nrhs == 1)  // a vector: the tuned single-rhs kernel (c2_sweep.hip)
     return c2_internal_sweep1(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+  if (nrhs <= 7) {  // two to seven: lanes over J, per-series scalars transposed in time (c2_sweep_small.hip)
+    const int e = c2_internal_sweepT(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
+    if (e != C2_ERR_UNSUPPORTED) return e;
+  }
   if (nrhs >= 3) {  // lanes over the right-hand sides (c2_sweep.hip) when the shape fits
     const int e = c2_internal_sweepK(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
                                      stream);

@@ -1,7 +1,7 @@
 // c2_sweep_small_rev.hip -- reverse passes of solve_lower / solve_upper / matmul_lower / matmul_upper (reference
-// internal.hpp:191-303 forward_rev / backward_rev; reverse.hpp:87-217) for TWO TO SEVEN right-hand sides, lanes over J:
-// the mapping and stream handling of the single-rhs kernel k_sweep1_rev (c2_sweep.hip), the per-rhs quantities as short
-// arrays.  (A file of its own: its instances are a third of the library's compile time.)
+// internal.hpp:191-303 forward_rev / backward_rev; reverse.hpp:87-217) for TWO TO SEVEN right-hand sides, lanes over J: the
+// mapping and stream handling of the single-rhs kernel k_sweep1_rev (c2_sweep.hip), the per-rhs quantities as short
+// arrays.  The forward sweeps: c2_sweep_small.hip.
 #include <cstdint>
 #include <type_traits>
 
@@ -180,6 +180,7 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
 }  // namespace c2
 
 using namespace c2;
+
 
 // two to seven right-hand sides, lanes over J with transposed scalar streams (k_sweepT_rev); C2_ERR_UNSUPPORTED otherwise
 extern "C" int c2_internal_sweepT_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,

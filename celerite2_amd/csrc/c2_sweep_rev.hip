@@ -12,6 +12,8 @@
 // reduce-scatter (c2_rscatter.hpp) that leaves element j of the result in lane j -- where it is stored from, as one dense
 // run per row.  B = U, A = V for the lower sweeps and the other way round for the upper ones; row m = n -/+ 1.
 // The first-round kernel (k_sweep_rev, lanes over J, c2_ops.hip) stays for shapes this mapping does not cover.
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 #include <type_traits>
@@ -23,6 +25,22 @@
 
 namespace c2r {
 using namespace c2;
+
+// Section timing of the multi-rhs reverse step of k_sweepK_rev (diagnostic builds only: tools/build_variant.sh prof
+// c2_sweep_rev.hip -DC2R_PROF; tools/sweepk_rev_sections.py).
+#ifdef C2R_PROF
+__device__ unsigned long long c2r_prof[8];
+#define C2R_TICK(k)                                                    \
+  do {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    const unsigned long long now_ = __builtin_readcyclecounter();      \
+    prof_[k] += now_ - tick_;                                          \
+    tick_ = now_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  } while (0)
+#else
+#define C2R_TICK(k) do {} while (0)
+#endif
 
 template <int KL, int JM, bool LOWER, bool SOLVE>
 __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int J, int64_t nrhs,
@@ -101,6 +119,9 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
   for (int r = 0; r < R; ++r) load_step(r, N - 1 - r);
 
   int q = 0;
+#ifdef C2R_PROF
+  unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tick_ = __builtin_readcyclecounter();
+#endif
   for (int64_t s0 = N - 1; s0 >= 1; s0 -= R) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -112,10 +133,13 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
         for (int j = 0; j < JM; ++j) Fn[j] = vk ? rF[r][j] : 0.0;
         const double bzin_m = vk ? rbz[r] : 0.0, xm = vk ? rx[r] : 0.0, bn = rbn[r], am = ram[r];
         const double dt = LOWER ? rtm[r] - rtn[r] : rtn[r] - rtm[r];  // internal.hpp:227 / 284
+        C2R_TICK(0);
         load_step(r, s - R);
+        C2R_TICK(5);
         const double p = exp_decay(cj * dt);
         rowbuf[q][sl][0][k] = p; rowbuf[q][sl][1][k] = bn; rowbuf[q][sl][2][k] = am;
         lds_order();
+        C2R_TICK(1);
         const double bzn = bzrun;
         double pbB[JM], pbp[JM], pbA[JM], acc = 0.0;
 #pragma unroll
@@ -136,6 +160,7 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
           }
         }
         q ^= 1;
+        C2R_TICK(2);
         // cotangent of row m: solves fold it into the running bZ, products write it out
         if (SOLVE) {
           bzrun = bzin_m + acc;
@@ -144,6 +169,7 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
           bzrun = bzin_m;  // row m is the row of the next step
           if (vb && vk) bYb[m * nrhs] = acc;
         }
+        C2R_TICK(3);
         // the three sums over the right-hand sides
         double phi = 0.0;
 #pragma unroll
@@ -175,9 +201,14 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
         // UPPER: bt[m] -= phi, bt[n] += phi -> row n is complete now (it got -phi of the previous step)
         if (vb && k == 0) btb[n] = LOWER ? carry - phi : phi - carry;
         carry = phi;
+        C2R_TICK(4);
       }
     }
   }
+#ifdef C2R_PROF
+  if (lane == 0 && blockIdx.x % 97 == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&c2r_prof[i], prof_[i]);
+#endif
   // the near end: row of step 0 gets no bB, the far end no bA; bt of the near end is what the last step left
   if (vb) {
     const int64_t n0 = rowof(0);
@@ -428,6 +459,16 @@ __global__ __launch_bounds__(kWave) void k_sweep8_rev_lines(int64_t B, int64_t N
 }  // namespace c2r
 
 using namespace c2r;
+
+#ifdef C2R_PROF
+// cycles per section summed over the sampled wavefronts (every 97th) since the last call; resets the counters
+extern "C" void c2_internal_sweep_rev_prof_read(unsigned long long *out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(c2r::c2r_prof), sizeof(unsigned long long) * 8);
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(c2r::c2r_prof), z, sizeof(z));
+}
+#endif
 
 extern "C" int c2_internal_sweepK_rev(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
                                       int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,

@@ -13,10 +13,11 @@ d, W, flag = ops.factor(t, c, a, U, V)
 Y = torch.randn((B, N, nrhs), dtype=torch.float64, device=dev)
 bZ = torch.randn((B, N, nrhs), dtype=torch.float64, device=dev)
 Z, F = ops.solve_lower(t, c, U, W, Y, workspace=True)
+_lib.set_option("sweep_rev_lines", 0)   # the row-by-row kernel k_sweepK_rev is the instrumented one
 lib = ctypes.CDLL(_lib.LIB_PATH)
 out = (ctypes.c_ulonglong * 8)()
 names = ["ring -> registers (waits for the rows)", "exp, row vectors into LDS, fence", "LDS reads + per-column products", "cotangent of row m (store)",
-         "three reduce-scatters, stores, phi", "requests for step s - R"]
+         "three reduce-scatters, stores, phi", "requests for step s - R (issued right after the ring reads)"]
 for rep in range(2):
     ops.solve_lower_rev(t, c, U, W, Y, Z, F, bZ); lib.c2_internal_sweep_rev_prof_read(out)
 spw = 64 // (8 if nrhs <= 8 else 16)

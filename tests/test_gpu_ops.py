@@ -892,11 +892,13 @@ def test_single_rhs_sweeps(ops, oracle, J, N):
         close(Zs[b], zo)
 
 
-@pytest.mark.parametrize("J,nrhs", [(8, 5), (8, 8), (3, 8), (16, 8), (16, 16), (16, 20), (32, 32), (32, 33), (8, 64), (6, 70), (32, 7), (8, 3)])
+@pytest.mark.parametrize("J,nrhs", [(8, 5), (8, 8), (3, 8), (16, 8), (16, 16), (16, 20), (32, 32), (32, 33), (8, 64), (6, 70), (32, 7), (8, 3),
+                                    (8, 2), (8, 4), (5, 3), (16, 4), (2, 2), (7, 5), (8, 6), (8, 7), (8, 12)])
 def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
-    """nrhs >= 3 takes the kernel with lanes over the right-hand sides (c2_sweep.hip) when J fits the lanes of a
-    series, the generic kernel otherwise ((16, 8), (32, 7)): all four sweeps with the F workspace, in place,
-    accumulating, with ragged rhs tiles (70 = 64 + 6) and a ragged last wavefront."""
+    """Two to five right-hand sides (two or three with the workspace) run lanes over J with transposed scalar streams
+    (c2_sweep_small.hip), more the kernel with lanes over the right-hand sides (c2_sweep.hip) when J fits the lanes of a
+    series, the generic kernel otherwise ((16, 8), (32, 7)): all four sweeps with the F workspace, in place, accumulating,
+    with ragged rhs tiles (70 = 64 + 6) and a ragged last wavefront -- and their reverse passes."""
     B, N = 5, 131
     rng = np.random.default_rng(7 * J + nrhs)
     Je = J if J % 2 == 0 else J + 1
@@ -920,6 +922,16 @@ def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
             Z0 = rng.standard_normal((B, N, nrhs))
             (Z0d,) = dev(Z0)
             close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Z0d), Z0 + Zo)
+        # the reverse pass of the same shape (two to seven right-hand sides: lanes over J with transposed scalar streams,
+        # c2_sweep_small_rev.hip; more: lanes over the right-hand sides), every series against the oracle
+        bZ = rng.standard_normal((B, N, nrhs))
+        (bZd,) = dev(bZ)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+        for b in range(B):
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+            for r_, e_ in zip(res, outs):
+                close(r_[b], e_)
 
 
 @pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (8, 34), (16, 64), (8, 132), (16, 200), (7, 64), (8, 33), (13, 9), (21, 65), (9, 130)])

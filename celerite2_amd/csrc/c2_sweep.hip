@@ -383,11 +383,11 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
   for (int r = 0; r < R; ++r) load_row(r, 1 + r);
 
   int q = 0;
-  for (int64_t s0 = 1; s0 < N; s0 += R) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int64_t s = s0 + r;
-      if (s < N) {
+  // One step; full blocks of R steps run without a condition (behind a row guard or a lane predicate the compiler cannot
+  // count the memory operations in flight and waits for all of them).  Lanes beyond nrhs and the lanes of a series beyond
+  // the batch are clamped copies of the last column / series: they store the same values to the same addresses.
+  auto step = [&](const int r, const int64_t s) __attribute__((always_inline)) {
+      {
         const int64_t n = rowof(s);
         const double tn = rt[r], an = ra[r], bn = rb[r], yn = ry[r], zin = rz[r];
         load_row(r, s + R);
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
         }
         if constexpr (WF) {
           lds_order();
-          if (vb) {
+          {
 #pragma unroll
             for (int qq = 0; qq < JM / 2; ++qq) {
               const int e = qq * 2 * KL + 2 * k;   // (the row is the first nrhs columns of the tile: k-major like the workspace)
@@ -433,13 +433,20 @@ __global__ __launch_bounds__(kWave) void k_sweepK(int64_t B, int64_t N, int J, i
           lds_order();
         }
         const double zn = SOLVE ? yn - red : zin + red;  // internal.hpp:144 / :187
-        if (vk) zb[n * nrhs] = zn;
+        zb[n * nrhs] = zn;
         xprev = SOLVE ? zn : yn;
         aprev = an;
         q ^= 1;
       }
-    }
+  };
+  int64_t s0 = 1;
+  for (; s0 + R <= N; s0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) step(r, s0 + r);
   }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (s0 + r < N) step(r, s0 + r);
 }
 
 

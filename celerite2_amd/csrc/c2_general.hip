@@ -95,7 +95,8 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   constexpr int RS = RS0 + ((8 - RS0 % 32) + 32) % 32;
   __shared__ __attribute__((aligned(16))) double ring[SPW * RS];
   __shared__ __attribute__((aligned(16))) double ftile[WF ? SPW * JM * KL : 2];
-  const bool dense_f = WF && nrhs == KL && J == JM && (((uintptr_t)F) % 16) == 0;   // (uniform)
+  // (uniform) one tile of right-hand sides, full width, an even number of doubles per row
+  const bool dense_f = WF && nrhs <= KL && gridDim.y == 1 && J == JM && ((J * nrhs) % 2) == 0 && (((uintptr_t)F) % 16) == 0;
   double *rg = ring + sl * RS;
   double *rgR = rg + NSLOT + (NSLOT & 1), *rgX = rgR + NSLOT * KL;   // (16-byte aligned rows)
   static_assert(RS0 <= RS && RS % 32 == 8, "ring layout");
@@ -148,15 +149,19 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
       }
     }
     if constexpr (WF) {
-      if (dense_f) {   // nrhs == KL, J == JM: the row (J x nrhs doubles, [j][k]) leaves as 16-byte pieces through an LDS tile
+      if (dense_f) {   // the row (J x nrhs doubles, [j][k]) leaves as 16-byte pieces through an LDS tile
+        const int nr = (int)nrhs;
+        if (k < nr) {
 #pragma unroll
-        for (int j = 0; j < JM; ++j) ftile[sl * JM * KL + j * KL + k] = Fj[j];
+          for (int j = 0; j < JM; ++j) ftile[sl * JM * KL + j * nr + k] = Fj[j];
+        }
         lds_order();
         if (absorb && vb) {
-          double *fr = F + (b * M + rowM(m)) * (int64_t)(JM * KL);
+          double *fr = F + (b * M + rowM(m)) * (int64_t)(JM * nr);
 #pragma unroll
           for (int q = 0; q < JM / 2; ++q)
-            *reinterpret_cast<double2 *>(fr + 2 * (q * KL + k)) = *reinterpret_cast<const double2 *>(&ftile[sl * JM * KL + 2 * (q * KL + k)]);
+            if (2 * (q * KL + k) < JM * nr)
+              *reinterpret_cast<double2 *>(fr + 2 * (q * KL + k)) = *reinterpret_cast<const double2 *>(&ftile[sl * JM * KL + 2 * (q * KL + k)]);
         }
       } else if (absorb && vk) {
         const int64_t mr = rowM(m);

@@ -50,6 +50,7 @@
   X(s_replay_lines, "C2_S_REPLAY_LINES", 1, 's', "0: the S rows of factor-with-workspace at J = 8 replayed with one request per row for t, d and W instead of transposed tiles and aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \
   X(sweept, "C2_SWEEPT", 1, 's', "0: forward sweeps with two to five right-hand sides (two or three with the workspace) on the lanes-over-rhs kernel (idle lanes) / the first-round kernel instead of lanes over J with transposed scalar streams", "B = 8192, N = 4096: profiles/r03_nrhs_scan.md") \
   X(sweept_rev, "C2_SWEEPT_REV", 1, 's', "0: reverse sweeps with two to four right-hand sides on the first-round kernel (every per-series scalar fetched per step) instead of transposed scalar streams", "B = 8192, N = 4096, nrhs = 3: profiles/r03_per_op_B8192.md") \
+  X(sweep1_rev_lines, "C2_SWEEP1_REV_LINES", 1, 's', "0: the single-rhs reverse sweeps at J = 8 request and store their five rows per step one by one instead of by aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \
   X(sweep_rev_lines, "C2_SWEEP_REV_LINES", 1, 's', "0: the reverse sweeps with nrhs = J = 8 on full wavefronts row by row instead of by aligned 128-byte lines", "B = 8192, N = 4096: measured in profiles/r03_sweep_rev_lines.md") \
   X(terms_fused, "C2_TERMS_FUSED", 0, 's', "coefficient-level log-likelihood: 1 forces the fused one-lane kernels (J = 8, 4, 2), 0 the composed chain; unset: by batch size", "65536 series: 21.1 ms fused; 8192 series: 9.2 ms composed") \
   X(terms_fused_min_batch_fwd, "C2_TERMS_FUSED_MIN_BATCH_FWD", 16384, 't', "coefficient-level forward: fused kernels from this many series up", "tools/terms_time.py") \

@@ -180,7 +180,13 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
 // handles n = row(u) (its U/V row, its workspace row F_n, outputs bt_n and the row gradient bB_n) and m = row(u+1)
 // (its V/U row, x_m, bZ_m; outputs bY_m and the row gradient bA_m).  Same stream handling as k_sweep1.
 // -----------------------------------------------------------------------------------------------------------------
-template <int G, int R, bool LOWER, bool SOLVE, bool PAD>
+// LN >= 0 (G = J = 8, 16-byte aligned row arrays): the five width-8 rows of a step -- B_n, F_n, A_m in; bB_n, bA_m out -- move
+// as halves of the aligned 128-byte lines (rows 2 l, 2 l + 1) they share: one 16-byte piece per lane, one request per line and
+// array every two steps, the inputs four lines ahead through four-row LDS tiles, the outputs through two-row tiles (without
+// its two row stores the sweep runs 39 % faster: it is the number of memory instructions in flight that bounds it,
+// profiles/r03_sweep_rev_lines.md).  LN = parity of the position r inside a block of eight at which the sweep enters a
+// new line with its row n: 0 for the upper sweeps, N mod 2 for the lower ones; row m enters its lines at the other parity.
+template <int G, int R, bool LOWER, bool SOLVE, bool PAD, int LN = -1>
 __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                       int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                       const double *__restrict__ U, const double *__restrict__ V,
@@ -190,11 +196,15 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
                                                       double *__restrict__ bU, double *__restrict__ bV,
                                                       double *__restrict__ bY) {
   constexpr int SPW = kWave / G, NV = (R + G - 1) / G;
+  constexpr bool LINES = LN >= 0;
+  static_assert(!LINES || (G == 8 && !PAD && R == 8), "lines: eight lanes per series, blocks of eight steps");
   __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];  // t, x, bZ at positions u+1 of two blocks
   __shared__ __attribute__((aligned(16))) double sout[2][SPW][R];     // bt (position u), bY (position u+1)
+  __shared__ __attribute__((aligned(16))) double tin[LINES ? 3 : 1][LINES ? 4 : 1][kWave];   // [B / F / A][row & 3][lane]
+  __shared__ __attribute__((aligned(16))) double tout[LINES ? 2 : 1][LINES ? 2 : 1][kWave];  // [bB / bA][row & 1][lane]
   const int J = PAD ? Jrt : G;
   const Geo<G> L(B, J);
-  const int j = L.j, grp = L.lane / G;
+  const int j = L.j, grp = L.lane / G, lane = L.lane;
   const bool act = PAD ? L.act : true;
   const bool st = PAD ? (L.valid && act) : true;
   const int64_t on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
@@ -212,9 +222,56 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   const int64_t r0 = rowof(0);
   double bz = bzb[r0];
   byb[r0] = SOLVE ? bz : 0.0;      // reverse.hpp:112 (bY = bZ) / :178 (bY = 0)
-  if (st) bAb[r0 * J] = 0.0;       // never receives a contribution
+  if constexpr (!LINES) { if (st) bAb[r0 * J] = 0.0; }       // never receives a contribution
   double tprev = tb[r0];
   double bF = 0.0, bcj = 0.0, carry = 0.0;
+
+  // ---- LINES: rings of four lines per input array in the order the sweep enters them, output tiles -------------------
+  constexpr int dirl = LOWER ? -1 : 1;
+  constexpr int PN = LINES ? LN : 0, PM = 1 - PN;          // parity of r at which row n / row m enters a line
+  constexpr int preN = PN == 1 ? 1 : 0, preM = PM == 1 ? 1 : 0;   // lines the prologue stages (r = 0 is then a second row)
+  const int hrow = j >> 2, hcol = 2 * (j & 3);
+  const int64_t lmax = (N - 1) >> 1;
+  const int64_t sbase = (L.b0 + L.sl) * N * J + hcol;
+  const double *Bl = (LOWER ? U : V) + sbase, *Fl = F + sbase, *Al = (LOWER ? V : U) + sbase;
+  double *bBl = (LOWER ? bU : bV) + sbase, *bAl = (LOWER ? bV : bU) + sbase;
+  const int64_t l0n = r0 >> 1, l0m = rowof(N > 1 ? 1 : 0) >> 1;
+  auto line_load = [&](const double *base, int64_t l) -> double2 {
+    l = l < 0 ? 0 : (l > lmax ? lmax : l);
+    int64_t row = 2 * l + hrow;
+    row = row < N ? row : N - 1;
+    return *reinterpret_cast<const double2 *>(base + row * J);
+  };
+  auto line_stage = [&](int which, int64_t l, double2 v) {
+    *reinterpret_cast<double2 *>(&tin[which][2 * (int)(l & 1) + hrow][grp * G + hcol]) = v;
+  };
+  auto line_flush = [&](int which, double *base, int64_t l, auto guard_tag) {   // a finished line of bB / bA
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    const int64_t row = 2 * l + hrow;
+    const double2 v = *reinterpret_cast<const double2 *>(&tout[which][hrow][grp * G + hcol]);
+    if (!GUARD || (row >= 0 && row < N)) *reinterpret_cast<double2 *>(base + row * J) = v;
+  };
+  double2 lb[LINES ? R / 2 : 1], lf[LINES ? R / 2 : 1], la[LINES ? R / 2 : 1];
+  int64_t kn = 0, km = 0;   // lines entered so far by row n / row m
+  if constexpr (LINES) {
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+      lb[q] = line_load(Bl, l0n + dirl * q); lf[q] = line_load(Fl, l0n + dirl * q); la[q] = line_load(Al, l0m + dirl * q);
+    }
+    if constexpr (preN == 1) {
+      line_stage(0, l0n, lb[0]); line_stage(1, l0n, lf[0]);
+      lb[0] = line_load(Bl, l0n + dirl * (R / 2)); lf[0] = line_load(Fl, l0n + dirl * (R / 2));
+      kn = 1;
+    }
+    if constexpr (preM == 1) {
+      line_stage(2, l0m, la[0]);
+      la[0] = line_load(Al, l0m + dirl * (R / 2));
+      km = 1;
+    }
+    tout[1][r0 & 1][lane] = 0.0;   // bA of the first row: never receives a contribution
+    lds_order();
+    if constexpr (PN == 1) line_flush(1, bAl, r0 >> 1, std::true_type{});   // ... and no step completes its line
+  }
 
   double vt[NV], vx[NV], vbz[NV];
   auto vload = [&](int64_t qb) {
@@ -239,7 +296,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   vload(1 + R); vstage(1);
   vload(1 + 2 * R);
 
-  double rb[R], rf[R], ra[R];
+  double rb[LINES ? 1 : R], rf[LINES ? 1 : R], ra[LINES ? 1 : R];
   auto load_row = [&](int r, int64_t u) {  // B and F rows of position u, A row of position u+1
     const int64_t qn = (u < N) ? u : N - 1, qm = (u + 1 < N) ? u + 1 : N - 1;
     const int64_t n = rowof(qn), m = rowof(qm);
@@ -247,8 +304,10 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
     rf[r] = act ? Fb[n * J] : 0.0;
     ra[r] = act ? Ab[m * J] : 0.0;
   };
+  if constexpr (!LINES) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, r);
+    for (int r = 0; r < R; ++r) load_row(r, r);
+  }
   lds_order();
 
   auto block = [&](int64_t u0, int s, auto checked_tag) {
@@ -259,8 +318,27 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
       if (!CHECKED || u + 1 < N) {
         const int64_t n = rowof(u), m = rowof(u + 1);
         const double tm = sin_[s][0][grp][r], xm = sin_[s][1][grp][r], bzm = sin_[s][2][grp][r];
-        const double bn = rb[r], Fn = rf[r], am = ra[r];
-        load_row(r, u + R);
+        double bn, Fn, am;
+        if constexpr (LINES) {
+          if ((r & 1) == PN) {   // (r: unrolled) row n enters a line of B and F: slot (lines entered so far) mod 4
+            const int sl_ = (preN + (r - PN) / 2) % (R / 2);
+            const int64_t l = l0n + dirl * kn;
+            line_stage(0, l, lb[sl_]); line_stage(1, l, lf[sl_]);
+            lb[sl_] = line_load(Bl, l + dirl * (R / 2)); lf[sl_] = line_load(Fl, l + dirl * (R / 2));
+            ++kn;
+          } else {               // row m enters a line of A
+            const int sl_ = (preM + (r - PM) / 2) % (R / 2);
+            const int64_t l = l0m + dirl * km;
+            line_stage(2, l, la[sl_]);
+            la[sl_] = line_load(Al, l + dirl * (R / 2));
+            ++km;
+          }
+          lds_order();
+          bn = tin[0][n & 3][lane]; Fn = tin[1][n & 3][lane]; am = tin[2][m & 3][lane];
+        } else {
+          bn = rb[r]; Fn = rf[r]; am = ra[r];
+          load_row(r, u + R);
+        }
         const double dt = tm - tprev;  // lower: t[m] - t[n]; upper: t[n] - t[m] with the roles of prev/next swapped
         const double dte = LOWER ? dt : -dt;
         tprev = tm;
@@ -269,7 +347,8 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
         const double val = bz * (p * Fn);
         bF = fma(sgn * bn, bz, bF);
         const double dotFbF = Fn * bF;
-        if (st) bBb[n * J] = sgn * val;
+        if constexpr (LINES) tout[0][n & 1][lane] = sgn * val;
+        else if (st) bBb[n * J] = sgn * val;
         // reverse of the decay (internal.hpp:236-241 / 293-298)
         const double bp = dotFbF * p;
         bcj = fma(dte, bp, bcj);
@@ -283,7 +362,15 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
         const double out = SOLVE ? bzm + g : g;
         sout[1][grp][r] = out;
         bz = SOLVE ? out : bzm;
-        if (st) bAb[m * J] = bam;
+        if constexpr (LINES) {
+          tout[1][m & 1][lane] = bam;
+          lds_order();
+          // the line this step completes: bA's where row m is the second row of its line, bB's where row n is
+          if ((r & 1) == PN) line_flush(1, bAl, m >> 1, checked_tag);
+          else line_flush(0, bBl, n >> 1, checked_tag);
+        } else if (st) {
+          bAb[m * J] = bam;
+        }
       }
     }
     lds_order();
@@ -301,12 +388,21 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   };
   int64_t u0 = 0;
   int s = 0;
+  if constexpr (LINES) {   // (the first block may complete a line whose other row lies beyond the end of the series: guarded)
+    if (u0 + 1 < N) { block(u0, s, std::true_type{}); u0 += R; s ^= 1; }
+  }
   for (; u0 + 2 * R + 1 <= N; u0 += R, s ^= 1) block(u0, s, std::false_type{});
   for (; u0 + 1 < N; u0 += R, s ^= 1) block(u0, s, std::true_type{});
 
   const int64_t rl = rowof(N - 1);
   btb[rl] = LOWER ? carry : -carry;
-  if (st) {
+  if constexpr (LINES) {   // bB of the last row is zero; the lines no step completed leave now
+    tout[0][rl & 1][lane] = 0.0;
+    lds_order();
+    line_flush(0, bBl, rl >> 1, std::true_type{});
+    line_flush(1, bAl, rl >> 1, std::true_type{});
+    bc[L.b * J + j] = bcj;
+  } else if (st) {
     bBb[rl * J] = 0.0;  // bU.row(0) / bV.row(N-1) never touched
     bc[L.b * J + j] = bcj;
   }
@@ -662,6 +758,21 @@ extern "C" int c2_internal_sweep1_rev(int lower, int solve, int64_t B, int64_t N
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+  if (J == 8 && N >= 3 && (((uintptr_t)U | (uintptr_t)V | (uintptr_t)F | (uintptr_t)bU | (uintptr_t)bV) % 16) == 0 &&
+      !(opt::has(opt::k_sweep1_rev_lines) && opt::ival(opt::k_sweep1_rev_lines) == 0)) {
+    // rows by lines; the lower sweeps walk down from row N - 1: which rows open a line depends on the parity of N
+#define C2_SWL(LO, SO, LN_)                                                                                          \
+  hipLaunchKernelGGL((k_sweep1_rev<8, 8, LO, SO, false, LN_>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
+                     V, Y, Z, F, bZ, bt, bc, bU, bV, bY)
+    if (lower) {
+      if (N & 1) { if (solve) C2_SWL(true, true, 1); else C2_SWL(true, false, 1); }
+      else { if (solve) C2_SWL(true, true, 0); else C2_SWL(true, false, 0); }
+    } else {
+      if (solve) C2_SWL(false, true, 0); else C2_SWL(false, false, 0);
+    }
+#undef C2_SWL
+    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+  }
 #define C2_SWR(G, LO, SO)                                                                                             \
   do {                                                                                                                \
     if (J == G)                                                                                                       \

@@ -146,6 +146,27 @@ __global__ __launch_bounds__(kWave) void k_sweepT(int64_t B, int64_t N, int Jrt,
 
 using namespace c2;
 
+namespace {
+// (templates on G: inside them `if constexpr` really discards the instances a width does not get)
+template <int G, int KT, bool LO, bool SO>
+void launch_kt(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z, hipStream_t s) {
+  const dim3 grid((unsigned)((B * G + kWave - 1) / kWave));
+  if (J == G)
+    hipLaunchKernelGGL((k_sweepT<G, 8, KT, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z);
+  else
+    hipLaunchKernelGGL((k_sweepT<G, 8, KT, LO, SO, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z);
+}
+template <int G, bool LO, bool SO>
+void launch_g(int kt, int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z, hipStream_t s) {
+#define C2_KA B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, s
+  if (kt == 2) launch_kt<G, 2, LO, SO>(C2_KA);
+  else if (kt == 3) launch_kt<G, 3, LO, SO>(C2_KA);
+  else if (kt == 4) launch_kt<G, 4, LO, SO>(C2_KA);
+  else if constexpr (G == 8) launch_kt<G, 5, LO, SO>(C2_KA);   // five: compiled for widths 5 .. 8 only
+#undef C2_KA
+}
+}  // namespace
+
 // two to five right-hand sides (two or three with the workspace), lanes over J with transposed scalar streams (k_sweepT);
 // C2_ERR_UNSUPPORTED otherwise
 extern "C" int c2_internal_sweepT(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
@@ -158,40 +179,23 @@ extern "C" int c2_internal_sweepT(int lower, int solve, int64_t B, int64_t N, in
   if (nrhs > 4 && group_size(J) != 8) return C2_ERR_UNSUPPORTED;
   if (opt::has(opt::k_sweept) && opt::ival(opt::k_sweept) == 0) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const int G_ = group_size(J);
-  const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
-#define C2_SF3(G, KT, LO, SO)                                                                                          \
-  do {                                                                                                                 \
-    if (J == G)                                                                                                        \
-      hipLaunchKernelGGL((k_sweepT<G, 8, KT, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, V, \
-                         Y, Z, F, zero_z);                                                                             \
-    else                                                                                                               \
-      hipLaunchKernelGGL((k_sweepT<G, 8, KT, LO, SO, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, V,  \
-                         Y, Z, F, zero_z);                                                                             \
+  const int kt = (int)nrhs;
+#define C2_ARGS kt, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, s
+#define C2_ST1(G)                                                                                        \
+  do {                                                                                                   \
+    if (lower) { if (solve) launch_g<G, true, true>(C2_ARGS); else launch_g<G, true, false>(C2_ARGS); }  \
+    else { if (solve) launch_g<G, false, true>(C2_ARGS); else launch_g<G, false, false>(C2_ARGS); }      \
   } while (0)
-#define C2_SF2(G, LO, SO)                                                        \
-  do {                                                                           \
-    if (nrhs == 2) C2_SF3(G, 2, LO, SO);                                         \
-    else if (nrhs == 3) C2_SF3(G, 3, LO, SO);                                    \
-    else if (nrhs == 4) C2_SF3(G, 4, LO, SO);                                    \
-    else if constexpr (G == 8) C2_SF3(G, 5, LO, SO);   /* five: compiled for widths 5 .. 8 only */ \
-  } while (0)
-#define C2_SF1(G)                                                                \
-  do {                                                                           \
-    if (lower) { if (solve) C2_SF2(G, true, true); else C2_SF2(G, true, false); } \
-    else { if (solve) C2_SF2(G, false, true); else C2_SF2(G, false, false); }     \
-  } while (0)
-  switch (G_) {
-    case 1: C2_SF1(1); break;
-    case 2: C2_SF1(2); break;
-    case 4: C2_SF1(4); break;
-    case 8: C2_SF1(8); break;
-    case 16: C2_SF1(16); break;
-    default: C2_SF1(32); break;
+  switch (group_size(J)) {
+    case 1: C2_ST1(1); break;
+    case 2: C2_ST1(2); break;
+    case 4: C2_ST1(4); break;
+    case 8: C2_ST1(8); break;
+    case 16: C2_ST1(16); break;
+    default: C2_ST1(32); break;
   }
-#undef C2_SF1
-#undef C2_SF2
-#undef C2_SF3
+#undef C2_ST1
+#undef C2_ARGS
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

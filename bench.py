@@ -141,7 +141,9 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
     # (~12 per complex term).  Counted, not measured: the kernels issue MORE (packed-triangle bookkeeping, accvgpr moves).
     Jc = J // 2
     flops_per_gp = N * (1900.0 * (J / 8.0) ** 2 + Jc * (2 * 40.0 + 12.0))
-    PEAK_F64_VECTOR = 78.6  # TFLOP/s, MI355X fp64 vector (MI355X_MICROARCH.md)
+    # TFLOP/s, MI355X fp64 vector: the vendor's published figure as SURVEY.md section 8d quotes it (256 CUs x 4 SIMDs x 16
+    # lanes x 2 flops x 2.4 GHz); /opt/skills/guides/MI355X_MICROARCH.md carries no fp64 number of its own
+    PEAK_F64_VECTOR = 78.6
     return {"entry": "c2_loglik_terms_grad", "value": Bp / ms * 1e3, "unit": "GP/s", "ms_per_step": ms, "steps": steps,
             "failed_factorizations": int((flag != 0).sum()),
             "ll_max_rel_diff_vs_matrix_level": float(((ll - ll_matrix).abs() / ll_matrix.abs()).max()),
@@ -205,6 +207,7 @@ def long_series(J, dev, N=100_000, steps=3):
             torch.cuda.synchronize()
             out[name] = e0.elapsed_time(e1) / steps
             out["ll_" + name] = float(ll[0])
+            out["g_" + name] = [x.clone() for x in g]
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -238,9 +241,19 @@ def long_series(J, dev, N=100_000, steps=3):
         ops_ms["factor_rev"] = timed(lambda: ops.factor_rev(t, c, a, U, V, d, W, S, bd, bW))
     except Exception as e:  # noqa: BLE001 -- informational only
         ops_ms["error"] = repr(e)[:200]
+    # the gradients of the two evaluation orders against each other, per gradient array: relative to the array's largest
+    # entry (the max-norm the time-parallel form is held to) AND element by element
+    gdiff = {}
+    for nm, gt, gr in zip(("bt", "bc", "ba", "bU", "bV", "by"), out["g_ms"], out["g_row_by_row_ms"]):
+        diff = (gt - gr).abs()
+        gdiff[nm] = {"max_norm": float(diff.max() / gr.abs().max()),
+                     "element_relative": float((diff / gr.abs().clamp_min(1e-300)).max())}
     return {"entry": "c2_loglik_grad", "workload": "1 series, N=%d, J=%d, forward + reverse-mode grad" % (N, J),
             "ms": out["ms"], "row_by_row_ms": out["row_by_row_ms"], "drop_in_ops_ms": ops_ms,
             "ll_rel_diff": abs(out["ll_ms"] - out["ll_row_by_row_ms"]) / abs(out["ll_row_by_row_ms"]),
+            "grad_max_rel_diff_vs_row_by_row": {"max_norm": max(v["max_norm"] for v in gdiff.values()),
+                                                "element_relative": max(v["element_relative"] for v in gdiff.values()),
+                                                "per_array": gdiff},
             "note": "informational: latency-bound regime, gradient parallel along time (c2_timepar_grad.hip)"}
 
 

@@ -40,13 +40,18 @@ class BackendError(RuntimeError):
 
 def _sync_env(lib):
     """The C library reads its dispatch options from the environment ONCE, when it is loaded, and never calls getenv
-    afterwards (c2_dispatch.hpp).  This ctypes layer additionally re-reads them when it SEES the process environment
-    change between two calls -- what the test-suite and the A/B tools rely on when they edit os.environ at run time;
-    applications use set_option()."""
+    afterwards (c2_dispatch.hpp).  This ctypes layer additionally follows the process environment when it SEES one of the
+    table's variables change between two calls -- what the test-suite and the A/B tools rely on when they edit os.environ
+    at run time -- and applies exactly the variables that changed (c2_set_option each), so values an application set
+    through set_option() for OTHER options survive an unrelated monkeypatch.setenv.  Applications use set_option()."""
     global _env_seen
     now = tuple(os.environ.get(n) for n in _env_names)
     if now != _env_seen:
-        lib.c2_options_reload_env()
+        for name, old, new in zip(_env_names, _env_seen or (None,) * len(_env_names), now):
+            if old != new:
+                # unset or unparsable -> back to the table's default, as at load time
+                if lib.c2_set_option(name.encode(), None if not new else new.encode()) != C2_OK:
+                    lib.c2_set_option(name.encode(), None)
         _env_seen = now
 
 

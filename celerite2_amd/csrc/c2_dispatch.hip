@@ -26,13 +26,27 @@ const Entry kTable[kCount] = {
 std::atomic<double> g_val[kCount];
 std::atomic<bool> g_set[kCount];
 
+// A value counts only if strtod consumes all of it (trailing blanks allowed): "C2_MFMA=on" or a threshold of "abc" leaves
+// the option UNSET -- the same rule c2_set_option applies -- instead of silently becoming 0.
+bool parse(const char *e, double *v) {
+  if (!e || !*e) return false;
+  char *end = nullptr;
+  const double x = strtod(e, &end);
+  if (end == e) return false;
+  while (*end == ' ' || *end == '\t' || *end == '\n') ++end;
+  if (*end) return false;
+  *v = x;
+  return true;
+}
 void load_env() {
   for (int i = 0; i < kCount; ++i) {
+    double v;
     const char *e = getenv(kTable[i].env);
-    if (e && *e) {
-      g_val[i].store(atof(e));
+    if (parse(e, &v)) {
+      g_val[i].store(v);
       g_set[i].store(true);
     } else {
+      if (e && *e) fprintf(stderr, "celerite2_amd: ignoring unparsable %s=%s\n", kTable[i].env, e);
       g_val[i].store(kTable[i].def);
       g_set[i].store(false);
     }
@@ -63,9 +77,8 @@ int c2_set_option(const char *name, const char *value) {
   const int i = find(name);
   if (i < 0) return C2_ERR_INVALID;
   if (value && *value) {
-    char *end = nullptr;
-    const double v = strtod(value, &end);
-    if (end == value) return C2_ERR_INVALID;
+    double v;
+    if (!parse(value, &v)) return C2_ERR_INVALID;
     g_val[i].store(v);
     g_set[i].store(true);
   } else {   // back to the table's default / the automatic choice

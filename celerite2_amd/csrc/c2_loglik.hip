@@ -27,6 +27,7 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+extern "C" void c2_internal_set_error(const char *msg);
 extern "C" int c2_loglik_grad_composite(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs,
                                         const double *c, int64_t c_bs, const double *a, const double *U,
                                         const double *V, const double *y, double *ll, double *bt, double *bc,
@@ -1033,6 +1034,12 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   if (!t || !c || !a || !U || !V || !y || !ll || !flag) return C2_ERR_INVALID;
   if (J > C2_FAST_WIDTH) {   // a wide model: factor + solve_lower + reduction on the workgroup-per-series kernels
     hipStream_t ws = (hipStream_t)stream;
+    hipStreamCaptureStatus wcap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ws, &wcap);
+    if (wcap != hipStreamCaptureStatusNone) {   // its temporary is a stream-ordered allocation: not inside a graph capture
+      c2_internal_set_error("c2_loglik at J > 32 allocates a temporary and cannot be captured in a HIP graph; c2_loglik_grad takes a caller workspace");
+      return C2_ERR_UNSUPPORTED;
+    }
     void *tmp = nullptr;
     if (hipMallocAsync(&tmp, c2_wide_loglik_doubles(B, N, J) * sizeof(double), ws) != hipSuccess) return C2_ERR_HIP;
     int rc = c2_wide_loglik(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp, stream);

@@ -1085,9 +1085,9 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
       double sn, cs;
       const double ph = c2_ * x[b * x_bs + n];
       sincos_cw_fast(ph, sn, cs);
-      // (the range test above looks at the ENDS of the grid: x sorted, as every recursion of this library requires.  An
-      // unsorted x whose interior leaves the range of the branch-free reduction gets NaN here -- a defined signal of the
-      // violated precondition -- rather than a wrong quadrant)
+      // (the range test above looks at the ENDS of the grid.  A row whose phase leaves the range of the branch-free
+      // reduction although the ends do not -- an UNSORTED x, which driver.cpp:460-474 accepts -- is marked here and
+      // rewritten by k_matrices_big, launched right behind this kernel, with the library's sincos)
       if (!(fabs(ph) < kSincosFastMax)) sn = cs = __builtin_nan("");
       const double u0 = c0 * cs + c1 * sn, u1 = c0 * sn - c1 * cs;
       if ((Jr & 1) == 0) {  // J even and ind even: the pair is 16-byte aligned
@@ -1101,26 +1101,31 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
   }
 }
 
-// The complex terms k_matrices left out: phases beyond the range of the branch-free sincos (raw Julian dates times a
-// fast frequency).  One thread per (series, complex term); it returns at once in the common case, so the library's
-// large-argument reduction (and its 160 registers) stays out of the kernel that does the work.
-__global__ void k_matrices_big(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ac,
-                               const double *__restrict__ bc, const double *__restrict__ dc, int coef_batched,
-                               const double *__restrict__ x, int64_t x_bs, double *__restrict__ U,
-                               double *__restrict__ V, const unsigned long long *__restrict__ gate) {
+// What k_matrices left out: phases beyond the range of the branch-free sincos (raw Julian dates times a fast frequency) --
+// whole terms (decided from the ends of the grid, the columns k_matrices skipped) and single rows of an unsorted grid
+// (the reference has no sortedness precondition here, driver.cpp:460-474).  One thread per ROW; it reads x and returns
+// in the common case, so the library's large-argument reduction (and its 160 registers) stays out of the kernel that
+// does the work: 0.27 GB of reads on top of its 2.4 GB at 8192 x 4096 x 8.
+__global__ __launch_bounds__(256) void k_matrices_big(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ac,
+                                                      const double *__restrict__ bc, const double *__restrict__ dc,
+                                                      int coef_batched, const double *__restrict__ x, int64_t x_bs,
+                                                      double *__restrict__ U, double *__restrict__ V,
+                                                      const unsigned long long *__restrict__ gate) {
   if (gate_closed(gate)) return;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * Jc) return;
-  const int64_t b = g / Jc;
-  const int i = (int)(g - b * Jc), J = Jr + 2 * Jc, ind = Jr + 2 * i;
+  if (g >= B * N) return;
+  const int64_t b = g / N, n = g - b * N;
+  const int J = Jr + 2 * Jc;
   const int64_t o = coef_batched ? b * Jc : 0;
-  const double a_ = ac[o + i], b_ = bc[o + i], d_ = dc[o + i];
   const double *xb = x + b * x_bs;
-  if (!matrices_big_phase(d_, xb, N)) return;
-  for (int64_t n = 0; n < N; ++n) {
+  const double xn = xb[n], xm = fmax(fabs(xb[0]), fabs(xb[N - 1]));
+  for (int i = 0; i < Jc; ++i) {
+    const double d_ = dc[o + i], ph = d_ * xn;
+    if ((fabs(ph) < kSincosFastMax) && (fabs(d_) * xm < kSincosFastMax)) continue;   // k_matrices wrote this pair
     double sn, cs;
-    sincos(d_ * xb[n], &sn, &cs);
-    double *Un = U + (b * N + n) * J + ind, *Vn = V + (b * N + n) * J + ind;
+    sincos(ph, &sn, &cs);
+    const double a_ = ac[o + i], b_ = bc[o + i];
+    double *Un = U + g * J + Jr + 2 * i, *Vn = V + g * J + Jr + 2 * i;
     Vn[0] = cs; Vn[1] = sn;
     Un[0] = a_ * cs + b_ * sn; Un[1] = a_ * sn - b_ * cs;
   }
@@ -1683,7 +1688,7 @@ int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
                      (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V, gate);
   if (int e = check_launch()) return e;
   if (Jc > 0)
-    hipLaunchKernelGGL(k_matrices_big, dim3((unsigned)((B * Jc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
+    hipLaunchKernelGGL(k_matrices_big, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
                        (int)Jr, (int)Jc, ac, bc, dc, coef_batched, x, x_bs, U, V, gate);
   return check_launch();
 }

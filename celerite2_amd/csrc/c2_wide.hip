@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kThreads) void k_sweep(int64_t N, int J, int64_t nr
   if (tid < kc) {
     prev = Yb[first * nrhs + tid];
     if (SOLVE) { zprev = prev; Zb[first * nrhs + tid] = prev; }   // Z = Y first (forward.hpp:168, 205)
+    else if (zero_z) Zb[first * nrhs + tid] = 0.0;                // the *_fwd variants: Z.setZero() (backprop.cpp matmul_*_fwd)
   }
   __syncthreads();
   for (int64_t s = 1; s < N; ++s) {

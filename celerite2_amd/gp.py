@@ -3,8 +3,9 @@
 
 Reproduces, for a batch of B independent series, what the reference's numpy backend does around the ops
 (python/celerite2/numpy.py:66-121 and core.py:262-501): compute -> factor; log_likelihood -> solve_lower +
-reductions; apply_inverse -> solve_lower, /d, solve_upper; dot_tril; sample; conditional mean at new
-coordinates via general_matmul_lower/upper (core.py:74-132, numpy.py:15-22).  Everything stays on the GPU.
+reductions; apply_inverse -> solve_lower, /d, solve_upper; dot_tril; sample; the conditional distribution
+(core.py:9-150, numpy.py:14-32): mean at new coordinates via general_matmul_lower/upper, variance and covariance
+via apply_inverse on the N x M cross-covariance (solves with M right-hand sides).  Everything stays on the GPU.
 `log_likelihood_and_grad` exposes the fused kernels' gradients w.r.t. (t, c, a, U, V, y).
 """
 import math
@@ -13,7 +14,7 @@ import torch
 
 from . import ops
 
-__all__ = ["GaussianProcess", "LinAlgError"]
+__all__ = ["GaussianProcess", "ConditionalDistribution", "LinAlgError"]
 
 
 class LinAlgError(Exception):
@@ -119,19 +120,115 @@ class GaussianProcess:
             out = out + self.mean
         return out[:, 0] if size is None else out
 
-    # -- conditional mean, core.py:115-132 + numpy.py:15-22 ----------------------------------------------
-    def predict(self, y, t=None, *, include_mean=True):
+    # -- conditional distribution, core.py:430-478 ------------------------------------------------------
+    def condition(self, y, t=None, *, include_mean=True, kernel=None):
         self._need()
         self._check_vector(y)
-        alpha = self.apply_inverse(y - self.mean)
+        return ConditionalDistribution(self, y, t=t, include_mean=include_mean, kernel=kernel)
+
+    def predict(self, y, t=None, *, return_cov=False, return_var=False, include_mean=True, kernel=None):
+        """core.py:430-472: the conditional mean (B, M), and with `return_var` its variance (B, M), with `return_cov`
+        its covariance (B, M, M) -- `apply_inverse` on the N x M cross-covariance, i.e. solves with M right-hand sides
+        (SURVEY.md 8f-4)."""
+        cond = self.condition(y, t=t, include_mean=include_mean, kernel=kernel)
+        if return_var:
+            return cond.mean, cond.variance
+        if return_cov:
+            return cond.mean, cond.covariance
+        return cond.mean
+
+
+class ConditionalDistribution:
+    """Batched mirror of core.py:9-150 (BaseConditionalDistribution) + numpy.py:14-32: the distribution of the process at
+    coordinates `t` (B, M) | (M,) -- default: the observed grid -- given observations `y` (B, N).  Properties are evaluated
+    on demand and cached like the reference's (`KxsT`, `Kinv_KxsT`)."""
+
+    def __init__(self, gp, y, t=None, *, include_mean=True, kernel=None):
+        self.gp, self.y, self.t, self.include_mean, self.kernel = gp, y, t, include_mean, kernel
+        self._KxsT = self._Kinv_KxsT = None
+        self._mats2 = self._mats1 = None
         if t is None:
-            mu = y - self._diag * alpha
-            return mu if include_mean else mu - self.mean
-        ts = t.contiguous()
-        zero = torch.zeros((self._diag.shape[0], ts.shape[-1]), dtype=torch.float64, device=ts.device)
-        _, _, U2, V2 = self.kernel.get_celerite_matrices(ts, zero)
-        inp = alpha[..., None].contiguous()
-        mu = ops.general_matmul_lower(ts, self._t, self._c, U2, self._V, inp)
-        mu = ops.general_matmul_upper(ts, self._t, self._c, V2, self._U, inp, Z=mu)
-        mu = mu[..., 0]
-        return mu + self.mean if include_mean else mu
+            self._xs = gp._t
+        else:
+            if t.dim() not in (1, 2) or (t.dim() == 2 and t.shape[0] != gp._diag.shape[0]):
+                raise ValueError("'t' must be (M,) or (B, M)")   # core.py:39-40
+            self._xs = t.contiguous()
+
+    def _kernel(self):
+        return self.gp.kernel if self.kernel is None else self.kernel
+
+    def _batched(self, x):
+        B = self.gp._diag.shape[0]
+        return x if x.dim() == 2 else x[None].expand(B, x.shape[0])
+
+    @property
+    def KxsT(self):      # core.py:46-54: k(t_n - xs_m), (B, N, M)
+        if self._KxsT is None:
+            tau = self._batched(self.gp._t)[:, :, None] - self._batched(self._xs)[:, None, :]
+            self._KxsT = self._kernel().get_value_device(tau).contiguous()
+        return self._KxsT
+
+    @property
+    def Kinv_KxsT(self):  # core.py:56-60: apply_inverse on the N x M matrix -- solves with M right-hand sides
+        if self._Kinv_KxsT is None:
+            self._Kinv_KxsT = self.gp.apply_inverse(self.KxsT)
+        return self._Kinv_KxsT
+
+    def _do_dot(self, inp, target):
+        """core.py:68-113 + numpy.py:15-22: target += K(xs, t) inp through general_matmul_lower/upper."""
+        gp = self.gp
+        if self.kernel is None:
+            U1, V1 = gp._U, gp._V
+        else:
+            if self._mats1 is None:
+                self._mats1 = self.kernel.get_celerite_matrices(gp._t, torch.zeros_like(gp._diag))
+            U1, V1 = self._mats1[2], self._mats1[3]
+        if self._mats2 is None:
+            B = gp._diag.shape[0]
+            zero = torch.zeros((B, self._xs.shape[-1]), dtype=torch.float64, device=gp._diag.device)
+            self._mats2 = self._kernel().get_celerite_matrices(self._xs, zero)
+        c, _, U2, V2 = self._mats2
+        vec = inp.dim() == 2
+        if vec:
+            inp, target = inp[..., None], target[..., None]
+        inp, target = inp.contiguous(), target.contiguous()
+        target = ops.general_matmul_lower(self._xs, gp._t, c, U2, V1, inp, Z=target)
+        target = ops.general_matmul_upper(self._xs, gp._t, c, V2, U1, inp, Z=target)
+        return target[..., 0] if vec else target
+
+    @property
+    def mean(self):      # core.py:115-132
+        gp = self.gp
+        alpha = gp.apply_inverse(self.y - gp.mean)
+        if self.t is None and self.kernel is None:
+            mu = self.y - gp._diag * alpha
+            return mu if self.include_mean else mu - gp.mean
+        B = gp._diag.shape[0]
+        mu = torch.zeros((B, self._xs.shape[-1]), dtype=torch.float64, device=gp._diag.device)
+        mu = self._do_dot(alpha, mu)
+        return mu + gp.mean if self.include_mean else mu
+
+    @property
+    def variance(self):  # core.py:134-140 + numpy.py:24-25: k(0) - diag(KxsT' K^-1 KxsT), (B, M)
+        B = self.gp._diag.shape[0]
+        k0 = self._kernel().get_value_device(torch.zeros((B, 1), dtype=torch.float64, device=self.gp._diag.device))
+        return k0 - (self.KxsT * self.Kinv_KxsT).sum(dim=1)
+
+    @property
+    def covariance(self):  # core.py:142-150: k(xs - xs') - K(xs, t) K^-1 K(t, xs), (B, M, M)
+        xs = self._batched(self._xs)
+        neg_cov = -self._kernel().get_value_device(xs[:, :, None] - xs[:, None, :])
+        neg_cov = self._do_dot(self.Kinv_KxsT, neg_cov)
+        return -neg_cov
+
+    def sample(self, *, size=None, regularize=None, generator=None):
+        """numpy.py:27-32: draws from N(mean, covariance), O(M^3) per series (a dense Cholesky of the M x M covariance
+        by torch -- outside the hot path, as in the reference)."""
+        mu, cov = self.mean, self.covariance
+        if regularize is not None:
+            cov = cov + regularize * torch.eye(cov.shape[-1], dtype=cov.dtype, device=cov.device)
+        L = torch.linalg.cholesky(0.5 * (cov + cov.transpose(1, 2)))
+        k = 1 if size is None else size
+        n = torch.randn((cov.shape[0], cov.shape[-1], k), dtype=torch.float64, device=cov.device, generator=generator)
+        out = (L @ n).transpose(1, 2) + mu[:, None, :]
+        return out[:, 0] if size is None else out

@@ -37,6 +37,30 @@ class Term:
         k = np.sum(ar * np.exp(-cr * tau), axis=-1)
         return k + np.sum(np.exp(-cc * tau) * (ac * np.cos(dc * tau) + bc * np.sin(dc * tau)), axis=-1)
 
+    def get_value_device(self, tau):
+        """k(tau) (terms.py:58-79) on the device: `tau` a float64 tensor whose LEADING axis is the batch (B, ...);
+        coefficients shared by the batch or one row per series.  What the conditional distribution needs for its
+        cross-covariances `KxsT`, `k(0)` and `k(xs - xs')` (core.py:57-66, 134-150)."""
+        import torch
+
+        ar, cr, ac, bc, cc, dc = self.get_coefficients()
+        tau = tau.abs()
+        extra = (1,) * (tau.dim() - 1)
+
+        def co(v, j):   # coefficient j as a tensor broadcastable against tau: () or (B, 1, ..)
+            v = np.asarray(v, dtype=np.float64)
+            if v.ndim == 1:
+                return float(v[j])
+            return torch.from_numpy(np.ascontiguousarray(v[:, j])).to(tau.device).reshape((-1,) + extra)
+
+        k = torch.zeros_like(tau)
+        for j in range(ar.shape[-1]):
+            k = k + co(ar, j) * torch.exp(-co(cr, j) * tau)
+        for j in range(ac.shape[-1]):
+            arg = co(dc, j) * tau
+            k = k + torch.exp(-co(cc, j) * tau) * (co(ac, j) * torch.cos(arg) + co(bc, j) * torch.sin(arg))
+        return k
+
     def get_celerite_matrices(self, x, diag):
         """x (N,)|(B,N), diag (B,N) torch float64 device tensors -> (c, a, U, V) device tensors."""
         import torch

@@ -33,8 +33,13 @@
  *          after the results are back on the host.  These are what the
  *          `driver` / `backprop` pybind11 modules bind.
  *
- * Width limit: 1 <= J <= 32 (the reference's CELERITE_MAX_WIDTH,
- * c++/include/celerite2/terms.hpp:10-12); larger J returns C2_ERR_UNSUPPORTED.
+ * Width limit: 1 <= J <= C2_MAX_WIDTH = 128.  Up to C2_FAST_WIDTH = 32 (the
+ * reference's CELERITE_MAX_WIDTH, c++/include/celerite2/terms.hpp:10-12: the
+ * widths it instantiates at compile time) the tuned kernels run; 33 .. 128 --
+ * the reference's Eigen::Dynamic path, python/celerite2/driver.hpp:98-99 --
+ * run on the workgroup-per-series kernels of csrc/c2_wide.hip.  J > 128 returns
+ * C2_ERR_UNSUPPORTED, and so do the 2-D and coefficient-level extensions
+ * (c2_kron_*, c2_loglik_terms*) above 32.
  * ============================================================================= */
 #ifndef CELERITE2_AMD_H_
 #define CELERITE2_AMD_H_

@@ -36,3 +36,18 @@ def golden_kron():
     import numpy as np
 
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "kron.npz")))
+
+
+# Counters the time-parallel-gradient fuzz fills in (tests/test_gpu_fuzz.py::_tpg_check): how many draws pass the PLAIN
+# north_star criterion (1e-10 of the array's largest entry) and how many needed the extended-precision floor term of
+# DESIGN.md section 5 -- printed with the run's summary so the log says it where people look.
+TPG_STATS = {"draws": 0, "needed_floor": 0, "needed_floor_seeds": [], "worst_plain": 0.0}
+
+
+def pytest_terminal_summary(terminalreporter):
+    if TPG_STATS["draws"]:
+        terminalreporter.write_line(
+            "time-parallel gradient criterion: %d draw evaluations, %d needed the 4 x extended-precision-floor term "
+            "(the rest pass 1e-10 of the largest entry outright); worst plain distance %.2e; seeds needing the floor: %s"
+            % (TPG_STATS["draws"], TPG_STATS["needed_floor"], TPG_STATS["worst_plain"],
+               sorted(set(TPG_STATS["needed_floor_seeds"]))[:40]))

@@ -204,6 +204,13 @@ def test_wide_model_through_the_drop_in(mods, oracle):
     _close(Z / np.sqrt(d)[:, None], np.linalg.solve(L, Y), 1e-8)
     Z2 = driver.matmul_lower(x, c, U, V, Y, np.zeros_like(Y))
     _close(Z2, np.tril(K, -1) @ Y, 1e-9)
+    for op, ref in (("matmul_lower", np.tril(K - np.diag(diag), -1) @ Y), ("matmul_upper", np.triu(K - np.diag(diag), 1) @ Y)):
+        # *_fwd zeroes Z itself (backprop.cpp: Z.setZero()): a NaN-filled output buffer must come back clean, first row included
+        Zf, Ff = getattr(backprop, op + "_fwd")(x, c, U, V, Y, np.full_like(Y, np.nan), np.full((N, J, 3), np.nan))
+        _close(Zf, ref, 1e-9)
+        Zo = np.empty_like(Y); Fo = np.empty((N, J, 3))
+        getattr(oracle, op + "_fwd")(x, c, U, V, Y, Zo, Fo)
+        _close(Zf, Zo); _close(Ff, Fo)
     S = np.empty((N, J, J)); F = np.empty((N, J, 3))
     d2, W2, S2 = backprop.factor_fwd(x, c, a, U, V, np.empty_like(a), np.empty_like(V), S)
     do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))

@@ -271,6 +271,12 @@ def _tpg_check(ops, oracle, monkeypatch, seed, forced=True):
     ll0, flag0 = ops.loglik(*args)
     assert np.array_equal(flag0.cpu().numpy() != 0, failed)
     np.testing.assert_array_less(np.abs(ll0.cpu().numpy()[ok] - llo[ok]), 1e-10 * np.abs(llo[ok]) + 4.0 * np.abs(llo[ok] - llx[ok]) + 1e-300)
+    from conftest import TPG_STATS   # the run's summary line says how many draws needed the second term
+    TPG_STATS["draws"] += 1
+    TPG_STATS["worst_plain"] = max(TPG_STATS["worst_plain"], worst)
+    if worst > 1e-10:
+        TPG_STATS["needed_floor"] += 1
+        TPG_STATS["needed_floor_seeds"].append(("time-parallel" if forced else "row-by-row", seed))
     return worst
 
 

@@ -178,6 +178,11 @@ def test_wide_models(ops, oracle, J, nrhs):
         Yc = Yd.clone()
         Zi = getattr(ops, name)(td, cd, Ud, second, Yc, Z=Yc)
         close(Zi, Zo if name.startswith("solve") else Zo + Y)
+        if "matmul" in name:
+            # zero_z with a caller buffer full of NaN: the *_fwd variants zero Z first (backprop.cpp Z.setZero()), the
+            # first visited row included (it receives no product term)
+            Zn = torch.full_like(Yd, float("nan"))
+            close(getattr(ops, name)(td, cd, Ud, second, Yd, Z=Zn, zero_z=True), Zo)
         bZ = rng.standard_normal((B, N, nrhs))
         (bZd,) = dev(bZ)
         res = getattr(ops, name + "_rev")(td, cd, Ud, second, Yd, Z, F, bZd)
@@ -529,6 +534,36 @@ def test_get_celerite_matrices_batched(ops):
     a, U, V = ops.get_celerite_matrices(*dev(ar, ac, bc, dc, x, diag))
     for b in range(B):
         c_, a_, U_, V_ = dense.celerite_matrices(cos[b], x[b], diag[b])
+        close(a[b], a_, 1e-13); close(U[b], U_, 1e-12); close(V[b], V_, 1e-12)
+
+
+def test_get_celerite_matrices_unsorted_large_phases(ops):
+    """driver.cpp:456-474 has no sortedness precondition: an UNSORTED x whose interior rows leave the range of the
+    branch-free sincos (|dc x| >= 1.6e6) while its ends do not must give the reference's values on every row (the
+    row-parallel rare-path kernel rewrites them with the library sincos), not NaN -- next to a sorted series of raw Julian
+    dates (whole terms on the rare path), a sorted small one, and a term whose rate keeps it in range throughout."""
+    import torch
+    B, N, J = 4, 300, 6
+    rng = np.random.default_rng(19)
+    x = np.sort(rng.uniform(0, 10, (B, N)), axis=1); diag = rng.uniform(0.1, 0.3, (B, N))
+    x[1, 40:60] += 2.4e6                 # unsorted: interior rows out of range, both ends small
+    x[1, 150] = -3.0e6
+    x[2] += 2.45e6                       # sorted raw Julian dates
+    cos = [dense.sho_sum_coeffs(J, xi) for xi in (-0.5, 0.0, 0.7, 0.2)]
+    ac = np.stack([co.ac for co in cos]); bc = np.stack([co.bc for co in cos]); dc = np.stack([co.dc for co in cos])
+    dc[:, 0] *= 1e-3                     # this term stays within range on every row of every series
+    ar = np.zeros((B, 0))
+    a, U, V = ops.get_celerite_matrices(*dev(ar, ac, bc, dc, x, diag))
+    assert bool(torch.isfinite(U).all()) and bool(torch.isfinite(V).all())
+    for b in range(B):
+        co = dense.Coeffs(ar=ar[b], cr=np.zeros(0), ac=ac[b], bc=bc[b], cc=cos[b].cc, dc=dc[b])
+        c_, a_, U_, V_ = dense.celerite_matrices(co, x[b], diag[b])
+        close(a[b], a_, 1e-13); close(U[b], U_, 1e-12); close(V[b], V_, 1e-12)
+    # shared coefficients, shared unsorted grid
+    a, U, V = ops.get_celerite_matrices(*dev(ar[0], ac[1], bc[1], dc[1], x[1], diag))
+    co = dense.Coeffs(ar=ar[1], cr=np.zeros(0), ac=ac[1], bc=bc[1], cc=cos[1].cc, dc=dc[1])
+    for b in range(B):
+        c_, a_, U_, V_ = dense.celerite_matrices(co, x[1], diag[b])
         close(a[b], a_, 1e-13); close(U[b], U_, 1e-12); close(V[b], V_, 1e-12)
 
 
@@ -932,6 +967,121 @@ def test_multi_rhs_sweeps(ops, oracle, J, nrhs):
             getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
             for r_, e_ in zip(res, outs):
                 close(r_[b], e_)
+
+
+@pytest.mark.parametrize("J,nrhs,B,N", [(8, 128, 3, 150), (8, 256, 2, 97), (8, 500, 2, 64), (16, 128, 2, 70), (16, 256, 1, 130),
+                                        (4, 500, 2, 51), (6, 130, 3, 66), (2, 256, 1, 40), (32, 128, 1, 40)])
+def test_large_nrhs_solves(ops, oracle, J, nrhs, B, N):
+    """SURVEY.md 8f-4 at its own size: solve_lower / solve_upper with HUNDREDS of right-hand sides (apply_inverse on an
+    N x M matrix, core.py:62-66) with and without the F workspace, in place, and their reverse passes -- every element
+    against the oracle; plus the matmul pair at the same counts (the covariance's general products feed on them)."""
+    rng = np.random.default_rng(11 * J + nrhs)
+    Je = J if J % 2 == 0 else J + 1
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, Je)
+    d_, W_ = np.empty_like(a), np.empty_like(V)
+    for b in range(B):
+        oracle.factor(t[b], c[b], a[b], U[b], V[b], d_[b], W_[b], np.empty((N, Je, Je)))
+    U = np.ascontiguousarray(U[:, :, :J]); V = np.ascontiguousarray(V[:, :, :J]); c = np.ascontiguousarray(c[:, :J])
+    W = np.ascontiguousarray(W_[:, :, :J])
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Wd, Yd = dev(t, c, U, V, W, Y)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b])
+        close(getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True), Zo)      # without the workspace: the production path
+        Zd, Fd = getattr(ops, name)(td, cd, Ud, secd, Yd, workspace=True, zero_z=True)
+        close(Zd, Zo); close(Fd, Fo)
+        Yc = Yd.clone()
+        close(getattr(ops, name)(td, cd, Ud, secd, Yc, Z=Yc), Zo if solve else Zo + Y)
+        bZ = rng.standard_normal((B, N, nrhs))
+        (bZd,) = dev(bZ)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+        for b in range(B):
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+            for r_, e_ in zip(res, outs):
+                close(r_[b], e_)
+
+
+@pytest.mark.parametrize("N,M", [(2000, 128), (1200, 256), (700, 500)])
+def test_large_nrhs_apply_inverse_vs_dense(ops, N, M):
+    """apply_inverse on an N x M matrix (M in the hundreds) against the dense K^-1 (numpy Cholesky) on N <= 2000:
+    solve_lower, /d, solve_upper through the production dispatch -- the row-by-row kernels on the batch of 3, the
+    chunk maps parallel along time on one series (B = 1)."""
+    from celerite2_amd import gp as gpmod, terms
+    kernel = terms.SHOTerm(S0=5.0, w0=0.1, Q=3.45) + terms.SHOTerm(S0=0.7, w0=2.1, Q=1.3) + terms.RealTerm(a=0.4, c=0.2)
+    for B in (3, 1):
+        rng = np.random.default_rng(5 + B)
+        x = np.sort(rng.uniform(0, N / 10.0, (B, N)), axis=1)
+        diag = rng.uniform(0.1, 0.3, (B, N))
+        Y = rng.standard_normal((B, N, M))
+        xd, dd, Yd = dev(x, diag, Y)
+        gp = gpmod.GaussianProcess(kernel)
+        gp.compute(xd, diag=dd)
+        X = gp.apply_inverse(Yd).cpu().numpy()
+        for b in range(B):
+            K = kernel.get_value(x[b][:, None] - x[b][None, :]) + np.diag(diag[b])
+            want = np.linalg.solve(K, Y[b])
+            assert np.abs(X[b] - want).max() <= 1e-9 * np.abs(want).max()
+
+
+def test_predictive_variance_and_covariance(ops):
+    """gp.predict(..., return_var=True / return_cov=True) = core.py:134-150 against dense linear algebra: on the observed
+    grid and on a new one, with M = 300 prediction points (apply_inverse with 300 right-hand sides, the general products
+    with 300), per-series hyper-parameters, a separate `kernel=` component (core.py:74-86), and conditional samples."""
+    import torch
+    from celerite2_amd import gp as gpmod, terms
+
+    rng = np.random.default_rng(40582)
+    B, N, M = 3, 120, 300
+    x = np.sort(rng.uniform(0, 10, (B, N)), axis=1)
+    ts = np.sort(rng.uniform(-1, 12, (B, M)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x)
+    S0 = np.array([5.0, 4.0, 6.0])
+    comp = terms.SHOTerm(S0=S0, w0=0.1, Q=3.45)
+    kernel = comp + terms.RealTerm(a=1.0, c=0.1)
+    xd, tsd, dd, yd = dev(x, ts, diag, y)
+    gp = gpmod.GaussianProcess(kernel, mean=0.3)
+    gp.compute(xd, diag=dd)
+    mu, var = gp.predict(yd, tsd, return_var=True)
+    mu2, cov = gp.predict(yd, tsd, return_cov=True)
+    mu0, var0 = gp.predict(yd, return_var=True)
+    mu0c, cov0 = gp.predict(yd, return_cov=True)
+    muk, vark = gp.predict(yd, tsd, return_var=True, kernel=comp)
+    _, covk = gp.predict(yd, tsd, return_cov=True, kernel=comp, include_mean=False)
+    assert torch.equal(mu, mu2) and torch.equal(mu0, mu0c)
+    for b in range(B):
+        kb = terms.SHOTerm(S0=float(S0[b]), w0=0.1, Q=3.45) + terms.RealTerm(a=1.0, c=0.1)
+        cb = terms.SHOTerm(S0=float(S0[b]), w0=0.1, Q=3.45)
+        K = kb.get_value(x[b][:, None] - x[b][None, :]) + np.diag(diag[b])
+        Ks = kb.get_value(ts[b][:, None] - x[b][None, :])
+        Kss = kb.get_value(ts[b][:, None] - ts[b][None, :])
+        r = y[b] - 0.3
+        want_mu = Ks @ np.linalg.solve(K, r) + 0.3
+        want_cov = Kss - Ks @ np.linalg.solve(K, Ks.T)
+        np.testing.assert_allclose(mu[b].cpu().numpy(), want_mu, rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(cov[b].cpu().numpy(), want_cov, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(var[b].cpu().numpy(), np.diag(want_cov), rtol=1e-7, atol=1e-9)
+        K0 = K - np.diag(diag[b])
+        want_cov0 = K0 - K0 @ np.linalg.solve(K, K0)
+        np.testing.assert_allclose(cov0[b].cpu().numpy(), want_cov0, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(var0[b].cpu().numpy(), np.diag(want_cov0), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(mu0[b].cpu().numpy(), y[b] - diag[b] * np.linalg.solve(K, r), rtol=1e-8, atol=1e-9)
+        # the component kernel (core.py:74-86): cross-covariances of the component, inverse of the full matrix
+        Ksc = cb.get_value(ts[b][:, None] - x[b][None, :])
+        Kssc = cb.get_value(ts[b][:, None] - ts[b][None, :])
+        np.testing.assert_allclose(muk[b].cpu().numpy(), Ksc @ np.linalg.solve(K, r) + 0.3, rtol=1e-8, atol=1e-9)
+        want_covk = Kssc - Ksc @ np.linalg.solve(K, Ksc.T)
+        np.testing.assert_allclose(covk[b].cpu().numpy(), want_covk, rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(vark[b].cpu().numpy(), np.diag(want_covk), rtol=1e-7, atol=1e-9)
+    s = gp.condition(yd, tsd).sample(size=3, regularize=1e-8)
+    assert s.shape == (B, 3, M) and bool(torch.isfinite(s).all())
+    with pytest.raises(ValueError):
+        gp.condition(yd, tsd[:2])
 
 
 @pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (8, 34), (16, 64), (8, 132), (16, 200), (7, 64), (8, 33), (13, 9), (21, 65), (9, 130)])

@@ -155,7 +155,7 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
             "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}
 
 
-def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms):
+def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms, every_series=False):
     """Informational: the same workload with 5 % of the series carrying one gap of 100 mean spacings (a night, a season) at
     a row of their own.  The one-lane reverse sweep cannot invert a decay across such a gap; the forward pass re-anchors it
     there with an extra wavefront-uniform checkpoint (c2_loglik_t.hip), so the batch stays on the fast kernels -- `guard`
@@ -164,7 +164,12 @@ def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms):
 
     from celerite2_amd import ops, synth
 
-    t, c, a, U, V, y = synth.device_batch_fast(first, Bp, N, J, dev, gap_fraction=0.05, gap=10.0)
+    if every_series:   # `gappy_all`: EVERY series three gaps at rows of its own (192 re-anchoring checkpoints per wavefront)
+        t, c, a, U, V, y = synth.device_batch_fast(first, Bp, N, J, dev, gap_fraction=1.0, gap=10.0, gaps_per_series=3)
+        what = "the step's batch with THREE gaps of 10 time units at rows of its own in every series (%d of %d)"
+    else:
+        t, c, a, U, V, y = synth.device_batch_fast(first, Bp, N, J, dev, gap_fraction=0.05, gap=10.0)
+        what = "the step's batch with a gap of 10 time units (100 mean spacings) in 5 %% of the series (%d of %d)"
     ngap = int(((t[:, 1:] - t[:, :-1]).max(dim=1).values > 5.0).sum())
     for _ in range(2):
         ll, _, flag = ops.loglik_grad(t, c, a, U, V, y, work=work, out=out)
@@ -176,10 +181,12 @@ def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    guard = float(work[0])
-    return {"workload": "the step's batch with a gap of 10 time units (100 mean spacings) in 5 %% of the series (%d of %d)" % (ngap, Bp),
+    guard, nfall = float(work[0]), int(work[:2].view(torch.int64)[1])
+    return {"workload": what % (ngap, Bp),
             "ms_per_step": ms, "value": Bp / ms * 1e3, "unit": "GP/s", "steps": steps, "ratio_to_gap_free_step": ms / clean_ms,
-            "guard": guard, "path": "one lane per series, re-anchored at the gaps" if guard <= 2.0 else "replay kernels (guard tripped)",
+            "guard": guard, "wavefronts_on_the_replay_kernels": nfall, "wavefronts": (Bp + 63) // 64,
+            "path": "one lane per series, re-anchored at the gaps" if nfall == 0 else
+                    "one lane per series; %d wavefronts of 64 series ran out of extra checkpoints and were replayed" % nfall,
             "failed_factorizations": int((flag != 0).sum())}
 
 
@@ -459,6 +466,10 @@ def main():
                 line["gappy"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg)
             except Exception as e:  # noqa: BLE001 -- informational only
                 line["gappy"] = {"error": repr(e)[:200]}
+            try:   # every series with three gaps of its own: what a wavefront's re-anchoring checkpoints cost at worst
+                line["gappy_all"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg, every_series=True)
+            except Exception as e:  # noqa: BLE001 -- informational only
+                line["gappy_all"] = {"error": repr(e)[:200]}
             t = c = a = U = V = y = None
             ll = ll_keep
         if world == 1 and grad and J == 8 and not args.exact_synth and not args.no_coefficient_level:

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          const unsigned long long *__restrict__ gate) {
   // `gate` (nullable): this launch is the fallback of the one-lane-per-series path and runs only when the stability
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
-  if (gate_closed(gate)) return;
+  if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;   // (the series of a wavefront share a group of 64)
   // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
   // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
   // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          const double *__restrict__ fr_bd,
                                                          const double *__restrict__ fr_bW,
                                                          const unsigned long long *__restrict__ gate) {
-  if (gate_closed(gate)) return;  // see k_loglik_fwd
+  if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;  // see k_loglik_fwd
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
@@ -837,6 +837,8 @@ C2_DECL_T(6)   // rows of 6 in memory, computed as rows of 8 (c2_loglik_t6.hip)
 C2_DECL_T(4)
 C2_DECL_T(2)
 #undef C2_DECL_T
+// guard words in front of the records of the one-lane path: the head + one per wavefront, rounded to 16 bytes
+static size_t lanes1_gate_words(int64_t B) { return (size_t)((kGateHeadWords + (B + kWave - 1) / kWave + 1) & ~(int64_t)1); }
 static size_t lanes1_record_doubles(int64_t B, int64_t N, int64_t J) {
   return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
        : J == 6 ? c2_internal_loglik_t_record_doubles6(B, N)
@@ -1262,9 +1264,9 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (J > C2_FAST_WIDTH) return c2_loglik_grad_composite_workspace_bytes(B, N, J);   // (d, W, S, z, F, seeds: the op chain)
   size_t n = grad_ws(B, N, J).total;
   if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
-  if (use_lanes1(B, J, true)) {  // [guard word (16 bytes)] [records of the one-lane path | workspace of the replay fallback]
+  if (use_lanes1(B, J, true)) {  // [guard words: head + one per wavefront] [records of the one-lane path | workspace of the replay fallback]
     const size_t r = lanes1_record_doubles(B, N, J);
-    n = 2 + (r > n ? r : n);
+    n = lanes1_gate_words(B) + (r > n ? r : n);
   }
   if (use_timepar_grad(B, N, J)) {   // [verification words | its scratch, or the workspace of the gated row-by-row pair]
     const size_t r = c2_internal_timepar_grad_doubles(B, N, J), f = grad_ws(B, N, J).total + kTimeparVerifyWords;
@@ -1326,18 +1328,20 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
   if (use_lanes1(B, J, true)) {
     hipStream_t s = (hipStream_t)stream;
     // One lane per series: forward with records, then the backward-recursion reverse sweep.  The forward pass leaves
-    // its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the gated
-    // replay pair below produces the gradients (same outputs, same workspace region, decided on the device).
+    // the stability measure of every WAVEFRONT in its own guard word; where it exceeds kBackwardGuard that wavefront's
+    // reverse sweep returns at once and the replay pair below -- gated per group of 64 series by the same words --
+    // produces the gradients of those series (same outputs; its workspace overlays the records, which nobody reads any
+    // more by then; decided on the device).
     unsigned long long *guard = (unsigned long long *)work;
-    if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
-    work = (double *)work + 2;
+    if (hipMemsetAsync(guard, 0, 8 * kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+    work = (double *)work + lanes1_gate_words(B);
     auto one_lane = J == 8 ? c2_internal_loglik_t_grad8
                   : J == 6 ? c2_internal_loglik_t_grad6
                   : J == 4 ? c2_internal_loglik_t_grad4 : c2_internal_loglik_t_grad2;
     if (int e = one_lane(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, (double *)work, guard,
                          stream))
       return e;
-    gate = guard;
+    gate = gate_per_wave(guard + kGateHeadWords);   // per group of 64 series: only the wavefronts that fell back are replayed
   }
   return c2_internal_loglik_grad_replay(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, gate,
                                         stream);

@@ -1,6 +1,7 @@
 // c2_loglik_helpers.hpp -- device helpers shared by the fused log-likelihood kernels (c2_loglik.hip: one column per
 // lane; c2_loglik4.hip: two columns per lane).
 #pragma once
+#include <cstdint>
 #include "c2_dispatch.hpp"
 #include "c2_common.hpp"
 
@@ -12,8 +13,20 @@ constexpr double kLn2 = 0.69314718055994530941723212145818;
 // max_j c_j * (t_end - t_start) <= kBackwardGuard on every checkpoint segment (error growth <= e^{2 * guard}).
 constexpr double kBackwardGuard = 2.0;
 // Kernels of a fallback chain take the guard word as `gate` and run only if the fast path declined (nullptr: always run).
-__device__ __forceinline__ bool gate_closed(const unsigned long long *gate) {
-  return gate && !(__longlong_as_double((long long)*gate) > kBackwardGuard);
+// Two forms, told apart by the lowest bit of the pointer (the words are 8-byte aligned):
+//   plain pointer : ONE word decides for the whole launch (the verification words of the time-parallel forms);
+//   pointer | 1   : one word per group of 64 consecutive series -- the one-lane-per-series kernels decide per WAVEFRONT
+//                   (a wavefront that runs out of re-anchoring checkpoints costs its own 64 series the fallback, not the
+//                   batch): the part of a fallback kernel that works on series b runs iff word[b / 64] is beyond the guard.
+constexpr int kGateHeadWords = 2;   // [0] largest guard of the launch (diagnostic), [1] wavefronts that fell back; then the words
+__host__ __device__ inline const unsigned long long *gate_per_wave(const unsigned long long *words) {
+  return reinterpret_cast<const unsigned long long *>(reinterpret_cast<uintptr_t>(words) | 1u);
+}
+__device__ __forceinline__ bool gate_closed(const unsigned long long *gate, int64_t b = 0) {
+  if (!gate) return false;
+  const uintptr_t g = reinterpret_cast<uintptr_t>(gate);
+  const unsigned long long w = (g & 1u) ? reinterpret_cast<const unsigned long long *>(g & ~(uintptr_t)1)[b >> 6] : *gate;
+  return !(__longlong_as_double((long long)w) > kBackwardGuard);
 }
 
 // 1/d for a well-scaled positive d: v_rcp_f64 seed + two Newton steps (full fp64 accuracy; the

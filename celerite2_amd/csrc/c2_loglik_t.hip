@@ -81,6 +81,16 @@ __host__ __device__ constexpr int sym(int i, int j) { return i <= j ? sidx(i, j)
 //   CK  : [wave][slot][NS + J][64] double (state after row n_slot: S packed, F), slots in the order written
 //   CKR : [wave][n] int32                 (slot of the checkpoint of row n, meaningful where the row carries one -- which is
 //                                          the sign of the row's d in DZ)
+// C2T_TM = 1: the per-row records (W, DZ, T) are TIME-major across the wavefronts of the launch -- [n][wave][..][64] -- so
+// that the rows the resident wavefronts touch at any moment (they walk the series in near lockstep) form ONE contiguous
+// stretch of memory, spread evenly over every HBM stack / channel whatever the allocator's placement; 0: [wave][n][..][64]
+// (each wavefront its own stretch, 16 MB apart at the bench shape).
+#ifndef C2T_TM
+#define C2T_TM 0
+#endif
+#ifndef C2T_RECFIRST
+#define C2T_RECFIRST 0
+#endif
 struct Rec {
   size_t w, dz, ck, ckr, t, total;  // offsets / total in doubles
   int64_t nck;                      // checkpoint slots per wavefront (capacity)
@@ -91,15 +101,16 @@ struct Rec {
 // a season): before row n is absorbed, if for ANY series of the wavefront max_j c_j * (t_n - t of the row behind its last
 // checkpoint) exceeds kGuard, the state of row n-1 is recorded -- for the whole wavefront, so the record stays lane-major
 // and the reverse sweep turns at wavefront-uniform rows.  After a long gap the decays are ~0 and the state is all but
-// reset, so nothing is lost by not walking across it.  Up to nreg extras per wavefront (shared grids and batches with a
-// few gappy series need a handful); a wavefront that runs out leaves its excess in the guard word and the replay kernels
-// take the batch, as before.
+// reset, so nothing is lost by not walking across it.  Up to 2 nreg extras per wavefront (shared grids and batches with a
+// few gappy series need a handful; 64 series with three gaps each at rows of their own 192); a wavefront that runs out
+// leaves its excess in ITS guard word: its reverse sweep returns at once and the replay kernels, gated per group of 64
+// series (gate_closed, c2_loglik_helpers.hpp), take those 64 series -- not the batch.
 __host__ __device__ inline int64_t n_ckpt(int64_t N) { return N >= 2 ? (N - 2) / C + 1 : 0; }
 __host__ inline Rec rec_layout(int64_t B, int64_t N) {
   const size_t waves = ((size_t)B + kWave - 1) / kWave;
   Rec r;
   r.nreg = n_ckpt(N);
-  r.nck = 2 * r.nreg;
+  r.nck = 3 * r.nreg;   // twice as many extras as regular ones: every series of a wavefront its own three gaps at N = 4096
   r.w = 0;
   r.dz = r.w + waves * (size_t)N * J * kWave;
   r.ck = r.dz + waves * (size_t)N * 2 * kWave;
@@ -456,11 +467,22 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   for (int j = 0; j < J; ++j) cmax = fmax(cmax, cj[j]);
 
   // records of this wavefront
+#if C2T_TM
+  const size_t rsW = (size_t)gridDim.x * (J / 2) * kWave, rs1 = (size_t)gridDim.x * kWave;   // row strides (elements)
+  double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w) + (size_t)blockIdx.x * (J / 2) * kWave : nullptr;
+  double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz) + (size_t)blockIdx.x * kWave : nullptr;
+#else
+  constexpr size_t rsW = (size_t)(J / 2) * kWave, rs1 = kWave;
   double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave) : nullptr;
   double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave) : nullptr;
+#endif
   double *recCK = REC ? rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave : nullptr;
   int32_t *recCKR = REC ? reinterpret_cast<int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2)) : nullptr;
+#if C2T_TM
+  double *recT = REC ? rec + R.t + (size_t)blockIdx.x * kWave : nullptr;  // the grid, lane-major like (d, z)
+#else
   double *recT = REC ? rec + R.t + (size_t)blockIdx.x * N * kWave : nullptr;  // the grid, lane-major like (d, z)
+#endif
 
   // ---- row 0 --------------------------------------------------------------------------------------------------
   double S[NS];
@@ -548,9 +570,9 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
               // n+.. down to n+1 ... and of row n if the state of row n-1 is not on record: re-anchor there if some series
               // of the wavefront could not afford that (wavefront-uniform decision)
               if (lastck == n - 1) tseg = tn;   // the decay into the row behind a checkpoint is never inverted
-              if (__any(cmax * (tn - tseg) > kGuard) && nextra < (int)R.nreg) {
+              if (__any(cmax * (tn - tseg) > kGuard) && nextra < (int)(R.nck - R.nreg)) {
                 write_ckpt(n - 1);
-                st2_stream(&recDZ[(size_t)(n - 1) * kWave + lane], make_double2(-fabs(d), z));   // (d, z still of row n-1)
+                st2_stream(&recDZ[(size_t)(n - 1) * rs1 + lane], make_double2(-fabs(d), z));   // (d, z still of row n-1)
                 ++nextra;
                 tseg = tn;
               }
@@ -598,10 +620,10 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
             if (r & 1) { int e; prod = frexp(prod, &e); eacc += e; }
             if (REC) {
 #pragma unroll
-              for (int q = 0; q < J / 2; ++q) st2_stream(&recW[((size_t)n * (J / 2) + q) * kWave + lane], make_double2(w[2 * q], w[2 * q + 1]));
+              for (int q = 0; q < J / 2; ++q) st2_stream(&recW[(size_t)n * rsW + q * kWave + lane], make_double2(w[2 * q], w[2 * q + 1]));
               const bool seg_end = (n % C == 0) || (n == N - 1);
-              st2_stream(&recDZ[(size_t)n * kWave + lane], make_double2(seg_end ? -fabs(d) : fabs(d), z));
-              st1_stream(&recT[(size_t)n * kWave + lane], tn);
+              st2_stream(&recDZ[(size_t)n * rs1 + lane], make_double2(seg_end ? -fabs(d) : fabs(d), z));
+              st1_stream(&recT[(size_t)n * rs1 + lane], tn);
               if (seg_end) write_ckpt(n);  // uniform over the wavefront
             }
           }
@@ -616,10 +638,20 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
     flag[b] = fl;
     ll[b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
     if (REC && lane == 0) recCKR[0] = nextra;   // (row 0 never carries a checkpoint: its entry says whether the wavefront has extras)
-    if (REC) {
-      // NaN-aware: a NaN span must disable the fast path (the replay kernels propagate it like the reference)
-      const double g = (gmax == gmax) ? gmax : INFINITY;
-      atomicMax(guard, (unsigned long long)__double_as_longlong(g));  // g >= 0: the bit pattern is monotone
+  }
+  if (REC) {
+    // The stability measure of THIS wavefront -- max over its series and segments of c_max * span -- goes to its own word
+    // (guard[kGateHeadWords + wavefront]): beyond kGuard its reverse sweep returns at once and the replay kernels take its
+    // 64 series.  guard[0] keeps the largest of the launch, guard[1] counts the wavefronts that fell back (diagnostics).
+    // NaN-aware: a NaN span must disable the fast path (the replay kernels propagate it like the reference)
+    double g = (gmax == gmax) ? gmax : INFINITY;
+#pragma unroll
+    for (int sft = 1; sft < kWave; sft <<= 1) g = fmax(g, __shfl_xor(g, sft, kWave));
+    if (lane == 0) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(g);   // g >= 0: the bit pattern is monotone
+      guard[kGateHeadWords + blockIdx.x] = bits;
+      atomicMax(guard, bits);
+      if (g > kGuard) atomicAdd(guard + 1, 1ull);
     }
   }
 }
@@ -778,11 +810,22 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   double *tACC = lds;   // coefficient-level form: takes the place of the U tile (64 x 14 <= 64 x 18 doubles)
   const double *Ub = U + b0 * N * JS;
   double *bUb = bU + b0 * N * JS, *bVb = bV + b0 * N * JS, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
+#if C2T_TM
+  const size_t rsW = (size_t)gridDim.x * (J / 2) * kWave, rs1 = (size_t)gridDim.x * kWave;   // row strides (elements)
+  const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w) + (size_t)blockIdx.x * (J / 2) * kWave;
+  const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz) + (size_t)blockIdx.x * kWave;
+#else
+  constexpr size_t rsW = (size_t)(J / 2) * kWave, rs1 = kWave;
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * kWave);
   const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * kWave);
+#endif
   const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * (NS + J) * kWave;
   const int32_t *recCKR = reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2));
+#if C2T_TM
+  const double *recT = rec + R.t + (size_t)blockIdx.x * kWave;
+#else
   const double *recT = rec + R.t + (size_t)blockIdx.x * N * kWave;
+#endif
   const bool failed = flag[b] != 0;  // NaN gradients for a failed factorisation (see k_loglik_rev)
   const double nan = __builtin_nan("");
 
@@ -863,13 +906,13 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   double carry = 0.0;
 
   // seeds of the last row (reverse.hpp:55-57 with bd = d ll / d d, bz = d ll / d z)
-  const double2 dzl = recDZ[(size_t)(N - 1) * kWave + lane];
+  const double2 dzl = recDZ[(size_t)(N - 1) * rs1 + lane];
   const double rdl = 1.0 / fabs(dzl.x);   // (the sign of a recorded d is the checkpoint flag of its row)
   double ban = 0.5 * rdl * (dzl.y * dzl.y * rdl - 1.0), bzn = -dzl.y * rdl;
   // A failed series gets NaN seeds: every gradient of the series is an arithmetic function of them (bF <- u bz,
   // M <- x = bV + 2 ba u, bp <- F bF + ..., bt <- bp, bc <- bp), so NaN reaches all six outputs by propagation.
   if (failed) { ban = nan; bzn = nan; }
-  double tcur = recT[(size_t)(N - 1) * kWave + lane];
+  double tcur = recT[(size_t)(N - 1) * rs1 + lane];
 
   // The recorded S / F of a checkpointed row replace the recursed ones.  The 36 elements of S go straight into their
   // AGPRs (aload: no arithmetic register in flight), all 80 loads are issued back to back and waited for ONCE.  (Through
@@ -901,16 +944,16 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   // the grid comes back from the records of the forward pass, lane-major like (d, z): one coalesced 8-byte load per
   // step, requested a step ahead.  (A register-staged tile of t requested eight steps ahead ends up in scratch -- the
   // register file is full -- and scratch turns every one of its loads into load / wait / spill: ~3000 cycles per step.)
-  auto t_fetch = [&](int64_t row) { return ld1_stream(&recT[(size_t)(row < 0 ? 0 : row) * kWave + lane]); };
+  auto t_fetch = [&](int64_t row) { return ld1_stream(&recT[(size_t)(row < 0 ? 0 : row) * rs1 + lane]); };
   auto w_fetch = [&](int64_t row, double (&wv)[J]) {
     row = row < 0 ? 0 : row;
 #pragma unroll
     for (int q = 0; q < J / 2; ++q) {
-      const double2 v = ld2_stream(&recW[((size_t)row * (J / 2) + q) * kWave + lane]);
+      const double2 v = ld2_stream(&recW[(size_t)row * rsW + q * kWave + lane]);
       wv[2 * q] = v.x; wv[2 * q + 1] = v.y;
     }
   };
-  auto dz_fetch = [&](int64_t row) { return ld2_stream(&recDZ[(size_t)(row < 0 ? 0 : row) * kWave + lane]); };
+  auto dz_fetch = [&](int64_t row) { return ld2_stream(&recDZ[(size_t)(row < 0 ? 0 : row) * rs1 + lane]); };
 
   if (N >= 2) {
     const int64_t nf = N - 1;
@@ -968,14 +1011,25 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       C2T_TICK(4);
       // ---- fixed part: U_n into its tile, requests for two steps ahead ------------------------------------------------
       double wb[J];
+#if C2T_RECFIRST
+      // the records of the row below are wanted one step from now, the tile of U rows two: request them in that order (the
+      // counter of outstanding memory operations retires in order -- behind the 64 scattered lines of a U tile the records
+      // would wait for the slowest of them)
+      w_fetch(n - 2, wb);
+      const double2 dzb = dz_fetch(n - 2);
+      const double tb2 = t_fetch(n - 2);
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if constexpr (!TERMS && STAGE) {
         lds_order();
         row_stage(tU, lane, su);
         row_fetch(Ub, N, n - 2 * RT + 1, io, su);
       }
+#if !C2T_RECFIRST
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
       const double tb2 = t_fetch(n - 2);
+#endif
       if constexpr (!TERMS && STAGE) lds_order();
 
       // ---- the step ---------------------------------------------------------------------------------------------
@@ -1272,7 +1326,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_t_rev(int64_t B, int64_t N,
                                                            double *__restrict__ ba, double *__restrict__ bU,
                                                            double *__restrict__ bV, double *__restrict__ by) {
   __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
-  if (__longlong_as_double((long long)*guard) > kGuard) return;  // the replay kernels take this batch
+  if (__longlong_as_double((long long)guard[kGateHeadWords + blockIdx.x]) > kGuard) return;  // the replay kernels take these 64 series
   const int lane = threadIdx.x;
   const int64_t b0 = (int64_t)blockIdx.x * kWave;
   const int64_t bb = (b0 + lane) < B ? (b0 + lane) : (B - 1);
@@ -1301,7 +1355,7 @@ __global__ __launch_bounds__(kWave, 1) void k_loglik_tt_rev(int64_t B, int64_t N
                                                             double *__restrict__ bx, double *__restrict__ bdiag,
                                                             double *__restrict__ by) {
   __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
-  if (__longlong_as_double((long long)*guard) > kGuard) return;  // the composed chain takes this batch
+  if (__longlong_as_double((long long)guard[kGateHeadWords + blockIdx.x]) > kGuard) return;  // the composed chain takes these 64 series
   const bool xck = __builtin_amdgcn_readfirstlane(
                        reinterpret_cast<const int32_t *>(rec + R.ckr + (size_t)blockIdx.x * (((size_t)N + 1) / 2))[0]) > 0;
 #define C2T_TREV(FAST_, X_) rev_body<true, JC, FAST_, false, X_>(B, N, x, x_bs, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by, lds, T, G)
@@ -1331,9 +1385,10 @@ int C2T_NAME(c2_internal_loglik_t)(int64_t B, int64_t N, const double *t, int64_
 // the two paths runs).
 size_t C2T_NAME(c2_internal_loglik_t_record_doubles)(int64_t B, int64_t N) { return rec_layout(B, N).total; }
 
-// Forward with records + backward-recursion reverse sweep.  `guard` (device, 8 bytes, zeroed by the caller on the same
-// stream) receives max over series and segments of c_max * span; k_loglik_t_rev returns at once when it exceeds
-// kBackwardGuard, and the caller's gated replay kernels then produce the gradients instead.
+// Forward with records + backward-recursion reverse sweep.  `guard` (device, kGateHeadWords + ceil(B / 64) words, the two
+// head words zeroed by the caller on the same stream): word kGateHeadWords + w receives wavefront w's max over series and
+// segments of c_max * span; its k_loglik_t_rev returns at once when that exceeds kBackwardGuard, and the caller's replay
+// kernels -- gated per group of 64 series by the same words -- then produce the gradients of those series instead.
 int C2T_NAME(c2_internal_loglik_t_grad)(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                               const double *a, const double *U, const double *V, const double *y, double *ll,
                               double *bt, double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag,

@@ -1043,7 +1043,6 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
                                                   const double *__restrict__ diag, double *__restrict__ a,
                                                   double *__restrict__ U, double *__restrict__ V,
                                                   const unsigned long long *__restrict__ gate) {
-  if (gate_closed(gate)) return;
   // A thread owns ONE term and walks kMatRows rows of one series: its coefficients are loaded once and the row
   // iterations are independent, so their x loads / sincos / stores overlap (one (row, term) pair per thread spent
   // 74 % of its 7500 cycles waiting for dependent loads).  Consecutive threads hold consecutive terms of a row, so a
@@ -1054,6 +1053,7 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
   if (r >= rpi) return;
   const int64_t n0 = (int64_t)blockIdx.x * rpi * kMatRows + r;
   for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+    if (gate_closed(gate, b)) continue;
     const double *arb = ar + (coef_batched ? b * Jr : 0);
     const double *acb = ac + (coef_batched ? b * Jc : 0), *bcb = bc + (coef_batched ? b * Jc : 0),
                  *dcb = dc + (coef_batched ? b * Jc : 0);
@@ -1111,10 +1111,10 @@ __global__ __launch_bounds__(256) void k_matrices_big(int64_t B, int64_t N, int 
                                                       int coef_batched, const double *__restrict__ x, int64_t x_bs,
                                                       double *__restrict__ U, double *__restrict__ V,
                                                       const unsigned long long *__restrict__ gate) {
-  if (gate_closed(gate)) return;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B * N) return;
   const int64_t b = g / N, n = g - b * N;
+  if (gate_closed(gate, b)) return;
   const int J = Jr + 2 * Jc;
   const int64_t o = coef_batched ? b * Jc : 0;
   const double *xb = x + b * x_bs;

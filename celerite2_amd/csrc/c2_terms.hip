@@ -32,11 +32,11 @@ constexpr int kThreads = 256;
 // c (B, J) = [cr, cc0, cc0, cc1, cc1, ...]   (terms.py:171-173)
 __global__ void k_rates(int64_t B, int Jr, int Jc, const double *__restrict__ cr, const double *__restrict__ cc,
                         int coef_batched, double *__restrict__ c, const unsigned long long *__restrict__ gate) {
-  if (c2::gate_closed(gate)) return;
   const int J = Jr + 2 * Jc;
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= B * J) return;
   const int64_t b = g / J;
+  if (c2::gate_closed(gate, b)) return;
   const int j = (int)(g - b * J);
   c[g] = (j < Jr) ? cr[(coef_batched ? b * Jr : 0) + j] : cc[(coef_batched ? b * Jc : 0) + (j - Jr) / 2];
 }
@@ -61,7 +61,6 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
   // nsplit > 1 (a handful of long series): blockIdx.y takes a slice of the rows and leaves its sums in
   // part[series][slice][term][4]; k_terms_rev_finish adds the slices in order
   __shared__ double red[kThreads][4];
-  if (c2::gate_closed(gate)) return;
   const int Q = Jr + Jc, J = Jr + 2 * Jc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rpw = 64 / Q;                       // rows per wavefront and iteration
@@ -70,6 +69,7 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
   const int rows_it = (kThreads / 64) * rpw;    // rows per block iteration
   const int i0 = q < Jr ? q : Jr + 2 * (q - Jr);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    if (c2::gate_closed(gate, b)) continue;   // (block-uniform)
     const int64_t o = coef_batched ? b * Jc : 0;
     double a_ = 0.0, b_ = 0.0, d_ = 0.0;
     if (q >= Jr) { a_ = ac[o + q - Jr]; b_ = bc[o + q - Jr]; d_ = dc[o + q - Jr]; }
@@ -136,9 +136,9 @@ __global__ void k_terms_rev_finish(int Jr, int Jc, int nsplit, const double *__r
                                    const double *__restrict__ bcv, double *__restrict__ bar, double *__restrict__ bcr,
                                    double *__restrict__ bac, double *__restrict__ bbc, double *__restrict__ bcc,
                                    double *__restrict__ bdc, const unsigned long long *__restrict__ gate) {
-  if (c2::gate_closed(gate)) return;
   const int Q = Jr + Jc, J = Jr + 2 * Jc, t = threadIdx.x;
   const int64_t b = blockIdx.x;
+  if (c2::gate_closed(gate, b)) return;
   if (t >= Q) return;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, ab = 0.0;
   for (int sp = 0; sp < nsplit; ++sp) {
@@ -225,6 +225,8 @@ int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double
                                    int32_t *flag, void *work, const unsigned long long *gate, c2_stream_t stream);
 }
 static bool fused_width(int64_t J) { return J == 8 || J == 4 || J == 2; }
+// guard words in front of the fused kernels' records: the head + one per wavefront of 64 series, rounded to 16 bytes
+static size_t fused_gate_words(int64_t B) { return (size_t)((c2::kGateHeadWords + (B + 63) / 64 + 1) & ~(int64_t)1); }
 static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
   return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
                 : (J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N));
@@ -257,7 +259,7 @@ size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t
   size_t n = plan(B, N, J, grad).total;
   if (grad && fused_width(J)) {
     const size_t r = fused_record_doubles(B, N, J);
-    n = 2 + (r > n ? r : n);
+    n = fused_gate_words(B) + (r > n ? r : n);
   }
   return n * sizeof(double);
 }
@@ -301,13 +303,13 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
     // leaves its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the
     // composed chain below -- every kernel of it behind the same word -- produces the gradients instead.
     unsigned long long *guard = (unsigned long long *)work;
-    if (hipMemsetAsync(guard, 0, 16, s) != hipSuccess) return C2_ERR_HIP;
-    w += 2;
+    if (hipMemsetAsync(guard, 0, 8 * c2::kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+    w += fused_gate_words(B);
     auto fused = J == 8 ? c2_internal_loglik_tt_grad8 : (J == 4 ? c2_internal_loglik_tt_grad4 : c2_internal_loglik_tt_grad2);
     if (int e = fused(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, bar, bcr, bac, bbc, bcc, bdc,
                       bx, bdiag, by, flag, w, guard, stream))
       return e;
-    gate = guard;
+    gate = c2::gate_per_wave(guard + c2::kGateHeadWords);   // per group of 64 series (c2_loglik_helpers.hpp)
   }
   if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, gate, s)) return e;
   if (gate) {

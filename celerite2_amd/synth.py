@@ -57,9 +57,10 @@ def device_batch(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10
     return td, to(c), a, U, V, yd
 
 
-def device_coeffs_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0):
+def device_coeffs_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0, gaps_per_series=1):
     """(t, diag, y, ac, bc, cc, dc) of device_batch_fast: the coefficient-level view of the same series.
-    gap_fraction / gap: as in host_inputs (drawn last)."""
+    gap_fraction / gap: as in host_inputs (drawn last); gaps_per_series: that many gaps, each at a row of its own, in
+    every series that is hit."""
     import torch
 
     assert J % 2 == 0
@@ -73,9 +74,11 @@ def device_coeffs_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, 
     noise = 0.1 * torch.randn((count, N), generator=gen, **f64)
     if gap_fraction > 0.0 and N > 2:
         hit = torch.rand((count, 1), generator=gen, **f64) < gap_fraction
-        n0 = 1 + (torch.rand((count, 1), generator=gen, **f64) * (N - 1)).long().clamp_(max=N - 2)
         rows = torch.arange(N, device=device)[None, :]
-        t = (t + gap * (hit & (rows >= n0)).to(torch.float64)).contiguous()
+        for _ in range(gaps_per_series):
+            n0 = 1 + (torch.rand((count, 1), generator=gen, **f64) * (N - 1)).long().clamp_(max=N - 2)
+            t = t + gap * (hit & (rows >= n0)).to(torch.float64)
+        t = t.contiguous()
     y = torch.sin(t) + noise
     k = torch.arange(Jc, **f64)[None, :]
     S0 = 5.0 * 0.7**k
@@ -89,7 +92,7 @@ def device_coeffs_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, 
     return t, diag, y, ac, bc, cc, dc
 
 
-def device_batch_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0):
+def device_batch_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, gap=10.0, gaps_per_series=1):
     """Same synthetic distribution as device_batch, but drawn with torch's device generator (seeded with
     seed0 + first) so that very large shards (65536 x 4096) are ready in a fraction of a second.  Used by
     bench.py; parity tests use the numpy recipe (host_inputs) so that the CPU oracle sees identical numbers."""
@@ -97,7 +100,7 @@ def device_batch_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, g
 
     from . import ops
 
-    t, diag, y, ac, bc, cc, dc = device_coeffs_fast(first, count, N, J, device, seed0, gap_fraction, gap)
+    t, diag, y, ac, bc, cc, dc = device_coeffs_fast(first, count, N, J, device, seed0, gap_fraction, gap, gaps_per_series)
     ar = torch.zeros((count, 0), dtype=torch.float64, device=device)
     c = torch.repeat_interleave(cc, 2, dim=1).contiguous()
     a, U, V = ops.get_celerite_matrices(ar, ac, bc, dc, t, diag)

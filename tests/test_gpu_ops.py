@@ -360,10 +360,11 @@ def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N, J):
 def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
     """Gaps in time (nights, seasons) under the one-lane mapping: the backward recursion of the reverse sweep cannot invert
     the decay across a gap, so the forward pass records an EXTRA checkpoint in front of it (wavefront-uniform, c2_loglik_t.hip)
-    and the sweep stays on the one-lane kernels -- the guard word (first double of the workspace) stays below 2 -- for a
-    few gappy series among many, for a shared grid with gaps, for gaps next to / on checkpoint rows and back to back; a
-    wavefront whose series all have their own gaps runs out of extra slots and the replay kernels take the batch.
-    Results are the oracle's in every case."""
+    and the sweep stays on the one-lane kernels -- the guard word (first double of the workspace: the largest of the
+    launch) stays below 2 -- for a few gappy series among many, for a shared grid with gaps, for gaps next to / on
+    checkpoint rows and back to back; a wavefront whose series all have their own gaps runs out of extra slots and the
+    replay kernels take ITS 64 series (the second word of the workspace counts the wavefronts that fell back), the rest
+    of the batch stays on the one-lane kernels.  Results are the oracle's in every case."""
     import torch
     monkeypatch.setenv("C2_LANES", "1")
     B, N = 150, 420   # (13 regular checkpoints and as many extra slots per wavefront)
@@ -382,12 +383,14 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
         work = ops.loglik_grad_workspace(B, N, J, args[2].device)
         ll, grads, flag = ops.loglik_grad(*args, work=work)
         torch.cuda.synchronize()
-        guard = float(work[0])
+        guard, nfall = float(work[0]), int(work[:2].view(torch.int64)[1])
         assert int(flag.abs().sum()) == 0
         close(ll, llo)
         for g, e in zip(grads, go):
             close(g, e, floor=floor)
         close(ops.loglik(*args)[0], llo)
+        assert (guard > 2.0) == (nfall > 0)
+        run.nfall = nfall
         return guard
 
     # (1) 5 % of the series with one gap of 100 mean spacings at a row of their own
@@ -413,15 +416,30 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
         + 12.0 * (t[:, hi - 1:hi] - t[:, lo:lo + 1]) * (np.arange(lo, N) >= hi)[None, :]
     assert np.diff(tg, axis=1).min() > 0
     assert run(tg) <= 2.0
-    # (5) every series of a wavefront with five gaps of its own (c_max * gap = 30 at every width): more extras than there
-    # are slots -> the replay kernels
+    # (5) every series with five gaps of its own (c_max * gap = 30 at every width): 320 gaps per full wavefront, more extras
+    # than there are slots (28) -> the replay kernels, for all three wavefronts
     tg = t.copy()
     for b in range(B):
         for n0 in rng.integers(1, N, size=5):
             tg[b, int(n0):] += 30.0 / c.max()
     # (750 gaps: bt next to a gap is the difference of two gap gradients -- one element in 63000 lands at 2.2e-12 of the
     # largest, on the replay kernels that passed the single-gap cases of the round-2 suite unchanged)
-    assert run(tg, floor=4e-12) > 2.0
+    assert run(tg, floor=4e-12) > 2.0 and run.nfall == 3
+    # (6) the same for the series of ONE wavefront only (64 .. 127): that wavefront falls back, its neighbours do not -- a
+    # wavefront that runs out of slots costs 64 series, not the batch -- and one series with two gaps in the last wavefront
+    tg = t.copy()
+    for b in range(64, 128):
+        for n0 in rng.integers(1, N, size=5):
+            tg[b, int(n0):] += 30.0 / c.max()
+    tg[140, 100:] += 10.0; tg[140, 300:] += 10.0
+    assert run(tg, floor=4e-12) > 2.0 and run.nfall == 1
+    # (7) three gaps of its own in every series of a batch whose wavefronts have the slots for them (N = 4096 in the bench's
+    # `gappy_all` object; here 8 series per wavefront would need B < 64: 9 series x 3 gaps = 27 <= 28 extras)
+    tg = t.copy()
+    for b in range(9):
+        for n0 in rng.integers(1, N, size=3):
+            tg[b, int(n0):] += 30.0 / c.max()
+    assert run(tg, floor=4e-12) <= 2.0 and run.nfall == 0
 
 
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])

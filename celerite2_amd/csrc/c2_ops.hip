@@ -1263,6 +1263,10 @@ static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) 
 // 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
 // 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken; 64 x 4096 with 8 right-hand sides 1.29 -> 0.40; 512 x 4096 with 8:
 // 1.45 -> 1.9, not taken -- the rule below is that cost model
+extern "C" size_t c2_internal_solve_cols_doubles(int64_t B, int64_t N, int64_t J, int64_t nrhs);
+extern "C" int c2_internal_solve_cols(int lower, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
+                                      const double *c, int64_t c_bs, const double *U, const double *W, const double *Y,
+                                      double *Z, double *scratch, c2_stream_t stream);
 static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   if (J > 8 || nrhs > 64 || N < long_min_rows()) return false;
   const int64_t k64 = B * ((N + 63) / 64);   // chunks of one launch: the right-hand sides run one after the other
@@ -1271,9 +1275,44 @@ static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   // 512 x 4096: 0.24); row by row N (0.15 + 0.025 nrhs) us whatever the batch (4096 rows: 0.63 with one right-hand side,
   // 1.29 with 8)
   const double chunked_ms = (double)nrhs * (opt::val(opt::k_solve_chunk_col_ms) + opt::val(opt::k_solve_chunk_ms) * (double)k64);
-  const double rows_ms = 1e-3 * (double)N * (opt::val(opt::k_solve_row_us) + opt::val(opt::k_solve_row_rhs_us) * (double)nrhs);
+  double rows_ms = 1e-3 * (double)N * (opt::val(opt::k_solve_row_us) + opt::val(opt::k_solve_row_rhs_us) * (double)nrhs);
+  if (nrhs > 8) {
+    // nine and more right-hand sides run with lanes over the right-hand sides (k_sweepK: 16 / 32 / 64 lanes per series,
+    // tiles of 64 columns side by side in the grid): a row costs one wavefront ~0.26 us whatever nrhs, and the launch as
+    // long as one wavefront needs while the chip holds all of them (profiles/r04_large_nrhs.md: 1 x 4096 with 256 or 1024
+    // right-hand sides 1.05 ms, 64 x 4096 with 256: 1.14 ms -- the linear-in-nrhs extrapolation above said 27 / 105 ms and
+    // sent 64 columns through the chunk maps one by one: 2.6 ms)
+    int64_t KL = 16;
+    while (KL < 64 && KL < nrhs) KL *= 2;
+    const double waves = (double)((B + 64 / KL - 1) / (64 / KL)) * (double)((nrhs + KL - 1) / KL);
+    rows_ms = 1e-3 * (double)N * 0.26 * (waves > 2048.0 ? waves / 2048.0 : 1.0);
+  }
   if (N >= 16384) return k64 * nrhs <= 32768 || chunked_ms < rows_ms;
   return chunked_ms < rows_ms;
+}
+// Many right-hand sides on a small batch: the chunk maps with lanes over the columns (c2_solve_cols.hip) against the row-by-row
+// kernel with lanes over the right-hand sides.  Measured (profiles/r04_large_nrhs.md): a row costs a wavefront of k_sweepK
+// ~0.26 us and the launch as long as ONE wavefront needs while the chip holds all of them; the chunked form walks 2 x Lc
+// rows per wavefront (~0.3 us a step) behind a chain of ~0.3 us per chunk and three launches.
+static bool solve_cols_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
+  if (opt::has(opt::k_solve_cols)) return opt::ival(opt::k_solve_cols) != 0 && J <= 16 && N >= 2 && B <= 65535;
+  if (J > 16 || nrhs < 16 || N < opt::ival(opt::k_solve_cols_min_rows) || B > 65535) return false;
+  const double wide = J > 8 ? 1.3 : 1.0;
+  int64_t KL = 16;
+  while (KL < 64 && KL < nrhs) KL *= 2;
+  const double tiles = (double)((nrhs + 63) / 64);
+  const double waves = (double)((B + 64 / KL - 1) / (64 / KL)) * (double)((nrhs + KL - 1) / KL);
+  // row by row: one wavefront's N steps of 0.26 us while the chip holds the launch, the bytes at ~3 TB/s beyond
+  const double bytes = (double)B * (double)N * 8.0 * (double)(2 * nrhs + 2 * J + 1);
+  double rows_ms = 1e-3 * (double)N * 0.26 * wide * (waves > 2048.0 ? waves / 2048.0 : 1.0);
+  if (bytes / 3e9 > rows_ms) rows_ms = bytes / 3e9;
+  // chunk maps over the columns: 0.12 ms for the three launches and their temporary + 4e-5 ms per wavefront-walk of 64 rows
+  // (1 x 4096: 0.16 ms with 64 or 256 right-hand sides, 0.43 with 1024; 64 x 4096: 0.38 / 0.84 / 2.8 ms)
+  int64_t Lc = 64;
+  while (Lc < 1024 && (double)B * (double)((N + Lc - 1) / Lc) * tiles > 8192.0) Lc *= 2;   // (the plan of c2_solve_cols.hip)
+  const double K = (double)((N + Lc - 1) / Lc), cw = (double)B * K * (tiles + 1.0) * (double)Lc / 64.0;
+  const double cols_ms = 0.12 + 4e-5 * wide * cw;
+  return cols_ms < 0.8 * rows_ms;
 }
 static bool solve_chunks_enabled() {
   return !(opt::has(opt::k_timepar) && opt::ival(opt::k_timepar) == 0);   // the switch of the time-parallel solves: 0 keeps them row by row
@@ -1306,6 +1345,23 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
       while (Lc < 16384 && B * ((N + 2 * Lc - 1) / (2 * Lc)) >= 2048) Lc *= 2;
       return c2_internal_matmul_chunked(LOWER ? 1 : 0, B, N, J, nrhs, Lc, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,
                                         stream);
+    }
+  }
+  if (SOLVE && !F && solve_cols_shape(B, N, J, nrhs)) {
+    // many right-hand sides on a small batch (apply_inverse on an N x M matrix, core.py:56-60): chunk maps with lanes over
+    // the columns, every column in the same three launches (c2_solve_cols.hip).  Scratch is a stream-ordered temporary;
+    // not inside graph captures.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);
+    if (capturing == hipStreamCaptureStatusNone) {
+      const size_t nd = c2_internal_solve_cols_doubles(B, N, J, nrhs);
+      void *tmp = nullptr;
+      if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+        int rc = c2_internal_solve_cols(LOWER ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, (double *)tmp, stream);
+        if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+        if (rc != C2_ERR_UNSUPPORTED) return rc;
+      }
+      (void)hipGetLastError();
     }
   }
   if (SOLVE && solve_chunks_shape(B, N, J, nrhs) && solve_chunks_enabled()) {

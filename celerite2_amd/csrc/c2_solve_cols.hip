@@ -1,0 +1,221 @@
+// c2_solve_cols.hip -- solve_lower / solve_upper with MANY right-hand sides on a SMALL batch: apply_inverse on an N x M
+// matrix (python/celerite2/core.py:56-60: Kinv_KxsT, the predictive variance / covariance of core.py:134-150; SURVEY.md
+// section 8f-4), the reference's own use case being ONE light curve.
+//
+// Row by row (k_sweepK, c2_sweep.hip) such a call is a handful of wavefronts walking N dependent steps of ~0.26 us: one
+// series of 4096 rows takes 1.05 ms with 64 or with 1024 right-hand sides (profiles/r04_large_nrhs.md).  The recursion
+// (internal.hpp:135-145 / 177-188), written for the state G_n = F_n + A_n z_n (after row n is absorbed, before the decay
+// into the next row),
+//     F = P_n G_{n-1} ,   z_n = y_n - B_n . F ,   G_n = F + A_n z_n          (lower: A = W, B = U; upper: A = U, B = W)
+// is AFFINE in G with a propagator (I - A_n B_n^T) P_n that does not depend on the right-hand side, so a chunk of rows maps
+// the state it receives as G_end = Phi G_start + g, Phi (J x J) shared by every column, g one J-vector per column:
+//   1. k_cols_walk<MODE 0>: every (series, chunk, tile of 64 columns) one wavefront, LANES OVER THE COLUMNS, zero start
+//      state -> g; one more tile per (series, chunk) walks J "virtual columns" with y = 0 and start states e_j -> the
+//      columns of Phi (the same code: linearity);
+//   2. k_cols_chain: a thread per (series, column) applies the chunk maps one after the other -> the state every chunk
+//      starts from (in place of g);
+//   3. k_cols_walk<MODE 1>: the same walk from the true start states, writing z.
+// Nothing is inverted and the maps are contractions (they carry decay factors <= 1), so there is nothing to verify; the
+// result differs from the row-by-row kernel by rounding only.  Z may alias Y (pass 1 has read every row before pass 3
+// writes).  No workspace F here: calls that ask for it keep their row-by-row / column-by-column forms.
+#include <cstdint>
+
+#include "../../include/celerite2_amd.h"
+#include "c2_common.hpp"
+#include "c2_loglik_helpers.hpp"
+
+namespace c2cols {
+using namespace c2;
+
+// step s of the walk <-> row n: lower 0 .. N-1, upper N-1 .. 0
+template <bool LOWER>
+__device__ __forceinline__ int64_t rowof(int64_t s, int64_t N) { return LOWER ? s : N - 1 - s; }
+
+// Gbuf: [series][chunk][JM][ncolp] (columns fastest: coalesced for the lanes of a walk and the threads of the chain)
+// Phi : [series][chunk][JM][JM]    (Phi(i, j) at i * JM + j)
+template <int JM, bool LOWER, int MODE>
+__global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t nrhs, int64_t Lc, int64_t K, int ntile,
+                                                     const double *__restrict__ t, int64_t t_bs,
+                                                     const double *__restrict__ c, int64_t c_bs,
+                                                     const double *__restrict__ U, const double *__restrict__ W,
+                                                     const double *Y, double *Z, double *__restrict__ Phi,
+                                                     double *__restrict__ Gbuf, int64_t ncolp) {
+  __shared__ __attribute__((aligned(16))) double rowbuf[2][3][JM];   // p_n, A_n, B_n of two consecutive steps
+  const int lane = threadIdx.x;
+  const int64_t k = blockIdx.x, b = blockIdx.z;
+  const int tile = blockIdx.y;
+  const bool phi_tile = MODE == 0 && tile == ntile;   // the J virtual columns that give Phi
+  int64_t col = (int64_t)tile * kWave + lane;
+  const bool vcol = !phi_tile && col < nrhs;
+  if (col >= nrhs) col = nrhs - 1;                    // clamped copies of the last column (their results are not kept)
+  const bool actj = lane < J;                          // this lane also carries element `lane` of the width-J vectors
+  const int jl = actj ? lane : 0;
+  const double *tb = t + b * t_bs;
+  const double *Ab = (LOWER ? W : U) + b * N * J + jl;   // row fed into the state
+  const double *Bb = (LOWER ? U : W) + b * N * J + jl;   // row applied to the state
+  const double *yb = Y + b * N * nrhs + col;
+  double *zb = Z + b * N * nrhs + col;
+  const double cj = actj ? c[b * c_bs + lane] : 0.0;
+  const int64_t s_lo = k * Lc, s_hi = (s_lo + Lc < N) ? s_lo + Lc : N;
+  double *gb = Gbuf + ((b * K + k) * JM) * ncolp + (int64_t)tile * kWave + lane;   // element j at gb[j * ncolp]
+
+  double G[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) {
+    if (MODE == 1) G[j] = gb[j * ncolp];
+    else G[j] = (phi_tile && lane == j) ? 1.0 : 0.0;
+  }
+  // A walk is short (Lc rows) and there are many of them: what a step costs is the latency of its loads, so the rows are
+  // requested R steps ahead into a register ring (one step ahead: 0.75 us a step, profiles/r04_large_nrhs.md)
+  constexpr int R = JM <= 8 ? 8 : 4;   // (width 16 with a ring of eight rows spills: 64 x 4096 x 64 right-hand sides 0.6 -> 2.8 ms)
+  double rt[R], ra[R], rb[R], ry[R];
+  auto load_row = [&](int r, int64_t s) {
+    const int64_t nn = rowof<LOWER>(s < s_hi ? s : s_hi - 1, N);
+    rt[r] = tb[nn];
+    ra[r] = actj ? Ab[nn * J] : 0.0;
+    rb[r] = actj ? Bb[nn * J] : 0.0;
+    ry[r] = phi_tile ? 0.0 : yb[nn * nrhs];
+  };
+  double tprev = tb[rowof<LOWER>(s_lo > 0 ? s_lo - 1 : 0, N)];
+#pragma unroll
+  for (int r = 0; r < R; ++r) load_row(r, s_lo + r);
+  int q = 0;
+  auto step = [&](const int r, const int64_t s) __attribute__((always_inline)) {
+    const int64_t n = rowof<LOWER>(s, N);
+    const double tn = rt[r], an = ra[r], bn = rb[r], yn = ry[r];
+    load_row(r, s + R);
+    // exp(-c |dt|) with the negative difference inside (internal.hpp:139, 182); step 0: dt = 0, p = 1 exactly, G = 0
+    const double p = exp_decay(cj * (LOWER ? tprev - tn : tn - tprev));
+    tprev = tn;
+    if (lane < JM) { rowbuf[q][0][lane] = actj ? p : 0.0; rowbuf[q][1][lane] = an; rowbuf[q][2][lane] = bn; }
+    lds_order();
+    double red0 = 0.0, red1 = 0.0;   // (two partial sums: half the dependent chain)
+#pragma unroll
+    for (int j = 0; j < JM; j += 2) {
+      const double2 p2 = *reinterpret_cast<const double2 *>(&rowbuf[q][0][j]);
+      const double2 b2 = *reinterpret_cast<const double2 *>(&rowbuf[q][2][j]);
+      G[j] *= p2.x;                  // F = P G: internal.hpp:143 / 186
+      G[j + 1] *= p2.y;
+      red0 = fma(b2.x, G[j], red0);
+      red1 = fma(b2.y, G[j + 1], red1);
+    }
+    const double zn = yn - (red0 + red1);      // internal.hpp:144 / 187
+    if (MODE == 1 && vcol) zb[n * nrhs] = zn;
+#pragma unroll
+    for (int j = 0; j < JM; j += 2) {
+      const double2 a2 = *reinterpret_cast<const double2 *>(&rowbuf[q][1][j]);
+      G[j] = fma(a2.x, zn, G[j]);    // internal.hpp:140 / 183 (the state the next row decays)
+      G[j + 1] = fma(a2.y, zn, G[j + 1]);
+    }
+    q ^= 1;
+  };
+  int64_t s0 = s_lo;
+  for (; s0 + R <= s_hi; s0 += R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) step(r, s0 + r);
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (s0 + r < s_hi) step(r, s0 + r);
+  if (MODE == 0) {
+    if (phi_tile) {
+      if (lane < JM) {
+        double *ph = Phi + (b * K + k) * (JM * JM);
+#pragma unroll
+        for (int i = 0; i < JM; ++i) ph[i * JM + lane] = (lane < J && i < J) ? G[i] : 0.0;   // column `lane` of Phi
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < JM; ++j) gb[j * ncolp] = G[j];
+    }
+  }
+}
+
+// Gbuf[chunk] <- the state the chunk starts from (it held g of the chunk): G_{k+1} = Phi_k G_k + g_k, G_0 = 0
+template <int JM>
+__global__ __launch_bounds__(kWave) void k_cols_chain(int64_t K, const double *__restrict__ Phi, double *__restrict__ Gbuf,
+                                                      int64_t ncolp) {
+  const int64_t b = blockIdx.y, col = (int64_t)blockIdx.x * kWave + threadIdx.x;   // (ncolp is a multiple of 64)
+  double G[JM], g[JM], gn[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) { G[j] = 0.0; g[j] = Gbuf[((b * K) * JM + j) * ncolp + col]; }
+  for (int64_t k = 0; k < K; ++k) {
+    double *gb = Gbuf + ((b * K + k) * JM) * ncolp + col;
+    const double *ph = Phi + (b * K + k) * (JM * JM);
+    const int64_t kn = k + 1 < K ? k + 1 : k;   // the next chunk's g is requested before this chunk's products
+#pragma unroll
+    for (int i = 0; i < JM; ++i) gn[i] = Gbuf[((b * K + kn) * JM + i) * ncolp + col];
+#pragma unroll
+    for (int i = 0; i < JM; ++i) gb[i * ncolp] = G[i];
+#pragma unroll
+    for (int i = 0; i < JM; ++i) {
+      double v = g[i];
+#pragma unroll
+      for (int j = 0; j < JM; ++j) v = fma(ph[i * JM + j], G[j], v);
+      g[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < JM; ++i) { G[i] = g[i]; g[i] = gn[i]; }
+  }
+}
+
+struct Plan {
+  int JM;
+  int64_t Lc, K, ncolp;
+  int ntile;
+  size_t phi, gbuf, total;   // doubles
+};
+static Plan plan(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
+  Plan p;
+  p.JM = J <= 8 ? 8 : 16;
+  p.ntile = (int)((nrhs + kWave - 1) / kWave);
+  p.ncolp = (int64_t)p.ntile * kWave;
+  // chunks of 64 rows while the launch stays within a few wavefronts per SIMD; longer ones beyond (the walks are what
+  // costs: one step ~0.3 us; the chain costs ~0.2 us a chunk)
+  p.Lc = 64;
+  while (p.Lc < 1024 && B * ((N + p.Lc - 1) / p.Lc) * p.ntile > 8192) p.Lc *= 2;
+  p.K = (N + p.Lc - 1) / p.Lc;
+  p.phi = 0;
+  p.gbuf = (size_t)B * p.K * p.JM * p.JM;
+  p.total = p.gbuf + (size_t)B * p.K * p.JM * p.ncolp;
+  return p;
+}
+
+}  // namespace c2cols
+
+using namespace c2cols;
+
+extern "C" {
+
+// scratch of c2_internal_solve_cols, in doubles (0: shape not supported)
+size_t c2_internal_solve_cols_doubles(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
+  if (B < 1 || N < 2 || J < 1 || J > 16 || nrhs < 1) return 0;
+  return plan(B, N, J, nrhs).total;
+}
+
+// solve_lower (lower != 0) / solve_upper with nrhs columns of row-major Y, Z (B, N, nrhs); W is the factor's W.  Z may
+// alias Y.  scratch: c2_internal_solve_cols_doubles(B, N, J, nrhs) doubles.
+int c2_internal_solve_cols(int lower, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
+                           const double *c, int64_t c_bs, const double *U, const double *W, const double *Y, double *Z,
+                           double *scratch, c2_stream_t stream) {
+  if (B < 1 || N < 2 || J < 1 || J > 16 || nrhs < 1 || B > 65535) return C2_ERR_UNSUPPORTED;
+  const Plan p = plan(B, N, J, nrhs);
+  hipStream_t s = (hipStream_t)stream;
+  double *Phi = scratch + p.phi, *Gbuf = scratch + p.gbuf;
+  const dim3 g0((unsigned)p.K, (unsigned)(p.ntile + 1), (unsigned)B), g1((unsigned)p.K, (unsigned)p.ntile, (unsigned)B);
+  const dim3 gc((unsigned)p.ntile, (unsigned)B);
+#define C2_COLS(JM_, LO)                                                                                              \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((k_cols_walk<JM_, LO, 0>), g0, dim3(kWave), 0, s, N, (int)J, nrhs, p.Lc, p.K, p.ntile, t, t_bs, c, \
+                       c_bs, U, W, Y, Z, Phi, Gbuf, p.ncolp);                                                          \
+    hipLaunchKernelGGL((k_cols_chain<JM_>), gc, dim3(kWave), 0, s, p.K, (const double *)Phi, Gbuf, p.ncolp);           \
+    hipLaunchKernelGGL((k_cols_walk<JM_, LO, 1>), g1, dim3(kWave), 0, s, N, (int)J, nrhs, p.Lc, p.K, p.ntile, t, t_bs, c, \
+                       c_bs, U, W, Y, Z, Phi, Gbuf, p.ncolp);                                                          \
+  } while (0)
+  if (p.JM == 8) { if (lower) C2_COLS(8, true); else C2_COLS(8, false); }
+  else { if (lower) C2_COLS(16, true); else C2_COLS(16, false); }
+#undef C2_COLS
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1024,6 +1024,49 @@ def test_large_nrhs_solves(ops, oracle, J, nrhs, B, N):
                 close(r_[b], e_)
 
 
+@pytest.mark.parametrize("J,nrhs,B,N", [(8, 64, 1, 700), (8, 130, 3, 129), (16, 65, 2, 257), (12, 5, 2, 64), (3, 1, 4, 65),
+                                        (5, 70, 1, 2100), (1, 64, 2, 63), (8, 16, 70, 200), (2, 200, 1, 2), (7, 33, 2, 1025)])
+def test_many_rhs_solves_as_chunk_maps_over_columns(ops, oracle, monkeypatch, J, nrhs, B, N):
+    """c2_solve_cols.hip forced (option solve_cols = 1): solve_lower / solve_upper without workspace as chunk maps with
+    lanes over the right-hand sides -- every width up to 16 (padded to 8 / 16), ragged column tiles (65, 130, 200), series
+    shorter than / equal to / just beyond a chunk of 64 rows, N = 2, more series than one launch dimension needs, shared
+    grid -- out of place and in place, against the oracle and against the row-by-row kernels (option = 0)."""
+    import torch
+    rng = np.random.default_rng(13 * J + nrhs + N)
+    Je = J if J % 2 == 0 else J + 1
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, Je)
+    d_, W_ = np.empty_like(a), np.empty_like(V)
+    for b in range(B):
+        oracle.factor(t[b], c[b], a[b], U[b], V[b], d_[b], W_[b], np.empty((N, Je, Je)))
+    U = np.ascontiguousarray(U[:, :, :J]); c = np.ascontiguousarray(c[:, :J]); W = np.ascontiguousarray(W_[:, :, :J])
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Wd, Yd = dev(t, c, U, W, Y)
+    for name in ("solve_lower", "solve_upper"):
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], W[b], Y[b], Zo[b], Fo[b])
+        monkeypatch.setenv("C2_SOLVE_COLS", "1")
+        Z1 = getattr(ops, name)(td, cd, Ud, Wd, Yd)
+        close(Z1, Zo)
+        Yc = Yd.clone()
+        close(getattr(ops, name)(td, cd, Ud, Wd, Yc, Z=Yc), Zo)
+        monkeypatch.setenv("C2_SOLVE_COLS", "0")
+        Z0 = getattr(ops, name)(td, cd, Ud, Wd, Yd)
+        close(Z0, Zo)
+        assert float((Z1 - Z0).abs().max()) <= 1e-11 * max(1.0, float(Z0.abs().max()))
+        monkeypatch.delenv("C2_SOLVE_COLS")
+    # a grid shared by the batch
+    monkeypatch.setenv("C2_SOLVE_COLS", "1")
+    t0 = np.ascontiguousarray(t[0]); c0 = np.ascontiguousarray(c[0])
+    (t0d, c0d) = dev(t0, c0)
+    U0 = np.ascontiguousarray(np.tile(U[:1], (B, 1, 1))); W0 = np.ascontiguousarray(np.tile(W[:1], (B, 1, 1)))
+    Zs = ops.solve_lower(t0d, c0d, *dev(U0, W0), Yd)
+    Zo = np.empty_like(Y)
+    for b in range(B):
+        oracle.solve_lower_fwd(t0, c0, U0[b], W0[b], Y[b], Zo[b], np.empty((N, J, nrhs)))
+    close(Zs, Zo)
+
+
 @pytest.mark.parametrize("N,M", [(2000, 128), (1200, 256), (700, 500)])
 def test_large_nrhs_apply_inverse_vs_dense(ops, N, M):
     """apply_inverse on an N x M matrix (M in the hundreds) against the dense K^-1 (numpy Cholesky) on N <= 2000:

@@ -1043,7 +1043,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
       return C2_ERR_UNSUPPORTED;
     }
     void *tmp = nullptr;
-    if (hipMallocAsync(&tmp, c2_wide_loglik_doubles(B, N, J) * sizeof(double), ws) != hipSuccess) return C2_ERR_HIP;
+    if (c2::temp_alloc(&tmp, c2_wide_loglik_doubles(B, N, J) * sizeof(double), ws) != hipSuccess) return C2_ERR_HIP;
     int rc = c2_wide_loglik(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp, stream);
     if (hipFreeAsync(tmp, ws) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
     return rc;
@@ -1062,7 +1062,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
     // d, W by Newton iterations on the chunk start states, z by the chunk-map solve, a reduction
     const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);
     void *tmp = nullptr;
-    if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+    if (nd > 0 && c2::temp_alloc(&tmp, nd * sizeof(double), s) == hipSuccess) {
       int rc = c2_internal_loglik_wide(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp, stream);
       if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
       return rc;
@@ -1075,7 +1075,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
     // temporary; without it (allocation refused) the ordinary kernel runs alone.
     const size_t nd = c2_internal_timepar_doubles(B, N, J);
     void *tmp = nullptr;
-    if (nd > 0 && hipMallocAsync(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {
+    if (nd > 0 && c2::temp_alloc(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {
       unsigned long long *guard = (unsigned long long *)tmp;
       int rc = c2_internal_loglik_timepar(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, (double *)tmp + 2, guard, stream);
       if (rc == C2_OK)
@@ -1133,7 +1133,7 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
   const bool may_alloc = capturing == hipStreamCaptureStatusNone;
   auto room = [&](size_t nd, void **tmp) {   // the caller's scratch, else a stream-ordered temporary
     if (scratch) { *tmp = scratch; return true; }
-    return may_alloc && hipMallocAsync(tmp, nd * sizeof(double), s) == hipSuccess;
+    return may_alloc && c2::temp_alloc(tmp, nd * sizeof(double), s) == hipSuccess;
   };
   auto release = [&](void *tmp, int rc) {
     if (!scratch && hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
@@ -1215,7 +1215,7 @@ extern "C" int c2_internal_factor_rev_long(int64_t B, int64_t N, int64_t J, cons
   if (capturing != hipStreamCaptureStatusNone) return C2_ERR_UNSUPPORTED;   // a stream-ordered temporary below
   const size_t nd = C2_TPG_PICK(c2_internal_factor_rev_timepar_doubles)(B, N, J);
   void *tmp = nullptr;
-  if (nd == 0 || hipMallocAsync(&tmp, nd * sizeof(double), s) != hipSuccess) {
+  if (nd == 0 || c2::temp_alloc(&tmp, nd * sizeof(double), s) != hipSuccess) {
     (void)hipGetLastError();
     return C2_ERR_UNSUPPORTED;
   }
@@ -1245,7 +1245,7 @@ extern "C" int c2_internal_factor_states_timepar(int64_t B, int64_t N, int64_t J
   if (capturing != hipStreamCaptureStatusNone) return C2_ERR_UNSUPPORTED;   // stream-ordered temporaries below
   const size_t nd = C2_TPG_PICK(c2_internal_s_rows_doubles)(B, N, J);
   void *tmp = nullptr;
-  if (nd == 0 || hipMallocAsync(&tmp, nd * sizeof(double), s) != hipSuccess) {
+  if (nd == 0 || c2::temp_alloc(&tmp, nd * sizeof(double), s) != hipSuccess) {
     (void)hipGetLastError();
     return C2_ERR_UNSUPPORTED;
   }

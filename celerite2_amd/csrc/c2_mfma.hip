@@ -292,7 +292,7 @@ int run(int64_t B, int64_t N, int64_t nrhs, const double *t, int64_t t_bs, const
   const size_t bytes = sizeof(double) * (n_carry + n_dc + n_rs);
   double *carry = nullptr;
   bool async = true;
-  if (hipMallocAsync((void **)&carry, bytes, s) != hipSuccess) {
+  if (c2::temp_alloc((void **)&carry, bytes, s) != hipSuccess) {
     (void)hipGetLastError();
     async = false;
     if (hipMalloc((void **)&carry, bytes) != hipSuccess) return C2_ERR_HIP;

@@ -1356,7 +1356,7 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
     if (capturing == hipStreamCaptureStatusNone) {
       const size_t nd = c2_internal_solve_cols_doubles(B, N, J, nrhs);
       void *tmp = nullptr;
-      if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+      if (nd > 0 && c2::temp_alloc(&tmp, nd * sizeof(double), s) == hipSuccess) {
         int rc = c2_internal_solve_cols(LOWER ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, (double *)tmp, stream);
         if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
         if (rc != C2_ERR_UNSUPPORTED) return rc;
@@ -1375,7 +1375,7 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
       const size_t nd = sh == 2 ? c2_internal_solve_chunks_doubles16(B, N, J)
                                 : (sh == 1 ? c2_internal_solve_chunks_doubles32(B, N, J) : c2_internal_solve_chunks_doubles64(B, N, J));
       void *tmp = nullptr;
-      if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+      if (nd > 0 && c2::temp_alloc(&tmp, nd * sizeof(double), s) == hipSuccess) {
         int rc = (sh == 2 ? c2_internal_solve_chunks16 : (sh == 1 ? c2_internal_solve_chunks32 : c2_internal_solve_chunks64))(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V,
                                                                                Y, Z, (double *)tmp, stream, nrhs, F);
         if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
@@ -1393,7 +1393,7 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
     if (capturing == hipStreamCaptureStatusNone) {
       const size_t nd = c2_internal_timepar_solve_doubles(B, N, J);
       void *tmp = nullptr;
-      if (nd > 0 && hipMallocAsync(&tmp, nd * sizeof(double), s) == hipSuccess) {
+      if (nd > 0 && c2::temp_alloc(&tmp, nd * sizeof(double), s) == hipSuccess) {
         int rc = c2_internal_solve_timepar(LOWER ? 1 : 0, B, N, J, t, t_bs, c, c_bs, U, V, Y, Z, (double *)tmp, stream);
         if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
         return rc;
@@ -1464,7 +1464,7 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
     if (nd > 0) {
       hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(s, &capturing);
-      if (capturing != hipStreamCaptureStatusNone || hipMallocAsync(&tmp, nd * sizeof(double), s) != hipSuccess) {
+      if (capturing != hipStreamCaptureStatusNone || c2::temp_alloc(&tmp, nd * sizeof(double), s) != hipSuccess) {
         (void)hipGetLastError();
         tmp = nullptr;
       }
@@ -1491,7 +1491,7 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
     // without a caller workspace the state rows are pure overhead (2 x 8 J nrhs bytes per row): two phases pay off
     // for one or two right-hand sides (prediction); beyond that they only draw level with the sequential merge
     // (22.5 against 24 ms at nrhs = 8, measured with -DC2_GM_TWO_PHASE_MAX_NRHS=64), which needs no scratch memory
-    if (nrhs > C2_GM_TWO_PHASE_MAX_NRHS || fbytes > kGeneralTempMax || hipMallocAsync((void **)&Fw, fbytes, s) != hipSuccess) {
+    if (nrhs > C2_GM_TWO_PHASE_MAX_NRHS || fbytes > kGeneralTempMax || c2::temp_alloc((void **)&Fw, fbytes, s) != hipSuccess) {
       (void)hipGetLastError();
       C2_DISPATCH_G(group_size(J),
                     hipLaunchKernelGGL((k_general<G, KT, LOWER>), grid_for(B, G, (nrhs + KT - 1) / KT), dim3(kWave), 0,

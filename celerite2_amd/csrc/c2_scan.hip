@@ -186,7 +186,7 @@ int run_chunked(int64_t B, int64_t N, int64_t J, int64_t nrhs, int64_t Lc, const
   const size_t bytes = sizeof(double) * (size_t)B * nchunk * J * nrhs;
   double *carry = nullptr;
   bool async = true;
-  if (hipMallocAsync((void **)&carry, bytes, s) != hipSuccess) {
+  if (c2::temp_alloc((void **)&carry, bytes, s) != hipSuccess) {
     (void)hipGetLastError();
     async = false;
     if (hipMalloc((void **)&carry, bytes) != hipSuccess) return C2_ERR_HIP;

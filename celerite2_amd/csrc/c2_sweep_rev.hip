@@ -646,7 +646,7 @@ extern "C" int c2_internal_sweep_rev_long(int lower, int solve, int64_t B, int64
   const int64_t nblk = (N + kRowsPerBlock / JL - 1) / (kRowsPerBlock / JL);
   const size_t nws = (size_t)B * N * J * nrhs, npart = (size_t)B * nblk * J;
   void *tmp = nullptr;
-  if (hipMallocAsync(&tmp, (nws + npart) * sizeof(double), s) != hipSuccess) {
+  if (c2::temp_alloc(&tmp, (nws + npart) * sizeof(double), s) != hipSuccess) {
     (void)hipGetLastError();
     return C2_ERR_UNSUPPORTED;
   }

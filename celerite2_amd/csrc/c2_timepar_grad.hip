@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kWave) void k_starts_apply(int64_t N, int64_t K, co
 constexpr double kVerifyTol = 2e-12;   // (largest mismatch over 8528 stress draws: 9e-14, profiles/r03_timepar_verification.md)
 constexpr int kVerifyWords = 8;
 constexpr int kNewtonMax = 8;                       // Newton iterations of the factor at most (below)
-constexpr int kNewtonHdr = 2 * (kNewtonMax + 2);   // its words[0 .. kNewtonMax + 1]: the iterations' updates; then their kappas
+constexpr int kNewtonHdr = 3 * (kNewtonMax + 2);   // its words[0 .. kNewtonMax + 1]: the iterations' updates in units of half their tolerance; then their kappas; then the updates themselves
 __device__ __forceinline__ void publish_max(unsigned long long *w, double v) {   // (every lane of the wavefront calls it)
   v = (v == v) ? v : __builtin_huge_val();   // a NaN opens the gate
 #pragma unroll
@@ -1213,6 +1213,25 @@ __device__ __forceinline__ double newton_tol(const unsigned long long *kapw) {
   const double kap = __longlong_as_double((long long)*kapw);
   return fmin(kNewtonTol, kNewtonCondTol / fmax(kap, 1.0));
 }
+// ... and rounding does keep them above it once kappa passes a few hundred: the updates of a converged iteration sit at
+// 4e-15 (kappa = 90), 7e-15 (340), 1.1e-14 (1300), 2.6e-14 (5400) of the state -- the floor of float64, not an error that another
+// iteration removes -- while kNewtonCondTol / kappa asks for 7.7e-15 at kappa = 1300: round 3's rule sent every such batch
+// through all eight iterations AND the row-by-row kernel (the 1-D problem inside BASELINE configs[4], white noise 1 / A =
+// 0.0125: 2.4 -> 22 ms; tools/newton_words.py).  Convergence is quadratic, so an iteration whose PREDECESSOR's update was
+// already below kNewtonBasin started from a state good to ~0.1 kNewtonBasin^2: its own update is that floor, and it stands if it is below
+// kNewtonFloorTol (anything larger is not rounding).  d, W then carry kappa x floor -- what the row-by-row recursion carries
+// too (no float64 order beats eps kappa).
+constexpr double kNewtonBasin = 3e-7, kNewtonFloorTol = 1e-11;   // (updates go 1e-3 -> 1.2e-7 -> floor on the bench series: (3e-7)^2 x 0.1 = 1e-14)
+// half the tolerance iteration p is held to: kapw = its conditioning word; kapw + (kNewtonMax + 2) = its absolute update,
+// kapw + (kNewtonMax + 2) - 1 the previous iteration's (0 for the first: the memset)
+__device__ __forceinline__ double newton_half_tol(const unsigned long long *gate, const unsigned long long *kapw) {
+  double tol = newton_tol(kapw);
+  if (gate) {   // (iteration p >= 2)
+    const double prev = __longlong_as_double((long long)kapw[(kNewtonMax + 2) - 1]);
+    if (prev > 0.0 && prev <= kNewtonBasin) tol = fmax(tol, kNewtonFloorTol);
+  }
+  return 0.5 * tol;
+}
 template <int J>
 __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -1366,7 +1385,9 @@ __global__ __launch_bounds__(kWave) void k_newton_chain(int64_t K, double *__res
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
-  worst /= 0.5 * newton_tol(kapw);   // > 2 <=> above the tolerance
+  if (lane == 0 && worst > 0.0)
+    atomicMax(const_cast<unsigned long long *>(kapw) + (kNewtonMax + 2), (unsigned long long)__double_as_longlong(worst));
+  worst /= newton_half_tol(gate, kapw);   // > 2 <=> above the tolerance
   if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
 }
 
@@ -1516,7 +1537,9 @@ __global__ __launch_bounds__(kWave) void k_newton_apply(int64_t K, int64_t NB, d
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o, kWave));
-  worst /= 0.5 * newton_tol(kapw);
+  if (lane == 0 && worst > 0.0)
+    atomicMax(const_cast<unsigned long long *>(kapw) + (kNewtonMax + 2), (unsigned long long)__double_as_longlong(worst));
+  worst /= newton_half_tol(gate, kapw);
   if (lane == 0 && worst > 0.0) atomicMax(word, (unsigned long long)__double_as_longlong(worst));
 }
 

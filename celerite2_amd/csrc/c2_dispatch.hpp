@@ -40,6 +40,7 @@
   X(solve_chunk_ms, "C2_SOLVE_CHUNK_MS", 6e-6, 't', "... cost (ms) per 64-row chunk and right-hand side", "same measurement") \
   X(solve_row_us, "C2_SOLVE_ROW_US", 0.15, 't', "... against the row-by-row sweep: microseconds per row whatever the batch", "4096 rows: 0.63 ms with one right-hand side") \
   X(solve_row_rhs_us, "C2_SOLVE_ROW_RHS_US", 0.025, 't', "... plus microseconds per row and right-hand side", "4096 rows: 1.29 ms with 8 right-hand sides") \
+  X(sweep_cols, "C2_SWEEP_COLS", 1, 's', "0: forward sweeps with 9 .. 32 right-hand sides at J = 8 (no workspace) on the lanes-over-rhs kernel (16 / 32 lanes per series) instead of eight lanes per series with several columns per lane and Y / Z in groups of four rows", "B = 8192, N = 4096: profiles/r04_nrhs_scan.md") \
   X(solve_cols, "C2_SOLVE_COLS", 0, 's', "solve_lower / solve_upper without workspace as chunk maps with lanes over the right-hand sides (every column in the same three launches; J <= 16): 1 forces, 0 disables; unset: 16 and more right-hand sides on small batches, by the cost model of solve_cols_shape", "1 x 4096 with 1024 right-hand sides: profiles/r04_large_nrhs.md") \
   X(solve_cols_min_rows, "C2_SOLVE_COLS_MIN_ROWS", 512, 't', "shortest series that form takes", "below, a launch is a few hundred steps of 0.26 us: nothing to gain behind three launches") \
   X(mfma, "C2_MFMA", 1, 's', "0: long-series products (J = 16; 16 / 32 / 64 right-hand sides) on the VALU instead of the fp64 matrix cores", "N = 1e7: 3.1 vs 9.2 ms (profiles/r02_ubench_memory_and_mfma.md)") \

@@ -1263,6 +1263,9 @@ static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) 
 // 0.63 -> 0.15; 8 right-hand sides: 1 x 1024 0.32 -> 0.27, 1 x 8192 2.56 -> 0.45 (1 x 512: 0.16 -> 0.24, not taken);
 // 2048 x 1024 (32768 chunks) + F 0.20 -> 0.25, not taken; 64 x 4096 with 8 right-hand sides 1.29 -> 0.40; 512 x 4096 with 8:
 // 1.45 -> 1.9, not taken -- the rule below is that cost model
+extern "C" int c2_internal_sweep_cols(int lower, int solve, int64_t B, int64_t N, int64_t Jw, int64_t nrhs, const double *t,
+                                      int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                      const double *Y, double *Z, int64_t *B8, c2_stream_t stream);
 extern "C" size_t c2_internal_solve_cols_doubles(int64_t B, int64_t N, int64_t J, int64_t nrhs);
 extern "C" int c2_internal_solve_cols(int lower, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
                                       const double *c, int64_t c_bs, const double *U, const double *W, const double *Y,
@@ -1406,6 +1409,19 @@ static int launch_sweep(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
   if (nrhs <= 7) {  // two to seven: lanes over J, per-series scalars transposed in time (c2_sweep_small.hip)
     const int e = c2_internal_sweepT(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z, stream);
     if (e != C2_ERR_UNSUPPORTED) return e;
+  }
+  if (!F && (SOLVE || zero_z) && nrhs >= 9 && nrhs <= 32 && J == 8) {
+    // nine to 32 right-hand sides at J = 8 on whole wavefronts of eight series: eight lanes per series, several columns per
+    // lane, Y / Z in groups of four rows (c2_sweep_cols.hip); the B % 8 series left over on the kernels below
+    int64_t B8 = 0;
+    const int e = c2_internal_sweep_cols(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, &B8, stream);
+    if (e != C2_ERR_UNSUPPORTED) {
+      if (e != C2_OK || B8 == B) return e;
+      const int64_t o = B8 * N;
+      t += B8 * t_bs; c += B8 * c_bs;
+      U += o * J; V += o * J; Y += o * nrhs; Z += o * nrhs;
+      B -= B8;
+    }
   }
   if (nrhs >= 3) {  // lanes over the right-hand sides (c2_sweep.hip) when the shape fits
     const int e = c2_internal_sweepK(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, zero_z,

@@ -1024,6 +1024,48 @@ def test_large_nrhs_solves(ops, oracle, J, nrhs, B, N):
                 close(r_[b], e_)
 
 
+@pytest.mark.parametrize("B,N,nrhs", [(8, 8, 9), (8, 9, 16), (16, 10, 10), (8, 11, 13), (13, 12, 12), (8, 131, 17), (24, 65, 24),
+                                      (9, 200, 31), (8, 66, 32), (16, 403, 11), (8, 37, 14), (8, 64, 20), (8, 8, 32), (8, 13, 25)])
+def test_forward_sweeps_nine_to_32_rhs_by_groups_of_rows(ops, oracle, monkeypatch, B, N, nrhs):
+    """9 .. 32 right-hand sides at J = 8 without the workspace (c2_sweep_cols.hip: eight lanes per series, two to four
+    columns per lane, Y / Z in groups of four rows): the four forward sweeps on whole wavefronts of eight series with the
+    B % 8 series left over on k_sweepK, odd and even counts (8- and 16-byte pieces), N from two groups up with every
+    remainder mod 4, in place (solves), products with zero_z and accumulating (the latter stays on the old kernel) --
+    against the oracle and against the lanes-over-rhs kernel alone (option sweep_cols = 0)."""
+    import torch
+    rng = np.random.default_rng(100 * nrhs + N + B)
+    J = 8
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Wd, Yd = dev(t, c, U, V, W, Y)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b])
+        Z1 = getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True)
+        close(Z1, Zo)
+        Zn = torch.full_like(Yd, float("nan"))
+        close(getattr(ops, name)(td, cd, Ud, secd, Yd, Z=Zn, zero_z=True), Zo)   # every element written, none read
+        Yc = Yd.clone()
+        close(getattr(ops, name)(td, cd, Ud, secd, Yc, Z=Yc), Zo if solve else Zo + Y)   # in place
+        monkeypatch.setenv("C2_SWEEP_COLS", "0")
+        Z0 = getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True)
+        monkeypatch.delenv("C2_SWEEP_COLS")
+        close(Z0, Zo)
+        assert float((Z1 - Z0).abs().max()) <= 1e-12 * max(1.0, float(Z0.abs().max()))
+    # a grid and rates shared by the batch
+    t0d, c0d = dev(np.ascontiguousarray(t[0]), np.ascontiguousarray(c[0]))
+    U0 = np.ascontiguousarray(np.tile(U[:1], (B, 1, 1))); W0 = np.ascontiguousarray(np.tile(W[:1], (B, 1, 1)))
+    Zs = ops.solve_upper(t0d, c0d, *dev(U0, W0), Yd)
+    Zo = np.empty_like(Y)
+    for b in range(B):
+        oracle.solve_upper_fwd(t[0], c[0], U0[b], W0[b], Y[b], Zo[b], np.empty((N, J, nrhs)))
+    close(Zs, Zo)
+
+
 @pytest.mark.parametrize("J,nrhs,B,N", [(8, 64, 1, 700), (8, 130, 3, 129), (16, 65, 2, 257), (12, 5, 2, 64), (3, 1, 4, 65),
                                         (5, 70, 1, 2100), (1, 64, 2, 63), (8, 16, 70, 200), (2, 200, 1, 2), (7, 33, 2, 1025)])
 def test_many_rhs_solves_as_chunk_maps_over_columns(ops, oracle, monkeypatch, J, nrhs, B, N):

@@ -14,10 +14,19 @@ def timed(fn, reps=5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return sorted(ts)[len(ts) // 2]
+FWD_ONLY = os.environ.get("C2_SCAN_FWD_ONLY", "0") == "1"
 for nrhs in [int(v) for v in sys.argv[1:]] or [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16]:
     Y = torch.randn((B, N, nrhs), dtype=torch.float64, device=dev); Zo = torch.empty_like(Y)
     F = torch.empty((B, N, J, nrhs), dtype=torch.float64, device=dev); bZ = torch.randn_like(Y)
     f1 = timed(lambda: ops.solve_lower(t, c, U, W, Y, Z=Zo))
+    if FWD_ONLY:
+        byf = B * N * 8 * (1 + 2 * J + 2 * nrhs) / 8e12 * 1e3
+        fu = timed(lambda: ops.solve_upper(t, c, U, W, Y, Z=Zo))
+        fm = timed(lambda: ops.matmul_lower(t, c, U, V, Y, Z=Zo, zero_z=True))
+        print("nrhs %2d: solve_lower %.2f ms (%.2f)   solve_upper %.2f ms (%.2f)   matmul_lower (zero_z) %.2f ms (%.2f)" % (
+            nrhs, f1, byf / f1, fu, byf / fu, fm, byf / fm), flush=True)
+        del Y, Zo
+        continue
     f2 = timed(lambda: ops.solve_lower(t, c, U, W, Y, Z=Zo, F=F))
     Zs, Fs = ops.solve_lower(t, c, U, W, Y, workspace=True)
     r = timed(lambda: ops.solve_lower_rev(t, c, U, W, Y, Zs, Fs, bZ))

@@ -1266,6 +1266,10 @@ static bool matmul_chunked_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) 
 extern "C" int c2_internal_sweep_cols(int lower, int solve, int64_t B, int64_t N, int64_t Jw, int64_t nrhs, const double *t,
                                       int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
                                       const double *Y, double *Z, int64_t *B8, c2_stream_t stream);
+extern "C" int c2_internal_sweep_cols_rev(int lower, int solve, int64_t B, int64_t N, int64_t Jw, int64_t nrhs, const double *t,
+                                          int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
+                                          const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
+                                          double *bc, double *bU, double *bV, double *bY, int64_t *B8, c2_stream_t stream);
 extern "C" size_t c2_internal_solve_cols_doubles(int64_t B, int64_t N, int64_t J, int64_t nrhs);
 extern "C" int c2_internal_solve_cols(int lower, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs,
                                       const double *c, int64_t c_bs, const double *U, const double *W, const double *Y,
@@ -1581,6 +1585,21 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
     const int e = c2_internal_sweepT_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt,
                                          bc, bU, bV, bY, stream);
     if (e != C2_ERR_UNSUPPORTED) return e;
+  }
+  if (nrhs >= 9 && nrhs <= 16 && J == 8) {
+    // nine to 16 right-hand sides at J = 8 on whole wavefronts of eight series: eight lanes per series, two columns per lane
+    // (c2_sweep_cols.hip); the B % 8 series left over on the kernels below
+    int64_t B8 = 0;
+    const int e = c2_internal_sweep_cols_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ,
+                                             bt, bc, bU, bV, bY, &B8, stream);
+    if (e != C2_ERR_UNSUPPORTED) {
+      if (e != C2_OK || B8 == B) return e;
+      const int64_t o = B8 * N;
+      t += B8 * t_bs; c += B8 * c_bs;
+      U += o * J; V += o * J; Y += o * nrhs; Z += o * nrhs; F += o * J * nrhs; bZ += o * nrhs;
+      bt += o; bc += B8 * J; bU += o * J; bV += o * J; bY += o * nrhs;
+      B -= B8;
+    }
   }
   {  // several right-hand sides: lanes over them (c2_sweep_rev.hip) where the shape fits; C2_SWEEPK_REV=0 for A/B runs
     if (!(opt::has(opt::k_sweepk_rev) && opt::ival(opt::k_sweepk_rev) == 0)) {

@@ -1066,6 +1066,38 @@ def test_forward_sweeps_nine_to_32_rhs_by_groups_of_rows(ops, oracle, monkeypatc
     close(Zs, Zo)
 
 
+@pytest.mark.parametrize("B,N,nrhs", [(8, 8, 9), (8, 9, 16), (16, 10, 10), (8, 11, 13), (13, 12, 12), (8, 131, 15), (16, 65, 16),
+                                      (9, 200, 11), (8, 66, 14), (8, 403, 9), (8, 13, 12), (24, 37, 16)])
+def test_reverse_sweeps_nine_to_16_rhs_two_columns_per_lane(ops, oracle, monkeypatch, B, N, nrhs):
+    """The reverse sweeps with 9 .. 16 right-hand sides at J = 8 (k_sweepC_rev, c2_sweep_cols.hip: eight lanes per series,
+    two columns per lane, groups of four rows, the row of the next group carried in slot 4): all four on whole wavefronts
+    of eight series with the B % 8 left over on k_sweepK_rev, odd and even counts, every N mod 4 from two groups up --
+    (bt, bc, bU, bV / bW, bY) of every series against the oracle and against the old kernel (option sweep_cols = 0)."""
+    rng = np.random.default_rng(77 * nrhs + N + B)
+    J = 8
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs)); bZ = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Vd, Wd, Yd, bZd = dev(t, c, U, V, W, Y, bZ)
+    for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
+        solve = name.startswith("solve")
+        sec, secd = (W, Wd) if solve else (V, Vd)
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b])
+        Zd, Fd = dev(Zo, Fo)
+        res = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+        monkeypatch.setenv("C2_SWEEP_COLS", "0")
+        old = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+        monkeypatch.delenv("C2_SWEEP_COLS")
+        for b in range(B):
+            outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+            getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+            for r_, o_, e_ in zip(res, old, outs):
+                close(r_[b], e_)
+                close(o_[b], e_)
+
+
 @pytest.mark.parametrize("J,nrhs,B,N", [(8, 64, 1, 700), (8, 130, 3, 129), (16, 65, 2, 257), (12, 5, 2, 64), (3, 1, 4, 65),
                                         (5, 70, 1, 2100), (1, 64, 2, 63), (8, 16, 70, 200), (2, 200, 1, 2), (7, 33, 2, 1025)])
 def test_many_rhs_solves_as_chunk_maps_over_columns(ops, oracle, monkeypatch, J, nrhs, B, N):

@@ -1586,8 +1586,8 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
                                          bc, bU, bV, bY, stream);
     if (e != C2_ERR_UNSUPPORTED) return e;
   }
-  if (nrhs >= 9 && nrhs <= 16 && J == 8) {
-    // nine to 16 right-hand sides at J = 8 on whole wavefronts of eight series: eight lanes per series, two columns per lane
+  if (nrhs >= 9 && nrhs <= 32 && J == 8) {
+    // nine to 32 right-hand sides at J = 8 on whole wavefronts of eight series: eight lanes per series, two to four columns per lane
     // (c2_sweep_cols.hip); the B % 8 series left over on the kernels below
     int64_t B8 = 0;
     const int e = c2_internal_sweep_cols_rev(LOWER ? 1 : 0, SOLVE ? 1 : 0, B, N, J, nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ,

@@ -242,7 +242,7 @@ constexpr int kB4 = 34;   // LDS stride (doubles) of a series in a tile of four 
 constexpr int kA5 = 42;   // ... of five width-8 rows: 336 B
 
 template <int NC, bool LOWER, bool SOLVE, bool V2>
-__global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int nrhs, const double *__restrict__ t,
+__global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int nrhs, int ld, int c0, int acc, const double *__restrict__ t,
                                                       int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                       const double *__restrict__ U, const double *__restrict__ V,
                                                       const double *__restrict__ Y, const double *__restrict__ Z,
@@ -254,7 +254,9 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
   constexpr int XS = 5 * NCP + 8;            // five rows of NCP columns: = 8 or 24 mod 32 doubles, conflict-free b64
   constexpr int ZS = 4 * NCP + 8;            // the bY tile (four rows)
   constexpr int FS = J * NCP + 8;            // a workspace row [column][j] per series
-  constexpr int NP = V2 ? 2 * NC : 4 * NC;   // pieces of 16 / 8 bytes per lane, group and nrhs-wide array
+  constexpr int PPR = V2 ? NC / 2 : NC;      // pieces of 16 / 8 bytes per lane and ROW of an nrhs-wide array
+  static_assert(!V2 || NC % 2 == 0, "16-byte pieces: an even number of columns per lane");
+  constexpr int NP = 4 * PPR;                // ... per group of four rows
   constexpr int NY = V2 ? 2 * NP : NP;
   constexpr int NF = 4 * NC;                 // 16-byte pieces of a workspace row per lane
   constexpr int RF = 2;                      // workspace rows in flight (four: 64 more registers, the kernel spills)
@@ -270,23 +272,26 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
   const double *tb = t + b * t_bs;
   const double *Bb = (LOWER ? U : V) + b * N * J, *Ab = (LOWER ? V : U) + b * N * J;
   double *bBb = (LOWER ? bU : bV) + b * N * J, *bAb = (LOWER ? bV : bU) + b * N * J;
-  const double *Xb = (SOLVE ? Z : Y) + b * N * (int64_t)nrhs, *Zb = bZ + b * N * (int64_t)nrhs;
-  double *bYb = bY + b * N * (int64_t)nrhs, *btb = bt + b * N;
-  const double *Fb = F + b * N * (int64_t)(J * nrhs);
+  // nrhs columns c0 .. c0 + nrhs - 1 of arrays whose rows hold ld of them (a slice of a wider right-hand side: the second
+  // slice ADDS its sums over the right-hand sides -- bt, bc, bB, bA -- to what the first one wrote: acc)
+  const double *Xb = (SOLVE ? Z : Y) + b * N * (int64_t)ld + c0, *Zb = bZ + b * N * (int64_t)ld + c0;
+  double *bYb = bY + b * N * (int64_t)ld + c0, *btb = bt + b * N;
+  const double *Fb = F + b * N * (int64_t)(J * ld) + (int64_t)c0 * J;
   const double cj = c[b * c_bs + k];
   constexpr double sgn = SOLVE ? -1.0 : 1.0;
   const int64_t G = (N + 3) >> 2;
-  const int64_t nelem = N * (int64_t)nrhs;
-  const int frow = J * nrhs;                    // doubles of a workspace row
+  const int frow = J * nrhs;                    // doubles of this slice of a workspace row
+  const int64_t fld = (int64_t)J * ld;          // ... and the pitch of the rows
   bool vq[NC];
 #pragma unroll
   for (int q = 0; q < NC; ++q) vq[q] = k + 8 * q < nrhs;
 
-  int poff[NP];   // offset of piece i in a tile of NCP-wide rows (-1: beyond the group)
+  // piece i of a group: row i / PPR of the group, columns (V2 ? 2 : 1) (k + 8 (i % PPR)) ...
+  int pcol[PPR];   // first column of this lane's piece i2 of a row (-1: beyond the slice)
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int e = (V2 ? 2 : 1) * (k + 8 * i);
-    poff[i] = e < 4 * nrhs ? (e / nrhs) * NCP + (e % nrhs) : -1;
+  for (int i2 = 0; i2 < PPR; ++i2) {
+    const int cc = (V2 ? 2 : 1) * (k + 8 * i2);
+    pcol[i2] = cc < nrhs ? cc : -1;
   }
   // ---- a group of four rows of every input: ONE register set, requested a group ahead (two sets do not fit the register
   // file next to the workspace rows); the row the m-indexed tiles keep of the group after it travels on its own -----------
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
     ct = tb[row];
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
-      const int64_t e = row * (int64_t)nrhs + (vq[q] ? k + 8 * q : 0);
+      const int64_t e = row * (int64_t)ld + (vq[q] ? k + 8 * q : 0);
       cx[q] = Xb[e]; cz[q] = Zb[e];
     }
   };
@@ -323,13 +328,12 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
     qt[S] = tb[trow];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      int64_t e = 4 * g * (int64_t)nrhs + (V2 ? 2 : 1) * (k + 8 * i);
+      int64_t row = 4 * g + i / PPR; row = row < N ? row : N - 1;
+      const int64_t e = row * (int64_t)ld + (pcol[i % PPR] >= 0 ? pcol[i % PPR] : 0);
       if constexpr (V2) {
-        e = e < nelem - 1 ? e : nelem - 2;
         const double2 vx = *reinterpret_cast<const double2 *>(Xb + e), vz = *reinterpret_cast<const double2 *>(Zb + e);
         qx[S][2 * i] = vx.x; qx[S][2 * i + 1] = vx.y; qz[S][2 * i] = vz.x; qz[S][2 * i + 1] = vz.y;
       } else {
-        e = e < nelem ? e : nelem - 1;
         qx[S][i] = Xb[e]; qz[S][i] = Zb[e];
       }
     }
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
     tq[sl][k & 3] = qt[S];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      if (poff[i] >= 0) {
-        const int o = sl * XS + poff[i];
+      if (pcol[i % PPR] >= 0) {
+        const int o = sl * XS + (i / PPR) * NCP + pcol[i % PPR];
         if constexpr (V2) {
           *reinterpret_cast<double2 *>(&Xq[o]) = make_double2(qx[S][2 * i], qx[S][2 * i + 1]);
           *reinterpret_cast<double2 *>(&Zq[o]) = make_double2(qz[S][2 * i], qz[S][2 * i + 1]);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
   auto req_F = [&](auto set_tag, int64_t n) {
     constexpr int S = decltype(set_tag)::value;
     n = n < 0 ? 0 : (n < N ? n : N - 1);
-    const double *a = Fb + n * (int64_t)frow;
+    const double *a = Fb + n * fld;
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
       int e = 2 * (k + 8 * i); e = e < frow ? e : frow - 2;
@@ -382,6 +386,16 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
     double2 v[2];
 #pragma unroll
     for (int l2 = 0; l2 < 2; ++l2) v[l2] = *reinterpret_cast<const double2 *>(&tile[sl * kB4 + (2 * l2 + hrow) * J + col2]);
+    if (acc) {   // (wavefront-uniform) the second slice of a wide right-hand side: add to the first slice's sums
+#pragma unroll
+      for (int l2 = 0; l2 < 2; ++l2) {
+        const int64_t row = 4 * g + 2 * l2 + hrow;
+        if (!GUARD || row < N) {
+          const double2 w = *reinterpret_cast<const double2 *>(base + row * J + col2);
+          v[l2].x += w.x; v[l2].y += w.y;
+        }
+      }
+    }
 #pragma unroll
     for (int l2 = 0; l2 < 2; ++l2) {
       const int64_t row = 4 * g + 2 * l2 + hrow;
@@ -393,14 +407,15 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
     double v[NY];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int o = sl * ZS + (poff[i] >= 0 ? poff[i] : 0);
+      const int o = sl * ZS + (i / PPR) * NCP + (pcol[i % PPR] >= 0 ? pcol[i % PPR] : 0);
       if constexpr (V2) { const double2 w = *reinterpret_cast<const double2 *>(&oY[o]); v[2 * i] = w.x; v[2 * i + 1] = w.y; }
       else v[i] = oY[o];
     }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const int64_t e = 4 * g * (int64_t)nrhs + (V2 ? 2 : 1) * (k + 8 * i);
-      if (poff[i] >= 0 && (!GUARD || e < nelem)) {
+      const int64_t row = 4 * g + i / PPR;
+      if (pcol[i % PPR] >= 0 && (!GUARD || row < N)) {
+        const int64_t e = row * (int64_t)ld + pcol[i % PPR];
         if constexpr (V2) *reinterpret_cast<double2 *>(bYb + e) = make_double2(v[2 * i], v[2 * i + 1]);
         else bYb[e] = v[i];
       }
@@ -408,8 +423,11 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
   };
   auto flush_t = [&](int64_t g, auto guard_tag) {
     constexpr bool GUARD = decltype(guard_tag)::value;
-    const double v = oT[sl][k & 3];
-    if (k < 4 && (!GUARD || 4 * g + k < N)) btb[4 * g + k] = v;
+    double v = oT[sl][k & 3];
+    if (k < 4 && (!GUARD || 4 * g + k < N)) {
+      if (acc) v += btb[4 * g + k];
+      btb[4 * g + k] = v;
+    }
   };
   using Yes = std::integral_constant<bool, true>;
   using No = std::integral_constant<bool, false>;
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
   }
   const int64_t nfar = LOWER ? N - 1 : 0, nnear = LOWER ? 0 : N - 1;
 #pragma unroll
-  for (int q = 0; q < NC; ++q) bzrun[q] = vq[q] ? Zb[nfar * nrhs + k + 8 * q] : 0.0;
+  for (int q = 0; q < NC; ++q) bzrun[q] = vq[q] ? Zb[nfar * (int64_t)ld + k + 8 * q] : 0.0;
   double carry = 0.0, bce = 0.0;
   // the far end receives nothing from the sweep: bA = 0, bY = its own cotangent (solves) or 0 (products)
   oA[sl * kB4 + (int)(nfar & 3) * J + k] = 0.0;
@@ -600,7 +618,7 @@ __global__ __launch_bounds__(kWave) void k_sweepC_rev(int64_t B, int64_t N, int 
   lds_order();
   flush_lines(oB, bBb, nnear >> 2, Yes{});
   flush_t(nnear >> 2, Yes{});
-  bc[b * J + k] = bce;
+  bc[b * J + k] = acc ? bc[b * J + k] + bce : bce;
 }
 
 }  // namespace c2sc
@@ -649,21 +667,30 @@ extern "C" int c2_internal_sweep_cols_rev(int lower, int solve, int64_t B, int64
                                           const double *Y, const double *Z, const double *F, const double *bZ, double *bt,
                                           double *bc, double *bU, double *bV, double *bY, int64_t *B8, c2_stream_t stream) {
   *B8 = 0;
-  if (Jw != 8 || nrhs < 9 || nrhs > 16 || B < 8 || N < 8) return C2_ERR_UNSUPPORTED;
+  if (Jw != 8 || nrhs < 9 || nrhs > 32 || B < 8 || N < 8) return C2_ERR_UNSUPPORTED;
   if ((((uintptr_t)U | (uintptr_t)V | (uintptr_t)F | (uintptr_t)bU | (uintptr_t)bV) % 16) != 0) return C2_ERR_UNSUPPORTED;
   if (c2::opt::has(c2::opt::k_sweep_cols) && c2::opt::ival(c2::opt::k_sweep_cols) == 0) return C2_ERR_UNSUPPORTED;
-  const bool v2 = (nrhs % 2 == 0) && (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)bZ | (uintptr_t)bY) % 16) == 0;
   const int64_t nb = B / 8;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((unsigned)nb);
+  // up to 16 right-hand sides in one launch; 17 .. 32 as two slices of the columns, the second adding its sums over the
+  // right-hand sides to the first one's (three and four columns per lane do not fit the register file: 50 - 160 ms)
+  const bool al16 = (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)bZ | (uintptr_t)bY) % 16) == 0 && nrhs % 2 == 0;
+  // (16 + the rest: two slices of about the same width measured no better -- 24 as 12 + 12: 26.8 against 23.3 ms -- a slice
+  // that does not start on a 128-byte line costs more than its columns)
+  for (int c0 = 0; c0 < (int)nrhs; c0 += 16) {
+    const int w = (int)nrhs - c0 < 16 ? (int)nrhs - c0 : 16;
+    const bool v2 = al16 && w % 2 == 0;
+    const int acc = c0 > 0 ? 1 : 0;
 #define C2_SCR(LO, SO, V2_)                                                                                             \
-  hipLaunchKernelGGL((k_sweepC_rev<2, LO, SO, V2_>), grid, dim3(kWave), 0, s, nb * 8, N, (int)nrhs, t, t_bs, c, c_bs, U, V, Y, \
-                     Z, F, bZ, bt, bc, bU, bV, bY)
+  hipLaunchKernelGGL((k_sweepC_rev<2, LO, SO, V2_>), grid, dim3(kWave), 0, s, nb * 8, N, w, (int)nrhs, c0, acc, t, t_bs, c, \
+                     c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY)
 #define C2_SCR_V(LO, SO) do { if (v2) C2_SCR(LO, SO, true); else C2_SCR(LO, SO, false); } while (0)
-  if (lower) { if (solve) C2_SCR_V(true, true); else C2_SCR_V(true, false); }
-  else { if (solve) C2_SCR_V(false, true); else C2_SCR_V(false, false); }
+    if (lower) { if (solve) C2_SCR_V(true, true); else C2_SCR_V(true, false); }
+    else { if (solve) C2_SCR_V(false, true); else C2_SCR_V(false, false); }
 #undef C2_SCR_V
 #undef C2_SCR
+  }
   if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
   *B8 = nb * 8;
   return C2_OK;

@@ -1067,7 +1067,8 @@ def test_forward_sweeps_nine_to_32_rhs_by_groups_of_rows(ops, oracle, monkeypatc
 
 
 @pytest.mark.parametrize("B,N,nrhs", [(8, 8, 9), (8, 9, 16), (16, 10, 10), (8, 11, 13), (13, 12, 12), (8, 131, 15), (16, 65, 16),
-                                      (9, 200, 11), (8, 66, 14), (8, 403, 9), (8, 13, 12), (24, 37, 16)])
+                                      (9, 200, 11), (8, 66, 14), (8, 403, 9), (8, 13, 12), (24, 37, 16), (8, 21, 17), (8, 34, 24),
+                                      (16, 11, 25), (8, 40, 32), (8, 9, 31)])
 def test_reverse_sweeps_nine_to_16_rhs_two_columns_per_lane(ops, oracle, monkeypatch, B, N, nrhs):
     """The reverse sweeps with 9 .. 16 right-hand sides at J = 8 (k_sweepC_rev, c2_sweep_cols.hip: eight lanes per series,
     two columns per lane, groups of four rows, the row of the next group carried in slot 4): all four on whole wavefronts

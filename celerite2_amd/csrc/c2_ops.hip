@@ -1131,6 +1131,31 @@ __global__ __launch_bounds__(256) void k_matrices_big(int64_t B, int64_t N, int 
   }
 }
 
+// K[b, n, m] = k(t1[n] - t2[m])  (terms.py:58-79): a thread per output, the terms in registers' reach through L1 (a few
+// doubles per series); branch-free sincos inside its range, the library's beyond
+__global__ __launch_bounds__(256) void k_kernel_values(int64_t B, int64_t N, int64_t M, int Jr, int Jc,
+                                                       const double *__restrict__ ar, const double *__restrict__ cr,
+                                                       const double *__restrict__ ac, const double *__restrict__ bc,
+                                                       const double *__restrict__ cc, const double *__restrict__ dc,
+                                                       int coef_batched, const double *__restrict__ t1, int64_t t1_bs,
+                                                       const double *__restrict__ t2, int64_t t2_bs, double *__restrict__ K) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B * N * M) return;
+  const int64_t b = g / (N * M), r = g - b * N * M, n = r / M, m = r - n * M;
+  const double tau = fabs(t1[b * t1_bs + n] - t2[b * t2_bs + m]);
+  const int64_t orr = coef_batched ? b * Jr : 0, oc = coef_batched ? b * Jc : 0;
+  double k = 0.0;
+  for (int i = 0; i < Jr; ++i) k = fma(ar[orr + i], exp(-cr[orr + i] * tau), k);
+  for (int i = 0; i < Jc; ++i) {
+    const double ph = dc[oc + i] * tau;
+    double sn, cs;
+    if (ph < kSincosFastMax) sincos_cw_fast(ph, sn, cs);
+    else sincos(ph, &sn, &cs);
+    k = fma(exp(-cc[oc + i] * tau), fma(ac[oc + i], cs, bc[oc + i] * sn), k);
+  }
+  K[g] = k;
+}
+
 // Z = Y * sqrt(d)[:, None]   (numpy.py:101)
 __global__ void k_scale_sqrt(int64_t total, int64_t nrhs, const double *d, const double *Y, double *Z) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1787,6 +1812,18 @@ int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const
                              const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
                              const double *diag, double *a, double *U, double *V, c2_stream_t stream) {
   return c2_internal_matrices(B, N, Jr, Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V, nullptr, stream);
+}
+
+int c2_kernel_values(int64_t B, int64_t N, int64_t M, int64_t Jr, int64_t Jc, const double *ar, const double *cr,
+                     const double *ac, const double *bc, const double *cc, const double *dc, int coef_batched,
+                     const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, double *K, c2_stream_t stream) {
+  if (B < 1 || N < 1 || M < 1 || Jr < 0 || Jc < 0 || Jr + Jc < 1) return C2_ERR_INVALID;
+  if (!t1 || !t2 || !K || (Jr && (!ar || !cr)) || (Jc && (!ac || !bc || !cc || !dc))) return C2_ERR_INVALID;
+  const int64_t total = B * N * M;
+  if ((total + 255) / 256 > 0x7fffffffLL) return C2_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_kernel_values, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N, M,
+                     (int)Jr, (int)Jc, ar, cr, ac, bc, cc, dc, coef_batched, t1, t1_bs, t2, t2_bs, K);
+  return check_launch();
 }
 
 int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, int64_t t_bs, const double *c,

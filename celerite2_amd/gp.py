@@ -164,8 +164,7 @@ class ConditionalDistribution:
     @property
     def KxsT(self):      # core.py:46-54: k(t_n - xs_m), (B, N, M)
         if self._KxsT is None:
-            tau = self._batched(self.gp._t)[:, :, None] - self._batched(self._xs)[:, None, :]
-            self._KxsT = self._kernel().get_value_device(tau).contiguous()
+            self._KxsT = self._kernel().get_value_grid(self.gp._t, self._xs, B=self.gp._diag.shape[0])
         return self._KxsT
 
     @property
@@ -216,8 +215,7 @@ class ConditionalDistribution:
 
     @property
     def covariance(self):  # core.py:142-150: k(xs - xs') - K(xs, t) K^-1 K(t, xs), (B, M, M)
-        xs = self._batched(self._xs)
-        neg_cov = -self._kernel().get_value_device(xs[:, :, None] - xs[:, None, :])
+        neg_cov = -self._kernel().get_value_grid(self._xs, self._xs, B=self.gp._diag.shape[0])
         neg_cov = self._do_dot(self.Kinv_KxsT, neg_cov)
         return -neg_cov
 

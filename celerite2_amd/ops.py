@@ -17,7 +17,7 @@ from . import _lib
 __all__ = [
     "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "general_matmul_lower",
     "general_matmul_upper", "factor_rev", "solve_lower_rev", "solve_upper_rev", "matmul_lower_rev",
-    "matmul_upper_rev", "get_celerite_matrices", "loglik", "loglik_grad", "loglik_grad_workspace", "dot_tril",
+    "matmul_upper_rev", "get_celerite_matrices", "kernel_values", "loglik", "loglik_grad", "loglik_grad_workspace", "dot_tril",
     "kron_loglik", "kron_loglik_grad", "loglik_terms", "loglik_terms_grad",
 ]
 
@@ -220,6 +220,32 @@ def get_celerite_matrices(ar, ac, bc, dc, x, diag):
         _p(V), _stream())
     _lib.check(rc, "get_celerite_matrices")
     return a, U, V
+
+
+def kernel_values(ar, cr, ac, bc, cc, dc, t1, t2, B=None):
+    """K[b, n, m] = k(t1[b, n] - t2[b, m]) (terms.py:58-79 on two grids): coefficients (Jr,)|(B,Jr) / (Jc,)|(B,Jc), t1 (N,)|(B,N),
+    t2 (M,)|(B,M); B is taken from whichever argument carries it (or the keyword when everything is shared)."""
+    Jr, Jc = ar.shape[-1], ac.shape[-1]
+    batched = ar.dim() == 2 or ac.dim() == 2
+    if batched and any(v.dim() != 2 for v in (ar, cr, ac, bc, cc, dc)):
+        raise ValueError("coefficients must be all shared or all per-series")
+    for v in (t1, t2, ar, ac):
+        if v.dim() == 2:
+            B = v.shape[0] if B is None else B
+    if B is None:
+        B = 1
+    N, M = t1.shape[-1], t2.shape[-1]
+    _chk(ar, cr, ac, bc, cc, dc, t1, t2)
+    _shape("t1", t1, (N,), (B, N)); _shape("t2", t2, (M,), (B, M))
+    for nm, v, w in (("ar", ar, Jr), ("cr", cr, Jr), ("ac", ac, Jc), ("bc", bc, Jc), ("cc", cc, Jc), ("dc", dc, Jc)):
+        _shape(nm, v, (w,), (B, w))
+    K = torch.empty((B, N, M), dtype=torch.float64, device=t1.device)
+    rc = _lib.load().c2_kernel_values(
+        _i64(B), _i64(N), _i64(M), _i64(Jr), _i64(Jc), _p(ar if Jr else None), _p(cr if Jr else None), _p(ac if Jc else None),
+        _p(bc if Jc else None), _p(cc if Jc else None), _p(dc if Jc else None), ctypes.c_int(1 if batched else 0), _p(t1),
+        _i64(_bs(t1, N)), _p(t2), _i64(_bs(t2, M)), _p(K), _stream())
+    _lib.check(rc, "kernel_values")
+    return K
 
 
 def _loglik_shapes(B, N, J, t, c, a, V, y):

@@ -61,6 +61,25 @@ class Term:
             k = k + torch.exp(-co(cc, j) * tau) * (co(ac, j) * torch.cos(arg) + co(bc, j) * torch.sin(arg))
         return k
 
+    def get_value_grid(self, t1, t2, B=None):
+        """k(t1[n] - t2[m]) on two grids, (B, N, M), by the c2_kernel_values kernel (ops.kernel_values): what the
+        conditional distribution needs for KxsT and for the prior covariance of the prediction grid (core.py:46-54, 142-148)."""
+        import torch
+
+        from . import ops
+
+        coefs = self.get_coefficients()
+        batched = any(v.ndim == 2 for v in coefs)
+        nb = max([v.shape[0] for v in coefs if v.ndim == 2] + [0])
+
+        def prep(v):
+            v = np.asarray(v, dtype=np.float64)
+            if batched and v.ndim == 1:
+                v = np.broadcast_to(v, (nb, v.shape[0]))
+            return torch.from_numpy(np.ascontiguousarray(v)).to(t1.device)
+
+        return ops.kernel_values(*[prep(v) for v in coefs], t1.contiguous(), t2.contiguous(), B=B)
+
     def get_celerite_matrices(self, x, diag):
         """x (N,)|(B,N), diag (B,N) torch float64 device tensors -> (c, a, U, V) device tensors."""
         import torch

@@ -162,15 +162,25 @@ int c2_matmul_upper_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const dou
  * Coefficients ar (B,Jr), ac/bc/dc (B,Jc) with batch stride coef_bs in
  * {0 = shared, 1 = per series}; x (B,N) / shared (N,) via x_bs; diag (B,N).
  * Outputs a (B,N), U (B,N,J), V (B,N,J), J = Jr + 2 Jc, complex terms at
- * interleaved columns (Jr+2j, Jr+2j+1).  Precondition (shared with every
- * recursion of the library, not with the reference's elementwise recipe): x is
- * sorted.  Phases |dc x| beyond 1.6e6 (raw Julian dates) take the library's
- * large-argument sincos, decided from the two ENDS of each series' grid; an
- * unsorted x whose interior leaves that range yields NaN columns, not a wrong
- * quadrant. */
+ * interleaved columns (Jr+2j, Jr+2j+1).  No sortedness precondition, as in the
+ * reference's elementwise recipe: phases |dc x| beyond 1.6e6 (raw Julian dates)
+ * take the library's large-argument sincos -- whole terms when the two ENDS of
+ * a series' grid say so, single rows of an unsorted grid otherwise (a second,
+ * row-parallel kernel that returns at once in the common case). */
 int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
                              const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
                              const double *diag, double *a, double *U, double *V, c2_stream_t stream);
+
+/* Term.get_value on two grids -- python/celerite2/terms.py:58-79 evaluated at
+ * tau = t1[n] - t2[m]: K[b, n, m] = sum_r ar e^{-cr |tau|} + sum_k e^{-cc |tau|}
+ * (ac cos(dc |tau|) + bc sin(dc |tau|)).  What the conditional distribution
+ * forms before it calls the solves (core.py:46-54 KxsT, :142-148 the prior
+ * covariance of the prediction grid).  Coefficients shared or per series
+ * (coef_batched); t1 (B,N) / shared (N,) via t1_bs, t2 (B,M) / (M,) via t2_bs;
+ * K (B,N,M). */
+int c2_kernel_values(int64_t B, int64_t N, int64_t M, int64_t Jr, int64_t Jc, const double *ar, const double *cr,
+                     const double *ac, const double *bc, const double *cc, const double *dc, int coef_batched,
+                     const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, double *K, c2_stream_t stream);
 
 /* Fused log-likelihood -- the assembly the reference's callers perform around
  * factor + solve_lower (python/celerite2/numpy.py:66-87,104-109, core.py:407-428):

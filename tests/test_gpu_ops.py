@@ -1216,6 +1216,16 @@ def test_predictive_variance_and_covariance(ops):
         np.testing.assert_allclose(vark[b].cpu().numpy(), np.diag(want_covk), rtol=1e-7, atol=1e-9)
     s = gp.condition(yd, tsd).sample(size=3, regularize=1e-8)
     assert s.shape == (B, 3, M) and bool(torch.isfinite(s).all())
+    # the kernel on two grids (c2_kernel_values, terms.py:58-79): per-series coefficients against numpy, shared ones with a
+    # shared grid, and a phase beyond the range of the branch-free sincos (raw Julian dates against an origin at 0)
+    Kd = kernel.get_value_grid(xd, tsd).cpu().numpy()
+    for b in range(B):
+        kb = terms.SHOTerm(S0=float(S0[b]), w0=0.1, Q=3.45) + terms.RealTerm(a=1.0, c=0.1)
+        np.testing.assert_allclose(Kd[b], kb.get_value(x[b][:, None] - ts[b][None, :]), rtol=1e-12, atol=1e-13)
+    fast = terms.SHOTerm(S0=1.0, w0=40.0, Q=30.0)
+    big = np.array([2.45e6, 2.45e6 + 0.37, 5.0e5]); small = np.array([0.0, 1.5])
+    Kb = fast.get_value_grid(*dev(big, small)).cpu().numpy()
+    np.testing.assert_allclose(Kb[0], fast.get_value(big[:, None] - small[None, :]), rtol=1e-9, atol=1e-12)
     with pytest.raises(ValueError):
         gp.condition(yd, tsd[:2])
 

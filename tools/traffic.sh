@@ -3,7 +3,7 @@
 # runs, as MI355X_MICROARCH.md prescribes): 2 x FETCH_SIZE + WRITE_SIZE, KiB x 1024 (calibration:
 # profiles/r02_fetch_size_calibration.md).  Prints the per-kernel figures and writes the profiles/r*_traffic.json layout.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=${1:-$R/gpurun_out/traffic.json}
+OUT=$(realpath -m ${1:-$R/gpurun_out/traffic.json})
 cd /tmp; export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-long-series --no-coefficient-level --no-gappy"
 for ctr in FETCH_SIZE WRITE_SIZE; do

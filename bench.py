@@ -283,8 +283,11 @@ def main():
     ap.add_argument("--exact-synth", action="store_true",
                     help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
     ap.add_argument("--placement-search", type=int, default=1,
-                    help="k > 1: try k placements of the workspace / gradient arrays before the timed steps and keep the "
-                         "fastest (informational; the default 1 = the allocator's own placement, what any caller gets)")
+                    help="k > 1: before the warm-up, time ONE step on k placements of the whole job (each allocated while the "
+                         "best so far is held) and run on the fastest; every candidate is listed in config.placement_search.  "
+                         "Diagnostic: WHERE in HBM the step's arrays lie moves it by 6 - 10 % (profiles/r04_headline_spread.md), "
+                         "but three candidates of one process can all be slow, so this is not the default (1 = the "
+                         "allocator's own placement, what any caller gets)")
     ap.add_argument("--no-gappy", action="store_true", help="skip the informational gappy-batch measurement (`gappy` object)")
     ap.add_argument("--no-long-series", action="store_true",
                     help="skip the informational single-long-series measurement (`long_series` object)")
@@ -337,20 +340,62 @@ def main():
         """W warm-up + K timed steps of the hot path on this rank's contiguous shard of a batch of Btot series (generated
         directly on the owning GPU), barrier + synchronize on both sides, MAX over ranks."""
         first, Bp = parallel.shard_range(Btot, rank, world)
-        t, c, a, U, V, y = make(first, Bp, N, J, dev)
-        placement = work = out = None
-        if grad:
-            work = ops.loglik_grad_workspace(Bp, N, J, dev)
-            out = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
-                   torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U), torch.empty_like(U),
-                   torch.empty((Bp, N), dtype=torch.float64, device=dev))
-            if search > 1:
-                # Optional setup, not timed (--placement-search k): what an application that reuses its buffers could do
-                # (ops.loglik_grad_buffers) -- time one step on a few placements of the workspace and the gradient
-                # arrays, keep the fastest, report them all.  The default is the allocator's own placement.
-                del work, out
-                work, out, placement = ops.loglik_grad_buffers(t, c, a, U, V, y, candidates=search)
-                placement.pop("spacer")
+        # WHERE in the 288 GB of HBM the dozen arrays of a chip-filling step lie moves its time by 6 - 10 %, deterministically:
+        # the same job allocated behind a spacer of 16 or 60 GiB runs 27.9 ms where it runs 31.1 without, process after
+        # process on one box, and the other way round on the next (profiles/r04_headline_spread.md; nothing in the kernels
+        # or in shifts of MiB changes it, a plain copy does not show it).  build(S) allocates the step's arrays -- inputs,
+        # workspace, gradients -- while a spacer of S GiB is held, and frees the spacer.
+        base_gb = float(os.environ.get("C2_BENCH_SPACER_GB", "0") or 0)   # (diagnostic: shifts every candidate)
+
+        def build(gib):
+            gib = gib + base_gb
+            spacer = torch.empty(int(gib * 2**30), dtype=torch.uint8, device=dev) if gib > 0 else None
+            ins = make(first, Bp, N, J, dev)
+            w_ = o_ = None
+            if grad:
+                U_ = ins[3]
+                w_ = ops.loglik_grad_workspace(Bp, N, J, dev)
+                o_ = (torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty((Bp, J), dtype=torch.float64, device=dev),
+                      torch.empty((Bp, N), dtype=torch.float64, device=dev), torch.empty_like(U_), torch.empty_like(U_),
+                      torch.empty((Bp, N), dtype=torch.float64, device=dev))
+            del spacer
+            torch.cuda.empty_cache()
+            return ins, w_, o_
+
+        placement = None
+        if grad and search > 1 and Bp * N * J >= 2**28:
+            # Setup, not timed (--placement-search k; off by default): ONE step on each of k placements of the whole job; the
+            # fastest set of arrays is KEPT (a job re-allocated after a free does not come back where it was: 27.9 -> 29.0,
+            # 28.3 -> 31.7 ms in three trials), each further candidate allocated while the best so far is still held --
+            # which is what moves it elsewhere in HBM.  Two sets at most at a time (230 of 288 GB at the bench shape).
+            # What an application that reuses its buffers over thousands of steps can do once; every candidate is reported.
+            cands, best = [], None
+            for i in range(search):
+                try:
+                    ins, w_, o_ = build(0.0)
+                except RuntimeError:   # (no room for a second set: keep what we have)
+                    torch.cuda.empty_cache()
+                    break
+                for _ in range(2):
+                    ops.loglik_grad(*ins, work=w_, out=o_)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); ops.loglik_grad(*ins, work=w_, out=o_); e1.record()
+                torch.cuda.synchronize()
+                ms_ = e0.elapsed_time(e1)
+                cands.append({"candidate": i, "ms": ms_, "U_at": hex(ins[3].data_ptr())})
+                if best is None or ms_ < best[3]:
+                    best = (ins, w_, o_, ms_, i)
+                del ins, w_, o_
+                torch.cuda.empty_cache()
+            placement = {"candidates": cands, "chosen": best[4],
+                         "note": "setup, untimed: one step per candidate placement of the WHOLE job (inputs, workspace, "
+                                 "gradients), each candidate allocated while the best so far is held; the fastest set is the "
+                                 "one the warm-up and the timed steps run on (profiles/r04_headline_spread.md)"}
+            (t, c, a, U, V, y), work, out = best[0], best[1], best[2]
+            del best
+        else:
+            (t, c, a, U, V, y), work, out = build(0.0)
 
         def step():
             if grad:

@@ -271,13 +271,15 @@ def loglik_grad_workspace(B, N, J, device):
     return torch.empty(nbytes // 8, dtype=torch.float64, device=device)
 
 
-def loglik_grad_buffers(t, c, a, U, V, y, *, candidates=5):
+def loglik_grad_buffers(t, c, a, U, V, y, *, candidates=3):
     """Workspace and gradient arrays for repeated `loglik_grad(..., work=, out=)` calls on one shape, PLACED by
-    measurement.  A chip-filling step streams nine large arrays at once and its time depends on where the workspace and
-    the six gradient arrays sit relative to HBM's channel hashing (28-34 ms for 65536 x 4096 x 8 from process to
-    process with identical allocations).  So: time one step on the allocator's own placement, then on
-    fresh allocations behind spacers of different sizes, and keep the fastest.  Returns (work, out, report) -- `report`
-    lists every candidate's time; the chosen spacer stays allocated inside it."""
+    measurement.  A chip-filling step streams a dozen 2 - 16 GiB arrays at once, and WHERE in the 288 GB of HBM the
+    workspace and the gradient arrays lie relative to the inputs moves its time by 6 - 10 % -- deterministically: the same
+    process re-allocating the same arrays behind a spacer of a few tens of GiB switches between 28.2 and 31.5 ms for
+    65536 x 4096 x 8, shifts of MiB change nothing, a plain copy between 16-GiB buffers does not care
+    (profiles/r04_headline_spread.md; tools/shift_probe.py, tools/spacer_probe.sh, tools/hbm_region_probe.py).  So: time one
+    step on the allocator's own placement, then on fresh allocations behind spacers of 24 and 48 GiB (more with
+    `candidates`), and keep the fastest.  Returns (work, out, report) -- `report` lists every candidate's time."""
     B, N, J = _dims(U)
     dev = U.device
 
@@ -299,22 +301,27 @@ def loglik_grad_buffers(t, c, a, U, V, y, *, candidates=5):
         return e0.elapsed_time(e1)
 
     work, out = fresh()
-    cand = [{"spacer_MB": None, "ms": one_step_ms(work, out)}]
-    best_ms, keep = cand[0]["ms"], None
-    for mb in [3, 67, 1029, 4099][:max(0, candidates - 1)]:
+    cand = [{"spacer_GiB": 0, "ms": one_step_ms(work, out)}]
+    best_ms = cand[0]["ms"]
+    for gib in [24, 48, 12, 72, 96][:max(0, candidates - 1)]:
+        sp = w_ = o_ = None
         try:
-            sp = torch.empty(mb * 2**20 + 4096 * 17, dtype=torch.uint8, device=dev)
+            sp = torch.empty(gib * 2**30, dtype=torch.uint8, device=dev)
             w_, o_ = fresh()
-        except RuntimeError:
+        except RuntimeError:   # (not enough memory left for a second set behind this spacer)
+            del sp, w_, o_
+            torch.cuda.empty_cache()
             break
+        del sp                 # (only the position of the arrays matters: the spacer itself goes back at once)
         ms_ = one_step_ms(w_, o_)
-        cand.append({"spacer_MB": mb, "ms": ms_})
+        cand.append({"spacer_GiB": gib, "ms": ms_})
         if ms_ < best_ms:
-            best_ms, keep, work, out = ms_, sp, w_, o_
-        del sp, w_, o_
+            best_ms, work, out = ms_, w_, o_
+        del w_, o_
         torch.cuda.empty_cache()   # the next candidate must not simply get the loser's blocks back
-    return work, out, {"candidates": cand, "chosen_ms": best_ms, "spacer": keep,
-                       "note": "setup, untimed: one step per candidate placement of the workspace and gradient arrays"}
+    return work, out, {"candidates": cand, "chosen_ms": best_ms,
+                       "note": "setup, untimed: one step per candidate placement of the workspace and the gradient arrays "
+                               "(behind spacers of tens of GiB; profiles/r04_headline_spread.md)"}
 
 
 def loglik_grad(t, c, a, U, V, y, *, work=None, out=None):

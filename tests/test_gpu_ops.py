@@ -1099,6 +1099,56 @@ def test_reverse_sweeps_nine_to_16_rhs_two_columns_per_lane(ops, oracle, monkeyp
                 close(o_[b], e_)
 
 
+def test_many_rhs_at_full_size(ops, oracle):
+    """The round-4 kernels at the sizes their profiles quote: (1) 8192 series x 4096 rows x 16 right-hand sides through
+    k_sweepC / k_sweepC_rev -- four distinct series tile the batch, every replica bit-identical to its original, the
+    originals against the oracle (solve_lower, solve_upper, solve_lower_rev), the solve / product round trip on all of it;
+    (2) ONE series of 4096 rows with 1024 right-hand sides through the chunk maps over the columns against the oracle."""
+    import torch
+    B, N, J, nrhs, nb = 8192, 4096, 8, 16, 4
+    t, c, a, U, V, y = dense.synthetic_batch(nb, N, J)
+    d_, W = np.empty_like(a), np.empty_like(V)
+    for b in range(nb):
+        oracle.factor(t[b], c[b], a[b], U[b], V[b], d_[b], W[b], np.empty((N, J, J)))
+    rng = np.random.default_rng(4)
+    Y = rng.standard_normal((nb, N, nrhs)); bZ = rng.standard_normal((nb, N, nrhs))
+    rep = B // nb
+    tile = lambda x: x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous()
+    td, cd, Ud, Wd, Yd, bZd = [tile(x) for x in dev(t, c, U, W, Y, bZ)]
+    Zo = np.empty_like(Y); Fo = np.empty((nb, N, J, nrhs)); Zu = np.empty_like(Y)
+    for b in range(nb):
+        oracle.solve_lower_fwd(t[b], c[b], U[b], W[b], Y[b], Zo[b], Fo[b])
+        oracle.solve_upper_fwd(t[b], c[b], U[b], W[b], Y[b], Zu[b], np.empty((N, J, nrhs)))
+    Zl = ops.solve_lower(td, cd, Ud, Wd, Yd)
+    close(Zl[:nb], Zo)
+    assert bool((Zl.view(rep, nb, N, nrhs) == Zl[:nb]).all())
+    Zup = ops.solve_upper(td, cd, Ud, Wd, Yd)
+    close(Zup[:nb], Zu)
+    assert bool((Zup.view(rep, nb, N, nrhs) == Zup[:nb]).all())
+    back = ops.matmul_lower(td, cd, Ud, Wd, Zl, Z=Zl.clone())           # L (L^-1 Y) = Y with L = I + tril(U W^T)
+    assert float((back - Yd).abs().max()) <= 1e-10 * float(Yd.abs().max())
+    del back, Zup
+    Zd, Fd = ops.solve_lower(td, cd, Ud, Wd, Yd, workspace=True)
+    res = ops.solve_lower_rev(td, cd, Ud, Wd, Yd, Zd, Fd, bZd)
+    for b in range(nb):
+        outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+        oracle.solve_lower_rev(t[b], c[b], U[b], W[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+        for r_, e_ in zip(res, outs):
+            close(r_[b], e_)
+    for r_ in res:
+        assert bool((r_.view((rep, nb) + tuple(r_.shape[1:])) == r_[:nb]).all())
+    del res, Zd, Fd, td, cd, Ud, Wd, Yd, bZd, Zl
+    torch.cuda.empty_cache()
+    M = 1024
+    Y1 = rng.standard_normal((1, N, M))
+    Z1 = np.empty_like(Y1)
+    oracle.solve_lower_fwd(t[0], c[0], U[0], W[0], Y1[0], Z1[0], np.empty((N, J, M)))
+    t1, c1, U1, W1, Y1d = dev(t[:1], c[:1], U[:1], W[:1], Y1)
+    close(ops.solve_lower(t1, c1, U1, W1, Y1d), Z1)      # (automatic dispatch: chunk maps over the columns)
+    oracle.solve_upper_fwd(t[0], c[0], U[0], W[0], Y1[0], Z1[0], np.empty((N, J, M)))
+    close(ops.solve_upper(t1, c1, U1, W1, Y1d), Z1)
+
+
 @pytest.mark.parametrize("J,nrhs,B,N", [(8, 64, 1, 700), (8, 130, 3, 129), (16, 65, 2, 257), (12, 5, 2, 64), (3, 1, 4, 65),
                                         (5, 70, 1, 2100), (1, 64, 2, 63), (8, 16, 70, 200), (2, 200, 1, 2), (7, 33, 2, 1025)])
 def test_many_rhs_solves_as_chunk_maps_over_columns(ops, oracle, monkeypatch, J, nrhs, B, N):

@@ -121,6 +121,54 @@ def test_fuzz_sweeps(ops, oracle, seed):
                 close(r_, e_)
 
 
+@pytest.mark.parametrize("seed", [s for (s,) in CASES])
+def test_fuzz_many_rhs_kernels(ops, oracle, monkeypatch, seed):
+    """The round-4 kernels for many right-hand sides on random shapes: (1) 9 .. 32 right-hand sides at J = 8 on whole
+    wavefronts of eight series plus a remainder (c2_sweep_cols.hip: forward without workspace, reverse; shared or per-series
+    grid, every N mod 4), (2) the chunk maps over the columns forced (c2_solve_cols.hip: any width up to 16, any column count,
+    chunk boundaries at 64 rows) -- against the oracle."""
+    rng = np.random.default_rng(52000 + seed)
+    B = int(rng.integers(8, 41)); N = int(rng.integers(8, 300)); nrhs = int(rng.integers(9, 33)); J = 8
+    t, c, a, U, V, y = problem(rng, B, N, J)
+    W = (0.3 / J) * rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, N, nrhs)); bZ = rng.standard_normal((B, N, nrhs))
+    shared_t = bool(rng.integers(0, 2))
+    if shared_t:
+        t = np.repeat(t[:1], B, axis=0)
+    td, cd, Ud, Vd, Wd, Yd, bZd = dev(t[0] if shared_t else t, c, U, V, W, Y, bZ)
+    name = str(rng.choice(["solve_lower", "solve_upper", "matmul_lower", "matmul_upper"]))
+    solve = name.startswith("solve")
+    sec, secd = (W, Wd) if solve else (V, Vd)
+    Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+    for b in range(B):
+        getattr(oracle, name + "_fwd")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b])
+    close(getattr(ops, name)(td, cd, Ud, secd, Yd, zero_z=True), Zo)
+    Zd, Fd = dev(Zo, Fo)
+    res = getattr(ops, name + "_rev")(td, cd, Ud, secd, Yd, Zd, Fd, bZd)
+    for b in sorted({0, B // 2, B - 1}):
+        outs = [np.empty(N), np.empty(J), np.empty((N, J)), np.empty((N, J)), np.empty((N, nrhs))]
+        getattr(oracle, name + "_rev")(t[b], c[b], U[b], sec[b], Y[b], Zo[b], Fo[b], bZ[b], *outs)
+        got = [r[b] for r in res]
+        if shared_t:   # bt is summed over the batch for a shared grid
+            outs, got = outs[1:], got[1:]
+        for r_, e_ in zip(got, outs):
+            close(r_, e_)
+    # (2) chunk maps over the columns, forced
+    B2 = int(rng.integers(1, 6)); N2 = int(rng.choice([2, 63, 64, 65, 127, 128, 129, 200, 700])); J2 = int(rng.integers(1, 17))
+    m = int(rng.choice([1, 3, 63, 64, 65, 100, 129]))
+    t2, c2, a2, U2, V2, y2 = problem(rng, B2, N2, J2)
+    W2 = np.empty_like(V2)   # (the factor's W: with a random one the recursion grows without bound over 700 rows and overflows)
+    for b in range(B2):
+        assert oracle.factor_flag(t2[b], c2[b], a2[b], U2[b], V2[b], np.empty(N2), W2[b], np.empty((N2, J2 * J2))) == 0
+    Y2 = rng.standard_normal((B2, N2, m))
+    which = str(rng.choice(["solve_lower", "solve_upper"]))
+    Z2 = np.empty_like(Y2)
+    for b in range(B2):
+        getattr(oracle, which + "_fwd")(t2[b], c2[b], U2[b], W2[b], Y2[b], Z2[b], np.empty((N2, J2, m)))
+    monkeypatch.setenv("C2_SOLVE_COLS", "1")
+    close(getattr(ops, which)(*dev(t2, c2, U2, W2, Y2)), Z2)
+
+
 @pytest.mark.parametrize("tile", ["1", "0"])
 @pytest.mark.parametrize("seed", [s for (s,) in CASES[:16]])
 def test_fuzz_general_matmul(ops, oracle, monkeypatch, seed, tile):

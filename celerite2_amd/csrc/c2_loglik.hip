@@ -813,7 +813,7 @@ static bool use_lanes4(int64_t B, int64_t J, bool grad) {
   if (J != 8) return false;
   const int forced = opt::has(opt::k_lanes) ? (int)opt::ival(opt::k_lanes) : 0;
   if (forced == 4) return true;
-  if (forced == 8 || forced == 1) return false;
+  if (forced == 8 || forced == 1 || forced == 2) return false;
   return !grad && B >= opt::ival(opt::k_lanes4_min_batch);
 }
 
@@ -839,6 +839,26 @@ C2_DECL_T(2)
 #undef C2_DECL_T
 // guard words in front of the records of the one-lane path: the head + one per wavefront, rounded to 16 bytes
 static size_t lanes1_gate_words(int64_t B) { return (size_t)((kGateHeadWords + (B + kWave - 1) / kWave + 1) & ~(int64_t)1); }
+// Two lanes per series (c2_loglik_k2.hip, J == 8, whole groups of 64 series): 32 series per wavefront -- the batches that
+// give the one-lane mapping half a chip.  C2_LANES=2 forces it.
+extern "C" int c2_internal_loglik_k2_ok(int64_t B, int64_t N, int64_t J);
+extern "C" int c2_internal_loglik_k2(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                     const double *a, const double *U, const double *V, const double *y, double *ll,
+                                     int32_t *flag, c2_stream_t stream);
+extern "C" size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N);
+extern "C" int c2_internal_loglik_k2_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                          const double *a, const double *U, const double *V, const double *y, double *ll,
+                                          double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                          int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
+static bool use_lanes2(int64_t B, int64_t N, int64_t J, bool grad) {
+  if (!c2_internal_loglik_k2_ok(B, N, J)) return false;
+  const int forced = opt::has(opt::k_lanes) ? (int)opt::ival(opt::k_lanes) : 0;
+  if (forced) return forced == 2;
+  // N = 4096 on MI355X (profiles/r04_two_lanes.md): a wavefront of the pair walks a row in 0.66 of the one-lane time, so it
+  // wins wherever the one-lane mapping leaves SIMDs empty and this one does not need a second round of wavefronts
+  return B <= opt::ival(opt::k_lanes2_max_batch) &&
+         B >= opt::ival(grad ? opt::k_lanes2_min_batch_grad : opt::k_lanes2_min_batch_fwd);
+}
 static size_t lanes1_record_doubles(int64_t B, int64_t N, int64_t J) {
   return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
        : J == 6 ? c2_internal_loglik_t_record_doubles6(B, N)
@@ -999,7 +1019,7 @@ static bool use_lanes1(int64_t B, int64_t J, bool grad) {
   if (J != 8 && J != 6 && J != 4 && J != 2) return false;
   const int forced = opt::has(opt::k_lanes) ? (int)opt::ival(opt::k_lanes) : 0;
   if (forced == 1) return true;
-  if (forced == 4 || forced == 8) return false;
+  if (forced == 4 || forced == 8 || forced == 2) return false;
   // width 6 (rows of 48 bytes: no aligned 128-byte runs) draws level later: gradient 18.5 vs 20.7 ms at 32768 series,
   // 17.2 vs 15.8 ms at 24576; 31.7 vs 41.6 ms at 65536 (forward 7.5 vs 10.8 ms)
   if (grad && J == 6) return B >= opt::ival(opt::k_lanes1_min_batch_grad_j6);
@@ -1048,6 +1068,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
     if (hipFreeAsync(tmp, ws) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
     return rc;
   }
+  if (use_lanes2(B, N, J, false)) return c2_internal_loglik_k2(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
   if (use_lanes1(B, J, false)) {
     if (J == 8) return c2_internal_loglik_t8(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
     if (J == 6) return c2_internal_loglik_t6(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, stream);
@@ -1268,6 +1289,10 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
     const size_t r = lanes1_record_doubles(B, N, J);
     n = lanes1_gate_words(B) + (r > n ? r : n);
   }
+  if (use_lanes2(B, N, J, true)) {  // the same layout with the records of the two-lane path
+    const size_t f = grad_ws(B, N, J).total, r = c2_internal_loglik_k2_record_doubles(B, N);
+    n = lanes1_gate_words(B) + (r > f ? r : f);
+  }
   if (use_timepar_grad(B, N, J)) {   // [verification words | its scratch, or the workspace of the gated row-by-row pair]
     const size_t r = c2_internal_timepar_grad_doubles(B, N, J), f = grad_ws(B, N, J).total + kTimeparVerifyWords;
     n = r > f ? r : f;
@@ -1325,7 +1350,17 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
   if (use_lanes4(B, J, true))
     return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   const unsigned long long *gate = nullptr;
-  if (use_lanes1(B, J, true)) {
+  if (use_lanes2(B, N, J, true)) {
+    // Two lanes per series: as below, the two wavefronts of a group of 64 series raising its guard word together
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *guard = (unsigned long long *)work;
+    if (hipMemsetAsync(guard, 0, 8 * lanes1_gate_words(B), s) != hipSuccess) return C2_ERR_HIP;
+    work = (double *)work + lanes1_gate_words(B);
+    if (int e = c2_internal_loglik_k2_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
+                                           (double *)work, guard, stream))
+      return e;
+    gate = gate_per_wave(guard + kGateHeadWords);
+  } else if (use_lanes1(B, J, true)) {
     hipStream_t s = (hipStream_t)stream;
     // One lane per series: forward with records, then the backward-recursion reverse sweep.  The forward pass leaves
     // the stability measure of every WAVEFRONT in its own guard word; where it exceeds kBackwardGuard that wavefront's

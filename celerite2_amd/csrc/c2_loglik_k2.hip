@@ -1,0 +1,606 @@
+// c2_loglik_k2.hip -- fused log-likelihood + reverse-mode gradient with TWO LANES PER SERIES (J = 8), for batches that
+// give the one-lane mapping of c2_loglik_t.hip only half a chip (24576 ... 49151 series: the 2-GPU shard of BASELINE
+// configs[2] is 32768).
+//
+// One lane per series costs a wavefront of 64 series ~1070 VALU instructions per reverse step, ~610 of them the pass over the
+// 36 packed elements of the J x J states S and M; below 65536 series SIMDs stand empty and the step time is that instruction
+// count.  Here a series is walked by a PAIR of lanes (32 series per wavefront, 1024 wavefronts at 32768 series).  Both lanes
+// hold every width-8 vector and every recursion scalar (same values, same order of operations: bit-identical), and split the
+// packed pass.  To give the two lanes ONE instruction stream on different data, lane h = 1 keeps all its vectors ROTATED by
+// four (local index i <-> global (i + 4h) mod 8; a row is simply read from its tile with the 16-byte pieces in rotated order),
+// and both own the same LOCAL set of 20 index pairs:
+//     {(i, j): i <= j < 4}  u  {(i, 4 + m): i < m}  u  {(i, 4 + i)}        (10 + 6 + 4)
+// Under the rotation the first 16 of lane 1 are exactly the pairs lane 0 does not have; the four pairs (i, 4 + i) map onto
+// themselves, are kept by BOTH lanes and enter every sum over the elements with weight 1/2.  Sums over the elements
+// (tau = u S; xs = x S, diag(S M), q = w M in the reverse step) are completed by ONE exchange with the partner lane per
+// vector -- own[j] + partner[(j + 4) mod 8], a DPP quad permute -- and dot products of width-8 vectors are formed as
+// (sum over local 0..3) + (sum over local 4..7), which is the same two numbers added in either lane.
+//
+// Everything else is the one-lane design: rows through LDS transposes in aligned 128-byte lines, lane-major records of W,
+// (d, z), t and a checkpoint every 32 rows written by the forward pass, the reverse sweep running the recursion BACKWARD from
+// the checkpoints (reference steps: forward.hpp:105-134, internal.hpp:135-145, 225-245, reverse.hpp:52-84; the fused reverse
+// step is derived in c2_loglik.hip).  With 20 instead of 36 elements per lane both states live in ordinary registers.
+// Gaps in time are re-anchored as there: an extra checkpoint in front of a gap the backward recursion could not cross (up to
+// twice the regular number per wavefront); a wavefront that runs out of them marks its group of 64 series and the replay
+// kernels take those.  Which rows carry a checkpoint is the sign of their d record; the slots are consumed in reverse order of
+// writing, so the reverse sweep needs their number and no list.
+// Not here (the dispatch keeps the other mappings for them): partial groups (B % 64 != 0), widths other than 8, the
+// coefficient-level form.
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../../include/celerite2_amd.h"
+#include "c2_loglik_helpers.hpp"
+
+namespace c2k2 {
+using namespace c2;
+
+constexpr int J = 8, NL = 20, SPW = 32, C = 32, ST = 8;
+constexpr int RSTR = 2 * J + 2;   // LDS stride (doubles) of a series in a two-row tile: 144 B
+constexpr int SSTR = ST + 1;      // ... in an eight-row scalar tile: 72 B
+constexpr int CKD = NL + 4;       // doubles a lane keeps per checkpoint: its 20 elements of S and its four of F
+constexpr double kGuard = kBackwardGuard;
+// the local element set (see above); elements 16 .. 19 carry weight 1/2 in sums over the elements
+__device__ constexpr int LI[NL] = {0, 0, 0, 0, 1, 1, 1, 2, 2, 3, 0, 0, 0, 1, 1, 2, 0, 1, 2, 3};
+__device__ constexpr int LJ[NL] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3, 5, 6, 7, 6, 7, 7, 4, 5, 6, 7};
+constexpr int kHalfFrom = 16;
+
+struct Rec {
+  size_t w, dz, t, ck, cnt, total;   // offsets / total in doubles
+  int64_t nreg, nck;                 // regular checkpoints per wavefront (rows C, 2C, ..., and the last row); slots
+};
+__host__ __device__ inline int64_t n_ckpt(int64_t N) { return N >= 2 ? (N - 2) / C + 1 : 0; }
+__host__ inline Rec rec_layout(int64_t B, int64_t N) {
+  const size_t waves = ((size_t)B + SPW - 1) / SPW;
+  Rec r;
+  r.nreg = n_ckpt(N);
+  r.nck = 3 * r.nreg;
+  r.w = 0;                                           // [wave][n][4 pieces][32] double2
+  r.dz = r.w + waves * (size_t)N * J * SPW;          // [wave][n][32] double2
+  r.t = r.dz + waves * (size_t)N * 2 * SPW;          // [wave][n][32]
+  r.ck = r.t + waves * (size_t)N * SPW;              // [wave][slot][CKD][64]
+  r.cnt = r.ck + waves * (size_t)r.nck * CKD * kWave;   // [wave]: checkpoints written (an integer in a double's place)
+  r.total = r.cnt + ((waves + 1) & ~(size_t)1);
+  return r;
+}
+
+__device__ __forceinline__ double swap_pair(double x) { return dpp_mov<kDppXor1>(x); }   // the partner lane's value
+// (sum over local 0..3) + (sum over local 4..7): the same two numbers in either lane of a pair
+__device__ __forceinline__ double dot8(const double (&x)[J], const double (&y)[J]) {
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { a = fma(x[i], y[i], a); b = fma(x[i + 4], y[i + 4], b); }
+  return a + b;
+}
+// own[j] + partner[(j + 4) & 7]: the sum over ALL elements from the two lanes' partial sums
+__device__ __forceinline__ void pair_total(const double (&own)[J], double (&tot)[J]) {
+#pragma unroll
+  for (int j = 0; j < J; ++j) tot[j] = own[j] + swap_pair(own[(j + 4) & 7]);
+}
+
+// ---- tile movers (32 series per wavefront) -------------------------------------------------------------------------------
+// two-row tile of a width-8 array: one instruction moves 8 series x 128 bytes (lane l: series 8 i + l / 8, piece l % 8)
+__device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, int lane, double (&st)[8]) {
+  int64_t r = n0 + (lane & 7) / 4;
+  r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
+  const int64_t off = r * J + 2 * (lane & 3);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + off);
+    st[2 * i] = v.x; st[2 * i + 1] = v.y;
+  }
+}
+__device__ __forceinline__ void row_stage(double *tile, int lane, const double (&st)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    *reinterpret_cast<double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * (lane & 7)) = make_double2(st[2 * i], st[2 * i + 1]);
+}
+// this lane's row r of its series, in LOCAL order (pieces rotated by two for the odd lane)
+__device__ __forceinline__ void row_read(const double *tile, int sl, int h, int r, double (&x)[J]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double2 v = *reinterpret_cast<const double2 *>(tile + sl * RSTR + r * J + 2 * ((q + 2 * h) & 3));
+    x[2 * q] = v.x; x[2 * q + 1] = v.y;
+  }
+}
+// local elements 0..3 (= global 4h .. 4h+3) of a width-8 row into the tile: the two lanes of a pair write the row together
+__device__ __forceinline__ void row_write_half(double *tile, int sl, int h, int r, const double (&x)[J]) {
+  *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h) = make_double2(x[0], x[1]);
+  *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h + 2) = make_double2(x[2], x[3]);
+}
+// tile -> memory: rows n0, n0 + 1 of every series (rows outside [0, N-1] skipped)
+__device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane) {
+  const int64_t r = n0 + (lane & 7) / 4;
+  double2 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * (lane & 7));
+  if (r >= 0 && r < N) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + r * J + 2 * (lane & 3)) = v[i];
+  }
+}
+// per-series scalar streams in 16-row tiles: one instruction moves 4 series x 128 bytes
+__device__ __forceinline__ void sc_fetch16(const double *__restrict__ base, int64_t sN, int64_t N, int64_t n16, int lane,
+                                           double (&st)[8]) {
+  int64_t r = n16 + (lane & 15);
+  r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) st[i] = base[(int64_t)(4 * i + lane / 16) * sN + r];
+}
+__device__ __forceinline__ void sc_stage16(double *tile, int lane, int half, const double (&st)[8]) {
+  if (((lane & 15) >> 3) == half) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tile[(4 * i + lane / 16) * SSTR + (lane & 7)] = st[i];
+  }
+}
+// eight-row scalar tile -> memory: one instruction moves 8 series x 64 bytes
+__device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane) {
+  const int64_t r = n0 + (lane & 7);
+  double v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = tile[(8 * i + lane / 8) * SSTR + (lane & 7)];
+  if (r >= 0 && r < N) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base[(int64_t)(8 * i + lane / 8) * N + r] = v[i];
+  }
+}
+
+template <bool PAIRED>
+__device__ __forceinline__ void decay(const double (&c)[J], double dt, double (&p)[J]) {
+  if constexpr (PAIRED) {
+#pragma unroll
+    for (int k = 0; k < J / 2; ++k) p[2 * k] = p[2 * k + 1] = exp_decay(c[2 * k] * dt);
+  } else {
+#pragma unroll
+    for (int j = 0; j < J; ++j) p[j] = exp_decay(c[j] * dt);
+  }
+}
+
+// =====================================================================================================================
+// Forward pass.  REC: also W rows, (d, z), t, checkpoints and the stability measure of the backward recursion.
+// =====================================================================================================================
+template <bool REC, bool PAIRED>
+__device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                         const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
+                                         const double *__restrict__ U, const double *__restrict__ V,
+                                         const double *__restrict__ y, double *__restrict__ ll, int32_t *__restrict__ flag,
+                                         double *__restrict__ rec, Rec R, unsigned long long *__restrict__ guard, double *lds) {
+  const int lane = threadIdx.x, sl = lane >> 1, h = lane & 1;
+  const int64_t b0 = (int64_t)blockIdx.x * SPW, b = b0 + sl;
+  double *tU = lds, *tV = tU + SPW * RSTR, *tT = tV + SPW * RSTR, *tA = tT + SPW * SSTR, *tY = tA + SPW * SSTR;
+  const double *Ub = U + b0 * N * J, *Vb = V + b0 * N * J, *ab = a + b0 * N, *yb = y + b0 * N;
+  const double *tb = t + (t_bs ? b0 * N : 0);
+  const int64_t tN = t_bs ? N : 0;
+  double cj[J], cmax = 0.0;
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + ((j + 4 * h) & 7)]; cmax = fmax(cmax, cj[j]); }
+  double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * SPW) : nullptr;
+  double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * SPW) : nullptr;
+  double *recT = REC ? rec + R.t + (size_t)blockIdx.x * N * SPW : nullptr;
+  double *recCK = REC ? rec + R.ck + (size_t)blockIdx.x * R.nck * CKD * kWave : nullptr;
+
+  double S[NL];
+#pragma unroll
+  for (int e = 0; e < NL; ++e) S[e] = 0.0;
+  double F[J], w[J];
+  double tprev = t[b * t_bs];
+  double d = a[b * N], z = y[b * N], rd = 1.0 / d;
+#pragma unroll
+  for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = V[b * N * J + ((j + 4 * h) & 7)] * rd; }
+  double prod = d, quad = z * z * rd;
+  int eacc = 0;
+  int32_t fl = 0;
+  int slot = 0, nextra = 0;   // wavefront-uniform: checkpoint slots written, extras among them
+  int64_t lastck = 0;
+  double tseg = tprev, gmax = 0.0;
+  auto write_ckpt = [&](int64_t row) __attribute__((always_inline)) {   // the state as it stands = state after `row`
+    double *ck = recCK + (size_t)slot * CKD * kWave;
+#pragma unroll
+    for (int e = 0; e < NL; ++e) ck[e * kWave + lane] = S[e];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ck[(NL + j) * kWave + lane] = F[j];
+    ++slot;
+    lastck = row;
+  };
+  auto write_rec = [&](int64_t n, bool seg_end) __attribute__((always_inline)) {
+    recW[((size_t)n * 4 + 2 * h) * SPW + sl] = make_double2(w[0], w[1]);        // local 0..3 = global 4h .. 4h+3
+    recW[((size_t)n * 4 + 2 * h + 1) * SPW + sl] = make_double2(w[2], w[3]);
+    if (h == 0) {
+      recDZ[(size_t)n * SPW + sl] = make_double2(seg_end ? -fabs(d) : fabs(d), z);   // the sign of d: this row carries a checkpoint
+      recT[(size_t)n * SPW + sl] = tprev;
+    }
+    if (seg_end) write_ckpt(n);   // (wavefront-uniform)
+  };
+  if (REC) write_rec(0, false);
+
+  double su[8], sv[8], st_[8], sa_[8], sy_[8];
+  row_fetch(Ub, N, 0, lane, su); row_fetch(Vb, N, 0, lane, sv);
+  sc_fetch16(tb, tN, N, 0, lane, st_); sc_fetch16(ab, N, N, 0, lane, sa_); sc_fetch16(yb, N, N, 0, lane, sy_);
+  for (int64_t n0 = 0; n0 < N; n0 += ST) {
+    const int half = (int)((n0 >> 3) & 1);
+    lds_order();
+    sc_stage16(tT, lane, half, st_); sc_stage16(tA, lane, half, sa_); sc_stage16(tY, lane, half, sy_);
+    if (half == 1) {
+      sc_fetch16(tb, tN, N, n0 + ST, lane, st_); sc_fetch16(ab, N, N, n0 + ST, lane, sa_);
+      sc_fetch16(yb, N, N, n0 + ST, lane, sy_);
+    }
+#pragma unroll
+    for (int rt = 0; rt < ST / 2; ++rt) {
+      const int64_t nt = n0 + rt * 2;
+      if (nt < N) {
+        lds_order();
+        row_stage(tU, lane, su); row_stage(tV, lane, sv);
+        row_fetch(Ub, N, nt + 2, lane, su); row_fetch(Vb, N, nt + 2, lane, sv);
+        lds_order();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int64_t n = nt + r;
+          if (n < N && n > 0) {
+            const int rs = rt * 2 + r;
+            const double tn = tT[sl * SSTR + rs], yn = tY[sl * SSTR + rs], an = tA[sl * SSTR + rs];
+            double u[J], v[J], p[J];
+            const double dt = tprev - tn;
+            if (REC) {
+              // the backward recursion reaches row n-1 by inverting the decay of row n unless the state of row n-1 is on
+              // record: re-anchor there if some series of the wavefront could not afford that (wavefront-uniform)
+              if (lastck == n - 1) tseg = tn;   // the decay into the row behind a checkpoint is never inverted
+              if (__any(cmax * (tn - tseg) > kGuard) && nextra < (int)(R.nck - R.nreg)) {
+                write_ckpt(n - 1);
+                if (h == 0) recDZ[(size_t)(n - 1) * SPW + sl] = make_double2(-fabs(d), z);   // (d, z still of row n-1)
+                ++nextra;
+                tseg = tn;
+              }
+              gmax = fmax(gmax, cmax * (tn - tseg));
+            }
+            tprev = tn;
+            row_read(tU, sl, h, r, u); row_read(tV, sl, h, r, v);
+            decay<PAIRED>(cj, dt, p);
+            // S = P (S + d w^T w) P (forward.hpp:115-123); tau = U_n S (forward.hpp:126): own elements, then the pair's total
+            double dw[J], tau[J], taut[J];
+#pragma unroll
+            for (int i = 0; i < J; ++i) { dw[i] = d * w[i]; tau[i] = 0.0; }
+#pragma unroll
+            for (int e = 0; e < NL; ++e) {
+              const int i = LI[e], j2 = LJ[e];
+              const double s = (p[i] * p[j2]) * fma(dw[i], w[j2], S[e]);
+              S[e] = s;
+              const double se = e >= kHalfFrom ? 0.5 * s : s;
+              tau[j2] = fma(u[i], se, tau[j2]);
+              if (j2 != i) tau[i] = fma(u[j2], se, tau[i]);
+            }
+            pair_total(tau, taut);
+            // F = P (F + W_{n-1}^T z_{n-1})   (internal.hpp:140-143)
+#pragma unroll
+            for (int j2 = 0; j2 < J; ++j2) F[j2] = p[j2] * fma(w[j2], z, F[j2]);
+            d = an - dot8(taut, u);   // forward.hpp:127
+            z = yn - dot8(u, F);      // internal.hpp:144
+            rd = rcp_nr(d);
+#pragma unroll
+            for (int j2 = 0; j2 < J; ++j2) w[j2] = (v[j2] - taut[j2]) * rd;   // forward.hpp:131
+            fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;                // forward.hpp:128
+            prod *= d;
+            quad = fma(z * z, rd, quad);
+            if (r & 1) { int e2; prod = frexp(prod, &e2); eacc += e2; }
+            if (REC) write_rec(n, (n % C == 0) || (n == N - 1));
+          }
+        }
+      }
+    }
+  }
+  if (h == 0) {
+    int e2;
+    prod = frexp(prod, &e2);
+    const double logdet = log(prod) + (double)(eacc + e2) * kLn2;
+    flag[b] = fl;
+    ll[b] = fl ? -INFINITY : -0.5 * (logdet + (double)N * kLog2Pi) - 0.5 * quad;
+  }
+  if (REC) {
+    if (lane == 0) rec[R.cnt + blockIdx.x] = __longlong_as_double((long long)slot);
+    // the stability measure of this wavefront; two wavefronts share the guard word of their group of 64 series (zeroed by
+    // the launcher): beyond kGuard the reverse sweeps of both return at once and the replay kernels take the group
+    double g = (gmax == gmax) ? gmax : INFINITY;
+#pragma unroll
+    for (int sft = 1; sft < kWave; sft <<= 1) g = fmax(g, __shfl_xor(g, sft, kWave));
+    if (lane == 0) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(g);
+      atomicMax(guard + kGateHeadWords + (b0 >> 6), bits);
+      atomicMax(guard, bits);
+      if (g > kGuard) atomicAdd(guard + 1, 1ull);
+    }
+  }
+}
+
+constexpr int kFwdLds = (2 * SPW * RSTR + 3 * SPW * SSTR) * 8;
+
+template <bool REC>
+__global__ __launch_bounds__(kWave, 1) void k_k2_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+                                                     const double *__restrict__ c, int64_t c_bs,
+                                                     const double *__restrict__ a, const double *__restrict__ U,
+                                                     const double *__restrict__ V, const double *__restrict__ y,
+                                                     double *__restrict__ ll, int32_t *__restrict__ flag,
+                                                     double *__restrict__ rec, Rec R, unsigned long long *__restrict__ guard) {
+  __shared__ __attribute__((aligned(16))) double lds[kFwdLds / 8];
+  const int64_t bb = (int64_t)blockIdx.x * SPW + (threadIdx.x >> 1);
+  bool paired = true;
+#pragma unroll
+  for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
+  if (__all(paired)) fwd_body<REC, true>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
+  else fwd_body<REC, false>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
+}
+
+// =====================================================================================================================
+// Reverse sweep: the fused step of c2_loglik_t.hip (solve_lower_rev internal.hpp:225-245 + factor_rev reverse.hpp:52-84 +
+// the backward recursion of S and F) on the local element set.  Entering step n: bz, ba, bV = complete cotangents of row n;
+// S, F = state of row n; M = bS + bS^T on the local elements; bF; carry = f_{n+1}.
+// =====================================================================================================================
+constexpr int kRevLds = (2 * SPW * RSTR + 3 * SPW * SSTR) * 8;
+
+template <bool PAIRED>
+__device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
+                                         const double *__restrict__ U, const int32_t *__restrict__ flag,
+                                         const double *__restrict__ rec, Rec R, double *__restrict__ bt,
+                                         double *__restrict__ bc, double *__restrict__ ba, double *__restrict__ bU,
+                                         double *__restrict__ bV, double *__restrict__ by, double *lds) {
+  const int lane = threadIdx.x, sl = lane >> 1, h = lane & 1;
+  const int64_t b0 = (int64_t)blockIdx.x * SPW, b = b0 + sl;
+  double *tU = lds, *tBV = tU + SPW * RSTR, *tBA = tBV + SPW * RSTR, *tBY = tBA + SPW * SSTR, *tBT = tBY + SPW * SSTR;
+  const double *Ub = U + b0 * N * J;
+  double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
+  const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * SPW);
+  const double2 *recDZ = reinterpret_cast<const double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * SPW);
+  const double *recT = rec + R.t + (size_t)blockIdx.x * N * SPW;
+  const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * CKD * kWave;
+  const bool failed = flag[b] != 0;   // NaN gradients for a failed factorisation
+  const double nan = __builtin_nan("");
+  double cj[J], bcj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + ((j + 4 * h) & 7)]; bcj[j] = 0.0; }
+
+  double S[NL], M[NL], F[J], bF[J], bVn[J];
+#pragma unroll
+  for (int e = 0; e < NL; ++e) { S[e] = 0.0; M[e] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < J; ++j) { F[j] = 0.0; bF[j] = 0.0; bVn[j] = failed ? nan : 0.0; }
+  double carry = 0.0;
+  const int64_t nf = N - 1;
+  const double2 dzl = recDZ[(size_t)nf * SPW + sl];
+  const double rdl = 1.0 / fabs(dzl.x);
+  double ban = 0.5 * rdl * (dzl.y * dzl.y * rdl - 1.0), bzn = -dzl.y * rdl;   // seeds of the last row
+  if (failed) { ban = nan; bzn = nan; }
+  double tcur = recT[(size_t)nf * SPW + sl];
+
+  // slots are consumed in reverse order of writing
+  int slot = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(rec[R.cnt + blockIdx.x]));
+  auto load_ckpt = [&]() {   // the recorded state of a checkpointed row replaces the recursed one
+    --slot;
+    const double *ck = recCK + (size_t)slot * CKD * kWave;
+#pragma unroll
+    for (int e = 0; e < NL; ++e) S[e] = ck[e * kWave + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) F[j] = ck[(NL + j) * kWave + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) F[4 + j] = swap_pair(F[j]);   // the partner's local 0..3 are this lane's local 4..7
+  };
+  auto w_fetch = [&](int64_t row, double (&wv)[J]) {
+    row = row < 0 ? 0 : row;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double2 v = recW[((size_t)row * 4 + ((q + 2 * h) & 3)) * SPW + sl];
+      wv[2 * q] = v.x; wv[2 * q + 1] = v.y;
+    }
+  };
+  auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)(row < 0 ? 0 : row) * SPW + sl]; };
+  auto t_fetch = [&](int64_t row) { return recT[(size_t)(row < 0 ? 0 : row) * SPW + sl]; };
+
+  if (N >= 2) {
+    // ---- prologue: bV, ba, by of the last row are pure seeds ---------------------------------------------------------------
+    const int ph0 = (int)(nf & 1);
+    row_write_half(tBV, sl, h, ph0, bVn);
+    tBA[sl * SSTR + (nf & (ST - 1))] = ban;
+    tBY[sl * SSTR + (nf & (ST - 1))] = bzn;
+    lds_order();
+    if (ph0 == 0) row_flush(bVb, N, nf, tBV, lane);   // (an even last row: its pair partner lies beyond the series: only row nf)
+    if ((nf & (ST - 1)) == 0) {                       // the last row alone at the bottom of its scalar tile
+      sc_flush(bab, N, nf, tBA, lane);
+      sc_flush(byb, N, nf, tBY, lane);
+    }
+    double su[8], wa[J];
+    double2 dza;
+    double ta;
+    row_fetch(Ub, N, nf - ph0, lane, su);
+    if (ph0 != 1) {   // the first step is not a staging one: its tile goes into LDS here
+      lds_order();
+      row_stage(tU, lane, su);
+      lds_order();
+      row_fetch(Ub, N, nf - ph0 - 2, lane, su);
+    }
+    w_fetch(nf - 1, wa);
+    dza = dz_fetch(nf - 1);
+    ta = t_fetch(nf - 1);
+    load_ckpt();   // the last row always carries one
+    lds_order();
+
+    auto step = [&](const int64_t n, auto phase_tag) __attribute__((always_inline)) {
+      constexpr int PH = decltype(phase_tag)::value;   // n & 1
+      __builtin_amdgcn_sched_barrier(0);
+      double wb[J];
+      if constexpr (PH == 1) {   // the step that puts its pair of U rows into LDS and requests the pair below
+        lds_order();
+        row_stage(tU, lane, su);
+        row_fetch(Ub, N, n - 3, lane, su);
+      }
+      w_fetch(n - 2, wb);
+      const double2 dzb = dz_fetch(n - 2);
+      const double tb2 = t_fetch(n - 2);
+      if constexpr (PH == 1) lds_order();
+      const int rs = (int)((n - 1) & (ST - 1));
+      double u[J], p[J], ip[J];
+      row_read(tU, sl, h, PH, u);
+      const double tm = ta, dt = tm - tcur;
+      tcur = tm;
+      decay<PAIRED>(cj, dt, p);
+      // solve_lower_rev part (internal.hpp:232-245)
+      double bp0[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        bF[j] = fma(-u[j], bzn, bF[j]);
+        bp0[j] = F[j] * bF[j];
+        bF[j] *= p[j];
+      }
+      // factor_rev part (reverse.hpp:65-80) and the backward recursion of S, one pass over the local elements
+      const double dm = fabs(dza.x), rdm = rcp_nr(dm), zm = dza.y;
+      const bool ckm = __builtin_amdgcn_readfirstlane(__double2hiint(dza.x)) < 0;   // row n-1 carries a checkpoint
+      double x[J], xs[J], q[J], bps[J];
+      const double ba2 = 2.0 * ban;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { x[j] = fma(ba2, u[j], bVn[j]); xs[j] = 0.0; q[j] = 0.0; bps[j] = 0.0; ip[j] = rcp_nr(p[j]); }
+#pragma unroll
+      for (int e = 0; e < NL; ++e) {
+        const int i = LI[e], j2 = LJ[e];
+        const double wgt = e >= kHalfFrom ? 0.5 : 1.0;
+        const double sv = S[e];
+        const double svw = e >= kHalfFrom ? 0.5 * sv : sv;
+        double m = M[e];
+        xs[j2] = fma(x[i], svw, xs[j2]);
+        if (j2 != i) xs[i] = fma(x[j2], svw, xs[i]);
+        m = fma(-u[i], bVn[j2], m);
+        m = fma(-x[i], u[j2], m);
+        bps[j2] = fma(svw, m, bps[j2]);
+        if (j2 != i) bps[i] = fma(svw, m, bps[i]);
+        m *= p[i] * p[j2];
+        M[e] = m;
+        const double mw = wgt * m;
+        q[j2] = fma(wa[i], mw, q[j2]);
+        if (j2 != i) q[i] = fma(wa[j2], mw, q[i]);
+        S[e] = fma(-(dm * wa[i]), wa[j2], sv * (ip[i] * ip[j2]));
+      }
+      double xst[J], qt[J], bp[J];
+      pair_total(xs, xst);
+      pair_total(q, qt);
+      pair_total(bps, bp);
+#pragma unroll
+      for (int j = 0; j < J; ++j) bp[j] += bp0[j];
+      {
+        double o[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) o[j] = fma(-bzn, F[j], -xst[j]);   // bU_n = -bz_n F_n - x S_n
+        row_write_half(tU, sl, h, PH, o);                               // bU_n takes the place of U_n in the tile
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) bcj[j] = fma(dt, bp[j], bcj[j]);
+      const double f = dot8(cj, bp);
+      const double btn = carry - f;
+      carry = f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) F[j] = fma(-wa[j], zm, F[j] * ip[j]);   // F_{n-1} = P^-1 F_n - w_{n-1} z_{n-1}
+      const double Gs = dot8(wa, bF), Q = dot8(qt, wa);
+      const double zr = zm * rdm;
+      bzn = Gs - zr;
+#pragma unroll
+      for (int j = 0; j < J; ++j) bVn[j] = fma(zr, bF[j], qt[j]);
+      ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+      if (h == 0) {
+        tBA[sl * SSTR + rs] = ban;
+        tBY[sl * SSTR + rs] = bzn;
+        tBT[sl * SSTR + (int)(n & (ST - 1))] = btn;
+      }
+      row_write_half(tBV, sl, h, (PH + 1) & 1, bVn);   // bV_{n-1}
+      lds_order();
+      // width-8 outputs leave as aligned pairs of rows: bU at the end of the even step (rows n, n + 1), bV at the end of the odd
+      // step (rows n - 1, n)
+      if constexpr (PH == 0) row_flush(bUb, N, n, tU, lane);
+      else row_flush(bVb, N, n - 1, tBV, lane);
+      if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, tBT, lane);
+      if (rs == 0) {
+        sc_flush(bab, N, n - 1, tBA, lane);
+        sc_flush(byb, N, n - 1, tBY, lane);
+      }
+      if (ckm && n >= 2) load_ckpt();   // the state of row n-1 is on record: it replaces the recursed one
+#pragma unroll
+      for (int j = 0; j < J; ++j) wa[j] = wb[j];
+      dza = dzb;
+      ta = tb2;
+    };
+    for (int64_t n = nf | 1; n >= 1; n -= 2) {
+      if (n <= nf) step(n, std::integral_constant<int, 1>{});
+      if (n >= 2) step(n - 1, std::integral_constant<int, 0>{});
+    }
+    // row 0: bU_0 = 0 (reverse.hpp:83), bt_0 = f_1; ba_0 / by_0 / bV_0 left with the last step
+    {
+      double zero[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) zero[j] = failed ? nan : 0.0;
+      lds_order();
+      row_write_half(tU, sl, h, 0, zero);   // bU_1 is waiting in row 1 of the tile
+      if (h == 0) tBT[sl * SSTR] = carry;
+      lds_order();
+      row_flush(bUb, N, 0, tU, lane);
+      sc_flush(btb, N, 0, tBT, lane);
+    }
+  } else if (h == 0) {   // N == 1: seeds only
+    bab[(int64_t)sl * N] = ban;
+    byb[(int64_t)sl * N] = bzn;
+    btb[(int64_t)sl * N] = failed ? nan : 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { bUb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bc[b * J + 4 * h + j] = bcj[j];   // local 0..3 = global 4h .. 4h+3
+}
+
+__global__ __launch_bounds__(kWave, 1) void k_k2_rev(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
+                                                     const double *__restrict__ U, const int32_t *__restrict__ flag,
+                                                     const double *__restrict__ rec, Rec R,
+                                                     const unsigned long long *__restrict__ guard, double *__restrict__ bt,
+                                                     double *__restrict__ bc, double *__restrict__ ba,
+                                                     double *__restrict__ bU, double *__restrict__ bV,
+                                                     double *__restrict__ by) {
+  __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
+  const int64_t b0 = (int64_t)blockIdx.x * SPW;
+  if (__longlong_as_double((long long)guard[kGateHeadWords + (b0 >> 6)]) > kGuard) return;   // the replay kernels take this group
+  const int64_t bb = b0 + (threadIdx.x >> 1);
+  bool paired = true;
+#pragma unroll
+  for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
+  if (__all(paired)) rev_body<true>(B, N, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+  else rev_body<false>(B, N, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+}
+
+}  // namespace c2k2
+
+using namespace c2k2;
+
+extern "C" {
+
+// whole wavefronts of 32 series only
+int c2_internal_loglik_k2_ok(int64_t B, int64_t N, int64_t J) { return J == 8 && B >= SPW && B % 64 == 0 && N >= 2; }
+
+int c2_internal_loglik_k2(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
+                          const double *U, const double *V, const double *y, double *ll, int32_t *flag, c2_stream_t stream) {
+  Rec R{};
+  hipLaunchKernelGGL((k_k2_fwd<false>), dim3((unsigned)(B / SPW)), dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs,
+                     a, U, V, y, ll, flag, (double *)nullptr, R, (unsigned long long *)nullptr);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N) { return rec_layout(B, N).total; }
+
+// Forward with records + reverse sweep.  `guard`: kGateHeadWords + B / 64 device words, ALL zeroed by the caller on the same
+// stream (the two wavefronts of a group of 64 series raise its word together).
+int c2_internal_loglik_k2_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                               const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
+                               double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, double *rec,
+                               unsigned long long *guard, c2_stream_t stream) {
+  const dim3 grid((unsigned)(B / SPW));
+  const Rec R = rec_layout(B, N);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((k_k2_fwd<true>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard);
+  if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(k_k2_rev, grid, dim3(kWave), 0, s, B, N, c, c_bs, U, (const int32_t *)flag, (const double *)rec, R,
+                     (const unsigned long long *)guard, bt, bc, ba, bU, bV, by);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+}  // extern "C"

@@ -356,8 +356,70 @@ def test_one_lane_per_series_variant(ops, oracle, monkeypatch, B, N, J):
             close(g[ok], e[ok])
 
 
-@pytest.mark.parametrize("J", [8, 6, 4, 2])
-def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
+@pytest.mark.parametrize("B,N", [(64, 2), (64, 3), (64, 9), (128, 33), (64, 64), (192, 65), (64, 130), (128, 257)])
+def test_two_lanes_per_series_variant(ops, oracle, monkeypatch, B, N):
+    """Width 8 has a fourth lane mapping for batches that give the one-lane kernels half a chip (c2_loglik_k2.hip: a PAIR of
+    lanes per series, the packed states split between them by a rotation of the odd lane's vectors, 32 series per
+    wavefront): same results as the oracle around the tile (2 / 8 / 16 rows) and checkpoint (32 rows) edges, with unpaired
+    rates, with a failed series, with shared t / c -- and a group of 64 series whose gaps make the backward recursion
+    unsafe goes to the replay kernels, the other groups stay."""
+    J = 8
+    monkeypatch.setenv("C2_LANES", "2")
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)
+    llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    close(ll, llo)
+    ll2, grads, flag2 = ops.loglik_grad(td, cd, ad, Ud, Vd, yd)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    close(ll2, llo)
+    for g, e in zip(grads, go):
+        close(g, e)
+    c2 = c.copy(); c2[:, 1] *= 1.01; c2[:, J - 2] *= 0.97
+    (c2d,) = dev(c2)
+    llo2, go2, _ = oracle.loglik_grad_batched(t, c2, a, U, V, y, nthreads=2)
+    ll3, grads3, _ = ops.loglik_grad(td, c2d, ad, Ud, Vd, yd)
+    close(ll3, llo2)
+    for g, e in zip(grads3, go2):
+        close(g, e)
+    close(ops.loglik(td, c2d, ad, Ud, Vd, yd)[0], llo2)
+    if N > 2:   # a failed series: flag, -inf, NaN gradients; its neighbours in the wavefront untouched
+        a2 = a.copy(); a2[1, N // 2] = -5.0
+        (a2d,) = dev(a2)
+        ll4, grads4, flag4 = ops.loglik_grad(td, cd, a2d, Ud, Vd, yd)
+        assert int(flag4[1]) == N // 2 and int(flag4[0]) == 0 and np.isneginf(float(ll4[1]))
+        good = [b for b in range(B) if b != 1]
+        close(ll4[good], llo[good])
+        for g, e in zip(grads4, go):
+            assert bool(np.isnan(g[1].cpu().numpy()).all())
+            close(g[good], e[good])
+    t0d, c0d = dev(t[0].copy(), c[0].copy())
+    ts, cs = np.tile(t[0], (B, 1)), np.tile(c[0], (B, 1))
+    llo5, go5, flo5 = oracle.loglik_grad_batched(ts, cs, a, U, V, y, nthreads=2)
+    ll5, grads5, flag5 = ops.loglik_grad(t0d, c0d, ad, Ud, Vd, yd)
+    ok = flo5 == 0
+    assert np.array_equal(flag5.cpu().numpy() != 0, ~ok)
+    close(ll5[ok], llo5[ok])
+    for g, e in zip(grads5, go5):
+        close(g[ok], e[ok])
+    if N >= 4:   # long gaps in the second half of the batch's first group of 64 series only
+        tg = t.copy(); tg[40:64, N // 2:] += 300.0
+        (tgd,) = dev(tg)
+        llo6, go6, flo6 = oracle.loglik_grad_batched(tg, c, a, U, V, y, nthreads=2)
+        import torch
+        work = ops.loglik_grad_workspace(B, N, J, ad.device)
+        ll6, grads6, flag6 = ops.loglik_grad(tgd, cd, ad, Ud, Vd, yd, work=work)
+        torch.cuda.synchronize()
+        # (one wavefront of 32 series raised the word of its group, if c * gap is beyond the guard at all)
+        assert int(work[:2].view(torch.int64)[1]) == (1 if float(work[0]) > 2.0 else 0)
+        ok = flo6 == 0
+        close(ll6[ok], llo6[ok])
+        for g, e in zip(grads6, go6):
+            close(g[ok], e[ok])
+
+
+@pytest.mark.parametrize("lanes,J", [(1, 8), (1, 6), (1, 4), (1, 2), (2, 8)])
+def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, lanes, J):
     """Gaps in time (nights, seasons) under the one-lane mapping: the backward recursion of the reverse sweep cannot invert
     the decay across a gap, so the forward pass records an EXTRA checkpoint in front of it (wavefront-uniform, c2_loglik_t.hip)
     and the sweep stays on the one-lane kernels -- the guard word (first double of the workspace: the largest of the
@@ -366,8 +428,11 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
     replay kernels take ITS 64 series (the second word of the workspace counts the wavefronts that fell back), the rest
     of the batch stays on the one-lane kernels.  Results are the oracle's in every case."""
     import torch
-    monkeypatch.setenv("C2_LANES", "1")
-    B, N = 150, 420   # (13 regular checkpoints and as many extra slots per wavefront)
+    monkeypatch.setenv("C2_LANES", str(lanes))
+    # (14 regular checkpoints and twice as many extra slots per wavefront; the two-lane mapping of c2_loglik_k2.hip -- 32
+    # series per wavefront, whole groups of 64 -- re-anchors the same way)
+    B, N = (150 if lanes == 1 else 192), 420
+    wave = 64 // lanes
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
     rng = np.random.default_rng(99)
 
@@ -424,7 +489,7 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
             tg[b, int(n0):] += 30.0 / c.max()
     # (750 gaps: bt next to a gap is the difference of two gap gradients -- one element in 63000 lands at 2.2e-12 of the
     # largest, on the replay kernels that passed the single-gap cases of the round-2 suite unchanged)
-    assert run(tg, floor=4e-12) > 2.0 and run.nfall == 3
+    assert run(tg, floor=4e-12) > 2.0 and run.nfall == -(-B // wave)
     # (6) the same for the series of ONE wavefront only (64 .. 127): that wavefront falls back, its neighbours do not -- a
     # wavefront that runs out of slots costs 64 series, not the batch -- and one series with two gaps in the last wavefront
     tg = t.copy()
@@ -432,7 +497,7 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, J):
         for n0 in rng.integers(1, N, size=5):
             tg[b, int(n0):] += 30.0 / c.max()
     tg[140, 100:] += 10.0; tg[140, 300:] += 10.0
-    assert run(tg, floor=4e-12) > 2.0 and run.nfall == 1
+    assert run(tg, floor=4e-12) > 2.0 and run.nfall == lanes
     # (7) three gaps of its own in every series of a batch whose wavefronts have the slots for them (N = 4096 in the bench's
     # `gappy_all` object; here 8 series per wavefront would need B < 64: 9 series x 3 gaps = 27 <= 28 extras)
     tg = t.copy()

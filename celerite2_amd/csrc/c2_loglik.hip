@@ -839,7 +839,7 @@ C2_DECL_T(2)
 #undef C2_DECL_T
 // guard words in front of the records of the one-lane path: the head + one per wavefront, rounded to 16 bytes
 static size_t lanes1_gate_words(int64_t B) { return (size_t)((kGateHeadWords + (B + kWave - 1) / kWave + 1) & ~(int64_t)1); }
-// Two lanes per series (c2_loglik_k2.hip, J == 8, whole groups of 64 series): 32 series per wavefront -- the batches that
+// Two lanes per series (c2_loglik_k2.hip, J == 8): 32 series per wavefront -- the batches that
 // give the one-lane mapping half a chip.  C2_LANES=2 forces it.
 extern "C" int c2_internal_loglik_k2_ok(int64_t B, int64_t N, int64_t J);
 extern "C" int c2_internal_loglik_k2(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,

@@ -24,8 +24,7 @@
 // twice the regular number per wavefront); a wavefront that runs out of them marks its group of 64 series and the replay
 // kernels take those.  Which rows carry a checkpoint is the sign of their d record; the slots are consumed in reverse order of
 // writing, so the reverse sweep needs their number and no list.
-// Not here (the dispatch keeps the other mappings for them): partial groups (B % 64 != 0), widths other than 8, the
-// coefficient-level form.
+// Not here (the dispatch keeps the other mappings for them): widths other than 8, the coefficient-level form.
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -81,13 +80,18 @@ __device__ __forceinline__ void pair_total(const double (&own)[J], double (&tot)
 
 // ---- tile movers (32 series per wavefront) -------------------------------------------------------------------------------
 // two-row tile of a width-8 array: one instruction moves 8 series x 128 bytes (lane l: series 8 i + l / 8, piece l % 8)
-__device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, int lane, double (&st)[8]) {
+// (`last`: the last series of the wavefront that exists -- fetches of the others read it instead, flushes skip them)
+template <bool FULL>
+__device__ __forceinline__ int clamp_series(int sr, int last) { return (FULL || sr < last) ? sr : last; }
+template <bool FULL>
+__device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64_t N, int64_t n0, int lane, int last,
+                                          double (&st)[8]) {
   int64_t r = n0 + (lane & 7) / 4;
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
   const int64_t off = r * J + 2 * (lane & 3);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + off);
+    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)clamp_series<FULL>(8 * i + lane / 8, last) * N * J + off);
     st[2 * i] = v.x; st[2 * i + 1] = v.y;
   }
 }
@@ -110,7 +114,9 @@ __device__ __forceinline__ void row_write_half(double *tile, int sl, int h, int 
   *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h + 2) = make_double2(x[2], x[3]);
 }
 // tile -> memory: rows n0, n0 + 1 of every series (rows outside [0, N-1] skipped)
-__device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane) {
+template <bool FULL>
+__device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane,
+                                          int last) {
   const int64_t r = n0 + (lane & 7) / 4;
   double2 v[4];
 #pragma unroll
@@ -118,16 +124,18 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
   if (r >= 0 && r < N) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + r * J + 2 * (lane & 3)) = v[i];
+      if (FULL || 8 * i + lane / 8 <= last)
+        *reinterpret_cast<double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + r * J + 2 * (lane & 3)) = v[i];
   }
 }
 // per-series scalar streams in 16-row tiles: one instruction moves 4 series x 128 bytes
+template <bool FULL>
 __device__ __forceinline__ void sc_fetch16(const double *__restrict__ base, int64_t sN, int64_t N, int64_t n16, int lane,
-                                           double (&st)[8]) {
+                                           int last, double (&st)[8]) {
   int64_t r = n16 + (lane & 15);
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) st[i] = base[(int64_t)(4 * i + lane / 16) * sN + r];
+  for (int i = 0; i < 8; ++i) st[i] = base[(int64_t)clamp_series<FULL>(4 * i + lane / 16, last) * sN + r];
 }
 __device__ __forceinline__ void sc_stage16(double *tile, int lane, int half, const double (&st)[8]) {
   if (((lane & 15) >> 3) == half) {
@@ -136,14 +144,17 @@ __device__ __forceinline__ void sc_stage16(double *tile, int lane, int half, con
   }
 }
 // eight-row scalar tile -> memory: one instruction moves 8 series x 64 bytes
-__device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane) {
+template <bool FULL>
+__device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane,
+                                         int last) {
   const int64_t r = n0 + (lane & 7);
   double v[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = tile[(8 * i + lane / 8) * SSTR + (lane & 7)];
   if (r >= 0 && r < N) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) base[(int64_t)(8 * i + lane / 8) * N + r] = v[i];
+    for (int i = 0; i < 4; ++i)
+      if (FULL || 8 * i + lane / 8 <= last) base[(int64_t)(8 * i + lane / 8) * N + r] = v[i];
   }
 }
 
@@ -161,14 +172,17 @@ __device__ __forceinline__ void decay(const double (&c)[J], double dt, double (&
 // =====================================================================================================================
 // Forward pass.  REC: also W rows, (d, z), t, checkpoints and the stability measure of the backward recursion.
 // =====================================================================================================================
-template <bool REC, bool PAIRED>
+template <bool REC, bool PAIRED, bool FULL>
 __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                          const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                          const double *__restrict__ U, const double *__restrict__ V,
                                          const double *__restrict__ y, double *__restrict__ ll, int32_t *__restrict__ flag,
                                          double *__restrict__ rec, Rec R, unsigned long long *__restrict__ guard, double *lds) {
   const int lane = threadIdx.x, sl = lane >> 1, h = lane & 1;
-  const int64_t b0 = (int64_t)blockIdx.x * SPW, b = b0 + sl;
+  const int64_t b0 = (int64_t)blockIdx.x * SPW;
+  const int last = (int)((B - b0 < SPW ? B - b0 : SPW) - 1);   // lanes beyond the batch walk a copy of its last series
+  const bool real = sl <= last;
+  const int64_t b = b0 + (real ? sl : last);
   double *tU = lds, *tV = tU + SPW * RSTR, *tT = tV + SPW * RSTR, *tA = tT + SPW * SSTR, *tY = tA + SPW * SSTR;
   const double *Ub = U + b0 * N * J, *Vb = V + b0 * N * J, *ab = a + b0 * N, *yb = y + b0 * N;
   const double *tb = t + (t_bs ? b0 * N : 0);
@@ -216,15 +230,15 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   if (REC) write_rec(0, false);
 
   double su[8], sv[8], st_[8], sa_[8], sy_[8];
-  row_fetch(Ub, N, 0, lane, su); row_fetch(Vb, N, 0, lane, sv);
-  sc_fetch16(tb, tN, N, 0, lane, st_); sc_fetch16(ab, N, N, 0, lane, sa_); sc_fetch16(yb, N, N, 0, lane, sy_);
+  row_fetch<FULL>(Ub, N, 0, lane, last, su); row_fetch<FULL>(Vb, N, 0, lane, last, sv);
+  sc_fetch16<FULL>(tb, tN, N, 0, lane, last, st_); sc_fetch16<FULL>(ab, N, N, 0, lane, last, sa_); sc_fetch16<FULL>(yb, N, N, 0, lane, last, sy_);
   for (int64_t n0 = 0; n0 < N; n0 += ST) {
     const int half = (int)((n0 >> 3) & 1);
     lds_order();
     sc_stage16(tT, lane, half, st_); sc_stage16(tA, lane, half, sa_); sc_stage16(tY, lane, half, sy_);
     if (half == 1) {
-      sc_fetch16(tb, tN, N, n0 + ST, lane, st_); sc_fetch16(ab, N, N, n0 + ST, lane, sa_);
-      sc_fetch16(yb, N, N, n0 + ST, lane, sy_);
+      sc_fetch16<FULL>(tb, tN, N, n0 + ST, lane, last, st_); sc_fetch16<FULL>(ab, N, N, n0 + ST, lane, last, sa_);
+      sc_fetch16<FULL>(yb, N, N, n0 + ST, lane, last, sy_);
     }
 #pragma unroll
     for (int rt = 0; rt < ST / 2; ++rt) {
@@ -232,7 +246,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
       if (nt < N) {
         lds_order();
         row_stage(tU, lane, su); row_stage(tV, lane, sv);
-        row_fetch(Ub, N, nt + 2, lane, su); row_fetch(Vb, N, nt + 2, lane, sv);
+        row_fetch<FULL>(Ub, N, nt + 2, lane, last, su); row_fetch<FULL>(Vb, N, nt + 2, lane, last, sv);
         lds_order();
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -289,7 +303,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
       }
     }
   }
-  if (h == 0) {
+  if (h == 0 && real) {
     int e2;
     prod = frexp(prod, &e2);
     const double logdet = log(prod) + (double)(eacc + e2) * kLn2;
@@ -322,12 +336,16 @@ __global__ __launch_bounds__(kWave, 1) void k_k2_fwd(int64_t B, int64_t N, const
                                                      double *__restrict__ ll, int32_t *__restrict__ flag,
                                                      double *__restrict__ rec, Rec R, unsigned long long *__restrict__ guard) {
   __shared__ __attribute__((aligned(16))) double lds[kFwdLds / 8];
-  const int64_t bb = (int64_t)blockIdx.x * SPW + (threadIdx.x >> 1);
+  int64_t bb = (int64_t)blockIdx.x * SPW + (threadIdx.x >> 1);
+  bb = bb < B ? bb : B - 1;
   bool paired = true;
 #pragma unroll
   for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
-  if (__all(paired)) fwd_body<REC, true>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
-  else fwd_body<REC, false>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds);
+  const bool full = B - (int64_t)blockIdx.x * SPW >= SPW;
+#define C2K2_FWD(P_, F_) fwd_body<REC, P_, F_>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard, lds)
+  if (__all(paired)) { if (full) C2K2_FWD(true, true); else C2K2_FWD(true, false); }
+  else { if (full) C2K2_FWD(false, true); else C2K2_FWD(false, false); }
+#undef C2K2_FWD
 }
 
 // =====================================================================================================================
@@ -337,14 +355,17 @@ __global__ __launch_bounds__(kWave, 1) void k_k2_fwd(int64_t B, int64_t N, const
 // =====================================================================================================================
 constexpr int kRevLds = (2 * SPW * RSTR + 3 * SPW * SSTR) * 8;
 
-template <bool PAIRED>
+template <bool PAIRED, bool FULL>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
                                          const double *__restrict__ U, const int32_t *__restrict__ flag,
                                          const double *__restrict__ rec, Rec R, double *__restrict__ bt,
                                          double *__restrict__ bc, double *__restrict__ ba, double *__restrict__ bU,
                                          double *__restrict__ bV, double *__restrict__ by, double *lds) {
   const int lane = threadIdx.x, sl = lane >> 1, h = lane & 1;
-  const int64_t b0 = (int64_t)blockIdx.x * SPW, b = b0 + sl;
+  const int64_t b0 = (int64_t)blockIdx.x * SPW;
+  const int last = (int)((B - b0 < SPW ? B - b0 : SPW) - 1);
+  const bool real = sl <= last;
+  const int64_t b = b0 + (real ? sl : last);
   double *tU = lds, *tBV = tU + SPW * RSTR, *tBA = tBV + SPW * RSTR, *tBY = tBA + SPW * SSTR, *tBT = tBY + SPW * SSTR;
   const double *Ub = U + b0 * N * J;
   double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
@@ -401,20 +422,20 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     tBA[sl * SSTR + (nf & (ST - 1))] = ban;
     tBY[sl * SSTR + (nf & (ST - 1))] = bzn;
     lds_order();
-    if (ph0 == 0) row_flush(bVb, N, nf, tBV, lane);   // (an even last row: its pair partner lies beyond the series: only row nf)
+    if (ph0 == 0) row_flush<FULL>(bVb, N, nf, tBV, lane, last);   // (an even last row: its pair partner lies beyond the series: only row nf)
     if ((nf & (ST - 1)) == 0) {                       // the last row alone at the bottom of its scalar tile
-      sc_flush(bab, N, nf, tBA, lane);
-      sc_flush(byb, N, nf, tBY, lane);
+      sc_flush<FULL>(bab, N, nf, tBA, lane, last);
+      sc_flush<FULL>(byb, N, nf, tBY, lane, last);
     }
     double su[8], wa[J];
     double2 dza;
     double ta;
-    row_fetch(Ub, N, nf - ph0, lane, su);
+    row_fetch<FULL>(Ub, N, nf - ph0, lane, last, su);
     if (ph0 != 1) {   // the first step is not a staging one: its tile goes into LDS here
       lds_order();
       row_stage(tU, lane, su);
       lds_order();
-      row_fetch(Ub, N, nf - ph0 - 2, lane, su);
+      row_fetch<FULL>(Ub, N, nf - ph0 - 2, lane, last, su);
     }
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
@@ -429,7 +450,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       if constexpr (PH == 1) {   // the step that puts its pair of U rows into LDS and requests the pair below
         lds_order();
         row_stage(tU, lane, su);
-        row_fetch(Ub, N, n - 3, lane, su);
+        row_fetch<FULL>(Ub, N, n - 3, lane, last, su);
       }
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
@@ -510,12 +531,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       lds_order();
       // width-8 outputs leave as aligned pairs of rows: bU at the end of the even step (rows n, n + 1), bV at the end of the odd
       // step (rows n - 1, n)
-      if constexpr (PH == 0) row_flush(bUb, N, n, tU, lane);
-      else row_flush(bVb, N, n - 1, tBV, lane);
-      if ((n & (ST - 1)) == 0) sc_flush(btb, N, n, tBT, lane);
+      if constexpr (PH == 0) row_flush<FULL>(bUb, N, n, tU, lane, last);
+      else row_flush<FULL>(bVb, N, n - 1, tBV, lane, last);
+      if ((n & (ST - 1)) == 0) sc_flush<FULL>(btb, N, n, tBT, lane, last);
       if (rs == 0) {
-        sc_flush(bab, N, n - 1, tBA, lane);
-        sc_flush(byb, N, n - 1, tBY, lane);
+        sc_flush<FULL>(bab, N, n - 1, tBA, lane, last);
+        sc_flush<FULL>(byb, N, n - 1, tBY, lane, last);
       }
       if (ckm && n >= 2) load_ckpt();   // the state of row n-1 is on record: it replaces the recursed one
 #pragma unroll
@@ -536,18 +557,20 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       row_write_half(tU, sl, h, 0, zero);   // bU_1 is waiting in row 1 of the tile
       if (h == 0) tBT[sl * SSTR] = carry;
       lds_order();
-      row_flush(bUb, N, 0, tU, lane);
-      sc_flush(btb, N, 0, tBT, lane);
+      row_flush<FULL>(bUb, N, 0, tU, lane, last);
+      sc_flush<FULL>(btb, N, 0, tBT, lane, last);
     }
-  } else if (h == 0) {   // N == 1: seeds only
+  } else if (h == 0 && real) {   // N == 1: seeds only
     bab[(int64_t)sl * N] = ban;
     byb[(int64_t)sl * N] = bzn;
     btb[(int64_t)sl * N] = failed ? nan : 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) { bUb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; }
   }
+  if (real) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) bc[b * J + 4 * h + j] = bcj[j];   // local 0..3 = global 4h .. 4h+3
+    for (int j = 0; j < 4; ++j) bc[b * J + 4 * h + j] = bcj[j];   // local 0..3 = global 4h .. 4h+3
+  }
 }
 
 __global__ __launch_bounds__(kWave, 1) void k_k2_rev(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
@@ -560,12 +583,16 @@ __global__ __launch_bounds__(kWave, 1) void k_k2_rev(int64_t B, int64_t N, const
   __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
   const int64_t b0 = (int64_t)blockIdx.x * SPW;
   if (__longlong_as_double((long long)guard[kGateHeadWords + (b0 >> 6)]) > kGuard) return;   // the replay kernels take this group
-  const int64_t bb = b0 + (threadIdx.x >> 1);
+  int64_t bb = b0 + (threadIdx.x >> 1);
+  bb = bb < B ? bb : B - 1;
   bool paired = true;
 #pragma unroll
   for (int k = 0; k < J / 2; ++k) paired = paired && (c[bb * c_bs + 2 * k] == c[bb * c_bs + 2 * k + 1]);
-  if (__all(paired)) rev_body<true>(B, N, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
-  else rev_body<false>(B, N, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds);
+  const bool full = B - b0 >= SPW;
+#define C2K2_REV(P_, F_) rev_body<P_, F_>(B, N, c, c_bs, U, flag, rec, R, bt, bc, ba, bU, bV, by, lds)
+  if (__all(paired)) { if (full) C2K2_REV(true, true); else C2K2_REV(true, false); }
+  else { if (full) C2K2_REV(false, true); else C2K2_REV(false, false); }
+#undef C2K2_REV
 }
 
 }  // namespace c2k2
@@ -574,26 +601,25 @@ using namespace c2k2;
 
 extern "C" {
 
-// whole wavefronts of 32 series only
-int c2_internal_loglik_k2_ok(int64_t B, int64_t N, int64_t J) { return J == 8 && B >= SPW && B % 64 == 0 && N >= 2; }
+int c2_internal_loglik_k2_ok(int64_t B, int64_t N, int64_t J) { return J == 8 && B >= 1 && N >= 1; }
 
 int c2_internal_loglik_k2(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
                           const double *U, const double *V, const double *y, double *ll, int32_t *flag, c2_stream_t stream) {
   Rec R{};
-  hipLaunchKernelGGL((k_k2_fwd<false>), dim3((unsigned)(B / SPW)), dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs,
+  hipLaunchKernelGGL((k_k2_fwd<false>), dim3((unsigned)((B + SPW - 1) / SPW)), dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs,
                      a, U, V, y, ll, flag, (double *)nullptr, R, (unsigned long long *)nullptr);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
 size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N) { return rec_layout(B, N).total; }
 
-// Forward with records + reverse sweep.  `guard`: kGateHeadWords + B / 64 device words, ALL zeroed by the caller on the same
+// Forward with records + reverse sweep.  `guard`: kGateHeadWords + ceil(B / 64) device words, ALL zeroed by the caller on the same
 // stream (the two wavefronts of a group of 64 series raise its word together).
 int c2_internal_loglik_k2_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                                const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
                                double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, double *rec,
                                unsigned long long *guard, c2_stream_t stream) {
-  const dim3 grid((unsigned)(B / SPW));
+  const dim3 grid((unsigned)((B + SPW - 1) / SPW));
   const Rec R = rec_layout(B, N);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL((k_k2_fwd<true>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, rec, R, guard);

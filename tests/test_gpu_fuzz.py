@@ -233,12 +233,12 @@ def test_fuzz_one_lane_kernels(ops, oracle, monkeypatch, seed):
 
 @pytest.mark.parametrize("seed", list(range(40)))
 def test_fuzz_two_lane_kernels(ops, oracle, monkeypatch, seed):
-    """The two-lanes-per-series kernels (width 8, whole groups of 64 series; c2_loglik_k2.hip) forced on random shapes: series
+    """The two-lanes-per-series kernels (width 8; c2_loglik_k2.hip) forced on random shapes: ragged wavefronts, series
     lengths around the row-tile (2), scalar-tile (8 / 16) and checkpoint (32) periods, paired / unpaired rates, shared grids,
     an occasional failed series, gaps of single series and of all (re-anchored, or beyond the extra slots: the gated replay
     kernels then answer for that group)."""
     rng = np.random.default_rng(9300 + seed)
-    B = int(rng.choice([64, 128, 192]))
+    B = int(rng.choice([1, 2, 31, 33, 64, 65, 100, 128, 190, 192]))
     N = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 16, 17, 18, 31, 32, 33, 34, 63, 64, 65, 66, 97, 130, 257, 420]))
     J = 8
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
@@ -249,14 +249,14 @@ def test_fuzz_two_lane_kernels(ops, oracle, monkeypatch, seed):
     if N > 40 and kind < 0.25:
         t[:, N // 2:] += rng.choice([3.0, 400.0])                     # a gap in every series at the same row
     elif N > 40 and kind < 0.5:
-        for b in rng.choice(B, size=int(rng.choice([3, 40, B])), replace=False):   # gaps of their own: a few series .. all
+        for b in rng.choice(B, size=min(B, int(rng.choice([3, 40, B]))), replace=False):   # gaps of their own: a few series .. all
             for n0 in rng.integers(1, N, size=int(rng.integers(1, 4))):
                 t[b, int(n0):] += 30.0 / c.max()
     shared = rng.random() < 0.3
     if shared:
         t = np.tile(t[0], (B, 1)); c = np.tile(c[0], (B, 1))
     bad = None
-    if N > 4 and rng.random() < 0.4:
+    if N > 4 and B > 3 and rng.random() < 0.4:
         bad = int(rng.integers(0, B)); a[bad, int(rng.integers(1, N))] = -7.0
     llo, go, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
     monkeypatch.setenv("C2_LANES", "2")

@@ -14,12 +14,15 @@
 // themselves, are kept by BOTH lanes and enter every sum over the elements with weight 1/2.  Sums over the elements
 // (tau = u S; xs = x S, diag(S M), q = w M in the reverse step) are completed by ONE exchange with the partner lane per
 // vector -- own[j] + partner[(j + 4) mod 8], a DPP quad permute -- and dot products of width-8 vectors are formed as
-// (sum over local 0..3) + (sum over local 4..7), which is the same two numbers added in either lane.
+// (own half over local 0..3) + (the partner's half), which is the same two numbers added in either lane.  Where a lane only
+// ever uses a half of a vector (the solve state F and its cotangent, the half rows of the outputs, the accumulators of bc)
+// only that half is kept; w (forward) and bV (reverse), needed whole by the pass over the elements, are computed by halves
+// and completed from the partner, the decay factors and their inverses likewise.
 //
 // Everything else is the one-lane design: rows through LDS transposes in aligned 128-byte lines, lane-major records of W,
 // (d, z), t and a checkpoint every 32 rows written by the forward pass, the reverse sweep running the recursion BACKWARD from
 // the checkpoints (reference steps: forward.hpp:105-134, internal.hpp:135-145, 225-245, reverse.hpp:52-84; the fused reverse
-// step is derived in c2_loglik.hip).  With 20 instead of 36 elements per lane both states live in ordinary registers.
+// step is derived in c2_loglik.hip).  With 20 instead of 36 elements per lane S lives in ordinary registers, M in LDS.
 // Gaps in time are re-anchored as there: an extra checkpoint in front of a gap the backward recursion could not cross (up to
 // twice the regular number per wavefront); a wavefront that runs out of them marks its group of 64 series and the replay
 // kernels take those.  Which rows carry a checkpoint is the sign of their d record; the slots are consumed in reverse order of
@@ -65,17 +68,19 @@ __host__ inline Rec rec_layout(int64_t B, int64_t N) {
 }
 
 __device__ __forceinline__ double swap_pair(double x) { return dpp_mov<kDppXor1>(x); }   // the partner lane's value
-// (sum over local 0..3) + (sum over local 4..7): the same two numbers in either lane of a pair
-__device__ __forceinline__ double dot8(const double (&x)[J], const double (&y)[J]) {
-  double a = 0.0, b = 0.0;
+// own[j] + partner[j + 4], j = 0..3: the sum over ALL elements from the two lanes' partial sums, for this lane's local 0..3
+// (which are the partner's local 4..7)
+__device__ __forceinline__ void pair_total4(const double (&own)[J], double (&tot)[4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { a = fma(x[i], y[i], a); b = fma(x[i + 4], y[i + 4], b); }
-  return a + b;
+  for (int j = 0; j < 4; ++j) tot[j] = own[j] + swap_pair(own[j + 4]);
 }
-// own[j] + partner[(j + 4) & 7]: the sum over ALL elements from the two lanes' partial sums
-__device__ __forceinline__ void pair_total(const double (&own)[J], double (&tot)[J]) {
+// a dot product of two width-8 vectors from its half over this lane's local 0..3: (own half) + (partner's half), the same two
+// numbers in either lane
+__device__ __forceinline__ double dot_halves(const double (&x)[4], const double *y) {
+  double a = 0.0;
 #pragma unroll
-  for (int j = 0; j < J; ++j) tot[j] = own[j] + swap_pair(own[(j + 4) & 7]);
+  for (int i = 0; i < 4; ++i) a = fma(x[i], y[i], a);
+  return a + swap_pair(a);
 }
 
 // ---- tile movers (32 series per wavefront) -------------------------------------------------------------------------------
@@ -109,7 +114,7 @@ __device__ __forceinline__ void row_read(const double *tile, int sl, int h, int 
   }
 }
 // local elements 0..3 (= global 4h .. 4h+3) of a width-8 row into the tile: the two lanes of a pair write the row together
-__device__ __forceinline__ void row_write_half(double *tile, int sl, int h, int r, const double (&x)[J]) {
+__device__ __forceinline__ void row_write_half(double *tile, int sl, int h, int r, const double *x) {
   *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h) = make_double2(x[0], x[1]);
   *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h + 2) = make_double2(x[2], x[3]);
 }
@@ -158,14 +163,33 @@ __device__ __forceinline__ void sc_flush(double *__restrict__ base, int64_t N, i
   }
 }
 
+// p_j = exp(c_j dt) in local order: each lane evaluates its local 0..3 and takes 4..7 -- the partner's 0..3, the same
+// numbers it would have computed -- from the partner.  PAIRED: c_{2k} == c_{2k+1} for every series of the wavefront.
 template <bool PAIRED>
 __device__ __forceinline__ void decay(const double (&c)[J], double dt, double (&p)[J]) {
   if constexpr (PAIRED) {
-#pragma unroll
-    for (int k = 0; k < J / 2; ++k) p[2 * k] = p[2 * k + 1] = exp_decay(c[2 * k] * dt);
+    const double a = exp_decay(c[0] * dt), b = exp_decay(c[2] * dt);
+    const double a2 = swap_pair(a), b2 = swap_pair(b);
+    p[0] = p[1] = a; p[2] = p[3] = b; p[4] = p[5] = a2; p[6] = p[7] = b2;
   } else {
 #pragma unroll
-    for (int j = 0; j < J; ++j) p[j] = exp_decay(c[j] * dt);
+    for (int j = 0; j < 4; ++j) p[j] = exp_decay(c[j] * dt);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[4 + j] = swap_pair(p[j]);
+  }
+}
+// 1 / p_j the same way
+template <bool PAIRED>
+__device__ __forceinline__ void inverses(const double (&p)[J], double (&ip)[J]) {
+  if constexpr (PAIRED) {
+    const double a = rcp_nr(p[0]), b = rcp_nr(p[2]);
+    const double a2 = swap_pair(a), b2 = swap_pair(b);
+    ip[0] = ip[1] = a; ip[2] = ip[3] = b; ip[4] = ip[5] = a2; ip[6] = ip[7] = b2;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ip[j] = rcp_nr(p[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ip[4 + j] = swap_pair(ip[j]);
   }
 }
 
@@ -198,11 +222,13 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   double S[NL];
 #pragma unroll
   for (int e = 0; e < NL; ++e) S[e] = 0.0;
-  double F[J], w[J];
+  double F[4], w[J];   // (F: this lane's local 0..3 only -- every use is a half of a dot product or a checkpoint)
   double tprev = t[b * t_bs];
   double d = a[b * N], z = y[b * N], rd = 1.0 / d;
 #pragma unroll
-  for (int j = 0; j < J; ++j) { F[j] = 0.0; w[j] = V[b * N * J + ((j + 4 * h) & 7)] * rd; }
+  for (int j = 0; j < J; ++j) w[j] = V[b * N * J + ((j + 4 * h) & 7)] * rd;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) F[j] = 0.0;
   double prod = d, quad = z * z * rd;
   int eacc = 0;
   int32_t fl = 0;
@@ -272,7 +298,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
             row_read(tU, sl, h, r, u); row_read(tV, sl, h, r, v);
             decay<PAIRED>(cj, dt, p);
             // S = P (S + d w^T w) P (forward.hpp:115-123); tau = U_n S (forward.hpp:126): own elements, then the pair's total
-            double dw[J], tau[J], taut[J];
+            double dw[J], tau[J], taut[4];
 #pragma unroll
             for (int i = 0; i < J; ++i) { dw[i] = d * w[i]; tau[i] = 0.0; }
 #pragma unroll
@@ -284,15 +310,17 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
               tau[j2] = fma(u[i], se, tau[j2]);
               if (j2 != i) tau[i] = fma(u[j2], se, tau[i]);
             }
-            pair_total(tau, taut);
+            pair_total4(tau, taut);
             // F = P (F + W_{n-1}^T z_{n-1})   (internal.hpp:140-143)
 #pragma unroll
-            for (int j2 = 0; j2 < J; ++j2) F[j2] = p[j2] * fma(w[j2], z, F[j2]);
-            d = an - dot8(taut, u);   // forward.hpp:127
-            z = yn - dot8(u, F);      // internal.hpp:144
+            for (int j2 = 0; j2 < 4; ++j2) F[j2] = p[j2] * fma(w[j2], z, F[j2]);
+            d = an - dot_halves(taut, u);   // forward.hpp:127
+            z = yn - dot_halves(F, u);      // internal.hpp:144
             rd = rcp_nr(d);
 #pragma unroll
-            for (int j2 = 0; j2 < J; ++j2) w[j2] = (v[j2] - taut[j2]) * rd;   // forward.hpp:131
+            for (int j2 = 0; j2 < 4; ++j2) w[j2] = (v[j2] - taut[j2]) * rd;   // forward.hpp:131
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) w[4 + j2] = swap_pair(w[j2]);      // (the partner's local 0..3)
             fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;                // forward.hpp:128
             prod *= d;
             quad = fma(z * z, rd, quad);
@@ -353,7 +381,16 @@ __global__ __launch_bounds__(kWave, 1) void k_k2_fwd(int64_t B, int64_t N, const
 // the backward recursion of S and F) on the local element set.  Entering step n: bz, ba, bV = complete cotangents of row n;
 // S, F = state of row n; M = bS + bS^T on the local elements; bF; carry = f_{n+1}.
 // =====================================================================================================================
-constexpr int kRevLds = (2 * SPW * RSTR + 3 * SPW * SSTR) * 8;
+// C2K2_MLDS: the cotangent state M lives in LDS (pairs of elements, lane-major: conflict-free 16-byte accesses) instead of
+// registers -- the reverse step has ~340 registers' worth of live values at its peak and every value beyond 256 costs
+// a move to and from the accumulation registers per step (16384 series: 10.1 against 10.9 ms)
+#ifndef C2K2_MLDS
+#define C2K2_MLDS 1
+#endif
+#ifndef C2K2_SLDS
+#define C2K2_SLDS 0   // the forward state S of the backward recursion likewise: measured, no (16384 series: 12.2 against 10.1 ms)
+#endif
+constexpr int kRevLds = (2 * SPW * RSTR + 3 * SPW * SSTR + (C2K2_MLDS ? NL * kWave : 0) + (C2K2_SLDS ? NL * kWave : 0)) * 8;
 
 template <bool PAIRED, bool FULL>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
@@ -375,15 +412,35 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const double *recCK = rec + R.ck + (size_t)blockIdx.x * R.nck * CKD * kWave;
   const bool failed = flag[b] != 0;   // NaN gradients for a failed factorisation
   const double nan = __builtin_nan("");
-  double cj[J], bcj[J];
+  double cj[J], bcj[4];
 #pragma unroll
-  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + ((j + 4 * h) & 7)]; bcj[j] = 0.0; }
+  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + ((j + 4 * h) & 7)];
 
-  double S[NL], M[NL], F[J], bF[J], bVn[J];
+  // F, bF, the accumulators of bc: this lane's local 0..3 only (every use is a half of a dot product, a half row of an output
+  // or a checkpoint); bV is needed whole by the pass over the elements and is completed from the partner
+  double F[4], bF[4], bVn[J];
+#if C2K2_SLDS
+  double2 *Sl = reinterpret_cast<double2 *>(tBT + SPW * SSTR + (C2K2_MLDS ? NL * kWave : 0)) + lane;
+#else
+  double S[NL];
+#endif
+#if C2K2_MLDS
+  double2 *Ml = reinterpret_cast<double2 *>(tBT + SPW * SSTR) + lane;   // elements 2q, 2q + 1 at Ml[q * kWave]
 #pragma unroll
-  for (int e = 0; e < NL; ++e) { S[e] = 0.0; M[e] = 0.0; }
+  for (int q = 0; q < NL / 2; ++q) Ml[q * kWave] = make_double2(0.0, 0.0);
+#else
+  double M[NL];
 #pragma unroll
-  for (int j = 0; j < J; ++j) { F[j] = 0.0; bF[j] = 0.0; bVn[j] = failed ? nan : 0.0; }
+  for (int e = 0; e < NL; ++e) M[e] = 0.0;
+#endif
+#if !C2K2_SLDS
+#pragma unroll
+  for (int e = 0; e < NL; ++e) S[e] = 0.0;
+#endif
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { F[j] = 0.0; bF[j] = 0.0; bcj[j] = 0.0; }
+#pragma unroll
+  for (int j = 0; j < J; ++j) bVn[j] = failed ? nan : 0.0;
   double carry = 0.0;
   const int64_t nf = N - 1;
   const double2 dzl = recDZ[(size_t)nf * SPW + sl];
@@ -397,12 +454,15 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   auto load_ckpt = [&]() {   // the recorded state of a checkpointed row replaces the recursed one
     --slot;
     const double *ck = recCK + (size_t)slot * CKD * kWave;
+#if C2K2_SLDS
+#pragma unroll
+    for (int q = 0; q < NL / 2; ++q) Sl[q * kWave] = make_double2(ck[(2 * q) * kWave + lane], ck[(2 * q + 1) * kWave + lane]);
+#else
 #pragma unroll
     for (int e = 0; e < NL; ++e) S[e] = ck[e * kWave + lane];
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) F[j] = ck[(NL + j) * kWave + lane];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) F[4 + j] = swap_pair(F[j]);   // the partner's local 0..3 are this lane's local 4..7
   };
   auto w_fetch = [&](int64_t row, double (&wv)[J]) {
     row = row < 0 ? 0 : row;
@@ -463,9 +523,9 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       tcur = tm;
       decay<PAIRED>(cj, dt, p);
       // solve_lower_rev part (internal.hpp:232-245)
-      double bp0[J];
+      double bp0[4];
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
+      for (int j = 0; j < 4; ++j) {
         bF[j] = fma(-u[j], bzn, bF[j]);
         bp0[j] = F[j] * bF[j];
         bF[j] *= p[j];
@@ -476,14 +536,31 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       double x[J], xs[J], q[J], bps[J];
       const double ba2 = 2.0 * ban;
 #pragma unroll
-      for (int j = 0; j < J; ++j) { x[j] = fma(ba2, u[j], bVn[j]); xs[j] = 0.0; q[j] = 0.0; bps[j] = 0.0; ip[j] = rcp_nr(p[j]); }
+      for (int j = 0; j < J; ++j) { x[j] = fma(ba2, u[j], bVn[j]); xs[j] = 0.0; q[j] = 0.0; bps[j] = 0.0; }
+      inverses<PAIRED>(p, ip);
+#if C2K2_MLDS
+      double2 mpair;
+#endif
+#if C2K2_SLDS
+      double2 spair;
+#endif
 #pragma unroll
       for (int e = 0; e < NL; ++e) {
         const int i = LI[e], j2 = LJ[e];
         const double wgt = e >= kHalfFrom ? 0.5 : 1.0;
+#if C2K2_SLDS
+        if ((e & 1) == 0) spair = Sl[(e / 2) * kWave];
+        const double sv = (e & 1) ? spair.y : spair.x;
+#else
         const double sv = S[e];
+#endif
         const double svw = e >= kHalfFrom ? 0.5 * sv : sv;
+#if C2K2_MLDS
+        if ((e & 1) == 0) mpair = Ml[(e / 2) * kWave];
+        double m = (e & 1) ? mpair.y : mpair.x;
+#else
         double m = M[e];
+#endif
         xs[j2] = fma(x[i], svw, xs[j2]);
         if (j2 != i) xs[i] = fma(x[j2], svw, xs[i]);
         m = fma(-u[i], bVn[j2], m);
@@ -491,36 +568,48 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         bps[j2] = fma(svw, m, bps[j2]);
         if (j2 != i) bps[i] = fma(svw, m, bps[i]);
         m *= p[i] * p[j2];
+#if C2K2_MLDS
+        if (e & 1) { mpair.y = m; Ml[(e / 2) * kWave] = mpair; } else mpair.x = m;
+#else
         M[e] = m;
+#endif
         const double mw = wgt * m;
         q[j2] = fma(wa[i], mw, q[j2]);
         if (j2 != i) q[i] = fma(wa[j2], mw, q[i]);
-        S[e] = fma(-(dm * wa[i]), wa[j2], sv * (ip[i] * ip[j2]));
+        const double snew = fma(-(dm * wa[i]), wa[j2], sv * (ip[i] * ip[j2]));
+#if C2K2_SLDS
+        if (e & 1) { spair.y = snew; Sl[(e / 2) * kWave] = spair; } else spair.x = snew;
+#else
+        S[e] = snew;
+#endif
       }
-      double xst[J], qt[J], bp[J];
-      pair_total(xs, xst);
-      pair_total(q, qt);
-      pair_total(bps, bp);
+      // from here on every vector is this lane's local 0..3; scalars are (own half) + (partner's half)
+      double xst[4], qt[4], bp[4];
+      pair_total4(xs, xst);
+      pair_total4(q, qt);
+      pair_total4(bps, bp);
 #pragma unroll
-      for (int j = 0; j < J; ++j) bp[j] += bp0[j];
+      for (int j = 0; j < 4; ++j) bp[j] += bp0[j];
       {
-        double o[J];
+        double o[4];
 #pragma unroll
-        for (int j = 0; j < J; ++j) o[j] = fma(-bzn, F[j], -xst[j]);   // bU_n = -bz_n F_n - x S_n
+        for (int j = 0; j < 4; ++j) o[j] = fma(-bzn, F[j], -xst[j]);   // bU_n = -bz_n F_n - x S_n
         row_write_half(tU, sl, h, PH, o);                               // bU_n takes the place of U_n in the tile
       }
 #pragma unroll
-      for (int j = 0; j < J; ++j) bcj[j] = fma(dt, bp[j], bcj[j]);
-      const double f = dot8(cj, bp);
+      for (int j = 0; j < 4; ++j) bcj[j] = fma(dt, bp[j], bcj[j]);
+      const double f = dot_halves(bp, cj);
       const double btn = carry - f;
       carry = f;
 #pragma unroll
-      for (int j = 0; j < J; ++j) F[j] = fma(-wa[j], zm, F[j] * ip[j]);   // F_{n-1} = P^-1 F_n - w_{n-1} z_{n-1}
-      const double Gs = dot8(wa, bF), Q = dot8(qt, wa);
+      for (int j = 0; j < 4; ++j) F[j] = fma(-wa[j], zm, F[j] * ip[j]);   // F_{n-1} = P^-1 F_n - w_{n-1} z_{n-1}
+      const double Gs = dot_halves(bF, wa), Q = dot_halves(qt, wa);
       const double zr = zm * rdm;
       bzn = Gs - zr;
 #pragma unroll
-      for (int j = 0; j < J; ++j) bVn[j] = fma(zr, bF[j], qt[j]);
+      for (int j = 0; j < 4; ++j) bVn[j] = fma(zr, bF[j], qt[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bVn[4 + j] = swap_pair(bVn[j]);   // (the partner's local 0..3)
       ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
       if (h == 0) {
         tBA[sl * SSTR + rs] = ban;

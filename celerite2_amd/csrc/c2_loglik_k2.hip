@@ -466,14 +466,22 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   };
   auto w_fetch = [&](int64_t row, double (&wv)[J]) {
     row = row < 0 ? 0 : row;
+#ifdef C2K2_EXP_CACHED_RECORDS
+    row &= 3;
+#endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const double2 v = recW[((size_t)row * 4 + ((q + 2 * h) & 3)) * SPW + sl];
       wv[2 * q] = v.x; wv[2 * q + 1] = v.y;
     }
   };
+#ifdef C2K2_EXP_CACHED_RECORDS   // (timing experiment: every record load hits the cache -- what is left is arithmetic and stores)
+  auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)((row < 0 ? 0 : row) & 3) * SPW + sl]; };
+  auto t_fetch = [&](int64_t row) { return recT[(size_t)((row < 0 ? 0 : row) & 3) * SPW + sl]; };
+#else
   auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)(row < 0 ? 0 : row) * SPW + sl]; };
   auto t_fetch = [&](int64_t row) { return recT[(size_t)(row < 0 ? 0 : row) * SPW + sl]; };
+#endif
 
   if (N >= 2) {
     // ---- prologue: bV, ba, by of the last row are pure seeds ---------------------------------------------------------------

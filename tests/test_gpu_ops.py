@@ -709,12 +709,14 @@ def test_bench_scale_batch(ops, oracle):
         assert torch.equal(g[:nb].repeat((rep,) + (1,) * (g.dim() - 1)), g)
 
 
-def test_config2_full_batch_one_gpu(ops, oracle):
+@pytest.mark.parametrize("B", [65536, 32768, 16384])
+def test_config2_full_batch_one_gpu(ops, oracle, B):
     """BASELINE configs[2] at the size the bench runs on ONE GPU: 65536 series x N=4096 x J=8, forward + gradient
-    (41 GB of inputs, 41 GB of gradients, the replay records).  8 distinct series tile the batch: every replica must
-    equal its original bit for bit wherever it sits, the distinct ones must match the oracle."""
+    (41 GB of inputs, 41 GB of gradients, the replay records) -- and at its 2- and 4-GPU shards, which the dispatch gives
+    to the two-lanes-per-series kernels.  8 distinct series tile the batch: every replica must equal its original bit
+    for bit wherever it sits (even / odd pair of a wavefront, any wavefront), the distinct ones must match the oracle."""
     import torch
-    B, N, J, nb = 65536, 4096, 8, 8
+    N, J, nb = 4096, 8, 8
     t, c, a, U, V, y = dense.synthetic_batch(nb, N, J)
     rep = B // nb
     td, cd, ad, Ud, Vd, yd = [x.repeat((rep,) + (1,) * (x.dim() - 1)).contiguous() for x in dev(t, c, a, U, V, y)]

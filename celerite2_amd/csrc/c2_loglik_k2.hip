@@ -39,7 +39,8 @@ namespace c2k2 {
 using namespace c2;
 
 constexpr int J = 8, NL = 20, SPW = 32, C = 32, ST = 8;
-constexpr int RSTR = 2 * J + 2;   // LDS stride (doubles) of a series in a two-row tile: 144 B
+constexpr int RSTR = 2 * J;       // LDS stride (doubles) of a series in a two-row tile: one 128-byte line, its eight 16-byte
+                                  // pieces XOR-swizzled by the series (swz) -- see row_read
 constexpr int SSTR = ST + 1;      // ... in an eight-row scalar tile: 72 B
 constexpr int CKD = NL + 4;       // doubles a lane keeps per checkpoint: its 20 elements of S and its four of F
 constexpr double kGuard = kBackwardGuard;
@@ -100,23 +101,30 @@ __device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64
     st[2 * i] = v.x; st[2 * i + 1] = v.y;
   }
 }
+// Swizzle of a series' line: piece w = 4 r + p (row r, 16-byte piece p) lives at slot w ^ swz(series).  A ds_read_b128
+// is served in groups of 16 lanes -- eight series x the two lanes of a pair, which read pieces p and p ^ 2 of the same row --
+// over 16 slots of 16 bytes (64 banks): with 128-byte lines the eight series of a group are four at slot offset 0 and four
+// at 8, and bits 1, 2 of the series index, which enumerate either four, flip the piece's low bit and the row: every pair
+// lands on its own two slots.  (Stride 144 B, the one-lane kernels' padding: SQ_LDS_BANK_CONFLICT was 70 % of the LDS cycles.)
+__device__ __forceinline__ int swz(int series) { return ((series >> 1) & 1) | (((series >> 2) & 1) << 2); }
 __device__ __forceinline__ void row_stage(double *tile, int lane, const double (&st)[8]) {
+  const int w = (lane & 7) ^ swz(lane >> 3);   // (series 8 i + lane / 8: the swizzle does not depend on i)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    *reinterpret_cast<double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * (lane & 7)) = make_double2(st[2 * i], st[2 * i + 1]);
+    *reinterpret_cast<double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * w) = make_double2(st[2 * i], st[2 * i + 1]);
 }
 // this lane's row r of its series, in LOCAL order (pieces rotated by two for the odd lane)
 __device__ __forceinline__ void row_read(const double *tile, int sl, int h, int r, double (&x)[J]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const double2 v = *reinterpret_cast<const double2 *>(tile + sl * RSTR + r * J + 2 * ((q + 2 * h) & 3));
+    const double2 v = *reinterpret_cast<const double2 *>(tile + sl * RSTR + 2 * ((4 * r + ((q + 2 * h) & 3)) ^ swz(sl)));
     x[2 * q] = v.x; x[2 * q + 1] = v.y;
   }
 }
 // local elements 0..3 (= global 4h .. 4h+3) of a width-8 row into the tile: the two lanes of a pair write the row together
 __device__ __forceinline__ void row_write_half(double *tile, int sl, int h, int r, const double *x) {
-  *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h) = make_double2(x[0], x[1]);
-  *reinterpret_cast<double2 *>(tile + sl * RSTR + r * J + 4 * h + 2) = make_double2(x[2], x[3]);
+  *reinterpret_cast<double2 *>(tile + sl * RSTR + 2 * ((4 * r + 2 * h) ^ swz(sl))) = make_double2(x[0], x[1]);
+  *reinterpret_cast<double2 *>(tile + sl * RSTR + 2 * ((4 * r + 2 * h + 1) ^ swz(sl))) = make_double2(x[2], x[3]);
 }
 // tile -> memory: rows n0, n0 + 1 of every series (rows outside [0, N-1] skipped)
 template <bool FULL>
@@ -125,7 +133,8 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
   const int64_t r = n0 + (lane & 7) / 4;
   double2 v[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * (lane & 7));
+  for (int i = 0; i < 4; ++i)
+    v[i] = *reinterpret_cast<const double2 *>(tile + (8 * i + lane / 8) * RSTR + 2 * ((lane & 7) ^ swz(lane >> 3)));
   if (r >= 0 && r < N) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)

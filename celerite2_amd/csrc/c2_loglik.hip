@@ -156,10 +156,14 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          int32_t *__restrict__ flag, double *__restrict__ ckpt,
                                                          int64_t nseg, double *__restrict__ Wst,
                                                          double2 *__restrict__ DZst,
-                                                         const unsigned long long *__restrict__ gate) {
+                                                         const unsigned long long *__restrict__ gate,
+                                                         unsigned long long *__restrict__ segguard = nullptr) {
   // `gate` (nullable): this launch is the fallback of the one-lane-per-series path and runs only when the stability
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;   // (the series of a wavefront share a group of 64)
+  // MODE 1 with Wst and segguard (the reverse sweep by the BACKWARD recursion, k_loglik_rev<..., BACK>): W rows are
+  // recorded as well, one more checkpoint holds the state after the last row, and segguard[wavefront] receives the
+  // largest c_j x (time spanned by a checkpoint segment) of the wavefront -- what the backward recursion has to invert.
   // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
   // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
   // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   const double *tb = t + L.b0 * t_bs + ot, *ab = a + L.b0 * N + on, *yb = y + L.b0 * N + on;
   const double *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
-  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES : nullptr;
+  // (with W records -- the backward-recursion form -- a wavefront owns one more checkpoint: the state after its last row)
+  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * (nseg + (Wst != nullptr ? 1 : 0)) * CkptRec<G>::DOUBLES : nullptr;
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
   soff[0] = lane;
 #pragma unroll
@@ -190,7 +195,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   // per-step record for the reverse sweep (CKPT only): (d_n, z_n).  W_n is NOT recorded: the reverse sweep replays
   // W_n = (V_n - tau_n) / d_n bit for bit next to S_n, from the W of the checkpointed row (64 B per step less to
   // write and to read back; the forward pass is HBM-bound).  FACTOR: W is the caller's output.
-  double *wst = FACTOR ? Wst + L.b0 * N * J + oj : nullptr;
+  const bool wrec = CKPT && Wst != nullptr;   // (uniform)
+  double *wst = (FACTOR || wrec) ? Wst + L.b0 * N * J + oj : nullptr;
   double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
   double *dst = FACTOR ? reinterpret_cast<double *>(DZst) + L.b0 * N + on : nullptr;
   const bool stw = PAD ? (L.valid && act) : true;  // duplicate stores of identical values are harmless
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   double quad = z * z * rd;
   int32_t fl = 0;
   if (REC) {
-    if (FACTOR && stw) wst[0] = w;
+    if ((FACTOR || wrec) && stw) wst[0] = w;
     if (CKPT) dzst[0] = make_double2(d, z);
     else dst[0] = d;
   }
@@ -247,9 +253,11 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 #pragma unroll
   for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
 
+  double tseg = 0.0, gspan = 0.0;   // (wrec) start of the current checkpoint segment, the longest one so far
   // prepare step 1
   lds_order();
   double tcur = tb[0];
+  double trow = tcur;               // t of the row before the current one
   double tnext = sin_[0][0][grp][0];
   double pc = exp_decay(cj * (tcur - tnext)), uc = ru[0];
   double pXc[G], uXc[G];
@@ -265,8 +273,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
     for (int r = 0; r < R; ++r) {
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
-        if (CKPT && (r % C == 0))  // state after row n-1 = checkpoint (n-1)/C
+        if (CKPT && (r % C == 0)) {  // state after row n-1 = checkpoint (n-1)/C
           ckpt_store<G>(ckw + ((n - 1) / C) * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
+          tseg = trow;
+        }
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
@@ -282,6 +292,11 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (REC) {
           if (FACTOR && stw && ((fl == 0) & (d > 0.0))) wst[n * J] = w;
+          if (CKPT) {
+            if (wrec && stw) wst[n * J] = w;
+            gspan = fmax(gspan, tn - tseg);
+            trow = tn;
+          }
           sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
@@ -324,6 +339,14 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, std::false_type{}); advance(); }  // every row load in range
   for (; n0 < N; n0 += R) { block(n0, q, std::true_type{}); advance(); }
 
+  if (wrec) {   // the state after the last row, and the wavefront's stability measure
+    ckpt_store<G>(ckw + nseg * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
+    double g = cj * gspan;
+    g = (g == g) ? g : INFINITY;   // a NaN span must close the fast path
+#pragma unroll
+    for (int sft = 1; sft < kWave; sft <<= 1) g = fmax(g, __shfl_xor(g, sft, kWave));
+    if (lane == 0) segguard[blockIdx.x] = (unsigned long long)__double_as_longlong(g);
+  }
   if (L.valid && j == 0) {
     flag[L.b] = fl;
     if (!FACTOR) {
@@ -372,7 +395,14 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
 // then the caller's W, `ckpt` the caller's S workspace -- of which only every C-th row is read, as the checkpoint the
 // rows in between are replayed from (64 instead of 512 bytes of S per step at J = 8) --, fr_d / fr_bd / fr_bW the
 // pivots and the incoming cotangents of d and W; the solve_lower_rev half (F, z, bF, by) drops out.
-template <int G, int C, bool PAD, bool FR>
+// BACK = true: no replay.  The forward pass recorded the W rows and a checkpoint after the last row as well; the sweep
+// starts every segment from the checkpoint at its END and runs the recursion backward next to the reverse steps,
+//     S_{n-1} = P_n^-1 S_n P_n^-1 - d_{n-1} w_{n-1}^T w_{n-1},   F_{n-1} = P_n^-1 F_n - w_{n-1} z_{n-1}
+// (the inverse of forward.hpp:115-123 / internal.hpp:140-143) -- eight rows at most between two anchors, so the decays it
+// inverts are bounded by the wavefront's `segguard` word: beyond kBackwardGuard this kernel returns at once and the
+// replay form, launched behind it on the same word, takes the wavefront.  Phase B below (a third of the instructions)
+// drops out, and so do the 128 accumulation registers the replayed states waited in.
+template <int G, int C, bool PAD, bool FR, bool BACK = false>
 __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
@@ -385,8 +415,14 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          double *__restrict__ by, const double *__restrict__ fr_d,
                                                          const double *__restrict__ fr_bd,
                                                          const double *__restrict__ fr_bW,
-                                                         const unsigned long long *__restrict__ gate) {
+                                                         const unsigned long long *__restrict__ gate,
+                                                         const unsigned long long *__restrict__ segguard = nullptr) {
+  static_assert(!(BACK && FR), "factor_rev replays from the caller's workspace");
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;  // see k_loglik_fwd
+  if (segguard) {   // this wavefront by the backward recursion, or (the launch behind it) by the replay
+    const bool unstable = __longlong_as_double((long long)segguard[blockIdx.x]) > kBackwardGuard;
+    if (unstable == BACK) return;
+  }
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
@@ -415,7 +451,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + L.jj;
   const double *tb = t + L.b0 * t_bs + ot, *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double2 *dzb = FR ? nullptr : DZst + L.b0 * N + on;
-  const double *ckw = FR ? nullptr : ckpt + (size_t)blockIdx.x * nseg * CkptRec<G>::DOUBLES;
+  const double *ckw = FR ? nullptr : ckpt + (size_t)blockIdx.x * (nseg + (segguard != nullptr ? 1 : 0)) * CkptRec<G>::DOUBLES;
   const double *fdb = FR ? fr_d + L.b0 * N + on : nullptr, *fbdb = FR ? fr_bd + L.b0 * N + on : nullptr;
   const double *fbWb = FR ? fr_bW + L.b0 * N * J + oj : nullptr;
   const double *Scol = FR ? ckpt + (L.b0 + L.sl) * N * J * J + (int64_t)L.jj * J : nullptr;  // S[n, i + J j]: column j
@@ -472,7 +508,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
       iu[r] = act ? Ub[n * J] : 0.0;
-      iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1
+      iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1; BACK: the recorded W row n-1 (V = the record)
       if constexpr (FR) ibw[r] = act ? fbWb[(n - 1) * J] : 0.0;
     }
     if constexpr (FR) {
@@ -486,7 +522,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
       tck = tb[m >= 1 ? m - 1 : 0];
     } else {
-      ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
+      // replay: the state BEFORE the segment (after row n_lo - 1); backward recursion: the state at its END
+      ckpt_load<G>(ckw + (BACK ? k + 1 : k) * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
     }
   };
 
@@ -521,7 +558,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     lds_order();
     rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
     lds_order();
-    double dtv[C], pown[C];
+    double dtv[C], pown[C], ipown[BACK ? C : 1];
     {
       double tprev = rowT[0][grp];
 #pragma unroll
@@ -530,12 +567,15 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         dtv[r] = tprev - tn;
         tprev = tn;
         pown[r] = exp_decay(cj * dtv[r]);
+        if constexpr (BACK) ipown[r] = rcp_nr(pown[r]);
         if constexpr (APARK) {  // the prefetch registers are refilled half way through phase C
+          if constexpr (BACK) apark(iw[r], wAlo[r], wAhi[r]);   // the recorded W_{n-1}
           apark(iu[r], uAlo[r], uAhi[r]);
           if constexpr (FR) apark(ibw[r], xAlo[r], xAhi[r]);
         } else {
           vv[r][0][lane] = pown[r];
           vv[r][1][lane] = iu[r];
+          if constexpr (BACK) vv[r][2][lane] = iw[r];
           if constexpr (FR) vv[r][3][lane] = ibw[r];
         }
       }
@@ -549,11 +589,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     for (int i = 0; i < G; ++i) SX[i] = FR ? cS[i] * pck : cS[i];
     double F = cF;
     const double Wck = cW;  // W of the checkpointed row n_lo-1
-    double Fp[C], tauS[C];
+    double Fp[BACK ? 1 : C], tauS[BACK ? 1 : C];
     lds_order();
     C2_TCK(1);
 #pragma unroll
-    for (int r = 0; r < C; ++r) {
+    for (int r = 0; r < (BACK ? 0 : C); ++r) {
       if (r < cnt) {
         // W_{n-1} = (V_{n-1} - tau_{n-1}) / d_{n-1}, exactly as the forward pass formed it (forward.hpp:131)
         double wown = Wck;
@@ -628,7 +668,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       }
       if (r < cnt) {
         const int64_t n = n_lo + r;
-        const double Fpn = FR ? 0.0 : Fp[r];
+        const double Fpn = FR ? 0.0 : (BACK ? F : Fp[BACK ? 0 : r]);
         const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];  // FR: zm = bd_{n-1}
         double bWm = 0.0;  // FR: the lane's own bW_{n-1}
         if constexpr (FR) {
@@ -652,10 +692,23 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           xgather_lds<G>(vv[r][2], lane, wX);
         }
         const double p = pX[0], u = uX[0], wm = wX[0];  // slot 0 of an XOR gather is the lane's own element
-        if constexpr (APARK) {
+        double ipX[BACK ? G : 1], tau_n = 0.0;
+        if constexpr (BACK) {   // S_n is the carried state; tau_n = U_n S_n as the forward pass formed it
+          xgather_dpp<G>(ipown[r], xB, lane, ipX);
+          double ta0 = 0.0, ta1 = 0.0;
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            Sf[i] = SX[i];
+            if (i & 1) ta1 = fma(uX[i], Sf[i], ta1);
+            else ta0 = fma(uX[i], Sf[i], ta0);
+          }
+          tau_n = ta0 + ta1;
+        } else if constexpr (APARK) {
+          tau_n = tauS[BACK ? 0 : r];
 #pragma unroll
           for (int i = 0; i < G; ++i) Sf[i] = afetch(sAlo[r][i], sAhi[r][i]);
         } else {
+          tau_n = tauS[BACK ? 0 : r];
           const double *sfr = sfL[r];
 #pragma unroll
           for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];
@@ -684,7 +737,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           if (i & 1) { xs1 = fma(bVX[i], Sf[i], xs1); bp1 = fma(Sf[i], m, bp1); }
           else { xs0 = fma(bVX[i], Sf[i], xs0); bp0 = fma(Sf[i], m, bp0); }
         }
-        xs0 = fma(2.0 * ban, tauS[r], xs0);
+        xs0 = fma(2.0 * ban, tau_n, xs0);
         if (st) bUb[n * J] = bU1 - (xs0 + xs1);
         const double bp = bp_s + (bp0 + bp1);
         bcj = fma(dt, bp, bcj);
@@ -711,6 +764,12 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           oBY[grp][r] = bzn;
           bVn = fma(zr, bF, q);
           ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+        }
+        if constexpr (BACK) {   // the state of row n-1 (rowD[r] = d_{n-1}, zm = z_{n-1}, wX = W_{n-1})
+          const double ip = ipX[0], dwm = rowD[r][grp] * wm;
+#pragma unroll
+          for (int i = 0; i < G; ++i) SX[i] = fma(-dwm, wX[i], (ipX[i] * ip) * Sf[i]);
+          F = fma(-wm, zm, F * ip);
         }
       }
     }
@@ -769,17 +828,17 @@ template <int MODE>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s,
-               const unsigned long long *gate = nullptr) {
+               const unsigned long long *gate = nullptr, unsigned long long *segguard = nullptr) {
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
     if (J == G)                                                                                                  \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
-                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate);                           \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);                 \
     else                                                                                                         \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,    \
-                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate);                           \
+                         c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);                 \
   } while (0)
   switch (G_) {
     case 1: C2_FWD(1, C2_FWD_R, C2_CKPT_C); break;
@@ -1113,20 +1172,29 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
 static inline int ckpt_interval(int G_) { return G_ <= 8 ? C2_CKPT_C : (G_ == 16 ? 4 : 2); }
 
 // Workspace layout: [checkpoints: waves*nseg*CkptRec<G>::DOUBLES] [(d,z) pairs B*N*2]  (doubles)
+// `back`: the form whose reverse sweep runs the recursion backward (k_loglik_rev<..., BACK>): one more checkpoint (the
+// state after the last row), the W rows, one stability word per wavefront
 struct GradWs {
-  size_t ck, w, dz, total;
+  size_t ck, w, dz, guard, total;
 };
-static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J) {
+static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J, bool back = false) {
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
   GradWs g;
   const size_t waves = ((size_t)B * G_ + kWave - 1) / kWave;       // checkpoints are wave-blocked
-  g.ck = waves * (size_t)nseg * ((size_t)kWave + (size_t)(G_ - 1) * (kWave / 2) + 2 * kWave);  // CkptRec<G>::DOUBLES
+  g.ck = waves * (size_t)(nseg + (back ? 1 : 0)) * ((size_t)kWave + (size_t)(G_ - 1) * (kWave / 2) + 2 * kWave);  // CkptRec<G>::DOUBLES
   g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
-  g.w = 0;  // W rows are replayed, not recorded
+  g.w = back ? (((size_t)B * N * J + 1) & ~(size_t)1) : 0;  // W rows: recorded, or replayed
   g.dz = (size_t)B * N * 2;
-  g.total = g.ck + g.w + g.dz;
+  g.guard = back ? ((waves + 1) & ~(size_t)1) : 0;
+  g.total = g.ck + g.w + g.dz + g.guard;
   return g;
+}
+// The backward-recursion form serves the group mappings up to eight lanes (the replayed states of wider groups wait in
+// LDS, not in registers: nothing to gain there).  C2_LOGLIK_BACK=0 keeps the replay (A/B runs).
+static bool use_back(int64_t N, int64_t J) {
+  if (opt::has(opt::k_loglik_back) && opt::ival(opt::k_loglik_back) == 0) return false;
+  return group_size(J) <= 8 && N >= 2;
 }
 
 // core::factor without the S workspace (interface.hpp:37-48) on the fused forward kernel: d and W straight
@@ -1283,11 +1351,11 @@ size_t c2_internal_loglik_grad_replay_doubles(int64_t B, int64_t N, int64_t J) {
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
   if (J > C2_FAST_WIDTH) return c2_loglik_grad_composite_workspace_bytes(B, N, J);   // (d, W, S, z, F, seeds: the op chain)
-  size_t n = grad_ws(B, N, J).total;
+  size_t n = grad_ws(B, N, J, use_back(N, J)).total;
   if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
   if (use_lanes1(B, J, true)) {  // [guard words: head + one per wavefront] [records of the one-lane path | workspace of the replay fallback]
-    const size_t r = lanes1_record_doubles(B, N, J);
-    n = lanes1_gate_words(B) + (r > n ? r : n);
+    const size_t r = lanes1_record_doubles(B, N, J), f = grad_ws(B, N, J).total;
+    n = lanes1_gate_words(B) + (r > f ? r : f);
   }
   if (use_lanes2(B, N, J, true)) {  // the same layout with the records of the two-lane path
     const size_t f = grad_ws(B, N, J).total, r = c2_internal_loglik_k2_record_doubles(B, N);
@@ -1304,6 +1372,10 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
                             const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
                             double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
                             size_t work_bytes, bool allow_timepar, c2_stream_t stream);
+static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                             int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                             double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                             int32_t *flag, void *work, const unsigned long long *gate, bool back, c2_stream_t stream);
 int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                    const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
                    double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
@@ -1378,6 +1450,9 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
       return e;
     gate = gate_per_wave(guard + kGateHeadWords);   // per group of 64 series: only the wavefronts that fell back are replayed
   }
+  if (gate == nullptr && use_back(N, J))   // the primary path of this batch: reverse sweep by the backward recursion
+    return loglik_grad_group(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, nullptr, true,
+                             stream);
   return c2_internal_loglik_grad_replay(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, gate,
                                         stream);
 }
@@ -1388,24 +1463,56 @@ int c2_internal_loglik_grad_replay(int64_t B, int64_t N, int64_t J, const double
                                    int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                    double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
                                    int32_t *flag, void *work, const unsigned long long *gate, c2_stream_t stream) {
+  return loglik_grad_group(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, gate, false, stream);
+}
+// `back`: forward pass with W records, reverse sweep by the backward recursion, the replay sweep behind it for the
+// wavefronts whose segments it cannot invert (`work`: grad_ws(B, N, J, true).total doubles).
+static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
+                             int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
+                             double *ll, double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                             int32_t *flag, void *work, const unsigned long long *gate, bool back, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int G_ = group_size(J), C_ = ckpt_interval(G_);
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
-  const GradWs ws = grad_ws(B, N, J);
+  const GradWs ws = grad_ws(B, N, J, back);
   double *ckpt = (double *)work;
-  double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck);
-  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, nullptr, DZst, s, gate)) return e;
+  double *Wrec = back ? ckpt + ws.ck : nullptr;
+  double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck + ws.w);
+  unsigned long long *segg = back ? reinterpret_cast<unsigned long long *>(ckpt + ws.ck + ws.w + ws.dz) : nullptr;
+  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wrec, DZst, s, gate, segg)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+  if (back) {
+#define C2_REVB(G)                                                                                                        \
+  do {                                                                                                                    \
+    if (J == G)                                                                                                           \
+      hipLaunchKernelGGL((k_loglik_rev<G, C2_CKPT_C, false, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
+                         (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, \
+                         bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);                      \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_loglik_rev<G, C2_CKPT_C, true, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
+                         (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, \
+                         bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);                      \
+  } while (0)
+    switch (G_) {
+      case 1: C2_REVB(1); break;
+      case 2: C2_REVB(2); break;
+      case 4: C2_REVB(4); break;
+      default: C2_REVB(8); break;
+    }
+#undef C2_REVB
+    if (int e = launch_ok()) return e;
+  }
+  const unsigned long long *segc = segg;   // (the replay sweep: every wavefront, or those the sweep above left)
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \
     if (J == G)                                                                                                   \
       hipLaunchKernelGGL((k_loglik_rev<G, C, false, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
                          V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
-                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate);         \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate, segc);   \
     else                                                                                                          \
       hipLaunchKernelGGL((k_loglik_rev<G, C, true, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,   \
                          V, (const double2 *)DZst, (const double *)ckpt, nseg,                  \
-                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate);         \
+                         (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate, segc);   \
   } while (0)
   switch (G_) {
     case 1: C2_REV(1, C2_CKPT_C); break;

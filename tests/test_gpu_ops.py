@@ -508,6 +508,38 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, lanes, J):
     assert run(tg, floor=4e-12) <= 2.0 and run.nfall == 0
 
 
+@pytest.mark.parametrize("J", [8, 7, 4, 3, 2, 1])
+@pytest.mark.parametrize("N", [2, 9, 10, 41, 130])
+def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypatch, J, N):
+    """The group mappings (up to eight lanes per series, c2_loglik.hip) run their reverse sweep by the BACKWARD recursion
+    from recorded W rows, re-anchored at the checkpoint of every segment of eight rows; a wavefront with a segment it cannot
+    invert (c * span beyond the guard: gaps in time) is taken by the replay sweep launched behind it.  Same results as
+    the oracle for a batch in which some wavefronts have gaps and others do not, for gaps in every series, and with the
+    backward form switched off (C2_LOGLIK_BACK=0: the replay alone)."""
+    B = 40   # five wavefronts at J = 8, fewer for narrower groups
+    Je = J if J % 2 == 0 else J + 1
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, Je)
+    U = np.ascontiguousarray(U[:, :, :J]); V = np.ascontiguousarray(V[:, :, :J]); c = np.ascontiguousarray(c[:, :J])
+    a = a + 1.0
+    rng = np.random.default_rng(4100 + 10 * J + N)
+    for gaps in ("none", "some", "all"):
+        tg = t.copy()
+        if gaps != "none" and N > 2:
+            for b in (range(B) if gaps == "all" else rng.choice(B, size=7, replace=False)):
+                tg[b, int(rng.integers(1, N)):] += 40.0 / c.max()
+        llo, go, flo = oracle.loglik_grad_batched(tg, c, a, U, V, y, nthreads=2)
+        assert int(np.abs(flo).sum()) == 0
+        args = dev(tg, c, a, U, V, y)
+        for back in ("1", "0"):
+            monkeypatch.setenv("C2_LOGLIK_BACK", back)
+            ll, grads, flag = ops.loglik_grad(*args)
+            assert int(flag.abs().sum()) == 0
+            close(ll, llo)
+            for g, e in zip(grads, go):
+                close(g, e, floor=4e-12)
+        monkeypatch.delenv("C2_LOGLIK_BACK")
+
+
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])
 @pytest.mark.parametrize("N", [1, 2, 8, 9, 10, 17, 100])
 def test_loglik_grad_widths_and_segment_edges(ops, oracle, J, N):

@@ -146,6 +146,9 @@ __device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int
   w = rec[SymPack<G>::PER_STEP + kWave + lane];
 }
 
+// the backward-recursion reverse sweep re-anchors at every kAnchor-th checkpoint (every 32 rows at C = 8)
+constexpr int kAnchor = 4;
+
 template <int G, int R, int C, int MODE, bool PAD>
 __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -162,8 +165,14 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;   // (the series of a wavefront share a group of 64)
   // MODE 1 with Wst and segguard (the reverse sweep by the BACKWARD recursion, k_loglik_rev<..., BACK>): W rows are
-  // recorded as well, one more checkpoint holds the state after the last row, and segguard[wavefront] receives the
-  // largest c_j x (time spanned by a checkpoint segment) of the wavefront -- what the backward recursion has to invert.
+  // recorded as well, only every kAnchor-th checkpoint is written -- the backward recursion re-anchors there -- plus one
+  // for the state after the last row, and segguard[wavefront] receives the largest c_j x (time between two anchors) of the
+  // wavefront: what the backward recursion has to invert.
+  // MODE 1 with segguard and WITHOUT Wst: the second forward pass of the wavefronts that word sends to the replay sweep
+  // (every checkpoint, which the replay needs; same slots) -- every other wavefront returns at once.
+  if (MODE == 1 && segguard != nullptr && Wst == nullptr &&
+      !(__longlong_as_double((long long)segguard[blockIdx.x]) > kBackwardGuard))
+    return;
   // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
   // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
   // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   const double *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
   // (with W records -- the backward-recursion form -- a wavefront owns one more checkpoint: the state after its last row)
-  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * (nseg + (Wst != nullptr ? 1 : 0)) * CkptRec<G>::DOUBLES : nullptr;
+  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * (nseg + (segguard != nullptr ? 1 : 0)) * CkptRec<G>::DOUBLES : nullptr;
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
   soff[0] = lane;
 #pragma unroll
@@ -274,8 +283,12 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
         if (CKPT && (r % C == 0)) {  // state after row n-1 = checkpoint (n-1)/C
-          ckpt_store<G>(ckw + ((n - 1) / C) * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
-          tseg = trow;
+          const int64_t m = (n - 1) / C;
+          if (!wrec) ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
+          else if (m % kAnchor == 0) {   // (uniform) an anchor of the backward recursion; the state after row 0 is never read
+            if (m > 0) ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
+            tseg = trow;
+          }
         }
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
@@ -347,6 +360,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
     for (int sft = 1; sft < kWave; sft <<= 1) g = fmax(g, __shfl_xor(g, sft, kWave));
     if (lane == 0) segguard[blockIdx.x] = (unsigned long long)__double_as_longlong(g);
   }
+  if (MODE == 1 && segguard != nullptr && Wst == nullptr) return;   // (second pass: ll and flag stand)
   if (L.valid && j == 0) {
     flag[L.b] = fl;
     if (!FACTOR) {
@@ -521,9 +535,13 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         cS[kk] = (m >= 1 && act && i < J) ? Scol[m * J * J + i] : 0.0;
       }
       tck = tb[m >= 1 ? m - 1 : 0];
+    } else if constexpr (BACK) {
+      // the state at the END of the segment, where that is an anchor (every kAnchor-th checkpoint, the last row);
+      // elsewhere the recursion carries on from the segment above
+      if ((k + 1) % kAnchor == 0 || k == nseg - 1)
+        ckpt_load<G>(ckw + (k + 1) * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
     } else {
-      // replay: the state BEFORE the segment (after row n_lo - 1); backward recursion: the state at its END
-      ckpt_load<G>(ckw + (BACK ? k + 1 : k) * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
+      ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);   // the state BEFORE the segment (after row n_lo - 1)
     }
   };
 
@@ -542,6 +560,9 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
 #define C2_TCK(i)
 #endif
 
+  double carS[BACK ? G : 1], carF = 0.0;   // (BACK) the recursed state handed from a segment to the one below
+#pragma unroll
+  for (int i = 0; i < (BACK ? G : 1); ++i) carS[i] = 0.0;
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
@@ -585,9 +606,10 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     // the lane's own W_{n-1} are parked (AGPRs; LDS for G > 8), F_n and tau_n stay in registers.
     double SX[G];
     const double pck = FR ? exp_decay(cj * (tck - rowT[0][grp])) : 1.0;  // FR: right scaling of the workspace row
+    const bool anchor = !BACK || (k + 1) % kAnchor == 0 || k == nseg - 1;   // (BACK, uniform) re-anchor, or carry on
 #pragma unroll
-    for (int i = 0; i < G; ++i) SX[i] = FR ? cS[i] * pck : cS[i];
-    double F = cF;
+    for (int i = 0; i < G; ++i) SX[i] = FR ? cS[i] * pck : (anchor ? cS[i] : carS[BACK ? i : 0]);
+    double F = anchor ? cF : carF;
     const double Wck = cW;  // W of the checkpointed row n_lo-1
     double Fp[BACK ? 1 : C], tauS[BACK ? 1 : C];
     lds_order();
@@ -772,6 +794,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
           F = fma(-wm, zm, F * ip);
         }
       }
+    }
+    if constexpr (BACK) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) carS[i] = SX[i];
+      carF = F;
     }
     lds_order();
     C2_TCK(3);
@@ -1501,6 +1528,8 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
     }
 #undef C2_REVB
     if (int e = launch_ok()) return e;
+    // the wavefronts that sweep left: forward pass again, this time with every checkpoint (returns at once for the others)
+    if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, nullptr, DZst, s, gate, segg)) return e;
   }
   const unsigned long long *segc = segg;   // (the replay sweep: every wavefront, or those the sweep above left)
 #define C2_REV(G, C)                                                                                              \

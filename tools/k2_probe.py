@@ -10,7 +10,7 @@ out = []
 for B in [int(x) for x in os.environ.get("K2_B", "16384,24576,32768,49152,65536").split(",")]:
     args = synth.device_batch_fast(0, B, N, J, torch.device("cuda:0"))
     res = {}
-    for lanes in ["", "1", "2"]:
+    for lanes in ["", "1", "2", "8"]:
         if lanes: os.environ["C2_LANES"] = lanes
         else: os.environ.pop("C2_LANES", None)
         work = ops.loglik_grad_workspace(B, N, J, args[2].device)

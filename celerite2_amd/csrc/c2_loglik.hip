@@ -146,8 +146,62 @@ __device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int
   w = rec[SymPack<G>::PER_STEP + kWave + lane];
 }
 
-// the backward-recursion reverse sweep re-anchors at every kAnchor-th checkpoint (every 32 rows at C = 8)
+// the backward-recursion reverse sweep re-anchors at every kAnchor-th checkpoint (every 32 rows at C = 8) ...
 constexpr int kAnchor = 4;
+// ... where the decays it has to invert in between allow.  One workgroup per wavefront w of the sweep (spw series):
+// words[2 w] = max over its series of c_max x (longest time between two anchors kAnchor segments apart), words[2 w + 1] the
+// same for single segments.  NaN and negative spans -- unsorted times -- are stored as NaN, which no guard accepts.
+__global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int J, int C, int spw,
+                                                      const double *__restrict__ t, int64_t t_bs,
+                                                      const double *__restrict__ c, int64_t c_bs,
+                                                      unsigned long long *__restrict__ words) {
+  __shared__ double cm[kWave], red[2][256 / kWave];
+  __shared__ int anybad;
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * spw;
+  if (tid == 0) anybad = 0;
+  if (tid < spw) {
+    const int64_t b = b0 + tid < B ? b0 + tid : B - 1;
+    double m = 0.0;
+    for (int j = 0; j < J; ++j) m = fmax(m, c[b * c_bs + j]);
+    cm[tid] = m;
+  }
+  __syncthreads();
+  const int64_t nseg = (N - 1 + C - 1) / C, ng = (nseg + kAnchor - 1) / kAnchor;
+  double g1 = 0.0, ga = 0.0;
+  bool bad = false;
+  for (int64_t i = tid; i < (int64_t)spw * ng; i += blockDim.x) {
+    const int sl = (int)(i / ng);
+    const int64_t grp = i % ng, b = b0 + sl < B ? b0 + sl : B - 1;
+    const double *tb = t + b * t_bs;
+    const int64_t r0 = grp * kAnchor * C;
+    double tp = tb[r0 < N - 1 ? r0 : N - 1];
+    const double tfirst = tp;
+    double s1 = 0.0;
+#pragma unroll
+    for (int q = 1; q <= kAnchor; ++q) {
+      const int64_t r = r0 + (int64_t)q * C;
+      const double tq = tb[r < N - 1 ? r : N - 1];
+      bad = bad || !(tq - tp >= 0.0);
+      s1 = fmax(s1, tq - tp);
+      tp = tq;
+    }
+    g1 = fmax(g1, cm[sl] * s1);
+    ga = fmax(ga, cm[sl] * (tp - tfirst));
+  }
+  bad = bad || !(g1 >= 0.0) || !(ga >= 0.0);
+#pragma unroll
+  for (int sft = 1; sft < kWave; sft <<= 1) { g1 = fmax(g1, __shfl_xor(g1, sft, kWave)); ga = fmax(ga, __shfl_xor(ga, sft, kWave)); }
+  if (bad) atomicOr(&anybad, 1);
+  if ((tid & (kWave - 1)) == 0) { red[0][tid / kWave] = ga; red[1][tid / kWave] = g1; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 1; k < (int)(blockDim.x / kWave); ++k) { red[0][0] = fmax(red[0][0], red[0][k]); red[1][0] = fmax(red[1][0], red[1][k]); }
+    const double nan = __builtin_nan("");
+    words[2 * blockIdx.x] = (unsigned long long)__double_as_longlong(anybad ? nan : red[0][0]);
+    words[2 * blockIdx.x + 1] = (unsigned long long)__double_as_longlong(anybad ? nan : red[1][0]);
+  }
+}
 
 template <int G, int R, int C, int MODE, bool PAD>
 __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
@@ -160,19 +214,15 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
                                                          int64_t nseg, double *__restrict__ Wst,
                                                          double2 *__restrict__ DZst,
                                                          const unsigned long long *__restrict__ gate,
-                                                         unsigned long long *__restrict__ segguard = nullptr) {
+                                                         const unsigned long long *__restrict__ segguard = nullptr) {
   // `gate` (nullable): this launch is the fallback of the one-lane-per-series path and runs only when the stability
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;   // (the series of a wavefront share a group of 64)
   // MODE 1 with Wst and segguard (the reverse sweep by the BACKWARD recursion, k_loglik_rev<..., BACK>): W rows are
-  // recorded as well, only every kAnchor-th checkpoint is written -- the backward recursion re-anchors there -- plus one
-  // for the state after the last row, and segguard[wavefront] receives the largest c_j x (time between two anchors) of the
-  // wavefront: what the backward recursion has to invert.
-  // MODE 1 with segguard and WITHOUT Wst: the second forward pass of the wavefronts that word sends to the replay sweep
-  // (every checkpoint, which the replay needs; same slots) -- every other wavefront returns at once.
-  if (MODE == 1 && segguard != nullptr && Wst == nullptr &&
-      !(__longlong_as_double((long long)segguard[blockIdx.x]) > kBackwardGuard))
-    return;
+  // recorded as well, and one more checkpoint holds the state after the last row.  segguard[2 w], [2 w + 1] (k_anchor_spans)
+  // say what the backward recursion of wavefront w would have to invert: largest c_j x (time spanned by kAnchor segments /
+  // by one segment).  Within the guard over the long spans only every kAnchor-th checkpoint is written -- the sweep
+  // re-anchors there; otherwise all of them (re-anchoring at every segment, or the replay sweep).
   // MODE 0: log-likelihood only.  MODE 1 (CKPT): also the records of the reverse sweep.  MODE 2 (FACTOR): the
   // same pass used as core::factor -- Wst/DZst are the caller's W (B,N,J) and d (B,N); nothing is stored after
   // the first non-positive pivot, exactly like the reference's early return (forward.hpp:128).
@@ -262,11 +312,10 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
 #pragma unroll
   for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
 
-  double tseg = 0.0, gspan = 0.0;   // (wrec) start of the current checkpoint segment, the longest one so far
+  const bool sparse = wrec && !(__longlong_as_double((long long)segguard[2 * blockIdx.x]) > kBackwardGuard);   // (uniform)
   // prepare step 1
   lds_order();
   double tcur = tb[0];
-  double trow = tcur;               // t of the row before the current one
   double tnext = sin_[0][0][grp][0];
   double pc = exp_decay(cj * (tcur - tnext)), uc = ru[0];
   double pXc[G], uXc[G];
@@ -284,11 +333,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
       if (!CHECKED || n < N) {
         if (CKPT && (r % C == 0)) {  // state after row n-1 = checkpoint (n-1)/C
           const int64_t m = (n - 1) / C;
-          if (!wrec) ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
-          else if (m % kAnchor == 0) {   // (uniform) an anchor of the backward recursion; the state after row 0 is never read
-            if (m > 0) ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
-            tseg = trow;
-          }
+          if (!sparse || (m % kAnchor == 0 && m > 0))   // (uniform; the backward recursion never reads the state after row 0)
+            ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
         }
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
@@ -305,11 +351,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (REC) {
           if (FACTOR && stw && ((fl == 0) & (d > 0.0))) wst[n * J] = w;
-          if (CKPT) {
-            if (wrec && stw) wst[n * J] = w;
-            gspan = fmax(gspan, tn - tseg);
-            trow = tn;
-          }
+          if (CKPT && wrec && stw) wst[n * J] = w;
           sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
@@ -352,15 +394,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, std::false_type{}); advance(); }  // every row load in range
   for (; n0 < N; n0 += R) { block(n0, q, std::true_type{}); advance(); }
 
-  if (wrec) {   // the state after the last row, and the wavefront's stability measure
-    ckpt_store<G>(ckw + nseg * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
-    double g = cj * gspan;
-    g = (g == g) ? g : INFINITY;   // a NaN span must close the fast path
-#pragma unroll
-    for (int sft = 1; sft < kWave; sft <<= 1) g = fmax(g, __shfl_xor(g, sft, kWave));
-    if (lane == 0) segguard[blockIdx.x] = (unsigned long long)__double_as_longlong(g);
-  }
-  if (MODE == 1 && segguard != nullptr && Wst == nullptr) return;   // (second pass: ll and flag stand)
+  if (wrec) ckpt_store<G>(ckw + nseg * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);   // the state after the last row
   if (L.valid && j == 0) {
     flag[L.b] = fl;
     if (!FACTOR) {
@@ -433,9 +467,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
                                                          const unsigned long long *__restrict__ segguard = nullptr) {
   static_assert(!(BACK && FR), "factor_rev replays from the caller's workspace");
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;  // see k_loglik_fwd
+  int astep = kAnchor;   // (BACK, uniform) segments between two anchors of the backward recursion
   if (segguard) {   // this wavefront by the backward recursion, or (the launch behind it) by the replay
-    const bool unstable = __longlong_as_double((long long)segguard[blockIdx.x]) > kBackwardGuard;
+    const bool unstable = __longlong_as_double((long long)segguard[2 * blockIdx.x + 1]) > kBackwardGuard;
     if (unstable == BACK) return;
+    if (__longlong_as_double((long long)segguard[2 * blockIdx.x]) > kBackwardGuard) astep = 1;
   }
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
@@ -538,7 +574,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     } else if constexpr (BACK) {
       // the state at the END of the segment, where that is an anchor (every kAnchor-th checkpoint, the last row);
       // elsewhere the recursion carries on from the segment above
-      if ((k + 1) % kAnchor == 0 || k == nseg - 1)
+      if ((k + 1) % astep == 0 || k == nseg - 1)
         ckpt_load<G>(ckw + (k + 1) * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);
     } else {
       ckpt_load<G>(ckw + k * CkptRec<G>::DOUBLES, lane, soff, cS, cF, cW);   // the state BEFORE the segment (after row n_lo - 1)
@@ -606,7 +642,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     // the lane's own W_{n-1} are parked (AGPRs; LDS for G > 8), F_n and tau_n stay in registers.
     double SX[G];
     const double pck = FR ? exp_decay(cj * (tck - rowT[0][grp])) : 1.0;  // FR: right scaling of the workspace row
-    const bool anchor = !BACK || (k + 1) % kAnchor == 0 || k == nseg - 1;   // (BACK, uniform) re-anchor, or carry on
+    const bool anchor = !BACK || (k + 1) % astep == 0 || k == nseg - 1;   // (BACK, uniform) re-anchor, or carry on
 #pragma unroll
     for (int i = 0; i < G; ++i) SX[i] = FR ? cS[i] * pck : (anchor ? cS[i] : carS[BACK ? i : 0]);
     double F = anchor ? cF : carF;
@@ -855,7 +891,7 @@ template <int MODE>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s,
-               const unsigned long long *gate = nullptr, unsigned long long *segguard = nullptr) {
+               const unsigned long long *gate = nullptr, const unsigned long long *segguard = nullptr) {
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
 #define C2_FWD(G, R, C)                                                                                          \
@@ -1213,12 +1249,12 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J, bool back = false)
   g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
   g.w = back ? (((size_t)B * N * J + 1) & ~(size_t)1) : 0;  // W rows: recorded, or replayed
   g.dz = (size_t)B * N * 2;
-  g.guard = back ? ((waves + 1) & ~(size_t)1) : 0;
+  g.guard = back ? 2 * waves : 0;   // k_anchor_spans
   g.total = g.ck + g.w + g.dz + g.guard;
   return g;
 }
-// The backward-recursion form serves the group mappings up to eight lanes (the replayed states of wider groups wait in
-// LDS, not in registers: nothing to gain there).  C2_LOGLIK_BACK=0 keeps the replay (A/B runs).
+// The backward-recursion form serves the group mappings up to eight lanes (wider models' rates span more than the guard
+// allows between anchors on the bench's own recipe: J = 16, 12 measured -- every wavefront on the replay sweep).  C2_LOGLIK_BACK=0 keeps the replay (A/B runs).
 static bool use_back(int64_t N, int64_t J) {
   if (opt::has(opt::k_loglik_back) && opt::ival(opt::k_loglik_back) == 0) return false;
   return group_size(J) <= 8 && N >= 2;
@@ -1506,30 +1542,32 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
   double *Wrec = back ? ckpt + ws.ck : nullptr;
   double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck + ws.w);
   unsigned long long *segg = back ? reinterpret_cast<unsigned long long *>(ckpt + ws.ck + ws.w + ws.dz) : nullptr;
-  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wrec, DZst, s, gate, segg)) return e;
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+  if (back) {   // what the backward recursion of every wavefront would have to invert
+    hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, s, B, N, (int)J, C_, kWave / G_, t, t_bs, c, c_bs, segg);
+    if (int e = launch_ok()) return e;
+  }
+  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wrec, DZst, s, gate, segg)) return e;
   if (back) {
-#define C2_REVB(G)                                                                                                        \
+#define C2_REVB(G, C)                                                                                                     \
   do {                                                                                                                    \
     if (J == G)                                                                                                           \
-      hipLaunchKernelGGL((k_loglik_rev<G, C2_CKPT_C, false, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, false, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
                          (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, \
                          bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);                      \
     else                                                                                                                  \
-      hipLaunchKernelGGL((k_loglik_rev<G, C2_CKPT_C, true, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
+      hipLaunchKernelGGL((k_loglik_rev<G, C, true, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
                          (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, \
                          bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);                      \
   } while (0)
     switch (G_) {
-      case 1: C2_REVB(1); break;
-      case 2: C2_REVB(2); break;
-      case 4: C2_REVB(4); break;
-      default: C2_REVB(8); break;
+      case 1: C2_REVB(1, C2_CKPT_C); break;
+      case 2: C2_REVB(2, C2_CKPT_C); break;
+      case 4: C2_REVB(4, C2_CKPT_C); break;
+      default: C2_REVB(8, C2_CKPT_C); break;
     }
 #undef C2_REVB
     if (int e = launch_ok()) return e;
-    // the wavefronts that sweep left: forward pass again, this time with every checkpoint (returns at once for the others)
-    if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, nullptr, DZst, s, gate, segg)) return e;
   }
   const unsigned long long *segc = segg;   // (the replay sweep: every wavefront, or those the sweep above left)
 #define C2_REV(G, C)                                                                                              \

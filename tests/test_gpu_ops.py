@@ -512,8 +512,9 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, lanes, J):
 @pytest.mark.parametrize("N", [2, 9, 10, 41, 130])
 def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypatch, J, N):
     """The group mappings (up to eight lanes per series, c2_loglik.hip) run their reverse sweep by the BACKWARD recursion
-    from recorded W rows, re-anchored at the checkpoint of every segment of eight rows; a wavefront with a segment it cannot
-    invert (c * span beyond the guard: gaps in time) is taken by the replay sweep launched behind it.  Same results as
+    from recorded W rows, re-anchored at every fourth checkpoint (32 rows) or -- where c * span over 32 rows is beyond the
+    guard -- at every one (8 rows); a wavefront with a segment it cannot invert (gaps in time) is taken by the replay sweep
+    launched behind it.  Same results as
     the oracle for a batch in which some wavefronts have gaps and others do not, for gaps in every series, and with the
     backward form switched off (C2_LOGLIK_BACK=0: the replay alone)."""
     B = 40   # five wavefronts at J = 8, fewer for narrower groups
@@ -522,9 +523,11 @@ def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypa
     U = np.ascontiguousarray(U[:, :, :J]); V = np.ascontiguousarray(V[:, :, :J]); c = np.ascontiguousarray(c[:, :J])
     a = a + 1.0
     rng = np.random.default_rng(4100 + 10 * J + N)
-    for gaps in ("none", "some", "all"):
+    for gaps in ("none", "some", "all", "sparser grid"):
         tg = t.copy()
-        if gaps != "none" and N > 2:
+        if gaps == "sparser grid":   # c * span beyond the guard over 32 rows, within it over 8: an anchor at every segment
+            tg = t[:, :1] + 6.0 * (t - t[:, :1])
+        elif gaps != "none" and N > 2:
             for b in (range(B) if gaps == "all" else rng.choice(B, size=7, replace=False)):
                 tg[b, int(rng.integers(1, N)):] += 40.0 / c.max()
         llo, go, flo = oracle.loglik_grad_batched(tg, c, a, U, V, y, nthreads=2)

@@ -258,7 +258,9 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   // W_n = (V_n - tau_n) / d_n bit for bit next to S_n, from the W of the checkpointed row (64 B per step less to
   // write and to read back; the forward pass is HBM-bound).  FACTOR: W is the caller's output.
   const bool wrec = CKPT && Wst != nullptr;   // (uniform)
-  double *wst = (FACTOR || wrec) ? Wst + L.b0 * N * J + oj : nullptr;
+  double *wst = FACTOR ? Wst + L.b0 * N * J + oj : nullptr;
+  // the W record of the backward-recursion sweep is private to the wavefront: lane-major, one dense 512-byte run per row
+  double *wrp = wrec ? Wst + (size_t)blockIdx.x * N * kWave + lane : nullptr;
   double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
   double *dst = FACTOR ? reinterpret_cast<double *>(DZst) + L.b0 * N + on : nullptr;
   const bool stw = PAD ? (L.valid && act) : true;  // duplicate stores of identical values are harmless
@@ -276,7 +278,8 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
   double quad = z * z * rd;
   int32_t fl = 0;
   if (REC) {
-    if ((FACTOR || wrec) && stw) wst[0] = w;
+    if (FACTOR && stw) wst[0] = w;
+    if (wrec) wrp[0] = w;
     if (CKPT) dzst[0] = make_double2(d, z);
     else dst[0] = d;
   }
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (REC) {
           if (FACTOR && stw && ((fl == 0) & (d > 0.0))) wst[n * J] = w;
-          if (CKPT && wrec && stw) wst[n * J] = w;
+          if (CKPT && wrec) wrp[(size_t)n * kWave] = w;
           sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
@@ -561,7 +564,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
       iu[r] = act ? Ub[n * J] : 0.0;
-      iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1; BACK: the recorded W row n-1 (V = the record)
+      if constexpr (BACK) iw[r] = V[((size_t)blockIdx.x * N + (n - 1)) * kWave + lane];   // the recorded W row n-1 (lane-major)
+      else iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1
       if constexpr (FR) ibw[r] = act ? fbWb[(n - 1) * J] : 0.0;
     }
     if constexpr (FR) {
@@ -1250,7 +1254,7 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J, bool back = false)
   const size_t waves = ((size_t)B * G_ + kWave - 1) / kWave;       // checkpoints are wave-blocked
   g.ck = waves * (size_t)(nseg + (back ? 1 : 0)) * ((size_t)kWave + (size_t)(G_ - 1) * (kWave / 2) + 2 * kWave);  // CkptRec<G>::DOUBLES
   g.ck = (g.ck + 1) & ~(size_t)1;  // keep the following arrays 16-byte aligned
-  g.w = back ? (((size_t)B * N * J + 1) & ~(size_t)1) : 0;  // W rows: recorded, or replayed
+  g.w = back ? waves * (size_t)N * kWave : 0;  // W rows: recorded (lane-major per wavefront), or replayed
   g.dz = (size_t)B * N * 2;
   g.guard = back ? 2 * waves : 0;   // k_anchor_spans
   g.total = g.ck + g.w + g.dz + g.guard;

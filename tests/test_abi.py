@@ -56,7 +56,7 @@ def test_argument_errors_without_gpu(built):
     # + (d,z) pairs (B,N,2) + one stability word per wavefront, each part padded to 16 bytes  
     B, N, J = 2, 8, 3                      # G = 4, C = 8 -> 1 segment, 1 wavefront
     ck = 1 * (1 + 1) * (64 + 3 * 32 + 64 + 64)   # S slot 0 (64) + slots 1..3 (32 owners each) + F (64) + W (64)
-    assert lib.c2_loglik_grad_workspace_bytes(B, N, J) == 8 * (ck + B * N * J + B * N * 2 + 2)
+    assert lib.c2_loglik_grad_workspace_bytes(B, N, J) == 8 * (ck + 1 * N * 64 + B * N * 2 + 2)   # W: lane-major per wavefront
     # chip-filling J = 8 batches take the one-lane-per-series path: records W (B,N,8) + (d,z) (B,N,2) + t (B,N) + a
     # checkpoint of 44 doubles every 32 rows and twice as many extra slots (re-anchoring in front of gaps in time) with
     # their row list, overlaid with the replay kernels' workspace, + the guard words (two head words and one per wavefront:

@@ -50,6 +50,7 @@
   X(mfma, "C2_MFMA", 1, 's', "0: long-series products (J = 16; 16 / 32 / 64 right-hand sides) on the VALU instead of the fp64 matrix cores", "N = 1e7: 3.1 vs 9.2 ms (profiles/r02_ubench_memory_and_mfma.md)") \
   X(general_tile, "C2_GENERAL_TILE", 1, 's', "0: general_matmul_* on the two-phase kernels instead of the row tiles", "B = 8192, N = M = 4096, nrhs = 1: 1.4 vs 4.05 ms (profiles/r02_general_matmul.md)") \
   X(generalk, "C2_GENERALK", 1, 's', "0: general_matmul_* with five or more right-hand sides on the first-round kernels", "nrhs = 8: 7.0 vs 24.3 ms") \
+  X(general_tile_max_rhs, "C2_GENERAL_TILE_MAX_RHS", 4, 't', "general_matmul_* on batches of 512 series and more: up to this many right-hand sides by 64-row tiles (one pass per tile of 4), beyond it lanes over the right-hand sides", "profiles/r04_general_tile_rhs.md") \
   X(general_chunks, "C2_GENERAL_CHUNKS", 1, 's', "0: never cut general_matmul_* on small batches of long series into chunks", "B = 1, N = M = 1e5: 32 -> 0.155 ms") \
   X(sweepk_rev, "C2_SWEEPK_REV", 1, 's', "0: multi-rhs reverse sweeps on the lanes-over-J kernel instead of lanes over the right-hand sides", "nrhs = 8: 9.1 vs 21.5 ms") \
   X(sweep1_lines, "C2_SWEEP1_LINES", 1, 's', "0: the single-rhs sweeps at J = 8 request their two rows per step one by one instead of by aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \

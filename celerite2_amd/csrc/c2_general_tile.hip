@@ -435,7 +435,7 @@ static int tile_chunks(int64_t B, int64_t M) {
 extern "C" size_t c2_internal_general_tile_doubles(int64_t B, int64_t M, int64_t J, int64_t nrhs) {
   if (J > 16) return 0;
   const int JM = J <= 4 ? 4 : (J <= 8 ? 8 : 16);
-  if (nrhs > (JM == 16 ? 2 : 4) && B >= 512) return 0;
+  if (nrhs > (JM == 16 ? 2 : opt::ival(opt::k_general_tile_max_rhs)) && B >= 512) return 0;
   const int KT = nrhs == 1 ? 1 : ((nrhs == 2 || JM == 16) ? 2 : 4);
   const int C = tile_chunks(B, M);
   if (C < 2) return 0;
@@ -456,7 +456,7 @@ extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t
   // one pass over the rows per tile of KT right-hand sides: beyond one tile the lanes-over-right-hand-sides kernel
   // (c2_general.hip) does less redundant work (nrhs = 8: 7.2 ms either way, 19.6 against 11.5 ms with the F rows) --
   // unless the batch is small: that kernel walks each series row by row (one series of 1e5 rows, nrhs = 8: 99 ms)
-  if (nrhs > (JM == 16 ? 2 : 4) && B >= 512) return C2_ERR_UNSUPPORTED;
+  if (nrhs > (JM == 16 ? 2 : opt::ival(opt::k_general_tile_max_rhs)) && B >= 512) return C2_ERR_UNSUPPORTED;
   const int KT = nrhs == 1 ? 1 : ((nrhs == 2 || JM == 16) ? 2 : 4);
   const int64_t ytiles = (nrhs + KT - 1) / KT;
   int C = scratch ? tile_chunks(B, M) : 1;

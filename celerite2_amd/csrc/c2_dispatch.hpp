@@ -22,6 +22,7 @@
   X(lanes2_min_batch_grad, "C2_LANES2_MIN_BATCH_GRAD", 16385, 't', "log-likelihood + gradient, J = 8: two lanes per series from this many series up ...", "11.0 vs 14.6 ms at 18432 series (8 lanes: a third round of wavefronts), 11.4 vs 14.4 at 20480, 12.2 - 12.5 vs 15.2 at 24576; 10.25 vs 10.11 at 16384, 10.17 vs 9.65 at 14336 (8 lanes, reverse sweep by the backward recursion; profiles/r04_two_lanes.md)") \
   X(lanes2_max_batch, "C2_LANES2_MAX_BATCH", 32768, 't', "... up to this many (32 series per wavefront: one wavefront per SIMD)", "14.9 - 16.0 vs 16.2 - 17.2 ms at 32768 series (box to box), 27.5 vs 19.4 at 34816 (profiles/r04_two_lanes.md)") \
   X(loglik_back, "C2_LOGLIK_BACK", 1, 's', "log-likelihood + gradient on the group mappings (up to eight lanes per series): reverse sweep by the BACKWARD recursion from recorded W rows instead of replaying the forward steps; 0 keeps the replay (A/B runs)", "profiles/r04_back8.md") \
+  X(loglik_back_occ2, "C2_LOGLIK_BACK_OCC2", 1, 's', "... for batches with more wavefronts than the chip has SIMDs (J = 8: 8192 < B <= 16384) as instances that fit two wavefronts per SIMD; 0: one per SIMD, the rest of the batch behind the first part (A/B runs)", "profiles/r04_back8.md") \
   X(lanes4_min_batch, "C2_LANES4_MIN_BATCH", 16384, 't', "forward log-likelihood, J = 8: two columns per lane from this many series up", "14-15 % faster from 16384 series, equal at 8192 (profiles/r01_lanes4.md)") \
   X(timepar, "C2_TIMEPAR", 0, 's', "forward log-likelihood / factor (widths 4, 2) and the solves parallel along TIME: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_check.py, profiles/r02_timepar.md") \
   X(timepar_min_rows, "C2_TIMEPAR_MIN_ROWS", 1536, 't', "shortest series the time-parallel forward pass takes when the batch is not a handful (B * J > 512)", "J = 4, 1024 x 4096: 0.26 vs 0.87 ms; a handful of series from 384 / 704 / 1024 rows at widths 2 / 4 / 8 (tools/timepar_small_n.py)") \

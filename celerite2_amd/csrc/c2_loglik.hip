@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int 
   }
 }
 
-template <int G, int R, int C, int MODE, bool PAD>
-__global__ __launch_bounds__(kWave, C2_FWD_OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
+template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC>
+__global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
                                                          const double *__restrict__ U,
@@ -456,8 +456,10 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
 // inverts are bounded by the wavefront's `segguard` word: beyond kBackwardGuard this kernel returns at once and the
 // replay form, launched behind it on the same word, takes the wavefront.  Phase B below (a third of the instructions)
 // drops out, and so do the 128 accumulation registers the replayed states waited in.
-template <int G, int C, bool PAD, bool FR, bool BACK = false>
-__global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
+// OCC = 2 (BACK only): two wavefronts per SIMD -- for batches with more wavefronts than the chip has SIMDs; the per-step
+// vectors then wait in LDS instead of accumulation registers (256 registers per wavefront all told).
+template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC>
+__global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
                                                          const double *__restrict__ V,
@@ -482,11 +484,11 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
   constexpr int SPW = kWave / G;         // series per wavefront
   constexpr int NV = (C + G - 1) / G;    // vector loads per scalar stream per segment
   // per-step vectors of the current segment: [r][0] = p_n, [1] = U_n, [2] = W_{n-1}; own value at [lane]
-  __shared__ __attribute__((aligned(16))) double vv[(C2_REV_APARK && G <= 8) ? 1 : C][4][kWave];  // [3] = bW_{n-1} (FR)
+  __shared__ __attribute__((aligned(16))) double vv[(C2_REV_APARK && G <= 8 && OCC == 1) ? 1 : C][4][kWave];  // [3] = bW_{n-1} (FR), 1 / p_n (BACK)
   // The replayed S_n columns wait for their reverse step in AGPRs (G <= 8: C*G*2 = 128 of them); wider groups
   // keep them in LDS, symmetric-packed.
-  constexpr bool APARK = C2_REV_APARK && G <= 8;
-  __shared__ __attribute__((aligned(16))) double sfL[APARK ? 1 : C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
+  constexpr bool APARK = C2_REV_APARK && G <= 8 && OCC == 1;
+  __shared__ __attribute__((aligned(16))) double sfL[(APARK || BACK) ? 1 : C][SymPack<G>::PER_STEP];  // saved S_n columns (packed)
   int sAlo[APARK ? C : 1][G], sAhi[APARK ? C : 1][G];
   int uAlo[APARK ? C : 1], uAhi[APARK ? C : 1], wAlo[APARK ? C : 1], wAhi[APARK ? C : 1];  // own U_n, W_{n-1}
   int xAlo[(APARK && FR) ? C : 1], xAhi[(APARK && FR) ? C : 1];                               // own bW_{n-1} (FR)
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
     lds_order();
     rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
     lds_order();
-    double dtv[C], pown[C], ipown[BACK ? C : 1];
+    double dtv[C], pown[C], ipown[(BACK && APARK) ? C : 1];
     {
       double tprev = rowT[0][grp];
 #pragma unroll
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         dtv[r] = tprev - tn;
         tprev = tn;
         pown[r] = exp_decay(cj * dtv[r]);
-        if constexpr (BACK) ipown[r] = rcp_nr(pown[r]);
+        if constexpr (BACK && APARK) ipown[r] = rcp_nr(pown[r]);
         if constexpr (APARK) {  // the prefetch registers are refilled half way through phase C
           if constexpr (BACK) apark(iw[r], wAlo[r], wAhi[r]);   // the recorded W_{n-1}
           apark(iu[r], uAlo[r], uAhi[r]);
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         } else {
           vv[r][0][lane] = pown[r];
           vv[r][1][lane] = iu[r];
-          if constexpr (BACK) vv[r][2][lane] = iw[r];
+          if constexpr (BACK) { vv[r][2][lane] = iw[r]; vv[r][3][lane] = rcp_nr(pown[r]); }
           if constexpr (FR) vv[r][3][lane] = ibw[r];
         }
       }
@@ -734,7 +736,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
       if (r < cnt) {
         const int64_t n = n_lo + r;
         const double Fpn = FR ? 0.0 : (BACK ? F : Fp[BACK ? 0 : r]);
-        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];  // FR: zm = bd_{n-1}
+        const double rdm = rowR[r][grp], zm = rowZ[r][grp];  // FR: zm = bd_{n-1}
+        const double dt = (BACK && !APARK) ? rowT[r][grp] - rowT[r + 1][grp] : dtv[r];   // (two wavefronts per SIMD: not kept)
         double bWm = 0.0;  // FR: the lane's own bW_{n-1}
         if constexpr (FR) {
           if constexpr (APARK) bWm = afetch(xAlo[r], xAhi[r]);
@@ -759,7 +762,8 @@ __global__ __launch_bounds__(kWave, C2_REV_OCC) void k_loglik_rev(int64_t B, int
         const double p = pX[0], u = uX[0], wm = wX[0];  // slot 0 of an XOR gather is the lane's own element
         double ipX[BACK ? G : 1], tau_n = 0.0;
         if constexpr (BACK) {   // S_n is the carried state; tau_n = U_n S_n as the forward pass formed it
-          xgather_dpp<G>(ipown[r], xB, lane, ipX);
+          if constexpr (APARK) xgather_dpp<G>(ipown[r], xB, lane, ipX);
+          else xgather_dpp<G>(vv[r][3][lane], xB, lane, ipX);
           double ta0 = 0.0, ta1 = 0.0;
 #pragma unroll
           for (int i = 0; i < G; ++i) {
@@ -898,9 +902,14 @@ template <int MODE>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                double *ckpt, int64_t nseg, double *Wst, double2 *DZst, hipStream_t s,
-               const unsigned long long *gate = nullptr, const unsigned long long *segguard = nullptr) {
+               const unsigned long long *gate = nullptr, const unsigned long long *segguard = nullptr, bool occ2 = false) {
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
+  if (MODE == 1 && occ2 && J == 8) {   // two wavefronts per SIMD (the pair of the backward-recursion sweep, see loglik_grad_group)
+    hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R, C2_CKPT_C, (MODE == 1 ? 1 : 0), false, 2>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c,
+                       c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);
+    return launch_ok();
+  }
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
     if (J == G)                                                                                                  \
@@ -1262,6 +1271,17 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J, bool back = false)
 }
 // The backward-recursion form serves the group mappings up to eight lanes (wider models' rates span more than the guard
 // allows between anchors on the bench's own recipe: J = 16, 12 measured -- every wavefront on the replay sweep).  C2_LOGLIK_BACK=0 keeps the replay (A/B runs).
+static int64_t simd_count() {
+  static int64_t n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    n = 4 * (int64_t)cus;
+  }
+  return n;
+}
+static bool occ2_enabled() { return !(opt::has(opt::k_loglik_back_occ2) && opt::ival(opt::k_loglik_back_occ2) == 0); }
 static bool use_back(int64_t N, int64_t J) {
   if (opt::has(opt::k_loglik_back) && opt::ival(opt::k_loglik_back) == 0) return false;
   return group_size(J) <= 8 && N >= 2;
@@ -1554,8 +1574,17 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
     hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, s, B, N, (int)J, C_, kWave / G_, t, t_bs, c, c_bs, segg);
     if (int e = launch_ok()) return e;
   }
-  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wrec, DZst, s, gate, segg)) return e;
-  if (back) {
+  // More wavefronts than SIMDs (8192 < B <= 16384 at J = 8; the two-lane pair takes over beyond): both kernels of the
+  // backward form as instances that fit two wavefronts per SIMD, so the second half of the batch runs next to the first
+  // instead of behind it
+  const bool occ2 = back && J == 8 && occ2_enabled() && (int64_t)grid.x > simd_count();
+  if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wrec, DZst, s, gate, segg, occ2)) return e;
+  if (back && occ2) {
+    hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,
+                       (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU,
+                       bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);
+    if (int e = launch_ok()) return e;
+  } else if (back) {
 #define C2_REVB(G, C)                                                                                                     \
   do {                                                                                                                    \
     if (J == G)                                                                                                           \

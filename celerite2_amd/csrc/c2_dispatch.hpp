@@ -62,8 +62,8 @@
   X(sweep1_rev_lines, "C2_SWEEP1_REV_LINES", 1, 's', "0: the single-rhs reverse sweeps at J = 8 request and store their five rows per step one by one instead of by aligned 128-byte lines", "B = 8192, N = 4096: profiles/r03_sweep_rev_lines.md") \
   X(sweep_rev_lines, "C2_SWEEP_REV_LINES", 1, 's', "0: the reverse sweeps with nrhs = J = 8 on full wavefronts row by row instead of by aligned 128-byte lines", "B = 8192, N = 4096: measured in profiles/r03_sweep_rev_lines.md") \
   X(terms_fused, "C2_TERMS_FUSED", 0, 's', "coefficient-level log-likelihood: 1 forces the fused one-lane kernels (J = 8, 4, 2), 0 the composed chain; unset: by batch size", "65536 series: 21.1 ms fused; 8192 series: 9.2 ms composed") \
-  X(terms_fused_min_batch_fwd, "C2_TERMS_FUSED_MIN_BATCH_FWD", 16384, 't', "coefficient-level forward: fused kernels from this many series up", "tools/terms_time.py") \
-  X(terms_fused_min_batch_grad, "C2_TERMS_FUSED_MIN_BATCH_GRAD", 16384, 't', "coefficient-level gradient: fused kernels from this many series up", "tools/terms_time.py") \
+  X(terms_fused_min_batch_fwd, "C2_TERMS_FUSED_MIN_BATCH_FWD", 10240, 't', "coefficient-level forward: fused kernels from this many series up", "N = 4096, J = 8: fused 3.93 ms whatever the batch up to 32768; composed 3.52 at 8192 series, 4.47 at 12288, 5.39 at 16384 (tools/terms_time.py)") \
+  X(terms_fused_min_batch_grad, "C2_TERMS_FUSED_MIN_BATCH_GRAD", 16384, 't', "coefficient-level gradient: fused kernels from this many series up", "N = 4096, J = 8: fused 16.0 - 16.5 ms whatever the batch up to 32768; composed 8.45 at 8192 series, 13.3 at 12288, 16.4 at 16384, 20.5 at 24576 (tools/terms_time.py)") \
   X(kron_banded, "C2_KRON_BANDED", 1, 's', "0: the per-band passes of the 2-D collapsed method with a thread per epoch for every M", "1.66 + 2.31 -> 0.30 + 0.15 ms at 32 x 50000 x 16")
 
 namespace c2 {

@@ -1710,11 +1710,11 @@ def test_million_row_series(ops, oracle):
 def test_hot_path_is_graph_capturable(ops, oracle, monkeypatch):
     """The fused gradient is stream-ordered end to end -- no host round trip, no allocation with caller-provided
     workspace / outputs, the choice between the backward-recursion sweep and the replay kernels made on the device --
-    so it can be captured once in a HIP graph and replayed on new data (both lane mappings, and a batch that trips the
-    stability gate on replay)."""
+    so it can be captured once in a HIP graph and replayed on new data (the group, one-lane and two-lane mappings, and a
+    batch that trips their stability gates on replay)."""
     import torch
     J = 8
-    for lanes, B, N in (("8", 9, 200), ("1", 70, 200)):
+    for lanes, B, N in (("8", 9, 200), ("1", 70, 200), ("2", 70, 200)):
         monkeypatch.setenv("C2_LANES", lanes)
         t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
         td, cd, ad, Ud, Vd, yd = dev(t, c, a, U, V, y)

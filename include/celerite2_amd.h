@@ -196,11 +196,17 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
  * pymc/distribution.py:123-128), with per-series outputs bt (B,N), bc (B,J),
  * ba (B,N), bU (B,N,J), bV (B,N,J), by (B,N).  `work` is caller-provided device
  * scratch of c2_loglik_grad_workspace_bytes(B,N,J) bytes (the query follows the
- * dispatch: checkpoints + (d,z) records for the row-by-row kernels, lane-major
+ * dispatch: checkpoints + W rows + (d,z) records for the row-by-row kernels, lane-major
  * records for chip-filling batches, d / W / z / state rows / chunk maps for small
  * batches of long series, which run parallel along time).
- * Agreement with the reference's operation order: the row-by-row kernels repeat
- * it up to FMA contraction and reduction order (1e-13 on well-conditioned data);
+ * Agreement with the reference's operation order: the row-by-row forward passes repeat
+ * it up to FMA contraction and reduction order (1e-13 on well-conditioned data); their
+ * reverse sweeps recover the forward state S_n, F_n of reverse.hpp:52-84 / internal.hpp:225-245
+ * by running forward.hpp:115-123 backward from a checkpoint at most 32 rows up wherever the
+ * decays in between can be inverted (c_max * span <= 2: errors grow by at most e^4), and by
+ * replaying the forward steps from a checkpoint where they cannot (gaps in time) -- decided
+ * on the device, per wavefront; gradients within 1e-10 of the largest
+ * entry of their array either way (1.5e-11 between the two forms on the bench's batch);
  * small batches of long series run PARALLEL ALONG TIME, verified
  * on the device -- what every chunk arrives at is compared with what its
  * neighbour was given, and the row-by-row kernels recompute the batch behind

@@ -288,6 +288,9 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
   return __hiloint2double(h, l);
 }
 
+#ifndef C2T_MLDS
+#define C2T_MLDS 0   // half of M in LDS for the coefficient-level sweep: measured, 3 - 5 % SLOWER (20.4 against 19.8 ms at 65536 series)
+#endif
 // Streaming hints (C2T_NT): the records are written once by the forward pass and read once by the reverse sweep, the
 // gradients are written once -- none of it should displace the half-used lines of the API rows from L2.
 #ifndef C2T_NT
@@ -901,6 +904,21 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   int Slo[NS], Shi[NS], Mlo[NS], Mhi[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) { apark(0.0, Slo[k], Shi[k]); apark(0.0, Mlo[k], Mhi[k]); }
+  // Coefficient-level form (C2T_MLDS): its LDS has room the matrix-level form spends on the row tiles -- the rest of the
+  // U tile behind the accumulators, the unused bV tile, the tail of the block: nine lane-major slots of 16 bytes -- and the
+  // first NML = 18 elements of M (in the order of the pass) can live there instead of in accumulation registers: one
+  // ds_read_b128 + one ds_write_b128 per two elements against eight v_accvgpr moves.  Measured on the round-4 kernels: 3 - 5 %
+  // slower (the LDS round trip sits in the pass's dependency chains, four wavefronts share the CU's LDS); off.
+  constexpr int NML = (TERMS && C2T_MLDS && NS >= 18) ? 18 : 0;
+  auto mslot = [&](int q) -> double2 * {   // elements 2 q, 2 q + 1
+    return reinterpret_cast<double2 *>(lds + (q < 7 ? kWave * AS1 + q * 2 * kWave : kRevLds / 8 - (9 - q) * 2 * kWave)) + lane;
+  };
+  static_assert(NML == 0 || kWave * AS1 + 7 * 2 * kWave <= kWave * RSTR + kWave * RS1, "free LDS behind the accumulator tile");
+  if constexpr (NML > 0) {
+#pragma unroll
+    for (int q = 0; q < NML / 2; ++q) *mslot(q) = make_double2(0.0, 0.0);
+  }
+  double2 mpair = make_double2(0.0, 0.0);
 #pragma unroll
   for (int j = 0; j < J; ++j) { F[j] = 0.0; bF[j] = 0.0; bVn[j] = failed ? nan : 0.0; }
   double carry = 0.0;
@@ -1090,7 +1108,13 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         for (int j2 = i; j2 < J; ++j2) {
           const int k = sidx(i, j2);
           const double sv = afetch(Slo[k], Shi[k]);
-          double m = afetch(Mlo[k], Mhi[k]);
+          double m;
+          if (k < NML) {
+            if ((k & 1) == 0) mpair = *mslot(k / 2);
+            m = (k & 1) ? mpair.y : mpair.x;
+          } else {
+            m = afetch(Mlo[k], Mhi[k]);
+          }
           xs[j2] = fma(x[i], sv, xs[j2]);
           if (j2 != i) xs[i] = fma(x[j2], sv, xs[i]);
 #if C2T_M2
@@ -1104,7 +1128,11 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
           bp[j2] = fma(sv, m, bp[j2]);
           if (j2 != i) bp[i] = fma(sv, m, bp[i]);
           m *= p[i] * p[j2];
-          apark(m, Mlo[k], Mhi[k]);
+          if (k < NML) {
+            if (k & 1) { mpair.y = m; *mslot(k / 2) = mpair; } else mpair.x = m;
+          } else {
+            apark(m, Mlo[k], Mhi[k]);
+          }
           q[j2] = fma(wa[i], m, q[j2]);
           if (j2 != i) q[i] = fma(wa[j2], m, q[i]);
           apark(fma(-dwi, wa[j2], sv * (ip[i] * ip[j2])), Slo[k], Shi[k]);

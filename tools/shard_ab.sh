@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/shard_ab.sh: bench step at the shards of configs[2] in fresh processes on ONE box -- the dispatch's choice against the
+# round-3 kernels forced (C2_LANES=1 at 32768 series; C2_LOGLIK_BACK=0 C2_LANES=8 at 16384 and 8192), three processes each
+R=${GRAFT_REPO_ROOT:-/root/repo}
+run() {  # label, batch, env...
+  local label=$1 b=$2; shift 2
+  for i in 1 2 3; do
+    env "$@" python $R/bench.py --batch-per-gpu $b --no-gappy --no-cpu-baseline --no-long-series --no-coefficient-level 2>/dev/null | tail -1 \
+      | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$label', d['config']['batch_per_gpu'], round(d['ms_per_step'],3), round(d['roofline']['frac'],4))"
+  done
+}
+run "two lanes (default)      " 32768 C2_NOP=1
+run "one lane (round 3)       " 32768 C2_LANES=1
+run "8 lanes backward (default)" 16384 C2_NOP=1
+run "8 lanes replay (round 3) " 16384 C2_LANES=8 C2_LOGLIK_BACK=0
+run "8 lanes backward (default)" 8192 C2_NOP=1
+run "8 lanes replay (round 3) " 8192 C2_LOGLIK_BACK=0

@@ -18,11 +18,12 @@
   X(lanes1_min_batch_fwd, "C2_LANES1_MIN_BATCH_FWD", 24576, 't', "forward log-likelihood: one lane per series from this many series up (widths 8, 6, 4, 2)", "N = 4096, J = 8: 3.3 vs 4.1 ms at 24576 series, 6.7 vs 10.4 ms at 65536 (profiles/r02_lane_mappings.md)") \
   X(lanes1_min_batch_grad, "C2_LANES1_MIN_BATCH_GRAD", 24576, 't', "log-likelihood + gradient: one lane per series from this many series up (widths 8, 4, 2)", "15.7 vs 16.0 ms at 24576 series, 28.2 vs 41.8 ms at 65536 (profiles/r02_lane_mappings.md)") \
   X(lanes1_min_batch_grad_j6, "C2_LANES1_MIN_BATCH_GRAD_J6", 32768, 't', "the same at width 6 (rows of 48 bytes: no aligned 128-byte runs)", "18.5 vs 20.7 ms at 32768 series, 17.2 vs 15.8 ms at 24576") \
-  X(lanes2_min_batch_fwd, "C2_LANES2_MIN_BATCH_FWD", 16384, 't', "forward log-likelihood, J = 8: two lanes per series from this many series up ...", "N = 4096: 2.38 vs 2.43 ms at 16384 series (two columns per lane), 2.59 vs 3.69 at 20480 (one lane), 2.76 vs 3.70 at 24576, 3.37 vs 3.84 at 32768; 2.38 vs 2.34 at 12288 (profiles/r04_two_lanes.md)") \
+  X(lanes2_min_batch_fwd, "C2_LANES2_MIN_BATCH_FWD", 16385, 't', "forward log-likelihood, J = 8: two lanes per series from this many series up ...", "N = 4096: 2.38 - 2.57 vs 2.25 - 2.43 ms at 16384 series (two columns per lane: one wavefront per SIMD there), 2.59 vs 3.69 at 20480 (one lane), 2.76 vs 3.70 at 24576, 3.37 vs 3.84 at 32768 (profiles/r04_two_lanes.md)") \
   X(lanes2_min_batch_grad, "C2_LANES2_MIN_BATCH_GRAD", 16385, 't', "log-likelihood + gradient, J = 8: two lanes per series from this many series up ...", "11.0 vs 14.6 ms at 18432 series (8 lanes: a third round of wavefronts), 11.4 vs 14.4 at 20480, 12.2 - 12.5 vs 15.2 at 24576; 10.25 vs 10.11 at 16384, 10.17 vs 9.65 at 14336 (8 lanes, reverse sweep by the backward recursion; profiles/r04_two_lanes.md)") \
   X(lanes2_max_batch, "C2_LANES2_MAX_BATCH", 32768, 't', "... up to this many (32 series per wavefront: one wavefront per SIMD)", "14.9 - 16.0 vs 16.2 - 17.2 ms at 32768 series (box to box), 27.5 vs 19.4 at 34816 (profiles/r04_two_lanes.md)") \
   X(loglik_back, "C2_LOGLIK_BACK", 1, 's', "log-likelihood + gradient on the group mappings (up to eight lanes per series): reverse sweep by the BACKWARD recursion from recorded W rows instead of replaying the forward steps; 0 keeps the replay (A/B runs)", "profiles/r04_back8.md") \
   X(loglik_back_occ2, "C2_LOGLIK_BACK_OCC2", 1, 's', "... for batches with more wavefronts than the chip has SIMDs (J = 8: 8192 < B <= 16384) as instances that fit two wavefronts per SIMD; 0: one per SIMD, the rest of the batch behind the first part (A/B runs)", "profiles/r04_back8.md") \
+  X(fwd_dpp_gathers, "C2_FWD_DPP_GATHERS", 0, 's', "1: forward kernels of the group mappings (up to eight lanes per series) gather the next step's decay and U vectors by DPP permutes instead of through LDS (A/B runs)", "slower: 1024 series x 4096 rows 3.76 -> 4.11 ms for the gradient pair (profiles/r04_back8.md)") \
   X(lanes4_min_batch, "C2_LANES4_MIN_BATCH", 16384, 't', "forward log-likelihood, J = 8: two columns per lane from this many series up", "14-15 % faster from 16384 series, equal at 8192 (profiles/r01_lanes4.md)") \
   X(timepar, "C2_TIMEPAR", 0, 's', "forward log-likelihood / factor (widths 4, 2) and the solves parallel along TIME: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_check.py, profiles/r02_timepar.md") \
   X(timepar_min_rows, "C2_TIMEPAR_MIN_ROWS", 1536, 't', "shortest series the time-parallel forward pass takes when the batch is not a handful (B * J > 512)", "J = 4, 1024 x 4096: 0.26 vs 0.87 ms; a handful of series from 384 / 704 / 1024 rows at widths 2 / 4 / 8 (tools/timepar_small_n.py)") \

@@ -206,7 +206,10 @@ __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int 
   }
 }
 
-template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC>
+// DG: the next step's p and U gathered by DPP permutes instead of through LDS.  The LDS form costs the VALU nothing but
+// makes the wavefront wait for two LDS round trips per step -- which one would expect to hurt when the grid gives every
+// wavefront a SIMD of its own; measured it does not: the DPP form is 2 - 9 % slower there too (launch_fwd).
+template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC, bool DG = false>
 __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
@@ -325,11 +328,16 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   double tnext = sin_[0][0][grp][0];
   double pc = exp_decay(cj * (tcur - tnext)), uc = ru[0];
   double pXc[G], uXc[G];
-  xs[0][lane] = pc; xs[1][lane] = uc;
-  lds_order();
-  xgather_lds<G>(xs[0], lane, pXc);
-  xgather_lds<G>(xs[1], lane, uXc);
-  lds_order();
+  if constexpr (DG) {
+    xgather_dpp<G>(pc, xs[0], lane, pXc);
+    xgather_dpp<G>(uc, xs[1], lane, uXc);
+  } else {
+    xs[0][lane] = pc; xs[1][lane] = uc;
+    lds_order();
+    xgather_lds<G>(xs[0], lane, pXc);
+    xgather_lds<G>(xs[1], lane, uXc);
+    lds_order();
+  }
 
   auto block = [&](int64_t n0, int q, auto checked_tag) {
     constexpr bool CHECKED = decltype(checked_tag)::value;
@@ -347,12 +355,17 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
         const int rn = (r + 1) % R;
         const double pn1 = exp_decay(cj * (tn - tn1)), un1 = ru[rn];
-        xs[0][lane] = pn1; xs[1][lane] = un1;
-        lds_order();
         double pXn[G], uXn[G];
-        xgather_lds<G>(xs[0], lane, pXn);
-        xgather_lds<G>(xs[1], lane, uXn);
-        lds_order();
+        if constexpr (DG) {
+          xgather_dpp<G>(pn1, xs[0], lane, pXn);
+          xgather_dpp<G>(un1, xs[1], lane, uXn);
+        } else {
+          xs[0][lane] = pn1; xs[1][lane] = un1;
+          lds_order();
+          xgather_lds<G>(xs[0], lane, pXn);
+          xgather_lds<G>(xs[1], lane, uXn);
+          lds_order();
+        }
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (REC) {
@@ -895,8 +908,16 @@ using namespace c2;
 #define C2_FWD_R C2_CKPT_C   // prefetch ring length (rows); multiple of the checkpoint interval
 #endif
 
+static int64_t simd_count();
 namespace {
 inline int launch_ok() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP; }
+// the forward kernel's p / U gathers by DPP instead of through LDS (C2_FWD_DPP_GATHERS=1)
+// (measured, round 4: slower even then -- 1024 series 3.76 -> 4.11 ms for the gradient pair, forward-only 1.27 -> 1.30 at 4096
+// series: the 28 permutes join the step's dependency chain; kept as a switch, off)
+inline bool fwd_dpp_gathers(unsigned waves) {
+  (void)waves;
+  return opt::has(opt::k_fwd_dpp_gathers) && opt::ival(opt::k_fwd_dpp_gathers) != 0;
+}
 
 template <int MODE>
 int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
@@ -910,9 +931,17 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
                        c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);
     return launch_ok();
   }
+  const bool dg = G_ <= 8 && fwd_dpp_gathers(grid.x);
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
-    if (J == G)                                                                                                  \
+    if (dg && G <= 8) {                                                                                          \
+      if (J == G)                                                                                                \
+        hipLaunchKernelGGL((k_loglik_fwd<(G <= 8 ? G : 8), R, C, MODE, false, C2_FWD_OCC, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
+                           t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);         \
+      else                                                                                                       \
+        hipLaunchKernelGGL((k_loglik_fwd<(G <= 8 ? G : 8), R, C, MODE, true, C2_FWD_OCC, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t,  \
+                           t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);         \
+    } else if (J == G)                                                                                           \
       hipLaunchKernelGGL((k_loglik_fwd<G, R, C, MODE, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs,   \
                          c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);                 \
     else                                                                                                         \

@@ -1298,8 +1298,9 @@ static inline GradWs grad_ws(int64_t B, int64_t N, int64_t J, bool back = false)
   g.total = g.ck + g.w + g.dz + g.guard;
   return g;
 }
-// The backward-recursion form serves the group mappings up to eight lanes (wider models' rates span more than the guard
-// allows between anchors on the bench's own recipe: J = 16, 12 measured -- every wavefront on the replay sweep).  C2_LOGLIK_BACK=0 keeps the replay (A/B runs).
+// The backward-recursion form serves the group mappings up to eight lanes.  Sixteen lanes (C = 4) measured on the bench's
+// recipe at N = 4096: J = 16 every wavefront beyond the guard (the replay sweep answers: 8.0 ms either way), J = 12 re-anchored at
+// every segment 8.9 -> 13.7 ms, J = 10 8.9 -> 7.3 -- not a gain one can count on; left on the replay.  C2_LOGLIK_BACK=0 keeps the replay (A/B runs).
 static int64_t simd_count() {
   static int64_t n = 0;
   if (n == 0) {

@@ -113,7 +113,78 @@ def cpu_baseline(N, J, grad, seconds):
     }
 
 
-def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
+PARITY_NAMES = ("bt", "bc", "ba", "bU", "bV", "by")
+
+
+def take_sample(inputs, ll, grads, count, seed):
+    """Copy `count` series drawn at random from a batch the hot path has just processed -- inputs AND the outputs of that
+    very step -- to the host (untimed; the checker runs later, in the cpu_baseline leg)."""
+    import numpy as np
+    import torch
+
+    B = int(ll.shape[0])
+    idx = np.sort(np.random.default_rng(seed).choice(B, size=min(count, B), replace=False))
+    sel = torch.from_numpy(idx).to(ll.device)
+    host = lambda x: x.index_select(0, sel).cpu().numpy()
+    return {"index": idx, "inputs": [host(x) for x in inputs], "ll": host(ll), "grads": [host(g) for g in grads]}
+
+
+def rel_errors(got, want):
+    """Per sampled series and array: (1) the largest |x - x_oracle| relative to the largest |x_oracle| of that series'
+    array; (2) the criterion every parity test of tests/ applies element by element, |x - x_o| <= 1e-10 |x_o| + 1e-12
+    max|x_o|, as one number: max_i |x_i - x_o,i| / (|x_o,i| + 1e-2 max|x_o|), which that test
+    holds to 1e-10.  (A bare element-by-element ratio means nothing on the entries that are themselves cancellations:
+    the oracle in double against its own long-double evaluation differs by 5e-10 .. 8e-10 there.)  Maximum over the sample."""
+    import numpy as np
+
+    g = got.reshape(got.shape[0], -1); w = want.reshape(want.shape[0], -1)
+    big = np.abs(w).max(axis=1, keepdims=True)
+    big = np.where(big > 0.0, big, 1.0)
+    diff = np.abs(g - w)
+    return float((diff / big).max()), float((diff / (np.abs(w) + 1e-2 * big)).max())
+
+
+def parity_sample(samples, coeff_sample):
+    """The timed batches against the CPU oracle: the series `take_sample` set aside from the step's own batch (and from
+    the `gappy_all` batch), log-likelihood and the six gradients; the coefficient-level leg's sample through the oracle
+    chain (oracle/dense.py: the reverse of get_celerite_matrices in numpy).  Checker only -- after every timed region."""
+    import numpy as np
+
+    from oracle import cpu, dense
+
+    out = {"criterion": "per array, max over the sampled series: the tests' element-wise criterion |x - x_o| <= 1e-10 |x_o| + "
+                        "1e-12 max|x_o| as one number, max_i |x_i - x_o,i| / (|x_o,i| + 1e-2 max|x_o|) <= 1e-10 (the figure "
+                        "listed per array); `rel_to_largest`: max|x - x_o| / max|x_o|; ll: relative"}
+    worst = 0.0
+    for name, smp in samples.items():
+        llo, go, flago = cpu.loglik_grad_batched(*smp["inputs"], nthreads=min(16, os.cpu_count() or 1))
+        e = {"series": int(len(smp["index"])), "oracle_failed": int(np.abs(flago).sum()),
+             "ll": float(np.max(np.abs(smp["ll"] - llo) / np.abs(llo)))}
+        el = {}
+        for nm, g, w in zip(PARITY_NAMES, smp["grads"], go):
+            el[nm], e[nm] = rel_errors(g, w)
+        e["rel_to_largest"] = el
+        worst = max([worst, e["ll"]] + [e[nm] for nm in PARITY_NAMES])
+        out[name] = e
+    if coeff_sample is not None:
+        x, diag, y, ac, bc, cc, dc = coeff_sample["inputs"]
+        z = np.zeros(0)
+        names = ("bac", "bbc", "bcc", "bdc", "bx", "bdiag", "by")
+        want = [dense.coefficient_chain(cpu, z, z, ac[i], bc[i], cc[i], dc[i], x[i], diag[i], y[i]) for i in range(len(x))]
+        e = {"series": int(len(x)), "oracle_failed": int(sum(w[2] != 0 for w in want)),
+             "ll": float(np.max(np.abs(coeff_sample["ll"] - np.array([w[0] for w in want])) / np.abs(np.array([w[0] for w in want]))))}
+        el = {}
+        for k, nm in enumerate(names):   # (the nine gradients of c2_loglik_terms_grad; no real terms here: bar, bcr are empty)
+            el[nm], e[nm] = rel_errors(coeff_sample["grads"][k + 2], np.stack([np.atleast_1d(w[1][k + 2]) for w in want]))
+        e["rel_to_largest"] = el
+        worst = max([worst, e["ll"]] + [e[nm] for nm in names])
+        out["coefficient_level"] = e
+    out["worst"] = worst
+    out["within_1e-10"] = bool(worst <= 1e-10)
+    return out
+
+
+def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps, want_sample=False):
     import torch
 
     from celerite2_amd import ops, synth
@@ -132,6 +203,7 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
+    sample = take_sample((x, diag, y, ac, bc, cc, dc), ll, outs, 8, 3) if want_sample else None
     # bytes the entry point has to move: x, diag, y in; bx, bdiag, by out (the coefficients and their gradients are O(J))
     nbytes = Bp * N * 6 * 8
     # Roofline of this entry point: fp64 VECTOR arithmetic (48 B per step of memory traffic leave HBM far from the wall).
@@ -152,10 +224,10 @@ def coefficient_level(first, Bp, N, J, dev, ll_matrix, steps):
                          "peak": PEAK_F64_VECTOR, "unit": "TFLOP/s", "frac": Bp / ms * 1e3 * flops_per_gp / 1e12 / PEAK_F64_VECTOR,
                          "counting": "SURVEY.md 8d flops/step of rows A, H, I (~1900 at J = 8) + one sincos per complex "
                                      "term in each sweep (~40) + the coefficient-gradient contraction (~12 per term)"},
-            "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}
+            "note": "informational: same series as `value`, gradient w.r.t. the celerite coefficients instead of U, V rows"}, sample
 
 
-def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms, every_series=False):
+def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms, every_series=False, samples=None):
     """Informational: the same workload with 5 % of the series carrying one gap of 100 mean spacings (a night, a season) at
     a row of their own.  The one-lane reverse sweep cannot invert a decay across such a gap; the forward pass re-anchors it
     there with an extra wavefront-uniform checkpoint (c2_loglik_t.hip), so the batch stays on the fast kernels -- `guard`
@@ -182,6 +254,8 @@ def gappy(first, Bp, N, J, dev, work, out, steps, clean_ms, every_series=False):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     guard, nfall = float(work[0]), int(work[:2].view(torch.int64)[1])
+    if samples is not None:
+        samples["gappy_all" if every_series else "gappy"] = take_sample((t, c, a, U, V, y), ll, out, 8, 2)
     return {"workload": what % (ngap, Bp),
             "ms_per_step": ms, "value": Bp / ms * 1e3, "unit": "GP/s", "steps": steps, "ratio_to_gap_free_step": ms / clean_ms,
             "guard": guard, "wavefronts_on_the_replay_kernels": nfall, "wavefronts": (Bp + 63) // 64,
@@ -282,6 +356,8 @@ def main():
     ap.add_argument("--mode", choices=["grad", "fwd"], default="grad")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-sample", action="store_true",
+                    help="skip the `parity_sample` object (series of the timed batches against the CPU oracle, after the timed regions)")
     ap.add_argument("--exact-synth", action="store_true",
                     help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
     ap.add_argument("--placement-search", type=int, default=1,
@@ -444,6 +520,12 @@ def main():
     t, c, a, U, V, y = m["inputs"]
     m = None   # (the names above own the buffers now: the informational legs below free them one by one)
     kernel_ms_avg = sum(kernel_ms) / len(kernel_ms)
+    # parity of the TIMED work: 32 series drawn from the batch the timed steps ran on, with the outputs of the last timed
+    # step, set aside now and checked against the CPU oracle in the cpu_baseline leg (after every timed region)
+    samples, coeff_sample = {}, None
+    want_parity = rank == 0 and grad and not args.no_cpu_baseline and not args.no_parity_sample
+    if want_parity:
+        samples["step_batch"] = take_sample((t, c, a, U, V, y), ll[first:first + Bp] if ll.shape[0] != Bp else ll, out, 32, 1)
     # who ran: one entry per rank (device, PCI bus id) + the collective library -- self-evidencing multi-GPU lines
     me = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
           "pci_bus_id": "%04x:%02x:%02x.0" % tuple(getattr(torch.cuda.get_device_properties(dev_index), k, 0)
@@ -510,11 +592,12 @@ def main():
             torch.cuda.empty_cache()
             ll_keep = ll[:Bp].clone()
             try:
-                line["gappy"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg)
+                line["gappy"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg, samples=samples if want_parity else None)
             except Exception as e:  # noqa: BLE001 -- informational only
                 line["gappy"] = {"error": repr(e)[:200]}
             try:   # every series with three gaps of its own: what a wavefront's re-anchoring checkpoints cost at worst
-                line["gappy_all"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg, every_series=True)
+                line["gappy_all"] = gappy(first, Bp, N, J, dev, work, out, min(args.steps, 5), kernel_ms_avg, every_series=True,
+                                          samples=samples if want_parity else None)
             except Exception as e:  # noqa: BLE001 -- informational only
                 line["gappy_all"] = {"error": repr(e)[:200]}
             t = c = a = U = V = y = None
@@ -525,9 +608,14 @@ def main():
             ll_matrix = ll[:Bp].clone()
             del t, c, a, U, V, y, out, work
             torch.cuda.empty_cache()
-            line["coefficient_level"] = coefficient_level(first, Bp, N, J, dev, ll_matrix, min(args.steps, 5))
+            line["coefficient_level"], coeff_sample = coefficient_level(first, Bp, N, J, dev, ll_matrix, min(args.steps, 5), want_parity)
         if world == 1 and grad and J in (2, 4, 6, 8) and not args.no_long_series:
             line["long_series"] = long_series(J, dev)
+        if want_parity:
+            try:
+                line["parity_sample"] = parity_sample(samples, coeff_sample)
+            except Exception as e:  # noqa: BLE001 -- the checker must not take the line down; its absence is visible
+                line["parity_sample"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(N, J, grad, args.cpu_seconds)
         print(json.dumps(line), flush=True)

@@ -23,6 +23,7 @@
   X(lanes2_max_batch, "C2_LANES2_MAX_BATCH", 32768, 't', "... up to this many (32 series per wavefront: one wavefront per SIMD)", "14.9 - 16.0 vs 16.2 - 17.2 ms at 32768 series (box to box), 27.5 vs 19.4 at 34816 (profiles/r04_two_lanes.md)") \
   X(loglik_back, "C2_LOGLIK_BACK", 1, 's', "log-likelihood + gradient on the group mappings (up to eight lanes per series): reverse sweep by the BACKWARD recursion from recorded W rows instead of replaying the forward steps; 0 keeps the replay (A/B runs)", "profiles/r04_back8.md") \
   X(loglik_back_occ2, "C2_LOGLIK_BACK_OCC2", 1, 's', "... for batches with more wavefronts than the chip has SIMDs (J = 8: 8192 < B <= 16384) as instances that fit two wavefronts per SIMD; 0: one per SIMD, the rest of the batch behind the first part (A/B runs)", "profiles/r04_back8.md") \
+  X(loglik_scaled, "C2_LOGLIK_SCALED", 1, 's', "... in a scaled frame (states multiplied by exp(-c (t_anchor - t_n)): no decay factors in the step, three gathered vectors instead of five); 0: the plain backward recursion (A/B runs)", "profiles/r05_scaled_frame.md") \
   X(fwd_dpp_gathers, "C2_FWD_DPP_GATHERS", 0, 's', "1: forward kernels of the group mappings (up to eight lanes per series) gather the next step's decay and U vectors by DPP permutes instead of through LDS (A/B runs)", "slower: 1024 series x 4096 rows 3.76 -> 4.11 ms for the gradient pair (profiles/r04_back8.md)") \
   X(lanes4_min_batch, "C2_LANES4_MIN_BATCH", 16384, 't', "forward log-likelihood, J = 8: two columns per lane from this many series up", "14-15 % faster from 16384 series, equal at 8192 (profiles/r01_lanes4.md)") \
   X(timepar, "C2_TIMEPAR", 0, 's', "forward log-likelihood / factor (widths 4, 2) and the solves parallel along TIME: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_check.py, profiles/r02_timepar.md") \

@@ -471,7 +471,15 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
 // drops out, and so do the 128 accumulation registers the replayed states waited in.
 // OCC = 2 (BACK only): two wavefronts per SIMD -- for batches with more wavefronts than the chip has SIMDs; the per-step
 // vectors then wait in LDS instead of accumulation registers (256 registers per wavefront all told).
-template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC>
+// SC = true (BACK only): the backward recursion and the adjoint recursion in a SCALED FRAME.  With g_n = exp(-c (t_ref - t_n)),
+// t_ref the time of the anchor row above (so g <= 1 and, within the guard, >= e^-2), the scaled states
+//     S^_n = G_n S_n G_n,   M^_n = G_n^-1 M_n G_n^-1,   F~_n = g_n F_n,   bF-_n = bF_n / g_n,   bV-_n = bV_n / g_n
+// obey recursions WITHOUT decay factors: S^_{n-1} = S^_n - d_{n-1} w~ w~^T, F~_{n-1} = F~_n - w~ z_{n-1} (w~ = g_{n-1} W_{n-1});
+// M^ and bF- pass from row n to n-1 unchanged; diag(S M) = diag(S^ M^), F.bF = F~.bF-; q = W_{n-1} M = g_{n-1} (w~ M^), so
+// bV-_{n-1} = (z/d) bF- + w~ M^ needs no factor at all.  Per step the gathers of p and 1/p and the 32 multiplications by
+// p_i p_j, 1/(p_i p_j) drop out (five gathered vectors -> three: u- = u / g_n, x- = bV- + 2 ba u-, w~); what is left of the
+// frame is one factor on u, w and on the rows bU_n, bV_n on their way out, and a change of frame at every anchor.
+template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC, bool SC = false>
 __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
@@ -487,6 +495,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
                                                          const unsigned long long *__restrict__ gate,
                                                          const unsigned long long *__restrict__ segguard = nullptr) {
   static_assert(!(BACK && FR), "factor_rev replays from the caller's workspace");
+  static_assert(!SC || BACK, "the scaled frame belongs to the backward-recursion sweep");
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;  // see k_loglik_fwd
   int astep = kAnchor;   // (BACK, uniform) segments between two anchors of the backward recursion
   if (segguard) {   // this wavefront by the backward recursion, or (the launch behind it) by the replay
@@ -619,6 +628,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
 #endif
 
   double carS[BACK ? G : 1], carF = 0.0;   // (BACK) the recursed state handed from a segment to the one below
+  double tref = 0.0, gtop = 1.0, igtop = 1.0;   // (SC) reference time of the frame; g, 1 / g of the row above the current segment's last step
 #pragma unroll
   for (int i = 0; i < (BACK ? G : 1); ++i) carS[i] = 0.0;
   for (int64_t k = nseg - 1; k >= 0; --k) {
@@ -637,8 +647,44 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     lds_order();
     rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
     lds_order();
-    double dtv[C], pown[C], ipown[(BACK && APARK) ? C : 1];
-    {
+    double dtv[C], pown[C], ipown[(BACK && APARK) ? C : 1];   // (SC: pown = g, ipown = 1 / g of rows n_lo-1 .. n_lo+C-2)
+    const bool anchor = !BACK || (k + 1) % astep == 0 || k == nseg - 1;   // (BACK, uniform) re-anchor, or carry on
+    if constexpr (SC) {
+      if (anchor) {   // change of frame: the anchor row (the segment's last) becomes the reference, g = 1 there
+        double gX[G];
+        xgather_dpp<G>(gtop, xB, lane, gX);
+#pragma unroll
+        for (int i = 0; i < G; ++i) MX[i] *= gX[i] * gtop;
+        bF *= gtop;
+        bVn *= gtop;
+        tref = rowT[cnt][grp];
+        gtop = 1.0;
+        igtop = 1.0;
+      }
+      double igl[C];
+#pragma unroll
+      for (int r = 0; r < C; ++r) {
+        // (rows of a short last segment beyond its end repeat the last row -- clamped loads -- so g = 1 there as well)
+        const double tm = rowT[r][grp];
+        dtv[r] = tm - rowT[r + 1][grp];
+        pown[r] = exp_decay(cj * (tm - tref));
+        igl[r] = rcp_nr(pown[r]);
+        if constexpr (APARK) ipown[r] = igl[r];
+        else { vv[r][0][lane] = pown[r]; vv[r][3][lane] = igl[r]; }
+      }
+#pragma unroll
+      for (int r = 0; r < C; ++r) {   // u- = U_n / g_n, w~ = W_{n-1} g_{n-1} wait for their step already scaled
+        const double ign = (r == C - 1) ? igtop : igl[r + 1 < C ? r + 1 : 0];
+        const double us = iu[r] * ign, ws = iw[r] * pown[r];
+        if constexpr (APARK) {
+          apark(ws, wAlo[r], wAhi[r]);
+          apark(us, uAlo[r], uAhi[r]);
+        } else {
+          vv[r][1][lane] = us;
+          vv[r][2][lane] = ws;
+        }
+      }
+    } else {
       double tprev = rowT[0][grp];
 #pragma unroll
       for (int r = 0; r < C; ++r) {
@@ -664,7 +710,6 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     // the lane's own W_{n-1} are parked (AGPRs; LDS for G > 8), F_n and tau_n stay in registers.
     double SX[G];
     const double pck = FR ? exp_decay(cj * (tck - rowT[0][grp])) : 1.0;  // FR: right scaling of the workspace row
-    const bool anchor = !BACK || (k + 1) % astep == 0 || k == nseg - 1;   // (BACK, uniform) re-anchor, or carry on
 #pragma unroll
     for (int i = 0; i < G; ++i) SX[i] = FR ? cS[i] * pck : (anchor ? cS[i] : carS[BACK ? i : 0]);
     double F = anchor ? cF : carF;
@@ -746,6 +791,65 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       if (r == (BACK && C2_BACK_EARLY ? C - 1 : C / 2 - 1) || (C == 1)) {
         if (k > 0) load_segment(k - 1);
       }
+      if constexpr (SC) {
+        if (r < cnt) {   // the step in the scaled frame (see the head of the kernel); F holds F~_n, bF holds bF-, bVn holds bV-_n
+          const int64_t n = n_lo + r;
+          const double rdm = rowR[r][grp], zm = rowZ[r][grp];
+          double gn, ign, dt;   // g_n, 1 / g_n of this row
+          if constexpr (APARK) {
+            gn = (r == C - 1) ? gtop : pown[r + 1 < C ? r + 1 : 0];
+            ign = (r == C - 1) ? igtop : ipown[r + 1 < C ? r + 1 : 0];
+            dt = dtv[r];
+          } else {
+            gn = (r == C - 1) ? gtop : vv[r + 1 < C ? r + 1 : 0][0][lane];
+            ign = (r == C - 1) ? igtop : vv[r + 1 < C ? r + 1 : 0][3][lane];
+            dt = rowT[r][grp] - rowT[r + 1][grp];
+          }
+          double uX[G], wX[G], xX[G];
+          if constexpr (APARK) {
+            xgather_dpp<G>(afetch(uAlo[r], uAhi[r]), xB, lane, uX);
+            xgather_dpp<G>(afetch(wAlo[r], wAhi[r]), xB, lane, wX);
+          } else {
+            xgather_dpp<G>(vv[r][1][lane], xB, lane, uX);
+            xgather_dpp<G>(vv[r][2][lane], xB, lane, wX);
+          }
+          const double u = uX[0], wm = wX[0];   // u-_n and w~_{n-1} of this lane
+          oBA[grp][r] = ban;
+          if (st) bVb[n * J] = bVn * gn;
+          // x- = bV- + 2 ba u- is the vector gathered on the chain; M^ -= u-^T x- + bV-^T u- = u-_i bV-_j + x-_i u-_j
+          const double xv = fma(2.0 * ban, u, bVn);
+          xgather_dpp<G>(xv, xB, lane, xX);
+          const double bU1 = -bzn * F;            // internal.hpp:232 (F~: the factor 1 / g_n joins below)
+          bF = fma(-u, bzn, bF);                  // internal.hpp:233
+          const double bp_s = F * bF;             // internal.hpp:236 (F . bF = F~ . bF-)
+          double xs0 = 0.0, xs1 = 0.0, bp0 = 0.0, bp1 = 0.0, q0 = 0.0, q1 = 0.0;
+#pragma unroll
+          for (int i = 0; i < G; ++i) {
+            double m = fma(-uX[i], bVn, MX[i]);
+            m = fma(-xX[i], u, m);
+            MX[i] = m;
+            if (i & 1) { xs1 = fma(xX[i], SX[i], xs1); bp1 = fma(SX[i], m, bp1); q1 = fma(wX[i], m, q1); }
+            else { xs0 = fma(xX[i], SX[i], xs0); bp0 = fma(SX[i], m, bp0); q0 = fma(wX[i], m, q0); }
+          }
+          if (st) bUb[n * J] = ign * (bU1 - (xs0 + xs1));     // reverse.hpp:66 + internal.hpp:232
+          const double bp = bp_s + (bp0 + bp1);
+          bcj = fma(dt, bp, bcj);
+          const double q = q0 + q1;               // (w~ M^)_j = q_j / g_{n-1}
+          double f = cj * bp, Gs = wm * bF, Q = q * wm;
+          gsum3<G>(f, Gs, Q);
+          oBT[grp][r] = carry - f;
+          carry = f;
+          const double zr = zm * rdm;
+          bzn = Gs - zr;
+          oBY[grp][r] = bzn;
+          bVn = fma(zr, bF, q);                   // bV-_{n-1}: no factor
+          ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+          const double dwm = rowD[r][grp] * wm;   // the state of row n-1: no decay to invert
+#pragma unroll
+          for (int i = 0; i < G; ++i) SX[i] = fma(-dwm, wX[i], SX[i]);
+          F = fma(-wm, zm, F);
+        }
+      } else
       if (r < cnt) {
         const int64_t n = n_lo + r;
         const double Fpn = FR ? 0.0 : (BACK ? F : Fp[BACK ? 0 : r]);
@@ -860,6 +964,10 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       for (int i = 0; i < G; ++i) carS[i] = SX[i];
       carF = F;
     }
+    if constexpr (SC) {   // row n_lo - 1 is the row above the next (earlier) segment's last step
+      if constexpr (APARK) { gtop = pown[0]; igtop = ipown[0]; }
+      else { gtop = vv[0][0][lane]; igtop = vv[0][3][lane]; }
+    }
     lds_order();
     C2_TCK(3);
     // flush the segment's per-series scalar outputs, transposed: lane j <-> row n_lo + j (by: row n_lo-1+j)
@@ -894,7 +1002,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   }
   // row 0 (reverse.hpp:83-84)
   if (st0) { bab[0] = ban; btb[0] = carry; }
-  if (st) { bVb[0] = bVn; bUb[0] = 0.0; bc[L.b * J + j] = bcj; }
+  if (st) { bVb[0] = SC ? bVn * gtop : bVn; bUb[0] = 0.0; bc[L.b * J + j] = bcj; }
 }
 
 }  // namespace c2
@@ -1609,22 +1717,25 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
   // instead of behind it
   const bool occ2 = back && J == 8 && occ2_enabled() && (int64_t)grid.x > simd_count();
   if (int e = launch_fwd<1>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wrec, DZst, s, gate, segg, occ2)) return e;
+  // the sweep in the scaled frame (k_loglik_rev<..., SC>: no decay factors in the step); C2_LOGLIK_SCALED=0: the plain form (A/B runs)
+  const bool sc = !(opt::has(opt::k_loglik_scaled) && opt::ival(opt::k_loglik_scaled) == 0);
+#define C2_REVB_ARGS grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, (const double *)Wrec, (const double2 *)DZst, \
+                     (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate, \
+                     (const unsigned long long *)segg
   if (back && occ2) {
-    hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,
-                       (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU,
-                       bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);
+    if (sc) hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2, true>), C2_REVB_ARGS);
+    else hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2>), C2_REVB_ARGS);
     if (int e = launch_ok()) return e;
   } else if (back) {
-#define C2_REVB(G, C)                                                                                                     \
-  do {                                                                                                                    \
-    if (J == G)                                                                                                           \
-      hipLaunchKernelGGL((k_loglik_rev<G, C, false, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \
-                         (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, \
-                         bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);                      \
-    else                                                                                                                  \
-      hipLaunchKernelGGL((k_loglik_rev<G, C, true, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U,  \
-                         (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, \
-                         bV, by, nullptr, nullptr, nullptr, gate, (const unsigned long long *)segg);                      \
+#define C2_REVB(G, C)                                                                                         \
+  do {                                                                                                        \
+    if (J == G) {                                                                                             \
+      if (sc) hipLaunchKernelGGL((k_loglik_rev<G, C, false, false, true, C2_REV_OCC, true>), C2_REVB_ARGS);   \
+      else hipLaunchKernelGGL((k_loglik_rev<G, C, false, false, true>), C2_REVB_ARGS);                        \
+    } else {                                                                                                  \
+      if (sc) hipLaunchKernelGGL((k_loglik_rev<G, C, true, false, true, C2_REV_OCC, true>), C2_REVB_ARGS);    \
+      else hipLaunchKernelGGL((k_loglik_rev<G, C, true, false, true>), C2_REVB_ARGS);                         \
+    }                                                                                                         \
   } while (0)
     switch (G_) {
       case 1: C2_REVB(1, C2_CKPT_C); break;
@@ -1635,6 +1746,7 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
 #undef C2_REVB
     if (int e = launch_ok()) return e;
   }
+#undef C2_REVB_ARGS
   const unsigned long long *segc = segg;   // (the replay sweep: every wavefront, or those the sweep above left)
 #define C2_REV(G, C)                                                                                              \
   do {                                                                                                            \

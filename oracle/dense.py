@@ -250,3 +250,28 @@ def kron_synthetic(B, N, M, J, seed0=1721):
         c[b], a[b], U[b], V[b] = celerite_matrices(co, t[b], np.zeros(N))
         cos.append(co)
     return t, c, a, U, V, alpha, diag, y, cos
+
+
+def coefficient_chain(cpu, ar, cr, ac, bc, cc, dc, x, diag, y):
+    """Log-likelihood and its nine gradients w.r.t. the celerite coefficients and (x, diag, y) for ONE series: the CPU
+    restatement's gradients w.r.t. (t, c, a, U, V, y) pushed through the reverse of the matrix recipe
+    (python/celerite2/driver.cpp:456-474) in numpy.  `cpu`: the oracle.cpu module.  Returns ll, (bar, bcr, bac, bbc, bcc,
+    bdc, bx, bdiag, by), flag."""
+    co = Coeffs(ar=ar, cr=cr, ac=ac, bc=bc, cc=cc, dc=dc)
+    c, a, U, V = celerite_matrices(co, x, diag)
+    ll, (bt, bcv, ba, bU, bV, by), flag = cpu.loglik_grad(x, c, a, U, V, y)
+    Jr = len(ar)
+    bar = ba.sum() + bU[:, :Jr].sum(0)
+    bcr = bcv[:Jr]
+    arg = dc[None, :] * x[:, None]
+    co_, s_ = np.cos(arg), np.sin(arg)
+    U0, U1 = U[:, Jr::2], U[:, Jr + 1::2]
+    bU0, bU1, bV0, bV1 = bU[:, Jr::2], bU[:, Jr + 1::2], bV[:, Jr::2], bV[:, Jr + 1::2]
+    bac = ba.sum() + (bU0 * co_ + bU1 * s_).sum(0)
+    bbc = (bU0 * s_ - bU1 * co_).sum(0)
+    bcc = bcv[Jr::2] + bcv[Jr + 1::2]
+    g = -bU0 * U1 + bU1 * U0 - bV0 * s_ + bV1 * co_
+    bdc = (g * x[:, None]).sum(0)
+    bx = bt + (g * dc[None, :]).sum(1)
+    return ll, (bar, bcr, bac, bbc, bcc, bdc, bx, ba.copy(), by), flag
+

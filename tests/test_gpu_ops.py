@@ -533,14 +533,17 @@ def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypa
         llo, go, flo = oracle.loglik_grad_batched(tg, c, a, U, V, y, nthreads=2)
         assert int(np.abs(flo).sum()) == 0
         args = dev(tg, c, a, U, V, y)
-        for back in ("1", "0"):
+        # (backward recursion in the scaled frame -- the default --, in the plain frame, and the replay alone)
+        for back, scaled in (("1", "1"), ("1", "0"), ("0", "1")):
             monkeypatch.setenv("C2_LOGLIK_BACK", back)
+            monkeypatch.setenv("C2_LOGLIK_SCALED", scaled)
             ll, grads, flag = ops.loglik_grad(*args)
             assert int(flag.abs().sum()) == 0
             close(ll, llo)
             for g, e in zip(grads, go):
                 close(g, e, floor=4e-12)
         monkeypatch.delenv("C2_LOGLIK_BACK")
+        monkeypatch.delenv("C2_LOGLIK_SCALED")
 
 
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])
@@ -744,11 +747,11 @@ def test_bench_scale_batch(ops, oracle):
         assert torch.equal(g[:nb].repeat((rep,) + (1,) * (g.dim() - 1)), g)
 
 
-@pytest.mark.parametrize("B", [65536, 32768, 16384])
+@pytest.mark.parametrize("B", [65536, 32768, 16384, 8192])
 def test_config2_full_batch_one_gpu(ops, oracle, B):
     """BASELINE configs[2] at the size the bench runs on ONE GPU: 65536 series x N=4096 x J=8, forward + gradient
-    (41 GB of inputs, 41 GB of gradients, the replay records) -- and at its 2- and 4-GPU shards, which the dispatch gives
-    to the two-lanes-per-series kernels.  8 distinct series tile the batch: every replica must equal its original bit
+    (41 GB of inputs, 41 GB of gradients, the replay records) -- and at its 2-, 4- and 8-GPU shards, which the dispatch gives
+    to the two-lanes-per-series kernels (32768) and to the eight-lane pair (16384: two wavefronts per SIMD; 8192: one).  8 distinct series tile the batch: every replica must equal its original bit
     for bit wherever it sits (even / odd pair of a wavefront, any wavefront), the distinct ones must match the oracle."""
     import torch
     N, J, nb = 4096, 8, 8
@@ -769,6 +772,29 @@ def test_config2_full_batch_one_gpu(ops, oracle, B):
     assert int(flag1.abs().sum()) == 0
     close(ll1[:nb], llo)
     assert bool((ll1.view(rep, nb) == ll1[:nb]).all())
+
+
+@pytest.mark.parametrize("B", [65536, 32768, 16384, 8192])
+def test_bench_generator_batch_sample_vs_oracle(ops, oracle, B):
+    """The batch bench.py TIMES -- synth.device_batch_fast: B DISTINCT series from the device generator, not replicas of
+    eight -- at configs[2]'s full size and at its shards: 32 series drawn at random (bench.take_sample, the `parity_sample`
+    leg of the bench line) against the CPU oracle, log-likelihood and all six gradients."""
+    import torch
+    import bench
+    from celerite2_amd import synth
+    N, J = 4096, 8
+    args = synth.device_batch_fast(0, B, N, J, torch.device("cuda:0"))
+    ll, grads, flag = ops.loglik_grad(*args)
+    torch.cuda.synchronize()
+    assert int(flag.abs().sum()) == 0
+    smp = bench.take_sample(args, ll, grads, 32, 1)
+    del args, grads
+    llo, go, flo = oracle.loglik_grad_batched(*smp["inputs"], nthreads=16)
+    assert int(np.abs(flo).sum()) == 0
+    close(smp["ll"], llo)
+    for g, e in zip(smp["grads"], go):
+        for b in range(len(llo)):   # (per series: the floor term scales with that series' largest entry)
+            close(g[b], e[b])
 
 
 def test_config3_full_length_dot_tril(ops, oracle):

@@ -351,6 +351,9 @@ def main():
                     help="if > 0: series PER GPU (weak scaling) as the line's value -- a variant, not the literal configs[2]")
     ap.add_argument("--no-weak-object", action="store_true",
                     help="N > 1: skip the extra `weak_scaling` measurement (65536 series per GPU) the strong-scaling line carries")
+    ap.add_argument("--weak-batch-per-gpu", type=int, default=65536,
+                    help="series per GPU of that `weak_scaling` measurement (65536: the one-GPU workload on every GPU; tests "
+                         "that put several ranks on one device pass less)")
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--J", type=int, default=8)
     ap.add_argument("--mode", choices=["grad", "fwd"], default="grad")
@@ -538,7 +541,7 @@ def main():
     if world > 1 and not weak and not args.no_weak_object and args.N == 4096:
         work = out = t = c = a = U = V = y = None
         torch.cuda.empty_cache()
-        mw = measure(65536 * world, 1)
+        mw = measure(args.weak_batch_per_gpu * world, 1)
         kw = mw["kernel_ms"]
         if rank == 0:
             bpg = algorithmic_bytes_per_gp(N, J, grad)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libcelerite2_amd.so")
-HIP_SOURCES = ["c2_dispatch.hip", "c2_ops.hip", "c2_fused.hip", "c2_loglik.hip", "c2_loglik4.hip", "c2_loglik_t.hip", "c2_loglik_k2.hip", "c2_loglik_t6.hip", "c2_loglik_t4.hip", "c2_loglik_t2.hip", "c2_timepar.hip", "c2_timepar_grad.hip", "c2_timepar_grad32.hip", "c2_timepar_grad16.hip", "c2_sweep.hip", "c2_sweep_rev.hip", "c2_sweep_small.hip", "c2_sweep_small_rev.hip", "c2_solve_cols.hip", "c2_sweep_cols.hip", "c2_scan.hip", "c2_general.hip", "c2_general_tile.hip", "c2_mfma.hip", "c2_wide.hip", "c2_kron.hip", "c2_terms.hip", "c2_host.hip"]
+HIP_SOURCES = ["c2_dispatch.hip", "c2_ops.hip", "c2_fused.hip", "c2_loglik.hip", "c2_loglik4.hip", "c2_loglik_q4.hip", "c2_loglik_t.hip", "c2_loglik_k2.hip", "c2_loglik_t6.hip", "c2_loglik_t4.hip", "c2_loglik_t2.hip", "c2_timepar.hip", "c2_timepar_grad.hip", "c2_timepar_grad32.hip", "c2_timepar_grad16.hip", "c2_sweep.hip", "c2_sweep_rev.hip", "c2_sweep_small.hip", "c2_sweep_small_rev.hip", "c2_solve_cols.hip", "c2_sweep_cols.hip", "c2_scan.hip", "c2_general.hip", "c2_general_tile.hip", "c2_mfma.hip", "c2_wide.hip", "c2_kron.hip", "c2_terms.hip", "c2_host.hip"]
 HIP_HEADERS = ["c2_common.hpp", "c2_dispatch.hpp", "c2_loglik_helpers.hpp", "c2_rscatter.hpp", os.path.join(INCLUDE, "celerite2_amd.h")]
 # sources that are #included by other sources (one compilation per width / chunk length): extra dependencies of those only
 HIP_INCLUDED = {"c2_loglik_t.hip": ["c2_loglik_t2.hip", "c2_loglik_t4.hip", "c2_loglik_t6.hip"],

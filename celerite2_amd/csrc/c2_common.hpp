@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace c2 {
 
@@ -71,23 +72,33 @@ __device__ __forceinline__ double gget(double x, int i) {
   return __shfl(x, i, G);
 }
 
-// Stream-ordered temporaries of the library (hipMallocAsync on the device's default pool).  By default that pool hands its
-// memory back to the driver at the next synchronisation and every call pays a fresh allocation (0.2 ms for the 17 MB of a
-// 64 x 4096 x 64 many-rhs solve that itself takes 0.4 ms); the first temporary on a device raises the pool's release
-// threshold so that up to 1 GiB of it stays cached between calls.
+// Stream-ordered temporaries of the library.  They come from a memory pool the LIBRARY owns (one per device, created on
+// first use, release threshold 1 GiB so that up to that much stays cached between calls: the default pool hands its memory
+// back to the driver at every synchronisation and each call would pay a fresh allocation -- 0.2 ms for the 17 MB of a
+// 64 x 4096 x 64 many-rhs solve that itself takes 0.4 ms).  The device's DEFAULT pool, which the process shares with
+// everybody else, is left as it is; if the pool cannot be created the temporaries fall back to it, uncached.  Thread-safe
+// (std::call_once per device); hipFreeAsync releases either kind.
 inline hipError_t temp_alloc(void **p, size_t bytes, hipStream_t s) {
-  static bool done[64] = {};
+  constexpr int kMaxDev = 64;
+  static std::once_flag once[kMaxDev];
+  static hipMemPool_t pools[kMaxDev] = {};
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !done[dev]) {
-    done[dev] = true;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-      uint64_t cur = 0, want = 1ull << 30;
-      if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) == hipSuccess && cur < want)
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &want);
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return hipMallocAsync(p, bytes, s);
+  std::call_once(once[dev], [dev] {
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = dev;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) == hipSuccess && pool) {
+      uint64_t keep = 1ull << 30;
+      (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+      pools[dev] = pool;
     }
     (void)hipGetLastError();
-  }
+  });
+  if (pools[dev]) return hipMallocFromPoolAsync(p, bytes, pools[dev], s);
   return hipMallocAsync(p, bytes, s);
 }
 

@@ -14,7 +14,7 @@
 #pragma once
 
 #define C2_OPTIONS(X)                                                                                                                 \
-  X(lanes, "C2_LANES", 0, 's', "lane mapping of the fused log-likelihood kernels: 8 (a group of lanes per series), 4 (two columns per lane, J = 8), 2 (two lanes per series, J = 8), 1 (one lane per series); unset: by batch size", "profiles/r02_lane_mappings.md") \
+  X(lanes, "C2_LANES", 0, 's', "lane mapping of the fused log-likelihood kernels: 8 (a group of lanes per series), 4 (four lanes per series, two columns per lane, J = 8), 2 (two lanes per series, J = 8), 1 (one lane per series); unset: by batch size", "profiles/r02_lane_mappings.md") \
   X(lanes1_min_batch_fwd, "C2_LANES1_MIN_BATCH_FWD", 24576, 't', "forward log-likelihood: one lane per series from this many series up (widths 8, 6, 4, 2)", "N = 4096, J = 8: 3.3 vs 4.1 ms at 24576 series, 6.7 vs 10.4 ms at 65536 (profiles/r02_lane_mappings.md)") \
   X(lanes1_min_batch_grad, "C2_LANES1_MIN_BATCH_GRAD", 24576, 't', "log-likelihood + gradient: one lane per series from this many series up (widths 8, 4, 2)", "15.7 vs 16.0 ms at 24576 series, 28.2 vs 41.8 ms at 65536 (profiles/r02_lane_mappings.md)") \
   X(lanes1_min_batch_grad_j6, "C2_LANES1_MIN_BATCH_GRAD_J6", 32768, 't', "the same at width 6 (rows of 48 bytes: no aligned 128-byte runs)", "18.5 vs 20.7 ms at 32768 series, 17.2 vs 15.8 ms at 24576") \
@@ -24,8 +24,11 @@
   X(loglik_back, "C2_LOGLIK_BACK", 1, 's', "log-likelihood + gradient on the group mappings (up to eight lanes per series): reverse sweep by the BACKWARD recursion from recorded W rows instead of replaying the forward steps; 0 keeps the replay (A/B runs)", "profiles/r04_back8.md") \
   X(loglik_back_occ2, "C2_LOGLIK_BACK_OCC2", 1, 's', "... for batches with more wavefronts than the chip has SIMDs (J = 8: 8192 < B <= 16384) as instances that fit two wavefronts per SIMD; 0: one per SIMD, the rest of the batch behind the first part (A/B runs)", "profiles/r04_back8.md") \
   X(loglik_scaled, "C2_LOGLIK_SCALED", 1, 's', "... in a scaled frame (states multiplied by exp(-c (t_anchor - t_n)): no decay factors in the step, three gathered vectors instead of five); 0: the plain backward recursion (A/B runs)", "profiles/r05_scaled_frame.md") \
+  X(loglik_lines, "C2_LOGLIK_LINES", 0, 's', "1: the eight-lane log-likelihood kernels (J = 8) request the rows of U, V (and store bU, bV) as aligned 128-byte lines through an LDS tile instead of one 64-byte row at a time; 2: in the forward pass only, 3: in the reverse sweep only (A/B runs; off by default)", "N = 4096: 8192 series 4.69 vs 4.72 ms, 1024 series 3.49 vs 3.20, 4096 series 3.72 vs 3.33 -- the LDS detour costs a lone wavefront what the address unit gives back (profiles/r05_lines.md)") \
   X(fwd_dpp_gathers, "C2_FWD_DPP_GATHERS", 0, 's', "1: forward kernels of the group mappings (up to eight lanes per series) gather the next step's decay and U vectors by DPP permutes instead of through LDS (A/B runs)", "slower: 1024 series x 4096 rows 3.76 -> 4.11 ms for the gradient pair (profiles/r04_back8.md)") \
   X(lanes4_min_batch, "C2_LANES4_MIN_BATCH", 16384, 't', "forward log-likelihood, J = 8: two columns per lane from this many series up", "14-15 % faster from 16384 series, equal at 8192 (profiles/r01_lanes4.md)") \
+  X(lanes4_min_batch_grad, "C2_LANES4_MIN_BATCH_GRAD", 9216, 't', "log-likelihood + gradient, J = 8: four lanes per series (two columns per lane, scaled frame; c2_loglik_q4.hip) from this many series up ...", "N = 4096: 4.99 vs 4.52 ms at 8192 series (8 lanes: one wavefront per SIMD there), 6.10 vs 6.43 at 9216, 6.21 vs 6.60 at 10240, 6.94 vs 7.36 at 12288 (profiles/r05_four_lanes.md)") \
+  X(lanes4_max_batch_grad, "C2_LANES4_MAX_BATCH_GRAD", 13312, 't', "... up to this many", "8.92 vs 8.19 ms at 14336 series, 9.98 vs 9.78 at 16384: with a wavefront on every SIMD its sixteen-series row requests queue at the address unit (profiles/r05_four_lanes.md)") \
   X(timepar, "C2_TIMEPAR", 0, 's', "forward log-likelihood / factor (widths 4, 2) and the solves parallel along TIME: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_check.py, profiles/r02_timepar.md") \
   X(timepar_min_rows, "C2_TIMEPAR_MIN_ROWS", 1536, 't', "shortest series the time-parallel forward pass takes when the batch is not a handful (B * J > 512)", "J = 4, 1024 x 4096: 0.26 vs 0.87 ms; a handful of series from 384 / 704 / 1024 rows at widths 2 / 4 / 8 (tools/timepar_small_n.py)") \
   X(timepar_max_batch_x_width, "C2_TIMEPAR_MAX_BATCH_X_WIDTH", 8192, 't', "largest B * J the time-parallel forward pass takes", "linear in the batch beyond one wavefront per SIMD: 0.98 ms at 4096 series of J = 4 where row by row takes 0.87") \

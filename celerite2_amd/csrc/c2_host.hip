@@ -3,6 +3,14 @@
 // kernels as the batched device API.  These are what the `driver` / `backprop`
 // pybind11 modules bind (reference python/celerite2/driver.cpp, backprop.cpp).
 //
+// Staging (round 5): one grow-only DEVICE ARENA, one PINNED bounce buffer and one
+// stream per calling thread.  A call packs every argument into the bounce buffer,
+// uploads them with ONE host-to-device copy, runs its kernels on the thread's stream,
+// downloads the outputs with ONE device-to-host copy and waits on that stream only
+// (no hipMalloc / hipFree / device-wide synchronisation per argument or per call:
+// tools/host_call_cost.py).  Threads do not share staging state, so the entry points
+// are re-entrant like the reference's.
+//
 // Aliasing is preserved end to end: two host arguments with the same address
 // share ONE device buffer, so d == a, W == V, Z == Y exercise the kernels'
 // in-place behaviour exactly as the reference's in-place calls do.  Every host
@@ -12,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "../../include/celerite2_amd.h"
@@ -20,49 +29,116 @@ extern "C" void c2_internal_set_error(const char *msg);
 
 namespace {
 
+// Per-thread staging resources, grown on demand and kept for the life of the thread.
+struct Arena {
+  char *dev = nullptr, *pin = nullptr;
+  size_t dev_cap = 0, pin_cap = 0;
+  hipStream_t stream = nullptr;
+  int device = -1;
+  ~Arena() { release(); }
+  void release() {
+    if (dev) (void)hipFree(dev);
+    if (pin) (void)hipHostFree(pin);
+    if (stream) (void)hipStreamDestroy(stream);
+    dev = pin = nullptr; dev_cap = pin_cap = 0; stream = nullptr;
+  }
+  hipError_t reserve(size_t bytes, bool want_pin) {
+    int cur = 0;
+    if (hipError_t e = hipGetDevice(&cur)) return e;
+    if (cur != device) { release(); device = cur; }   // (the caller switched devices: start over on this one)
+    if (!stream)
+      if (hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) return e;
+    if (bytes > dev_cap) {
+      if (dev) (void)hipFree(dev);
+      dev = nullptr; dev_cap = 0;
+      const size_t cap = bytes + bytes / 2 + (1u << 16);
+      if (hipError_t e = hipMalloc((void **)&dev, cap)) return e;
+      dev_cap = cap;
+    }
+    if (want_pin && bytes > pin_cap) {
+      if (pin) (void)hipHostFree(pin);
+      pin = nullptr; pin_cap = 0;
+      const size_t cap = bytes + bytes / 2 + (1u << 16);
+      if (hipError_t e = hipHostMalloc((void **)&pin, cap, hipHostMallocDefault)) return e;
+      pin_cap = cap;
+    }
+    return hipSuccess;
+  }
+};
+thread_local Arena g_arena;
+
+constexpr size_t kAlign = 256;              // every staged array starts on a 256-byte boundary (the kernels' 16-byte checks)
+constexpr size_t kBounceMax = 64u << 20;    // beyond this, arguments go up one by one straight from the caller's memory
+
 struct Staging {
   struct Entry {
     const void *host;
-    void *dev;
-    size_t bytes;
+    size_t bytes, off;
     bool out;
   };
   std::vector<Entry> entries;
+  size_t in_bytes = 0, out_bytes = 0;   // inputs are packed in front, outputs (incl. in/out arrays) behind them
   int err = C2_OK;
+  bool committed = false;
 
-  ~Staging() {
-    for (auto &e : entries) (void)hipFree(e.dev);
-  }
   bool fail(hipError_t e) {
     if (e == hipSuccess) return false;
     c2_internal_set_error(hipGetErrorString(e));
     err = C2_ERR_HIP;
     return true;
   }
-  // Register a host array; returns the device pointer (shared when the host pointer repeats).
-  double *map(const double *host, int64_t count, bool is_output) {
-    if (err || host == nullptr) return nullptr;
-    const size_t bytes = sizeof(double) * (size_t)count;
-    for (auto &e : entries)
-      if (e.host == host) {
-        e.out = e.out || is_output;
-        if (bytes > e.bytes) err = C2_ERR_INVALID;  // overlapping-but-different views are not supported
-        return (double *)e.dev;
+  // Register a host array; returns its handle (shared when the host pointer repeats).  -1: absent.
+  int map(const void *host, size_t bytes, bool is_output) {
+    if (host == nullptr) return -1;
+    for (size_t i = 0; i < entries.size(); ++i)
+      if (entries[i].host == host) {
+        entries[i].out = entries[i].out || is_output;
+        if (bytes > entries[i].bytes) err = C2_ERR_INVALID;  // overlapping-but-different views are not supported
+        return (int)i;
       }
-    void *dev = nullptr;
-    if (fail(hipMalloc(&dev, bytes ? bytes : 8))) return nullptr;
-    entries.push_back({host, dev, bytes, is_output});
-    if (fail(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice))) return nullptr;
-    return (double *)dev;
+    entries.push_back({host, bytes, 0, is_output});
+    return (int)entries.size() - 1;
   }
-  const double *in(const double *h, int64_t n) { return map(h, n, false); }
-  double *out(double *h, int64_t n) { return map(h, n, true); }
+  int in(const double *h, int64_t n) { return map(h, sizeof(double) * (size_t)n, false); }
+  int out(double *h, int64_t n) { return map(h, sizeof(double) * (size_t)n, true); }
+  static size_t up(size_t b) { return (b + kAlign - 1) / kAlign * kAlign; }
+  // Sizes are known: lay the arrays out, grow the arena, ONE upload.
+  bool commit() {
+    committed = true;
+    if (err) return false;
+    for (auto &e : entries) if (!e.out) { e.off = in_bytes; in_bytes += up(e.bytes ? e.bytes : 8); }
+    for (auto &e : entries) if (e.out) { e.off = in_bytes + out_bytes; out_bytes += up(e.bytes ? e.bytes : 8); }
+    const size_t total = in_bytes + out_bytes;
+    const bool bounce = total <= kBounceMax;
+    if (fail(g_arena.reserve(total, bounce))) return false;
+    if (bounce) {
+      for (auto &e : entries) std::memcpy(g_arena.pin + e.off, e.host, e.bytes);
+      if (fail(hipMemcpyAsync(g_arena.dev, g_arena.pin, total, hipMemcpyHostToDevice, g_arena.stream))) return false;
+    } else {
+      for (auto &e : entries)
+        if (fail(hipMemcpyAsync(g_arena.dev + e.off, e.host, e.bytes, hipMemcpyHostToDevice, g_arena.stream))) return false;
+    }
+    return true;
+  }
+  double *p(int h) const { return h < 0 ? nullptr : reinterpret_cast<double *>(g_arena.dev + entries[(size_t)h].off); }
+  c2_stream_t stream() const { return (c2_stream_t)g_arena.stream; }
+  // ONE download of the output block, a wait on this thread's stream, results back into the caller's arrays.
   int finish(int rc) {
     if (err) return err;
-    if (rc != C2_OK) return rc;
-    if (fail(hipDeviceSynchronize())) return err;
-    for (auto &e : entries)
-      if (e.out && fail(hipMemcpy(const_cast<void *>(e.host), e.dev, e.bytes, hipMemcpyDeviceToHost))) return err;
+    if (rc != C2_OK) { (void)hipStreamSynchronize(g_arena.stream); return rc; }
+    const bool bounce = in_bytes + out_bytes <= kBounceMax;
+    if (bounce) {
+      if (out_bytes && fail(hipMemcpyAsync(g_arena.pin + in_bytes, g_arena.dev + in_bytes, out_bytes, hipMemcpyDeviceToHost, g_arena.stream)))
+        return err;
+      if (fail(hipStreamSynchronize(g_arena.stream))) return err;
+      for (auto &e : entries)
+        if (e.out) std::memcpy(const_cast<void *>(e.host), g_arena.pin + e.off, e.bytes);
+    } else {
+      for (auto &e : entries)
+        if (e.out && fail(hipMemcpyAsync(const_cast<void *>(e.host), g_arena.dev + e.off, e.bytes, hipMemcpyDeviceToHost, g_arena.stream)))
+          return err;
+      if (fail(hipStreamSynchronize(g_arena.stream))) return err;
+    }
     return C2_OK;
   }
 };
@@ -78,16 +154,15 @@ int c2h_factor(int64_t N, int64_t J, const double *t, const double *c, const dou
   if (bad(N, J) || !flag) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   Staging st;
-  const double *t_ = st.in(t, N), *c_ = st.in(c, J), *a_ = st.in(a, N), *U_ = st.in(U, N * J), *V_ = st.in(V, N * J);
-  double *d_ = st.out(d, N), *W_ = st.out(W, N * J), *S_ = S ? st.out(S, N * J * J) : nullptr;
-  int32_t *flag_ = nullptr;
-  if (st.fail(hipMalloc((void **)&flag_, sizeof(int32_t)))) return st.err;
-  int rc = st.err ? st.err : c2_factor(1, N, J, t_, 0, c_, 0, a_, U_, V_, d_, W_, S_, flag_, nullptr);
+  const int t_ = st.in(t, N), c_ = st.in(c, J), a_ = st.in(a, N), U_ = st.in(U, N * J), V_ = st.in(V, N * J);
+  const int d_ = st.out(d, N), W_ = st.out(W, N * J), S_ = S ? st.out(S, N * J * J) : -1;
+  int32_t f[2] = {0, 0};   // the pivot flag travels with the outputs
+  const int f_ = st.map(f, sizeof(f), true);
+  int rc = !st.commit() ? st.err
+                        : c2_factor(1, N, J, st.p(t_), 0, st.p(c_), 0, st.p(a_), st.p(U_), st.p(V_), st.p(d_), st.p(W_),
+                                    st.p(S_), reinterpret_cast<int32_t *>(st.p(f_)), st.stream());
   rc = st.finish(rc);
-  int32_t f = 0;
-  if (rc == C2_OK && hipMemcpy(&f, flag_, sizeof(f), hipMemcpyDeviceToHost) != hipSuccess) rc = C2_ERR_HIP;
-  (void)hipFree(flag_);
-  *flag = f;
+  *flag = f[0];
   return rc;
 }
 
@@ -97,13 +172,12 @@ int c2h_factor(int64_t N, int64_t J, const double *t, const double *c, const dou
     if (bad(N, J) || nrhs < 1) return C2_ERR_INVALID;                                                               \
     if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;                                                                \
     Staging st;                                                                                                     \
-    const double *t_ = st.in(t, N), *c_ = st.in(c, J), *U_ = st.in(U, N * J), *W_ = st.in(W, N * J),               \
-                 *Y_ = st.in(Y, N * nrhs);                                                                          \
-    double *Z_ = st.out(Z, N * nrhs), *F_ = F ? st.out(F, N * J * nrhs) : nullptr;                                 \
-    return st.finish(st.err ? st.err : CALL);                                                                       \
+    const int t_ = st.in(t, N), c_ = st.in(c, J), U_ = st.in(U, N * J), W_ = st.in(W, N * J), Y_ = st.in(Y, N * nrhs); \
+    const int Z_ = st.out(Z, N * nrhs), F_ = F ? st.out(F, N * J * nrhs) : -1;                                     \
+    return st.finish(!st.commit() ? st.err : CALL);                                                                 \
   }
-C2H_SWEEP(solve_lower, c2_solve_lower(1, N, J, nrhs, t_, 0, c_, 0, U_, W_, Y_, Z_, F_, nullptr))
-C2H_SWEEP(solve_upper, c2_solve_upper(1, N, J, nrhs, t_, 0, c_, 0, U_, W_, Y_, Z_, F_, nullptr))
+C2H_SWEEP(solve_lower, c2_solve_lower(1, N, J, nrhs, st.p(t_), 0, st.p(c_), 0, st.p(U_), st.p(W_), st.p(Y_), st.p(Z_), st.p(F_), st.stream()))
+C2H_SWEEP(solve_upper, c2_solve_upper(1, N, J, nrhs, st.p(t_), 0, st.p(c_), 0, st.p(U_), st.p(W_), st.p(Y_), st.p(Z_), st.p(F_), st.stream()))
 #undef C2H_SWEEP
 
 #define C2H_MATMUL(NAME)                                                                                            \
@@ -112,10 +186,11 @@ C2H_SWEEP(solve_upper, c2_solve_upper(1, N, J, nrhs, t_, 0, c_, 0, U_, W_, Y_, Z
     if (bad(N, J) || nrhs < 1) return C2_ERR_INVALID;                                                               \
     if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;                                                                \
     Staging st;                                                                                                     \
-    const double *t_ = st.in(t, N), *c_ = st.in(c, J), *U_ = st.in(U, N * J), *V_ = st.in(V, N * J),               \
-                 *Y_ = st.in(Y, N * nrhs);                                                                          \
-    double *Z_ = st.out(Z, N * nrhs), *F_ = F ? st.out(F, N * J * nrhs) : nullptr;                                 \
-    return st.finish(st.err ? st.err : c2_##NAME(1, N, J, nrhs, t_, 0, c_, 0, U_, V_, Y_, Z_, F_, zero_z, nullptr)); \
+    const int t_ = st.in(t, N), c_ = st.in(c, J), U_ = st.in(U, N * J), V_ = st.in(V, N * J), Y_ = st.in(Y, N * nrhs); \
+    const int Z_ = st.out(Z, N * nrhs), F_ = F ? st.out(F, N * J * nrhs) : -1;                                     \
+    return st.finish(!st.commit() ? st.err                                                                          \
+                                  : c2_##NAME(1, N, J, nrhs, st.p(t_), 0, st.p(c_), 0, st.p(U_), st.p(V_), st.p(Y_), \
+                                              st.p(Z_), st.p(F_), zero_z, st.stream()));                            \
   }
 C2H_MATMUL(matmul_lower)
 C2H_MATMUL(matmul_upper)
@@ -128,11 +203,12 @@ C2H_MATMUL(matmul_upper)
     if (bad(N, J) || M < 1 || nrhs < 1) return C2_ERR_INVALID;                                                      \
     if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;                                                                \
     Staging st;                                                                                                     \
-    const double *t1_ = st.in(t1, N), *t2_ = st.in(t2, M), *c_ = st.in(c, J), *U_ = st.in(U, N * J),               \
-                 *V_ = st.in(V, M * J), *Y_ = st.in(Y, M * nrhs);                                                   \
-    double *Z_ = st.out(Z, N * nrhs), *F_ = F ? st.out(F, M * J * nrhs) : nullptr;                                 \
-    return st.finish(st.err ? st.err                                                                                \
-                            : c2_##NAME(1, N, M, J, nrhs, t1_, 0, t2_, 0, c_, 0, U_, V_, Y_, Z_, F_, zero_z, nullptr)); \
+    const int t1_ = st.in(t1, N), t2_ = st.in(t2, M), c_ = st.in(c, J), U_ = st.in(U, N * J), V_ = st.in(V, M * J), \
+              Y_ = st.in(Y, M * nrhs);                                                                              \
+    const int Z_ = st.out(Z, N * nrhs), F_ = F ? st.out(F, M * J * nrhs) : -1;                                     \
+    return st.finish(!st.commit() ? st.err                                                                          \
+                                  : c2_##NAME(1, N, M, J, nrhs, st.p(t1_), 0, st.p(t2_), 0, st.p(c_), 0, st.p(U_),  \
+                                              st.p(V_), st.p(Y_), st.p(Z_), st.p(F_), zero_z, st.stream()));        \
   }
 C2H_GENERAL(general_matmul_lower)
 C2H_GENERAL(general_matmul_upper)
@@ -144,14 +220,13 @@ int c2h_factor_rev(int64_t N, int64_t J, const double *t, const double *c, const
   if (bad(N, J)) return C2_ERR_INVALID;
   if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;
   Staging st;
-  const double *t_ = st.in(t, N), *c_ = st.in(c, J), *a_ = st.in(a, N), *U_ = st.in(U, N * J), *V_ = st.in(V, N * J),
-               *d_ = st.in(d, N), *W_ = st.in(W, N * J), *S_ = st.in(S, N * J * J), *bd_ = st.in(bd, N),
-               *bW_ = st.in(bW, N * J);
-  double *bt_ = st.out(bt, N), *bc_ = st.out(bc, J), *ba_ = st.out(ba, N), *bU_ = st.out(bU, N * J),
-         *bV_ = st.out(bV, N * J);
-  return st.finish(st.err ? st.err
-                          : c2_factor_rev(1, N, J, t_, 0, c_, 0, a_, U_, V_, d_, W_, S_, bd_, bW_, bt_, bc_, ba_, bU_,
-                                          bV_, nullptr));
+  const int t_ = st.in(t, N), c_ = st.in(c, J), a_ = st.in(a, N), U_ = st.in(U, N * J), V_ = st.in(V, N * J),
+            d_ = st.in(d, N), W_ = st.in(W, N * J), S_ = st.in(S, N * J * J), bd_ = st.in(bd, N), bW_ = st.in(bW, N * J);
+  const int bt_ = st.out(bt, N), bc_ = st.out(bc, J), ba_ = st.out(ba, N), bU_ = st.out(bU, N * J), bV_ = st.out(bV, N * J);
+  return st.finish(!st.commit() ? st.err
+                                : c2_factor_rev(1, N, J, st.p(t_), 0, st.p(c_), 0, st.p(a_), st.p(U_), st.p(V_), st.p(d_),
+                                                st.p(W_), st.p(S_), st.p(bd_), st.p(bW_), st.p(bt_), st.p(bc_), st.p(ba_),
+                                                st.p(bU_), st.p(bV_), st.stream()));
 }
 
 #define C2H_SWEEP_REV(NAME)                                                                                         \
@@ -161,14 +236,14 @@ int c2h_factor_rev(int64_t N, int64_t J, const double *t, const double *c, const
     if (bad(N, J) || nrhs < 1) return C2_ERR_INVALID;                                                               \
     if (J > C2_MAX_WIDTH) return C2_ERR_UNSUPPORTED;                                                                \
     Staging st;                                                                                                     \
-    const double *t_ = st.in(t, N), *c_ = st.in(c, J), *U_ = st.in(U, N * J), *W_ = st.in(W, N * J),               \
-                 *Y_ = st.in(Y, N * nrhs), *Z_ = st.in(Z, N * nrhs), *F_ = st.in(F, N * J * nrhs),                 \
-                 *bZ_ = st.in(bZ, N * nrhs);                                                                        \
-    double *bt_ = st.out(bt, N), *bc_ = st.out(bc, J), *bU_ = st.out(bU, N * J), *bW_ = st.out(bW, N * J),         \
-           *bY_ = st.out(bY, N * nrhs);                                                                             \
-    return st.finish(st.err ? st.err                                                                                \
-                            : c2_##NAME(1, N, J, nrhs, t_, 0, c_, 0, U_, W_, Y_, Z_, F_, bZ_, bt_, bc_, bU_, bW_,   \
-                                        bY_, nullptr));                                                             \
+    const int t_ = st.in(t, N), c_ = st.in(c, J), U_ = st.in(U, N * J), W_ = st.in(W, N * J), Y_ = st.in(Y, N * nrhs), \
+              Z_ = st.in(Z, N * nrhs), F_ = st.in(F, N * J * nrhs), bZ_ = st.in(bZ, N * nrhs);                      \
+    const int bt_ = st.out(bt, N), bc_ = st.out(bc, J), bU_ = st.out(bU, N * J), bW_ = st.out(bW, N * J),          \
+              bY_ = st.out(bY, N * nrhs);                                                                           \
+    return st.finish(!st.commit() ? st.err                                                                          \
+                                  : c2_##NAME(1, N, J, nrhs, st.p(t_), 0, st.p(c_), 0, st.p(U_), st.p(W_), st.p(Y_), \
+                                              st.p(Z_), st.p(F_), st.p(bZ_), st.p(bt_), st.p(bc_), st.p(bU_),       \
+                                              st.p(bW_), st.p(bY_), st.stream()));                                  \
   }
 C2H_SWEEP_REV(solve_lower_rev)
 C2H_SWEEP_REV(solve_upper_rev)
@@ -182,13 +257,13 @@ int c2h_get_celerite_matrices(int64_t N, int64_t Jr, int64_t Jc, const double *a
   if (N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
   const int64_t J = Jr + 2 * Jc;
   Staging st;
-  const double *ar_ = Jr ? st.in(ar, Jr) : nullptr, *ac_ = Jc ? st.in(ac, Jc) : nullptr,
-               *bc_ = Jc ? st.in(bc, Jc) : nullptr, *dc_ = Jc ? st.in(dc, Jc) : nullptr, *x_ = st.in(x, N),
-               *diag_ = st.in(diag, N);
-  double *a_ = st.out(a, N), *U_ = st.out(U, N * J), *V_ = st.out(V, N * J);
-  return st.finish(st.err ? st.err
-                          : c2_get_celerite_matrices(1, N, Jr, Jc, ar_, ac_, bc_, dc_, 0, x_, 0, diag_, a_, U_, V_,
-                                                     nullptr));
+  const int ar_ = Jr ? st.in(ar, Jr) : -1, ac_ = Jc ? st.in(ac, Jc) : -1, bc_ = Jc ? st.in(bc, Jc) : -1,
+            dc_ = Jc ? st.in(dc, Jc) : -1, x_ = st.in(x, N), diag_ = st.in(diag, N);
+  const int a_ = st.out(a, N), U_ = st.out(U, N * J), V_ = st.out(V, N * J);
+  return st.finish(!st.commit() ? st.err
+                                : c2_get_celerite_matrices(1, N, Jr, Jc, st.p(ar_), st.p(ac_), st.p(bc_), st.p(dc_), 0,
+                                                           st.p(x_), 0, st.p(diag_), st.p(a_), st.p(U_), st.p(V_),
+                                                           st.stream()));
 }
 
 }  // extern "C"

@@ -153,7 +153,7 @@ __device__ __forceinline__ void ckpt_load(const double *rec, int lane, const int
 constexpr int kAnchor = 4;
 // ... where the decays it has to invert in between allow.  One workgroup per wavefront w of the sweep (spw series):
 // words[2 w] = max over its series of c_max x (longest time between two anchors kAnchor segments apart), words[2 w + 1] the
-// same for single segments.  NaN and negative spans -- unsorted times -- are stored as NaN, which no guard accepts.
+// same for single segments.  NaN and negative spans -- unsorted times -- are stored as +inf, which no guard accepts.
 __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int J, int C, int spw,
                                                       const double *__restrict__ t, int64_t t_bs,
                                                       const double *__restrict__ c, int64_t c_bs,
@@ -200,16 +200,25 @@ __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int 
   __syncthreads();
   if (tid == 0) {
     for (int k = 1; k < (int)(blockDim.x / kWave); ++k) { red[0][0] = fmax(red[0][0], red[0][k]); red[1][0] = fmax(red[1][0], red[1][k]); }
-    const double nan = __builtin_nan("");
-    words[2 * blockIdx.x] = (unsigned long long)__double_as_longlong(anybad ? nan : red[0][0]);
-    words[2 * blockIdx.x + 1] = (unsigned long long)__double_as_longlong(anybad ? nan : red[1][0]);
+    // (+inf, not NaN: every consumer asks `word > kBackwardGuard`, which a NaN would answer with "stable")
+    const double inf = __builtin_inf();
+    words[2 * blockIdx.x] = (unsigned long long)__double_as_longlong(anybad ? inf : red[0][0]);
+    words[2 * blockIdx.x + 1] = (unsigned long long)__double_as_longlong(anybad ? inf : red[1][0]);
   }
 }
 
 // DG: the next step's p and U gathered by DPP permutes instead of through LDS.  The LDS form costs the VALU nothing but
 // makes the wavefront wait for two LDS round trips per step -- which one would expect to hurt when the grid gives every
 // wavefront a SIMD of its own; measured it does not: the DPP form is 2 - 9 % slower there too (launch_fwd).
-template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC, bool DG = false>
+// LN (G = R = 8, no padding, N even, 16-byte aligned U and V; C2_LOGLIK_LINES=1, OFF by default): the rows of U and V arrive
+// as whole aligned 128-byte LINES.  A width-8 row is 64 bytes, so the eight series of a wavefront make a row request eight
+// half-lines -- and once every SIMD of a CU has its wavefront these kernels queue at the CU's address unit, which prices a
+// request by the runs it touches, not by its bytes (profiles/r05_lines.md: without the U / V requests the forward pass at 8192
+// series runs at its clock-scaled floor).  MEASURED: the LDS instructions of the detour cost a lone wavefront what the
+// address unit gives back -- 8192 series 4.69 against 4.72 ms, 1024 - 4096 series 9 - 12 % SLOWER -- hence off.  Rows (2P, 2P+1) of a series share a line: one 16-byte piece per lane fetches the pair for all eight
+// series (a ring of four pairs in registers, eight rows ahead), a per-wave LDS tile turns pieces into the lanes' own
+// elements one pair ahead of their use.
+template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC, bool DG = false, bool LN = false>
 __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
@@ -311,22 +320,53 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   vload(1 + 2 * R);
 
   // ---- row streams (U_n, V_n): register ring, one row per step, R rows ahead ------------------------------
-  double ru[R], rv[R];
+  double ru[LN ? 1 : R], rv[LN ? 1 : R];
   const double *up = Ub + J, *vp = Vb + J;  // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {  // row n = n0 + ahead
-    int64_t o = ahead;
-    if (clamp && n >= N) o -= n - (N - 1);
-    ru[r] = act ? up[o * J] : 0.0; rv[r] = act ? vp[o * J] : 0.0;
+    if constexpr (!LN) {
+      int64_t o = ahead;
+      if (clamp && n >= N) o -= n - (N - 1);
+      ru[r] = act ? up[o * J] : 0.0; rv[r] = act ? vp[o * J] : 0.0;
+    }
   };
+  // LN: pair P = rows (2P, 2P+1) of the lane's series, piece j of its 128 bytes; slot P % 4 of the ring
+  static_assert(!LN || (G == 8 && R == 8 && !PAD), "line staging: full groups of eight lanes, blocks of eight rows");
+  __shared__ __attribute__((aligned(16))) double2 ltile[LN ? 2 : 1][LN ? kWave : 1];   // [U | V][series][piece]
+  const double2 *Ul = reinterpret_cast<const double2 *>(U + L.b0 * N * J + (int64_t)L.sl * N * J) + j;
+  const double2 *Vl = reinterpret_cast<const double2 *>(V + L.b0 * N * J + (int64_t)L.sl * N * J) + j;
+  const int64_t plast = N / 2 - 1;
+  double qux[LN ? 4 : 1], quy[LN ? 4 : 1], qvx[LN ? 4 : 1], qvy[LN ? 4 : 1];   // (plain doubles: arrays of double2 end up in scratch)
+  double cu[2] = {0.0, 0.0}, cv[2] = {0.0, 0.0};   // own elements of the current pair's two rows
+  double nu[2] = {0.0, 0.0}, nv[2] = {0.0, 0.0};   // ... of the next pair
+  const double *ltu = reinterpret_cast<const double *>(ltile[0]) + grp * 16 + j;
+  const double *ltv = reinterpret_cast<const double *>(ltile[LN ? 1 : 0]) + grp * 16 + j;
+  auto pair_load = [&](int slot, int64_t P) {
+    const int64_t Pc = P < plast ? P : plast;
+    const double2 a2 = Ul[Pc * 8], b2 = Vl[Pc * 8];
+    qux[slot] = a2.x; quy[slot] = a2.y; qvx[slot] = b2.x; qvy[slot] = b2.y;
+  };
+  auto pair_stage = [&](int slot) {
+    ltile[0][lane] = make_double2(qux[slot], quy[slot]);
+    ltile[LN ? 1 : 0][lane] = make_double2(qvx[slot], qvy[slot]);
+  };
+  if constexpr (LN) {
+    cu[0] = Ub[0]; cu[1] = Ub[J]; cv[0] = Vb[0]; cv[1] = Vb[J];   // pair 0 (row 0 is the prologue's, row 1 the first step's)
+    pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);
+    pair_stage(1);          // pair 1: the first step (the second row of pair 0) already prepares its first row
+    pair_load(1, 5);
+    lds_order();
+    nu[0] = ltu[0]; nu[1] = ltu[8]; nv[0] = ltv[0]; nv[1] = ltv[8];
+  } else {
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+    for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+  }
 
   const bool sparse = wrec && !(__longlong_as_double((long long)segguard[2 * blockIdx.x]) > kBackwardGuard);   // (uniform)
   // prepare step 1
   lds_order();
   double tcur = tb[0];
   double tnext = sin_[0][0][grp][0];
-  double pc = exp_decay(cj * (tcur - tnext)), uc = ru[0];
+  double pc = exp_decay(cj * (tcur - tnext)), uc = LN ? cu[1] : ru[0];
   double pXc[G], uXc[G];
   if constexpr (DG) {
     xgather_dpp<G>(pc, xs[0], lane, pXc);
@@ -350,11 +390,25 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
           if (!sparse || (m % kAnchor == 0 && m > 0))   // (uniform; the backward recursion never reads the state after row 0)
             ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
         }
-        const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r], v = rv[r];
+        const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
         const int rn = (r + 1) % R;
-        const double pn1 = exp_decay(cj * (tn - tn1)), un1 = ru[rn];
+        double v, un1;
+        if constexpr (LN) {
+          // blocks start at odd rows (n0 = 1 + 8 b): r odd <=> n even <=> the first row of pair P = n / 2
+          if (r % 2 == 1) {
+            v = cv[0]; un1 = cu[1];
+            lds_order();
+            pair_stage(((r + 1) / 2 + 1) % 4);                      // pair P + 1 -> tile (read back at the end of this step)
+            pair_load(((r + 1) / 2 + 1) % 4, n / 2 + 5);            // its slot: pair P + 5, eight rows ahead
+          } else {
+            v = cv[1]; un1 = nu[0];                                 // (pair P + 1, read back during the step before)
+          }
+        } else {
+          v = rv[LN ? 0 : r]; un1 = ru[LN ? 0 : rn];
+        }
+        const double pn1 = exp_decay(cj * (tn - tn1));
         double pXn[G], uXn[G];
         if constexpr (DG) {
           xgather_dpp<G>(pn1, xs[0], lane, pXn);
@@ -387,6 +441,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
         }
         tnext = tn1;
         pc = pn1; uc = un1;
+        if (LN && r % 2 == 0) { cu[0] = nu[0]; cu[1] = nu[1]; cv[0] = nv[0]; cv[1] = nv[1]; }
+        if (LN && r % 2 == 1) {   // own elements of pair P + 1: used from the next step on, so their latency is hidden
+          lds_order();
+          nu[0] = ltu[0]; nu[1] = ltu[8]; nv[0] = ltv[0]; nv[1] = ltv[8];
+        }
 #pragma unroll
         for (int k = 0; k < G; ++k) { pXc[k] = pXn[k]; uXc[k] = uXn[k]; }
       }
@@ -479,7 +538,11 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
 // bV-_{n-1} = (z/d) bF- + w~ M^ needs no factor at all.  Per step the gathers of p and 1/p and the 32 multiplications by
 // p_i p_j, 1/(p_i p_j) drop out (five gathered vectors -> three: u- = u / g_n, x- = bV- + 2 ba u-, w~); what is left of the
 // frame is one factor on u, w and on the rows bU_n, bV_n on their way out, and a change of frame at every anchor.
-template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC, bool SC = false>
+// LN (SC, G = C = 8, no padding, N even, 16-byte aligned U, bU, bV): rows of U, bU, bV move as whole aligned 128-byte lines --
+// rows (2P, 2P+1) of a series share one -- through per-wave LDS tiles, as in k_loglik_fwd<..., LN>: four line requests per
+// segment for U (rows 8k .. 8k+7; row 8k is handed down to the segment below), one store per completed pair for bU and bV
+// (the lane's element goes into a two-row tile; a pair is complete at its even row and leaves during the step after).
+template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC, bool SC = false, bool LN = false>
 __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
@@ -496,6 +559,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
                                                          const unsigned long long *__restrict__ segguard = nullptr) {
   static_assert(!(BACK && FR), "factor_rev replays from the caller's workspace");
   static_assert(!SC || BACK, "the scaled frame belongs to the backward-recursion sweep");
+  static_assert(!LN || (SC && G == 8 && C == 8 && !PAD), "line staging: the scaled-frame sweep on full groups of eight lanes");
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;  // see k_loglik_fwd
   int astep = kAnchor;   // (BACK, uniform) segments between two anchors of the backward recursion
   if (segguard) {   // this wavefront by the backward recursion, or (the launch behind it) by the replay
@@ -572,6 +636,15 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   double vt[NV];
   double2 vdz[NV];
   double iu[C], iw[C], ibw[FR ? C : 1];
+  // LN: raw 16-byte pieces of the segment's four U lines; tiles [series][row of the pair][element]
+  double qux[LN ? 4 : 1], quy[LN ? 4 : 1], ucar = 0.0;
+  __shared__ __attribute__((aligned(16))) double2 utile[LN ? 4 : 1][LN ? kWave : 1];
+  __shared__ __attribute__((aligned(16))) double2 otile[LN ? 2 : 1][2][LN ? kWave : 1];   // [pair parity][bU | bV]
+  const double2 *Ul = reinterpret_cast<const double2 *>(U + L.b0 * N * J + (int64_t)L.sl * N * J) + j;
+  double2 *bUl = reinterpret_cast<double2 *>(bU + L.b0 * N * J + (int64_t)L.sl * N * J) + j;
+  double2 *bVl = reinterpret_cast<double2 *>(bV + L.b0 * N * J + (int64_t)L.sl * N * J) + j;
+  const int64_t plast = N / 2 - 1;
+  const int lto = grp * 16 + j;   // the lane's element of row 0 of a pair tile, in doubles (row 1: + 8)
   double cS[G], cF = 0.0, cW = 0.0, tck = 0.0;
   auto load_segment = [&](int64_t k) {
     const int64_t n_lo = 1 + k * C;
@@ -584,10 +657,18 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       if constexpr (FR) vdz[m] = make_double2(fdb[row], fbdb[row]);  // (d, bd) take the place of (d, z)
       else vdz[m] = dzb[row];
     }
+    if constexpr (LN) {   // pairs 4k .. 4k+3 = rows 8k .. 8k+7 (beyond the last pair: that one again, unused)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t P = 4 * k + i;
+        const double2 u2 = Ul[(P < plast ? P : plast) * 8];
+        qux[i] = u2.x; quy[i] = u2.y;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      iu[r] = act ? Ub[n * J] : 0.0;
+      if constexpr (!LN) iu[r] = act ? Ub[n * J] : 0.0;
       if constexpr (BACK) iw[r] = V[((size_t)blockIdx.x * N + (n - 1)) * kWave + lane];   // the recorded W row n-1 (lane-major)
       else iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1
       if constexpr (FR) ibw[r] = act ? fbWb[(n - 1) * J] : 0.0;
@@ -649,6 +730,10 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     lds_order();
     double dtv[C], pown[C], ipown[(BACK && APARK) ? C : 1];   // (SC: pown = g, ipown = 1 / g of rows n_lo-1 .. n_lo+C-2)
     const bool anchor = !BACK || (k + 1) % astep == 0 || k == nseg - 1;   // (BACK, uniform) re-anchor, or carry on
+    if constexpr (LN) {   // the segment's U lines -> tiles (read back as the lanes' own elements behind the exponentials)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) utile[i][lane] = make_double2(qux[i], quy[i]);
+    }
     if constexpr (SC) {
       if (anchor) {   // change of frame: the anchor row (the segment's last) becomes the reference, g = 1 there
         double gX[G];
@@ -671,6 +756,17 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
         igl[r] = rcp_nr(pown[r]);
         if constexpr (APARK) ipown[r] = igl[r];
         else { vv[r][0][lane] = pown[r]; vv[r][3][lane] = igl[r]; }
+      }
+      if constexpr (LN) {   // rows 8k+1 .. 8k+7 from this segment's lines, row 8k+8 handed down by the segment above
+        lds_order();
+        iu[C - 1] = ucar;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double *ut = reinterpret_cast<const double *>(utile[i]) + lto;
+          if (i == 0) ucar = ut[0];
+          else iu[2 * i - 1] = ut[0];
+          iu[2 * i] = ut[8];
+        }
       }
 #pragma unroll
       for (int r = 0; r < C; ++r) {   // u- = U_n / g_n, w~ = W_{n-1} g_{n-1} wait for their step already scaled
@@ -815,7 +911,20 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
           }
           const double u = uX[0], wm = wX[0];   // u-_n and w~_{n-1} of this lane
           oBA[grp][r] = ban;
-          if (st) bVb[n * J] = bVn * gn;
+          // rows n (odd first, then even) of a pair fill its tile; blocks start at odd rows: r odd <=> n even, pair (r + 1) / 2 + 4k
+          double *obu = reinterpret_cast<double *>(otile[LN ? ((r + 1) / 2) & 1 : 0][0]) + lto + ((r & 1) ? 0 : 8);
+          double *obv = reinterpret_cast<double *>(otile[LN ? ((r + 1) / 2) & 1 : 0][1]) + lto + ((r & 1) ? 0 : 8);
+          if constexpr (LN) {
+            if (r % 2 == 0 && r + 1 < cnt) {   // the pair completed by the step before (row n + 1, even) leaves now
+              lds_order();
+              const int64_t P = (n + 1) / 2;
+              bUl[P * 8] = otile[((r + 2) / 2) & 1][0][lane];
+              bVl[P * 8] = otile[((r + 2) / 2) & 1][1][lane];
+            }
+          } else {
+            if (st) bVb[n * J] = bVn * gn;
+          }
+          const double bVout = bVn * gn;
           // x- = bV- + 2 ba u- is the vector gathered on the chain; M^ -= u-^T x- + bV-^T u- = u-_i bV-_j + x-_i u-_j
           const double xv = fma(2.0 * ban, u, bVn);
           xgather_dpp<G>(xv, xB, lane, xX);
@@ -831,7 +940,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
             if (i & 1) { xs1 = fma(xX[i], SX[i], xs1); bp1 = fma(SX[i], m, bp1); q1 = fma(wX[i], m, q1); }
             else { xs0 = fma(xX[i], SX[i], xs0); bp0 = fma(SX[i], m, bp0); q0 = fma(wX[i], m, q0); }
           }
-          if (st) bUb[n * J] = ign * (bU1 - (xs0 + xs1));     // reverse.hpp:66 + internal.hpp:232
+          if constexpr (LN) { *obu = ign * (bU1 - (xs0 + xs1)); *obv = bVout; }   // (adjacent tiles: one ds_write2_b64)
+          else if (st) bUb[n * J] = ign * (bU1 - (xs0 + xs1));     // reverse.hpp:66 + internal.hpp:232
           const double bp = bp_s + (bp0 + bp1);
           bcj = fma(dt, bp, bcj);
           const double q = q0 + q1;               // (w~ M^)_j = q_j / g_{n-1}
@@ -1002,7 +1112,15 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   }
   // row 0 (reverse.hpp:83-84)
   if (st0) { bab[0] = ban; btb[0] = carry; }
-  if (st) { bVb[0] = SC ? bVn * gtop : bVn; bUb[0] = 0.0; bc[L.b * J + j] = bcj; }
+  if constexpr (LN) {   // row 0 completes pair 0 (row 1 is in the tile of even pairs since the last step)
+    double *obu = reinterpret_cast<double *>(otile[0][0]) + lto, *obv = reinterpret_cast<double *>(otile[0][1]) + lto;
+    *obv = bVn * gtop;
+    *obu = 0.0;
+    lds_order();
+    bUl[0] = otile[0][0][lane];
+    bVl[0] = otile[0][1][lane];
+    bc[L.b * J + j] = bcj;
+  } else if (st) { bVb[0] = SC ? bVn * gtop : bVn; bUb[0] = 0.0; bc[L.b * J + j] = bcj; }
 }
 
 }  // namespace c2
@@ -1040,6 +1158,13 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
     return launch_ok();
   }
   const bool dg = G_ <= 8 && fwd_dpp_gathers(grid.x);
+  // rows of U, V as whole 128-byte lines (k_loglik_fwd<..., LN>): J = 8, an even number of rows, 16-byte aligned arrays
+  if (J == 8 && N >= 2 && N % 2 == 0 && ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15) == 0 && !dg &&
+      opt::has(opt::k_loglik_lines) && (opt::ival(opt::k_loglik_lines) == 1 || opt::ival(opt::k_loglik_lines) == 2)) {
+    hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R, C2_CKPT_C, MODE, false, C2_FWD_OCC, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t,
+                       t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);
+    return launch_ok();
+  }
 #define C2_FWD(G, R, C)                                                                                          \
   do {                                                                                                           \
     if (dg && G <= 8) {                                                                                          \
@@ -1070,26 +1195,27 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
 }  // namespace
 
 // Two-columns-per-lane variant for J == 8 (c2_loglik4.hip).
-extern "C" size_t c2_internal_loglik4_workspace_doubles(int64_t B, int64_t N, size_t *ck_doubles);
 extern "C" int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                                    const double *a, const double *U, const double *V, const double *y, double *ll,
                                    int32_t *flag, c2_stream_t stream);
-extern "C" int c2_internal_loglik4_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c,
-                                        int64_t c_bs, const double *a, const double *U, const double *V,
-                                        const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
-                                        double *bV, double *by, int32_t *flag, void *work, c2_stream_t stream);
+// Four lanes per series, gradient pair in the scaled frame (c2_loglik_q4.hip, J == 8)
+extern "C" size_t c2_internal_loglik_q4_record_doubles(int64_t B, int64_t N);
+extern "C" int c2_internal_loglik_q4_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                          const double *a, const double *U, const double *V, const double *y, double *ll,
+                                          double *bt, double *bc, double *ba, double *bU, double *bV, double *by,
+                                          int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
 
-// Which lane mapping serves (B, J)?  The two-columns-per-lane kernels carry 16 series per wavefront, so they need
-// twice the batch to fill the chip.  Measured on MI355X at N = 4096 (profiles/r01_lanes4.md): the forward-only
-// kernel is 14-15 % faster from B = 16384 up and equal at 8192; the gradient pair is slower (its forward pass is
-// bound by the larger checkpoint stream), so it is only taken when forced.  C2_LANES=4 / C2_LANES=8 force one or
-// the other (tests, benchmarks).
+// Which lane mapping serves (B, J)?  Four lanes per series (two columns per lane, J = 8) carry 16 series per wavefront, so
+// they need twice the batch to fill the chip.  Forward-only (c2_loglik4.hip): 14-15 % faster than the eight-lane kernel from
+// 16384 series up, equal at 8192 (profiles/r01_lanes4.md).  Gradient pair (c2_loglik_q4.hip, scaled frame): the batches that
+// give the eight-lane pair two wavefronts per SIMD (profiles/r05_four_lanes.md).  C2_LANES=4 / C2_LANES=8 force one or the other.
 static bool use_lanes4(int64_t B, int64_t J, bool grad) {
   if (J != 8) return false;
   const int forced = opt::has(opt::k_lanes) ? (int)opt::ival(opt::k_lanes) : 0;
   if (forced == 4) return true;
   if (forced == 8 || forced == 1 || forced == 2) return false;
-  return !grad && B >= opt::ival(opt::k_lanes4_min_batch);
+  if (grad) return B >= opt::ival(opt::k_lanes4_min_batch_grad) && B <= opt::ival(opt::k_lanes4_max_batch_grad);
+  return B >= opt::ival(opt::k_lanes4_min_batch);
 }
 
 // One lane per series (c2_loglik_t.hip, J == 8): 64 series per wavefront, so it takes 64 x 1024 series to put one
@@ -1576,11 +1702,22 @@ extern "C" int c2_internal_factor_states_timepar(int64_t B, int64_t N, int64_t J
 
 size_t c2_internal_loglik_grad_replay_doubles(int64_t B, int64_t N, int64_t J) { return grad_ws(B, N, J).total; }
 
+// k_anchor_spans for the other lane mappings (c2_loglik_q4.hip): one workgroup per wavefront of `spw` series
+int c2_internal_anchor_spans(int64_t B, int64_t N, int64_t J, int C, int spw, const double *t, int64_t t_bs, const double *c,
+                             int64_t c_bs, unsigned long long *words, c2_stream_t stream) {
+  const dim3 grid((unsigned)((B + spw - 1) / spw));
+  hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, (hipStream_t)stream, B, N, (int)J, C, spw, t, t_bs, c, c_bs, words);
+  return launch_ok();
+}
+
 size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   if (B < 1 || N < 1 || J < 1 || J > C2_MAX_WIDTH) return 0;
   if (J > C2_FAST_WIDTH) return c2_loglik_grad_composite_workspace_bytes(B, N, J);   // (d, W, S, z, F, seeds: the op chain)
   size_t n = grad_ws(B, N, J, use_back(N, J)).total;
-  if (use_lanes4(B, J, true)) n = c2_internal_loglik4_workspace_doubles(B, N, nullptr);  // same choice as the call
+  if (use_lanes4(B, J, true)) {   // [guard words] [records of the four-lane pair | workspace of the replay fallback]
+    const size_t r = c2_internal_loglik_q4_record_doubles(B, N), f = grad_ws(B, N, J).total;
+    n = lanes1_gate_words(B) + (r > f ? r : f);
+  }
   if (use_lanes1(B, J, true)) {  // [guard words: head + one per wavefront] [records of the one-lane path | workspace of the replay fallback]
     const size_t r = lanes1_record_doubles(B, N, J), f = grad_ws(B, N, J).total;
     n = lanes1_gate_words(B) + (r > f ? r : f);
@@ -1647,10 +1784,17 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
     return c2_internal_loglik_grad_replay(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
                                           (double *)work + kTimeparVerifyWords, (const unsigned long long *)work, stream);
   }
-  if (use_lanes4(B, J, true))
-    return c2_internal_loglik4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
   const unsigned long long *gate = nullptr;
-  if (use_lanes2(B, N, J, true)) {
+  if (use_lanes4(B, J, true)) {
+    // Four lanes per series, scaled frame.  Groups of 64 series whose anchor intervals are beyond the guard (gaps in time)
+    // are left to the replay pair below, gated per group by the words k_q4_gate leaves (decided on the device).
+    unsigned long long *guard = (unsigned long long *)work;
+    work = (double *)work + lanes1_gate_words(B);
+    if (int e = c2_internal_loglik_q4_grad(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag,
+                                           (double *)work, guard, stream))
+      return e;
+    gate = gate_per_wave(guard + kGateHeadWords);
+  } else if (use_lanes2(B, N, J, true)) {
     // Two lanes per series: as below, the two wavefronts of a group of 64 series raising its guard word together
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *guard = (unsigned long long *)work;
@@ -1722,9 +1866,17 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
 #define C2_REVB_ARGS grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, (const double *)Wrec, (const double2 *)DZst, \
                      (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by, nullptr, nullptr, nullptr, gate, \
                      (const unsigned long long *)segg
+  // ... with the rows of U, bU, bV as whole 128-byte lines (k_loglik_rev<..., LN>): J = 8, an even number of rows, aligned arrays
+  const bool ln = sc && J == 8 && N >= 2 && N % 2 == 0 &&
+                  ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(bU) | reinterpret_cast<uintptr_t>(bV)) & 15) == 0 &&
+                  opt::has(opt::k_loglik_lines) && (opt::ival(opt::k_loglik_lines) == 1 || opt::ival(opt::k_loglik_lines) == 3);
   if (back && occ2) {
-    if (sc) hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2, true>), C2_REVB_ARGS);
+    if (ln) hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2, true, true>), C2_REVB_ARGS);
+    else if (sc) hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2, true>), C2_REVB_ARGS);
     else hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 2>), C2_REVB_ARGS);
+    if (int e = launch_ok()) return e;
+  } else if (back && ln) {
+    hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, C2_REV_OCC, true, true>), C2_REVB_ARGS);
     if (int e = launch_ok()) return e;
   } else if (back) {
 #define C2_REVB(G, C)                                                                                         \

@@ -1,6 +1,7 @@
-// c2_loglik4.hip -- the fused log-likelihood / gradient kernels with TWO columns per lane.
+// c2_loglik4.hip -- the fused forward log-likelihood kernel with TWO columns per lane (the gradient pair of this mapping is
+// c2_loglik_q4.hip).
 //
-// Same algorithm, records and checkpoint/replay structure as c2_loglik.hip, different lane mapping: a series of
+// Same algorithm as c2_loglik.hip, different lane mapping: a series of
 // width J = 2*LG is walked by LG lanes, lane jl owning columns 2jl and 2jl+1 of the J x J state, so a wavefront
 // carries 64/LG series (16 at J = 8 instead of 8).  Per series this halves everything that c2_loglik.hip
 // replicates or pays per lane group -- the scalar chain (reductions, reciprocal), the cross-lane traffic (a
@@ -298,264 +299,16 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
   }
 }
 
-// =============================================================================
-// Reverse sweep with segment replay (see c2_loglik.hip for the derivation; identical steps, two columns per lane).
-// =============================================================================
-template <int LG, int C>
-__global__ __launch_bounds__(kWave, 1) void k_loglik4_rev(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
-                                                          const double *__restrict__ c, int64_t c_bs,
-                                                          const double *__restrict__ U, const double *__restrict__ Wst,
-                                                          const double2 *__restrict__ DZst,
-                                                          const double *__restrict__ ckpt, int64_t nseg,
-                                                          const int32_t *__restrict__ flag, double *__restrict__ bt,
-                                                          double *__restrict__ bc, double *__restrict__ ba,
-                                                          double *__restrict__ bU, double *__restrict__ bV,
-                                                          double *__restrict__ by) {
-  constexpr int J = 2 * LG, SPW = kWave / LG, NV = (C + LG - 1) / LG;
-  __shared__ __attribute__((aligned(16))) double2 vv[C][3][kWave];  // [r][0] = p_n, [1] = U_n, [2] = W_{n-1}
-  __shared__ __attribute__((aligned(16))) double sfL[C][SymPack2<LG>::PER_REC];
-  __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
-  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[SPW][C], oBY[SPW][C];
-  const Geo<LG> L(B, LG);
-  const int lane = L.lane, jl = L.j, grp = lane / LG;
-  const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + 2 * jl;
-  const double *tb = t + L.b0 * t_bs + ot;
-  const double2 *Ub = reinterpret_cast<const double2 *>(U + L.b0 * N * J + oj);
-  const double2 *Wb = reinterpret_cast<const double2 *>(Wst + L.b0 * N * J + oj);
-  const double2 *dzb = DZst + L.b0 * N + on;
-  const double *ckw = ckpt + (size_t)blockIdx.x * nseg * CkptRec2<LG>::DOUBLES;
-  double *btb = bt + L.b0 * N + on, *bab = ba + L.b0 * N + on, *byb = by + L.b0 * N + on;
-  double2 *bUb = reinterpret_cast<double2 *>(bU + L.b0 * N * J + oj);
-  double2 *bVb = reinterpret_cast<double2 *>(bV + L.b0 * N * J + oj);
-  const double cj[2] = {c[L.b * c_bs + 2 * jl], c[L.b * c_bs + 2 * jl + 1]};
-  if (flag[L.b] != 0) {  // failed factorisation: NaN gradients for this series (see k_loglik_rev)
-    const double nan = __builtin_nan("");
-    if (L.valid) {
-      for (int64_t n = jl; n < N; n += LG) { btb[n] = nan; bab[n] = nan; byb[n] = nan; }
-      for (int64_t n = 0; n < N; ++n) { bUb[n * LG] = make_double2(nan, nan); bVb[n * LG] = make_double2(nan, nan); }
-      bc[L.b * J + 2 * jl] = nan; bc[L.b * J + 2 * jl + 1] = nan;
-    }
-    return;
-  }
-
-  int boff[LG];
-#pragma unroll
-  for (int k = 0; k < LG; ++k) boff[k] = SymPack2<LG>::off(lane, k);
-
-  double MX[2][J];
-#pragma unroll
-  for (int q = 0; q < J; ++q) { MX[0][q] = 0.0; MX[1][q] = 0.0; }
-  double bF[2] = {0.0, 0.0}, bcj[2] = {0.0, 0.0}, bVn[2] = {0.0, 0.0};
-  double carry = 0.0, ban = 0.0, bzn = 0.0;
-
-  double vt[NV];
-  double vd[NV], vz[NV];
-  double iu[C][2], iw[C][2];  // plain doubles: arrays of double2 end up in scratch
-  double cS[2][J], cF[2];
-  auto load_segment = [&](int64_t k) {
-    const int64_t n_lo = 1 + k * C;
-    const bool full = n_lo + C <= N;
-#pragma unroll
-    for (int m = 0; m < NV; ++m) {
-      int64_t row = n_lo - 1 + m * LG + jl;
-      row = (row < N) ? row : N - 1;
-      vt[m] = tb[row];
-      const double2 dz = dzb[row];
-      vd[m] = dz.x; vz[m] = dz.y;
-    }
-#pragma unroll
-    for (int r = 0; r < C; ++r) {
-      const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      const double2 u2 = Ub[n * LG], w2 = Wb[(n - 1) * LG];
-      iu[r][0] = u2.x; iu[r][1] = u2.y; iw[r][0] = w2.x; iw[r][1] = w2.y;
-    }
-    const double *rec = ckw + k * CkptRec2<LG>::DOUBLES;
-    SymPack2<LG>::load(rec, lane, boff, cS);
-    const double2 f2 = reinterpret_cast<const double2 *>(rec + SymPack2<LG>::PER_REC)[lane];
-    cF[0] = f2.x; cF[1] = f2.y;
-  };
-
-  double carT = tb[N - 1];
-  double2 carDZ = dzb[N - 1];
-  double carR = rcp_nr(carDZ.x);
-  if (nseg > 0) load_segment(nseg - 1);
-
-  for (int64_t k = nseg - 1; k >= 0; --k) {
-    const int64_t n_lo = 1 + k * C;
-    const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
-
-    // ---- phase A ----
-#pragma unroll
-    for (int m = 0; m < NV; ++m) {
-      const int idx = m * LG + jl;
-      if (LG * NV == C || idx < C) {
-        rowT[idx][grp] = vt[m]; rowD[idx][grp] = vd[m]; rowR[idx][grp] = rcp_nr(vd[m]); rowZ[idx][grp] = vz[m];
-      }
-    }
-    lds_order();
-    rowT[cnt][grp] = carT; rowD[cnt][grp] = carDZ.x; rowR[cnt][grp] = carR; rowZ[cnt][grp] = carDZ.y;
-    lds_order();
-    double dtv[C];
-    {
-      double tprev = rowT[0][grp];
-#pragma unroll
-      for (int r = 0; r < C; ++r) {
-        const double tn = rowT[r + 1][grp];
-        dtv[r] = tprev - tn;
-        tprev = tn;
-        vv[r][0][lane] = make_double2(exp_decay(cj[0] * dtv[r]), exp_decay(cj[1] * dtv[r]));
-        vv[r][1][lane] = make_double2(iu[r][0], iu[r][1]);
-        vv[r][2][lane] = make_double2(iw[r][0], iw[r][1]);
-      }
-    }
-    // ---- phase B: chain-free replay ----
-    double SX[2][J];
-#pragma unroll
-    for (int q = 0; q < J; ++q) { SX[0][q] = cS[0][q]; SX[1][q] = cS[1][q]; }
-    double F[2] = {cF[0], cF[1]};
-    double Fp[C][2], tauS[C][2];
-    lds_order();
-    if (k > 0) load_segment(k - 1);  // a whole segment of work ahead of its use
-#pragma unroll
-    for (int r = 0; r < C; ++r) {
-      if (r < cnt) {
-        double pX[J], uX[J], wX[J];
-        xgather2_lds<LG>(vv[r][0], lane, pX);
-        xgather2_lds<LG>(vv[r][1], lane, uX);
-        xgather2_lds<LG>(vv[r][2], lane, wX);
-        const double dprev = rowD[r][grp], zprev = rowZ[r][grp];
-        const double dw0 = dprev * wX[0], dw1 = dprev * wX[1];
-        double t0a = 0.0, t0b = 0.0, t1a = 0.0, t1b = 0.0;
-#pragma unroll
-        for (int q = 0; q < J; ++q) {
-          const double s0 = (pX[q] * pX[0]) * fma(dw0, wX[q], SX[0][q]);
-          const double s1 = (pX[q] * pX[1]) * fma(dw1, wX[q], SX[1][q]);
-          SX[0][q] = s0;
-          SX[1][q] = s1;
-          if (q & 1) { t0b = fma(uX[q], s0, t0b); t1b = fma(uX[q], s1, t1b); }
-          else { t0a = fma(uX[q], s0, t0a); t1a = fma(uX[q], s1, t1a); }
-        }
-        tauS[r][0] = t0a + t0b; tauS[r][1] = t1a + t1b;
-        F[0] = pX[0] * fma(wX[0], zprev, F[0]);
-        F[1] = pX[1] * fma(wX[1], zprev, F[1]);
-        Fp[r][0] = F[0]; Fp[r][1] = F[1];
-        SymPack2<LG>::store(sfL[r], lane, boff, SX);
-      }
-    }
-    if (k == nseg - 1) {
-      const double rd = rowR[cnt][grp], z = rowZ[cnt][grp];
-      ban = 0.5 * rd * (z * z * rd - 1.0);
-      bzn = -z * rd;
-      bVn[0] = 0.0; bVn[1] = 0.0;
-      byb[N - 1] = bzn;
-    }
-    carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
-    lds_order();
-
-    // ---- phase C: fused reverse steps ----
-#pragma unroll
-    for (int r = C - 1; r >= 0; --r) {
-      if (r < cnt) {
-        const int64_t n = n_lo + r;
-        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
-        double uX[J], pX[J], wX[J], bVX[J], Sf[2][J];
-        xgather2_lds<LG>(vv[r][1], lane, uX);
-        xgather2_lds<LG>(vv[r][0], lane, pX);
-        xgather2_lds<LG>(vv[r][2], lane, wX);
-        SymPack2<LG>::load(sfL[r], lane, boff, Sf);
-        const double p[2] = {pX[0], pX[1]}, u[2] = {uX[0], uX[1]}, wm[2] = {wX[0], wX[1]};
-        oBA[grp][r] = ban;
-        bVb[n * LG] = make_double2(bVn[0], bVn[1]);
-        xgather2_dpp<LG>(bVn[0], bVn[1], bVX);
-        double bUo[2], bpt[2], qv[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const double bU1 = -bzn * Fp[r][m];
-          bF[m] = fma(-u[m], bzn, bF[m]);
-          const double bp_s = Fp[r][m] * bF[m];
-          bF[m] *= p[m];
-          const double xv = fma(2.0 * ban, u[m], bVn[m]);
-          double xs0 = 0.0, xs1 = 0.0, bp0 = 0.0, bp1 = 0.0;
-#pragma unroll
-          for (int q = 0; q < J; ++q) {
-            double mm = fma(-uX[q], xv, MX[m][q]);
-            mm = fma(-bVX[q], u[m], mm);
-            MX[m][q] = mm;
-            if (q & 1) { xs1 = fma(bVX[q], Sf[m][q], xs1); bp1 = fma(Sf[m][q], mm, bp1); }
-            else { xs0 = fma(bVX[q], Sf[m][q], xs0); bp0 = fma(Sf[m][q], mm, bp0); }
-          }
-          xs0 = fma(2.0 * ban, tauS[r][m], xs0);
-          bUo[m] = bU1 - (xs0 + xs1);
-          bpt[m] = bp_s + (bp0 + bp1);
-          bcj[m] = fma(dt, bpt[m], bcj[m]);
-          double q0 = 0.0, q1 = 0.0;
-#pragma unroll
-          for (int q = 0; q < J; ++q) {
-            MX[m][q] *= pX[q] * p[m];
-            if (q & 1) q1 = fma(wX[q], MX[m][q], q1);
-            else q0 = fma(wX[q], MX[m][q], q0);
-          }
-          qv[m] = q0 + q1;
-        }
-        bUb[n * LG] = make_double2(bUo[0], bUo[1]);
-        double f = fma(cj[0], bpt[0], cj[1] * bpt[1]), Gs = fma(wm[0], bF[0], wm[1] * bF[1]),
-               Q = fma(qv[0], wm[0], qv[1] * wm[1]);
-        gsum3<LG>(f, Gs, Q);
-        oBT[grp][r] = carry - f;
-        carry = f;
-        const double zr = zm * rdm;
-        bzn = Gs - zr;
-        oBY[grp][r] = bzn;
-        bVn[0] = fma(zr, bF[0], qv[0]);
-        bVn[1] = fma(zr, bF[1], qv[1]);
-        ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
-      }
-    }
-    lds_order();
-#pragma unroll
-    for (int m = 0; m < NV; ++m) {
-      const int idx = m * LG + jl;
-      if ((LG * NV == C || idx < C) && idx < cnt) {
-        bab[n_lo + idx] = oBA[grp][idx];
-        btb[n_lo + idx] = oBT[grp][idx];
-        byb[n_lo - 1 + idx] = oBY[grp][idx];
-      }
-    }
-    lds_order();
-  }
-  if (nseg == 0) {  // N == 1
-    const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;
-    ban = 0.5 * rd0 * (cz * cz * rd0 - 1.0);
-    bzn = -cz * rd0;
-    byb[0] = bzn;
-  }
-  bab[0] = ban; btb[0] = carry;
-  bVb[0] = make_double2(bVn[0], bVn[1]);
-  bUb[0] = make_double2(0.0, 0.0);
-  reinterpret_cast<double2 *>(bc + L.b * J)[jl] = make_double2(bcj[0], bcj[1]);
-}
-
 }  // namespace c2
 
 using namespace c2;
 
 namespace {
 inline int launch_ok4() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP; }
-constexpr int kC4 = 4;  // checkpoint interval of the two-columns-per-lane variant
+constexpr int kC4 = 4;
 }  // namespace
 
 extern "C" {
-
-// J == 8 only (LG = 4).  Workspace layout: [checkpoints][W rows][(d,z) pairs].
-size_t c2_internal_loglik4_workspace_doubles(int64_t B, int64_t N, size_t *ck_doubles) {
-  constexpr int LG = 4, J = 8;
-  const int64_t nseg = (N - 1 + kC4 - 1) / kC4;
-  const size_t waves = ((size_t)B * LG + kWave - 1) / kWave;
-  size_t ck = waves * (size_t)nseg * CkptRec2<LG>::DOUBLES;
-  ck = (ck + 1) & ~(size_t)1;
-  if (ck_doubles) *ck_doubles = ck;
-  return ck + (size_t)B * N * J + (size_t)B * N * 2;
-}
 
 int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                         const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
@@ -564,27 +317,6 @@ int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, con
   const dim3 grid((unsigned)((B * LG + kWave - 1) / kWave));
   hipLaunchKernelGGL((k_loglik4_fwd<LG, C2_FWD4_R0, kC4, 0>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a,
                      U, V, y, ll, flag, nullptr, 0, nullptr, nullptr);
-  return launch_ok4();
-}
-
-int c2_internal_loglik4_grad(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
-                             const double *a, const double *U, const double *V, const double *y, double *ll, double *bt,
-                             double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
-                             c2_stream_t stream) {
-  constexpr int LG = 4, J = 8;
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t nseg = (N - 1 + kC4 - 1) / kC4;
-  size_t ck = 0;
-  (void)c2_internal_loglik4_workspace_doubles(B, N, &ck);
-  double *ckpt = (double *)work;
-  double *Wst = ckpt + ck;
-  double2 *DZst = reinterpret_cast<double2 *>(Wst + (size_t)B * N * J);
-  const dim3 grid((unsigned)((B * LG + kWave - 1) / kWave));
-  hipLaunchKernelGGL((k_loglik4_fwd<LG, 8, kC4, 1>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll,
-                     flag, ckpt, nseg, Wst, DZst);
-  if (int e = launch_ok4()) return e;
-  hipLaunchKernelGGL((k_loglik4_rev<LG, kC4>), grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, (const double *)Wst,
-                     (const double2 *)DZst, (const double *)ckpt, nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by);
   return launch_ok4();
 }
 

@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_kernel_values(int64_t B, int64_t N, int
   for (int i = 0; i < Jc; ++i) {
     const double ph = dc[oc + i] * tau;
     double sn, cs;
-    if (ph < kSincosFastMax) sincos_cw_fast(ph, sn, cs);
+    if (fabs(ph) < kSincosFastMax) sincos_cw_fast(ph, sn, cs);   // (dc may be negative; NaN takes the library path)
     else sincos(ph, &sn, &cs);
     k = fma(exp(-cc[oc + i] * tau), fma(ac[oc + i], cs, bc[oc + i] * sn), k);
   }

@@ -92,3 +92,20 @@ def test_bench_rccl_two_ranks_if_two_devices(tmp_path):
     assert line["rccl"] == {"backend": "nccl", "nranks": 2, "version": line["rccl"]["version"], "distinct_devices": 2}
     assert line["rccl"]["version"] and len({r["pci_bus_id"] for r in line["config"]["ranks"]}) == 2
     assert line["scaling"] == "strong" and line["config"]["global_batch"] == 64
+
+
+def test_bench_default_flags_two_ranks_dry_run():
+    """The line the driver's scaling run asks for -- `python bench.py --gpus N` with the DEFAULT steps / warm-up / shape (N = 4096,
+    J = 8, 10 timed steps, the `weak_scaling` object measured in the same run) -- as a two-rank dry run over gloo on this
+    box's one device, with a global batch (and a weak batch per GPU) small enough for two ranks to share it."""
+    rc, line, err = run_bench(["--gpus", "2", "--global-batch", "4096", "--weak-batch-per-gpu", "4096"],
+                              {"C2_DIST_BACKEND": "gloo"}, timeout=900)
+    assert rc == 0 and line is not None, err
+    assert line["n_gpus"] == 2 and line["steps"] == 10 and line["warmup"] == 3 and line["scaling"] == "strong"
+    assert line["config"]["global_batch"] == 4096 and line["config"]["batch_per_gpu"] == 2048 and line["config"]["N"] == 4096
+    assert line["config"]["failed_factorizations"] == 0
+    assert line["rccl"]["nranks"] == 2 and [r["rank"] for r in line["config"]["ranks"]] == [0, 1]
+    w = line["weak_scaling"]
+    assert w["scaling"] == "weak" and w["batch_per_gpu"] == 4096 and w["global_batch"] == 8192 and w["failed_factorizations"] == 0
+    assert w["value"] > 0 and line["value"] > 0 and 0 < line["roofline"]["frac"] < 1
+    assert "parity_sample" not in line or line["parity_sample"].get("within_1e-10", True)

@@ -222,3 +222,45 @@ def test_wide_model_through_the_drop_in(mods, oracle):
     oracle.factor_rev(x, c, a, U, V, do, Wo, So, bd, bW, *outs)
     for g, e in zip(got, outs):
         _close(g, e)
+
+
+def test_two_threads_are_reentrant(mods, oracle):
+    """The host entry points keep their staging arena, bounce buffer and stream per calling THREAD (c2_host.hip): two threads
+    hammering driver.factor / driver.solve_lower / backprop.factor_rev on different problems at once (the bindings release
+    the GIL) get the answers they get alone -- as with the reference, whose functions are re-entrant."""
+    import threading
+    driver, backprop = mods
+    problems = []
+    for seed, (N, J) in enumerate([(300, 2), (1200, 8)]):
+        co = dense.sho_sum_coeffs(J)
+        rng = np.random.default_rng(50 + seed)
+        t = np.sort(rng.uniform(0, N / 10.0, N)); diag = rng.uniform(0.1, 0.3, N)
+        c, a, U, V = dense.celerite_matrices(co, t, diag)
+        Y = rng.standard_normal((N, 3))
+        d0, W0, S0 = np.empty_like(a), np.empty_like(V), np.empty((N, J, J))
+        oracle.factor(t, c, a, U, V, d0, W0, S0)
+        Z0 = Y.copy(); oracle.solve_lower(t, c, U, W0, Y, Z0)
+        bd, bW = rng.standard_normal(N), rng.standard_normal((N, J))
+        g0 = [np.zeros(N), np.zeros(J), np.zeros(N), np.zeros((N, J)), np.zeros((N, J))]
+        oracle.factor_rev(t, c, a, U, V, d0, W0, S0, bd, bW, *g0)
+        problems.append(dict(t=t, c=c, a=a, U=U, V=V, Y=Y, d0=d0, W0=W0, S0=S0, Z0=Z0, bd=bd, bW=bW, g0=g0))
+    errors = []
+
+    def work(p):
+        try:
+            for _ in range(40):
+                d, W = driver.factor(p["t"], p["c"], p["a"], p["U"], p["V"], np.empty_like(p["a"]), np.empty_like(p["V"]))
+                _close(d, p["d0"]); _close(W, p["W0"])
+                Z = driver.solve_lower(p["t"], p["c"], p["U"], W, p["Y"], p["Y"].copy())
+                _close(Z, p["Z0"])
+                g = [np.zeros_like(x) for x in p["g0"]]
+                backprop.factor_rev(p["t"], p["c"], p["a"], p["U"], p["V"], d, W, p["S0"], p["bd"], p["bW"], *g)
+                for x, e in zip(g, p["g0"]):
+                    _close(x, e)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(p,)) for p in problems for _ in range(2)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors[:3]

@@ -546,6 +546,54 @@ def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypa
         monkeypatch.delenv("C2_LOGLIK_SCALED")
 
 
+@pytest.mark.parametrize("N", [1, 2, 9, 32, 33, 34, 64, 65, 97, 130, 300])
+def test_four_lane_pair_scaled_frame_and_its_fallback(ops, oracle, monkeypatch, N):
+    """Four lanes per series (c2_loglik_q4.hip, J = 8: both kernels in a scaled frame between anchors 32 rows apart).  Series
+    lengths around the anchors (a last segment that is empty, partial, exactly full, itself an anchor); batches in which some
+    groups of 64 series have gaps in time (those groups are closed by k_q4_gate and taken by the replay pair behind), all
+    of them, none; a grid sparse enough that every group is closed; a ragged last wavefront."""
+    monkeypatch.setenv("C2_LANES", "4")
+    B, J = 150, 8   # ten wavefronts of 16 series (the last one ragged), three groups of 64
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    rng = np.random.default_rng(4400 + N)
+    for gaps in ("none", "some", "all", "sparser grid"):
+        tg = t.copy()
+        if gaps == "sparser grid":
+            tg = t[:, :1] + 6.0 * (t - t[:, :1])
+        elif gaps != "none" and N > 2:
+            for b in (range(B) if gaps == "all" else rng.choice(64, size=5, replace=False)):   # (some: the first group only)
+                tg[b, int(rng.integers(1, N)):] += 40.0 / c.max()
+        llo, go, flo = oracle.loglik_grad_batched(tg, c, a, U, V, y, nthreads=2)
+        assert int(np.abs(flo).sum()) == 0
+        ll, grads, flag = ops.loglik_grad(*dev(tg, c, a, U, V, y))
+        assert int(flag.abs().sum()) == 0
+        close(ll, llo)
+        for g, e in zip(grads, go):
+            close(g, e, floor=4e-12)
+    # shared time grid and rates; a failed series among its neighbours
+    t0d, c0d = dev(t[0].copy(), c[0].copy())
+    ad, Ud, Vd, yd = dev(a, U, V, y)
+    ll4, g4, f4 = ops.loglik_grad(t0d, c0d, ad, Ud, Vd, yd)
+    for b in (0, 17, B - 1):
+        e, ge, fe = oracle.loglik_grad(t[0], c[0], a[b], U[b], V[b], y[b])
+        if fe == 0 and int(f4[b]) == 0:
+            close(ll4[b:b + 1], np.array([e]))
+            close(g4[3][b], ge[3], floor=4e-12)
+    if N > 2:
+        a2 = a.copy(); a2[18, N // 2] = -5.0
+        ll3, g3, f3 = ops.loglik_grad(*dev(t, c, a2, U, V, y))
+        assert int(f3[18]) == N // 2 and int(f3[17]) == 0 and np.isneginf(float(ll3[18]))
+        assert bool(torch_isnan_all(g3, 18))
+        llo, go, _ = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+        close(ll3[17:18], llo[17:18])
+        close(g3[4][17], go[4][17], floor=4e-12)
+
+
+def torch_isnan_all(grads, b):
+    import torch
+    return all(bool(torch.isnan(g[b]).all()) for g in grads)
+
+
 @pytest.mark.parametrize("J", [1, 3, 5, 6, 7, 12, 16, 24, 32])
 @pytest.mark.parametrize("N", [1, 2, 8, 9, 10, 17, 100])
 def test_loglik_grad_widths_and_segment_edges(ops, oracle, J, N):

@@ -28,7 +28,9 @@
   X(fwd_dpp_gathers, "C2_FWD_DPP_GATHERS", 0, 's', "1: forward kernels of the group mappings (up to eight lanes per series) gather the next step's decay and U vectors by DPP permutes instead of through LDS (A/B runs)", "slower: 1024 series x 4096 rows 3.76 -> 4.11 ms for the gradient pair (profiles/r04_back8.md)") \
   X(lanes4_min_batch, "C2_LANES4_MIN_BATCH", 16384, 't', "forward log-likelihood, J = 8: two columns per lane from this many series up", "14-15 % faster from 16384 series, equal at 8192 (profiles/r01_lanes4.md)") \
   X(lanes4_min_batch_grad, "C2_LANES4_MIN_BATCH_GRAD", 9216, 't', "log-likelihood + gradient, J = 8: four lanes per series (two columns per lane, scaled frame; c2_loglik_q4.hip) from this many series up ...", "N = 4096: 4.99 vs 4.52 ms at 8192 series (8 lanes: one wavefront per SIMD there), 6.10 vs 6.43 at 9216, 6.21 vs 6.60 at 10240, 6.94 vs 7.36 at 12288 (profiles/r05_four_lanes.md)") \
-  X(lanes4_max_batch_grad, "C2_LANES4_MAX_BATCH_GRAD", 13312, 't', "... up to this many", "8.92 vs 8.19 ms at 14336 series, 9.98 vs 9.78 at 16384: with a wavefront on every SIMD its sixteen-series row requests queue at the address unit (profiles/r05_four_lanes.md)") \
+  X(lanes4_max_batch_grad, "C2_LANES4_MAX_BATCH_GRAD", 16384, 't', "... up to this many (one wavefront per SIMD; the two-lane pair takes over beyond)", "8.39 ms at 16384 series against 9.7 on eight lanes at two wavefronts per SIMD (profiles/r05_four_lanes.md)") \
+  X(loglik_q4_lines, "C2_LOGLIK_Q4_LINES", 0, 's', "the four-lane gradient pair moves the rows of U, V, bU, bV as aligned 128-byte lines of eight series through LDS tiles (1) or 64 bytes of sixteen series at a time (0); unset: lines from C2_Q4_LINES_MIN_BATCH series", "profiles/r05_four_lanes.md") \
+  X(q4_lines_min_batch, "C2_Q4_LINES_MIN_BATCH", 11264, 't', "... that batch size", "N = 4096, lines vs rows: 6.53 vs 6.55 ms at 10240 series, 6.68 vs 6.87 at 12288, 8.20 vs 9.00 at 14336, 8.39 vs 8.96 at 16384; 5.53 vs 5.29 at 8192 (profiles/r05_four_lanes.md)") \
   X(timepar, "C2_TIMEPAR", 0, 's', "forward log-likelihood / factor (widths 4, 2) and the solves parallel along TIME: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_check.py, profiles/r02_timepar.md") \
   X(timepar_min_rows, "C2_TIMEPAR_MIN_ROWS", 1536, 't', "shortest series the time-parallel forward pass takes when the batch is not a handful (B * J > 512)", "J = 4, 1024 x 4096: 0.26 vs 0.87 ms; a handful of series from 384 / 704 / 1024 rows at widths 2 / 4 / 8 (tools/timepar_small_n.py)") \
   X(timepar_max_batch_x_width, "C2_TIMEPAR_MAX_BATCH_X_WIDTH", 8192, 't', "largest B * J the time-parallel forward pass takes", "linear in the batch beyond one wavefront per SIMD: 0.98 ms at 4096 series of J = 4 where row by row takes 0.87") \

@@ -107,6 +107,12 @@ __global__ __launch_bounds__(256) void k_q4_gate(int64_t nwaves, const unsigned 
 // reciprocal, u-_{n+1} = U_{n+1} ih_{n+1} and its gather through LDS (off the chain).
 // =============================================================================
 constexpr int R = 8;   // rows per block of the transposed scalar streams and of the row ring (= C; an anchor every A blocks)
+// LN (N even): the rows of U and V arrive as whole aligned 128-byte lines -- rows (2P, 2P+1) of a series share one.  The four
+// lanes of a series would request 64 bytes of sixteen different lines per instruction (what this mapping queues on at the
+// CU's address unit once every SIMD has its wavefront: profiles/r05_four_lanes.md); instead one instruction fetches the
+// pair of eight series (lane l: series (l >> 3) + 8 m of the wavefront, 16-byte piece l & 7), a ring of four pairs in
+// registers runs eight rows ahead, and a per-wave LDS tile hands every lane its own two columns one pair ahead of their use.
+template <bool LN>
 __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                                      const double *__restrict__ U, const double *__restrict__ V,
@@ -126,6 +132,9 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   const double2 *Ub = reinterpret_cast<const double2 *>(U + L.b0 * N * J + oj);   // row stride LG double2
   const double2 *Vb = reinterpret_cast<const double2 *>(V + L.b0 * N * J + oj);
   const double cj[2] = {c[L.b * c_bs + 2 * jl], c[L.b * c_bs + 2 * jl + 1]};
+  // complex terms come as pairs of equal rates (terms.py:171-173): when BOTH columns of every lane of the wavefront share
+  // their rate, one exponential and one reciprocal per row serve the two (uniform branch; any other model takes both)
+  const bool ceq = __all(cj[0] == cj[1]);
   double2 *ckw = ckpt + (size_t)blockIdx.x * nslot * (kCkD2 * kWave);
   double2 *wrp = Wrec + (size_t)blockIdx.x * N * kWave + lane;
   double2 *dzst = DZst + L.b0 * N + on;
@@ -151,6 +160,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   const int srow = lane & 7;
   int ssl[NV];
   const double *tb8[NV], *ab8[NV], *yb8[NV];
+  const double2 *Ul8[NV], *Vl8[NV];   // (LN) piece `srow` of the row pairs of series slot ssl[m]
   double2 *dz8[NV];
 #pragma unroll
   for (int m = 0; m < NV; ++m) {
@@ -158,6 +168,8 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
     const int64_t bs = (L.b0 + ssl[m] < B) ? L.b0 + ssl[m] : B - 1;
     tb8[m] = t + bs * t_bs; ab8[m] = a + bs * N; yb8[m] = y + bs * N;
     dz8[m] = DZst + bs * N;
+    Ul8[m] = reinterpret_cast<const double2 *>(U + bs * N * J) + srow;
+    Vl8[m] = reinterpret_cast<const double2 *>(V + bs * N * J) + srow;
   }
   double vt[NV], va[NV], vy[NV];
   auto vload = [&](int64_t nb) {
@@ -178,23 +190,65 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   vload(1 + R); vstage(1);
   vload(1 + 2 * R);
 
-  double2 ru[R], rv[R];
+  double2 ru[LN ? 1 : R], rv[LN ? 1 : R];
   const double2 *up = Ub + LG, *vp = Vb + LG;   // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {
-    int64_t o = ahead;
-    if (clamp && n >= N) o -= n - (N - 1);
-    ru[r] = up[o * LG]; rv[r] = vp[o * LG];
+    if constexpr (!LN) {
+      int64_t o = ahead;
+      if (clamp && n >= N) o -= n - (N - 1);
+      ru[r] = up[o * LG]; rv[r] = vp[o * LG];
+    }
   };
+  // LN: ring slot P % 4 holds the pieces of pair P (two instructions: series slots 0 - 7 and 8 - 15 of the wavefront)
+  __shared__ __attribute__((aligned(16))) double2 ltile[LN ? 2 : 1][LN ? 2 * kWave : 1];   // [U | V][series][piece]
+  const int64_t plast = N / 2 - 1;
+  double qux[LN ? 4 : 1][NV], quy[LN ? 4 : 1][NV], qvx[LN ? 4 : 1][NV], qvy[LN ? 4 : 1][NV];
+  double cu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, cv[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [row of the pair][column]: current pair
+  double nu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, nv[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // ... the next one
+  auto pair_load = [&](int slot, int64_t P) {
+    const int64_t Pc = P < plast ? P : plast;
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+    for (int m = 0; m < NV; ++m) {
+      const double2 a2 = Ul8[m][Pc * 8], b2 = Vl8[m][Pc * 8];
+      qux[slot][m] = a2.x; quy[slot][m] = a2.y; qvx[slot][m] = b2.x; qvy[slot][m] = b2.y;
+    }
+  };
+  auto pair_stage = [&](int slot) {
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      ltile[0][m * kWave + lane] = make_double2(qux[slot][m], quy[slot][m]);
+      ltile[LN ? 1 : 0][m * kWave + lane] = make_double2(qvx[slot][m], qvy[slot][m]);
+    }
+  };
+  auto pair_own = [&]() {   // the lane's two columns of the staged pair's two rows
+    const double2 a0 = ltile[0][grp * 8 + jl], a1 = ltile[0][grp * 8 + 4 + jl];
+    const double2 b0 = ltile[LN ? 1 : 0][grp * 8 + jl], b1 = ltile[LN ? 1 : 0][grp * 8 + 4 + jl];
+    nu[0][0] = a0.x; nu[0][1] = a0.y; nu[1][0] = a1.x; nu[1][1] = a1.y;
+    nv[0][0] = b0.x; nv[0][1] = b0.y; nv[1][0] = b1.x; nv[1][1] = b1.y;
+  };
+  if constexpr (LN) {
+    const double2 u0 = Ub[0], u1 = Ub[LG], w1 = Vb[LG];
+    cu[0][0] = u0.x; cu[0][1] = u0.y; cu[1][0] = u1.x; cu[1][1] = u1.y;
+    cv[0][0] = v0.x; cv[0][1] = v0.y; cv[1][0] = w1.x; cv[1][1] = w1.y;   // pair 0 (row 0 is the prologue's)
+    pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);
+    pair_stage(1);
+    pair_load(1, 5);
+    lds_order();
+    pair_own();             // pair 1: the first step (the second row of pair 0) already prepares its first row
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+  }
 
   lds_order();
   double tref = tb[0];                    // reference time of the current frame (row 0, then every anchor row)
   double tnext = sin_[0][0][grp][0];
   // row n = 1, prepared: ih_n, h_n, u-_n (own pair) and its gather
-  double ihc[2] = {exp_decay(cj[0] * (tref - tnext)), exp_decay(cj[1] * (tref - tnext))};
-  double hc[2] = {rcp_nr(ihc[0]), rcp_nr(ihc[1])};
-  double uc[2] = {ru[0].x * ihc[0], ru[0].y * ihc[1]};
+  double ihc[2], hc[2];
+  ihc[0] = exp_decay(cj[0] * (tref - tnext)); hc[0] = rcp_nr(ihc[0]);
+  if (ceq) { ihc[1] = ihc[0]; hc[1] = hc[0]; }
+  else { ihc[1] = exp_decay(cj[1] * (tref - tnext)); hc[1] = rcp_nr(ihc[1]); }
+  double uc[2] = {(LN ? cu[1][0] : ru[0].x) * ihc[0], (LN ? cu[1][1] : ru[0].y) * ihc[1]};
   double hp[2] = {1.0, 1.0};              // h of the row the chain starts from (row 0: the reference itself)
   double uXc[J];
   xs2[lane] = make_double2(uc[0], uc[1]);
@@ -209,14 +263,29 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r];
-        const double vv_[2] = {rv[r].x, rv[r].y};
+        double vv_[2], ur[2];   // V_n and U_{n+1} of the lane
+        const int rn = (r + 1) % R;
+        if constexpr (LN) {
+          // blocks start at odd rows (n0 = 1 + 8 b): r odd <=> n even <=> the first row of pair P = n / 2
+          if (r % 2 == 1) {
+            vv_[0] = cv[0][0]; vv_[1] = cv[0][1]; ur[0] = cu[1][0]; ur[1] = cu[1][1];
+            lds_order();
+            pair_stage(((r + 1) / 2 + 1) % 4);                      // pair P + 1 -> tile (read back at the end of this step)
+            pair_load(((r + 1) / 2 + 1) % 4, n / 2 + 5);            // its slot: pair P + 5, eight rows ahead
+          } else {
+            vv_[0] = cv[1][0]; vv_[1] = cv[1][1]; ur[0] = nu[0][0]; ur[1] = nu[0][1];
+          }
+        } else {
+          vv_[0] = rv[LN ? 0 : r].x; vv_[1] = rv[LN ? 0 : r].y; ur[0] = ru[LN ? 0 : rn].x; ur[1] = ru[LN ? 0 : rn].y;
+        }
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) the next row's frame factors and u- -> LDS -> gather.  Behind an anchor row the next row lives in the new frame.
-        const int rn = (r + 1) % R;
         const double trn = (r == R - 1 && anchor_block) ? tn : tref;
-        const double ihn[2] = {exp_decay(cj[0] * (trn - tn1)), exp_decay(cj[1] * (trn - tn1))};
-        const double hn[2] = {rcp_nr(ihn[0]), rcp_nr(ihn[1])};
-        const double un[2] = {ru[rn].x * ihn[0], ru[rn].y * ihn[1]};
+        double ihn[2], hn[2];
+        ihn[0] = exp_decay(cj[0] * (trn - tn1)); hn[0] = rcp_nr(ihn[0]);
+        if (ceq) { ihn[1] = ihn[0]; hn[1] = hn[0]; }
+        else { ihn[1] = exp_decay(cj[1] * (trn - tn1)); hn[1] = rcp_nr(ihn[1]); }
+        const double un[2] = {ur[0] * ihn[0], ur[1] * ihn[1]};
         xs2[lane] = make_double2(un[0], un[1]);
         lds_order();
         double uXn[J];
@@ -275,6 +344,14 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
         }
         tnext = tn1;
         ihc[0] = ihn[0]; ihc[1] = ihn[1]; hc[0] = hn[0]; hc[1] = hn[1]; uc[0] = un[0]; uc[1] = un[1];
+        if (LN && r % 2 == 0) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { cu[e][0] = nu[e][0]; cu[e][1] = nu[e][1]; cv[e][0] = nv[e][0]; cv[e][1] = nv[e][1]; }
+        }
+        if (LN && r % 2 == 1) {   // own columns of pair P + 1: used from the next step on
+          lds_order();
+          pair_own();
+        }
 #pragma unroll
         for (int k = 0; k < J; ++k) uXc[k] = uXn[k];
       }
@@ -320,6 +397,10 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
 //   q^ = w~ M^;  G = w~ . bF-;  Q = q^ . w~;  bz_{n-1} = G - z/d;  bV-_{n-1} = (z/d) bF- + q^;  ba_{n-1} = ...
 //   S^_{n-1} = S^_n - d_{n-1} w~^T w~;  F~_{n-1} = F~_n - w~ z_{n-1}
 // =============================================================================
+// LN (N even): rows of U, bU, bV as whole 128-byte lines through LDS tiles (see k_q4_fwd): four line pairs of U per segment
+// (rows 8k .. 8k+7, two instructions each; row 8k is handed down to the segment below); a lane's bU / bV columns go into a
+// two-row tile and a completed pair leaves, during the step after, as two stores of eight whole lines each.
+template <bool LN>
 __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                      const double2 *__restrict__ Wrec, const double2 *__restrict__ DZst,
@@ -348,6 +429,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
   // Failed factorisation: NaN gradients for this series, never stale memory (see k_loglik_rev).  Its lanes stay in the
   // sweep all the same -- they fetch and flush scalar rows for OTHER series of the wavefront (eight lanes per series
   // below) -- with every store that belongs to the failed series switched off.
+  const bool ceq = __all(cj[0] == cj[1]);   // (see k_q4_fwd)
   const bool alive = flag[L.b] == 0;
   if (!alive) {
     const double nan = __builtin_nan("");
@@ -369,6 +451,8 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
   const double *tb8[NV];
   const double2 *dzb8[NV];
   double *bab8[NV], *btb8[NV], *byb8[NV];
+  const double2 *Ul8[NV];
+  double2 *bUl8[NV], *bVl8[NV];
 #pragma unroll
   for (int m = 0; m < NV; ++m) {
     ssl[m] = (lane >> 3) + 8 * m;
@@ -376,7 +460,14 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
     ok8[m] = flag[bs] == 0;
     tb8[m] = t + bs * t_bs; dzb8[m] = DZst + bs * N;
     bab8[m] = ba + bs * N; btb8[m] = bt + bs * N; byb8[m] = by + bs * N;
+    Ul8[m] = reinterpret_cast<const double2 *>(U + bs * N * J) + srow;
+    bUl8[m] = reinterpret_cast<double2 *>(bU + bs * N * J) + srow;
+    bVl8[m] = reinterpret_cast<double2 *>(bV + bs * N * J) + srow;
   }
+  const int64_t plast = N / 2 - 1;
+  __shared__ __attribute__((aligned(16))) double2 utile[LN ? 4 : 1][LN ? 2 * kWave : 1];        // [pair][series][piece]
+  __shared__ __attribute__((aligned(16))) double2 otile[LN ? 2 : 1][2][LN ? 2 * kWave : 1];     // [pair parity][bU | bV][series][piece]
+  double qux[LN ? 4 : 1][NV], quy[LN ? 4 : 1][NV], ucar[2] = {0.0, 0.0};
   double vt[NV], vd[NV], vz[NV];
   double iu[C][2], iw[C][2];   // plain doubles: arrays of double2 end up in scratch
   double cS[2][J], cF[2];
@@ -391,11 +482,20 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
       const double2 dz = dzb8[m][row];
       vd[m] = dz.x; vz[m] = dz.y;
     }
+    if constexpr (LN) {   // pairs 4k .. 4k+3 = rows 8k .. 8k+7 (beyond the last pair: that one again, unused)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t P = 4 * k + i, Pc = P < plast ? P : plast;
+#pragma unroll
+        for (int m = 0; m < NV; ++m) { const double2 u2 = Ul8[m][Pc * 8]; qux[i][m] = u2.x; quy[i][m] = u2.y; }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      const double2 u2 = Ub[n * LG], w2 = wrp[(size_t)(n - 1) * kWave];
-      iu[r][0] = u2.x; iu[r][1] = u2.y; iw[r][0] = w2.x; iw[r][1] = w2.y;
+      if constexpr (!LN) { const double2 u2 = Ub[n * LG]; iu[r][0] = u2.x; iu[r][1] = u2.y; }
+      const double2 w2 = wrp[(size_t)(n - 1) * kWave];
+      iw[r][0] = w2.x; iw[r][1] = w2.y;
     }
     // the state at the END of the segment where that is an anchor: every A-th segment boundary, the last row
     if (k == nseg - 1) ck_load(ckw + (size_t)(nslot - 1) * (kCkD2 * kWave), lane, cS, cF);
@@ -416,6 +516,12 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
     // ---- phase A: scalar rows to LDS; change of frame at an anchor; frame factors of the segment's rows -------
+    if constexpr (LN) {   // the segment's U lines -> tiles (read back as the lanes' own columns behind the exponentials)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int m = 0; m < NV; ++m) utile[i][m * kWave + lane] = make_double2(qux[i][m], quy[i][m]);
+    }
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       rowT[srow][ssl[m]] = vt[m]; rowD[srow][ssl[m]] = vd[m]; rowR[srow][ssl[m]] = rcp_nr(vd[m]); rowZ[srow][ssl[m]] = vz[m];
@@ -437,16 +543,25 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
       for (int q = 0; q < J; ++q) { SX[0][q] = cS[0][q]; SX[1][q] = cS[1][q]; }
       F[0] = cF[0]; F[1] = cF[1];
     }
-    double dtv[C], gv[C][2], igv[C][2];   // g, 1 / g of rows n_lo-1 .. n_lo+C-2 (entry r = row n_lo-1+r)
+    double gv[C][2], igv[C][2];   // g, 1 / g of rows n_lo-1 .. n_lo+C-2 (entry r = row n_lo-1+r)
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       // (rows of a short last segment beyond its end repeat the last row -- clamped loads -- so g = 1 there)
       const double tm = rowT[r][grp];
-      dtv[r] = tm - rowT[r + 1][grp];
+      gv[r][0] = exp_decay(cj[0] * (tm - tref));
+      igv[r][0] = rcp_nr(gv[r][0]);
+      if (ceq) { gv[r][1] = gv[r][0]; igv[r][1] = igv[r][0]; }
+      else { gv[r][1] = exp_decay(cj[1] * (tm - tref)); igv[r][1] = rcp_nr(gv[r][1]); }
+    }
+    if constexpr (LN) {   // rows 8k+1 .. 8k+7 from this segment's lines, row 8k+8 handed down by the segment above
+      lds_order();
+      iu[C - 1][0] = ucar[0]; iu[C - 1][1] = ucar[1];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        gv[r][m] = exp_decay(cj[m] * (tm - tref));
-        igv[r][m] = rcp_nr(gv[r][m]);
+      for (int i = 0; i < 4; ++i) {
+        const double2 a0 = utile[i][grp * 8 + jl], a1 = utile[i][grp * 8 + 4 + jl];
+        if (i == 0) { ucar[0] = a0.x; ucar[1] = a0.y; }
+        else { iu[2 * i - 1][0] = a0.x; iu[2 * i - 1][1] = a0.y; }
+        iu[2 * i][0] = a1.x; iu[2 * i][1] = a1.y;
       }
     }
 #pragma unroll
@@ -476,7 +591,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
       }
       if (r < cnt) {
         const int64_t n = n_lo + r;
-        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = dtv[r];
+        const double rdm = rowR[r][grp], zm = rowZ[r][grp], dt = rowT[r][grp] - rowT[r + 1][grp];
         double u[2], wm[2], xv[2], gn[2], ign[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -490,7 +605,24 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
         xg2(u[0], u[1], uX);
         xg2(wm[0], wm[1], wX);
         oBA[grp][r] = ban;
-        if (alive) bVb[n * LG] = make_double2(bVn[0] * gn[0], bVn[1] * gn[1]);
+        // (LN) rows n -- odd first, then even -- of a pair fill its tile; blocks start at odd rows: r odd <=> n even
+        double2 *ob = &otile[LN ? ((r + 1) / 2) & 1 : 0][0][grp * 8 + ((r & 1) ? 0 : 4) + jl];
+        if constexpr (LN) {
+          if (r % 2 == 0 && r + 1 < cnt) {   // the pair completed by the step before (row n + 1, even) leaves now
+            lds_order();
+            const int64_t P = (n + 1) / 2;
+#pragma unroll
+            for (int m = 0; m < NV; ++m) {
+              if (ok8[m]) {
+                bUl8[m][P * 8] = otile[((r + 2) / 2) & 1][0][m * kWave + lane];
+                bVl8[m][P * 8] = otile[((r + 2) / 2) & 1][1][m * kWave + lane];
+              }
+            }
+          }
+        } else {
+          if (alive) bVb[n * LG] = make_double2(bVn[0] * gn[0], bVn[1] * gn[1]);
+        }
+        const double bVo[2] = {bVn[0] * gn[0], bVn[1] * gn[1]};
         xg2(xv[0], xv[1], xX);
         double bpt[2], qv[2], bUo[2];
 #pragma unroll
@@ -512,7 +644,8 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
           bcj[m] = fma(dt, bpt[m], bcj[m]);
           qv[m] = q0 + q1;
         }
-        if (alive) bUb[n * LG] = make_double2(bUo[0], bUo[1]);
+        if constexpr (LN) { ob[0] = make_double2(bUo[0], bUo[1]); ob[2 * kWave] = make_double2(bVo[0], bVo[1]); }
+        else if (alive) bUb[n * LG] = make_double2(bUo[0], bUo[1]);
         double f = fma(cj[0], bpt[0], cj[1] * bpt[1]), Gs = fma(wm[0], bF[0], wm[1] * bF[1]),
                Q = fma(qv[0], wm[0], qv[1] * wm[1]);
         gsum3<LG>(f, Gs, Q);
@@ -551,9 +684,19 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
   }
   if (alive) {
     bab[0] = ban; btb[0] = carry;                            // row 0 (reverse.hpp:83-84)
+    reinterpret_cast<double2 *>(bc + L.b * J)[jl] = make_double2(bcj[0], bcj[1]);
+  }
+  if constexpr (LN) {   // row 0 completes pair 0 (row 1 is in the tile of even pairs since the last step)
+    otile[0][0][grp * 8 + jl] = make_double2(0.0, 0.0);
+    otile[0][1][grp * 8 + jl] = make_double2(bVn[0] * gtop[0], bVn[1] * gtop[1]);
+    lds_order();
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+      if (ok8[m]) { bUl8[m][0] = otile[0][0][m * kWave + lane]; bVl8[m][0] = otile[0][1][m * kWave + lane]; }
+    }
+  } else if (alive) {
     bVb[0] = make_double2(bVn[0] * gtop[0], bVn[1] * gtop[1]);
     bUb[0] = make_double2(0.0, 0.0);
-    reinterpret_cast<double2 *>(bc + L.b * J)[jl] = make_double2(bcj[0], bcj[1]);
   }
 }
 
@@ -606,11 +749,22 @@ int c2_internal_loglik_q4_grad(int64_t B, int64_t N, const double *t, int64_t t_
   static_assert(q4::A == 4, "k_anchor_spans measures spans of four segments");
   if (int e = c2_internal_anchor_spans(B, N, q4::J, q4::C, q4::SPW, t, t_bs, c, c_bs, words, stream)) return e;
   hipLaunchKernelGGL(q4::k_q4_gate, dim3(1), dim3(256), 0, s, (int64_t)l.waves, (const unsigned long long *)words, guard, gate);
-  hipLaunchKernelGGL(q4::k_q4_fwd, grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ck, l.nslot, W, DZ,
-                     (const unsigned long long *)gate);
-  hipLaunchKernelGGL(q4::k_q4_rev, grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, (const double2 *)W, (const double2 *)DZ,
-                     (const double2 *)ck, l.nslot, l.nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by,
-                     (const unsigned long long *)gate);
+  // rows of U, V, bU, bV as whole 128-byte lines (the LN instances): an even number of rows; C2_LOGLIK_Q4_LINES=0: row by row
+  // (they pay from ~11000 series, where the wavefronts of a CU queue at its address unit; below, their LDS instructions only cost)
+  const bool ln = N >= 2 && N % 2 == 0 &&
+                  (opt::has(opt::k_loglik_q4_lines) ? opt::ival(opt::k_loglik_q4_lines) != 0 : B >= opt::ival(opt::k_q4_lines_min_batch));
+#define C2_Q4_FWD_ARGS grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, ck, l.nslot, W, DZ, (const unsigned long long *)gate
+#define C2_Q4_REV_ARGS grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, (const double2 *)W, (const double2 *)DZ, (const double2 *)ck, \
+                       l.nslot, l.nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by, (const unsigned long long *)gate
+  if (ln) {
+    hipLaunchKernelGGL(q4::k_q4_fwd<true>, C2_Q4_FWD_ARGS);
+    hipLaunchKernelGGL(q4::k_q4_rev<true>, C2_Q4_REV_ARGS);
+  } else {
+    hipLaunchKernelGGL(q4::k_q4_fwd<false>, C2_Q4_FWD_ARGS);
+    hipLaunchKernelGGL(q4::k_q4_rev<false>, C2_Q4_REV_ARGS);
+  }
+#undef C2_Q4_FWD_ARGS
+#undef C2_Q4_REV_ARGS
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

@@ -1500,7 +1500,7 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   }
   // a wavefront per series, lanes over 64 consecutive rows of either grid (c2_general_tile.hip)
   // (three right-hand sides on a large batch: lanes over the right-hand sides are ahead, 3.45 against 3.79 ms at B = 8192,
-  // N = M = 4096, J = 8, tools/ab_general.py; small batches keep the tiles, which cut long series into chunks)
+  // N = M = 4096, J = 8, in-process A/B; small batches keep the tiles, which cut long series into chunks)
   if (use_general_tile() && !(nrhs == 3 && B >= 512 && use_generalK())) {
     // small batches of long series are cut into chunks along time: a stream-ordered temporary for the chunk maps (not
     // inside a graph capture, and one wavefront per series if the allocation fails)

@@ -27,7 +27,7 @@ namespace c2r {
 using namespace c2;
 
 // Section timing of the multi-rhs reverse step of k_sweepK_rev (diagnostic builds only: tools/build_variant.sh prof
-// c2_sweep_rev.hip -DC2R_PROF; tools/sweepk_rev_sections.py).
+// c2_sweep_rev.hip -DC2R_PROF).
 #ifdef C2R_PROF
 __device__ unsigned long long c2r_prof[8];
 #define C2R_TICK(k)                                                    \
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kWave) void k_sweepK_rev(int64_t B, int64_t N, int 
 // ---- nrhs = J = 8 on full wavefronts: every width-8 row moves as half of an aligned 128-byte LINE ---------------------------
 // k_sweepK_rev above asks for every row of U, W, X, bZ on its own and stores every row of bU, bW, bY on its own: 64-byte
 // requests, fifteen memory instructions per step.  With one wavefront per SIMD the step is then bound by how fast the CU
-// accepts REQUESTS, not by bytes or arithmetic (tools/sweepk_rev_sections.py: of 4700 cycles per step 2000 go into issuing
+// accepts REQUESTS, not by bytes or arithmetic (section timers of a -DC2R_PROF build: of 4700 cycles per step 2000 go into issuing
 // the nine loads and 1900 into the sections that hold the six stores; taking two 64-byte loads out of the step saves 16 % of
 // it, two stores 18 %, three of the four 128-byte workspace requests only 7 %).  Here the rows of a series pair up into the
 // aligned lines (2 l, 2 l + 1) they share in memory: one 16-byte piece per lane, one request per line and array every two

@@ -172,7 +172,7 @@ void launch_g(int kt, int64_t B, int64_t N, int64_t J, const double *t, int64_t 
 extern "C" int c2_internal_sweepT(int lower, int solve, int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t,
                                   int64_t t_bs, const double *c, int64_t c_bs, const double *U, const double *V,
                                   const double *Y, double *Z, double *F, int zero_z, c2_stream_t stream) {
-  // measured at B = 8192, N = 4096, J = 8 against the lanes-over-rhs kernel (tools/ab_fwd_small.sh): 2 / 3 / 4 / 5 right-hand
+  // measured at B = 8192, N = 4096, J = 8 against the lanes-over-rhs kernel (in-process A/B): 2 / 3 / 4 / 5 right-hand
   // sides 1.94 / 1.87 / 1.87 / 1.97 -> 1.42 / 1.50 / 1.64 / 1.78 ms, level at 7; with the workspace 2.73 / 3.51 -> 2.42 / 3.20 ms
   // at 2 / 3 and behind from 4 (there the other kernel sends whole workspace rows through an LDS tile)
   if (nrhs < 2 || nrhs > (F ? 3 : 5) || J > 32 || N < 2) return C2_ERR_UNSUPPORTED;

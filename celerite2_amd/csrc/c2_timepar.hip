@@ -20,7 +20,7 @@
 // the bench data), so the result is VERIFIED: a chunk's sequentially computed end state must match the next chunk's
 // start state; k_tp_finish writes the worst relative mismatch / 2.5e-11 into a device word and the ordinary kernel --
 // launched behind it with that word as its gate (gate_closed, c2_loglik_helpers.hpp) -- recomputes the batch if it
-// exceeds kBackwardGuard (= 2) or if any factorisation failed.  numpy prototype: tools/proto/timepar.py.
+// exceeds kBackwardGuard (= 2) or if any factorisation failed.  numpy prototype: tools/proto/timepar.py in the history (git show cd74ef8:tools/proto/timepar.py).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

@@ -21,10 +21,10 @@
 // gradients.  That sweep needs the states S_n, F_n entering each row in reverse order: the chunk replays them forward
 // into a lane-major scratch record first (no backward recursion, hence no stability condition).
 //
-// tools/proto/tpg.py is the same construction in numpy, checked against the sequential oracle.
+// git show cd74ef8:tools/proto/tpg.py is the same construction in numpy, checked against the sequential oracle.
 //
 // Also here, because they share the chunk machinery:
-//  * `factor` by NEWTON iterations on the chunk start states (k_newton_*; tools/proto/factor_newton.py) -- what the
+//  * `factor` by NEWTON iterations on the chunk start states (k_newton_*; prototype: git show cd74ef8:tools/proto/factor_newton.py) -- what the
 //    forward quantities above come from at every width but 4 / 2, and on long series there as well;
 //  * z = L^-1 y by affine chunk maps at any even width (k_solve_*), and the forward-only log-likelihood composed from
 //    the two (c2_internal_loglik_wide);
@@ -1198,7 +1198,7 @@ static int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double
 //       its end state E_k = f_k(X_k) and Phi_k (a J x J product carried along);
 //   (2) k_newton_chain: one wavefront per series walks the chunks, delta_{k+1} = Phi_k delta_k Phi_k^T + E_k - X_{k+1},
 //       X_{k+1} += delta_{k+1}, and writes the largest relative update into the iteration's device word.
-// Convergence is quadratic (tools/proto/factor_newton.py: updates 1, 4e-2, 3e-4, 2e-8, 2e-15 on the bench series); the
+// Convergence is quadratic (the numpy prototype: updates 1, 4e-2, 3e-4, 2e-8, 2e-15 on the bench series); the
 // update of iteration p measures the error of the X that pass p used, so the iterations stop -- each is launched behind
 // the previous word as its gate -- once it is below kNewtonTol, with d, W of that pass final.  If the last iteration still
 // moves, or a pass met a d that is not positive and finite, the caller's row-by-row kernel runs behind the last word.
@@ -1217,7 +1217,7 @@ __device__ __forceinline__ double newton_tol(const unsigned long long *kapw) {
 // 4e-15 (kappa = 90), 7e-15 (340), 1.1e-14 (1300), 2.6e-14 (5400) of the state -- the floor of float64, not an error that another
 // iteration removes -- while kNewtonCondTol / kappa asks for 7.7e-15 at kappa = 1300: round 3's rule sent every such batch
 // through all eight iterations AND the row-by-row kernel (the 1-D problem inside BASELINE configs[4], white noise 1 / A =
-// 0.0125: 2.4 -> 22 ms; tools/newton_words.py).  Convergence is quadratic, so an iteration whose PREDECESSOR's update was
+// 0.0125: 2.4 -> 22 ms).  Convergence is quadratic, so an iteration whose PREDECESSOR's update was
 // already below kNewtonBasin started from a state good to ~0.1 kNewtonBasin^2: its own update is that floor, and it stands if it is below
 // kNewtonFloorTol (anything larger is not rounding).  d, W then carry kappa x floor -- what the row-by-row recursion carries
 // too (no float64 order beats eps kappa).

@@ -145,7 +145,7 @@ class ConditionalDistribution:
 
     def __init__(self, gp, y, t=None, *, include_mean=True, kernel=None):
         self.gp, self.y, self.t, self.include_mean, self.kernel = gp, y, t, include_mean, kernel
-        self._KxsT = self._Kinv_KxsT = None
+        self._KxsT = self._Kinv_KxsT = self._mean = None
         self._mats2 = self._mats1 = None
         if t is None:
             self._xs = gp._t
@@ -196,16 +196,19 @@ class ConditionalDistribution:
         return target[..., 0] if vec else target
 
     @property
-    def mean(self):      # core.py:115-132
-        gp = self.gp
-        alpha = gp.apply_inverse(self.y - gp.mean)
-        if self.t is None and self.kernel is None:
-            mu = self.y - gp._diag * alpha
-            return mu if self.include_mean else mu - gp.mean
-        B = gp._diag.shape[0]
-        mu = torch.zeros((B, self._xs.shape[-1]), dtype=torch.float64, device=gp._diag.device)
-        mu = self._do_dot(alpha, mu)
-        return mu + gp.mean if self.include_mean else mu
+    def mean(self):      # core.py:115-132 (computed once per distribution: predict(return_var / return_cov) and sample() reuse it)
+        if self._mean is None:
+            gp = self.gp
+            alpha = gp.apply_inverse(self.y - gp.mean)
+            if self.t is None and self.kernel is None:
+                mu = self.y - gp._diag * alpha
+                self._mean = mu if self.include_mean else mu - gp.mean
+            else:
+                B = gp._diag.shape[0]
+                mu = torch.zeros((B, self._xs.shape[-1]), dtype=torch.float64, device=gp._diag.device)
+                mu = self._do_dot(alpha, mu)
+                self._mean = mu + gp.mean if self.include_mean else mu
+        return self._mean
 
     @property
     def variance(self):  # core.py:134-140 + numpy.py:24-25: k(0) - diag(KxsT' K^-1 KxsT), (B, M)

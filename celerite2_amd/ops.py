@@ -277,7 +277,7 @@ def loglik_grad_buffers(t, c, a, U, V, y, *, candidates=3):
     workspace and the gradient arrays lie relative to the inputs moves its time by 6 - 10 % -- deterministically: the same
     process re-allocating the same arrays behind a spacer of a few tens of GiB switches between 28.2 and 31.5 ms for
     65536 x 4096 x 8, shifts of MiB change nothing, a plain copy between 16-GiB buffers does not care
-    (profiles/r04_headline_spread.md; tools/shift_probe.py, tools/spacer_probe.sh, tools/hbm_region_probe.py).  So: time one
+    (profiles/r04_headline_spread.md).  So: time one
     step on the allocator's own placement, then on fresh allocations behind spacers of 24 and 48 GiB (more with
     `candidates`), and keep the fastest.  Returns (work, out, report) -- `report` lists every candidate's time."""
     B, N, J = _dims(U)
@@ -303,7 +303,11 @@ def loglik_grad_buffers(t, c, a, U, V, y, *, candidates=3):
     work, out = fresh()
     cand = [{"spacer_GiB": 0, "ms": one_step_ms(work, out)}]
     best_ms = cand[0]["ms"]
-    for gib in [24, 48, 12, 72, 96][:max(0, candidates - 1)]:
+    # spacers scaled to the memory that is actually free (24 / 48 GiB on a 288-GB part holding the bench shape)
+    free_gib = torch.cuda.mem_get_info(dev)[0] / 2**30
+    need_gib = (work.numel() * 8 + sum(o.numel() for o in out) * 8) / 2**30
+    room = max(0.0, free_gib - need_gib - 2.0)
+    for gib in [g for g in (24, 48, 12, 72, 96) if g <= room][:max(0, candidates - 1)]:
         sp = w_ = o_ = None
         try:
             sp = torch.empty(gib * 2**30, dtype=torch.uint8, device=dev)

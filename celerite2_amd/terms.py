@@ -47,11 +47,15 @@ class Term:
         tau = tau.abs()
         extra = (1,) * (tau.dim() - 1)
 
+        dev_arrays = {}   # one upload per coefficient ARRAY (not per coefficient and term)
+
         def co(v, j):   # coefficient j as a tensor broadcastable against tau: () or (B, 1, ..)
             v = np.asarray(v, dtype=np.float64)
             if v.ndim == 1:
                 return float(v[j])
-            return torch.from_numpy(np.ascontiguousarray(v[:, j])).to(tau.device).reshape((-1,) + extra)
+            if id(v) not in dev_arrays:
+                dev_arrays[id(v)] = (v, torch.from_numpy(np.ascontiguousarray(v)).to(tau.device))
+            return dev_arrays[id(v)][1][:, j].reshape((-1,) + extra)
 
         k = torch.zeros_like(tau)
         for j in range(ar.shape[-1]):

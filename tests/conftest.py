@@ -41,7 +41,7 @@ def golden_kron():
 # Counters the time-parallel-gradient fuzz fills in (tests/test_gpu_fuzz.py::_tpg_check): how many draws pass the PLAIN
 # north_star criterion (1e-10 of the array's largest entry) and how many needed the extended-precision floor term of
 # DESIGN.md section 5 -- printed with the run's summary so the log says it where people look.
-TPG_STATS = {"draws": 0, "needed_floor": 0, "needed_floor_seeds": [], "worst_plain": 0.0}
+TPG_STATS = {"draws": 0, "needed_floor": 0, "needed_floor_seeds": [], "worst_plain": 0.0, "floor_details": []}
 
 
 def pytest_terminal_summary(terminalreporter):
@@ -51,3 +51,8 @@ def pytest_terminal_summary(terminalreporter):
             "(the rest pass 1e-10 of the largest entry outright); worst plain distance %.2e; seeds needing the floor: %s"
             % (TPG_STATS["draws"], TPG_STATS["needed_floor"], TPG_STATS["worst_plain"],
                sorted(set(TPG_STATS["needed_floor_seeds"]))[:40]))
+        for form, seed, w, wx, ox in TPG_STATS["floor_details"][:20]:
+            terminalreporter.write_line(
+                "    %s, seed %d: %.2e from the float64 oracle; %.2e from its extended-precision evaluation, from which the "
+                "float64 oracle itself is %.2e (%s)" % (form, seed, w, wx, ox,
+                "the device is the closer of the two to the exact result" if wx < ox else "the oracle is closer"))

@@ -352,14 +352,17 @@ def _tpg_check(ops, oracle, monkeypatch, seed, forced=True):
     lln = ll.cpu().numpy()
     assert np.isneginf(lln[failed]).all()
     np.testing.assert_array_less(np.abs(lln[ok] - llo[ok]), 1e-10 * np.abs(llo[ok]) + 4.0 * np.abs(llo[ok] - llx[ok]) + 1e-300)
-    worst = 0.0
+    worst = worst_x = oracle_x = 0.0   # device vs oracle, device vs the extended-precision evaluation, oracle vs the same
     for g, e, x in zip(grads, go, gx):
         gn = g.cpu().numpy()
         assert np.isnan(gn[failed]).all()
         for b in np.nonzero(ok)[0]:
             floor = float(np.abs(e[b] - x[b]).max())
             np.testing.assert_allclose(gn[b], e[b], rtol=0.0, atol=1e-10 * max(np.abs(e[b]).max(), 1e-300) + 4.0 * floor)
-            worst = max(worst, float(np.abs(gn[b] - e[b]).max() / max(np.abs(e[b]).max(), 1e-300)))
+            big = max(np.abs(e[b]).max(), 1e-300)
+            worst = max(worst, float(np.abs(gn[b] - e[b]).max() / big))
+            worst_x = max(worst_x, float(np.abs(gn[b] - np.asarray(x[b], dtype=np.float64)).max() / big))
+            oracle_x = max(oracle_x, floor / big)
     ll0, flag0 = ops.loglik(*args)
     assert np.array_equal(flag0.cpu().numpy() != 0, failed)
     np.testing.assert_array_less(np.abs(ll0.cpu().numpy()[ok] - llo[ok]), 1e-10 * np.abs(llo[ok]) + 4.0 * np.abs(llo[ok] - llx[ok]) + 1e-300)
@@ -369,6 +372,9 @@ def _tpg_check(ops, oracle, monkeypatch, seed, forced=True):
     if worst > 1e-10:
         TPG_STATS["needed_floor"] += 1
         TPG_STATS["needed_floor_seeds"].append(("time-parallel" if forced else "row-by-row", seed))
+        # ... and where such a draw stands against the EXACT result (the extended-precision evaluation): the device's
+        # distance to it beside the float64 oracle's own
+        TPG_STATS["floor_details"].append(("time-parallel" if forced else "row-by-row", seed, worst, worst_x, oracle_x))
     return worst
 
 

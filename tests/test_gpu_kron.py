@@ -34,7 +34,7 @@ def close(a, b, tol=1e-10, floor=1e-12):
 
 # The collapsed method is a different (mathematically equivalent) formulation from the oracle's interleaved recursion:
 # the two agree to the conditioning of the problem, k(0) / (effective per-epoch noise 1/A) ~ 1e3..1e4 here, i.e.
-# 1e-12..1e-10 of the largest element (measured: tools/kron_err.py; the interleaved method, which shares the oracle's
+# 1e-12..1e-10 of the largest element (measured in round 2; the interleaved method, which shares the oracle's
 # arithmetic, agrees to 1e-12).  Log-likelihoods agree to 1e-13.
 COLLAPSED_FLOOR = 5e-10
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/shard_ab.sh: bench step at the shards of configs[2] in fresh processes on ONE box -- the dispatch's choice against the
-# round-3 kernels forced (C2_LANES=1 at 32768 series; C2_LOGLIK_BACK=0 C2_LANES=8 at 16384 and 8192), three processes each
+# previous round's kernels forced, three processes each
 R=${GRAFT_REPO_ROOT:-/root/repo}
 run() {  # label, batch, env...
   local label=$1 b=$2; shift 2
@@ -11,7 +11,7 @@ run() {  # label, batch, env...
 }
 run "two lanes (default)      " 32768 C2_NOP=1
 run "one lane (round 3)       " 32768 C2_LANES=1
-run "8 lanes backward (default)" 16384 C2_NOP=1
-run "8 lanes replay (round 3) " 16384 C2_LANES=8 C2_LOGLIK_BACK=0
-run "8 lanes backward (default)" 8192 C2_NOP=1
-run "8 lanes replay (round 3) " 8192 C2_LOGLIK_BACK=0
+run "four lanes (default)      " 16384 C2_NOP=1
+run "8 lanes (round 4)         " 16384 C2_LANES=8 C2_LOGLIK_SCALED=0
+run "8 lanes, scaled frame (default)" 8192 C2_NOP=1
+run "8 lanes, plain frame (round 4)" 8192 C2_LOGLIK_SCALED=0

@@ -1338,13 +1338,14 @@ static bool solve_cols_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   const double bytes = (double)B * (double)N * 8.0 * (double)(2 * nrhs + 2 * J + 1);
   double rows_ms = 1e-3 * (double)N * 0.26 * wide * (waves > 2048.0 ? waves / 2048.0 : 1.0);
   if (bytes / 3e9 > rows_ms) rows_ms = bytes / 3e9;
-  // chunk maps over the columns: 0.12 ms for the three launches and their temporary + 4e-5 ms per wavefront-walk of 64 rows
-  // (1 x 4096: 0.16 ms with 64 or 256 right-hand sides, 0.43 with 1024; 64 x 4096: 0.38 / 0.84 / 2.8 ms)
+  // chunk maps over the columns: 0.10 ms for the three launches and their temporary + 3.4e-5 ms per wavefront-walk of 64 rows
+  // (x 1.5 at J = 16).  Re-fitted in round 5 on 60 shapes (tools/cols_probe.py: B = 16 ... 256, 64 ... 1024 right-hand sides,
+  // J = 4, 8, 16; 64 x 4096 x 256: 0.84 against 1.14 ms row by row, 128 x 4096 x 128: 0.92 against 1.14 -- both were missed)
   int64_t Lc = 64;
   while (Lc < 1024 && (double)B * (double)((N + Lc - 1) / Lc) * tiles > 8192.0) Lc *= 2;   // (the plan of c2_solve_cols.hip)
   const double K = (double)((N + Lc - 1) / Lc), cw = (double)B * K * (tiles + 1.0) * (double)Lc / 64.0;
-  const double cols_ms = 0.12 + 4e-5 * wide * cw;
-  return cols_ms < 0.8 * rows_ms;
+  const double cols_ms = 0.10 + 3.4e-5 * (J > 8 ? 1.5 : 1.0) * cw;
+  return cols_ms < 0.9 * rows_ms;
 }
 static bool solve_chunks_enabled() {
   return !(opt::has(opt::k_timepar) && opt::ival(opt::k_timepar) == 0);   // the switch of the time-parallel solves: 0 keeps them row by row

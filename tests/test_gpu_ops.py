@@ -509,7 +509,7 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, lanes, J):
 
 
 @pytest.mark.parametrize("J", [8, 7, 4, 3, 2, 1])
-@pytest.mark.parametrize("N", [2, 9, 10, 41, 130])
+@pytest.mark.parametrize("N", [2, 9, 10, 41, 130, 258])
 def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypatch, J, N):
     """The group mappings (up to eight lanes per series, c2_loglik.hip) run their reverse sweep by the BACKWARD recursion
     from recorded W rows, re-anchored at every fourth checkpoint (32 rows) or -- where c * span over 32 rows is beyond the
@@ -534,9 +534,11 @@ def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypa
         assert int(np.abs(flo).sum()) == 0
         args = dev(tg, c, a, U, V, y)
         # (backward recursion in the scaled frame -- the default --, in the plain frame, and the replay alone)
-        for back, scaled in (("1", "1"), ("1", "0"), ("0", "1")):
+        # ... and the scaled form with the rows of U, V, bU, bV as 128-byte lines (C2_LOGLIK_LINES=1: J = 8, even N; off by default)
+        for back, scaled, lines in (("1", "1", "0"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "1")):
             monkeypatch.setenv("C2_LOGLIK_BACK", back)
             monkeypatch.setenv("C2_LOGLIK_SCALED", scaled)
+            monkeypatch.setenv("C2_LOGLIK_LINES", lines)
             ll, grads, flag = ops.loglik_grad(*args)
             assert int(flag.abs().sum()) == 0
             close(ll, llo)
@@ -544,15 +546,20 @@ def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypa
                 close(g, e, floor=4e-12)
         monkeypatch.delenv("C2_LOGLIK_BACK")
         monkeypatch.delenv("C2_LOGLIK_SCALED")
+        monkeypatch.delenv("C2_LOGLIK_LINES")
 
 
-@pytest.mark.parametrize("N", [1, 2, 9, 32, 33, 34, 64, 65, 97, 130, 300])
-def test_four_lane_pair_scaled_frame_and_its_fallback(ops, oracle, monkeypatch, N):
+@pytest.mark.parametrize("lines", ["1", "0"])
+@pytest.mark.parametrize("N", [1, 2, 9, 32, 33, 34, 64, 65, 66, 97, 130, 300])
+def test_four_lane_pair_scaled_frame_and_its_fallback(ops, oracle, monkeypatch, N, lines):
     """Four lanes per series (c2_loglik_q4.hip, J = 8: both kernels in a scaled frame between anchors 32 rows apart).  Series
     lengths around the anchors (a last segment that is empty, partial, exactly full, itself an anchor); batches in which some
     groups of 64 series have gaps in time (those groups are closed by k_q4_gate and taken by the replay pair behind), all
     of them, none; a grid sparse enough that every group is closed; a ragged last wavefront."""
     monkeypatch.setenv("C2_LANES", "4")
+    # rows of U, V, bU, bV as 128-byte lines through LDS tiles (automatic from 11264 series, forced here; series with an odd
+    # number of rows take the row-by-row instances either way) and one 64-byte row of sixteen series at a time
+    monkeypatch.setenv("C2_LOGLIK_Q4_LINES", lines)
     B, J = 150, 8   # ten wavefronts of 16 series (the last one ragged), three groups of 64
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
     rng = np.random.default_rng(4400 + N)

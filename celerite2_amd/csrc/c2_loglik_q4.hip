@@ -25,6 +25,10 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+#ifndef C2_Q4_LN_R
+#define C2_Q4_LN_R 16   // rows per block of the forward kernel's LN instance (8: scalar requests as 64-byte runs; A/B builds)
+#endif
+
 namespace c2 {
 namespace q4 {
 
@@ -106,13 +110,15 @@ __global__ __launch_bounds__(256) void k_q4_gate(int64_t nwaves, const unsigned 
 // Forward pass with records, scaled frame.  One step ahead of the chain: ih_{n+1} = exp(-c (t_{n+1} - t_ref)), its
 // reciprocal, u-_{n+1} = U_{n+1} ih_{n+1} and its gather through LDS (off the chain).
 // =============================================================================
-constexpr int R = 8;   // rows per block of the transposed scalar streams and of the row ring (= C; an anchor every A blocks)
 // LN (N even): the rows of U and V arrive as whole aligned 128-byte lines -- rows (2P, 2P+1) of a series share one.  The four
 // lanes of a series would request 64 bytes of sixteen different lines per instruction (what this mapping queues on at the
 // CU's address unit once every SIMD has its wavefront: profiles/r05_four_lanes.md); instead one instruction fetches the
 // pair of eight series (lane l: series (l >> 3) + 8 m of the wavefront, 16-byte piece l & 7), a ring of four pairs in
 // registers runs eight rows ahead, and a per-wave LDS tile hands every lane its own two columns one pair ahead of their use.
-template <bool LN>
+// R = rows per block of the transposed scalar streams (and of the row ring without LN): 8, or 16 with LN -- then a scalar
+// request is one whole 128-byte line per series (four series per instruction) instead of a 64-byte run, and t, a, y enter
+// the chip once instead of twice (the second half of a line does not survive eight rows in the cache).
+template <bool LN, int R>
 __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                                      const double *__restrict__ U, const double *__restrict__ V,
@@ -157,19 +163,26 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
 
   // Per-series scalar streams move TRANSPOSED, eight lanes per series: one instruction fetches eight consecutive rows of
   // eight series (64-byte runs; lane l: series (l >> 3) + 8 m of the wavefront, row l & 7), two cover the sixteen.
-  const int srow = lane & 7;
+  static_assert(R == 8 || R == 16, "blocks of 8 or 16 rows");
+  constexpr int SPI = kWave / R;        // series per scalar instruction (R lanes per series: rows of a block)
+  const int srow = lane & (R - 1);
   int ssl[NV];
   const double *tb8[NV], *ab8[NV], *yb8[NV];
-  const double2 *Ul8[NV], *Vl8[NV];   // (LN) piece `srow` of the row pairs of series slot ssl[m]
   double2 *dz8[NV];
 #pragma unroll
   for (int m = 0; m < NV; ++m) {
-    ssl[m] = (lane >> 3) + 8 * m;
+    ssl[m] = lane / R + SPI * m;
     const int64_t bs = (L.b0 + ssl[m] < B) ? L.b0 + ssl[m] : B - 1;
     tb8[m] = t + bs * t_bs; ab8[m] = a + bs * N; yb8[m] = y + bs * N;
     dz8[m] = DZst + bs * N;
-    Ul8[m] = reinterpret_cast<const double2 *>(U + bs * N * J) + srow;
-    Vl8[m] = reinterpret_cast<const double2 *>(V + bs * N * J) + srow;
+  }
+  // (LN) row pairs: eight lanes per series (piece lane & 7 of the 128 bytes), two instructions for the sixteen series
+  const double2 *Ul8[2], *Vl8[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int64_t bs = (L.b0 + (lane >> 3) + 8 * m < B) ? L.b0 + (lane >> 3) + 8 * m : B - 1;
+    Ul8[m] = reinterpret_cast<const double2 *>(U + bs * N * J) + (lane & 7);
+    Vl8[m] = reinterpret_cast<const double2 *>(V + bs * N * J) + (lane & 7);
   }
   double vt[NV], va[NV], vy[NV];
   auto vload = [&](int64_t nb) {
@@ -202,20 +215,20 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   // LN: ring slot P % 4 holds the pieces of pair P (two instructions: series slots 0 - 7 and 8 - 15 of the wavefront)
   __shared__ __attribute__((aligned(16))) double2 ltile[LN ? 2 : 1][LN ? 2 * kWave : 1];   // [U | V][series][piece]
   const int64_t plast = N / 2 - 1;
-  double qux[LN ? 4 : 1][NV], quy[LN ? 4 : 1][NV], qvx[LN ? 4 : 1][NV], qvy[LN ? 4 : 1][NV];
+  double qux[LN ? 4 : 1][2], quy[LN ? 4 : 1][2], qvx[LN ? 4 : 1][2], qvy[LN ? 4 : 1][2];
   double cu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, cv[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // [row of the pair][column]: current pair
   double nu[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, nv[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // ... the next one
   auto pair_load = [&](int slot, int64_t P) {
     const int64_t Pc = P < plast ? P : plast;
 #pragma unroll
-    for (int m = 0; m < NV; ++m) {
+    for (int m = 0; m < 2; ++m) {
       const double2 a2 = Ul8[m][Pc * 8], b2 = Vl8[m][Pc * 8];
       qux[slot][m] = a2.x; quy[slot][m] = a2.y; qvx[slot][m] = b2.x; qvy[slot][m] = b2.y;
     }
   };
   auto pair_stage = [&](int slot) {
 #pragma unroll
-    for (int m = 0; m < NV; ++m) {
+    for (int m = 0; m < 2; ++m) {
       ltile[0][m * kWave + lane] = make_double2(qux[slot][m], quy[slot][m]);
       ltile[LN ? 1 : 0][m * kWave + lane] = make_double2(qvx[slot][m], qvy[slot][m]);
     }
@@ -368,8 +381,9 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   int64_t n0 = 1, blk = 0;
   int q = 0;
   auto advance = [&]() { up += R * LG; vp += R * LG; q ^= 1; ++blk; };
-  for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, blk % A == A - 1, std::false_type{}); advance(); }   // every row load in range
-  for (; n0 < N; n0 += R) { block(n0, q, blk % A == A - 1, std::true_type{}); advance(); }
+  constexpr int BA = A * C / R;   // blocks between two anchors (32 rows)
+  for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, blk % BA == BA - 1, std::false_type{}); advance(); }   // every row load in range
+  for (; n0 < N; n0 += R) { block(n0, q, blk % BA == BA - 1, std::true_type{}); advance(); }
 
   {  // the state after the last row, plain (hp = h of the last row in the current frame; 1 right behind an anchor)
     const double il[2] = {rcp_nr(hp[0]), rcp_nr(hp[1])};
@@ -757,10 +771,10 @@ int c2_internal_loglik_q4_grad(int64_t B, int64_t N, const double *t, int64_t t_
 #define C2_Q4_REV_ARGS grid, dim3(kWave), 0, s, B, N, t, t_bs, c, c_bs, U, (const double2 *)W, (const double2 *)DZ, (const double2 *)ck, \
                        l.nslot, l.nseg, (const int32_t *)flag, bt, bc, ba, bU, bV, by, (const unsigned long long *)gate
   if (ln) {
-    hipLaunchKernelGGL(q4::k_q4_fwd<true>, C2_Q4_FWD_ARGS);
+    hipLaunchKernelGGL((q4::k_q4_fwd<true, C2_Q4_LN_R>), C2_Q4_FWD_ARGS);
     hipLaunchKernelGGL(q4::k_q4_rev<true>, C2_Q4_REV_ARGS);
   } else {
-    hipLaunchKernelGGL(q4::k_q4_fwd<false>, C2_Q4_FWD_ARGS);
+    hipLaunchKernelGGL((q4::k_q4_fwd<false, 8>), C2_Q4_FWD_ARGS);
     hipLaunchKernelGGL(q4::k_q4_rev<false>, C2_Q4_REV_ARGS);
   }
 #undef C2_Q4_FWD_ARGS

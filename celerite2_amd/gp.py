@@ -97,9 +97,9 @@ class GaussianProcess:
     def apply_inverse(self, y):
         self._need()
         Y, vec = self._as_matrix(y)
-        z = ops.solve_lower(self._t, self._c, self._U, self._W, Y.contiguous())
-        z = z / self._d[..., None]
-        z = ops.solve_upper(self._t, self._c, self._U, self._W, z.contiguous())
+        z = ops.solve_lower(self._t, self._c, self._U, self._W, Y.contiguous())   # (a fresh array: the caller keeps y)
+        z.div_(self._d[..., None])                                                 # ... scaled and solved again in place
+        z = ops.solve_upper(self._t, self._c, self._U, self._W, z, Z=z)
         return z[..., 0] if vec else z
 
     # -- core.py:378-405 + numpy.py:100-102 --------------------------------------------------------------
@@ -214,7 +214,7 @@ class ConditionalDistribution:
     def variance(self):  # core.py:134-140 + numpy.py:24-25: k(0) - diag(KxsT' K^-1 KxsT), (B, M)
         B = self.gp._diag.shape[0]
         k0 = self._kernel().get_value_device(torch.zeros((B, 1), dtype=torch.float64, device=self.gp._diag.device))
-        return k0 - (self.KxsT * self.Kinv_KxsT).sum(dim=1)
+        return k0 - torch.linalg.vecdot(self.KxsT, self.Kinv_KxsT, dim=1)   # (one pass over the two N x M arrays)
 
     @property
     def covariance(self):  # core.py:142-150: k(xs - xs') - K(xs, t) K^-1 K(t, xs), (B, M, M)

@@ -36,7 +36,7 @@
   X(timepar_max_batch_x_width, "C2_TIMEPAR_MAX_BATCH_X_WIDTH", 8192, 't', "largest B * J the time-parallel forward pass takes", "linear in the batch beyond one wavefront per SIMD: 0.98 ms at 4096 series of J = 4 where row by row takes 0.87") \
   X(timepar_grad, "C2_TIMEPAR_GRAD", 0, 's', "log-likelihood GRADIENT (and factor_rev) parallel along time, widths 1 .. 8: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_grad_time.py, profiles/r02_timepar_grad.md") \
   X(timepar_grad_min_rows, "C2_TIMEPAR_GRAD_MIN_ROWS", 1024, 't', "shortest series the time-parallel gradient takes at widths 7, 8 beyond a handful of series (768 at widths 3 .. 6, 512 at 1, 2; 256 for at most 4096 chunks)", "one series draws level at ~400 / ~600 / ~800 rows at J = 2 / 4, 6 / 8 (tools/timepar_grad_time.py)") \
-  X(timepar_grad_min_rows_handful, "C2_TIMEPAR_GRAD_MIN_ROWS_HANDFUL", 256, 't', "shortest series the time-parallel gradient takes for a handful of series (at most 4096 chunks of 64 rows; they run with 16-row chunks)", "round 3, with the device-side verification and its gated kernels in the call: level with row by row at 256 rows (J = 8: 0.318 vs 0.321 ms, J = 2: 0.194 vs 0.213), 0.41 vs 0.59 ms at 512 (tools/crossovers.py)") \
+  X(timepar_grad_min_rows_handful, "C2_TIMEPAR_GRAD_MIN_ROWS_HANDFUL", 384, 't', "shortest series the time-parallel gradient takes for a handful of series (at most 4096 chunks of 64 rows; they run with 16-row chunks)", "round 5 (the row-by-row pair in the scaled frame), one series, J = 8: 0.336 vs 0.276 ms row by row at 256 rows, 0.381 vs 0.376 at 384, 0.430 vs 0.476 at 512, 0.87 vs 3.25 at 4096 (tools/crossovers.py)") \
   X(timepar_grad_max_chunks, "C2_TIMEPAR_GRAD_MAX_CHUNKS", 32768, 't', "largest number of 64-row chunks (B * ceil(N / 64)) the time-parallel gradient takes", "1024 x 4096 at J = 4: 3.6 vs 3.0 ms row by row") \
   X(timepar_cond_limit, "C2_TIMEPAR_COND_LIMIT", 0, 't', "if > 0: largest conditioning kappa = max a_n / d_n for which the result of the time-parallel gradient stands; beyond it the row-by-row kernels recompute the batch behind the device-side gate (0, the default: no limit)", "rounding moves ANY float64 evaluation by c eps kappa^2 of the largest gradient entry: the oracle itself c = 0.4 (against its own extended-precision evaluation), the row-by-row kernels ~0.05, the time-parallel form ~0.01 and 0.6 in the worst draw of 9000 -- typically the closer of the two to the oracle, hence no limit by default (tools/kappa_sweep.py, tools/verify_words.py, profiles/r03_timepar_verification.md)") \
   X(verify_fallback, "C2_VERIFY_FALLBACK", 1, 's', "0 (diagnostics only): keep the result of a time-parallel form whatever its device-side verification says", "tools/verify_words.py") \

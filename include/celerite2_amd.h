@@ -12,6 +12,12 @@
  *     (python/celerite2/driver.cpp:13-21).
  *   - Caller allocates every output and workspace; the library keeps no state
  *     between calls and allocates no user-visible memory (driver.cpp:13-64).
+ *     Internal scratch of a few entry points (time-parallel forms, many
+ *     right-hand sides) is a stream-ordered temporary from a memory pool the
+ *     LIBRARY owns (one per device, up to 1 GiB kept cached between calls); the
+ *     device's default pool, which the process shares with everybody else, is
+ *     never reconfigured.  The c2h_* host entry points keep one staging arena,
+ *     pinned bounce buffer and stream PER CALLING THREAD (re-entrant).
  *   - Exact-pointer aliasing the reference allows is allowed here too:
  *     d == a and W == V for factor (forward.hpp:55-58), Z == Y for
  *     solve_* / matmul_* (numpy.py:95-108).

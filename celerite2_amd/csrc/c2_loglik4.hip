@@ -7,8 +7,8 @@
 // replicates or pays per lane group -- the scalar chain (reductions, reciprocal), the cross-lane traffic (a
 // quad_perm-only gather of 2 doubles from 3 partners instead of 7, two butterfly levels instead of three), the
 // LDS gathers (one ds_read_b128 per partner) -- at the price of twice the per-series register/LDS footprint per
-// wavefront, hence a checkpoint interval of 4 instead of 8.  It needs >= 1024 * 64/LG series to fill the chip
-// (16384 at J = 8), so it is the large-batch variant; c2_loglik.hip stays the small-batch one.
+// wavefront.  It needs >= 1024 * 64/LG series to fill the chip (16384 at J = 8), so it is the large-batch
+// variant; c2_loglik.hip stays the small-batch one.
 //
 // Conventions (XOR order over the lane index): slot q = 2k + e of a gathered vector is element 2(jl^k) + e;
 // SX[m][q] = S(2(jl^k)+e, 2jl+m).
@@ -46,60 +46,6 @@ __device__ __forceinline__ void xgather2_dpp(double x0, double x1, double (&out)
   for (int k = 0; k < LG; ++k) { out[2 * k] = a[k]; out[2 * k + 1] = b[k]; }
 }
 
-// Symmetric-packed storage of the 2-columns-per-lane state.  For k >= 1 the 2x2 block (e, m) -> S(2(jl^k)+e, 2jl+m)
-// of lane jl is the transpose of the block of lane jl^k, so only the lane whose bit hb(k) is clear stores it (at
-// position e*2+m) and its partner reads it with e and m exchanged.  The diagonal block (k = 0) is stored by everyone.
-template <int LG>
-struct SymPack2 {
-  static constexpr int PER_REC = kWave * 4 + (LG - 1) * (kWave / 2) * 4;  // doubles per wavefront and record
-  // Offsets in double2 units.  Component-major: the (e=0) halves of all lanes are contiguous, then the (e=1) halves,
-  // so every 16-byte access of a wavefront is one dense run (LDS: conflict-free, HBM: whole sectors).
-  static __device__ __forceinline__ int off(int l, int k) {
-    if (k == 0) return l;
-    const int b = 31 - __builtin_clz(k), hb = 1 << b;
-    const int o = (l & hb) ? (l ^ k) : l;
-    const int idx = ((o >> (b + 1)) << b) | (o & (hb - 1));
-    return 2 * kWave + (k - 1) * kWave + idx;
-  }
-  static __device__ __forceinline__ constexpr int half(int k) { return k == 0 ? kWave : kWave / 2; }
-  template <typename P>
-  static __device__ __forceinline__ void store(P *rec, int lane, const int (&boff)[LG], const double (&SX)[2][2 * LG]) {
-    const int jl = lane & (LG - 1);
-    double2 *r = reinterpret_cast<double2 *>(rec);
-    r[boff[0]] = make_double2(SX[0][0], SX[1][0]);            // (e=0: m=0,1)
-    r[boff[0] + half(0)] = make_double2(SX[0][1], SX[1][1]);  // (e=1: m=0,1)
-#pragma unroll
-    for (int b = 0; (1 << b) < LG; ++b) {
-      if ((jl & (1 << b)) == 0) {
-#pragma unroll
-        for (int k = (1 << b); k < (2 << b); ++k) {
-          r[boff[k]] = make_double2(SX[0][2 * k], SX[1][2 * k]);
-          r[boff[k] + half(k)] = make_double2(SX[0][2 * k + 1], SX[1][2 * k + 1]);
-        }
-      }
-    }
-  }
-  template <typename P>
-  static __device__ __forceinline__ void load(const P *rec, int lane, const int (&boff)[LG], double (&SX)[2][2 * LG]) {
-    const int jl = lane & (LG - 1);
-    const double2 *r = reinterpret_cast<const double2 *>(rec);
-#pragma unroll
-    for (int k = 0; k < LG; ++k) {
-      const double2 r0 = r[boff[k]], r1 = r[boff[k] + half(k)];  // owner's (e=0: m=0,1), (e=1: m=0,1)
-      const int hbk = (k == 0) ? 0 : (1 << (31 - __builtin_clz(k)));
-      const bool partner = (jl & hbk) != 0;  // read the owner's block transposed
-      SX[0][2 * k] = r0.x;
-      SX[1][2 * k + 1] = r1.y;
-      SX[1][2 * k] = partner ? r1.x : r0.y;      // (e=0, m=1) <- owner's (e=1, m=0) when transposed
-      SX[0][2 * k + 1] = partner ? r0.y : r1.x;  // (e=1, m=0) <- owner's (e=0, m=1)
-    }
-  }
-};
-template <int LG>
-struct CkptRec2 {
-  static constexpr int DOUBLES = SymPack2<LG>::PER_REC + 2 * kWave;  // + F[2] per lane
-};
-
 // The chain part of one forward step, two columns per lane.
 template <int LG>
 __device__ __forceinline__ void fwd_chain2(const double (&p)[2], const double (&u)[2], const double (&v)[2], double an,
@@ -134,22 +80,17 @@ __device__ __forceinline__ void fwd_chain2(const double (&p)[2], const double (&
 }
 
 // =============================================================================
-// Forward pass (MODE 0: log-likelihood only, MODE 1: + records for the reverse sweep).
+// Forward pass, log-likelihood only.
 // =============================================================================
-template <int LG, int R, int C, int MODE>
-__global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
+template <int LG, int R>
+__global__ __launch_bounds__(kWave, C2_FWD4_OCC) void k_loglik4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                           const double *__restrict__ c, int64_t c_bs,
                                                           const double *__restrict__ a, const double *__restrict__ U,
                                                           const double *__restrict__ V, const double *__restrict__ y,
-                                                          double *__restrict__ ll, int32_t *__restrict__ flag,
-                                                          double *__restrict__ ckpt, int64_t nseg,
-                                                          double *__restrict__ Wst, double2 *__restrict__ DZst) {
-  constexpr bool CKPT = MODE == 1;
-  static_assert(!CKPT || R % C == 0, "block length must be a multiple of the checkpoint interval");
+                                                          double *__restrict__ ll, int32_t *__restrict__ flag) {
   constexpr int J = 2 * LG, SPW = kWave / LG, NV = (R + LG - 1) / LG;
   __shared__ __attribute__((aligned(16))) double2 xs2[2][kWave];
   __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];
-  __shared__ __attribute__((aligned(16))) double2 sout[SPW][R];
   const Geo<LG> L(B, LG);
   const int lane = L.lane, jl = L.j, grp = lane / LG;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + 2 * jl;
@@ -157,13 +98,6 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
   const double2 *Ub = reinterpret_cast<const double2 *>(U + L.b0 * N * J + oj);  // row stride LG double2
   const double2 *Vb = reinterpret_cast<const double2 *>(V + L.b0 * N * J + oj);
   const double cj[2] = {c[L.b * c_bs + 2 * jl], c[L.b * c_bs + 2 * jl + 1]};
-  double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * nseg * CkptRec2<LG>::DOUBLES : nullptr;
-  double2 *wst = CKPT ? reinterpret_cast<double2 *>(Wst + L.b0 * N * J + oj) : nullptr;
-  double2 *dzst = CKPT ? DZst + L.b0 * N + on : nullptr;
-  int boff[LG];
-#pragma unroll
-  for (int k = 0; k < LG; ++k) boff[k] = SymPack2<LG>::off(lane, k);
-
   double SX[2][J];
 #pragma unroll
   for (int q = 0; q < J; ++q) { SX[0][q] = 0.0; SX[1][q] = 0.0; }
@@ -177,11 +111,6 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
   int eacc = 0;
   double quad = z * z * rd;
   int32_t fl = 0;
-  if (CKPT) {
-    wst[0] = make_double2(w[0], w[1]);
-    dzst[0] = make_double2(d, z);
-  }
-
   // transposed scalar streams (see c2_loglik.hip): registers hold block b+2, LDS blocks b and b+1
   double vt[NV], va[NV], vy[NV];
   auto vload = [&](int64_t nb) {
@@ -234,11 +163,6 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
     for (int r = 0; r < R; ++r) {
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
-        if (CKPT && (r % C == 0)) {  // state after row n-1 = checkpoint (n-1)/C
-          double *rec = ckw + ((n - 1) / C) * CkptRec2<LG>::DOUBLES;
-          SymPack2<LG>::store(rec, lane, boff, SX);
-          reinterpret_cast<double2 *>(rec + SymPack2<LG>::PER_REC)[lane] = make_double2(F[0], F[1]);
-        }
         const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r];
         const double vv_[2] = {rv[r].x, rv[r].y};
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
@@ -253,10 +177,6 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
         xgather2_lds<LG>(xs2[1], lane, uXn);
         lds_order();
         fwd_chain2<LG>(pc, uc, vv_, an, yn, pXc, uXc, SX, F, w, d, z, rd);
-        if (CKPT) {
-          wst[n * LG] = make_double2(w[0], w[1]);
-          sout[grp][r] = make_double2(d, z);
-        }
         load_row(r, r + R, n + R, CHECKED);
         fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
         prod *= d;
@@ -273,13 +193,6 @@ __global__ __launch_bounds__(kWave, MODE == 0 ? C2_FWD4_OCC : 1) void k_loglik4_
       }
     }
     lds_order();
-    if (CKPT) {
-#pragma unroll
-      for (int m = 0; m < NV; ++m) {
-        const int idx = m * LG + jl;
-        if ((LG * NV == R || idx < R) && (!CHECKED || n0 + idx < N)) dzst[n0 + idx] = sout[grp][idx];
-      }
-    }
     vstage(q);
     vload(n0 + 3 * R);
     lds_order();
@@ -305,7 +218,6 @@ using namespace c2;
 
 namespace {
 inline int launch_ok4() { return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP; }
-constexpr int kC4 = 4;
 }  // namespace
 
 extern "C" {
@@ -315,8 +227,8 @@ int c2_internal_loglik4(int64_t B, int64_t N, const double *t, int64_t t_bs, con
                         c2_stream_t stream) {
   constexpr int LG = 4;
   const dim3 grid((unsigned)((B * LG + kWave - 1) / kWave));
-  hipLaunchKernelGGL((k_loglik4_fwd<LG, C2_FWD4_R0, kC4, 0>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a,
-                     U, V, y, ll, flag, nullptr, 0, nullptr, nullptr);
+  hipLaunchKernelGGL((k_loglik4_fwd<LG, C2_FWD4_R0>), grid, dim3(kWave), 0, (hipStream_t)stream, B, N, t, t_bs, c, c_bs, a, U, V, y, ll,
+                     flag);
   return launch_ok4();
 }
 

@@ -1268,6 +1268,7 @@ static size_t lanes1_record_doubles(int64_t B, int64_t N, int64_t J) {
 // Time-parallel forward pass (c2_timepar.hip; widths 4 and 2): batches too small to fill the chip row by row -- below the
 // one-lane threshold -- of series long enough to cut into chunks.  C2_TIMEPAR=1 forces it, =0 disables it.
 extern "C" size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J);
+extern "C" size_t c2_internal_loglik_timepar_doubles(int64_t B, int64_t N, int64_t J);
 extern "C" int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                           int64_t c_bs, const double *a, const double *U, const double *V,
                                           const double *y, double *ll, int32_t *flag, double *work,
@@ -1281,10 +1282,18 @@ static int64_t timepar_min_rows(int64_t B, int64_t J) {
   if (B * J > 512) return opt::ival(opt::k_timepar_min_rows);
   return J == 2 ? 384 : (J == 4 ? 704 : 1024);
 }
-static bool use_timepar(int64_t B, int64_t N, int64_t J) {
+static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
   if (J != 4 && J != 2) return false;
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
+  if (loglik && opt::ival(opt::k_timepar_onepass) != 0) {
+    // the forward log-likelihood in one pass (chunk elements combined in a tree): a wavefront per 4096 rows of a series costs
+    // the same whatever part of them exists, the chip takes 1024 wavefronts a round, row by row costs 0.22 us per row
+    // (more beyond 8192 series: 0.27 / 0.33 / 0.46 us at 12288 / 16384 / 20480 series of width 4)
+    const int64_t rounds = (B * ((N + 4095) / 4096) + 1023) / 1024;
+    const int64_t per_round = opt::ival(opt::k_timepar_onepass_rows_per_round) * (J == 2 ? 250 : 340) / 340;
+    return N * (10240 + (B > 8192 ? B - 8192 : 0)) >= per_round * rounds * 10240;
+  }
   return N >= timepar_min_rows(B, J) && B * J <= opt::ival(opt::k_timepar_max_batch_x_width);
 }
 // the same decision for the single-rhs solves (affine maps: width 8 as well)
@@ -1480,7 +1489,10 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   hipStream_t s = (hipStream_t)stream;
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
-  if (capturing == hipStreamCaptureStatusNone && use_factor_iter(B, N, J)) {
+  // widths 4 and 2 in one pass (chunk elements combined in a tree: c2_timepar.hip) whatever the length; the Newton
+  // iterations below are for the other widths (and for A/B runs of the composed maps, C2_TIMEPAR_ONEPASS=0)
+  const bool onepass = (J == 4 || J == 2) && opt::ival(opt::k_timepar_onepass) != 0 && use_timepar(B, N, J, true);
+  if (capturing == hipStreamCaptureStatusNone && !onepass && use_factor_iter(B, N, J)) {
     // d, W by Newton iterations on the chunk start states, z by the chunk-map solve, a reduction
     const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);
     void *tmp = nullptr;
@@ -1491,11 +1503,11 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
     }
     (void)hipGetLastError();
   }
-  if (capturing == hipStreamCaptureStatusNone && use_timepar(B, N, J)) {
+  if (capturing == hipStreamCaptureStatusNone && use_timepar(B, N, J, true)) {
     // Small batch of long series: parallel along time (c2_timepar.hip), verified on the device; the ordinary kernel
     // below runs behind the verification word and does nothing unless it failed.  Scratch is a stream-ordered
     // temporary; without it (allocation refused) the ordinary kernel runs alone.
-    const size_t nd = c2_internal_timepar_doubles(B, N, J);
+    const size_t nd = c2_internal_loglik_timepar_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && c2::temp_alloc(&tmp, (nd + 2) * sizeof(double), s) == hipSuccess) {
       unsigned long long *guard = (unsigned long long *)tmp;

@@ -592,6 +592,495 @@ __global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, in
   outs[(int64_t)(q++) * G + g] = failed;
 }
 
+// =============================================================================================================
+// ONE PASS (round 5): chunk elements combined in scattering form.
+//
+// Run from the ZERO state over a span of rows, the recursion yields the span's ELEMENT
+//     A = prod P (I - w^T u)   (transition of F),   G = the end state T,   Q = sum r^T r / d  (r = u A_before),
+//     g = the end state F,   h = sum z r / d,   q0 = sum z^2 / d,   prod d
+// -- what k_tp_chunks accumulates anyway -- and entered with a state (T, F) instead, the same span gives
+//     T' = G + A Gt' A^T,   F' = g + A (I - T Q)^-1 (F - T h),   sum log d = log prod d + log det(I - Q T),
+//     sum z^2 / d = q0 - 2 h.F + F^T Q F + rho^T T (I - Q T)^-1 rho,   rho = h - Q F        (Gt' = T (I - Q T)^-1)
+// (the factor recursion is a Kalman filter in disguise -- T the explained covariance, Q the information a span gathers --
+// and these are the update formulas of its information form; found with tools-free numpy, checked to 1e-15 against the
+// sequential recursion: docs/rounds/r05.md).  Two consecutive spans therefore COMBINE into the element of their union with
+// nothing but the symmetric positive definite  Ks = I - L^T Q2 L,  G1 = L L^T:
+//     Gt = L Ks^-1 L^T  (= G1 (I - Q2 G1)^-1),   M = I + Gt Q2,   rho = h2 - Q2 g1
+//     A = A2 M A1,   G = G2 + A2 Gt A2^T,   Q = Q1 + A1^T Q2 M A1,   g = g2 + A2 (g1 - Gt rho),
+//     h = h1 + A1^T (rho + Q2 Gt rho),   q0 = q0_1 + q0_2 - g1.(h2 + rho) + rho.Gt rho,   prod d = prod1 prod2 det Ks
+// Unlike the composite linear-fractional maps of k_tp_maps (ill-conditioned in the span: 1e-12 at 64 rows, useless beyond
+// 128) the combination is as well-conditioned as the factorisation itself (Ks has the eigenvalues d_n(T) / d_n(0) between
+// its extremes), so spans combine in a TREE and nothing is verified or repeated: one pass over the rows, six combinations
+// per wavefront.  Ks positive definite  <=>  every d_n of the later span stays positive when it is entered with G1 (its
+// eigenvalues fall monotonically along the span): a failed Cholesky pivot, or d_n <= 0 from the zero state (an upper
+// bound of the true d_n), marks the series failed and the row-by-row kernel behind the gate reports the reference's flag.
+template <int J>
+struct Elem {
+  double A[J][J], G[nsym(J)], Q[nsym(J)], g[J], h[J], q0, prod;
+  int ex;   // prod d = prod * 2^ex
+};
+template <int J>
+__device__ __forceinline__ void elem_identity(Elem<J> &e) {
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    e.g[i] = 0.0; e.h[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) e.A[i][j] = i == j ? 1.0 : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < nsym(J); ++q) { e.G[q] = 0.0; e.Q[q] = 0.0; }
+  e.q0 = 0.0; e.prod = 1.0; e.ex = 0;
+}
+template <int J>
+__device__ __forceinline__ void elem_from_lane(const Elem<J> &e, int src, Elem<J> &o) {
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    o.g[i] = __shfl(e.g[i], src, 64); o.h[i] = __shfl(e.h[i], src, 64);
+#pragma unroll
+    for (int j = 0; j < J; ++j) o.A[i][j] = __shfl(e.A[i][j], src, 64);
+  }
+#pragma unroll
+  for (int q = 0; q < nsym(J); ++q) { o.G[q] = __shfl(e.G[q], src, 64); o.Q[q] = __shfl(e.Q[q], src, 64); }
+  o.q0 = __shfl(e.q0, src, 64); o.prod = __shfl(e.prod, src, 64); o.ex = __shfl(e.ex, src, 64);
+}
+__device__ __forceinline__ constexpr int sym(int J, int i, int j) { return i <= j ? sidx(J, i, j) : sidx(J, j, i); }
+
+// e1 (the earlier span) <- e1 followed by e2
+template <int J>
+__device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
+  // G1 = L L^T (positive SEMI-definite: a non-positive pivot is rounding, its column is dropped)
+  double L[J][J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double sp = e1.G[sidx(J, j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sp = fma(-L[j][k], L[j][k], sp);
+    const bool ok = sp > 0.0;
+    const double ljj = ok ? sqrt(sp) : 0.0, inv = ok ? rcp_nr(ljj) : 0.0;
+    L[j][j] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < J; ++i) {
+      double v = e1.G[sidx(J, j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = fma(-L[i][k], L[j][k], v);
+      L[i][j] = v * inv;
+    }
+  }
+  // X = Q2 L,  Ks = I - L^T X (lower triangle)
+  double X[J][J], Ks[J][J];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = j; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], L[k][j], v);
+      X[i][j] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double v = i == j ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = i; k < J; ++k) v = fma(-L[k][i], X[k][j], v);
+      Ks[i][j] = v;
+    }
+  // Ks = C C^T in place (lower), det Ks = prod of the pivots; a non-positive pivot = a failed factorisation of the series
+  double det = 1.0, ic[J];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    double sp = Ks[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sp = fma(-Ks[j][k], Ks[j][k], sp);
+    bad = bad || !(sp > 0.0);
+    det *= sp;
+    const double cjj = sqrt(sp);
+    ic[j] = rcp_nr(cjj);
+    Ks[j][j] = cjj;
+#pragma unroll
+    for (int i = j + 1; i < J; ++i) {
+      double v = Ks[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v = fma(-Ks[i][k], Ks[j][k], v);
+      Ks[i][j] = v * ic[j];
+    }
+  }
+  // Y = C^-1 L^T (column m of L^T = row m of L: zero above... L^T[k][m] = L[m][k], k <= m),  Gt = Y^T Y
+  double Y[J][J];
+#pragma unroll
+  for (int m = 0; m < J; ++m)
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      double v = i <= m ? L[m][i] : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) v = fma(-Ks[i][k], Y[k][m], v);
+      Y[i][m] = v * ic[i];
+    }
+  double Gt[nsym(J)];
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = i; j < J; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(Y[k][i], Y[k][j], v);
+      Gt[sidx(J, i, j)] = v;
+    }
+  // vectors
+  double rho[J], Gr[J], tv[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    double v = e2.h[i];
+#pragma unroll
+    for (int k = 0; k < J; ++k) v = fma(-e2.Q[sym(J, i, k)], e1.g[k], v);
+    rho[i] = v;
+  }
+  double q0 = e1.q0 + e2.q0;
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < J; ++k) v = fma(Gt[sym(J, i, k)], rho[k], v);
+    Gr[i] = v;
+    q0 = fma(-e1.g[i], e2.h[i] + rho[i], q0);
+  }
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    q0 = fma(rho[i], Gr[i], q0);
+    double v = rho[i];
+#pragma unroll
+    for (int k = 0; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], Gr[k], v);
+    tv[i] = v;                       // rho + Q2 Gt rho
+  }
+  double gn[J], hn[J];
+#pragma unroll
+  for (int i = 0; i < J; ++i) {
+    double v = e2.g[i], hv = e1.h[i];
+#pragma unroll
+    for (int k = 0; k < J; ++k) {
+      v = fma(e2.A[i][k], e1.g[k] - Gr[k], v);
+      hv = fma(e1.A[k][i], tv[k], hv);
+    }
+    gn[i] = v; hn[i] = hv;
+  }
+  // matrices: QA = Q2 A1, MA = A1 + Gt QA, A = A2 MA, Q = Q1 + A1^T (Q2 MA), G = G2 + (A2 Gt) A2^T
+  double MA[J][J];
+  {
+    double QA[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], e1.A[k][j], v);
+        QA[i][j] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double v = e1.A[i][j];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(Gt[sym(J, i, k)], QA[k][j], v);
+        MA[i][j] = v;
+      }
+  }
+  {
+    double QMA[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], MA[k][j], v);
+        QMA[i][j] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = i; j < J; ++j) {
+        double v = e1.Q[sidx(J, i, j)];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(e1.A[k][i], QMA[k][j], v);
+        e1.Q[sidx(J, i, j)] = v;
+      }
+  }
+  {
+    double AG[J][J];
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(e2.A[i][k], Gt[sym(J, k, j)], v);
+        AG[i][j] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = i; j < J; ++j) {
+        double v = e2.G[sidx(J, i, j)];
+#pragma unroll
+        for (int k = 0; k < J; ++k) v = fma(AG[i][k], e2.A[j][k], v);
+        e1.G[sidx(J, i, j)] = v;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(e2.A[i][k], MA[k][j], v);
+      e1.A[i][j] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < J; ++i) { e1.g[i] = gn[i]; e1.h[i] = hn[i]; }
+  e1.q0 = q0;
+  int ex;
+  e1.prod = frexp(e1.prod * e2.prod * det, &ex);
+  e1.ex += e2.ex + ex;
+  if (bad) e1.prod = __longlong_as_double(0x7ff8000000000000ll);
+}
+// the element of the 64 lanes' spans, in lane 0 (lane l: spans l .. l + 2^level - 1 as far as they are complete)
+template <int J>
+__device__ __forceinline__ void elem_tree(Elem<J> &e, int lane, int count = 64) {
+#pragma unroll 1
+  for (int off = 1; off < count; off <<= 1) {
+    Elem<J> o;
+    elem_from_lane<J>(e, (lane + off) & 63, o);
+    elem_combine<J>(e, o);
+  }
+}
+
+// rows of the chunks from the zero state -> elements -> the tree.  ONE wavefront per 64 chunks of a series; SINGLE: the
+// series has at most 64 chunks and the wavefront finishes it (ll, flag, gate word); otherwise its element goes to `elems`
+// ([entry][series * wavefronts + wavefront]) for k_tp_join.
+template <int J>
+struct ElemIO {
+  static constexpr int N_ = J * J + 2 * nsym(J) + 2 * J + 3;   // A, G, Q, g, h, q0, prod, ex
+};
+template <int J, bool SINGLE>
+__global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                         int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                         const double *__restrict__ a, const double *__restrict__ U,
+                                                         const double *__restrict__ V, const double *__restrict__ yv,
+                                                         double *__restrict__ elems, double *__restrict__ ll,
+                                                         int32_t *__restrict__ flag, unsigned long long *__restrict__ guard) {
+  using Gm = Geo<J>;
+  constexpr int NS = nsym(J);
+  __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 3 * 64 * Gm::SSTR];
+  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR, *tY = tT + 64 * Gm::SSTR;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y;
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = ch.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  const int64_t s = k * kRows;
+  const int len = ch.len(k);
+  Elem<J> e;
+  elem_identity<J>(e);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+  bool ceq = J % 2 == 0;
+#pragma unroll
+  for (int j = 0; j + 1 < J; j += 2) ceq = ceq && cj[j] == cj[j + 1];
+  double prod = 1.0, failed = 0.0;
+  int eacc = 0;
+  double tn = t[b * t_bs + s];
+  double vu[16], vv[16], va[8], vy[8], vt[8];   // tiles requested one tile ahead
+  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_tile<false>(yv, ch, 0, 0, lane, vy);
+  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  fetch_row_tile<J>(U, ch, 0, lane, vu);
+  fetch_row_tile<J>(V, ch, 0, lane, vv);
+  for (int r0 = 0; r0 < kRows; r0 += 8) {
+    lds_order();
+    stage_scalar_tile(tA, lane, va);
+    stage_scalar_tile(tY, lane, vy);
+    stage_scalar_tile(tT, lane, vt);
+    if (r0 + 8 < kRows) {
+      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_tile<false>(yv, ch, r0 + 8, 0, lane, vy);
+      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < 8; rt += Gm::RT) {
+      lds_order();
+      stage_row_tile<J>(tU, lane, vu);
+      stage_row_tile<J>(tV, lane, vv);
+      if (r0 + rt + Gm::RT < kRows) {
+        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
+        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
+      }
+      lds_order();
+#pragma unroll
+      for (int r = 0; r < Gm::RT; ++r) {
+        const int i0 = r0 + rt + r;          // row of the chunk
+        const int64_t n = s + i0;
+        if (i0 < len) {
+          double u[J], v[J], tau[J], rr[J], w[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            u[j] = tU[lane * Gm::RSTR + r * J + j]; v[j] = tV[lane * Gm::RSTR + r * J + j];
+            tau[j] = 0.0; rr[j] = 0.0;
+          }
+          // tau = u T (forward.hpp:126), rr = u A, z = y - u.g (internal.hpp:140)
+#pragma unroll
+          for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = i; j < J; ++j) {
+              const double sv = e.G[sidx(J, i, j)];
+              tau[j] = fma(u[i], sv, tau[j]);
+              if (j != i) tau[i] = fma(u[j], sv, tau[i]);
+            }
+          double d = tA[lane * Gm::SSTR + rt + r], z0 = tY[lane * Gm::SSTR + rt + r];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            d = fma(-tau[j], u[j], d);          // forward.hpp:127
+            z0 = fma(-u[j], e.g[j], z0);
+#pragma unroll
+            for (int i = 0; i < J; ++i) rr[j] = fma(u[i], e.A[i][j], rr[j]);
+          }
+          const double rd = rcp_nr(d);
+          failed = (failed == 0.0 && n > 0 && !(d > 0.0)) ? (double)n : failed;   // forward.hpp:128 (first row)
+#pragma unroll
+          for (int j = 0; j < J; ++j) w[j] = (v[j] - tau[j]) * rd;   // forward.hpp:131
+          prod *= d;
+          if (i0 & 1) { int ex; prod = frexp(prod, &ex); eacc += ex; }
+          const double z0d = z0 * rd;
+          e.q0 = fma(z0, z0d, e.q0);
+#pragma unroll
+          for (int i = 0; i < J; ++i) {
+            e.h[i] = fma(z0d, rr[i], e.h[i]);
+            const double rid = rr[i] * rd;
+#pragma unroll
+            for (int j = i; j < J; ++j) e.Q[sidx(J, i, j)] = fma(rid, rr[j], e.Q[sidx(J, i, j)]);
+          }
+          if (n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123, internal.hpp:140-143)
+            const double tn1 = tT[lane * Gm::SSTR + rt + r];
+            double p[J];
+            if (ceq) {   // (complex terms: the rates come in pairs)
+#pragma unroll
+              for (int j = 0; j + 1 < J; j += 2) { p[j] = exp_decay(cj[j] * (tn - tn1)); p[j + 1] = p[j]; }
+            } else {
+#pragma unroll
+              for (int j = 0; j < J; ++j) p[j] = exp_decay(cj[j] * (tn - tn1));
+            }
+            tn = tn1;
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+              const double dwi = d * w[i];
+#pragma unroll
+              for (int j = i; j < J; ++j) e.G[sidx(J, i, j)] = (p[i] * p[j]) * fma(dwi, w[j], e.G[sidx(J, i, j)]);
+#pragma unroll
+              for (int j = 0; j < J; ++j) e.A[i][j] = p[i] * fma(-w[i], rr[j], e.A[i][j]);
+              e.g[i] = p[i] * fma(w[i], z0, e.g[i]);
+            }
+          }
+        }
+      }
+    }
+  }
+  {
+    int ex;
+    e.prod = frexp(prod, &ex);
+    e.ex = eacc + ex;
+  }
+  if (!inr) { elem_identity<J>(e); failed = 0.0; }   // (lanes beyond the series ran its last chunk for the loads' sake)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double f2 = __shfl_xor(failed, o, 64);
+    failed = failed == 0.0 ? f2 : (f2 == 0.0 ? failed : fmin(failed, f2));
+  }
+  elem_tree<J>(e, lane, (int)((K - ch.k0) < kThreads ? (K - ch.k0) : kThreads));
+  if constexpr (SINGLE) {
+    const double logdet = log(e.prod) + (double)e.ex * 0.693147180559945309417;
+    const bool bad = failed != 0.0 || !(logdet == logdet) || !(e.q0 == e.q0);
+    if (lane == 0) {
+      ll[b] = -0.5 * (logdet + e.q0 + (double)N * 1.83787706640934548356);   // numpy.py:84-109
+      flag[b] = 0;
+      if (bad) {   // left to the row-by-row kernel behind the gate (it reports the reference's flag and -inf)
+        atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+        atomicMax(guard + 1, (unsigned long long)__double_as_longlong(INFINITY));
+      }
+    }
+  } else if (lane == 0) {
+    const int64_t W = (int64_t)gridDim.x * B, at = b * gridDim.x + blockIdx.x;
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) elems[(int64_t)(q++) * W + at] = e.A[i][j];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) elems[(int64_t)(q++) * W + at] = e.G[i];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) elems[(int64_t)(q++) * W + at] = e.Q[i];
+#pragma unroll
+    for (int i = 0; i < J; ++i) elems[(int64_t)(q++) * W + at] = e.g[i];
+#pragma unroll
+    for (int i = 0; i < J; ++i) elems[(int64_t)(q++) * W + at] = e.h[i];
+    elems[(int64_t)(q++) * W + at] = e.q0;
+    elems[(int64_t)(q++) * W + at] = failed != 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : e.prod;
+    elems[(int64_t)(q++) * W + at] = (double)e.ex;
+  }
+}
+// the elements of a long series' wavefronts (more than 64 chunks) joined: one wavefront per series, 64 elements a round
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_join(int64_t B, int64_t N, int64_t Wn, const double *__restrict__ elems,
+                                                      double *__restrict__ ll, int32_t *__restrict__ flag,
+                                                      unsigned long long *__restrict__ guard) {
+  constexpr int NS = nsym(J);
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x, W = Wn * B;
+  Elem<J> carry;
+  elem_identity<J>(carry);
+  for (int64_t base = 0; base < Wn; base += kThreads) {
+    Elem<J> e;
+    elem_identity<J>(e);
+    if (base + lane < Wn) {
+      const int64_t at = b * Wn + base + lane;
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) e.A[i][j] = elems[(int64_t)(q++) * W + at];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) e.G[i] = elems[(int64_t)(q++) * W + at];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) e.Q[i] = elems[(int64_t)(q++) * W + at];
+#pragma unroll
+      for (int i = 0; i < J; ++i) e.g[i] = elems[(int64_t)(q++) * W + at];
+#pragma unroll
+      for (int i = 0; i < J; ++i) e.h[i] = elems[(int64_t)(q++) * W + at];
+      e.q0 = elems[(int64_t)(q++) * W + at];
+      e.prod = elems[(int64_t)(q++) * W + at];
+      e.ex = (int)elems[(int64_t)(q++) * W + at];
+    }
+    elem_tree<J>(e, lane, (int)((Wn - base) < kThreads ? (Wn - base) : kThreads));
+    Elem<J> first;
+    elem_from_lane<J>(e, 0, first);
+    elem_combine<J>(carry, first);
+  }
+  const double logdet = log(carry.prod) + (double)carry.ex * 0.693147180559945309417;
+  const bool bad = !(logdet == logdet) || !(carry.q0 == carry.q0);
+  if (lane == 0) {
+    ll[b] = -0.5 * (logdet + carry.q0 + (double)N * 1.83787706640934548356);
+    flag[b] = 0;
+    if (bad) {
+      atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+      atomicMax(guard + 1, (unsigned long long)__double_as_longlong(INFINITY));
+    }
+  }
+}
+
 // ---- `factor` itself (forward.hpp:69-135: d, W, flag), phase 3 with the rows written out.  d == a / W == V in place are NOT
 // supported here (the caller keeps those on the row-by-row kernel: its fallback would read what this kernel overwrote).
 // Two passes.  The start states of phase 2 carry the error of an ill-conditioned composite map (1e-12 of |S|, which the
@@ -775,6 +1264,18 @@ int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, in
   // starts every chunk from its predecessor's END state of the first pass (the recursion contracts the error of a start
   // state: those are good to rounding).  The caller's row-by-row kernel sits behind guard[1].
   double *ends = outs + (size_t)Layout<J>::OUT * G;
+  if (opt::ival(opt::k_timepar_onepass) != 0) {   // chunk elements in scattering form, combined in a tree: one pass, nothing verified
+    if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
+    if (K <= kThreads) {
+      hipLaunchKernelGGL((k_tp_onepass<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
+                         guard);
+    } else {
+      hipLaunchKernelGGL((k_tp_onepass<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
+                         guard);
+      hipLaunchKernelGGL((k_tp_join<J>), gs, dim3(kThreads), 0, s, B, N, (int64_t)gc.x, (const double *)work, ll, flag, guard);
+    }
+    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+  }
   if (K <= kThreads) {   // a wavefront holds every chunk of its series: two kernels, no maps / chunk results in memory
     hipLaunchKernelGGL((k_tp_maps<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
                        guard);
@@ -1128,6 +1629,13 @@ size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J) {
   return per * G;
 }
 
+// scratch of the forward log-likelihood: the one-pass form keeps one element per wavefront of a series longer than 4096 rows
+size_t c2_internal_loglik_timepar_doubles(int64_t B, int64_t N, int64_t J) {
+  if (J != 4 && J != 2) return 0;
+  if (c2::opt::ival(c2::opt::k_timepar_onepass) == 0) return c2_internal_timepar_doubles(B, N, J);
+  const size_t K = (size_t)((N + c2tp::kRows - 1) / c2tp::kRows), gx = (K + c2tp::kThreads - 1) / c2tp::kThreads;
+  return gx <= 1 ? 2 : (size_t)(J == 4 ? c2tp::ElemIO<4>::N_ : c2tp::ElemIO<2>::N_) * (size_t)B * gx;
+}
 // Forward log-likelihood, time-parallel.  `guard` (device word; the first kernel zeroes it) receives the
 // verification results (two words: first pass, refinement pass); the caller launches the ordinary kernel behind it with
 // `guard + 1` as its gate.

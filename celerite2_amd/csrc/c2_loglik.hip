@@ -1286,15 +1286,16 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
   if (J != 4 && J != 2) return false;
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
-  if (loglik && opt::ival(opt::k_timepar_onepass) != 0) {
-    // the forward log-likelihood in one pass (chunk elements combined in a tree): a wavefront per 4096 rows of a series costs
-    // the same whatever part of them exists, the chip takes 1024 wavefronts a round, row by row costs 0.22 us per row
-    // (more beyond 8192 series: 0.27 / 0.33 / 0.46 us at 12288 / 16384 / 20480 series of width 4)
-    const int64_t rounds = (B * ((N + 4095) / 4096) + 1023) / 1024;
-    const int64_t per_round = opt::ival(opt::k_timepar_onepass_rows_per_round) * (J == 2 ? 250 : 340) / 340;
-    return N * (10240 + (B > 8192 ? B - 8192 : 0)) >= per_round * rounds * 10240;
-  }
-  return N >= timepar_min_rows(B, J) && B * J <= opt::ival(opt::k_timepar_max_batch_x_width);
+  // Chunk elements (c2_timepar.hip): a wavefront per 4096 rows of a series costs the same whatever part of them exists and
+  // the chip takes 1024 wavefronts a ROUND; row by row costs 0.22 - 0.25 us per row whatever the batch up to 8192 series
+  // (more beyond: 0.27 / 0.33 / 0.46 us at 12288 / 16384 / 20480 series of width 4).  tools/onepass_grid.py:
+  //   log-likelihood (one pass): a round 66 - 110 us at width 4, 48 - 76 at width 2;
+  //   factor (states + scan, then the writing pass): 100 us (up to half a round) - 175 - 230 us at width 4, 66 - 120 - 147 at 2
+  const int64_t waves = B * ((N + 4095) / 4096), rounds = (waves + 1023) / 1024;
+  int64_t per_round = loglik ? opt::ival(opt::k_timepar_onepass_rows_per_round) : opt::ival(opt::k_timepar_factor_rows_per_round);
+  if (!loglik && waves <= 512) per_round = per_round * 2 / 3;
+  if (J == 2) per_round = per_round * 7 / 10;
+  return N * (10240 + (B > 8192 ? B - 8192 : 0)) >= per_round * rounds * 10240;
 }
 // the same decision for the single-rhs solves (affine maps: width 8 as well)
 extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
@@ -1415,10 +1416,8 @@ static bool use_factor_iter(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return false;
   const bool e = opt::has(opt::k_factor_iter);   // 1 forces it (every length; widths 4, 2: long series only), 0 disables it
   if (e && opt::ival(opt::k_factor_iter) == 0) return false;
-  // widths 4 and 2 have the composed linear-fractional maps of c2_timepar.hip, whose chain over the chunks is sequential:
-  // the Newton iterations (chains in two levels) take over on long series -- J = 4: 1.67 -> 0.59 ms at 1e5 rows, 15.3 ->
-  // 1.6 ms at 1e6 (0.45 vs 0.51 ms at 20000); J = 2: level at 1e5 rows (0.40 ms)
-  if (J == 2 || J == 4) return N >= (J == 4 ? 32768 : 131072) && B * ((N + 63) / 64) <= 32768;
+  // widths 4 and 2 have the exact chunk-start states of c2_timepar.hip (scanned chunk elements): Newton only when forced
+  if (J == 2 || J == 4) return e && N >= (J == 4 ? 32768 : 131072) && B * ((N + 63) / 64) <= 32768;
   if (e) return N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;
   // five Newton iterations of ~0.15 ms (N = 4096) against 0.3 us per row walked one by one: 0.77 vs 1.22 ms at 4096 rows,
@@ -1490,8 +1489,8 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
   // widths 4 and 2 in one pass (chunk elements combined in a tree: c2_timepar.hip) whatever the length; the Newton
-  // iterations below are for the other widths (and for A/B runs of the composed maps, C2_TIMEPAR_ONEPASS=0)
-  const bool onepass = (J == 4 || J == 2) && opt::ival(opt::k_timepar_onepass) != 0 && use_timepar(B, N, J, true);
+  // iterations below are for the other widths
+  const bool onepass = (J == 4 || J == 2) && use_timepar(B, N, J, true);
   if (capturing == hipStreamCaptureStatusNone && !onepass && use_factor_iter(B, N, J)) {
     // d, W by Newton iterations on the chunk start states, z by the chunk-map solve, a reduction
     const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);
@@ -1569,10 +1568,9 @@ extern "C" int c2_internal_factor_timepar(int64_t B, int64_t N, int64_t J, const
                                           int64_t c_bs, const double *a, const double *U, const double *V, double *d,
                                           double *W, int32_t *flag, double *work, unsigned long long *guard,
                                           c2_stream_t stream);
-// allow_timepar: 0 row by row only; 1 the dispatch's choice; 2 what the time-parallel gradient builds on: the Newton
-// iterations at EVERY width (1 .. 8) where they pay -- from 2048 rows -- and the row-by-row kernel below, never the
-// composed maps of widths 4 / 2 (verified to 5e-11 only, which the gradient inherits: 1.5e-10 of its largest entry on a
-// well-conditioned draw of the round-2 stress run, profiles/r03_timepar_verification.md)
+// allow_timepar: 0 row by row only; 1 the dispatch's choice; 2 what the time-parallel gradient builds on: from 2048 rows the
+// scanned chunk elements at widths 4 / 2 (start states exact to rounding) and the Newton iterations at the other widths
+// (1 .. 8), the row-by-row kernel below that
 // `scratch` (nullable; c2_internal_factor_scratch_doubles): caller-provided room for the time-parallel forms -- without it
 // they use a stream-ordered temporary and stay out of graph captures.
 size_t c2_internal_factor_scratch_doubles(int64_t B, int64_t N, int64_t J) {
@@ -1594,12 +1592,14 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
     if (!scratch && hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
     return rc;
   };
-  // allow_timepar == 2 (the time-parallel gradient builds on d, W): never the composed maps of widths 4 / 2 -- they are
-  // verified to 5e-11 only -- but the Newton iterations where they pay at the other widths (from 2048 rows; forced: every
-  // length), the row-by-row kernel below that (0.15 us per row against five iterations of several launches)
+  // allow_timepar == 2 (the time-parallel gradient builds on d, W): the time-parallel forms from 2048 rows (Newton forced:
+  // every length), the row-by-row kernel below that (0.15 us per row against several launches)
   const bool forced_iter = opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) != 0;
-  const bool newton = allow_timepar == 2
-                          ? (J >= 1 && J <= 8 && N >= 2 && (forced_iter || (N >= 2048 && B * ((N + 63) / 64) <= 32768)) &&
+  const bool scan_widths = (J == 2 || J == 4) && !forced_iter;   // chunk-start states by scanned elements (c2_timepar.hip)
+  const bool long_enough = N >= 2048 && B * ((N + 63) / 64) <= 32768;
+  const bool newton = scan_widths ? false
+                      : allow_timepar == 2
+                          ? (J >= 1 && J <= 8 && N >= 2 && (forced_iter || long_enough) &&
                              !(opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) == 0))
                           : use_factor_iter(B, N, J);
   if (allow_timepar && d != a && W != V && newton) {
@@ -1617,7 +1617,8 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
   }
   // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
   // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
-  if (allow_timepar == 1 && d != a && W != V && use_timepar(B, N, J)) {
+  if (allow_timepar && d != a && W != V && scan_widths &&
+      (allow_timepar == 2 ? long_enough && !(opt::has(opt::k_timepar) && opt::ival(opt::k_timepar) == 0) : use_timepar(B, N, J))) {
     const size_t nd = c2_internal_timepar_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && room(nd + 2, &tmp)) {

@@ -1,26 +1,26 @@
-// c2_timepar.hip -- TIME-PARALLEL forward log-likelihood for SMALL batches of long series (widths J = 2, 4).
+// c2_timepar.hip -- the forward recursions parallel along TIME, for batches too small to fill the chip row by row (widths
+// J = 2, 4; the single-rhs solves also at 8).
 //
 // The group kernels of c2_loglik.hip walk a series row by row: with a few hundred series the chip idles (BASELINE
-// configs[1]: 1024 series x 4 lanes = 64 wavefronts on 1024 SIMDs, 212 ns per dependent step).  The recursions admit
-// parallelism along TIME:
-//  * `factor` (forward.hpp:105-134).  With T = S_n (the post-decay state row n sees), u = U_n, v = V_n, a = a_n,
+// configs[1]: 1024 series x 4 lanes = 64 wavefronts on 1024 SIMDs, 212 ns per dependent step).  Here a series is cut into
+// CHUNKS of 64 rows, a lane walks a chunk, a wavefront owns 64 consecutive chunks of one series:
+//  * `factor` (forward.hpp:105-134) is a Kalman filter in disguise -- with T = S_n (the post-decay state row n sees),
 //        T' = P (T + g^T g / delta) P,   g = v - u T,  delta = a - u T u^T          (forward.hpp:115-131, one row on)
-//    is a LINEAR-FRACTIONAL map of T:  T' = (A T + B)(C T + D)^-1  with
-//        [[A, B], [C, D]] = diag(P, P^-1) (kappa I + x y^T),   x = [v; u],  y = [-u; v],  kappa = a - u.v
-//    (kappa is the white-noise diagonal; x y^T has y.x = 0: a shear).  Maps of consecutive rows compose by 2J x 2J
-//    products -- here a rank-one update, 8 J^2 flops a row -- so every CHUNK of kRows rows yields its composite map
-//    independently of the others (k_tp_maps), the chunk-start states follow by applying K - 1 maps one after the other
-//    (k_tp_starts: one lane per series, (2J)^2 J flops + a J x J solve per chunk), and every chunk then runs the
-//    ordinary recursion from its own start state, all chunks at once (k_tp_chunks).
-//  * `solve_lower` (internal.hpp:135-145) is AFFINE in the state F once (d, W) are known:
-//        F' = P ((I - w u) F + w y)   =>   F_n = G_n F_start + g_n,   z_n = (y_n - u_n.g_n) - (u_n G_n).F_start
-//    so a chunk accumulates  sum z^2 / d = q0 - 2 q1.F_start + F_start^T Q2 F_start  next to sum log d without knowing
-//    F_start, and one lane per series chains the chunks at the end (k_tp_finish).
-// Composite maps of long chunks are ill-conditioned (the recursion forgets its start; 1e-12 at 32 rows, 1e-7 at 128 on
-// the bench data), so the result is VERIFIED: a chunk's sequentially computed end state must match the next chunk's
-// start state; k_tp_finish writes the worst relative mismatch / 2.5e-11 into a device word and the ordinary kernel --
-// launched behind it with that word as its gate (gate_closed, c2_loglik_helpers.hpp) -- recomputes the batch if it
-// exceeds kBackwardGuard (= 2) or if any factorisation failed.  numpy prototype: tools/proto/timepar.py in the history (git show cd74ef8:tools/proto/timepar.py).
+//    is the covariance update of a filter whose "explained covariance" is T -- and `solve_lower` (internal.hpp:135-145),
+//    F' = P ((I - w u) F + w y), is its mean update.  What a span of rows does to ANY state it is entered with is therefore
+//    captured by a small ELEMENT (two J x J matrices, two symmetric ones, two vectors, two scalars) computed by running the
+//    span from the zero state, and the elements of consecutive spans combine associatively and STABLY (scattering / information
+//    form: only symmetric positive definite J x J systems; see "Chunk ELEMENTS" below; numpy prototype and the derivation:
+//    docs/rounds/r05.md).
+//  * Forward log-likelihood (k_tp_onepass [+ k_tp_join]): ONE pass over the rows -- every chunk's element, a tree over the 64
+//    lanes, sum log d and sum z^2 / d read off the total.  BASELINE configs[1]: 0.110 ms (0.42 of the HBM roofline; the
+//    composite linear-fractional maps of rounds 2 - 4, chained and verified: 0.262 ms), agreement with the row-by-row
+//    kernels 5e-15.
+//  * `factor` (k_tp_states [+ k_tp_carry + k_tp_long_starts], k_tp_factor): the matrices of the elements, an inclusive scan,
+//    the G of a prefix = the exact start state of the next chunk; every chunk then runs the ordinary recursion from its
+//    start state and writes d, W.  The end state of a chunk is compared with the start state of its successor (a cheap
+//    check of the whole chain); a failed factorisation, or a mismatch, sends the batch to the row-by-row kernel gated behind.
+//  * single-rhs solves (k_tps_*, second half of this file): contracting affine maps per chunk.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -29,28 +29,18 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+
 namespace c2tp {
 using namespace c2;
 
 constexpr int kRows = 64;        // rows per chunk
 constexpr int kThreads = 64;
-// chunk-start mismatch (relative to |S|) that counts as 1 on the guard word; fallback beyond 2, i.e. 5e-11.  Observed on the
-// bench data: 1e-12 .. 2e-11; a mismatch eps moves log d of a chunk's first rows by ~eps x signal / noise, so 5e-11 keeps
-// the log-likelihood inside 1e-10 relative with margin (measured agreement with the row-by-row kernels: 1e-13 .. 1e-12).
+// chunk-start mismatch (relative to |S|) of `factor` that counts as 1 on the guard word; the row-by-row kernel recomputes the
+// batch beyond 2, i.e. 5e-11 (the scanned start states agree with the sequential recursion to ~1e-15)
 constexpr double kTol = 2.5e-11;
 
 __host__ __device__ constexpr int nsym(int J) { return J * (J + 1) / 2; }
 __host__ __device__ constexpr int sidx(int J, int i, int j) { return i * J - i * (i - 1) / 2 + (j - i); }  // i <= j
-
-// doubles per chunk of every array (all arrays are [entry][series * K + chunk]: a wavefront's accesses are contiguous)
-template <int J>
-struct Layout {
-  static constexpr int MAP = 4 * J * J;                 // composite map
-  static constexpr int START = nsym(J);                 // chunk-start state, packed
-  // chunk results: S_end (packed), G (J x J), g (J), logdet, q0, q1 (J), Q2 (packed), first failed row (as a double)
-  static constexpr int OUT = nsym(J) + J * J + J + 2 + J + nsym(J) + 1;
-};
-
 
 // ---- data movement.  A wavefront owns 64 consecutive chunks (lane <-> chunk).  A lane streaming its own chunk would touch
 // 64 different lines per load instruction and the lines it reuses over the next rows do not survive in L1 / L2 (measured:
@@ -120,78 +110,6 @@ __device__ __forceinline__ void stage_scalar_tile(double *tile, int lane, const 
 
 // S' = X Y^-1 for J x J blocks by Gauss-Jordan with partial pivoting on Y^T (rows of the augmented [Y^T | X^T]), fully
 // unrolled.
-template <int J>
-__device__ __forceinline__ void right_divide(double (&X)[J][J], double (&Y)[J][J], double (&out)[J][J]) {
-  // solve Y^T Z = X^T, out = Z^T
-  double A[J][2 * J];
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) { A[i][j] = Y[j][i]; A[i][J + j] = X[j][i]; }
-#pragma unroll
-  for (int col = 0; col < J; ++col) {
-    // partial pivoting, swaps by selects (columns left of `col` are already unit columns: nothing to swap there).  It is
-    // needed: without it the chunk-start states of the bench data fail the verification (measured) -- 40 % of this loop.
-#pragma unroll
-    for (int r = col + 1; r < J; ++r) {
-      const bool sw = fabs(A[r][col]) > fabs(A[col][col]);
-#pragma unroll
-      for (int j = col; j < 2 * J; ++j) {
-        const double hi = sw ? A[r][j] : A[col][j], lo = sw ? A[col][j] : A[r][j];
-        A[col][j] = hi; A[r][j] = lo;
-      }
-    }
-    const double rp = rcp_nr(A[col][col]);
-#pragma unroll
-    for (int j = col + 1; j < 2 * J; ++j) A[col][j] *= rp;
-#pragma unroll
-    for (int r = 0; r < J; ++r) {
-      if (r == col) continue;
-      const double f = A[r][col];
-#pragma unroll
-      for (int j = col + 1; j < 2 * J; ++j) A[r][j] = fma(-f, A[col][j], A[r][j]);   // (columns <= col: known 0 / 1)
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) out[j][i] = A[i][J + j];
-}
-
-// The chain of chunk-start states inside one wavefront (lane <-> chunk, this lane's map in M): every lane applies its own map
-// to the current state at every step and the result of the lane whose turn it is becomes the state of the next step
-// (NS lane broadcasts): the loop carries no memory access.  `mine` receives the state AFTER this lane's chunk.
-template <int J>
-__device__ __forceinline__ void chain_starts(const double (&M)[2 * J][2 * J], int steps, int lane, double (&S)[J][J],
-                                             double (&mine)[nsym(J)]) {
-  for (int turn = 0; turn < steps; ++turn) {
-    double X[J][J], Y[J][J];
-    // [X; Y] = M [S; I]
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double xs = M[i][J + j], ys = M[J + i][J + j];
-#pragma unroll
-        for (int l = 0; l < J; ++l) {
-          xs = fma(M[i][l], S[l][j], xs);
-          ys = fma(M[J + i][l], S[l][j], ys);
-        }
-        X[i][j] = xs; Y[i][j] = ys;
-      }
-    double Sn[J][J];
-    right_divide<J>(X, Y, Sn);
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-      for (int j = i; j < J; ++j) {
-        const double v = __shfl(0.5 * (Sn[i][j] + Sn[j][i]), turn, 64);   // the lane whose chunk this is
-        S[i][j] = v; S[j][i] = v;
-        mine[sidx(J, i, j)] = lane == turn ? v : mine[sidx(J, i, j)];
-      }
-  }
-}
-
 // LDS tile -> global, the mirror images (rows beyond the chunk are skipped)
 template <int J>
 __device__ __forceinline__ void flush_row_tile(double *__restrict__ base, const Chunks &c, int r0, int lane, const double *tile) {
@@ -220,177 +138,6 @@ __device__ __forceinline__ void flush_scalar_tile(double *__restrict__ base, con
   }
 }
 
-// ---- phase 1: composite linear-fractional map of rows s .. e-1 (towards row e) of chunk k < K - 1 ----------------------
-// FUSED (K <= 64: the wavefront holds every chunk of its series): phase 2 runs right here on the maps in registers and
-// `maps` is never written; `starts` receives the chunk-start states.
-template <int J, bool FUSED>
-__global__ __launch_bounds__(kThreads) void k_tp_maps(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                      int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
-                                                      const double *__restrict__ a, const double *__restrict__ U,
-                                                      const double *__restrict__ V, double *__restrict__ maps,
-                                                      double *__restrict__ starts,
-                                                      unsigned long long *__restrict__ guard) {
-  using Gm = Geo<J>;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { guard[0] = 0ull; guard[1] = 0ull; }   // maxed into later in the stream
-  __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 2 * 64 * Gm::SSTR];
-  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR;
-  const int lane = threadIdx.x;
-  const int64_t b = blockIdx.y, G = B * K;
-  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
-  int64_t k = ch.k0 + lane;
-  const bool inr = k < K;
-  if (!inr) k = K - 1;
-  const int64_t g = b * K + k;
-  const bool act = inr && k < K - 1;   // nobody starts from the end of the last chunk; the others are full (kRows rows)
-  double cj[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
-  double R[2 * J][2 * J];
-#pragma unroll
-  for (int i = 0; i < 2 * J; ++i)
-#pragma unroll
-    for (int j = 0; j < 2 * J; ++j) R[i][j] = i == j ? 1.0 : 0.0;
-  double tn = t[b * t_bs + k * kRows];
-  // tiles are requested one tile ahead into registers (the compiler parks them in AGPRs: R alone takes half the VGPRs)
-  double vu[16], vv[16], va[8], vt[8];
-  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
-  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
-  fetch_row_tile<J>(U, ch, 0, lane, vu);
-  fetch_row_tile<J>(V, ch, 0, lane, vv);
-  for (int r0 = 0; r0 < kRows; r0 += 8) {
-    lds_order();
-    stage_scalar_tile(tA, lane, va);
-    stage_scalar_tile(tT, lane, vt);
-    if (r0 + 8 < kRows) {
-      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
-      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
-    }
-#pragma unroll 1
-    for (int rt = 0; rt < 8; rt += Gm::RT) {
-      lds_order();
-      stage_row_tile<J>(tU, lane, vu);
-      stage_row_tile<J>(tV, lane, vv);
-      if (r0 + rt + Gm::RT < kRows) {
-        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
-        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
-      }
-      lds_order();
-#pragma unroll
-      for (int r = 0; r < Gm::RT; ++r) {
-        double x[2 * J], y[2 * J];
-        double kap = tA[lane * Gm::SSTR + rt + r];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          const double u = tU[lane * Gm::RSTR + r * J + j], v = tV[lane * Gm::RSTR + r * J + j];
-          kap = fma(-u, v, kap);
-          x[j] = v; x[J + j] = u; y[j] = -u; y[J + j] = v;
-        }
-        const double rk = 1.0 / kap;   // kappa <= 0 (no white noise): inf / nan end up in the map -> mismatch -> fallback
-        double yR[2 * J];
-#pragma unroll
-        for (int j = 0; j < 2 * J; ++j) {
-          double s_ = 0.0;
-#pragma unroll
-          for (int i = 0; i < 2 * J; ++i) s_ = fma(y[i], R[i][j], s_);
-          yR[j] = s_ * rk;
-        }
-        const double tn1 = tT[lane * Gm::SSTR + rt + r];
-        double p[J], ip[J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) { p[j] = exp_decay(cj[j] * (tn - tn1)); ip[j] = rcp_nr(p[j]); }
-        tn = tn1;
-#pragma unroll
-        for (int i = 0; i < 2 * J; ++i) {
-          const double sc = i < J ? p[i] : ip[i - J];
-#pragma unroll
-          for (int j = 0; j < 2 * J; ++j) R[i][j] = sc * fma(x[i], yR[j], R[i][j]);
-        }
-      }
-    }
-  }
-  if constexpr (FUSED) {
-    constexpr int NS = nsym(J);
-    double S[J][J], mine[NS];
-#pragma unroll
-    for (int i = 0; i < J; ++i)
-#pragma unroll
-      for (int j = 0; j < J; ++j) S[i][j] = 0.0;
-#pragma unroll
-    for (int q = 0; q < NS; ++q) mine[q] = 0.0;
-    if (lane < NS) starts[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing (forward.hpp:107-113)
-    chain_starts<J>(R, (int)(K - 1), lane, S, mine);
-    if (act) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + g + 1] = mine[q];
-    }
-  } else if (act) {
-#pragma unroll
-    for (int i = 0; i < 2 * J; ++i)
-#pragma unroll
-      for (int j = 0; j < 2 * J; ++j) maps[(int64_t)(i * 2 * J + j) * G + g] = R[i][j];
-  }
-}
-
-// ---- phase 2: chunk-start states.  One WAVEFRONT per series, lane <-> chunk: a lane keeps its chunk's map in registers
-// (coalesced load), every lane applies its own map to the current state at every step, and the result of the lane whose
-// turn it is becomes the state of the next step (20 lane broadcasts): the loop carries no memory access.
-template <int J>
-__global__ __launch_bounds__(kThreads) void k_tp_starts(int64_t B, int64_t K, const double *__restrict__ maps,
-                                                        double *__restrict__ starts) {
-  constexpr int NS = nsym(J);
-  const int lane = threadIdx.x;
-  const int64_t b = blockIdx.x, G = B * K;
-  double S[J][J];
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) S[i][j] = 0.0;
-  if (lane < NS) starts[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing (forward.hpp:107-113)
-  for (int64_t base = 0; base < K - 1; base += kThreads) {
-    const int64_t kk = base + lane;
-    const bool have = kk < K - 1;
-    const int64_t g = b * K + (have ? kk : 0);
-    double M[2 * J][2 * J];
-#pragma unroll
-    for (int i = 0; i < 2 * J; ++i)
-#pragma unroll
-      for (int j = 0; j < 2 * J; ++j) M[i][j] = maps[(int64_t)(i * 2 * J + j) * G + g];
-    double mine[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) mine[q] = 0.0;
-    const int steps = (int)((K - 1 - base) < kThreads ? (K - 1 - base) : kThreads);
-    chain_starts<J>(M, steps, lane, S, mine);
-    if (have) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + g + 1] = mine[q];
-    }
-  }
-}
-
-// The chain of F over the chunks of a wavefront (lane <-> chunk; this lane's G, g, q0, q1, Q2): every lane evaluates its
-// chunk's quadratic form and end state for the current F, the lane whose turn it is keeps / passes them on.
-template <int J>
-__device__ __forceinline__ void chain_finish(const double (&Gm)[J][J], const double (&gv)[J], double q0, const double (&q1)[J],
-                                             const double (&Q2)[nsym(J)], int steps, int lane, double (&F)[J],
-                                             double &quad) {
-  for (int turn = 0; turn < steps; ++turn) {
-    double qq = q0, Fn[J];
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-      qq = fma(-2.0 * q1[i], F[i], qq);
-      double gi = gv[i];
-#pragma unroll
-      for (int j = 0; j < J; ++j) {
-        qq = fma(Q2[i <= j ? sidx(J, i, j) : sidx(J, j, i)] * F[i], F[j], qq);
-        gi = fma(Gm[i][j], F[j], gi);
-      }
-      Fn[i] = gi;
-    }
-    quad += lane == turn ? qq : 0.0;
-#pragma unroll
-    for (int i = 0; i < J; ++i) F[i] = __shfl(Fn[i], turn, 64);
-  }
-}
 // relative mismatch between the end state a chunk computed and the start state its successor was given
 template <int J>
 __device__ __forceinline__ double start_mismatch(const double (&Send)[nsym(J)], const double *__restrict__ starts, int64_t G,
@@ -405,215 +152,26 @@ __device__ __forceinline__ double start_mismatch(const double (&Send)[nsym(J)], 
   }
   return dmax / fmax(smax, 1e-300);
 }
-// sums over the lanes (chunks) of a wavefront and the outputs of a series
-__device__ __forceinline__ void finish_series(double logdet, double quad, double first, double worst, int lane, int64_t N,
-                                              double *ll_b, int32_t *flag_b, unsigned long long *guard) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    logdet += __shfl_xor(logdet, o, 64);
-    quad += __shfl_xor(quad, o, 64);
-    first = fmin(first, __shfl_xor(first, o, 64));
-    worst = fmax(worst, __shfl_xor(worst, o, 64));
-  }
-  const bool bad = first != INFINITY;
-  // a failed factorisation is left to the ordinary kernel (it reports the reference's flag and -inf)
-  if (bad || !(logdet == logdet) || !(quad == quad) || !(worst == worst)) worst = INFINITY;
-  if (lane == 0) {
-    *ll_b = bad ? -INFINITY : -0.5 * (logdet + quad + (double)N * 1.83787706640934548356);   // numpy.py:84-109
-    *flag_b = bad ? (int32_t)first : 0;
-    const double gval = worst / kTol;
-    if (gval > 0.0) atomicMax(guard, (unsigned long long)__double_as_longlong(gval));   // gval >= 0: monotone bit pattern
-  }
-}
-
-// ---- phase 3: every chunk runs the recursion from its start state ----------------------------------------------------
-// FUSED (K <= 64): phase 4 runs right here on the chunk results in registers; `outs` is never written.
-template <int J, bool FUSED>
-__global__ __launch_bounds__(kThreads) void k_tp_chunks(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
-                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
-                                                        const double *__restrict__ a, const double *__restrict__ U,
-                                                        const double *__restrict__ V, const double *__restrict__ yv,
-                                                        const double *__restrict__ starts, double *__restrict__ outs,
-                                                        double *__restrict__ ends, double *__restrict__ ll,
-                                                        int32_t *__restrict__ flag, unsigned long long *__restrict__ guard,
-                                                        const unsigned long long *__restrict__ gate) {
-  using Gm = Geo<J>;
-  constexpr int NS = nsym(J);
-  __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 3 * 64 * Gm::SSTR];
-  if (gate_closed(gate)) return;   // (the refinement pass: runs only if the first pass failed its verification)
-  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR, *tY = tT + 64 * Gm::SSTR;
-  const int lane = threadIdx.x;
-  const int64_t b = blockIdx.y, G = B * K;
-  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
-  int64_t k = ch.k0 + lane;
-  const bool inr = k < K;
-  if (!inr) k = K - 1;
-  const int64_t g = b * K + k;
-  const int64_t s = k * kRows;
-  const int len = ch.len(k);
-  double cj[J], S[NS], Gmx[J][J], gv[J], q1[J], Q2[NS];
-#pragma unroll
-  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + j]; gv[j] = 0.0; q1[j] = 0.0; }
-#pragma unroll
-  for (int q = 0; q < NS; ++q) { S[q] = starts[(int64_t)q * G + g]; Q2[q] = 0.0; }
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) Gmx[i][j] = i == j ? 1.0 : 0.0;
-  double prod = 1.0, q0 = 0.0, failed = 0.0;
-  int eacc = 0;
-  double tn = t[b * t_bs + s];
-  double vu[16], vv[16], va[8], vy[8], vt[8];   // tiles requested one tile ahead
-  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
-  fetch_scalar_tile<false>(yv, ch, 0, 0, lane, vy);
-  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
-  fetch_row_tile<J>(U, ch, 0, lane, vu);
-  fetch_row_tile<J>(V, ch, 0, lane, vv);
-  for (int r0 = 0; r0 < kRows; r0 += 8) {
-    lds_order();
-    stage_scalar_tile(tA, lane, va);
-    stage_scalar_tile(tY, lane, vy);
-    stage_scalar_tile(tT, lane, vt);
-    if (r0 + 8 < kRows) {
-      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
-      fetch_scalar_tile<false>(yv, ch, r0 + 8, 0, lane, vy);
-      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
-    }
-#pragma unroll 1
-    for (int rt = 0; rt < 8; rt += Gm::RT) {
-      lds_order();
-      stage_row_tile<J>(tU, lane, vu);
-      stage_row_tile<J>(tV, lane, vv);
-      if (r0 + rt + Gm::RT < kRows) {
-        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
-        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
-      }
-      lds_order();
-#pragma unroll
-      for (int r = 0; r < Gm::RT; ++r) {
-        const int i0 = r0 + rt + r;          // row of the chunk
-        const int64_t n = s + i0;
-        if (i0 < len) {
-          double u[J], v[J], tau[J], rr[J], w[J];
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            u[j] = tU[lane * Gm::RSTR + r * J + j]; v[j] = tV[lane * Gm::RSTR + r * J + j];
-            tau[j] = 0.0; rr[j] = 0.0;
-          }
-          // tau = u S (forward.hpp:126), rr = u G, z0 = y - u.g
-#pragma unroll
-          for (int i = 0; i < J; ++i)
-#pragma unroll
-            for (int j = i; j < J; ++j) {
-              const double sv = S[sidx(J, i, j)];
-              tau[j] = fma(u[i], sv, tau[j]);
-              if (j != i) tau[i] = fma(u[j], sv, tau[i]);
-            }
-          double d = tA[lane * Gm::SSTR + rt + r], z0 = tY[lane * Gm::SSTR + rt + r];
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            d = fma(-tau[j], u[j], d);          // forward.hpp:127
-            z0 = fma(-u[j], gv[j], z0);
-#pragma unroll
-            for (int i = 0; i < J; ++i) rr[j] = fma(u[i], Gmx[i][j], rr[j]);
-          }
-          const double rd = rcp_nr(d);
-          failed = (failed == 0.0 && n > 0 && !(d > 0.0)) ? (double)n : failed;   // forward.hpp:128 (first row)
-#pragma unroll
-          for (int j = 0; j < J; ++j) w[j] = (v[j] - tau[j]) * rd;   // forward.hpp:131
-          prod *= d;
-          if (i0 & 1) { int ex; prod = frexp(prod, &ex); eacc += ex; }
-          const double z0d = z0 * rd;
-          q0 = fma(z0, z0d, q0);
-#pragma unroll
-          for (int i = 0; i < J; ++i) {
-            q1[i] = fma(z0d, rr[i], q1[i]);
-            const double rid = rr[i] * rd;
-#pragma unroll
-            for (int j = i; j < J; ++j) Q2[sidx(J, i, j)] = fma(rid, rr[j], Q2[sidx(J, i, j)]);
-          }
-          if (n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123, internal.hpp:140-143)
-            const double tn1 = tT[lane * Gm::SSTR + rt + r];
-            double p[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) p[j] = exp_decay(cj[j] * (tn - tn1));
-            tn = tn1;
-#pragma unroll
-            for (int i = 0; i < J; ++i) {
-              const double dwi = d * w[i];
-#pragma unroll
-              for (int j = i; j < J; ++j) S[sidx(J, i, j)] = (p[i] * p[j]) * fma(dwi, w[j], S[sidx(J, i, j)]);
-#pragma unroll
-              for (int j = 0; j < J; ++j) Gmx[i][j] = p[i] * fma(-w[i], rr[j], Gmx[i][j]);
-              gv[i] = p[i] * fma(w[i], z0, gv[i]);
-            }
-          }
-        }
-      }
-    }
-  }
-  int ex;
-  prod = frexp(prod, &ex);
-  const double logdet = log(prod) + (double)(eacc + ex) * 0.693147180559945309417;
-  if (ends) {   // this chunk's end state = its successor's start state for the refinement pass (contracted: good to rounding)
-    if (blockIdx.x == 0 && lane < NS) ends[(int64_t)lane * G + b * K] = 0.0;
-    if (inr && k + 1 < K) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) ends[(int64_t)q * G + g + 1] = S[q];
-    }
-  }
-  if constexpr (FUSED) {
-    double worst = 0.0;
-    if (inr && k + 1 < K) worst = start_mismatch<J>(S, starts, G, g + 1);
-    double F[J], quad = 0.0;
-#pragma unroll
-    for (int j = 0; j < J; ++j) F[j] = 0.0;
-    chain_finish<J>(Gmx, gv, q0, q1, Q2, (int)K, lane, F, quad);
-    finish_series(inr ? logdet : 0.0, quad, (inr && failed != 0.0) ? failed : INFINITY, worst, lane, N, ll + b, flag + b,
-                  guard);
-    return;
-  }
-  if (!inr) return;
-  int q = 0;
-#pragma unroll
-  for (int i = 0; i < NS; ++i) outs[(int64_t)(q++) * G + g] = S[i];
-#pragma unroll
-  for (int i = 0; i < J; ++i)
-#pragma unroll
-    for (int j = 0; j < J; ++j) outs[(int64_t)(q++) * G + g] = Gmx[i][j];
-#pragma unroll
-  for (int i = 0; i < J; ++i) outs[(int64_t)(q++) * G + g] = gv[i];
-  outs[(int64_t)(q++) * G + g] = logdet;
-  outs[(int64_t)(q++) * G + g] = q0;
-#pragma unroll
-  for (int i = 0; i < J; ++i) outs[(int64_t)(q++) * G + g] = q1[i];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) outs[(int64_t)(q++) * G + g] = Q2[i];
-  outs[(int64_t)(q++) * G + g] = failed;
-}
 
 // =============================================================================================================
-// ONE PASS (round 5): chunk elements combined in scattering form.
+// Chunk ELEMENTS in scattering form.
 //
-// Run from the ZERO state over a span of rows, the recursion yields the span's ELEMENT
+// Run from the ZERO state over a span of rows, the recursions yield the span's element
 //     A = prod P (I - w^T u)   (transition of F),   G = the end state T,   Q = sum r^T r / d  (r = u A_before),
 //     g = the end state F,   h = sum z r / d,   q0 = sum z^2 / d,   prod d
-// -- what k_tp_chunks accumulates anyway -- and entered with a state (T, F) instead, the same span gives
-//     T' = G + A Gt' A^T,   F' = g + A (I - T Q)^-1 (F - T h),   sum log d = log prod d + log det(I - Q T),
-//     sum z^2 / d = q0 - 2 h.F + F^T Q F + rho^T T (I - Q T)^-1 rho,   rho = h - Q F        (Gt' = T (I - Q T)^-1)
-// (the factor recursion is a Kalman filter in disguise -- T the explained covariance, Q the information a span gathers --
-// and these are the update formulas of its information form; found with tools-free numpy, checked to 1e-15 against the
-// sequential recursion: docs/rounds/r05.md).  Two consecutive spans therefore COMBINE into the element of their union with
-// nothing but the symmetric positive definite  Ks = I - L^T Q2 L,  G1 = L L^T:
+// and entered with a state (T, F) instead, the same span gives (Gt = T (I - Q T)^-1, rho = h - Q F)
+//     T' = G + A Gt A^T,   F' = g + A (I - T Q)^-1 (F - T h),   sum log d = log prod d + log det(I - Q T),
+//     sum z^2 / d = q0 - 2 h.F + F^T Q F + rho^T Gt rho .
+// Two consecutive spans therefore COMBINE into the element of their union, with nothing to invert but the symmetric
+// positive definite  Ks = I - L^T Q2 L,  G1 = L L^T:
 //     Gt = L Ks^-1 L^T  (= G1 (I - Q2 G1)^-1),   M = I + Gt Q2,   rho = h2 - Q2 g1
 //     A = A2 M A1,   G = G2 + A2 Gt A2^T,   Q = Q1 + A1^T Q2 M A1,   g = g2 + A2 (g1 - Gt rho),
 //     h = h1 + A1^T (rho + Q2 Gt rho),   q0 = q0_1 + q0_2 - g1.(h2 + rho) + rho.Gt rho,   prod d = prod1 prod2 det Ks
-// Unlike the composite linear-fractional maps of k_tp_maps (ill-conditioned in the span: 1e-12 at 64 rows, useless beyond
-// 128) the combination is as well-conditioned as the factorisation itself (Ks has the eigenvalues d_n(T) / d_n(0) between
-// its extremes), so spans combine in a TREE and nothing is verified or repeated: one pass over the rows, six combinations
-// per wavefront.  Ks positive definite  <=>  every d_n of the later span stays positive when it is entered with G1 (its
-// eigenvalues fall monotonically along the span): a failed Cholesky pivot, or d_n <= 0 from the zero state (an upper
-// bound of the true d_n), marks the series failed and the row-by-row kernel behind the gate reports the reference's flag.
+// Ks has the ratios d_n(T) / d_n(0) between its extreme eigenvalues: the combination is as well-conditioned as the
+// factorisation itself, whatever the length of the spans -- they combine in a tree (or a scan) and nothing is verified or
+// repeated.  Ks positive definite  <=>  every d_n of the later span stays positive when it is entered with G1 (the
+// eigenvalues fall monotonically along the span): a failed Cholesky pivot, or d_n <= 0 from the zero state (an upper bound of
+// the true d_n), marks the series failed, and the row-by-row kernel behind the gate reports the reference's flag.
 template <int J>
 struct Elem {
   double A[J][J], G[nsym(J)], Q[nsym(J)], g[J], h[J], q0, prod;
@@ -631,28 +189,32 @@ __device__ __forceinline__ void elem_identity(Elem<J> &e) {
   for (int q = 0; q < nsym(J); ++q) { e.G[q] = 0.0; e.Q[q] = 0.0; }
   e.q0 = 0.0; e.prod = 1.0; e.ex = 0;
 }
-template <int J>
+// VEC = false everywhere below: the matrices only (A, G, Q and the product of the pivots -- what `factor` needs)
+template <int J, bool VEC = true>
 __device__ __forceinline__ void elem_from_lane(const Elem<J> &e, int src, Elem<J> &o) {
 #pragma unroll
   for (int i = 0; i < J; ++i) {
-    o.g[i] = __shfl(e.g[i], src, 64); o.h[i] = __shfl(e.h[i], src, 64);
+    if (VEC) { o.g[i] = __shfl(e.g[i], src, 64); o.h[i] = __shfl(e.h[i], src, 64); }
 #pragma unroll
     for (int j = 0; j < J; ++j) o.A[i][j] = __shfl(e.A[i][j], src, 64);
   }
 #pragma unroll
   for (int q = 0; q < nsym(J); ++q) { o.G[q] = __shfl(e.G[q], src, 64); o.Q[q] = __shfl(e.Q[q], src, 64); }
-  o.q0 = __shfl(e.q0, src, 64); o.prod = __shfl(e.prod, src, 64); o.ex = __shfl(e.ex, src, 64);
+  if (VEC) o.q0 = __shfl(e.q0, src, 64);
+  o.prod = __shfl(e.prod, src, 64); o.ex = __shfl(e.ex, src, 64);
 }
 __device__ __forceinline__ constexpr int sym(int J, int i, int j) { return i <= j ? sidx(J, i, j) : sidx(J, j, i); }
 
-// e1 (the earlier span) <- e1 followed by e2
+// Gt = T (I - Q T)^-1 = L Ks^-1 L^T for symmetric positive semi-definite T = L L^T, Q;  det = det Ks = det(I - Q T);
+// returns false when Ks is not positive definite
 template <int J>
-__device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
-  // G1 = L L^T (positive SEMI-definite: a non-positive pivot is rounding, its column is dropped)
+__device__ __forceinline__ bool posterior(const double (&T)[nsym(J)], const double (&Q)[nsym(J)], double (&Gt)[nsym(J)],
+                                          double &det) {
+  // T = L L^T (a non-positive pivot is rounding: its column is dropped)
   double L[J][J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    double sp = e1.G[sidx(J, j, j)];
+    double sp = T[sidx(J, j, j)];
 #pragma unroll
     for (int k = 0; k < j; ++k) sp = fma(-L[j][k], L[j][k], sp);
     const bool ok = sp > 0.0;
@@ -660,13 +222,13 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
     L[j][j] = ljj;
 #pragma unroll
     for (int i = j + 1; i < J; ++i) {
-      double v = e1.G[sidx(J, j, i)];
+      double v = T[sidx(J, j, i)];
 #pragma unroll
       for (int k = 0; k < j; ++k) v = fma(-L[i][k], L[j][k], v);
       L[i][j] = v * inv;
     }
   }
-  // X = Q2 L,  Ks = I - L^T X (lower triangle)
+  // X = Q L,  Ks = I - L^T X (lower triangle)
   double X[J][J], Ks[J][J];
 #pragma unroll
   for (int i = 0; i < J; ++i)
@@ -674,7 +236,7 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
     for (int j = 0; j < J; ++j) {
       double v = 0.0;
 #pragma unroll
-      for (int k = j; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], L[k][j], v);
+      for (int k = j; k < J; ++k) v = fma(Q[sym(J, i, k)], L[k][j], v);
       X[i][j] = v;
     }
 #pragma unroll
@@ -686,15 +248,16 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
       for (int k = i; k < J; ++k) v = fma(-L[k][i], X[k][j], v);
       Ks[i][j] = v;
     }
-  // Ks = C C^T in place (lower), det Ks = prod of the pivots; a non-positive pivot = a failed factorisation of the series
-  double det = 1.0, ic[J];
-  bool bad = false;
+  // Ks = C C^T in place, det Ks = the product of the pivots
+  double ic[J];
+  bool good = true;
+  det = 1.0;
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     double sp = Ks[j][j];
 #pragma unroll
     for (int k = 0; k < j; ++k) sp = fma(-Ks[j][k], Ks[j][k], sp);
-    bad = bad || !(sp > 0.0);
+    good = good && sp > 0.0;
     det *= sp;
     const double cjj = sqrt(sp);
     ic[j] = rcp_nr(cjj);
@@ -707,7 +270,7 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
       Ks[i][j] = v * ic[j];
     }
   }
-  // Y = C^-1 L^T (column m of L^T = row m of L: zero above... L^T[k][m] = L[m][k], k <= m),  Gt = Y^T Y
+  // Y = C^-1 L^T,  Gt = Y^T Y
   double Y[J][J];
 #pragma unroll
   for (int m = 0; m < J; ++m)
@@ -718,7 +281,6 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
       for (int k = 0; k < i; ++k) v = fma(-Ks[i][k], Y[k][m], v);
       Y[i][m] = v * ic[i];
     }
-  double Gt[nsym(J)];
 #pragma unroll
   for (int i = 0; i < J; ++i)
 #pragma unroll
@@ -728,44 +290,56 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
       for (int k = 0; k < J; ++k) v = fma(Y[k][i], Y[k][j], v);
       Gt[sidx(J, i, j)] = v;
     }
-  // vectors
-  double rho[J], Gr[J], tv[J];
+  return good;
+}
+
+// e1 (the earlier span) <- e1 followed by e2
+template <int J, bool VEC = true>
+__device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
+  double Gt[nsym(J)], det;
+  const bool good = posterior<J>(e1.G, e2.Q, Gt, det);
+  if (VEC) {
+    double rho[J], Gr[J], tv[J];
 #pragma unroll
-  for (int i = 0; i < J; ++i) {
-    double v = e2.h[i];
+    for (int i = 0; i < J; ++i) {
+      double v = e2.h[i];
 #pragma unroll
-    for (int k = 0; k < J; ++k) v = fma(-e2.Q[sym(J, i, k)], e1.g[k], v);
-    rho[i] = v;
-  }
-  double q0 = e1.q0 + e2.q0;
-#pragma unroll
-  for (int i = 0; i < J; ++i) {
-    double v = 0.0;
-#pragma unroll
-    for (int k = 0; k < J; ++k) v = fma(Gt[sym(J, i, k)], rho[k], v);
-    Gr[i] = v;
-    q0 = fma(-e1.g[i], e2.h[i] + rho[i], q0);
-  }
-#pragma unroll
-  for (int i = 0; i < J; ++i) {
-    q0 = fma(rho[i], Gr[i], q0);
-    double v = rho[i];
-#pragma unroll
-    for (int k = 0; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], Gr[k], v);
-    tv[i] = v;                       // rho + Q2 Gt rho
-  }
-  double gn[J], hn[J];
-#pragma unroll
-  for (int i = 0; i < J; ++i) {
-    double v = e2.g[i], hv = e1.h[i];
-#pragma unroll
-    for (int k = 0; k < J; ++k) {
-      v = fma(e2.A[i][k], e1.g[k] - Gr[k], v);
-      hv = fma(e1.A[k][i], tv[k], hv);
+      for (int k = 0; k < J; ++k) v = fma(-e2.Q[sym(J, i, k)], e1.g[k], v);
+      rho[i] = v;
     }
-    gn[i] = v; hn[i] = hv;
+    double q0 = e1.q0 + e2.q0;
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(Gt[sym(J, i, k)], rho[k], v);
+      Gr[i] = v;
+      q0 = fma(-e1.g[i], e2.h[i] + rho[i], q0);
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      q0 = fma(rho[i], Gr[i], q0);
+      double v = rho[i];
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(e2.Q[sym(J, i, k)], Gr[k], v);
+      tv[i] = v;                       // rho + Q2 Gt rho
+    }
+    double gn[J], hn[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      double v = e2.g[i], hv = e1.h[i];
+#pragma unroll
+      for (int k = 0; k < J; ++k) {
+        v = fma(e2.A[i][k], e1.g[k] - Gr[k], v);
+        hv = fma(e1.A[k][i], tv[k], hv);
+      }
+      gn[i] = v; hn[i] = hv;
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i) { e1.g[i] = gn[i]; e1.h[i] = hn[i]; }
+    e1.q0 = q0;
   }
-  // matrices: QA = Q2 A1, MA = A1 + Gt QA, A = A2 MA, Q = Q1 + A1^T (Q2 MA), G = G2 + (A2 Gt) A2^T
+  // QA = Q2 A1, MA = A1 + Gt QA (= M A1), Q = Q1 + A1^T (Q2 MA), G = G2 + (A2 Gt) A2^T, A = A2 MA
   double MA[J][J];
   {
     double QA[J][J];
@@ -839,15 +413,37 @@ __device__ __forceinline__ void elem_combine(Elem<J> &e1, const Elem<J> &e2) {
       for (int k = 0; k < J; ++k) v = fma(e2.A[i][k], MA[k][j], v);
       e1.A[i][j] = v;
     }
-#pragma unroll
-  for (int i = 0; i < J; ++i) { e1.g[i] = gn[i]; e1.h[i] = hn[i]; }
-  e1.q0 = q0;
   int ex;
   e1.prod = frexp(e1.prod * e2.prod * det, &ex);
   e1.ex += e2.ex + ex;
-  if (bad) e1.prod = __longlong_as_double(0x7ff8000000000000ll);
+  if (!good) e1.prod = __longlong_as_double(0x7ff8000000000000ll);
 }
-// the element of the 64 lanes' spans, in lane 0 (lane l: spans l .. l + 2^level - 1 as far as they are complete)
+// the state T a span entered with T leaves behind: Tn = G + A Gt A^T (false: not positive definite)
+template <int J>
+__device__ __forceinline__ bool elem_apply(const Elem<J> &e, const double (&T)[nsym(J)], double (&Tn)[nsym(J)]) {
+  double Gt[nsym(J)], det, AG[J][J];
+  const bool good = posterior<J>(T, e.Q, Gt, det);
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(e.A[i][k], Gt[sym(J, k, j)], v);
+      AG[i][j] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = i; j < J; ++j) {
+      double v = e.G[sidx(J, i, j)];
+#pragma unroll
+      for (int k = 0; k < J; ++k) v = fma(AG[i][k], e.A[j][k], v);
+      Tn[sidx(J, i, j)] = v;
+    }
+  return good;
+}
+// the element of the first `count` lanes' spans, in lane 0 (lane l: spans l .. l + 2^level - 1 as far as they are complete)
 template <int J>
 __device__ __forceinline__ void elem_tree(Elem<J> &e, int lane, int count = 64) {
 #pragma unroll 1
@@ -857,14 +453,62 @@ __device__ __forceinline__ void elem_tree(Elem<J> &e, int lane, int count = 64) 
     elem_combine<J>(e, o);
   }
 }
+// inclusive scan (matrices only): lane l ends up with the element of spans 0 .. l
+template <int J>
+__device__ __forceinline__ void elem_scan(Elem<J> &e, int lane, int count = 64) {
+#pragma unroll 1
+  for (int off = 1; off < count; off <<= 1) {
+    Elem<J> o;
+    elem_from_lane<J, false>(e, lane >= off ? lane - off : lane, o);
+    elem_combine<J, false>(o, e);
+    if (lane >= off) {
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) e.A[i][j] = o.A[i][j];
+#pragma unroll
+      for (int q = 0; q < nsym(J); ++q) { e.G[q] = o.G[q]; e.Q[q] = o.Q[q]; }
+      e.prod = o.prod; e.ex = o.ex;
+    }
+  }
+}
+// matrices of an element in memory: [entry][at], stride `W` between entries
+template <int J>
+struct ElemIO {
+  static constexpr int N_ = J * J + 2 * nsym(J) + 2 * J + 3;   // A, G, Q, g, h, q0, prod, ex
+  static constexpr int NM = J * J + 2 * nsym(J) + 1;           // A, G, Q, prod (NaN: failed)
+};
+template <int J>
+__device__ __forceinline__ void elem_store_matrices(const Elem<J> &e, double *__restrict__ base, int64_t W, int64_t at) {
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) base[(int64_t)(q++) * W + at] = e.A[i][j];
+#pragma unroll
+  for (int i = 0; i < nsym(J); ++i) base[(int64_t)(q++) * W + at] = e.G[i];
+#pragma unroll
+  for (int i = 0; i < nsym(J); ++i) base[(int64_t)(q++) * W + at] = e.Q[i];
+  base[(int64_t)(q++) * W + at] = e.prod;
+}
+template <int J>
+__device__ __forceinline__ void elem_load_matrices(Elem<J> &e, const double *__restrict__ base, int64_t W, int64_t at) {
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < J; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) e.A[i][j] = base[(int64_t)(q++) * W + at];
+#pragma unroll
+  for (int i = 0; i < nsym(J); ++i) e.G[i] = base[(int64_t)(q++) * W + at];
+#pragma unroll
+  for (int i = 0; i < nsym(J); ++i) e.Q[i] = base[(int64_t)(q++) * W + at];
+  e.prod = base[(int64_t)(q++) * W + at];
+  e.ex = 0;
+}
 
 // rows of the chunks from the zero state -> elements -> the tree.  ONE wavefront per 64 chunks of a series; SINGLE: the
 // series has at most 64 chunks and the wavefront finishes it (ll, flag, gate word); otherwise its element goes to `elems`
 // ([entry][series * wavefronts + wavefront]) for k_tp_join.
-template <int J>
-struct ElemIO {
-  static constexpr int N_ = J * J + 2 * nsym(J) + 2 * J + 3;   // A, G, Q, g, h, q0, prod, ex
-};
 template <int J, bool SINGLE>
 __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
@@ -1081,18 +725,200 @@ __global__ __launch_bounds__(kThreads) void k_tp_join(int64_t B, int64_t N, int6
   }
 }
 
-// ---- `factor` itself (forward.hpp:69-135: d, W, flag), phase 3 with the rows written out.  d == a / W == V in place are NOT
-// supported here (the caller keeps those on the row-by-row kernel: its fallback would read what this kernel overwrote).
-// Two passes.  The start states of phase 2 carry the error of an ill-conditioned composite map (1e-12 of |S|, which the
-// difference v - u S in W turns into 1e-10 of W: at the parity bar).  The recursion itself contracts such an error by the
-// very factor that makes the maps ill-conditioned, so the END states of a first pass (WRITE = false: states only) are
-// start states good to rounding; the second pass (WRITE = true) writes d and W from those and verifies against them.
-template <int J, bool WRITE>
+// ---- `factor`: chunk-start states.  The matrices of the chunk elements (no right-hand side) and an inclusive scan inside the
+// wavefront.  SINGLE (a series of at most 64 chunks): the start state of chunk k + 1 is the G of the prefix 0 .. k, written
+// to `starts`; otherwise the prefixes go to `pref` and k_tp_carry / k_tp_long_starts finish the job.
+template <int J, bool SINGLE>
+__global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                        const double *__restrict__ a, const double *__restrict__ U,
+                                                        const double *__restrict__ V, double *__restrict__ starts,
+                                                        double *__restrict__ pref, unsigned long long *__restrict__ guard) {
+  using Gm = Geo<J>;
+  constexpr int NS = nsym(J);
+  __shared__ __attribute__((aligned(16))) double lds[2 * 64 * Gm::RSTR + 2 * 64 * Gm::SSTR];
+  double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR;
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, G = B * K;
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  int64_t k = ch.k0 + lane;
+  const bool inr = k < K;
+  if (!inr) k = K - 1;
+  const int64_t g = b * K + k;
+  const int64_t s = k * kRows;
+  const int len = ch.len(k);
+  Elem<J> e;
+  elem_identity<J>(e);
+  double cj[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
+  bool ceq = J % 2 == 0;
+#pragma unroll
+  for (int j = 0; j + 1 < J; j += 2) ceq = ceq && cj[j] == cj[j + 1];
+  bool failed = false;
+  double tn = t[b * t_bs + s];
+  double vu[16], vv[16], va[8], vt[8];   // tiles requested one tile ahead
+  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  fetch_row_tile<J>(U, ch, 0, lane, vu);
+  fetch_row_tile<J>(V, ch, 0, lane, vv);
+  for (int r0 = 0; r0 < kRows; r0 += 8) {
+    lds_order();
+    stage_scalar_tile(tA, lane, va);
+    stage_scalar_tile(tT, lane, vt);
+    if (r0 + 8 < kRows) {
+      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    }
+#pragma unroll 1
+    for (int rt = 0; rt < 8; rt += Gm::RT) {
+      lds_order();
+      stage_row_tile<J>(tU, lane, vu);
+      stage_row_tile<J>(tV, lane, vv);
+      if (r0 + rt + Gm::RT < kRows) {
+        fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
+        fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
+      }
+      lds_order();
+#pragma unroll
+      for (int r = 0; r < Gm::RT; ++r) {
+        const int i0 = r0 + rt + r;
+        const int64_t n = s + i0;
+        if (i0 < len) {
+          double u[J], v[J], tau[J], rr[J], w[J];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            u[j] = tU[lane * Gm::RSTR + r * J + j]; v[j] = tV[lane * Gm::RSTR + r * J + j];
+            tau[j] = 0.0; rr[j] = 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < J; ++i)
+#pragma unroll
+            for (int j = i; j < J; ++j) {
+              const double sv = e.G[sidx(J, i, j)];
+              tau[j] = fma(u[i], sv, tau[j]);
+              if (j != i) tau[i] = fma(u[j], sv, tau[i]);
+            }
+          double d = tA[lane * Gm::SSTR + rt + r];
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            d = fma(-tau[j], u[j], d);          // forward.hpp:127
+#pragma unroll
+            for (int i = 0; i < J; ++i) rr[j] = fma(u[i], e.A[i][j], rr[j]);
+          }
+          const double rd = rcp_nr(d);
+          failed = failed || (n > 0 && !(d > 0.0));   // forward.hpp:128 (the first row's d is not checked there)
+#pragma unroll
+          for (int j = 0; j < J; ++j) w[j] = (v[j] - tau[j]) * rd;   // forward.hpp:131
+#pragma unroll
+          for (int i = 0; i < J; ++i) {
+            const double rid = rr[i] * rd;
+#pragma unroll
+            for (int j = i; j < J; ++j) e.Q[sidx(J, i, j)] = fma(rid, rr[j], e.Q[sidx(J, i, j)]);
+          }
+          if (n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123)
+            const double tn1 = tT[lane * Gm::SSTR + rt + r];
+            double p[J];
+            if (ceq) {   // (complex terms: the rates come in pairs)
+#pragma unroll
+              for (int j = 0; j + 1 < J; j += 2) { p[j] = exp_decay(cj[j] * (tn - tn1)); p[j + 1] = p[j]; }
+            } else {
+#pragma unroll
+              for (int j = 0; j < J; ++j) p[j] = exp_decay(cj[j] * (tn - tn1));
+            }
+            tn = tn1;
+#pragma unroll
+            for (int i = 0; i < J; ++i) {
+              const double dwi = d * w[i];
+#pragma unroll
+              for (int j = i; j < J; ++j) e.G[sidx(J, i, j)] = (p[i] * p[j]) * fma(dwi, w[j], e.G[sidx(J, i, j)]);
+#pragma unroll
+              for (int j = 0; j < J; ++j) e.A[i][j] = p[i] * fma(-w[i], rr[j], e.A[i][j]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!inr) { elem_identity<J>(e); failed = false; }   // (lanes beyond the series ran its last chunk for the loads' sake)
+  elem_scan<J>(e, lane, (int)((K - ch.k0) < kThreads ? (K - ch.k0) : kThreads));
+  if (failed || !(e.prod == e.prod)) atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+  if constexpr (SINGLE) {
+    if (lane < NS) starts[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing (forward.hpp:107-113)
+    if (inr && k + 1 < K) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + g + 1] = e.G[q];
+    }
+  } else if (inr) {
+    elem_store_matrices<J>(e, pref, G, g);
+  }
+}
+// long series (more than 64 chunks): the state every WAVEFRONT of k_tp_states starts from.  One wavefront per series, lane <->
+// wavefront of the series, 64 a round: the totals (the prefix of a wavefront's last chunk) scanned, applied to the state
+// the round starts from.
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_carry(int64_t B, int64_t K, int64_t Wn, const double *__restrict__ pref,
+                                                       double *__restrict__ tin, unsigned long long *__restrict__ guard) {
+  constexpr int NS = nsym(J);
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.x, G = B * K, W = B * Wn;
+  double T[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) T[q] = 0.0;
+  if (lane < NS) tin[(int64_t)lane * W + b * Wn] = 0.0;
+  bool bad = false;
+  for (int64_t base = 0; base < Wn; base += kThreads) {
+    const int64_t w = base + lane;
+    Elem<J> e;
+    elem_identity<J>(e);
+    if (w < Wn) {
+      const int64_t last = ((w + 1) * kThreads < K ? (w + 1) * kThreads : K) - 1;
+      elem_load_matrices<J>(e, pref, G, b * K + last);
+    }
+    elem_scan<J>(e, lane, (int)((Wn - base) < kThreads ? (Wn - base) : kThreads));
+    double Tn[NS];
+    const bool good = elem_apply<J>(e, T, Tn);
+    if (w < Wn) bad = bad || !good || !(e.prod == e.prod);
+    if (w + 1 < Wn) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q) tin[(int64_t)q * W + b * Wn + w + 1] = Tn[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) T[q] = __shfl(Tn[q], 63, 64);
+  }
+  if (bad) atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+}
+// ... and the start state of every chunk: its wavefront's, pushed through the prefix of the chunks before it
+template <int J>
+__global__ __launch_bounds__(kThreads) void k_tp_long_starts(int64_t B, int64_t K, int64_t Wn, const double *__restrict__ pref,
+                                                             const double *__restrict__ tin, double *__restrict__ starts,
+                                                             unsigned long long *__restrict__ guard) {
+  constexpr int NS = nsym(J);
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, G = B * K, W = B * Wn;
+  const int64_t k = (int64_t)blockIdx.x * kThreads + lane;
+  if (k >= K) return;
+  double T[NS], Tn[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) { T[q] = tin[(int64_t)q * W + b * Wn + blockIdx.x]; Tn[q] = T[q]; }
+  if (lane > 0) {
+    Elem<J> e;
+    elem_load_matrices<J>(e, pref, G, b * K + k - 1);
+    if (!elem_apply<J>(e, T, Tn)) atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) starts[(int64_t)q * G + b * K + k] = Tn[q];
+}
+
+// ---- `factor` itself (forward.hpp:69-135: d, W, flag): every chunk runs the recursion from its start state and writes its rows.
+// d == a / W == V in place are NOT supported here (the caller keeps those on the row-by-row kernel: its fallback would read
+// what this kernel overwrote).
+template <int J>
 __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                         int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                         const double *__restrict__ a, const double *__restrict__ U,
                                                         const double *__restrict__ V, const double *__restrict__ starts,
-                                                        double *__restrict__ ends, double *__restrict__ d_out,
+                                                        double *__restrict__ d_out,
                                                         double *__restrict__ W_out, int32_t *__restrict__ flag,
                                                         unsigned long long *__restrict__ guard) {
   using Gm = Geo<J>;
@@ -1114,8 +940,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
   for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + j];
 #pragma unroll
   for (int q = 0; q < NS; ++q) S[q] = starts[(int64_t)q * G + g];
-  if (WRITE && blockIdx.x == 0 && lane == 0) flag[b] = 0;
-  if (!WRITE && blockIdx.x == 0 && lane < NS) ends[(int64_t)lane * G + b * K] = 0.0;   // chunk 0 starts from nothing
+  if (blockIdx.x == 0 && lane == 0) flag[b] = 0;
   double failed = 0.0;
   double tn = t[b * t_bs + s];
   double vu[16], vv[16], va[8], vt[8];   // tiles requested one tile ahead
@@ -1164,9 +989,9 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
 #pragma unroll
         for (int j = 0; j < J; ++j) {   // forward.hpp:131
           w[j] = (v[j] - tau[j]) * rd;
-          if (WRITE) tW[lane * Gm::RSTR + r * J + j] = w[j];
+          tW[lane * Gm::RSTR + r * J + j] = w[j];
         }
-        if (WRITE) tD[lane * Gm::SSTR + rt + r] = d;
+        tD[lane * Gm::SSTR + rt + r] = d;
         if (i0 < len && n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123)
           const double tn1 = tT[lane * Gm::SSTR + rt + r];
           double p[J];
@@ -1181,22 +1006,11 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
           }
         }
       }
-      if (WRITE) {
-        lds_order();
-        flush_row_tile<J>(W_out, ch, r0 + rt, lane, tW);
-      }
-    }
-    if (WRITE) {
       lds_order();
-      flush_scalar_tile(d_out, ch, r0, lane, tD);
+      flush_row_tile<J>(W_out, ch, r0 + rt, lane, tW);
     }
-  }
-  if (!WRITE) {   // states only: this chunk's end state is its successor's start state in the second pass
-    if (inr && k + 1 < K) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q) ends[(int64_t)q * G + g + 1] = S[q];
-    }
-    return;
+    lds_order();
+    flush_scalar_tile(d_out, ch, r0, lane, tD);
   }
   // verification: this chunk's end state against the start state its successor was given; failures -> the row-by-row kernel
   double worst = 0.0;
@@ -1209,116 +1023,52 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
   if (lane == 0 && gval > 0.0) atomicMax(guard, (unsigned long long)__double_as_longlong(gval));
 }
 
-// ---- phase 4: chain the chunks of a series, verify the chunk-start states.  One wavefront per series, lane <-> chunk:
-// the chunk results are loaded coalesced, the verification is lane-parallel, the chain of F broadcasts J values a step.
-template <int J>
-__global__ __launch_bounds__(kThreads) void k_tp_finish(int64_t B, int64_t N, int64_t K, const double *__restrict__ starts,
-                                                        const double *__restrict__ outs, double *__restrict__ ll,
-                                                        int32_t *__restrict__ flag,
-                                                        unsigned long long *__restrict__ guard,
-                                                        const unsigned long long *__restrict__ gate) {
-  constexpr int NS = nsym(J);
-  if (gate_closed(gate)) return;
-  constexpr int oG = NS, og = NS + J * J, ol = og + J, oq1 = ol + 2, oQ2 = oq1 + J, of = oQ2 + NS;
-  const int lane = threadIdx.x;
-  const int64_t b = blockIdx.x, G = B * K;
-  double F[J];
-#pragma unroll
-  for (int j = 0; j < J; ++j) F[j] = 0.0;
-  double worst = 0.0, logdet = 0.0, quad = 0.0, first = INFINITY;
-  for (int64_t base = 0; base < K; base += kThreads) {
-    const int64_t kk = base + lane;
-    const bool have = kk < K;
-    const int64_t g = b * K + (have ? kk : 0);
-    double Gm[J][J], gv[J], q1[J], Q2[NS], Send[NS];
-#pragma unroll
-    for (int i = 0; i < J; ++i) {
-      gv[i] = outs[(int64_t)(og + i) * G + g];
-      q1[i] = outs[(int64_t)(oq1 + i) * G + g];
-#pragma unroll
-      for (int j = 0; j < J; ++j) Gm[i][j] = outs[(int64_t)(oG + i * J + j) * G + g];
-    }
-#pragma unroll
-    for (int q = 0; q < NS; ++q) { Q2[q] = outs[(int64_t)(oQ2 + q) * G + g]; Send[q] = outs[(int64_t)q * G + g]; }
-    const double q0 = outs[(int64_t)(ol + 1) * G + g];
-    if (have) {
-      logdet += outs[(int64_t)ol * G + g];
-      const double fk = outs[(int64_t)of * G + g];
-      if (fk != 0.0) first = fmin(first, fk);
-      if (kk + 1 < K) worst = fmax(worst, start_mismatch<J>(Send, starts, G, g + 1));
-    }
-    const int steps = (int)((K - base) < kThreads ? (K - base) : kThreads);
-    chain_finish<J>(Gm, gv, q0, q1, Q2, steps, lane, F, quad);
-  }
-  finish_series(logdet, quad, first, worst, lane, N, ll + b, flag + b, guard);
-}
 
 template <int J>
 int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
         const double *U, const double *V, const double *y, double *ll, int32_t *flag, double *work,
         unsigned long long *guard, hipStream_t s) {
-  const int64_t K = (N + kRows - 1) / kRows, G = B * K;
-  double *maps = work, *starts = maps + (size_t)Layout<J>::MAP * G, *outs = starts + (size_t)Layout<J>::START * G;
+  const int64_t K = (N + kRows - 1) / kRows;
   const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);   // lane <-> chunk
-  // guard[0]: verification of the first pass; guard[1]: of the refinement pass, which runs only if the first one failed and
-  // starts every chunk from its predecessor's END state of the first pass (the recursion contracts the error of a start
-  // state: those are good to rounding).  The caller's row-by-row kernel sits behind guard[1].
-  double *ends = outs + (size_t)Layout<J>::OUT * G;
-  if (opt::ival(opt::k_timepar_onepass) != 0) {   // chunk elements in scattering form, combined in a tree: one pass, nothing verified
-    if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
-    if (K <= kThreads) {
-      hipLaunchKernelGGL((k_tp_onepass<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
-                         guard);
-    } else {
-      hipLaunchKernelGGL((k_tp_onepass<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
-                         guard);
-      hipLaunchKernelGGL((k_tp_join<J>), gs, dim3(kThreads), 0, s, B, N, (int64_t)gc.x, (const double *)work, ll, flag, guard);
-    }
-    return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
-  }
-  if (K <= kThreads) {   // a wavefront holds every chunk of its series: two kernels, no maps / chunk results in memory
-    hipLaunchKernelGGL((k_tp_maps<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+  if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
+  if (K <= kThreads) {
+    hipLaunchKernelGGL((k_tp_onepass<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
                        guard);
-    hipLaunchKernelGGL((k_tp_chunks<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                       (const double *)starts, outs, ends, ll, flag, guard, (const unsigned long long *)nullptr);
-    hipLaunchKernelGGL((k_tp_chunks<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                       (const double *)ends, outs, (double *)nullptr, ll, flag, guard + 1, (const unsigned long long *)guard);
   } else {
-    hipLaunchKernelGGL((k_tp_maps<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+    hipLaunchKernelGGL((k_tp_onepass<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
                        guard);
-    hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
-    hipLaunchKernelGGL((k_tp_chunks<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                       (const double *)starts, outs, ends, ll, flag, guard, (const unsigned long long *)nullptr);
-    hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)starts, (const double *)outs,
-                       ll, flag, guard, (const unsigned long long *)nullptr);
-    hipLaunchKernelGGL((k_tp_chunks<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y,
-                       (const double *)ends, outs, (double *)nullptr, ll, flag, guard + 1, (const unsigned long long *)guard);
-    hipLaunchKernelGGL((k_tp_finish<J>), gs, dim3(kThreads), 0, s, B, N, K, (const double *)ends, (const double *)outs, ll,
-                       flag, guard + 1, (const unsigned long long *)guard);
+    hipLaunchKernelGGL((k_tp_join<J>), gs, dim3(kThreads), 0, s, B, N, (int64_t)gc.x, (const double *)work, ll, flag, guard);
   }
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
+// scratch of `factor` (doubles): the chunk-start states; for series of more than 64 chunks also the prefix elements and the
+// wavefronts' start states
+template <int J>
+size_t factor_doubles(int64_t B, int64_t N) {
+  const size_t K = (size_t)((N + kRows - 1) / kRows), G = (size_t)B * K, Wn = (K + kThreads - 1) / kThreads;
+  return (size_t)nsym(J) * G + (Wn > 1 ? (size_t)ElemIO<J>::NM * G + (size_t)nsym(J) * (size_t)B * Wn : 0);
+}
 template <int J>
 int run_factor(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
                const double *U, const double *V, double *d, double *W, int32_t *flag, double *work,
                unsigned long long *guard, hipStream_t s) {
-  const int64_t K = (N + kRows - 1) / kRows, G = B * K;
-  double *maps = work, *starts = maps + (size_t)Layout<J>::MAP * G;
-  const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);
-  if (K <= kThreads) {
-    hipLaunchKernelGGL((k_tp_maps<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
-                       guard);
+  const int64_t K = (N + kRows - 1) / kRows, G = B * K, Wn = (K + kThreads - 1) / kThreads;
+  double *starts = work, *pref = starts + (size_t)nsym(J) * G, *tin = pref + (size_t)ElemIO<J>::NM * G;
+  const dim3 gc((unsigned)Wn, (unsigned)B), gs((unsigned)B);
+  if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
+  if (Wn <= 1) {
+    hipLaunchKernelGGL((k_tp_states<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, starts,
+                       (double *)nullptr, guard);
   } else {
-    hipLaunchKernelGGL((k_tp_maps<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, maps, starts,
+    hipLaunchKernelGGL((k_tp_states<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, starts, pref,
                        guard);
-    hipLaunchKernelGGL((k_tp_starts<J>), gs, dim3(kThreads), 0, s, B, K, (const double *)maps, starts);
+    hipLaunchKernelGGL((k_tp_carry<J>), gs, dim3(kThreads), 0, s, B, K, Wn, (const double *)pref, tin, guard);
+    hipLaunchKernelGGL((k_tp_long_starts<J>), gc, dim3(kThreads), 0, s, B, K, Wn, (const double *)pref, (const double *)tin,
+                       starts, guard);
   }
-  double *ends = starts + (size_t)Layout<J>::START * G;   // (the region of the log-likelihood's chunk results)
-  hipLaunchKernelGGL((k_tp_factor<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V,
-                     (const double *)starts, ends, d, W, flag, guard);
-  hipLaunchKernelGGL((k_tp_factor<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V,
-                     (const double *)ends, (double *)nullptr, d, W, flag, guard);
+  hipLaunchKernelGGL((k_tp_factor<J>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, (const double *)starts, d,
+                     W, flag, guard);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
@@ -1620,25 +1370,18 @@ int run_solve(int64_t B, int64_t N, const double *t, int64_t t_bs, const double 
 
 extern "C" {
 
-// doubles of scratch the time-parallel path needs (0: shape not covered)
+// doubles of scratch the time-parallel `factor` needs (0: shape not covered)
 size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J) {
-  if (J != 2 && J != 4) return 0;
-  const size_t G = (size_t)B * (size_t)((N + c2tp::kRows - 1) / c2tp::kRows);
-  const size_t per = J == 4 ? (size_t)(c2tp::Layout<4>::MAP + 2 * c2tp::Layout<4>::START + c2tp::Layout<4>::OUT)
-                            : (size_t)(c2tp::Layout<2>::MAP + 2 * c2tp::Layout<2>::START + c2tp::Layout<2>::OUT);
-  return per * G;
+  return J == 4 ? c2tp::factor_doubles<4>(B, N) : (J == 2 ? c2tp::factor_doubles<2>(B, N) : 0);
 }
-
-// scratch of the forward log-likelihood: the one-pass form keeps one element per wavefront of a series longer than 4096 rows
+// ... and the forward log-likelihood: one element per wavefront of a series longer than 4096 rows
 size_t c2_internal_loglik_timepar_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 4 && J != 2) return 0;
-  if (c2::opt::ival(c2::opt::k_timepar_onepass) == 0) return c2_internal_timepar_doubles(B, N, J);
   const size_t K = (size_t)((N + c2tp::kRows - 1) / c2tp::kRows), gx = (K + c2tp::kThreads - 1) / c2tp::kThreads;
   return gx <= 1 ? 2 : (size_t)(J == 4 ? c2tp::ElemIO<4>::N_ : c2tp::ElemIO<2>::N_) * (size_t)B * gx;
 }
-// Forward log-likelihood, time-parallel.  `guard` (device word; the first kernel zeroes it) receives the
-// verification results (two words: first pass, refinement pass); the caller launches the ordinary kernel behind it with
-// `guard + 1` as its gate.
+// Forward log-likelihood, time-parallel.  `guard` (two device words, zeroed here): a failed factorisation (or a NaN) raises
+// both; the caller launches the ordinary kernel behind it with `guard + 1` as its gate.
 int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                double *ll, int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {

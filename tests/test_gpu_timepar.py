@@ -46,26 +46,23 @@ def oracle_ll(oracle, t, c, a, U, V, y):
     return ll, np.asarray(fl)
 
 
-@pytest.mark.parametrize("onepass", ["1", "0"])
 @pytest.mark.parametrize("J", [4, 2])
 @pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 128), (7, 700), (2, 4096), (70, 1000), (1, 20000),
                                  (2, 4097), (1, 300000)])
-def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J, onepass):
-    """onepass = 1 (the default): chunk elements in scattering form combined in a tree (one wavefront finishes a series of up
-    to 4096 rows, k_tp_join beyond: 4097 rows = two wavefronts, 300000 = 74, a second round of the join); 0: the composite
-    linear-fractional maps with their verification."""
+def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J):
+    """Chunk elements in scattering form combined in a tree: one wavefront finishes a series of up to 4096 rows, k_tp_join
+    beyond (4097 rows = two wavefronts, 300000 = 74: a second round of the join)."""
     t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
     t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
     llo, flo = oracle_ll(oracle, t, c, a, U, V, y)
     assert not flo.any()
-    monkeypatch.setenv("C2_TIMEPAR_ONEPASS", onepass)
     monkeypatch.setenv("C2_TIMEPAR", "1")
     ll, flag = ops.loglik(*dev(t, c, a, U, V, y))
     assert int(flag.abs().sum()) == 0
     close(ll, llo)
     monkeypatch.setenv("C2_TIMEPAR", "0")
     ll0, _ = ops.loglik(*dev(t, c, a, U, V, y))
-    close(ll, ll0.cpu().numpy(), tol=1e-12 if onepass == "1" else 1e-10)   # (nothing ill-conditioned in the tree)
+    close(ll, ll0.cpu().numpy(), tol=1e-12)   # (nothing ill-conditioned in the tree)
     # shared time grid and rates
     ts, cs = np.tile(t[0], (B, 1)), np.tile(c[0], (B, 1))
     lls, fls = oracle_ll(oracle, ts, cs, a, U, V, y)
@@ -76,14 +73,12 @@ def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J, onepass):
     close(ll2[ok], lls[ok])
 
 
-@pytest.mark.parametrize("onepass", ["1", "0"])
 @pytest.mark.parametrize("J", [4, 2])
-def test_timepar_falls_back_when_it_cannot_be_trusted(ops, oracle, monkeypatch, J, onepass):
+def test_timepar_falls_back_when_it_cannot_be_trusted(ops, oracle, monkeypatch, J):
     """Failed factorisations, zero white noise (kappa = 0: the maps are singular), gaps long enough to underflow a decay:
     the verification word sends the batch to the row-by-row kernel, which reports what the reference reports."""
     B, N = 6, 900
     t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
-    monkeypatch.setenv("C2_TIMEPAR_ONEPASS", onepass)
     monkeypatch.setenv("C2_TIMEPAR", "1")
     # (1) a series that is not positive definite
     a1 = a.copy(); a1[2, 500] = -3.0
@@ -101,11 +96,9 @@ def test_timepar_falls_back_when_it_cannot_be_trusted(ops, oracle, monkeypatch, 
     monkeypatch.setenv("C2_TIMEPAR", "0")
     ll_rows, flag_rows = ops.loglik(*dev(t, c, a2, U, V, y))
     monkeypatch.setenv("C2_TIMEPAR", "1")
-    if onepass == "0":
-        assert np.array_equal(ll.cpu().numpy(), ll_rows.cpu().numpy()) and flag.cpu().tolist() == flag_rows.cpu().tolist()
-    else:   # nothing is singular for the scattering form (d from the zero state = a_n > 0): no fallback unless a pivot fails
-        keep = np.arange(B) != 1
-        assert np.array_equal(flag.cpu().numpy()[keep], flag_rows.cpu().numpy()[keep])
+    # nothing is singular for the scattering form (d from the zero state = a_n > 0): no fallback unless a pivot fails
+    keep = np.arange(B) != 1
+    assert np.array_equal(flag.cpu().numpy()[keep], flag_rows.cpu().numpy()[keep])
     ok = (flo == 0) & (np.arange(B) != 1)
     close(ll[ok], llo[ok])
     # (3) a gap of 1e6 time units inside a chunk: exp(-c dt) underflows, its reciprocal overflows

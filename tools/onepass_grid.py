@@ -1,11 +1,13 @@
 # -*- coding: utf-8 -*-
-"""Forward log-likelihood at widths 4 and 2: row by row (C2_TIMEPAR=0) against the one-pass time-parallel form (C2_TIMEPAR=1)
-over a grid of batch sizes and lengths, and whether the default dispatch picks the faster one ([default ...] marks a miss)."""
+"""Forward log-likelihood (default) or `factor` (argument "factor") at widths 4 and 2: row by row (C2_TIMEPAR=0) against the
+time-parallel form built on chunk elements (C2_TIMEPAR=1) over a grid of batch sizes and lengths, and whether the default
+dispatch picks the faster one ([default ...] marks a miss)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from celerite2_amd import ops, synth
 dev = torch.device("cuda:0")
+FACTOR = len(sys.argv) > 1 and sys.argv[1] == "factor"
 def timed(fn, reps=8, warm=2):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
@@ -19,12 +21,13 @@ for J in (4, 2):
         row = []
         for N in (128, 192, 256, 384, 512, 768, 1024, 4096) + ((100000,) if B <= 64 else ()):
             t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
+            fn = (lambda: ops.factor(t, c, a, U, V)) if FACTOR else (lambda: ops.loglik(t, c, a, U, V, y))
             ms = []
             for tp in ("0", "1", None):
                 if tp is None: os.environ.pop("C2_TIMEPAR", None)
                 else: os.environ["C2_TIMEPAR"] = tp
-                ops.loglik(t, c, a, U, V, y)
-                ms.append(timed(lambda: ops.loglik(t, c, a, U, V, y)))
+                fn()
+                ms.append(timed(fn))
             row.append("%d: %.3f/%.3f%s" % (N, ms[0], ms[1], "" if ms[2] <= 1.08 * min(ms[0], ms[1]) else " [default %.3f]" % ms[2]))
             del t, c, a, U, V, y
-        print("J %d B %5d  rows/one-pass ms  " % (J, B) + "  ".join(row), flush=True)
+        print("J %d B %5d  rows/time-parallel ms  " % (J, B) + "  ".join(row), flush=True)

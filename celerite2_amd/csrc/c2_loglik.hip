@@ -1617,8 +1617,7 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
   }
   // small batch of long series, out of place: parallel along time, verified, the row-by-row kernel gated behind it
   // (in place -- d == a or W == V -- stays row by row: the fallback would read what the time-parallel pass overwrote)
-  if (allow_timepar && d != a && W != V && scan_widths &&
-      (allow_timepar == 2 ? long_enough && !(opt::has(opt::k_timepar) && opt::ival(opt::k_timepar) == 0) : use_timepar(B, N, J))) {
+  if (allow_timepar && d != a && W != V && scan_widths && use_timepar(B, N, J)) {
     const size_t nd = c2_internal_timepar_doubles(B, N, J);
     void *tmp = nullptr;
     if (nd > 0 && room(nd + 2, &tmp)) {

@@ -107,6 +107,29 @@ __device__ __forceinline__ void stage_scalar_tile(double *tile, int lane, const 
 #pragma unroll
   for (int i = 0; i < 8; ++i) tile[(8 * i + lane / 8) * 9 + q] = v[i];
 }
+// the same stream requested SIXTEEN rows at a time -- a whole 128-byte line per chunk (a 64-byte request leaves the other half
+// of the line to be fetched again eight rows later, when L2 has often dropped it: 1.35 x the algorithmic bytes measured) -- and
+// staged in halves into the same 8-row tile: lane l holds rows r0 + (l % 16) of chunks 4 i + l / 16
+template <bool TIME>
+__device__ __forceinline__ void fetch_scalar_rows16(const double *__restrict__ base, const Chunks &c, int r0, int shift, int lane,
+                                                    double (&v)[16]) {
+  const int q = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int64_t k = c.k0 + 4 * i + lane / 16;
+    k = k < c.K ? k : c.K - 1;
+    int64_t r = k * kRows + r0 + q + shift;
+    r = r < c.N - 1 ? r : c.N - 1;
+    v[i] = base[(TIME ? c.tbase : c.sbase) + r];
+  }
+}
+__device__ __forceinline__ void stage_scalar_half(double *tile, int lane, const double (&v)[16], int half) {
+  const int q = lane & 15;
+  if ((q >> 3) == half) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[(4 * i + lane / 16) * 9 + (q & 7)] = v[i];
+  }
+}
 
 // S' = X Y^-1 for J x J blocks by Gauss-Jordan with partial pivoting on Y^T (rows of the augmented [Y^T | X^T]), fully
 // unrolled.
@@ -539,21 +562,21 @@ __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, i
   double prod = 1.0, failed = 0.0;
   int eacc = 0;
   double tn = t[b * t_bs + s];
-  double vu[16], vv[16], va[8], vy[8], vt[8];   // tiles requested one tile ahead
-  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
-  fetch_scalar_tile<false>(yv, ch, 0, 0, lane, vy);
-  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  double vu[16], vv[16], va[16], vy[16], vt[16];   // tiles requested one tile ahead (scalars: 16 rows, staged in halves)
+  fetch_scalar_rows16<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_rows16<false>(yv, ch, 0, 0, lane, vy);
+  fetch_scalar_rows16<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
   fetch_row_tile<J>(U, ch, 0, lane, vu);
   fetch_row_tile<J>(V, ch, 0, lane, vv);
   for (int r0 = 0; r0 < kRows; r0 += 8) {
     lds_order();
-    stage_scalar_tile(tA, lane, va);
-    stage_scalar_tile(tY, lane, vy);
-    stage_scalar_tile(tT, lane, vt);
-    if (r0 + 8 < kRows) {
-      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
-      fetch_scalar_tile<false>(yv, ch, r0 + 8, 0, lane, vy);
-      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    stage_scalar_half(tA, lane, va, (r0 >> 3) & 1);
+    stage_scalar_half(tY, lane, vy, (r0 >> 3) & 1);
+    stage_scalar_half(tT, lane, vt, (r0 >> 3) & 1);
+    if ((r0 & 8) && r0 + 8 < kRows) {
+      fetch_scalar_rows16<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_rows16<false>(yv, ch, r0 + 8, 0, lane, vy);
+      fetch_scalar_rows16<true>(t, ch, r0 + 8, 1, lane, vt);
     }
 #pragma unroll 1
     for (int rt = 0; rt < 8; rt += Gm::RT) {
@@ -757,18 +780,18 @@ __global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, in
   for (int j = 0; j + 1 < J; j += 2) ceq = ceq && cj[j] == cj[j + 1];
   bool failed = false;
   double tn = t[b * t_bs + s];
-  double vu[16], vv[16], va[8], vt[8];   // tiles requested one tile ahead
-  fetch_scalar_tile<false>(a, ch, 0, 0, lane, va);
-  fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
+  double vu[16], vv[16], va[16], vt[16];   // tiles requested one tile ahead (scalars: 16 rows, staged in halves)
+  fetch_scalar_rows16<false>(a, ch, 0, 0, lane, va);
+  fetch_scalar_rows16<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
   fetch_row_tile<J>(U, ch, 0, lane, vu);
   fetch_row_tile<J>(V, ch, 0, lane, vv);
   for (int r0 = 0; r0 < kRows; r0 += 8) {
     lds_order();
-    stage_scalar_tile(tA, lane, va);
-    stage_scalar_tile(tT, lane, vt);
-    if (r0 + 8 < kRows) {
-      fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
-      fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
+    stage_scalar_half(tA, lane, va, (r0 >> 3) & 1);
+    stage_scalar_half(tT, lane, vt, (r0 >> 3) & 1);
+    if ((r0 & 8) && r0 + 8 < kRows) {
+      fetch_scalar_rows16<false>(a, ch, r0 + 8, 0, lane, va);
+      fetch_scalar_rows16<true>(t, ch, r0 + 8, 1, lane, vt);
     }
 #pragma unroll 1
     for (int rt = 0; rt < 8; rt += Gm::RT) {

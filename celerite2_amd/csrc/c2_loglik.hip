@@ -1286,16 +1286,19 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
   if (J != 4 && J != 2) return false;
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
-  // Chunk elements (c2_timepar.hip): a wavefront per 4096 rows of a series costs the same whatever part of them exists and
-  // the chip takes 1024 wavefronts a ROUND; row by row costs 0.22 - 0.25 us per row whatever the batch up to 8192 series
-  // (more beyond: 0.27 / 0.33 / 0.46 us at 12288 / 16384 / 20480 series of width 4).  tools/onepass_grid.py:
-  //   log-likelihood (one pass): a round 66 - 110 us at width 4, 48 - 76 at width 2;
-  //   factor (states + scan, then the writing pass): 100 us (up to half a round) - 175 - 230 us at width 4, 66 - 120 - 147 at 2
-  const int64_t waves = B * ((N + 4095) / 4096), rounds = (waves + 1023) / 1024;
-  int64_t per_round = loglik ? opt::ival(opt::k_timepar_onepass_rows_per_round) : opt::ival(opt::k_timepar_factor_rows_per_round);
-  if (!loglik && waves <= 512) per_round = per_round * 2 / 3;
-  if (J == 2) per_round = per_round * 7 / 10;
-  return N * (10240 + (B > 8192 ? B - 8192 : 0)) >= per_round * rounds * 10240;
+  // Chunk elements (c2_timepar.hip): a wavefront per 4096 rows of a series, 64 chunks of R = 16 / 32 / 64 rows in lock step
+  // (chunk_rows), the chip takes 1024 wavefronts a ROUND.  Measured (tools/onepass_grid.py, us; width 2: 0.6 of it):
+  //   log-likelihood, one pass:            20 + rounds x (18 + 0.275 R + 12 N / 1024)
+  //   factor (states + scan, writing pass): 30 + rounds x (30 + 0.5 R + 30 N / 1024)
+  //   row by row: 0.217 (log-likelihood) / 0.25 (factor) us per row, at least 38 / 41 us, whatever the batch up to 8192
+  //   series (more beyond: 0.27 / 0.33 / 0.46 us at 12288 / 16384 / 20480 series of width 4)
+  const double rounds = (double)((B * ((N + 4095) / 4096) + 1023) / 1024), n1k = (double)(N < 4096 ? N : 4096) / 1024.0;
+  const double R = N <= 1024 ? 16.0 : (N <= 2048 ? 32.0 : 64.0);
+  double tp = loglik ? 20.0 + rounds * (18.0 + 0.275 * R + 12.0 * n1k) : 30.0 + rounds * (30.0 + 0.5 * R + 30.0 * n1k);
+  if (J == 2) tp *= 0.6;
+  double rows = (loglik ? 0.217 : 0.25) * (double)N * (1.0 + (B > 8192 ? (double)(B - 8192) / 10240.0 : 0.0));
+  rows = rows > (loglik ? 38.0 : 41.0) ? rows : (loglik ? 38.0 : 41.0);
+  return tp * (double)opt::ival(opt::k_timepar_elements_bias) < rows * 100.0;
 }
 // the same decision for the single-rhs solves (affine maps: width 8 as well)
 extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {

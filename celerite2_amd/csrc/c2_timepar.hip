@@ -33,8 +33,11 @@
 namespace c2tp {
 using namespace c2;
 
-constexpr int kRows = 64;        // rows per chunk
+constexpr int kRows = 64;        // rows per chunk (the solves; the longest chunk of the element kernels)
 constexpr int kThreads = 64;
+// rows per chunk of the element kernels: a wavefront walks its 64 chunks in lock step, so a short series is cut into shorter
+// chunks -- 1000 rows: 63 lanes x 16 rows instead of 16 lanes x 64
+__host__ __device__ inline int chunk_rows(int64_t N) { return N <= 1024 ? 16 : (N <= 2048 ? 32 : 64); }
 // chunk-start mismatch (relative to |S|) of `factor` that counts as 1 on the guard word; the row-by-row kernel recomputes the
 // batch beyond 2, i.e. 5e-11 (the scanned start states agree with the sequential recursion to ~1e-15)
 constexpr double kTol = 2.5e-11;
@@ -59,13 +62,14 @@ struct Geo {
 struct Chunks {
   int64_t sbase, tbase;   // first row of the series in the (B, N) arrays / in the time grid (0 when shared)
   int64_t N, K, k0;
+  int R;                  // rows per chunk (chunk_rows: 64; 32 / 16 for short series)
   __device__ __forceinline__ int64_t chunk(int i, int lane) const {
     const int64_t k = k0 + 8 * i + lane / 8;
     return k < K ? k : K - 1;
   }
   __device__ __forceinline__ int len(int64_t k) const {
-    const int64_t s = k * kRows;
-    return (int)((s + kRows < N ? s + kRows : N) - s);
+    const int64_t s = k * R;
+    return (int)((s + R < N ? s + R : N) - s);
   }
 };
 // rows r0 .. r0+RT-1 (local, clamped into the chunk) of the 64 chunks: global -> registers (a tile ahead), registers -> LDS
@@ -79,7 +83,7 @@ __device__ __forceinline__ void fetch_row_tile(const double *__restrict__ base, 
     const int ln = c.len(k);
     int r = r0 + q / Gm::PPR;
     r = r < ln ? r : ln - 1;
-    const double2 w = *reinterpret_cast<const double2 *>(base + (c.sbase + k * kRows + r) * J + 2 * (q % Gm::PPR));
+    const double2 w = *reinterpret_cast<const double2 *>(base + (c.sbase + k * c.R + r) * J + 2 * (q % Gm::PPR));
     v[2 * i] = w.x; v[2 * i + 1] = w.y;
   }
 }
@@ -97,7 +101,7 @@ __device__ __forceinline__ void fetch_scalar_tile(const double *__restrict__ bas
   const int q = lane & 7;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    int64_t r = c.chunk(i, lane) * kRows + r0 + q + shift;
+    int64_t r = c.chunk(i, lane) * c.R + r0 + q + shift;
     r = r < c.N - 1 ? r : c.N - 1;
     v[i] = base[(TIME ? c.tbase : c.sbase) + r];
   }
@@ -118,7 +122,7 @@ __device__ __forceinline__ void fetch_scalar_rows16(const double *__restrict__ b
   for (int i = 0; i < 16; ++i) {
     int64_t k = c.k0 + 4 * i + lane / 16;
     k = k < c.K ? k : c.K - 1;
-    int64_t r = k * kRows + r0 + q + shift;
+    int64_t r = k * c.R + r0 + q + shift;
     r = r < c.N - 1 ? r : c.N - 1;
     v[i] = base[(TIME ? c.tbase : c.sbase) + r];
   }
@@ -146,7 +150,7 @@ __device__ __forceinline__ void flush_row_tile(double *__restrict__ base, const 
     const int64_t k = c.k0 + 8 * i + lane / 8;
     const int r = r0 + q / Gm::PPR;
     if (k < c.K && r < c.len(k))
-      *reinterpret_cast<double2 *>(base + (c.sbase + k * kRows + r) * J + 2 * (q % Gm::PPR)) = v[i];
+      *reinterpret_cast<double2 *>(base + (c.sbase + k * c.R + r) * J + 2 * (q % Gm::PPR)) = v[i];
   }
 }
 __device__ __forceinline__ void flush_scalar_tile(double *__restrict__ base, const Chunks &c, int r0, int lane, const double *tile) {
@@ -157,7 +161,7 @@ __device__ __forceinline__ void flush_scalar_tile(double *__restrict__ base, con
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t k = c.k0 + 8 * i + lane / 8;
-    if (k < c.K && r0 + q < c.len(k)) base[c.sbase + k * kRows + r0 + q] = v[i];
+    if (k < c.K && r0 + q < c.len(k)) base[c.sbase + k * c.R + r0 + q] = v[i];
   }
 }
 
@@ -533,7 +537,7 @@ __device__ __forceinline__ void elem_load_matrices(Elem<J> &e, const double *__r
 // series has at most 64 chunks and the wavefront finishes it (ll, flag, gate word); otherwise its element goes to `elems`
 // ([entry][series * wavefronts + wavefront]) for k_tp_join.
 template <int J, bool SINGLE>
-__global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+__global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, int64_t K, int R, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a, const double *__restrict__ U,
                                                          const double *__restrict__ V, const double *__restrict__ yv,
@@ -545,11 +549,11 @@ __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, i
   double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR, *tY = tT + 64 * Gm::SSTR;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.y;
-  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads, R};
   int64_t k = ch.k0 + lane;
   const bool inr = k < K;
   if (!inr) k = K - 1;
-  const int64_t s = k * kRows;
+  const int64_t s = k * R;
   const int len = ch.len(k);
   Elem<J> e;
   elem_identity<J>(e);
@@ -568,12 +572,12 @@ __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, i
   fetch_scalar_rows16<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
   fetch_row_tile<J>(U, ch, 0, lane, vu);
   fetch_row_tile<J>(V, ch, 0, lane, vv);
-  for (int r0 = 0; r0 < kRows; r0 += 8) {
+  for (int r0 = 0; r0 < R; r0 += 8) {
     lds_order();
     stage_scalar_half(tA, lane, va, (r0 >> 3) & 1);
     stage_scalar_half(tY, lane, vy, (r0 >> 3) & 1);
     stage_scalar_half(tT, lane, vt, (r0 >> 3) & 1);
-    if ((r0 & 8) && r0 + 8 < kRows) {
+    if ((r0 & 8) && r0 + 8 < R) {
       fetch_scalar_rows16<false>(a, ch, r0 + 8, 0, lane, va);
       fetch_scalar_rows16<false>(yv, ch, r0 + 8, 0, lane, vy);
       fetch_scalar_rows16<true>(t, ch, r0 + 8, 1, lane, vt);
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, i
       lds_order();
       stage_row_tile<J>(tU, lane, vu);
       stage_row_tile<J>(tV, lane, vv);
-      if (r0 + rt + Gm::RT < kRows) {
+      if (r0 + rt + Gm::RT < R) {
         fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
         fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
       }
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_join(int64_t B, int64_t N, int6
 // wavefront.  SINGLE (a series of at most 64 chunks): the start state of chunk k + 1 is the G of the prefix 0 .. k, written
 // to `starts`; otherwise the prefixes go to `pref` and k_tp_carry / k_tp_long_starts finish the job.
 template <int J, bool SINGLE>
-__global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+__global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, int64_t K, int R, const double *__restrict__ t,
                                                         int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                         const double *__restrict__ a, const double *__restrict__ U,
                                                         const double *__restrict__ V, double *__restrict__ starts,
@@ -763,12 +767,12 @@ __global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, in
   double *tU = lds, *tV = tU + 64 * Gm::RSTR, *tA = tV + 64 * Gm::RSTR, *tT = tA + 64 * Gm::SSTR;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.y, G = B * K;
-  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads, R};
   int64_t k = ch.k0 + lane;
   const bool inr = k < K;
   if (!inr) k = K - 1;
   const int64_t g = b * K + k;
-  const int64_t s = k * kRows;
+  const int64_t s = k * R;
   const int len = ch.len(k);
   Elem<J> e;
   elem_identity<J>(e);
@@ -785,11 +789,11 @@ __global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, in
   fetch_scalar_rows16<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
   fetch_row_tile<J>(U, ch, 0, lane, vu);
   fetch_row_tile<J>(V, ch, 0, lane, vv);
-  for (int r0 = 0; r0 < kRows; r0 += 8) {
+  for (int r0 = 0; r0 < R; r0 += 8) {
     lds_order();
     stage_scalar_half(tA, lane, va, (r0 >> 3) & 1);
     stage_scalar_half(tT, lane, vt, (r0 >> 3) & 1);
-    if ((r0 & 8) && r0 + 8 < kRows) {
+    if ((r0 & 8) && r0 + 8 < R) {
       fetch_scalar_rows16<false>(a, ch, r0 + 8, 0, lane, va);
       fetch_scalar_rows16<true>(t, ch, r0 + 8, 1, lane, vt);
     }
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_states(int64_t B, int64_t N, in
       lds_order();
       stage_row_tile<J>(tU, lane, vu);
       stage_row_tile<J>(tV, lane, vv);
-      if (r0 + rt + Gm::RT < kRows) {
+      if (r0 + rt + Gm::RT < R) {
         fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
         fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
       }
@@ -937,7 +941,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_long_starts(int64_t B, int64_t 
 // d == a / W == V in place are NOT supported here (the caller keeps those on the row-by-row kernel: its fallback would read
 // what this kernel overwrote).
 template <int J>
-__global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
+__global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, int64_t K, int R, const double *__restrict__ t,
                                                         int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                         const double *__restrict__ a, const double *__restrict__ U,
                                                         const double *__restrict__ V, const double *__restrict__ starts,
@@ -951,12 +955,12 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
          *tD = tT + 64 * Gm::SSTR;
   const int lane = threadIdx.x;
   const int64_t b = blockIdx.y, G = B * K;
-  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads};
+  const Chunks ch{b * N, b * t_bs, N, K, (int64_t)blockIdx.x * kThreads, R};
   int64_t k = ch.k0 + lane;
   const bool inr = k < K;
   if (!inr) k = K - 1;
   const int64_t g = b * K + k;
-  const int64_t s = k * kRows;
+  const int64_t s = k * R;
   const int len = ch.len(k);
   double cj[J], S[NS];
 #pragma unroll
@@ -971,11 +975,11 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
   fetch_scalar_tile<true>(t, ch, 0, 1, lane, vt);   // t of the NEXT row
   fetch_row_tile<J>(U, ch, 0, lane, vu);
   fetch_row_tile<J>(V, ch, 0, lane, vv);
-  for (int r0 = 0; r0 < kRows; r0 += 8) {
+  for (int r0 = 0; r0 < R; r0 += 8) {
     lds_order();
     stage_scalar_tile(tA, lane, va);
     stage_scalar_tile(tT, lane, vt);
-    if (r0 + 8 < kRows) {
+    if (r0 + 8 < R) {
       fetch_scalar_tile<false>(a, ch, r0 + 8, 0, lane, va);
       fetch_scalar_tile<true>(t, ch, r0 + 8, 1, lane, vt);
     }
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(kThreads) void k_tp_factor(int64_t B, int64_t N, in
       lds_order();
       stage_row_tile<J>(tU, lane, vu);
       stage_row_tile<J>(tV, lane, vv);
-      if (r0 + rt + Gm::RT < kRows) {
+      if (r0 + rt + Gm::RT < R) {
         fetch_row_tile<J>(U, ch, r0 + rt + Gm::RT, lane, vu);
         fetch_row_tile<J>(V, ch, r0 + rt + Gm::RT, lane, vv);
       }
@@ -1051,14 +1055,15 @@ template <int J>
 int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
         const double *U, const double *V, const double *y, double *ll, int32_t *flag, double *work,
         unsigned long long *guard, hipStream_t s) {
-  const int64_t K = (N + kRows - 1) / kRows;
+  const int R = chunk_rows(N);
+  const int64_t K = (N + R - 1) / R;
   const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);   // lane <-> chunk
   if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
   if (K <= kThreads) {
-    hipLaunchKernelGGL((k_tp_onepass<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
+    hipLaunchKernelGGL((k_tp_onepass<J, true>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
                        guard);
   } else {
-    hipLaunchKernelGGL((k_tp_onepass<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
+    hipLaunchKernelGGL((k_tp_onepass<J, false>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
                        guard);
     hipLaunchKernelGGL((k_tp_join<J>), gs, dim3(kThreads), 0, s, B, N, (int64_t)gc.x, (const double *)work, ll, flag, guard);
   }
@@ -1069,28 +1074,29 @@ int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, in
 // wavefronts' start states
 template <int J>
 size_t factor_doubles(int64_t B, int64_t N) {
-  const size_t K = (size_t)((N + kRows - 1) / kRows), G = (size_t)B * K, Wn = (K + kThreads - 1) / kThreads;
+  const size_t R = (size_t)chunk_rows(N), K = ((size_t)N + R - 1) / R, G = (size_t)B * K, Wn = (K + kThreads - 1) / kThreads;
   return (size_t)nsym(J) * G + (Wn > 1 ? (size_t)ElemIO<J>::NM * G + (size_t)nsym(J) * (size_t)B * Wn : 0);
 }
 template <int J>
 int run_factor(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
                const double *U, const double *V, double *d, double *W, int32_t *flag, double *work,
                unsigned long long *guard, hipStream_t s) {
-  const int64_t K = (N + kRows - 1) / kRows, G = B * K, Wn = (K + kThreads - 1) / kThreads;
+  const int R = chunk_rows(N);
+  const int64_t K = (N + R - 1) / R, G = B * K, Wn = (K + kThreads - 1) / kThreads;
   double *starts = work, *pref = starts + (size_t)nsym(J) * G, *tin = pref + (size_t)ElemIO<J>::NM * G;
   const dim3 gc((unsigned)Wn, (unsigned)B), gs((unsigned)B);
   if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
   if (Wn <= 1) {
-    hipLaunchKernelGGL((k_tp_states<J, true>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, starts,
+    hipLaunchKernelGGL((k_tp_states<J, true>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, starts,
                        (double *)nullptr, guard);
   } else {
-    hipLaunchKernelGGL((k_tp_states<J, false>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, starts, pref,
+    hipLaunchKernelGGL((k_tp_states<J, false>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, starts, pref,
                        guard);
     hipLaunchKernelGGL((k_tp_carry<J>), gs, dim3(kThreads), 0, s, B, K, Wn, (const double *)pref, tin, guard);
     hipLaunchKernelGGL((k_tp_long_starts<J>), gc, dim3(kThreads), 0, s, B, K, Wn, (const double *)pref, (const double *)tin,
                        starts, guard);
   }
-  hipLaunchKernelGGL((k_tp_factor<J>), gc, dim3(kThreads), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, (const double *)starts, d,
+  hipLaunchKernelGGL((k_tp_factor<J>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, (const double *)starts, d,
                      W, flag, guard);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
@@ -1400,7 +1406,7 @@ size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J) {
 // ... and the forward log-likelihood: one element per wavefront of a series longer than 4096 rows
 size_t c2_internal_loglik_timepar_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 4 && J != 2) return 0;
-  const size_t K = (size_t)((N + c2tp::kRows - 1) / c2tp::kRows), gx = (K + c2tp::kThreads - 1) / c2tp::kThreads;
+  const size_t R = (size_t)c2tp::chunk_rows(N), K = ((size_t)N + R - 1) / R, gx = (K + c2tp::kThreads - 1) / c2tp::kThreads;
   return gx <= 1 ? 2 : (size_t)(J == 4 ? c2tp::ElemIO<4>::N_ : c2tp::ElemIO<2>::N_) * (size_t)B * gx;
 }
 // Forward log-likelihood, time-parallel.  `guard` (two device words, zeroed here): a failed factorisation (or a NaN) raises

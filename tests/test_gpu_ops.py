@@ -90,9 +90,13 @@ def test_ops_vs_oracle_batched(ops, oracle, J):
     # in-place factor: d aliases a, W aliases V
     a2, V2 = ad.clone(), Vd.clone()
     d2, W2, _ = ops.factor(td, cd, a2, Ud, V2, d=a2, W=V2)
-    d3, W3, _ = ops.factor(td, cd, ad, Ud, Vd)            # same (workspace-free) path, out of place
-    assert d2.data_ptr() == a2.data_ptr() and torch.equal(d2, d3) and torch.equal(W2, W3)
-    close(d2, do); close(W2, Wo)
+    d3, W3, _ = ops.factor(td, cd, ad, Ud, Vd)            # workspace-free, out of place (widths 4, 2: parallel along time here)
+    assert d2.data_ptr() == a2.data_ptr()
+    if J in (2, 4):
+        close(d2, d3.cpu().numpy(), 1e-12); close(W2, W3.cpu().numpy(), 1e-10)
+    else:
+        assert torch.equal(d2, d3) and torch.equal(W2, W3)
+    close(d2, do); close(W2, Wo); close(d3, do); close(W3, Wo)
     for name in ("solve_lower", "solve_upper", "matmul_lower", "matmul_upper"):
         second = W if name.startswith("solve") else Vd
         second_o = Wo if name.startswith("solve") else V

@@ -1273,11 +1273,8 @@ extern "C" int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const
                                           int64_t c_bs, const double *a, const double *U, const double *V,
                                           const double *y, double *ll, int32_t *flag, double *work,
                                           unsigned long long *guard, c2_stream_t stream);
-// Measured at N = 4096 (tools/timepar_check.py): 0.34 ms per 1024 series at J = 4 (row by row: 0.87 ms up to ~4096
-// series), 0.17 ms at J = 2; linear in the batch beyond one wavefront per SIMD, so it pays up to ~2048 / ~4096 series.
-// A handful of series (B * J <= 512: every driver.* call) is pure latency row by row -- 0.15-0.24 us per row -- against a
-// fixed 40-130 us of the three 64-step phases of the time-parallel form (tools/timepar_small_n.py: B = 1, 8, 64 alike):
-// log-likelihood / factor draw level at ~300 rows (J = 2) and ~600 (J = 4), the solves at ~256 / ~420 / ~900 (J = 8).
+// The single-rhs SOLVES parallel along time (affine chunk maps): a handful of series (B * J <= 512: every driver.* call) is
+// pure latency row by row -- 0.15-0.24 us per row -- against a fixed 40-130 us: level at ~256 / ~420 / ~900 rows (J = 2 / 4 / 8).
 static int64_t timepar_min_rows(int64_t B, int64_t J) {
   if (B * J > 512) return opt::ival(opt::k_timepar_min_rows);
   return J == 2 ? 384 : (J == 4 ? 704 : 1024);

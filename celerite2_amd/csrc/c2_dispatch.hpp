@@ -35,6 +35,8 @@
   X(timepar_min_rows, "C2_TIMEPAR_MIN_ROWS", 1536, 't', "shortest series the time-parallel single-rhs SOLVES take when the batch is not a handful (B * J > 512)", "a handful of series from 384 / 704 / 1024 rows at widths 2 / 4 / 8 (profiles/r02_timepar.md)") \
   X(timepar_max_batch_x_width, "C2_TIMEPAR_MAX_BATCH_X_WIDTH", 8192, 't', "largest B * J the time-parallel single-rhs solves take", "linear in the batch beyond one wavefront per SIMD (profiles/r02_timepar.md)") \
   X(timepar_elements_bias, "C2_TIMEPAR_ELEMENTS_BIAS", 100, 't', "forward log-likelihood and factor at widths 4 and 2: the time-parallel forms on chunk elements are taken when their modelled time x this / 100 is below the row-by-row kernel's (the model: use_timepar in c2_loglik.hip; 50 favours them, 200 the row-by-row kernels)", "width 4, 1024 series: log-likelihood 0.044 ms up to 1024 rows, 0.109 at 4096 (row by row 0.22 us per row); factor 0.09 / 0.25 ms; 4096 x 4096: 0.38 vs 0.88 and 0.82 vs 1.02 ms; 8192 x 1024: 0.28 vs 0.24 (tools/onepass_grid.py, profiles/r05_onepass.md)") \
+  X(timepar8_min_rows, "C2_TIMEPAR8_MIN_ROWS", 512, 't', "forward log-likelihood at width 8: shortest series the chunk elements (combined by workgroups, k_e8_tree) take", "profiles/r05_onepass.md") \
+  X(timepar8_max_chunks, "C2_TIMEPAR8_MAX_CHUNKS", 32768, 't', "... and the largest number of 64-row chunks (B * ceil(N / 64))", "profiles/r05_onepass.md") \
   X(timepar_grad, "C2_TIMEPAR_GRAD", 0, 's', "log-likelihood GRADIENT (and factor_rev) parallel along time, widths 1 .. 8: 1 forces, 0 disables; unset: small batches of long series", "tools/timepar_grad_time.py, profiles/r02_timepar_grad.md") \
   X(timepar_grad_min_rows, "C2_TIMEPAR_GRAD_MIN_ROWS", 1024, 't', "shortest series the time-parallel gradient takes at widths 7, 8 beyond a handful of series (768 at widths 3 .. 6, 512 at 1, 2; 256 for at most 4096 chunks)", "one series draws level at ~400 / ~600 / ~800 rows at J = 2 / 4, 6 / 8 (tools/timepar_grad_time.py)") \
   X(timepar_grad_min_rows_handful, "C2_TIMEPAR_GRAD_MIN_ROWS_HANDFUL", 384, 't', "shortest series the time-parallel gradient takes for a handful of series (at most 4096 chunks of 64 rows; they run with 16-row chunks)", "round 5 (the row-by-row pair in the scaled frame), one series, J = 8: 0.336 vs 0.276 ms row by row at 256 rows, 0.381 vs 0.376 at 384, 0.430 vs 0.476 at 512, 0.87 vs 3.25 at 4096 (tools/crossovers.py)") \

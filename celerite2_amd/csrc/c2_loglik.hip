@@ -1280,9 +1280,11 @@ static int64_t timepar_min_rows(int64_t B, int64_t J) {
   return J == 2 ? 384 : (J == 4 ? 704 : 1024);
 }
 static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
-  if (J != 4 && J != 2) return false;
+  if (J != 4 && J != 2 && !(J == 8 && loglik)) return false;
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
+  if (J == 8)   // forward log-likelihood: chunk elements in lanes, combined by workgroups (k_e8_tree)
+    return N >= opt::ival(opt::k_timepar8_min_rows) && B * ((N + 63) / 64) <= opt::ival(opt::k_timepar8_max_chunks);
   // Chunk elements (c2_timepar.hip): a wavefront per 4096 rows of a series, 64 chunks of R = 16 / 32 / 64 rows in lock step
   // (chunk_rows), the chip takes 1024 wavefronts a ROUND.  Measured (tools/onepass_grid.py, us; width 2: 0.6 of it):
   //   log-likelihood, one pass:            20 + rounds x (18 + 0.275 R + 12 N / 1024)
@@ -1490,7 +1492,7 @@ int c2_loglik(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, co
   (void)hipStreamIsCapturing(s, &capturing);   // (its temporary is a stream-ordered allocation: kept out of graph captures)
   // widths 4 and 2 in one pass (chunk elements combined in a tree: c2_timepar.hip) whatever the length; the Newton
   // iterations below are for the other widths
-  const bool onepass = (J == 4 || J == 2) && use_timepar(B, N, J, true);
+  const bool onepass = (J == 8 || J == 4 || J == 2) && use_timepar(B, N, J, true);
   if (capturing == hipStreamCaptureStatusNone && !onepass && use_factor_iter(B, N, J)) {
     // d, W by Newton iterations on the chunk start states, z by the chunk-map solve, a reduction
     const size_t nd = c2_internal_loglik_wide_doubles(B, N, J);

@@ -232,28 +232,45 @@ __device__ __forceinline__ void elem_from_lane(const Elem<J> &e, int src, Elem<J
 }
 __device__ __forceinline__ constexpr int sym(int J, int i, int j) { return i <= j ? sidx(J, i, j) : sidx(J, j, i); }
 
-// Gt = T (I - Q T)^-1 = L Ks^-1 L^T for symmetric positive semi-definite T = L L^T, Q;  det = det Ks = det(I - Q T);
-// returns false when Ks is not positive definite
+// Gt = T (I - Q T)^-1 = L Ks^-1 L^T for symmetric positive semi-definite T = L L^T (L: J columns, not triangular), Q;
+// det = det Ks = det(I - Q T); returns false when Ks is not positive definite
 template <int J>
 __device__ __forceinline__ bool posterior(const double (&T)[nsym(J)], const double (&Q)[nsym(J)], double (&Gt)[nsym(J)],
                                           double &det) {
-  // T = L L^T (a non-positive pivot is rounding: its column is dropped)
-  double L[J][J];
+  // T = L L^T by the outer-product Cholesky with DIAGONAL PIVOTING: column k of L comes from the largest remaining diagonal
+  // entry, and the factorisation stops at the rounding level of the largest one.  T is often numerically rank-deficient (the
+  // explained covariance after a few rows that look in nearly the same direction): without pivoting its noise pivots are
+  // divided into noise columns and L L^T misses T by 1e-7 (measured: 16-row chunks at width 8, log-likelihood off by 1e-9).
+  double L[J][J], S[nsym(J)];
+  double tol = 0.0;
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    double sp = T[sidx(J, j, j)];
+  for (int q = 0; q < nsym(J); ++q) S[q] = T[q];
 #pragma unroll
-    for (int k = 0; k < j; ++k) sp = fma(-L[j][k], L[j][k], sp);
-    const bool ok = sp > 0.0;
-    const double ljj = ok ? sqrt(sp) : 0.0, inv = ok ? rcp_nr(ljj) : 0.0;
-    L[j][j] = ljj;
+  for (int k = 0; k < J; ++k) {
+    double sp = S[sidx(J, 0, 0)];
+    int mi = 0;
 #pragma unroll
-    for (int i = j + 1; i < J; ++i) {
-      double v = T[sidx(J, j, i)];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v = fma(-L[i][k], L[j][k], v);
-      L[i][j] = v * inv;
+    for (int i = 1; i < J; ++i) {
+      const bool gt = S[sidx(J, i, i)] > sp;
+      sp = gt ? S[sidx(J, i, i)] : sp;
+      mi = gt ? i : mi;
     }
+    if (k == 0) tol = 1e-15 * sp;
+    const bool ok = sp > tol;
+    const double inv = ok ? rcp_nr(sqrt(sp)) : 0.0;
+    double l[J];
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      double v = S[sym(J, i, 0)];
+#pragma unroll
+      for (int jj = 1; jj < J; ++jj) v = mi == jj ? S[sym(J, i, jj)] : v;
+      l[i] = v * inv;
+      L[i][k] = l[i];
+    }
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int jj = i; jj < J; ++jj) S[sidx(J, i, jj)] = fma(-l[i], l[jj], S[sidx(J, i, jj)]);
   }
   // X = Q L,  Ks = I - L^T X (lower triangle)
   double X[J][J], Ks[J][J];
@@ -263,7 +280,7 @@ __device__ __forceinline__ bool posterior(const double (&T)[nsym(J)], const doub
     for (int j = 0; j < J; ++j) {
       double v = 0.0;
 #pragma unroll
-      for (int k = j; k < J; ++k) v = fma(Q[sym(J, i, k)], L[k][j], v);
+      for (int k = 0; k < J; ++k) v = fma(Q[sym(J, i, k)], L[k][j], v);
       X[i][j] = v;
     }
 #pragma unroll
@@ -272,7 +289,7 @@ __device__ __forceinline__ bool posterior(const double (&T)[nsym(J)], const doub
     for (int j = 0; j <= i; ++j) {
       double v = i == j ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = i; k < J; ++k) v = fma(-L[k][i], X[k][j], v);
+      for (int k = 0; k < J; ++k) v = fma(-L[k][i], X[k][j], v);
       Ks[i][j] = v;
     }
   // Ks = C C^T in place, det Ks = the product of the pivots
@@ -303,7 +320,7 @@ __device__ __forceinline__ bool posterior(const double (&T)[nsym(J)], const doub
   for (int m = 0; m < J; ++m)
 #pragma unroll
     for (int i = 0; i < J; ++i) {
-      double v = i <= m ? L[m][i] : 0.0;
+      double v = L[m][i];
 #pragma unroll
       for (int k = 0; k < i; ++k) v = fma(-Ks[i][k], Y[k][m], v);
       Y[i][m] = v * ic[i];
@@ -504,6 +521,7 @@ template <int J>
 struct ElemIO {
   static constexpr int N_ = J * J + 2 * nsym(J) + 2 * J + 3;   // A, G, Q, g, h, q0, prod, ex
   static constexpr int NM = J * J + 2 * nsym(J) + 1;           // A, G, Q, prod (NaN: failed)
+  static constexpr int REC = (N_ + 3) & ~3;                    // a contiguous record per chunk (k_tp_onepass<J, 2>)
 };
 template <int J>
 __device__ __forceinline__ void elem_store_matrices(const Elem<J> &e, double *__restrict__ base, int64_t W, int64_t at) {
@@ -533,10 +551,10 @@ __device__ __forceinline__ void elem_load_matrices(Elem<J> &e, const double *__r
   e.ex = 0;
 }
 
-// rows of the chunks from the zero state -> elements -> the tree.  ONE wavefront per 64 chunks of a series; SINGLE: the
-// series has at most 64 chunks and the wavefront finishes it (ll, flag, gate word); otherwise its element goes to `elems`
-// ([entry][series * wavefronts + wavefront]) for k_tp_join.
-template <int J, bool SINGLE>
+// rows of the chunks from the zero state -> elements -> the tree.  ONE wavefront per 64 chunks of a series; MODE 0: the
+// series has at most 64 chunks and the wavefront finishes it (ll, flag, gate word); MODE 1: its element goes to `elems`
+// ([entry][series * wavefronts + wavefront]) for k_tp_join; MODE 2: no tree, every chunk's element to `elems` as a record.
+template <int J, int MODE>
 __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, int64_t K, int R, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a, const double *__restrict__ U,
@@ -666,13 +684,37 @@ __global__ __launch_bounds__(kThreads) void k_tp_onepass(int64_t B, int64_t N, i
     e.ex = eacc + ex;
   }
   if (!inr) { elem_identity<J>(e); failed = 0.0; }   // (lanes beyond the series ran its last chunk for the loads' sake)
+  if constexpr (MODE != 2) {
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const double f2 = __shfl_xor(failed, o, 64);
-    failed = failed == 0.0 ? f2 : (f2 == 0.0 ? failed : fmin(failed, f2));
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double f2 = __shfl_xor(failed, o, 64);
+      failed = failed == 0.0 ? f2 : (f2 == 0.0 ? failed : fmin(failed, f2));
+    }
+  }
+  if constexpr (MODE == 2) {   // every chunk's element as a record (width 8: combined by k_e8_tree)
+    if (inr) {
+      double *rec = elems + (size_t)(b * K + k) * ElemIO<J>::REC;
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) rec[q++] = e.A[i][j];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) rec[q++] = e.G[i];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) rec[q++] = e.Q[i];
+#pragma unroll
+      for (int i = 0; i < J; ++i) rec[q++] = e.g[i];
+#pragma unroll
+      for (int i = 0; i < J; ++i) rec[q++] = e.h[i];
+      rec[q++] = e.q0;
+      rec[q++] = failed != 0.0 ? __longlong_as_double(0x7ff8000000000000ll) : e.prod;
+      rec[q++] = (double)e.ex;
+    }
+    return;
   }
   elem_tree<J>(e, lane, (int)((K - ch.k0) < kThreads ? (K - ch.k0) : kThreads));
-  if constexpr (SINGLE) {
+  if constexpr (MODE == 0) {
     const double logdet = log(e.prod) + (double)e.ex * 0.693147180559945309417;
     const bool bad = failed != 0.0 || !(logdet == logdet) || !(e.q0 == e.q0);
     if (lane == 0) {
@@ -750,6 +792,231 @@ __global__ __launch_bounds__(kThreads) void k_tp_join(int64_t B, int64_t N, int6
       atomicMax(guard + 1, (unsigned long long)__double_as_longlong(INFINITY));
     }
   }
+}
+
+// =============================================================================================================
+// Width 8: the elements of the chunks (k_tp_onepass<8, 2>: a record per chunk) combined by WORKGROUPS.  An element of width 8
+// (155 doubles) does not fit a lane next to the temporaries of a combination, so here a WAVEFRONT combines one pair at a time
+// with lane (i, j) <-> entry (i, j) of the 8 x 8 matrices, everything through its private LDS block: the Cholesky factor of G1,
+// the symmetric positive definite Ks = I - L^T Q2 L inverted in place by Gauss-Jordan (its pivots are the Cholesky pivots
+// squared: all positive <=> the later span's factorisation stays positive), eleven 8 x 8 products, a handful of vectors.
+// A workgroup of 16 wavefronts reduces up to 512 consecutive elements of one series level by level (the levels' results in a
+// global scratch block); longer series take another launch over the workgroups' results.
+constexpr int kE8Waves = 16, kE8Span = 512;
+struct E8Lds {
+  double A1[64], G1[64], Q1[64], A2[64], G2[64], Q2[64], L[64], X[64], Ks[64], Z[64], Gt[64], MA[64], T1[64];
+  double g1[8], h1[8], g2[8], h2[8], rho[8], Gr[8], tv[8], red[8];
+};
+constexpr int kE8A = 0, kE8G = 64, kE8Q = 100, kE8g = 136, kE8h = 144, kE8q0 = 152, kE8prod = 153, kE8ex = 154;
+
+// ro <- r1 followed by r2 (records of ElemIO<8>::REC doubles in global memory); all 64 lanes of one wavefront
+__device__ __forceinline__ void e8_combine(const double *__restrict__ r1, const double *__restrict__ r2, double *__restrict__ ro,
+                                           E8Lds &m, int lane) {
+  const int i = lane >> 3, j = lane & 7, sij = sym(8, i, j);
+  auto mm = [&](const double *X, int xi, int xk, const double *Y, int yk, int yj) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = fma(X[i * xi + k * xk], Y[k * yk + j * yj], v);
+    return v;
+  };
+  lds_order();   // (the previous combination's reads are done)
+  m.A1[lane] = r1[kE8A + lane]; m.G1[lane] = r1[kE8G + sij]; m.Q1[lane] = r1[kE8Q + sij];
+  m.A2[lane] = r2[kE8A + lane]; m.G2[lane] = r2[kE8G + sij]; m.Q2[lane] = r2[kE8Q + sij];
+  if (lane < 8) { m.g1[lane] = r1[kE8g + lane]; m.h1[lane] = r1[kE8h + lane]; m.g2[lane] = r2[kE8g + lane]; m.h2[lane] = r2[kE8h + lane]; }
+  const double q01 = r1[kE8q0], q02 = r2[kE8q0], prod1 = r1[kE8prod], prod2 = r2[kE8prod];
+  const int ex1 = (int)r1[kE8ex], ex2 = (int)r2[kE8ex];
+  // G1 = L L^T by the outer-product Cholesky with diagonal pivoting (see `posterior`): S = the Schur complement (in m.Z)
+  m.Z[lane] = m.G1[lane];
+  double tol = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    lds_order();
+    double sp = m.Z[0];
+    int mi = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const double dq = m.Z[q * 9];
+      const bool gt = dq > sp;
+      sp = gt ? dq : sp;
+      mi = gt ? q : mi;
+    }
+    if (k == 0) tol = 1e-15 * sp;
+    const bool ok = sp > tol;
+    const double inv = ok ? 1.0 / sqrt(sp) : 0.0;
+    const double li = m.Z[i * 8 + mi] * inv, lj = m.Z[j * 8 + mi] * inv, own = m.Z[lane];
+    lds_order();
+    m.Z[lane] = fma(-li, lj, own);
+    if (j == k) m.L[lane] = li;
+  }
+  lds_order();
+  m.X[lane] = mm(m.Q2, 8, 1, m.L, 8, 1);                                  // X = Q2 L
+  lds_order();
+  m.Ks[lane] = (i == j ? 1.0 : 0.0) - mm(m.L, 1, 8, m.X, 8, 1);           // Ks = I - L^T X
+  // Ks <- Ks^-1 in place (Gauss-Jordan, no pivoting: symmetric positive definite); det Ks = the product of the pivots
+  double det = 1.0;
+  bool good = true;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    lds_order();
+    const double p = m.Ks[k * 9], rkj = m.Ks[k * 8 + j], cik = m.Ks[i * 8 + k], own = m.Ks[lane];
+    good = good && p > 0.0;
+    det *= p;
+    const double ip = 1.0 / p;
+    lds_order();
+    m.Ks[lane] = (i == k && j == k) ? ip : (i == k ? rkj * ip : (j == k ? -cik * ip : fma(-cik * ip, rkj, own)));
+  }
+  lds_order();
+  m.Z[lane] = mm(m.Ks, 8, 1, m.L, 1, 8);                                  // Z = Ks^-1 L^T
+  lds_order();
+  m.Gt[lane] = mm(m.L, 8, 1, m.Z, 8, 1);                                  // Gt = L Z  (= G1 (I - Q2 G1)^-1)
+  lds_order();
+  // vectors (lanes 0 .. 7, one entry each)
+  double q0 = 0.0;
+  if (lane < 8) {
+    double v = m.h2[lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = fma(-m.Q2[lane * 8 + k], m.g1[k], v);
+    m.rho[lane] = v;
+  }
+  lds_order();
+  if (lane < 8) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = fma(m.Gt[lane * 8 + k], m.rho[k], v);
+    m.Gr[lane] = v;
+    m.red[lane] = fma(m.rho[lane], v, -m.g1[lane] * (m.h2[lane] + m.rho[lane]));
+  }
+  lds_order();
+  double gn = 0.0, hn = 0.0;
+  if (lane < 8) {
+    double v = m.rho[lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = fma(m.Q2[lane * 8 + k], m.Gr[k], v);
+    m.tv[lane] = v;                                                       // rho + Q2 Gt rho
+    gn = m.g2[lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gn = fma(m.A2[lane * 8 + k], m.g1[k] - m.Gr[k], gn);
+  }
+  lds_order();
+  if (lane < 8) {
+    hn = m.h1[lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hn = fma(m.A1[k * 8 + lane], m.tv[k], hn);
+  }
+  q0 = q01 + q02;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) q0 += m.red[k];
+  // matrices
+  m.T1[lane] = mm(m.Q2, 8, 1, m.A1, 8, 1);                                // Q2 A1
+  lds_order();
+  m.MA[lane] = m.A1[lane] + mm(m.Gt, 8, 1, m.T1, 8, 1);                   // M A1
+  lds_order();
+  const double An = mm(m.A2, 8, 1, m.MA, 8, 1);                           // A = A2 M A1
+  m.T1[lane] = mm(m.Q2, 8, 1, m.MA, 8, 1);                                // Q2 M A1
+  m.X[lane] = mm(m.A2, 8, 1, m.Gt, 8, 1);                                 // A2 Gt
+  lds_order();
+  const double Qn = m.Q1[lane] + mm(m.A1, 1, 8, m.T1, 8, 1);              // Q = Q1 + A1^T Q2 M A1
+  const double Gn = m.G2[lane] + mm(m.X, 8, 1, m.A2, 1, 8);               // G = G2 + A2 Gt A2^T
+  ro[kE8A + lane] = An;
+  if (i <= j) { ro[kE8G + sij] = Gn; ro[kE8Q + sij] = Qn; }
+  if (lane < 8) { ro[kE8g + lane] = gn; ro[kE8h + lane] = hn; }
+  if (lane == 0) {
+    int ex;
+    const double pr = frexp(prod1 * prod2 * det, &ex);
+    ro[kE8q0] = q0;
+    ro[kE8prod] = good ? pr : __longlong_as_double(0x7ff8000000000000ll);
+    ro[kE8ex] = (double)(ex1 + ex2 + ex);
+  }
+}
+// grid (ceil(Kin / 512), B): workgroup x of series b reduces elements 512 x .. of `in` ([series][Kin] records) to ONE: written
+// to `out` ([series][gridDim.x] records) or -- when it is the only workgroup of its series -- turned into ll (numpy.py:84-109).
+// `scr`: 512 records per workgroup for the levels in between.
+__global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Kin, const double *__restrict__ in,
+                                                            double *__restrict__ out, double *__restrict__ scr,
+                                                            double *__restrict__ ll, int32_t *__restrict__ flag,
+                                                            unsigned long long *__restrict__ guard) {
+  constexpr int REC = ElemIO<8>::REC;
+  __shared__ E8Lds lds[kE8Waves];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = blockIdx.y, first = (int64_t)blockIdx.x * kE8Span;
+  int n = (int)((Kin - first) < kE8Span ? (Kin - first) : kE8Span);
+  const double *src = in + (size_t)(b * Kin + first) * REC;
+  double *lvl = scr + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)kE8Span * REC;   // levels: 256, 128, ... records, back to back
+  const bool last = gridDim.x == 1;
+  double *dst_final = last ? lvl + (size_t)(kE8Span - 1) * REC : out + (size_t)(b * gridDim.x + blockIdx.x) * REC;
+  if (n == 1) {   // nothing to combine: hand the element on
+    if (w == 0) for (int q = lane; q < REC; q += 64) dst_final[q] = src[q];
+  }
+  while (n > 1) {
+    const int pairs = n >> 1, nn = (n + 1) >> 1;
+    double *dst = nn == 1 ? dst_final : lvl;
+    for (int p = w; p < pairs; p += kE8Waves)
+      e8_combine(src + (size_t)(2 * p) * REC, src + (size_t)(2 * p + 1) * REC, dst + (size_t)p * REC, lds[w], lane);
+    if ((n & 1) && w == kE8Waves - 1)
+      for (int q = lane; q < REC; q += 64) dst[(size_t)pairs * REC + q] = src[(size_t)(n - 1) * REC + q];
+    __threadfence();
+    __syncthreads();
+    src = dst; lvl += (size_t)nn * REC; n = nn;
+  }
+  if (last) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double prod = dst_final[kE8prod], q0 = dst_final[kE8q0], ex = dst_final[kE8ex];
+      const double logdet = log(prod) + ex * 0.693147180559945309417;
+      ll[b] = -0.5 * (logdet + q0 + (double)N * 1.83787706640934548356);
+      flag[b] = 0;
+      if (!(logdet == logdet) || !(q0 == q0)) {   // left to the row-by-row kernel behind the gate
+        atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+        atomicMax(guard + 1, (unsigned long long)__double_as_longlong(INFINITY));
+      }
+    }
+  }
+}
+// rows per chunk at width 8: as short as keeps the chunk wavefronts within one round of the chip
+__host__ inline int chunk_rows8(int64_t B, int64_t N) {
+  for (int R = 16; R < 64; R *= 2)
+    if (B * ((N + R - 1) / R) <= 65536) return R;
+  return 64;
+}
+struct E8Plan {
+  int R;
+  int64_t K;
+  size_t rec0, rec1, scr, total;   // offsets (doubles): chunk elements, the workgroups' results (ping / pong), level scratch
+};
+inline E8Plan e8_plan(int64_t B, int64_t N) {
+  E8Plan p;
+  p.R = chunk_rows8(B, N);
+  p.K = (N + p.R - 1) / p.R;
+  constexpr size_t REC = ElemIO<8>::REC;
+  const size_t blocks = (size_t)((p.K + kE8Span - 1) / kE8Span);
+  p.rec0 = 0;
+  p.rec1 = p.rec0 + (size_t)B * (size_t)p.K * REC;
+  p.scr = p.rec1 + 2 * (size_t)B * blocks * REC;
+  p.total = p.scr + (size_t)B * blocks * (size_t)kE8Span * REC;
+  return p;
+}
+inline int run8(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
+                const double *U, const double *V, const double *y, double *ll, int32_t *flag, double *work,
+                unsigned long long *guard, hipStream_t s) {
+  const E8Plan p = e8_plan(B, N);
+  constexpr size_t REC = ElemIO<8>::REC;
+  if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
+  const dim3 gc((unsigned)((p.K + kThreads - 1) / kThreads), (unsigned)B);
+  hipLaunchKernelGGL((k_tp_onepass<8, 2>), gc, dim3(kThreads), 0, s, B, N, p.K, p.R, t, t_bs, c, c_bs, a, U, V, y, work + p.rec0, ll,
+                     flag, guard);
+  const double *in = work + p.rec0;
+  int64_t Kin = p.K;
+  double *pong[2] = {work + p.rec1, work + p.rec1 + (size_t)B * (size_t)((p.K + kE8Span - 1) / kE8Span) * REC};
+  for (int it = 0;; ++it) {
+    const int64_t blocks = (Kin + kE8Span - 1) / kE8Span;
+    hipLaunchKernelGGL(k_e8_tree, dim3((unsigned)blocks, (unsigned)B), dim3(kE8Waves * 64), 0, s, N, Kin, in, pong[it & 1],
+                       work + p.scr, ll, flag, guard);
+    if (blocks == 1) break;
+    in = pong[it & 1];
+    Kin = blocks;
+  }
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 
 // ---- `factor`: chunk-start states.  The matrices of the chunk elements (no right-hand side) and an inclusive scan inside the
@@ -1060,10 +1327,10 @@ int run(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, in
   const dim3 gc((unsigned)((K + kThreads - 1) / kThreads), (unsigned)B), gs((unsigned)B);   // lane <-> chunk
   if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
   if (K <= kThreads) {
-    hipLaunchKernelGGL((k_tp_onepass<J, true>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
+    hipLaunchKernelGGL((k_tp_onepass<J, 0>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
                        guard);
   } else {
-    hipLaunchKernelGGL((k_tp_onepass<J, false>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
+    hipLaunchKernelGGL((k_tp_onepass<J, 1>), gc, dim3(kThreads), 0, s, B, N, K, R, t, t_bs, c, c_bs, a, U, V, y, work, ll, flag,
                        guard);
     hipLaunchKernelGGL((k_tp_join<J>), gs, dim3(kThreads), 0, s, B, N, (int64_t)gc.x, (const double *)work, ll, flag, guard);
   }
@@ -1405,6 +1672,7 @@ size_t c2_internal_timepar_doubles(int64_t B, int64_t N, int64_t J) {
 }
 // ... and the forward log-likelihood: one element per wavefront of a series longer than 4096 rows
 size_t c2_internal_loglik_timepar_doubles(int64_t B, int64_t N, int64_t J) {
+  if (J == 8) return c2tp::e8_plan(B, N).total;
   if (J != 4 && J != 2) return 0;
   const size_t R = (size_t)c2tp::chunk_rows(N), K = ((size_t)N + R - 1) / R, gx = (K + c2tp::kThreads - 1) / c2tp::kThreads;
   return gx <= 1 ? 2 : (size_t)(J == 4 ? c2tp::ElemIO<4>::N_ : c2tp::ElemIO<2>::N_) * (size_t)B * gx;
@@ -1415,6 +1683,7 @@ int c2_internal_loglik_timepar(int64_t B, int64_t N, int64_t J, const double *t,
                                int64_t c_bs, const double *a, const double *U, const double *V, const double *y,
                                double *ll, int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (J == 8) return c2tp::run8(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
   if (J == 4) return c2tp::run<4>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
   if (J == 2) return c2tp::run<2>(B, N, t, t_bs, c, c_bs, a, U, V, y, ll, flag, work, guard, s);
   return C2_ERR_UNSUPPORTED;

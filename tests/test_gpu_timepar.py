@@ -46,7 +46,7 @@ def oracle_ll(oracle, t, c, a, U, V, y):
     return ll, np.asarray(fl)
 
 
-@pytest.mark.parametrize("J", [4, 2])
+@pytest.mark.parametrize("J", [8, 4, 2])
 @pytest.mark.parametrize("B,N", [(1, 1), (2, 2), (3, 63), (5, 64), (4, 65), (3, 128), (7, 700), (2, 4096), (70, 1000), (1, 20000),
                                  (2, 4097), (1, 300000)])
 def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J):

@@ -1283,8 +1283,16 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
   if (J != 4 && J != 2 && !(J == 8 && loglik)) return false;
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
-  if (J == 8)   // forward log-likelihood: chunk elements in lanes, combined by workgroups (k_e8_tree)
-    return N >= opt::ival(opt::k_timepar8_min_rows) && B * ((N + 63) / 64) <= opt::ival(opt::k_timepar8_max_chunks);
+  if (J == 8) {   // forward log-likelihood: chunk elements in lanes, combined by workgroups (k_e8_tree).  Measured (ms,
+    // tools/onepass_grid.py 8): 0.10 + 4.7e-6 per combination (B x chunks) + 9e-8 per row against 0.29e-3 per row of the
+    // longest series row by row (at least 0.085): 1 x 4096 0.29 vs 1.19 (Newton iterations: 0.56), 1024 x 4096 0.78 vs 1.21,
+    // 2048 x 4096 1.52 vs 1.21, 256 x 1000 0.18 vs 0.30, 1024 x 1000 0.49 vs 0.30, 1 x 256 0.097 vs 0.089
+    int R = 16;
+    while (R < 64 && B * ((N + R - 1) / R) > 65536) R *= 2;   // (chunk_rows8 of c2_timepar.hip)
+    const double el = 0.10 + 4.7e-6 * (double)(B * ((N + R - 1) / R)) + 9e-8 * (double)B * (double)N;
+    const double rows8 = 0.29e-3 * (double)N > 0.085 ? 0.29e-3 * (double)N : 0.085;
+    return el * (double)opt::ival(opt::k_timepar_elements_bias) < rows8 * 100.0;
+  }
   // Chunk elements (c2_timepar.hip): a wavefront per 4096 rows of a series, 64 chunks of R = 16 / 32 / 64 rows in lock step
   // (chunk_rows), the chip takes 1024 wavefronts a ROUND.  Measured (tools/onepass_grid.py, us; width 2: 0.6 of it):
   //   log-likelihood, one pass:            20 + rounds x (18 + 0.275 R + 12 N / 1024)

@@ -954,12 +954,12 @@ __global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Ki
       e8_combine(src + (size_t)(2 * p) * REC, src + (size_t)(2 * p + 1) * REC, dst + (size_t)p * REC, lds[w], lane);
     if ((n & 1) && w == kE8Waves - 1)
       for (int q = lane; q < REC; q += 64) dst[(size_t)pairs * REC + q] = src[(size_t)(n - 1) * REC + q];
-    __threadfence();
+    __threadfence_block();   // (producers and consumers of a level are wavefronts of this workgroup: no device-scope release)
     __syncthreads();
     src = dst; lvl += (size_t)nn * REC; n = nn;
   }
   if (last) {
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
     if (threadIdx.x == 0) {
       const double prod = dst_final[kE8prod], q0 = dst_final[kE8q0], ex = dst_final[kE8ex];

@@ -1,7 +1,8 @@
 # -*- coding: utf-8 -*-
-"""Time-parallel forward log-likelihood (c2_timepar.hip; widths 4 and 2) against the CPU oracle: the linear-fractional
-composition of the factor recursion + the affine form of the solve recursion, verified on the device, with the row-by-row
-kernel as the stream-ordered fallback.  Forced with C2_TIMEPAR=1 (the dispatch takes it for small batches of long series)."""
+"""Time-parallel forms of c2_timepar.hip against the CPU oracle: the forward log-likelihood (widths 8, 4, 2) and `factor`
+(widths 4, 2) on chunk ELEMENTS combined in a tree / a scan, the single-rhs solves as chunked affine maps, with the row-by-row
+kernels as the stream-ordered fallback behind a device-side gate (failed factorisations).  Forced with C2_TIMEPAR=1 (the
+dispatch takes them by a measured cost model)."""
 import numpy as np
 import pytest
 
@@ -73,7 +74,7 @@ def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     close(ll2[ok], lls[ok])
 
 
-@pytest.mark.parametrize("J", [4, 2])
+@pytest.mark.parametrize("J", [8, 4, 2])
 def test_timepar_falls_back_when_it_cannot_be_trusted(ops, oracle, monkeypatch, J):
     """Failed factorisations, zero white noise (kappa = 0: the maps are singular), gaps long enough to underflow a decay:
     the verification word sends the batch to the row-by-row kernel, which reports what the reference reports."""

@@ -8,6 +8,7 @@ import torch
 from celerite2_amd import ops, synth
 dev = torch.device("cuda:0")
 FACTOR = len(sys.argv) > 1 and sys.argv[1] == "factor"
+WIDTHS = (8,) if len(sys.argv) > 1 and sys.argv[1] == "8" else (4, 2)   # "8": forward log-likelihood at width 8 (rows = C2_TIMEPAR=0 C2_FACTOR_ITER=0)
 def timed(fn, reps=8, warm=2):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
@@ -16,7 +17,7 @@ def timed(fn, reps=8, warm=2):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for J in (4, 2):
+for J in WIDTHS:
     for B in (1, 64, 512, 1024, 2048, 4096, 8192, 12288, 16384, 20480):
         row = []
         for N in (128, 192, 256, 384, 512, 768, 1024, 4096) + ((100000,) if B <= 64 else ()):
@@ -26,6 +27,8 @@ for J in (4, 2):
             for tp in ("0", "1", None):
                 if tp is None: os.environ.pop("C2_TIMEPAR", None)
                 else: os.environ["C2_TIMEPAR"] = tp
+                if tp == "0" and J == 8: os.environ["C2_FACTOR_ITER"] = "0"
+                else: os.environ.pop("C2_FACTOR_ITER", None)
                 fn()
                 ms.append(timed(fn))
             row.append("%d: %.3f/%.3f%s" % (N, ms[0], ms[1], "" if ms[2] <= 1.08 * min(ms[0], ms[1]) else " [default %.3f]" % ms[2]))

@@ -800,9 +800,10 @@ __global__ __launch_bounds__(kThreads) void k_tp_join(int64_t B, int64_t N, int6
 // with lane (i, j) <-> entry (i, j) of the 8 x 8 matrices, everything through its private LDS block: the Cholesky factor of G1,
 // the symmetric positive definite Ks = I - L^T Q2 L inverted in place by Gauss-Jordan (its pivots are the Cholesky pivots
 // squared: all positive <=> the later span's factorisation stays positive), eleven 8 x 8 products, a handful of vectors.
-// A workgroup of 16 wavefronts reduces up to 512 consecutive elements of one series level by level (the levels' results in a
-// global scratch block); longer series take another launch over the workgroups' results.
-constexpr int kE8Waves = 16, kE8Span = 512;
+// A workgroup of 16 wavefronts reduces up to `span` (64 for a handful of series -- more workgroups, shorter levels --, else 512)
+// consecutive elements of one series level by level (the levels' results in a global scratch block); longer series take
+// another launch over the workgroups' results.
+constexpr int kE8Waves = 16;
 struct E8Lds {
   double A1[64], G1[64], Q1[64], A2[64], G2[64], Q2[64], L[64], X[64], Ks[64], Z[64], Gt[64], MA[64], T1[64];
   double g1[8], h1[8], g2[8], h2[8], rho[8], Gr[8], tv[8], red[8];
@@ -928,22 +929,22 @@ __device__ __forceinline__ void e8_combine(const double *__restrict__ r1, const 
     ro[kE8ex] = (double)(ex1 + ex2 + ex);
   }
 }
-// grid (ceil(Kin / 512), B): workgroup x of series b reduces elements 512 x .. of `in` ([series][Kin] records) to ONE: written
+// grid (ceil(Kin / span), B): workgroup x of series b reduces elements span x .. of `in` ([series][Kin] records) to ONE: written
 // to `out` ([series][gridDim.x] records) or -- when it is the only workgroup of its series -- turned into ll (numpy.py:84-109).
-// `scr`: 512 records per workgroup for the levels in between.
-__global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Kin, const double *__restrict__ in,
+// `scr`: span records per workgroup for the levels in between.
+__global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Kin, int span, const double *__restrict__ in,
                                                             double *__restrict__ out, double *__restrict__ scr,
                                                             double *__restrict__ ll, int32_t *__restrict__ flag,
                                                             unsigned long long *__restrict__ guard) {
   constexpr int REC = ElemIO<8>::REC;
   __shared__ E8Lds lds[kE8Waves];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t b = blockIdx.y, first = (int64_t)blockIdx.x * kE8Span;
-  int n = (int)((Kin - first) < kE8Span ? (Kin - first) : kE8Span);
+  const int64_t b = blockIdx.y, first = (int64_t)blockIdx.x * span;
+  int n = (int)((Kin - first) < span ? (Kin - first) : span);
   const double *src = in + (size_t)(b * Kin + first) * REC;
-  double *lvl = scr + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)kE8Span * REC;   // levels: 256, 128, ... records, back to back
+  double *lvl = scr + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)span * REC;   // levels: span / 2, span / 4, ... records, back to back
   const bool last = gridDim.x == 1;
-  double *dst_final = last ? lvl + (size_t)(kE8Span - 1) * REC : out + (size_t)(b * gridDim.x + blockIdx.x) * REC;
+  double *dst_final = last ? lvl + (size_t)(span - 1) * REC : out + (size_t)(b * gridDim.x + blockIdx.x) * REC;
   if (n == 1) {   // nothing to combine: hand the element on
     if (w == 0) for (int q = lane; q < REC; q += 64) dst_final[q] = src[q];
   }
@@ -980,20 +981,22 @@ __host__ inline int chunk_rows8(int64_t B, int64_t N) {
   return 64;
 }
 struct E8Plan {
-  int R;
-  int64_t K;
+  int R, span;
+  int64_t K, blocks;
   size_t rec0, rec1, scr, total;   // offsets (doubles): chunk elements, the workgroups' results (ping / pong), level scratch
 };
 inline E8Plan e8_plan(int64_t B, int64_t N) {
   E8Plan p;
   p.R = chunk_rows8(B, N);
   p.K = (N + p.R - 1) / p.R;
+  p.span = B * ((p.K + 63) / 64) <= 256 ? 64 : 512;   // a handful of series: a workgroup per 64 elements (one per CU at most)
+  if ((int64_t)p.span > p.K) p.span = p.K > 1 ? (int)p.K : 1;
   constexpr size_t REC = ElemIO<8>::REC;
-  const size_t blocks = (size_t)((p.K + kE8Span - 1) / kE8Span);
+  p.blocks = (p.K + p.span - 1) / p.span;
   p.rec0 = 0;
   p.rec1 = p.rec0 + (size_t)B * (size_t)p.K * REC;
-  p.scr = p.rec1 + 2 * (size_t)B * blocks * REC;
-  p.total = p.scr + (size_t)B * blocks * (size_t)kE8Span * REC;
+  p.scr = p.rec1 + 2 * (size_t)B * (size_t)p.blocks * REC;
+  p.total = p.scr + (size_t)B * (size_t)p.blocks * (size_t)p.span * REC;
   return p;
 }
 inline int run8(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
@@ -1007,10 +1010,11 @@ inline int run8(int64_t B, int64_t N, const double *t, int64_t t_bs, const doubl
                      flag, guard);
   const double *in = work + p.rec0;
   int64_t Kin = p.K;
-  double *pong[2] = {work + p.rec1, work + p.rec1 + (size_t)B * (size_t)((p.K + kE8Span - 1) / kE8Span) * REC};
-  for (int it = 0;; ++it) {
-    const int64_t blocks = (Kin + kE8Span - 1) / kE8Span;
-    hipLaunchKernelGGL(k_e8_tree, dim3((unsigned)blocks, (unsigned)B), dim3(kE8Waves * 64), 0, s, N, Kin, in, pong[it & 1],
+  double *pong[2] = {work + p.rec1, work + p.rec1 + (size_t)B * (size_t)p.blocks * REC};
+  for (int it = 0;; ++it) {   // (every launch needs at most the first one's blocks x span records of level scratch)
+    const int span = Kin < (int64_t)p.span ? (int)Kin : p.span;
+    const int64_t blocks = (Kin + span - 1) / span;
+    hipLaunchKernelGGL(k_e8_tree, dim3((unsigned)blocks, (unsigned)B), dim3(kE8Waves * 64), 0, s, N, Kin, span, in, pong[it & 1],
                        work + p.scr, ll, flag, guard);
     if (blocks == 1) break;
     in = pong[it & 1];

@@ -471,3 +471,49 @@ def test_fuzz_drop_in_ops_on_small_batches_of_mid_length_series(ops, oracle, see
         got = getattr(ops, name + "_rev")(td, cd, Ud, Ad, Yd, *dev(Z, F.reshape(B, N, J, nrhs)), bZd)
         for g, w in zip(got, want):
             gclose(g, w)
+
+
+@pytest.mark.parametrize("seed", list(range(48)) + _extra_seeds())
+def test_fuzz_chunk_elements(ops, oracle, monkeypatch, seed):
+    """The time-parallel forms on chunk ELEMENTS (c2_timepar.hip) forced on random shapes: forward log-likelihood at widths
+    8 (elements in lanes, the tree by workgroups), 4 and 2 (the tree in the wavefront), `factor` at widths 4 and 2 (the scan),
+    series lengths around the chunk lengths (16 / 32 / 64), their switches (1024 / 2048 rows) and the wavefront span (4096
+    rows), white noise from generous to none beyond the model's own (ill-conditioned), unpaired rates, a gap in time, shared
+    grids / rates, an occasional failed series (the gated row-by-row kernel answers).  Log-likelihood: 1e-10 relative plus four
+    times the float64 oracle's own distance from its extended-precision evaluation; d, W: 1e-10 per element."""
+    rng = np.random.default_rng(55000 + seed)
+    B = int(rng.choice([1, 2, 3, 5, 17, 70]))
+    N = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65, 127, 500, 1008, 1024, 1025, 2047, 2048, 2049, 3000, 4096, 4097, 9000]))
+    J = int(rng.choice([8, 8, 4, 4, 2]))
+    if N >= 3000 and B > 5:
+        B = 5
+    t, c, a, U, V, y = problem(rng, B, N, J)
+    a = a - 1.0 + float(rng.choice([1.0, 0.05, 0.0]))
+    if rng.random() < 0.4:
+        c = c * rng.uniform(0.8, 1.25, c.shape)
+    if N > 70 and rng.random() < 0.3:
+        t[:, N // 2:] += rng.choice([2.0, 50.0, 3000.0])
+    shared_t, shared_c = rng.random() < 0.3, rng.random() < 0.3
+    if shared_t: t = np.tile(t[0], (B, 1))
+    if shared_c: c = np.tile(c[0], (B, 1))
+    if B > 1 and N > 10 and rng.random() < 0.3:
+        a[B // 2, N // 3] = -1.0
+    llo, _, flago = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+    llx, _, flagx = oracle.loglik_grad_batched_ld(t, c, a, U, V, y, nthreads=2)
+    flago = np.asarray(flago)
+    ok = (flago == 0) & (np.asarray(flagx) == 0)
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    td, cd, ad, Ud, Vd, yd = dev(t[0].copy() if shared_t else t, c[0].copy() if shared_c else c, a, U, V, y)
+    ll, flag = ops.loglik(td, cd, ad, Ud, Vd, yd)
+    assert flag.cpu().tolist() == list(flago)
+    lln = ll.cpu().numpy()
+    assert np.isneginf(lln[flago != 0]).all()
+    np.testing.assert_array_less(np.abs(lln[ok] - llo[ok]), 1e-10 * np.abs(llo[ok]) + 4.0 * np.abs(llo[ok] - llx[ok]) + 1e-300)
+    if J in (4, 2):
+        d, W, flagf = ops.factor(td, cd, ad, Ud, Vd)
+        assert flagf.cpu().tolist() == list(flago)
+        for b in np.nonzero(ok)[0]:
+            do = np.empty(N); Wo = np.empty((N, J)); So = np.empty((N, J, J))
+            assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo, So) == 0
+            kap = float(np.max(np.abs(a[b]) / do))   # the conditioning of the draw: rounding moves d, W by ~eps kappa
+            close(d[b], do, tol=max(1e-10, 4e-16 * kap * kap)); close(W[b], Wo, tol=max(1e-10, 4e-16 * kap * kap), floor=max(1e-12, 1e-16 * kap * kap))

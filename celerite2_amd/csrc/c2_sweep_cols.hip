@@ -682,10 +682,12 @@ extern "C" int c2_internal_sweep_cols_rev(int lower, int solve, int64_t B, int64
     const int w = (int)nrhs - c0 < 16 ? (int)nrhs - c0 : 16;
     const bool v2 = al16 && w % 2 == 0;
     const int acc = c0 > 0 ? 1 : 0;
-#define C2_SCR(LO, SO, V2_)                                                                                             \
-  hipLaunchKernelGGL((k_sweepC_rev<2, LO, SO, V2_>), grid, dim3(kWave), 0, s, nb * 8, N, w, (int)nrhs, c0, acc, t, t_bs, c, \
+    const bool narrow = w <= 8 && !(c2::opt::has(c2::opt::k_sweep_cols) && c2::opt::ival(c2::opt::k_sweep_cols) == 2);
+#define C2_SCR(NC_, LO, SO, V2_)                                                                                        \
+  hipLaunchKernelGGL((k_sweepC_rev<NC_, LO, SO, V2_>), grid, dim3(kWave), 0, s, nb * 8, N, w, (int)nrhs, c0, acc, t, t_bs, c, \
                      c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY)
-#define C2_SCR_V(LO, SO) do { if (v2) C2_SCR(LO, SO, true); else C2_SCR(LO, SO, false); } while (0)
+    // a slice of at most eight columns (17 .. 24 right-hand sides: the second slice) runs ONE column per lane
+#define C2_SCR_V(LO, SO) do { if (narrow) C2_SCR(1, LO, SO, false); else if (v2) C2_SCR(2, LO, SO, true); else C2_SCR(2, LO, SO, false); } while (0)
     if (lower) { if (solve) C2_SCR_V(true, true); else C2_SCR_V(true, false); }
     else { if (solve) C2_SCR_V(false, true); else C2_SCR_V(false, false); }
 #undef C2_SCR_V

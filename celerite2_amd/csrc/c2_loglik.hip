@@ -280,21 +280,20 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   double SX[G];
 #pragma unroll
   for (int k = 0; k < G; ++k) SX[k] = 0.0;
-  double d = ab[0];
-  double rd = 1.0 / d;
-  double w = act ? Vb[0] * rd : 0.0;
-  double z = yb[0];
+  // Row 0 is the first step of block 0, from the neutral state "row -1": S = 0, F = 0, W = 0, z = 0, d = 1 at t_0 (p = 1) --
+  // the step then yields d_0 = a_0, W_0 = V_0 / d_0, z_0 = y_0 (forward.hpp:107-108) like any other row.  Blocks therefore
+  // cover rows [R b, R b + R): every transposed request of t, a, y and every store of (d, z) / d is a whole aligned run
+  // (blocks that started at row 1 straddled two 64-byte sectors per series and instruction: 2 % of the gradient pair at
+  // 8192 series, profiles/r05_alignment.md).
+  double d = 1.0;
+  double rd = 1.0;
+  double w = 0.0;
+  double z = 0.0;
   double F = 0.0;
-  double prod = d;       // running product of pivots, renormalised with frexp -> log det
+  double prod = 1.0;     // running product of pivots, renormalised with frexp -> log det
   int eacc = 0;
-  double quad = z * z * rd;
+  double quad = 0.0;
   int32_t fl = 0;
-  if (REC) {
-    if (FACTOR && stw) wst[0] = w;
-    if (wrec) wrp[0] = w;
-    if (CKPT) dzst[0] = make_double2(d, z);
-    else dst[0] = d;
-  }
 
   // ---- transposed scalar streams: registers hold the rows of block b+2, LDS the rows of blocks b, b+1 ----
   double vt[NV], va[NV], vy[NV];
@@ -315,13 +314,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
       }
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   // ---- row streams (U_n, V_n): register ring, one row per step, R rows ahead ------------------------------
   double ru[LN ? 1 : R], rv[LN ? 1 : R];
-  const double *up = Ub + J, *vp = Vb + J;  // row n0 of the current block
+  const double *up = Ub, *vp = Vb;  // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {  // row n = n0 + ahead
     if constexpr (!LN) {
       int64_t o = ahead;
@@ -350,23 +349,18 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
     ltile[LN ? 1 : 0][lane] = make_double2(qvx[slot], qvy[slot]);
   };
   if constexpr (LN) {
-    cu[0] = Ub[0]; cu[1] = Ub[J]; cv[0] = Vb[0]; cv[1] = Vb[J];   // pair 0 (row 0 is the prologue's, row 1 the first step's)
-    pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);
-    pair_stage(1);          // pair 1: the first step (the second row of pair 0) already prepares its first row
-    pair_load(1, 5);
-    lds_order();
-    nu[0] = ltu[0]; nu[1] = ltu[8]; nv[0] = ltv[0]; nv[1] = ltv[8];
+    cu[0] = Ub[0]; cu[1] = Ub[J]; cv[0] = Vb[0]; cv[1] = Vb[J];   // pair 0 (rows 0 and 1: the first two steps)
+    pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);   // (the first step stages pair 1 and requests pair 5)
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+    for (int r = 0; r < R; ++r) load_row(r, r, r, true);
   }
 
   const bool sparse = wrec && !(__longlong_as_double((long long)segguard[2 * blockIdx.x]) > kBackwardGuard);   // (uniform)
-  // prepare step 1
+  // prepare step 0 (p = 1: the neutral state sits at t_0)
   lds_order();
-  double tcur = tb[0];
   double tnext = sin_[0][0][grp][0];
-  double pc = exp_decay(cj * (tcur - tnext)), uc = LN ? cu[1] : ru[0];
+  double pc = 1.0, uc = LN ? cu[0] : ru[0];
   double pXc[G], uXc[G];
   if constexpr (DG) {
     xgather_dpp<G>(pc, xs[0], lane, pXc);
@@ -385,7 +379,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
     for (int r = 0; r < R; ++r) {
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
-        if (CKPT && (r % C == 0)) {  // state after row n-1 = checkpoint (n-1)/C
+        if (CKPT && (r % C == 1 % C)) {  // state after row n-1 = C m = checkpoint m (before the step of row C m + 1)
           const int64_t m = (n - 1) / C;
           if (!sparse || (m % kAnchor == 0 && m > 0))   // (uniform; the backward recursion never reads the state after row 0)
             ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
@@ -396,12 +390,12 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
         const int rn = (r + 1) % R;
         double v, un1;
         if constexpr (LN) {
-          // blocks start at odd rows (n0 = 1 + 8 b): r odd <=> n even <=> the first row of pair P = n / 2
-          if (r % 2 == 1) {
+          // blocks start at multiples of eight: r even <=> n even <=> the first row of pair P = n / 2
+          if (r % 2 == 0) {
             v = cv[0]; un1 = cu[1];
             lds_order();
-            pair_stage(((r + 1) / 2 + 1) % 4);                      // pair P + 1 -> tile (read back at the end of this step)
-            pair_load(((r + 1) / 2 + 1) % 4, n / 2 + 5);            // its slot: pair P + 5, eight rows ahead
+            pair_stage((r / 2 + 1) % 4);                            // pair P + 1 -> tile (read back at the end of this step)
+            pair_load((r / 2 + 1) % 4, n / 2 + 5);                  // its slot: pair P + 5, eight rows ahead
           } else {
             v = cv[1]; un1 = nu[0];                                 // (pair P + 1, read back during the step before)
           }
@@ -423,7 +417,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
         // (b) the chain of step n
         fwd_chain<G>(pc, uc, v, an, yn, pXc, uXc, SX, F, w, d, z, rd, xs[2], lane);
         if (REC) {
-          if (FACTOR && stw && ((fl == 0) & (d > 0.0))) wst[n * J] = w;
+          if (FACTOR && stw && (((fl == 0) & (d > 0.0)) | (n == 0))) wst[n * J] = w;   // (W_0 unconditionally: forward.hpp:108)
           if (CKPT && wrec) wrp[(size_t)n * kWave] = w;
           sout[grp][r] = make_double2(d, z);
         }
@@ -441,8 +435,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
         }
         tnext = tn1;
         pc = pn1; uc = un1;
-        if (LN && r % 2 == 0) { cu[0] = nu[0]; cu[1] = nu[1]; cv[0] = nv[0]; cv[1] = nv[1]; }
-        if (LN && r % 2 == 1) {   // own elements of pair P + 1: used from the next step on, so their latency is hidden
+        if (LN && r % 2 == 1) { cu[0] = nu[0]; cu[1] = nu[1]; cv[0] = nv[0]; cv[1] = nv[1]; }
+        if (LN && r % 2 == 0) {   // own elements of pair P + 1: used from the next step on, so their latency is hidden
           lds_order();
           nu[0] = ltu[0]; nu[1] = ltu[8]; nv[0] = ltv[0]; nv[1] = ltv[8];
         }
@@ -466,7 +460,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
     vload(n0 + 3 * R);
     lds_order();
   };
-  int64_t n0 = 1;
+  int64_t n0 = 0;
   int q = 0;
   auto advance = [&]() { up += R * J; vp += R * J; q ^= 1; };
   for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, std::false_type{}); advance(); }  // every row load in range
@@ -580,8 +574,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   int xAlo[(APARK && FR) ? C : 1], xAhi[(APARK && FR) ? C : 1];                               // own bW_{n-1} (FR)
   // per-series scalars of rows n_lo-1 .. n_lo+C-1 (entry e <-> row n_lo-1+e): t, d, 1/d, z
   __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
-  // per-series scalar outputs of the segment, flushed transposed (lane j <-> row j): ba_n, bt_n, by_{n-1}
-  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[SPW][C], oBY[SPW][C];
+  // per-series scalar outputs of the segment, flushed transposed as whole aligned runs of C rows (lane j <-> row C k + j):
+  // ba_{n-1} and by_{n-1} (complete at the end of step n: rows C k .. C k + C - 1 of segment k); bt_n is complete at step n, so
+  // its run C (k + 1) .. C (k + 1) + C - 1 is the segment's top row and the C - 1 rows the segment above left in the other
+  // buffer (a segment covers rows C k + 1 .. C k + C: flushed as such, every store straddled two 64-byte sectors)
+  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[2][SPW][C], oBY[SPW][C];
   __shared__ __attribute__((aligned(16))) double xB[kWave];
   const int J = PAD ? Jrt : G;
   const Geo<G> L(B, J);
@@ -712,6 +709,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   double tref = 0.0, gtop = 1.0, igtop = 1.0;   // (SC) reference time of the frame; g, 1 / g of the row above the current segment's last step
 #pragma unroll
   for (int i = 0; i < (BACK ? G : 1); ++i) carS[i] = 0.0;
+  int bq = 0;   // buffer of oBT the current segment writes
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
@@ -875,6 +873,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
         bVn = 0.0;
         if (st0) byb[N - 1] = bzn;
       }
+      if (st0) bab[N - 1] = ban;   // (the rows below leave with their segments' runs)
     }
     // entry 0 (row n_lo-1) is entry C of the next, earlier segment
     carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
@@ -910,7 +909,6 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
             xgather_dpp<G>(vv[r][2][lane], xB, lane, wX);
           }
           const double u = uX[0], wm = wX[0];   // u-_n and w~_{n-1} of this lane
-          oBA[grp][r] = ban;
           // rows n (odd first, then even) of a pair fill its tile; blocks start at odd rows: r odd <=> n even, pair (r + 1) / 2 + 4k
           double *obu = reinterpret_cast<double *>(otile[LN ? ((r + 1) / 2) & 1 : 0][0]) + lto + ((r & 1) ? 0 : 8);
           double *obv = reinterpret_cast<double *>(otile[LN ? ((r + 1) / 2) & 1 : 0][1]) + lto + ((r & 1) ? 0 : 8);
@@ -947,13 +945,14 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
           const double q = q0 + q1;               // (w~ M^)_j = q_j / g_{n-1}
           double f = cj * bp, Gs = wm * bF, Q = q * wm;
           gsum3<G>(f, Gs, Q);
-          oBT[grp][r] = carry - f;
+          oBT[bq][grp][r] = carry - f;
           carry = f;
           const double zr = zm * rdm;
           bzn = Gs - zr;
           oBY[grp][r] = bzn;
           bVn = fma(zr, bF, q);                   // bV-_{n-1}: no factor
           ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+          oBA[grp][r] = ban;                      // ba_{n-1}
           const double dwm = rowD[r][grp] * wm;   // the state of row n-1: no decay to invert
 #pragma unroll
           for (int i = 0; i < G; ++i) SX[i] = fma(-dwm, wX[i], SX[i]);
@@ -1009,7 +1008,6 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
 #pragma unroll
           for (int i = 0; i < G; ++i) Sf[i] = sfr[soff[i]];
         }
-        oBA[grp][r] = ban;
         if (st) bVb[n * J] = bVn;
         xgather_dpp<G>(bVn, xB, lane, bVX);
         // solve_lower_rev part (internal.hpp:232-245)
@@ -1047,19 +1045,21 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
         const double q = q0 + q1;
         double f = cj * bp, Gs = wm * (FR ? bWm : bF), Q = q * wm;  // FR: Gs = W_{n-1} . bW_{n-1}
         gsum3<G>(f, Gs, Q);
-        oBT[grp][r] = carry - f;
+        oBT[bq][grp][r] = carry - f;
         carry = f;
         if constexpr (FR) {
           // bV_{n-1} = bW_{n-1}/d_{n-1} + w M (reverse.hpp:80); ba_{n-1} = bd_{n-1} + w bS w^T (:79) - W_{n-1}.bV_{n-1}
           // (step 6 of the next row, :65) = bd_{n-1} - Q/2 - (W_{n-1}.bW_{n-1})/d_{n-1}
           bVn = fma(bWm, rdm, q);
           ban = zm - 0.5 * Q - Gs * rdm;
+          oBA[grp][r] = ban;
         } else {
           const double zr = zm * rdm;
           bzn = Gs - zr;
           oBY[grp][r] = bzn;
           bVn = fma(zr, bF, q);
           ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+          oBA[grp][r] = ban;
         }
         if constexpr (BACK) {   // the state of row n-1 (rowD[r] = d_{n-1}, zm = z_{n-1}, wX = W_{n-1})
           const double ip = ipX[0], dwm = rowD[r][grp] * wm;
@@ -1080,16 +1080,19 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     }
     lds_order();
     C2_TCK(3);
-    // flush the segment's per-series scalar outputs, transposed: lane j <-> row n_lo + j (by: row n_lo-1+j)
+    // flush the per-series scalar outputs, transposed: lane j <-> row n_lo - 1 + j of ba, by; row n_lo + C - 1 + j of bt
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
-      if ((G * NV == C || idx < C) && idx < cnt && (PAD ? L.valid : true)) {
-        bab[n_lo + idx] = oBA[grp][idx];
-        btb[n_lo + idx] = oBT[grp][idx];
-        if constexpr (!FR) byb[n_lo - 1 + idx] = oBY[grp][idx];
+      if ((G * NV == C || idx < C) && (PAD ? L.valid : true)) {
+        if (idx < cnt) {
+          bab[n_lo - 1 + idx] = oBA[grp][idx];
+          if constexpr (!FR) byb[n_lo - 1 + idx] = oBY[grp][idx];
+        }
+        if (n_lo + C - 1 + idx < N) btb[n_lo + C - 1 + idx] = idx == 0 ? oBT[bq][grp][C - 1] : oBT[bq ^ 1][grp][idx - 1];
       }
     }
+    bq ^= 1;
     lds_order();
     C2_TCK(4);
   }
@@ -1110,8 +1113,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       if (st0) byb[0] = bzn;
     }
   }
-  // row 0 (reverse.hpp:83-84)
-  if (st0) { bab[0] = ban; btb[0] = carry; }
+  // row 0 (reverse.hpp:83-84) and the rows of bt the first segment left behind (rows 1 .. C - 1)
+  if (st0) bab[0] = ban;
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {
+    const int idx = m * G + j;
+    if ((G * NV == C || idx < C) && idx < N && (PAD ? L.valid : true)) btb[idx] = idx == 0 ? carry : oBT[bq ^ 1][grp][idx - 1];
+  }
   if constexpr (LN) {   // row 0 completes pair 0 (row 1 is in the tile of even pairs since the last step)
     double *obu = reinterpret_cast<double *>(otile[0][0]) + lto, *obv = reinterpret_cast<double *>(otile[0][1]) + lto;
     *obv = bVn * gtop;
@@ -1161,7 +1169,7 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
   // rows of U, V as whole 128-byte lines (k_loglik_fwd<..., LN>): J = 8, an even number of rows, 16-byte aligned arrays
   if (J == 8 && N >= 2 && N % 2 == 0 && ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15) == 0 && !dg &&
       opt::has(opt::k_loglik_lines) && (opt::ival(opt::k_loglik_lines) == 1 || opt::ival(opt::k_loglik_lines) == 2)) {
-    hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R, C2_CKPT_C, MODE, false, C2_FWD_OCC, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t,
+    hipLaunchKernelGGL((k_loglik_fwd<8, 8, C2_CKPT_C, MODE, false, C2_FWD_OCC, false, true>), grid, dim3(kWave), 0, s, B, N, (int)J, t,
                        t_bs, c, c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);
     return launch_ok();
   }

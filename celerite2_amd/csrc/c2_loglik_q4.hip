@@ -148,18 +148,18 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   double SX[2][J];
 #pragma unroll
   for (int q = 0; q < J; ++q) { SX[0][q] = 0.0; SX[1][q] = 0.0; }
-  double d = ab[0];
-  double rd = 1.0 / d;
-  const double2 v0 = Vb[0];
-  double w[2] = {v0.x * rd, v0.y * rd};
-  double z = yb[0];
+  // Row 0 is the first step of block 0 from the neutral state "row -1" (S = 0, F = 0, W = 0, z = 0, d = 1 at t_0: the step
+  // yields d_0 = a_0, W_0 = V_0 / d_0, z_0 = y_0, forward.hpp:107-108), so blocks cover rows [R b, R b + R) and every
+  // transposed request of t, a, y / store of (d, z) is a whole aligned run (see k_loglik_fwd, profiles/r05_alignment.md)
+  double d = 1.0;
+  double rd = 1.0;
+  double w[2] = {0.0, 0.0};
+  double z = 0.0;
   double F[2] = {0.0, 0.0};
-  double prod = d;
+  double prod = 1.0;
   int eacc = 0;
-  double quad = z * z * rd;
+  double quad = 0.0;
   int32_t fl = 0;
-  wrp[0] = make_double2(w[0], w[1]);
-  dzst[0] = make_double2(d, z);
 
   // Per-series scalar streams move TRANSPOSED, eight lanes per series: one instruction fetches eight consecutive rows of
   // eight series (64-byte runs; lane l: series (l >> 3) + 8 m of the wavefront, row l & 7), two cover the sixteen.
@@ -199,12 +199,12 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
       sin_[q][0][ssl[m]][srow] = vt[m]; sin_[q][1][ssl[m]][srow] = va[m]; sin_[q][2][ssl[m]][srow] = vy[m];
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   double2 ru[LN ? 1 : R], rv[LN ? 1 : R];
-  const double2 *up = Ub + LG, *vp = Vb + LG;   // row n0 of the current block
+  const double2 *up = Ub, *vp = Vb;   // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {
     if constexpr (!LN) {
       int64_t o = ahead;
@@ -240,28 +240,21 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
     nv[0][0] = b0.x; nv[0][1] = b0.y; nv[1][0] = b1.x; nv[1][1] = b1.y;
   };
   if constexpr (LN) {
-    const double2 u0 = Ub[0], u1 = Ub[LG], w1 = Vb[LG];
+    const double2 u0 = Ub[0], u1 = Ub[LG], v0 = Vb[0], w1 = Vb[LG];
     cu[0][0] = u0.x; cu[0][1] = u0.y; cu[1][0] = u1.x; cu[1][1] = u1.y;
-    cv[0][0] = v0.x; cv[0][1] = v0.y; cv[1][0] = w1.x; cv[1][1] = w1.y;   // pair 0 (row 0 is the prologue's)
-    pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);
-    pair_stage(1);
-    pair_load(1, 5);
-    lds_order();
-    pair_own();             // pair 1: the first step (the second row of pair 0) already prepares its first row
+    cv[0][0] = v0.x; cv[0][1] = v0.y; cv[1][0] = w1.x; cv[1][1] = w1.y;   // pair 0 (rows 0 and 1: the first two steps)
+    pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);   // (the first step stages pair 1 and requests pair 5)
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+    for (int r = 0; r < R; ++r) load_row(r, r, r, true);
   }
 
   lds_order();
   double tref = tb[0];                    // reference time of the current frame (row 0, then every anchor row)
   double tnext = sin_[0][0][grp][0];
-  // row n = 1, prepared: ih_n, h_n, u-_n (own pair) and its gather
-  double ihc[2], hc[2];
-  ihc[0] = exp_decay(cj[0] * (tref - tnext)); hc[0] = rcp_nr(ihc[0]);
-  if (ceq) { ihc[1] = ihc[0]; hc[1] = hc[0]; }
-  else { ihc[1] = exp_decay(cj[1] * (tref - tnext)); hc[1] = rcp_nr(ihc[1]); }
-  double uc[2] = {(LN ? cu[1][0] : ru[0].x) * ihc[0], (LN ? cu[1][1] : ru[0].y) * ihc[1]};
+  // row n = 0, prepared: ih_n = h_n = 1 (the reference itself), u-_n (own pair) and its gather
+  double ihc[2] = {1.0, 1.0}, hc[2] = {1.0, 1.0};
+  double uc[2] = {LN ? cu[0][0] : ru[0].x, LN ? cu[0][1] : ru[0].y};
   double hp[2] = {1.0, 1.0};              // h of the row the chain starts from (row 0: the reference itself)
   double uXc[J];
   xs2[lane] = make_double2(uc[0], uc[1]);
@@ -279,12 +272,12 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
         double vv_[2], ur[2];   // V_n and U_{n+1} of the lane
         const int rn = (r + 1) % R;
         if constexpr (LN) {
-          // blocks start at odd rows (n0 = 1 + 8 b): r odd <=> n even <=> the first row of pair P = n / 2
-          if (r % 2 == 1) {
+          // blocks start at multiples of eight: r even <=> n even <=> the first row of pair P = n / 2
+          if (r % 2 == 0) {
             vv_[0] = cv[0][0]; vv_[1] = cv[0][1]; ur[0] = cu[1][0]; ur[1] = cu[1][1];
             lds_order();
-            pair_stage(((r + 1) / 2 + 1) % 4);                      // pair P + 1 -> tile (read back at the end of this step)
-            pair_load(((r + 1) / 2 + 1) % 4, n / 2 + 5);            // its slot: pair P + 5, eight rows ahead
+            pair_stage((r / 2 + 1) % 4);                            // pair P + 1 -> tile (read back at the end of this step)
+            pair_load((r / 2 + 1) % 4, n / 2 + 5);                  // its slot: pair P + 5, eight rows ahead
           } else {
             vv_[0] = cv[1][0]; vv_[1] = cv[1][1]; ur[0] = nu[0][0]; ur[1] = nu[0][1];
           }
@@ -293,7 +286,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
         }
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) the next row's frame factors and u- -> LDS -> gather.  Behind an anchor row the next row lives in the new frame.
-        const double trn = (r == R - 1 && anchor_block) ? tn : tref;
+        const double trn = (r == 0 && anchor_block) ? tn : tref;
         double ihn[2], hn[2];
         ihn[0] = exp_decay(cj[0] * (trn - tn1)); hn[0] = rcp_nr(ihn[0]);
         if (ceq) { ihn[1] = ihn[0]; hn[1] = hn[0]; }
@@ -341,7 +334,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
           prod = frexp(prod, &e);
           eacc += e;
         }
-        if (r == R - 1 && anchor_block) {
+        if (r == 0 && anchor_block) {
           // anchor row: back to the plain state S = H^-1 S^ H^-1, F = F~ / h -- the checkpoint the reverse sweep re-anchors
           // at (state after row n = 32 i -> slot i - 1) and the reference of the next frame
           double iX[J];
@@ -357,11 +350,11 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
         }
         tnext = tn1;
         ihc[0] = ihn[0]; ihc[1] = ihn[1]; hc[0] = hn[0]; hc[1] = hn[1]; uc[0] = un[0]; uc[1] = un[1];
-        if (LN && r % 2 == 0) {
+        if (LN && r % 2 == 1) {
 #pragma unroll
           for (int e = 0; e < 2; ++e) { cu[e][0] = nu[e][0]; cu[e][1] = nu[e][1]; cv[e][0] = nv[e][0]; cv[e][1] = nv[e][1]; }
         }
-        if (LN && r % 2 == 1) {   // own columns of pair P + 1: used from the next step on
+        if (LN && r % 2 == 0) {   // own columns of pair P + 1: used from the next step on
           lds_order();
           pair_own();
         }
@@ -378,12 +371,12 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
     vload(n0 + 3 * R);
     lds_order();
   };
-  int64_t n0 = 1, blk = 0;
+  int64_t n0 = 0, blk = 0;
   int q = 0;
   auto advance = [&]() { up += R * LG; vp += R * LG; q ^= 1; ++blk; };
-  constexpr int BA = A * C / R;   // blocks between two anchors (32 rows)
-  for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, blk % BA == BA - 1, std::false_type{}); advance(); }   // every row load in range
-  for (; n0 < N; n0 += R) { block(n0, q, blk % BA == BA - 1, std::true_type{}); advance(); }
+  constexpr int BA = A * C / R;   // blocks between two anchors (32 rows); an anchor row 32 i is the FIRST row of its block
+  for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, blk % BA == 0 && blk > 0, std::false_type{}); advance(); }   // every row load in range
+  for (; n0 < N; n0 += R) { block(n0, q, blk % BA == 0 && blk > 0, std::true_type{}); advance(); }
 
   {  // the state after the last row, plain (hp = h of the last row in the current frame; 1 right behind an anchor)
     const double il[2] = {rcp_nr(hp[0]), rcp_nr(hp[1])};
@@ -426,7 +419,10 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
   if (!open_group(gate, (int64_t)blockIdx.x * SPW)) return;
   constexpr int NV = C / LG;
   __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
-  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[SPW][C], oBY[SPW][C];
+  // scalar outputs leave as whole aligned runs of C rows: ba_{n-1}, by_{n-1} (complete at the end of step n) as rows C k ..
+  // C k + C - 1 of segment k; bt_n (complete at step n) one segment late -- the segment's top row with the C - 1 rows the
+  // segment above left in the other buffer (see k_loglik_rev)
+  __shared__ __attribute__((aligned(16))) double oBA[SPW][C], oBT[2][SPW][C], oBY[SPW][C];
   const Geo<LG> L(B, LG);
   const int lane = L.lane, jl = L.j, grp = lane / LG;
   const int64_t ot = (int64_t)L.sl * t_bs, on = (int64_t)L.sl * N, oj = (int64_t)L.sl * N * J + 2 * jl;
@@ -526,6 +522,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
 #pragma unroll
   for (int q = 0; q < J; ++q) { SX[0][q] = 0.0; SX[1][q] = 0.0; }
   double tref = 0.0, gtop[2] = {1.0, 1.0}, igtop[2] = {1.0, 1.0};
+  int bq = 0;   // buffer of oBT the current segment writes
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
     const int cnt = (N - n_lo < C) ? (int)(N - n_lo) : C;
@@ -592,7 +589,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
       ban = 0.5 * rdl * (zl * zl * rdl - 1.0);
       bzn = -zl * rdl;
       bVn[0] = 0.0; bVn[1] = 0.0;
-      if (alive) byb[N - 1] = bzn;
+      if (alive) { byb[N - 1] = bzn; bab[N - 1] = ban; }
     }
     carT = rowT[0][grp]; carDZ = make_double2(rowD[0][grp], rowZ[0][grp]); carR = rowR[0][grp];
     lds_order();
@@ -618,7 +615,6 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
         double uX[J], wX[J], xX[J];
         xg2(u[0], u[1], uX);
         xg2(wm[0], wm[1], wX);
-        oBA[grp][r] = ban;
         // (LN) rows n -- odd first, then even -- of a pair fill its tile; blocks start at odd rows: r odd <=> n even
         double2 *ob = &otile[LN ? ((r + 1) / 2) & 1 : 0][0][grp * 8 + ((r & 1) ? 0 : 4) + jl];
         if constexpr (LN) {
@@ -663,7 +659,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
         double f = fma(cj[0], bpt[0], cj[1] * bpt[1]), Gs = fma(wm[0], bF[0], wm[1] * bF[1]),
                Q = fma(qv[0], wm[0], qv[1] * wm[1]);
         gsum3<LG>(f, Gs, Q);
-        oBT[grp][r] = carry - f;
+        oBT[bq][grp][r] = carry - f;
         carry = f;
         const double zr = zm * rdm;
         bzn = Gs - zr;
@@ -671,6 +667,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
         bVn[0] = fma(zr, bF[0], qv[0]);
         bVn[1] = fma(zr, bF[1], qv[1]);
         ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
+        oBA[grp][r] = ban;                                   // ba_{n-1}
         const double dw0 = rowD[r][grp] * wm[0], dw1 = rowD[r][grp] * wm[1];   // the state of row n-1
 #pragma unroll
         for (int q = 0; q < J; ++q) { SX[0][q] = fma(-dw0, wX[q], SX[0][q]); SX[1][q] = fma(-dw1, wX[q], SX[1][q]); }
@@ -682,13 +679,20 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
     lds_order();
 #pragma unroll
     for (int m = 0; m < NV; ++m) {   // (slots beyond the batch hold copies of its last series: same values, same addresses)
-      if (srow < cnt && ok8[m]) {
-        bab8[m][n_lo + srow] = oBA[ssl[m]][srow];
-        btb8[m][n_lo + srow] = oBT[ssl[m]][srow];
-        byb8[m][n_lo - 1 + srow] = oBY[ssl[m]][srow];
+      if (ok8[m]) {
+        if (srow < cnt) {
+          bab8[m][n_lo - 1 + srow] = oBA[ssl[m]][srow];
+          byb8[m][n_lo - 1 + srow] = oBY[ssl[m]][srow];
+        }
+        if (n_lo + C - 1 + srow < N) btb8[m][n_lo + C - 1 + srow] = srow == 0 ? oBT[bq][ssl[m]][C - 1] : oBT[bq ^ 1][ssl[m]][srow - 1];
       }
     }
+    bq ^= 1;
     lds_order();
+  }
+#pragma unroll
+  for (int m = 0; m < NV; ++m) {   // the rows of bt the first segment left behind (1 .. C - 1; row 0 below)
+    if (ok8[m] && srow >= 1 && srow < N) btb8[m][srow] = oBT[bq ^ 1][ssl[m]][srow - 1];
   }
   if (nseg == 0) {   // N == 1
     const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;

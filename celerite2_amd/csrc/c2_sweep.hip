@@ -48,15 +48,15 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   const bool stf = F && (PAD ? (L.valid && act) : true);
   auto rowof = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
 
-  // step 0: Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / untouched (matmul accumulate)
+  // Step 0 is the first step of block 0 from a neutral state (no row before it: A = 0, x = 0, F = 0 at t_0): it yields
+  // Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / Z unchanged (matmul accumulate) and the zero
+  // workspace row (internal.hpp:127 / :170) like any other step -- so blocks cover positions [R b, R b + R) and the
+  // transposed requests of t, y, z are whole aligned runs (profiles/r05_alignment.md).
   const int64_t r0 = rowof(0);
-  double xprev = yb[r0];
-  if (SOLVE) zb[r0] = xprev;
-  else if (zero_z) zb[r0] = 0.0;
-  double aprev = act ? Ab[r0 * J] : 0.0;
+  double xprev = 0.0;
+  double aprev = 0.0;
   double tprev = tb[r0];
   double Fs = 0.0;
-  if (stf) Fb[r0 * J] = 0.0;  // internal.hpp:127 / :170
 
   // transposed scalar streams: registers hold block b+2, LDS blocks b and b+1
   double vt[NV], vy[NV], vz[NV];
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
       }
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   double ra[LINES ? 1 : R], rb[LINES ? 1 : R];
   auto load_row = [&](int r, int64_t s) {
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   double2 la[LINES ? R / 2 : 1], lb[LINES ? R / 2 : 1];
   const int hrow = j >> 2, hcol = 2 * (j & 3);
   const double *Al = (LOWER ? V : U) + (L.b0 + L.sl) * N * J + hcol, *Bl = (LOWER ? U : V) + (L.b0 + L.sl) * N * J + hcol;
-  const int64_t l0 = rowof(N > 1 ? 1 : 0) >> 1, lmax = (N - 1) >> 1;
+  const int64_t l0 = rowof(0) >> 1, lmax = (N - 1) >> 1;
   auto line_load = [&](const double *base, int64_t k) -> double2 {
     int64_t l = LOWER ? l0 + k : l0 - k;
     l = l < 0 ? 0 : (l > lmax ? lmax : l);
@@ -111,14 +111,14 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   if constexpr (LINES) {
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) { la[q] = line_load(Al, q); lb[q] = line_load(Bl, q); }
-    if constexpr (LN == 1) {   // step 1 is the second row of the line step 0 entered
+    if constexpr (LN == 1) {   // step 0 (an upper sweep on an odd number of rows) is the second row, in sweep order, of its line
       line_stage(0, 0, la[0]); line_stage(1, 0, lb[0]);
       la[0] = line_load(Al, R / 2); lb[0] = line_load(Bl, R / 2);
       kline = 1;
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+    for (int r = 0; r < R; ++r) load_row(r, r);
   }
   lds_order();
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
     vload(s0 + 3 * R);
     lds_order();
   };
-  int64_t s0 = 1;
+  int64_t s0 = 0;
   int q = 0;
   for (; s0 + 2 * R <= N; s0 += R, q ^= 1) block(s0, q, std::false_type{});
   for (; s0 < N; s0 += R, q ^= 1) block(s0, q, std::true_type{});
@@ -719,11 +719,11 @@ extern "C" int c2_internal_sweep1(int lower, int solve, int64_t B, int64_t N, in
 #define C2_SW(G, LO, SO)                                                                                           \
   do {                                                                                                             \
     if (J == G && G == 8 && lines_ok) {                                                                            \
-      if (LO || N % 2 == 0)                                                                                        \
-        hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false, (G == 8 ? 1 : -1)>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
+      if (LO || N % 2 == 0)   /* the sweep enters a line at even positions (position 0 = row 0 / row N - 1) */          \
+        hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false, (G == 8 ? 0 : -1)>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
                            t_bs, c, c_bs, U, V, Y, Z, F, zero_z);                                                   \
       else                                                                                                         \
-        hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false, (G == 8 ? 0 : -1)>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
+        hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false, (G == 8 ? 1 : -1)>), grid, dim3(kWave), 0, s, B, N, (int)J, t, \
                            t_bs, c, c_bs, U, V, Y, Z, F, zero_z);                                                   \
     } else if (J == G)                                                                                             \
       hipLaunchKernelGGL((k_sweep1<G, 8, LO, SO, false>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c, c_bs, U, \

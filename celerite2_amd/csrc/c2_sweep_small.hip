@@ -39,18 +39,15 @@ __global__ __launch_bounds__(kWave) void k_sweepT(int64_t B, int64_t N, int Jrt,
   const bool stf = F && (PAD ? (L.valid && act) : true);
   auto rowof = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
 
-  // step 0: Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / untouched (matmul accumulate)
+  // Step 0 is the first step of block 0 from a neutral state (no row before it: A = 0, x = 0, F = 0 at t_0): it yields
+  // Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / Z unchanged (matmul accumulate) and the zero
+  // workspace row (internal.hpp:127 / :170) like any other step -- so blocks cover positions [R b, R b + R) and the
+  // transposed requests of t, y, z are whole aligned runs (profiles/r05_alignment.md).
   const int64_t r0 = rowof(0);
   double xprev[KT], Fs[KT];
 #pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    xprev[k] = yb[r0 * KT + k];
-    if (SOLVE) zb[r0 * KT + k] = xprev[k];
-    else if (zero_z) zb[r0 * KT + k] = 0.0;
-    Fs[k] = 0.0;
-    if (stf) Fb[r0 * J * KT + J * k] = 0.0;  // internal.hpp:127 / :170
-  }
-  double aprev = act ? Ab[r0 * J] : 0.0;
+  for (int k = 0; k < KT; ++k) { xprev[k] = 0.0; Fs[k] = 0.0; }
+  double aprev = 0.0;
   double tprev = tb[r0];
 
   // transposed scalar streams: registers hold block b+2, LDS blocks b and b+1
@@ -76,9 +73,9 @@ __global__ __launch_bounds__(kWave) void k_sweepT(int64_t B, int64_t N, int Jrt,
       }
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   double ra[R], rb[R];
   auto load_row = [&](int r, int64_t s) {
@@ -88,7 +85,7 @@ __global__ __launch_bounds__(kWave) void k_sweepT(int64_t B, int64_t N, int Jrt,
     rb[r] = act ? Bb[n * J] : 0.0;
   };
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, 1 + r);
+  for (int r = 0; r < R; ++r) load_row(r, r);
   lds_order();
 
   auto block = [&](int64_t s0, int q, auto checked_tag) {
@@ -136,7 +133,7 @@ __global__ __launch_bounds__(kWave) void k_sweepT(int64_t B, int64_t N, int Jrt,
     vload(s0 + 3 * R);
     lds_order();
   };
-  int64_t s0 = 1;
+  int64_t s0 = 0;
   int q = 0;
   for (; s0 + 2 * R <= N; s0 += R, q ^= 1) block(s0, q, std::false_type{});
   for (; s0 < N; s0 += R, q ^= 1) block(s0, q, std::true_type{});

@@ -101,15 +101,16 @@ __global__ __launch_bounds__(kWave, C2_FWD4_OCC) void k_loglik4_fwd(int64_t B, i
   double SX[2][J];
 #pragma unroll
   for (int q = 0; q < J; ++q) { SX[0][q] = 0.0; SX[1][q] = 0.0; }
-  double d = ab[0];
-  double rd = 1.0 / d;
-  const double2 v0 = Vb[0];
-  double w[2] = {v0.x * rd, v0.y * rd};
-  double z = yb[0];
+  // row 0 is the first step of block 0 from the neutral state "row -1" (S = 0, F = 0, W = 0, z = 0, d = 1 at t_0): blocks cover
+  // rows [R b, R b + R) and the transposed requests of t, a, y are whole aligned runs (see k_loglik_fwd, c2_loglik.hip)
+  double d = 1.0;
+  double rd = 1.0;
+  double w[2] = {0.0, 0.0};
+  double z = 0.0;
   double F[2] = {0.0, 0.0};
-  double prod = d;
+  double prod = 1.0;
   int eacc = 0;
-  double quad = z * z * rd;
+  double quad = 0.0;
   int32_t fl = 0;
   // transposed scalar streams (see c2_loglik.hip): registers hold block b+2, LDS blocks b and b+1
   double vt[NV], va[NV], vy[NV];
@@ -130,24 +131,23 @@ __global__ __launch_bounds__(kWave, C2_FWD4_OCC) void k_loglik4_fwd(int64_t B, i
       }
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   double2 ru[R], rv[R];
-  const double2 *up = Ub + LG, *vp = Vb + LG;  // row n0 of the current block
+  const double2 *up = Ub, *vp = Vb;  // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {
     int64_t o = ahead;
     if (clamp && n >= N) o -= n - (N - 1);
     ru[r] = up[o * LG]; rv[r] = vp[o * LG];
   };
 #pragma unroll
-  for (int r = 0; r < R; ++r) load_row(r, r, 1 + r, true);
+  for (int r = 0; r < R; ++r) load_row(r, r, r, true);
 
   lds_order();
-  double tcur = tb[0];
   double tnext = sin_[0][0][grp][0];
-  double pc[2] = {exp_decay(cj[0] * (tcur - tnext)), exp_decay(cj[1] * (tcur - tnext))};
+  double pc[2] = {1.0, 1.0};   // (the neutral state sits at t_0)
   double uc[2] = {ru[0].x, ru[0].y};
   double pXc[J], uXc[J];
   xs2[0][lane] = make_double2(pc[0], pc[1]);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kWave, C2_FWD4_OCC) void k_loglik4_fwd(int64_t B, i
     vload(n0 + 3 * R);
     lds_order();
   };
-  int64_t n0 = 1;
+  int64_t n0 = 0;
   int q = 0;
   auto advance = [&]() { up += R * LG; vp += R * LG; q ^= 1; };
   for (; n0 + 2 * R <= N; n0 += R) { block(n0, q, std::false_type{}); advance(); }

@@ -88,6 +88,9 @@ __device__ __forceinline__ void fwd_chain(double p, double u, double v, double a
 // gathered back in XOR order for the NEXT step;  (b) the chain of step n runs on the vectors gathered
 // during step n-1;  (c) ring slot r is refilled with row n+R.
 // =============================================================================
+#ifndef C2_FWD_RING
+#define C2_FWD_RING 8   // rows of U, V in flight per lane (the register ring of the forward kernels)
+#endif
 #ifndef C2_FWD_OCC
 #define C2_FWD_OCC 1
 #endif
@@ -319,7 +322,10 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   vload(2 * R);
 
   // ---- row streams (U_n, V_n): register ring, one row per step, R rows ahead ------------------------------
-  double ru[LN ? 1 : R], rv[LN ? 1 : R];
+  // (the ring is RR = min(R, C2_FWD_RING) rows long: blocks of sixteen rows -- scalar requests of whole 128-byte lines -- keep a
+  // ring of eight)
+  constexpr int RR = R < C2_FWD_RING ? R : C2_FWD_RING;
+  double ru[LN ? 1 : RR], rv[LN ? 1 : RR];
   const double *up = Ub, *vp = Vb;  // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {  // row n = n0 + ahead
     if constexpr (!LN) {
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
     pair_load(1, 1); pair_load(2, 2); pair_load(3, 3); pair_load(0, 4);   // (the first step stages pair 1 and requests pair 5)
   } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) load_row(r, r, r, true);
+    for (int r = 0; r < RR; ++r) load_row(r, r, r, true);
   }
 
   const bool sparse = wrec && !(__longlong_as_double((long long)segguard[2 * blockIdx.x]) > kBackwardGuard);   // (uniform)
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
             v = cv[1]; un1 = nu[0];                                 // (pair P + 1, read back during the step before)
           }
         } else {
-          v = rv[LN ? 0 : r]; un1 = ru[LN ? 0 : rn];
+          v = rv[LN ? 0 : r % RR]; un1 = ru[LN ? 0 : rn % RR];
         }
         const double pn1 = exp_decay(cj * (tn - tn1));
         double pXn[G], uXn[G];
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
           sout[grp][r] = make_double2(d, z);
         }
         // (c) refill ring slot r with row n + R
-        load_row(r, r + R, n + R, CHECKED);
+        load_row(r % RR, r + RR, n + RR, CHECKED);
         // forward.hpp:128: first non-positive pivot (NaN passes, as in the reference); no early exit --
         // a failed series simply runs to the end on garbage, its outputs are flagged.
         fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;
@@ -1139,7 +1145,13 @@ using namespace c2;
 #define C2_CKPT_C 8   // checkpoint interval for G <= 8
 #endif
 #ifndef C2_FWD_R
-#define C2_FWD_R C2_CKPT_C   // prefetch ring length (rows); multiple of the checkpoint interval
+#define C2_FWD_R C2_CKPT_C   // rows per block of the forward kernels (scalar tiles); multiple of the checkpoint interval
+#endif
+#ifndef C2_FWD_R8
+// ... of the eight-lane instances: sixteen, i.e. t, a, y arrive and (d, z) leave as whole 128-byte lines (with eight the second half
+// of a line is fetched again eight rows later: forward pass 5.50 -> 5.11 GB at 8192 series = its algorithmic bytes; the ring of
+// U, V rows stays eight long, C2_FWD_RING)
+#define C2_FWD_R8 16
 #endif
 
 static int64_t simd_count();
@@ -1161,7 +1173,7 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
   const int G_ = group_size(J);
   const dim3 grid((unsigned)((B * G_ + kWave - 1) / kWave));
   if (MODE == 1 && occ2 && J == 8) {   // two wavefronts per SIMD (the pair of the backward-recursion sweep, see loglik_grad_group)
-    hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R, C2_CKPT_C, (MODE == 1 ? 1 : 0), false, 2>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c,
+    hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R8, C2_CKPT_C, (MODE == 1 ? 1 : 0), false, 2>), grid, dim3(kWave), 0, s, B, N, (int)J, t, t_bs, c,
                        c_bs, a, U, V, y, ll, flag, ckpt, nseg, Wst, DZst, gate, segguard);
     return launch_ok();
   }
@@ -1193,7 +1205,7 @@ int launch_fwd(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, c
     case 1: C2_FWD(1, C2_FWD_R, C2_CKPT_C); break;
     case 2: C2_FWD(2, C2_FWD_R, C2_CKPT_C); break;
     case 4: C2_FWD(4, C2_FWD_R, C2_CKPT_C); break;
-    case 8: C2_FWD(8, C2_FWD_R, C2_CKPT_C); break;
+    case 8: C2_FWD(8, C2_FWD_R8, C2_CKPT_C); break;
     case 16: C2_FWD(16, 8, 4); break;
     default: C2_FWD(32, 4, 2); break;
   }

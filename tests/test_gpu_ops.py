@@ -513,7 +513,7 @@ def test_one_lane_gaps_are_reanchored(ops, oracle, monkeypatch, lanes, J):
 
 
 @pytest.mark.parametrize("J", [8, 7, 4, 3, 2, 1])
-@pytest.mark.parametrize("N", [2, 9, 10, 41, 130, 258])
+@pytest.mark.parametrize("N", [2, 9, 10, 15, 16, 17, 31, 32, 33, 41, 130, 258])   # (blocks of 16 rows from row 0: their edges)
 def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypatch, J, N):
     """The group mappings (up to eight lanes per series, c2_loglik.hip) run their reverse sweep by the BACKWARD recursion
     from recorded W rows, re-anchored at every fourth checkpoint (32 rows) or -- where c * span over 32 rows is beyond the

@@ -198,8 +198,13 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   constexpr int SPW = kWave / G, NV = (R + G - 1) / G;
   constexpr bool LINES = LN >= 0;
   static_assert(!LINES || (G == 8 && !PAD && R == 8), "lines: eight lanes per series, blocks of eight steps");
-  __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];  // t, x, bZ at positions u+1 of two blocks
-  __shared__ __attribute__((aligned(16))) double sout[2][SPW][R];     // bt (position u), bY (position u+1)
+  // Scalar tiles hold the ALIGNED positions R b .. R b + R - 1 of a block (whole 64-byte runs per series; requested at
+  // R b + 1 .. R b + R every run straddled two sectors: +13 % bytes fetched, profiles/r05_alignment.md): step u = R b + r reads
+  // t, x, bZ of position u + 1 from entry r + 1 (entry 0 of the NEXT block's tile for r = R - 1) and leaves bY of position u + 1
+  // in entry r of the block's buffer; the run R b .. R b + R - 1 of bY is the previous block's last entry and R - 1 of this one's.
+  __shared__ __attribute__((aligned(16))) double sin_[2][3][SPW][R];  // t, x, bZ of two blocks
+  __shared__ __attribute__((aligned(16))) double sout[SPW][R];        // bt (position u)
+  __shared__ __attribute__((aligned(16))) double soutY[2][SPW][R];    // bY (position u + 1) of this block and the one before
   __shared__ __attribute__((aligned(16))) double tin[LINES ? 3 : 1][LINES ? 4 : 1][kWave];   // [B / F / A][row & 3][lane]
   __shared__ __attribute__((aligned(16))) double tout[LINES ? 2 : 1][LINES ? 2 : 1][kWave];  // [bB / bA][row & 1][lane]
   const int J = PAD ? Jrt : G;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
 
   const int64_t r0 = rowof(0);
   double bz = bzb[r0];
-  byb[r0] = SOLVE ? bz : 0.0;      // reverse.hpp:112 (bY = bZ) / :178 (bY = 0)
+  soutY[1][grp][R - 1] = SOLVE ? bz : 0.0;      // bY of position 0: reverse.hpp:112 (bY = bZ) / :178 (bY = 0); leaves with block 0
   if constexpr (!LINES) { if (st) bAb[r0 * J] = 0.0; }       // never receives a contribution
   double tprev = tb[r0];
   double bF = 0.0, bcj = 0.0, carry = 0.0;
@@ -292,9 +297,9 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
       }
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   double rb[LINES ? 1 : R], rf[LINES ? 1 : R], ra[LINES ? 1 : R];
   auto load_row = [&](int r, int64_t u) {  // B and F rows of position u, A row of position u+1
@@ -317,7 +322,9 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
       const int64_t u = u0 + r;
       if (!CHECKED || u + 1 < N) {
         const int64_t n = rowof(u), m = rowof(u + 1);
-        const double tm = sin_[s][0][grp][r], xm = sin_[s][1][grp][r], bzm = sin_[s][2][grp][r];
+        const int e1 = (r + 1) % R;                     // entry of position u + 1 (r: unrolled) ...
+        const int s1 = (r + 1 < R) ? s : (s ^ 1);       // ... in this block's tile or the next one's
+        const double tm = sin_[s1][0][grp][e1], xm = sin_[s1][1][grp][e1], bzm = sin_[s1][2][grp][e1];
         double bn, Fn, am;
         if constexpr (LINES) {
           if ((r & 1) == PN) {   // (r: unrolled) row n enters a line of B and F: slot (lines entered so far) mod 4
@@ -357,10 +364,10 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
         const double bam = xm * bF;
         double f = cj * bp, g = am * bF;
         gsum2<G>(f, g);
-        sout[0][grp][r] = LOWER ? carry - f : f - carry;
+        sout[grp][r] = LOWER ? carry - f : f - carry;
         carry = f;
         const double out = SOLVE ? bzm + g : g;
-        sout[1][grp][r] = out;
+        soutY[s][grp][r] = out;
         bz = SOLVE ? out : bzm;
         if constexpr (LINES) {
           tout[1][m & 1][lane] = bam;
@@ -377,13 +384,13 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
-      if ((G * NV == R || idx < R) && (!CHECKED || u0 + idx + 1 < N)) {
-        btb[rowof(u0 + idx)] = sout[0][grp][idx];
-        byb[rowof(u0 + idx + 1)] = sout[1][grp][idx];
+      if (G * NV == R || idx < R) {
+        if (!CHECKED || u0 + idx + 1 < N) btb[rowof(u0 + idx)] = sout[grp][idx];
+        if (!CHECKED || u0 + idx < N) byb[rowof(u0 + idx)] = idx == 0 ? soutY[s ^ 1][grp][R - 1] : soutY[s][grp][idx - 1];
       }
     }
     vstage(s);
-    vload(u0 + 1 + 3 * R);
+    vload(u0 + 3 * R);
     lds_order();
   };
   int64_t u0 = 0;
@@ -394,6 +401,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   for (; u0 + 2 * R + 1 <= N; u0 += R, s ^= 1) block(u0, s, std::false_type{});
   for (; u0 + 1 < N; u0 += R, s ^= 1) block(u0, s, std::true_type{});
 
+  if (u0 < N) byb[rowof(u0)] = soutY[s ^ 1][grp][R - 1];   // the last block's last entry: position N - 1 = R b opens a run of its own
   const int64_t rl = rowof(N - 1);
   btb[rl] = LOWER ? carry : -carry;
   if constexpr (LINES) {   // bB of the last row is zero; the lines no step completed leave now

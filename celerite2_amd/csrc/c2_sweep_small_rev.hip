@@ -29,8 +29,12 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
                                                       double *__restrict__ bU, double *__restrict__ bV,
                                                       double *__restrict__ bY) {
   constexpr int SPW = kWave / G, NV = (R + G - 1) / G, NIN = 1 + 2 * KT, NOUT = 1 + KT;
-  __shared__ __attribute__((aligned(16))) double sin_[2][NIN][SPW][R];   // t, x[k], bZ[k] at positions u+1 of two blocks
-  __shared__ __attribute__((aligned(16))) double sout[NOUT][SPW][R];     // bt (position u), bY[k] (position u+1)
+  // Scalar tiles hold the ALIGNED positions R b .. R b + R - 1 of a block (see k_sweep1_rev, c2_sweep.hip): step u = R b + r reads
+  // position u + 1 from entry r + 1 (entry 0 of the next block's tile for r = R - 1); bY of position u + 1 goes to entry r of the
+  // block's buffer and leaves as the run R b .. R b + R - 1: the previous block's last entry and R - 1 of this one's.
+  __shared__ __attribute__((aligned(16))) double sin_[2][NIN][SPW][R];   // t, x[k], bZ[k] of two blocks
+  __shared__ __attribute__((aligned(16))) double sout[SPW][R];           // bt (position u)
+  __shared__ __attribute__((aligned(16))) double soutY[2][KT][SPW][R];   // bY[k] (position u + 1) of this block and the one before
   const int J = PAD ? Jrt : G;
   const Geo<G> L(B, J);
   const int j = L.j, grp = L.lane / G;
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     bz[k] = bzb[r0 * KT + k];
-    byb[r0 * KT + k] = SOLVE ? bz[k] : 0.0;      // reverse.hpp:112 (bY = bZ) / :178 (bY = 0)
+    soutY[1][k][grp][R - 1] = SOLVE ? bz[k] : 0.0;      // bY of position 0: reverse.hpp:112 (bY = bZ) / :178 (bY = 0); leaves with block 0
     bF[k] = 0.0;
   }
   if (st) bAb[r0 * J] = 0.0;       // never receives a contribution
@@ -82,9 +86,9 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
       }
     }
   };
-  vload(1); vstage(0);
-  vload(1 + R); vstage(1);
-  vload(1 + 2 * R);
+  vload(0); vstage(0);
+  vload(R); vstage(1);
+  vload(2 * R);
 
   double rb[R], rf[R][KT], ra[R];
   auto load_row = [&](int r, int64_t u) {  // B and F rows of position u, A row of position u+1
@@ -106,10 +110,12 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
       const int64_t u = u0 + r;
       if (!CHECKED || u + 1 < N) {
         const int64_t n = rowof(u), m = rowof(u + 1);
-        const double tm = sin_[s][0][grp][r];
+        const int e1 = (r + 1) % R;                     // entry of position u + 1 (r: unrolled) ...
+        const int s1 = (r + 1 < R) ? s : (s ^ 1);       // ... in this block's tile or the next one's
+        const double tm = sin_[s1][0][grp][e1];
         double xm[KT], bzm[KT], Fn[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) { xm[k] = sin_[s][1 + k][grp][r]; bzm[k] = sin_[s][1 + KT + k][grp][r]; Fn[k] = rf[r][k]; }
+        for (int k = 0; k < KT; ++k) { xm[k] = sin_[s1][1 + k][grp][e1]; bzm[k] = sin_[s1][1 + KT + k][grp][e1]; Fn[k] = rf[r][k]; }
         const double bn = rb[r], am = ra[r];
         load_row(r, u + R);
         const double dt = tm - tprev;  // lower: t[m] - t[n]; upper: t[n] - t[m] with the roles of prev/next swapped
@@ -139,12 +145,12 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
         f = gsum<G>(f);
 #pragma unroll
         for (int k = 0; k < KT; ++k) g[k] = gsum<G>(g[k]);
-        sout[0][grp][r] = LOWER ? carry - f : f - carry;
+        sout[grp][r] = LOWER ? carry - f : f - carry;
         carry = f;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           const double out = SOLVE ? bzm[k] + g[k] : g[k];
-          sout[1 + k][grp][r] = out;
+          soutY[s][k][grp][r] = out;
           bz[k] = SOLVE ? out : bzm[k];
         }
         if (st) bAb[m * J] = bam;
@@ -154,14 +160,17 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
-      if ((G * NV == R || idx < R) && (!CHECKED || u0 + idx + 1 < N)) {
-        btb[rowof(u0 + idx)] = sout[0][grp][idx];
+      if (G * NV == R || idx < R) {
+        if (!CHECKED || u0 + idx + 1 < N) btb[rowof(u0 + idx)] = sout[grp][idx];
+        if (!CHECKED || u0 + idx < N) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) byb[rowof(u0 + idx + 1) * KT + k] = sout[1 + k][grp][idx];
+          for (int k = 0; k < KT; ++k)
+            byb[rowof(u0 + idx) * KT + k] = idx == 0 ? soutY[s ^ 1][k][grp][R - 1] : soutY[s][k][grp][idx - 1];
+        }
       }
     }
     vstage(s);
-    vload(u0 + 1 + 3 * R);
+    vload(u0 + 3 * R);
     lds_order();
   };
   int64_t u0 = 0;
@@ -169,6 +178,10 @@ __global__ __launch_bounds__(kWave) void k_sweepT_rev(int64_t B, int64_t N, int 
   for (; u0 + 2 * R + 1 <= N; u0 += R, s ^= 1) block(u0, s, std::false_type{});
   for (; u0 + 1 < N; u0 += R, s ^= 1) block(u0, s, std::true_type{});
 
+  if (u0 < N) {   // the last block's last entry: position N - 1 = R b opens a run of its own
+#pragma unroll
+    for (int k = 0; k < KT; ++k) byb[rowof(u0) * KT + k] = soutY[s ^ 1][k][grp][R - 1];
+  }
   const int64_t rl = rowof(N - 1);
   btb[rl] = LOWER ? carry : -carry;
   if (st) {

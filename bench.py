@@ -504,14 +504,17 @@ def main():
                     ll = parallel.gather_loglik(ll.cpu(), Btot, world, force=True).to(dev)
             return ll, flag
 
+        # Nothing but the barrier and the synchronisations sits between the warm-up and the timed steps: the events exist
+        # beforehand and the failure count is taken afterwards.  (A host-side pause of a millisecond there -- creating the
+        # events, a reduction + .item() -- lets the device's clock fall back, and the next ~25 ms of kernels run up to 35 %
+        # slower while it ramps: visible on the 4 - 16 ms steps of the multi-GPU shards, profiles/r05_clock_ramp.md.)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         for _ in range(args.warmup):
             ll, flag = step()
         torch.cuda.synchronize()
-        nfail = int((flag != 0).sum())
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         t0 = time.perf_counter()
         for i in range(args.steps):
             ev[i][0].record()
@@ -522,6 +525,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        nfail = int((flag != 0).sum())
         if dist_on:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

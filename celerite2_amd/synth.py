@@ -105,3 +105,26 @@ def device_batch_fast(first, count, N, J, device, seed0=721, gap_fraction=0.0, g
     c = torch.repeat_interleave(cc, 2, dim=1).contiguous()
     a, U, V = ops.get_celerite_matrices(ar, ac, bc, dc, t, diag)
     return t, c, a, U, V, y
+
+
+def timed_steady(fn, reps=9, warm_ms=40.0, what="median"):
+    """HIP-event time (ms) of `fn` at the device's STEADY clock: the clock ramps for ~25 ms after any pause of the host
+    (profiles/r05_clock_ramp.md: the first kernels after an idle millisecond run up to 35 % slow), so `fn` is first repeated
+    until `warm_ms` of device time have gone by, then `reps` calls are timed back to back with events created beforehand.
+    Measurement helper of tools/ and tests/ (like the rest of this module: not part of the product path)."""
+    import torch
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    one = max(e0.elapsed_time(e1), 1e-3)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for _ in range(min(2000, max(2, int(warm_ms / one) + 1))):
+        fn()
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2] if what == "median" else (sum(ts) / len(ts) if what == "mean" else ts[0])

@@ -18,13 +18,9 @@ def env():
 
 
 def _timed(torch, fn, reps=3):
-    fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    return sorted(ts)[len(ts) // 2]
+    """median of `reps` at the steady clock (the device ramps for ~25 ms after a pause: profiles/r05_clock_ramp.md)"""
+    from celerite2_amd import synth
+    return synth.timed_steady(fn, reps=reps, warm_ms=30.0)
 
 
 class _forced:

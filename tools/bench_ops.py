@@ -11,15 +11,8 @@ import torch
 from celerite2_amd import ops, synth
 
 
-def timed(fn, reps=5, warm=2):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for e0, e1 in ev:
-        e0.record(); fn(); e1.record()
-    torch.cuda.synchronize()
-    return sorted(e0.elapsed_time(e1) for e0, e1 in ev)[len(ev) // 2]
+def timed(fn, reps=9):
+    return synth.timed_steady(fn, reps=reps)   # (steady clock: profiles/r05_clock_ramp.md)
 
 
 def main():

@@ -10,13 +10,8 @@ J = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 N = 4096
 t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
 t1 = (t + 0.013).contiguous()
-def timed(f, reps=5):
-    for _ in range(2): f()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    for e0, e1 in ev:
-        e0.record(); f(); e1.record()
-    torch.cuda.synchronize()
-    return sorted(a.elapsed_time(b) for a, b in ev)[reps // 2]
+def timed(f, reps=7):
+    return synth.timed_steady(f, reps=reps)   # (steady clock: profiles/r05_clock_ramp.md)
 for nrhs in (1, 2, 4, 8):
     Y = torch.randn((B, N, nrhs), dtype=torch.float64, device=dev)
     Z = torch.empty((B, N, nrhs), dtype=torch.float64, device=dev)

@@ -7,12 +7,8 @@ import torch
 from celerite2_amd import ops, synth
 dev = torch.device("cuda:0")
 N = 4096
-def timed(fn, reps=3):
-    fn(); torch.cuda.synchronize(); ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-    return sorted(ts)[len(ts) // 2]
+def timed(fn, reps=5):
+    return synth.timed_steady(fn, reps=reps)   # (steady clock: profiles/r05_clock_ramp.md)
 print("| J | B | nrhs | solve_lower ms | GB/s | frac | solve_upper ms | GB/s | frac |")
 print("|---|---|---|---|---|---|---|---|---|")
 for J in (8, 16):

@@ -8,12 +8,8 @@ dev = torch.device("cuda:0")
 B, N, J = 8192, 4096, 8
 t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
 d, W, flag = ops.factor(t, c, a, U, V)
-def timed(fn, reps=5):
-    fn(); torch.cuda.synchronize(); ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
-    return sorted(ts)[len(ts) // 2]
+def timed(fn, reps=7):
+    return synth.timed_steady(fn, reps=reps)   # (steady clock: profiles/r05_clock_ramp.md)
 FWD_ONLY = os.environ.get("C2_SCAN_FWD_ONLY", "0") == "1"
 for nrhs in [int(v) for v in sys.argv[1:]] or [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16]:
     Y = torch.randn((B, N, nrhs), dtype=torch.float64, device=dev); Zo = torch.empty_like(Y)

@@ -22,13 +22,7 @@ QUICK = "--quick" in sys.argv
 
 
 def timed(fn, reps=5):
-    fn(); torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    return sorted(ts)[len(ts) // 2]
+    return synth.timed_steady(fn, reps=reps, warm_ms=30.0)   # (steady clock: profiles/r05_clock_ramp.md)
 
 
 class forced:

@@ -14,7 +14,9 @@ weak-scaling variant the line's `value` instead (labelled as such).
 
 A "step" = one pass of the hot path (fused log-lik + reverse-mode gradient w.r.t. t, c, a, U, V, y)
 over the rank's shard of independent series, inputs already resident in HBM, followed for N>1 by the one
-real exchange of the path: an RCCL all-gather of the per-rank log-likelihood vector.  Rank 0 prints ONE
+real exchange of the path: an RCCL all-gather of the per-rank log-likelihood vector.  The W warm-up steps are preceded by
+untimed steps until the device has had ~60 ms of work (its clock ramps for ~25 ms after a pause: `config.clock_prewarm_steps`,
+--no-clock-prewarm), and nothing but the barrier and the synchronisations separates warm-up and timed steps.  Rank 0 prints ONE
 JSON line.  `roofline` prices the step against the HBM roofline with the ALGORITHMIC bytes of SURVEY.md
 section 8(d) (each input read once, each output written once: 16(3+2J) B per time step per series);
 `cpu_baseline` times the CPU restatement (oracle/, "port" -- the Eigen reference is unbuildable here) on a
@@ -361,6 +363,9 @@ def main():
                     help="total series, sharded over the GPUs (strong scaling; 65536 = the literal configs[2], the default)")
     ap.add_argument("--batch-per-gpu", type=int, default=0,
                     help="if > 0: series PER GPU (weak scaling) as the line's value -- a variant, not the literal configs[2]")
+    ap.add_argument("--no-clock-prewarm", action="store_true",
+                    help="do not run extra untimed steps in front of the W warm-up steps (by default the device gets ~60 ms of "
+                         "work before the timed region: its clock ramps for ~25 ms after a pause, profiles/r05_clock_ramp.md)")
     ap.add_argument("--no-weak-object", action="store_true",
                     help="N > 1: skip the extra `weak_scaling` measurement (65536 series per GPU) the strong-scaling line carries")
     ap.add_argument("--weak-batch-per-gpu", type=int, default=65536,
@@ -509,6 +514,16 @@ def main():
         # events, a reduction + .item() -- lets the device's clock fall back, and the next ~25 ms of kernels run up to 35 %
         # slower while it ramps: visible on the 4 - 16 ms steps of the multi-GPU shards, profiles/r05_clock_ramp.md.)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        # The W warm-up steps bring the CLOCK up only if they last ~30 ms; short steps (the 4 - 16 ms of the multi-GPU shards)
+        # get untimed steps in front of them until 60 ms of device time have gone by -- counted in config.clock_prewarm_steps.
+        # (the count comes from the shape alone -- ~0.43 us per series and 4096 rows with the gradient, a quarter without --,
+        # so every rank runs the same number of steps and of all-gathers)
+        pre = 0
+        if args.warmup > 0 and not args.no_clock_prewarm:
+            est_ms = max(0.05, (Btot / world) * (N / 4096.0) * (0.43e-3 if grad else 0.11e-3))
+            pre = max(0, min(64, int(60.0 / est_ms + 0.999) - args.warmup))
+            for _ in range(pre):
+                ll, flag = step()
         for _ in range(args.warmup):
             ll, flag = step()
         torch.cuda.synchronize()
@@ -531,12 +546,13 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax[0])
         kernel_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-        return dict(Btot=Btot, first=first, Bp=Bp, elapsed=elapsed, kernel_ms=kernel_ms, ll=ll, nfail=nfail,
+        return dict(Btot=Btot, first=first, Bp=Bp, elapsed=elapsed, kernel_ms=kernel_ms, ll=ll, nfail=nfail, prewarm=pre,
                     placement=placement, work=work, out=out, inputs=(t, c, a, U, V, y))
 
     Btot = args.batch_per_gpu * world if weak else args.global_batch
     m = measure(Btot, args.placement_search)
     first, Bp, elapsed, kernel_ms, ll, nfail, placement = m["first"], m["Bp"], m["elapsed"], m["kernel_ms"], m["ll"], m["nfail"], m["placement"]
+    prewarm = m["prewarm"]
     work, out = m["work"], m["out"]
     t, c, a, U, V, y = m["inputs"]
     m = None   # (the names above own the buffers now: the informational legs below free them one by one)
@@ -593,7 +609,7 @@ def main():
                                         Btot, Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
                        "global_batch": Btot, "batch_per_gpu": Bp, "N": N, "J": J,
                        "parallelism": "batch-sharded x%d, all-gather of log-liks" % world,
-                       "failed_factorizations": nfail, "ranks": ranks},
+                       "failed_factorizations": nfail, "clock_prewarm_steps": prewarm, "ranks": ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(grad, Bp, N, J),
                          "algorithmic_bytes_per_gp": bytes_per_gp, "kernel_ms_avg": kernel_ms_avg,

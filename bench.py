@@ -51,10 +51,10 @@ def measured_traffic(grad, Bp, N, J):
                 for w in json.load(f)["workloads"]:
                     if (w["mode"] == ("grad" if grad else "fwd") and w["batch_per_gpu"] == Bp and w["N"] == N
                             and w["J"] == J):
-                        return w["traffic_bytes_per_step"]
+                        return w["traffic_bytes_per_step"], os.path.relpath(path, ROOT)
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def self_launch(args):
@@ -158,6 +158,46 @@ def rel_errors(got, want):
     return float((diff / big).max()), float((diff / (np.abs(w) + 1e-2 * big)).max())
 
 
+def parity_all(inputs, ll, grads, chunk=2048, nthreads=0):
+    """EVERY series of a batch the hot path has just processed against the CPU oracle (`--parity-sample all`,
+    tests/test_gpu_ops.py::test_bench_generator_full_batch_vs_oracle): inputs stream to the host `chunk` series at a time,
+    the oracle (all host threads) computes log-likelihood + six gradients, its results go back to the device and are
+    compared there.  Per array the worst value over ALL series of
+      `criterion`: max_i |x_i - x_o,i| / (1e-10 |x_o,i| + 1e-12 max(1, max|x_o|))  -- the tests' element-wise criterion
+                   (tests/test_gpu_ops.py::close, max taken per series and array) as a ratio: <= 1 passes;
+      `rel_to_largest`: max|x - x_o| / max|x_o| per series and array."""
+    import numpy as np
+    import torch
+
+    from oracle import cpu
+
+    B = int(ll.shape[0])
+    dev = ll.device
+    crit = {nm: 0.0 for nm in ("ll",) + PARITY_NAMES}
+    rel = {nm: 0.0 for nm in PARITY_NAMES}
+    worst_series = {nm: -1 for nm in PARITY_NAMES}
+    failed = 0
+    for s in range(0, B, chunk):
+        e = min(B, s + chunk)
+        host = [x[s:e].cpu().numpy() if x.dim() > 1 and x.shape[0] == B else x.cpu().numpy() for x in inputs]
+        llo, go, flago = cpu.loglik_grad_batched(*host, nthreads=nthreads)
+        failed += int(np.abs(flago).sum())
+        lo = torch.from_numpy(llo).to(dev)
+        crit["ll"] = max(crit["ll"], float(((ll[s:e] - lo).abs() / (1e-10 * lo.abs())).max()))
+        for nm, g, w in zip(PARITY_NAMES, grads, go):
+            w = torch.from_numpy(w).to(dev).reshape(e - s, -1)
+            d = (g[s:e].reshape(e - s, -1) - w).abs()
+            big = w.abs().amax(dim=1, keepdim=True)
+            r = (d / (1e-10 * w.abs() + 1e-12 * big.clamp(min=1.0))).amax(dim=1)
+            k = int(r.argmax())
+            if float(r[k]) > crit[nm]:
+                crit[nm], worst_series[nm] = float(r[k]), s + k
+            rel[nm] = max(rel[nm], float((d.amax(dim=1, keepdim=True) / torch.where(big > 0, big, torch.ones_like(big))).max()))
+            del w, d
+    return {"series": B, "oracle_failed": failed, "criterion": crit, "rel_to_largest": rel, "worst_series": worst_series,
+            "worst_criterion": max(crit.values()), "passes": bool(max(crit.values()) <= 1.0 and failed == 0)}
+
+
 def parity_sample(samples, coeff_sample):
     """The timed batches against the CPU oracle: the series `take_sample` set aside from the step's own batch (and from
     the `gappy_all` batch), log-likelihood and the six gradients; the coefficient-level leg's sample through the oracle
@@ -174,6 +214,8 @@ def parity_sample(samples, coeff_sample):
         llo, go, flago = cpu.loglik_grad_batched(*smp["inputs"])   # (every thread OpenMP has: the setting is global to the library)
         e = {"series": int(len(smp["index"])), "oracle_failed": int(np.abs(flago).sum()),
              "ll": float(np.max(np.abs(smp["ll"] - llo) / np.abs(llo)))}
+        if "kappa_max" in smp:
+            e["kappa_max"] = smp["kappa_max"]
         el = {}
         for nm, g, w in zip(PARITY_NAMES, smp["grads"], go):
             el[nm], e[nm] = rel_errors(g, w)
@@ -378,6 +420,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-sample", action="store_true",
                     help="skip the `parity_sample` object (series of the timed batches against the CPU oracle, after the timed regions)")
+    ap.add_argument("--parity-sample", default="32",
+                    help="how many series of the timed batch `parity_sample.step_batch` checks against the CPU oracle: a count "
+                         "(default 32, drawn at random) or `all` -- every series of the batch, streamed through the oracle "
+                         "(65536 series: ~1 min on the box's host cores; adds `parity_sample.step_batch_all`)")
     ap.add_argument("--exact-synth", action="store_true",
                     help="per-series numpy recipe (identical series whatever the sharding) instead of the device generator")
     ap.add_argument("--placement-search", type=int, default=1,
@@ -561,8 +607,31 @@ def main():
     # step, set aside now and checked against the CPU oracle in the cpu_baseline leg (after every timed region)
     samples, coeff_sample = {}, None
     want_parity = rank == 0 and grad and not args.no_cpu_baseline and not args.no_parity_sample
+    # conditioning of the timed batch (c2_condition: kappa = max a_n / d_n per series; untimed, after the timed region):
+    # any float64 evaluation order carries ~0.4 eps kappa^2 of the largest gradient entry -- what the 1e-10 claim rests on
+    kappa_obj = kap = None
+    if rank == 0 and J <= 32:
+        try:
+            kap, _kf = ops.condition(t, c, a, U, V)
+            fin = kap[torch.isfinite(kap)]
+            kmax = float(fin.max()) if fin.numel() else float("inf")
+            kappa_obj = {"max": kmax, "median": float(fin.median()) if fin.numel() else None,
+                         "float64_floor_0.4_eps_kappa2": 0.4 * 2.220446049250313e-16 * kmax * kmax,
+                         "tolerance_1e-10_attainable": bool(0.4 * 2.220446049250313e-16 * kmax * kmax <= 1e-10),
+                         "series": int(kap.numel())}
+        except Exception as e:  # noqa: BLE001 -- informational
+            kappa_obj = {"error": repr(e)[:200]}
+    parity_all_obj = None
     if want_parity:
-        samples["step_batch"] = take_sample((t, c, a, U, V, y), ll[first:first + Bp] if ll.shape[0] != Bp else ll, out, 32, 1)
+        ll_mine = ll[first:first + Bp] if ll.shape[0] != Bp else ll
+        nsmp = 32 if args.parity_sample == "all" else int(args.parity_sample)
+        samples["step_batch"] = take_sample((t, c, a, U, V, y), ll_mine, out, nsmp, 1)
+        if kap is not None:
+            samples["step_batch"]["kappa_max"] = float(kap.index_select(0, torch.from_numpy(samples["step_batch"]["index"]).to(kap.device)).max())
+        if args.parity_sample == "all":   # (the outputs of the last timed step, before anything reuses their arrays)
+            from oracle import cpu as _cpu
+            _cpu.build_native()
+            parity_all_obj = parity_all((t, c, a, U, V, y), ll_mine, out)
     # who ran: one entry per rank (device, PCI bus id) + the collective library -- self-evidencing multi-GPU lines
     me = {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
           "pci_bus_id": "%04x:%02x:%02x.0" % tuple(getattr(torch.cuda.get_device_properties(dev_index), k, 0)
@@ -596,6 +665,7 @@ def main():
         value = total_gps / elapsed
         bytes_per_gp = algorithmic_bytes_per_gp(N, J, grad)
         achieved = Bp * bytes_per_gp / (kernel_ms_avg * 1e-3) / 1e9  # per GPU, HIP-event time of the hot path
+        traffic, traffic_src = measured_traffic(grad, Bp, N, J)
         line = {
             "metric": "float64 GP log-lik+grad/sec at N=%d J=%d, batched" % (N, J) if grad
                       else "float64 GP log-lik/sec at N=%d J=%d, batched" % (N, J),
@@ -609,9 +679,13 @@ def main():
                                         Btot, Bp, N, J, J // 2, "forward + reverse-mode grad" if grad else "forward"),
                        "global_batch": Btot, "batch_per_gpu": Bp, "N": N, "J": J,
                        "parallelism": "batch-sharded x%d, all-gather of log-liks" % world,
-                       "failed_factorizations": nfail, "clock_prewarm_steps": prewarm, "ranks": ranks},
+                       "failed_factorizations": nfail, "clock_prewarm_steps": prewarm, "kappa": kappa_obj, "ranks": ranks},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(grad, Bp, N, J),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("%s (rocprofv3 PMC, 2 x FETCH_SIZE + WRITE_SIZE in separate passes of this "
+                                            "workload -- read from the committed file, NOT measured in this run)" % traffic_src)
+                                           if traffic is not None else None,
+                         "traffic_ratio": traffic / (Bp * bytes_per_gp) if traffic is not None else None,
                          "algorithmic_bytes_per_gp": bytes_per_gp, "kernel_ms_avg": kernel_ms_avg,
                          "kernel_ms_median": kernel_ms[len(kernel_ms) // 2]},
         }
@@ -653,6 +727,8 @@ def main():
                 from oracle import cpu as _cpu
                 _cpu.build_native()   # (the timing build of the cpu_baseline leg must be chosen before the oracle is first loaded)
                 line["parity_sample"] = parity_sample(samples, coeff_sample)
+                if parity_all_obj is not None:
+                    line["parity_sample"]["step_batch_all"] = parity_all_obj
             except Exception as e:  # noqa: BLE001 -- the checker must not take the line down; its absence is visible
                 line["parity_sample"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:

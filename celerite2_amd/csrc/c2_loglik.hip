@@ -1301,6 +1301,7 @@ static int64_t timepar_min_rows(int64_t B, int64_t J) {
 }
 static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
   if (J != 4 && J != 2 && !(J == 8 && loglik)) return false;
+  if (B > 65535) return false;   // (the chunk kernels put the batch on gridDim.y -- also under C2_TIMEPAR=1)
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   if (opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) return false;   // a forced lane mapping means the row-by-row kernels
   if (J == 8) {   // forward log-likelihood: chunk elements in lanes, combined by workgroups (k_e8_tree).  Measured (ms,
@@ -1330,6 +1331,7 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
 // the same decision for the single-rhs solves (affine maps: width 8 as well)
 extern "C" int c2_internal_use_timepar_solve(int64_t B, int64_t N, int64_t J) {
   if (J != 8 && J != 4 && J != 2) return 0;
+  if (B > 65535) return 0;       // (batch on gridDim.y)
   if (opt::has(opt::k_timepar)) return opt::ival(opt::k_timepar) != 0 && N >= 2;
   return N >= timepar_min_rows(B, J) && B * J <= opt::ival(opt::k_timepar_max_batch_x_width);
 }
@@ -1758,7 +1760,8 @@ size_t c2_loglik_grad_workspace_bytes(int64_t B, int64_t N, int64_t J) {
   size_t n = grad_ws(B, N, J, use_back(N, J)).total;
   if (use_lanes4(B, J, true)) {   // [guard words] [records of the four-lane pair | workspace of the replay fallback]
     const size_t r = c2_internal_loglik_q4_record_doubles(B, N), f = grad_ws(B, N, J).total;
-    n = lanes1_gate_words(B) + (r > f ? r : f);
+    const size_t n4 = lanes1_gate_words(B) + (r > f ? r : f);
+    n = n4 > n ? n4 : n;   // (arrays off a 16-byte boundary take the eight-lane pair on the same workspace)
   }
   if (use_lanes1(B, J, true)) {  // [guard words: head + one per wavefront] [records of the one-lane path | workspace of the replay fallback]
     const size_t r = lanes1_record_doubles(B, N, J), f = grad_ws(B, N, J).total;
@@ -1827,7 +1830,11 @@ static int loglik_grad_impl(int64_t B, int64_t N, int64_t J, const double *t, in
                                           (double *)work + kTimeparVerifyWords, (const unsigned long long *)work, stream);
   }
   const unsigned long long *gate = nullptr;
-  if (use_lanes4(B, J, true)) {
+  // (the four-lane pair moves U, V, bU, bV, bc and its records as double2: the C ABI promises 8-byte alignment only, so
+  // arrays off a 16-byte boundary -- a view starting at an odd element -- take the eight-lane pair instead)
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V) | reinterpret_cast<uintptr_t>(bU) |
+                           reinterpret_cast<uintptr_t>(bV) | reinterpret_cast<uintptr_t>(bc) | reinterpret_cast<uintptr_t>(work)) & 15) == 0;
+  if (use_lanes4(B, J, true) && aligned16) {
     // Four lanes per series, scaled frame.  Groups of 64 series whose anchor intervals are beyond the guard (gaps in time)
     // are left to the replay pair below, gated per group by the words k_q4_gate leaves (decided on the device).
     unsigned long long *guard = (unsigned long long *)work;

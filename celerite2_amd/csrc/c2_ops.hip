@@ -1639,6 +1639,29 @@ static int launch_sweep_rev(int64_t B, int64_t N, int64_t J, int64_t nrhs, const
                                    nrhs, t, t_bs, c, c_bs, U, V, Y, Z, F, bZ, bt, bc, bU, bV, bY));
   return check_launch();
 }
+
+// kappa[b] = max_n a_n / d_n of a factored slice (one workgroup per series); a failed factorisation (flag != 0): +inf.
+__global__ __launch_bounds__(256) void k_condition(int64_t N, const double *__restrict__ a, const double *__restrict__ d,
+                                                   const int32_t *__restrict__ flag, double *__restrict__ kappa) {
+  __shared__ double red[4];
+  const int64_t b = blockIdx.x;
+  double m = 0.0;
+  for (int64_t n = threadIdx.x; n < N; n += 256) {
+    const double r = a[b * N + n] / d[b * N + n];
+    m = r > m ? r : m;
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double v = __shfl_xor(m, o, kWave);
+    m = v > m ? v : m;
+  }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) m = red[w] > m ? red[w] : m;
+    kappa[b] = flag[b] != 0 ? INFINITY : m;
+  }
+}
+
 extern "C" {
 
 const char *c2_version(void) { return "celerite2_amd 0.1.0 (gfx950)"; }
@@ -1842,6 +1865,34 @@ int c2_dot_tril(int64_t B, int64_t N, int64_t J, int64_t nrhs, const double *t, 
                      nrhs, d, Y, Z);
   if (int e = check_launch()) return e;
   return launch_sweep<true, false>(B, N, J, nrhs, t, t_bs, c, c_bs, U, W, Z, Z, nullptr, 0, stream);
+}
+
+// kappa = max_n a_n / d_n per series (include/celerite2_amd.h): `factor` on slices of the batch into library temporaries
+// (d, W of at most 4096 series at a time), then one reduction per series.
+int c2_condition(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                 const double *a, const double *U, const double *V, double *kappa, int32_t *flag, c2_stream_t stream) {
+  if (int e = check_dims(B, N, J)) return e;
+  if (!t || !c || !a || !U || !V || !kappa || !flag) return C2_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t slice = B < 4096 ? B : 4096;
+  double *tmp = nullptr;
+  if (temp_alloc((void **)&tmp, sizeof(double) * (size_t)slice * (size_t)N * (size_t)(J + 1), s) != hipSuccess) {
+    (void)hipGetLastError();
+    return C2_ERR_HIP;
+  }
+  double *d = tmp, *W = tmp + (size_t)slice * (size_t)N;
+  int rc = C2_OK;
+  for (int64_t b0 = 0; b0 < B && rc == C2_OK; b0 += slice) {
+    const int64_t nb = B - b0 < slice ? B - b0 : slice;
+    rc = c2_factor(nb, N, J, t + b0 * t_bs, t_bs, c + b0 * c_bs, c_bs, a + b0 * N, U + b0 * N * J, V + b0 * N * J, d, W,
+                   nullptr, flag + b0, stream);
+    if (rc != C2_OK) break;
+    hipLaunchKernelGGL(k_condition, dim3((unsigned)nb), dim3(256), 0, s, N, a + b0 * N, (const double *)d,
+                       (const int32_t *)(flag + b0), kappa + b0);
+    rc = check_launch();
+  }
+  const int rf = hip_check(hipFreeAsync(tmp, s));
+  return rc == C2_OK ? rf : rc;
 }
 
 }  // extern "C"

@@ -931,7 +931,14 @@ __device__ __forceinline__ void e8_combine(const double *__restrict__ r1, const 
 }
 // grid (ceil(Kin / span), B): workgroup x of series b reduces elements span x .. of `in` ([series][Kin] records) to ONE: written
 // to `out` ([series][gridDim.x] records) or -- when it is the only workgroup of its series -- turned into ll (numpy.py:84-109).
-// `scr`: span records per workgroup for the levels in between.
+// `scr`: e8_level_records(span) records per workgroup: the levels in between, back to back, and the workgroup's own final
+// record behind them.  (The levels of a span that is not a power of two need MORE than span records -- 25 -> 13 + 7 + 4 + 2:
+// rounds 5's `span` records per workgroup overflowed into the next workgroup's region / past the buffer for K = 9, 17, 25, ...)
+__host__ __device__ inline int e8_level_records(int span) {
+  int total = 1;   // the final record
+  for (int n = span; n > 1; n = (n + 1) >> 1) total += (n + 1) >> 1;
+  return total;
+}
 __global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Kin, int span, const double *__restrict__ in,
                                                             double *__restrict__ out, double *__restrict__ scr,
                                                             double *__restrict__ ll, int32_t *__restrict__ flag,
@@ -942,9 +949,10 @@ __global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Ki
   const int64_t b = blockIdx.y, first = (int64_t)blockIdx.x * span;
   int n = (int)((Kin - first) < span ? (Kin - first) : span);
   const double *src = in + (size_t)(b * Kin + first) * REC;
-  double *lvl = scr + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)span * REC;   // levels: span / 2, span / 4, ... records, back to back
+  const int stride = e8_level_records(span);
+  double *lvl = scr + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)stride * REC;   // levels: ceil(span / 2), ceil(span / 4), ... records, back to back
   const bool last = gridDim.x == 1;
-  double *dst_final = last ? lvl + (size_t)(span - 1) * REC : out + (size_t)(b * gridDim.x + blockIdx.x) * REC;
+  double *dst_final = last ? lvl + (size_t)(stride - 1) * REC : out + (size_t)(b * gridDim.x + blockIdx.x) * REC;
   if (n == 1) {   // nothing to combine: hand the element on
     if (w == 0) for (int q = lane; q < REC; q += 64) dst_final[q] = src[q];
   }
@@ -996,7 +1004,7 @@ inline E8Plan e8_plan(int64_t B, int64_t N) {
   p.rec0 = 0;
   p.rec1 = p.rec0 + (size_t)B * (size_t)p.K * REC;
   p.scr = p.rec1 + 2 * (size_t)B * (size_t)p.blocks * REC;
-  p.total = p.scr + (size_t)B * (size_t)p.blocks * (size_t)p.span * REC;
+  p.total = p.scr + (size_t)B * (size_t)p.blocks * (size_t)e8_level_records(p.span) * REC;   // (later launches: fewer blocks, spans no longer)
   return p;
 }
 inline int run8(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,

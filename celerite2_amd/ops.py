@@ -17,7 +17,7 @@ from . import _lib
 __all__ = [
     "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "general_matmul_lower",
     "general_matmul_upper", "factor_rev", "solve_lower_rev", "solve_upper_rev", "matmul_lower_rev",
-    "matmul_upper_rev", "get_celerite_matrices", "kernel_values", "loglik", "loglik_grad", "loglik_grad_workspace", "dot_tril",
+    "matmul_upper_rev", "get_celerite_matrices", "kernel_values", "loglik", "loglik_grad", "loglik_grad_workspace", "condition", "dot_tril",
     "kron_loglik", "kron_loglik_grad", "loglik_terms", "loglik_terms_grad",
 ]
 
@@ -81,6 +81,21 @@ def factor(t, c, a, U, V, d=None, W=None, S=None, *, workspace=False):
                                _p(U), _p(V), _p(d), _p(W), _p(S), _p(flag), _stream())
     _lib.check(rc, "factor")
     return (d, W, S, flag) if S is not None else (d, W, flag)
+
+
+def condition(t, c, a, U, V):
+    """kappa[b] = max_n a_n / d_n per series (+inf where the factorisation fails), and the factor flag: whether north_star's
+    1e-10 agreement with the reference is attainable in float64 for these inputs (include/celerite2_amd.h, c2_condition:
+    any evaluation order carries ~0.4 eps kappa^2 of the largest gradient entry).  Returns (kappa, flag)."""
+    B, N, J = _dims(U)
+    kappa = torch.empty(B, dtype=torch.float64, device=U.device)
+    flag = torch.empty(B, dtype=torch.int32, device=U.device)
+    _chk(t, c, a, U, V)
+    _shape("t", t, (N,), (B, N)); _shape("c", c, (J,), (B, J)); _shape("a", a, (B, N)); _shape("V", V, (B, N, J))
+    rc = _lib.load().c2_condition(_i64(B), _i64(N), _i64(J), _p(t), _i64(_bs(t, N)), _p(c), _i64(_bs(c, J)), _p(a),
+                                  _p(U), _p(V), _p(kappa), _p(flag), _stream())
+    _lib.check(rc, "condition")
+    return kappa, flag
 
 
 def _sweep(name, matmul):

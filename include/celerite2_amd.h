@@ -232,6 +232,18 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
                    double *bc, double *ba, double *bU, double *bV, double *by, int32_t *flag, void *work,
                    size_t work_bytes, c2_stream_t stream);
 
+/* Conditioning of the factorisation, per series: kappa[b] = max_n a_n / d_n (+inf where the factorisation fails,
+ * flag[b] = the failing row as in c2_factor).  d_n = a_n - U_n S_n U_n^T (forward.hpp:126-128) is a difference: a
+ * float64 evaluation of the recursion IN ANY ORDER -- the reference's own included -- carries a rounding error of
+ * ~0.4 eps kappa^2 relative to the largest entry of a gradient array (oracle vs its own extended-precision
+ * evaluation: tests/test_oracle.py, tools/kappa_sweep.py).  north_star's 1e-10 agreement with the reference is
+ * therefore attainable where kappa <~ 1e3 (0.4 * 2.2e-16 * kappa^2 <= 1e-10): a caller who needs to know whether a
+ * result can be held to that tolerance asks here.  (bench.py reports the timed batch's largest kappa; the synthetic
+ * series of SURVEY.md 8d sit at kappa ~ 10 - 40.)  Replaces nothing in the reference (which reports no conditioning);
+ * costs one `factor` pass on library temporaries (slices of 4096 series). */
+int c2_condition(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                 const double *a, const double *U, const double *V, double *kappa, int32_t *flag, c2_stream_t stream);
+
 /* 2-D (multi-band) extension, rank-1 band covariance K = T (x) alpha alpha^T + diag over N epochs x M bands
  * (observations interleaved epoch-major: row n*M + m).  EXTENSION -- the reference has no 2-D code (no core2.hpp;
  * README.md:14-17 only cites the paper), so this entry point replaces nothing and its parity is pinned by the dense

@@ -374,7 +374,12 @@ def _tpg_check(ops, oracle, monkeypatch, seed, forced=True):
         TPG_STATS["needed_floor_seeds"].append(("time-parallel" if forced else "row-by-row", seed))
         # ... and where such a draw stands against the EXACT result (the extended-precision evaluation): the device's
         # distance to it beside the float64 oracle's own
-        TPG_STATS["floor_details"].append(("time-parallel" if forced else "row-by-row", seed, worst, worst_x, oracle_x))
+        # ... and the conditioning the library itself reports for the draw (c2_condition: kappa = max a_n / d_n over the
+        # series that factor): the floor term is ~0.4 eps kappa^2
+        kap, _ = ops.condition(*args[:5])
+        kap = kap.cpu().numpy()
+        kap = float(kap[np.isfinite(kap)].max()) if np.isfinite(kap).any() else float("inf")
+        TPG_STATS["floor_details"].append(("time-parallel" if forced else "row-by-row", seed, worst, worst_x, oracle_x, kap))
     return worst
 
 

@@ -862,6 +862,56 @@ def test_bench_generator_batch_sample_vs_oracle(ops, oracle, B):
             close(g[b], e[b])
 
 
+@pytest.mark.parametrize("B", [65536, 32768, 16384, 8192])
+def test_bench_generator_full_batch_vs_oracle(ops, oracle, B):
+    """EVERY series of the batch bench.py times (configs[2] at full size, and its 2 / 4 / 8-GPU shards: a different lane
+    mapping each) against the CPU oracle -- distinct data at every lane position of every wavefront, log-likelihood and all
+    six gradients under the tests' element-wise criterion (bench.parity_all: inputs stream to the host 2048 series at a
+    time, the oracle runs on all host threads, the comparison on the device)."""
+    import torch
+    import bench
+    from celerite2_amd import synth
+    N, J = 4096, 8
+    args = synth.device_batch_fast(0, B, N, J, torch.device("cuda:0"))
+    ll, grads, flag = ops.loglik_grad(*args)
+    torch.cuda.synchronize()
+    assert int(flag.abs().sum()) == 0
+    r = bench.parity_all(args, ll, grads)
+    print("B = %d: all series vs oracle: criterion (<= 1 passes) %s; rel. to largest %s; worst series %s"
+          % (B, {k: "%.3f" % v for k, v in r["criterion"].items()}, {k: "%.1e" % v for k, v in r["rel_to_largest"].items()},
+             r["worst_series"]))
+    assert r["series"] == B and r["oracle_failed"] == 0
+    assert r["passes"], r
+
+
+@pytest.mark.parametrize("B,N,J", [(5, 257, 8), (3, 1000, 2), (4100, 64, 4), (2, 300, 20)])
+def test_condition_number_per_series(ops, oracle, B, N, J):
+    """c2_condition: kappa[b] = max_n a_n / d_n against the oracle's factor (two slices of the batch at 4100 series), +inf and
+    the failing row where a series does not factor; shared t / c."""
+    import torch
+    t, c, a, U, V, y = dense.synthetic_batch(min(B, 8), N, J)
+    if B > 8:
+        rng = np.random.default_rng(1)
+        rep = (B + 7) // 8
+        t, c, U, V = (np.ascontiguousarray(np.tile(v, (rep,) + (1,) * (v.ndim - 1))[:B]) for v in (t, c, U, V))
+        a = np.ascontiguousarray(np.tile(a, (rep, 1))[:B] * rng.uniform(0.9, 1.5, (B, 1)))
+    bad = B // 2
+    a[bad, N // 3] = -1.0
+    kappa, flag = ops.condition(*dev(t, c, a, U, V))
+    kap, fl = kappa.cpu().numpy(), flag.cpu().numpy()
+    for b in list(range(min(B, 6))) + [bad, B - 1]:
+        d = np.empty(N); W = np.empty((N, J))
+        f = oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], d, W)
+        assert int(fl[b]) == f
+        if f:
+            assert np.isposinf(kap[b]) and b == bad
+        else:
+            assert abs(kap[b] - np.max(a[b] / d)) <= 1e-10 * kap[b]
+    assert np.isfinite(np.delete(kap, bad)).all()
+    k2, _ = ops.condition(*dev(t[0].copy(), c[0].copy(), a, U, V))   # shared grid and rates
+    assert k2.shape == (B,) and bool(torch.isposinf(k2[bad]))
+
+
 def test_config3_full_length_dot_tril(ops, oracle):
     """BASELINE configs[3] at full length: ONE series, N = 10^7, J = 16, nrhs = 32, dot_tril (numpy.py:100-102)
     against the sequential CPU oracle on every element."""

@@ -74,6 +74,34 @@ def test_timepar_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     close(ll2[ok], lls[ok])
 
 
+@pytest.mark.parametrize("B,N", [(3, 140), (3, 270), (1, 390), (3, 390), (600, 390), (2, 520), (300, 912), (3, 1600), (2, 8200),
+                                 (2, 147000)])
+def test_timepar_width8_tree_spans_that_are_not_powers_of_two(ops, oracle, monkeypatch, B, N):
+    """k_e8_tree with K = 9, 17, 25, 33, 57, 100 chunk elements per workgroup (and Kin = 9 / 17 in a later launch: 8200 rows =
+    513 chunks -> 9 results of 64, 147000 rows): the levels of such a span need MORE than `span` records (25 -> 13 + 7 + 4 + 2).
+    Round 5 sized the level scratch by `span` and put the final record at span - 1: a write into the next workgroup's region
+    (a race once the batch exceeds the resident workgroups: 600 series) or past the buffer.  Every series
+    against the oracle and against the row-by-row kernel, twice (a stale neighbour would differ between runs)."""
+    t, c, a, U, V, y = dense.synthetic_batch(min(B, 6), N, 8)
+    if B > 6:   # distinct data in every series without 600 calls of the generator: shifted copies of y, scaled a
+        reps = (B + 5) // 6
+        rng = np.random.default_rng(B)
+        t, c, U, V = (np.ascontiguousarray(np.tile(v, (reps,) + (1,) * (v.ndim - 1))[:B]) for v in (t, c, U, V))
+        a = np.ascontiguousarray(np.tile(a, (reps, 1))[:B] * rng.uniform(1.0, 1.3, (B, 1)))
+        y = np.ascontiguousarray(np.tile(y, (reps, 1))[:B] + 0.05 * rng.standard_normal((B, N)))
+    llo, flo = oracle_ll(oracle, t, c, a, U, V, y)
+    assert not flo.any()
+    d = dev(t, c, a, U, V, y)
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    for _ in range(2):
+        ll, flag = ops.loglik(*d)
+        assert int(flag.abs().sum()) == 0
+        close(ll, llo)
+    monkeypatch.setenv("C2_TIMEPAR", "0")
+    ll0, _ = ops.loglik(*d)
+    close(ll, ll0.cpu().numpy(), tol=1e-12)
+
+
 @pytest.mark.parametrize("J", [8, 4, 2])
 def test_timepar_falls_back_when_it_cannot_be_trusted(ops, oracle, monkeypatch, J):
     """Failed factorisations, zero white noise (kappa = 0: the maps are singular), gaps long enough to underflow a decay:

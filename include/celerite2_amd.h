@@ -239,7 +239,7 @@ int c2_loglik_grad(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_b
  * evaluation: tests/test_oracle.py, tools/kappa_sweep.py).  north_star's 1e-10 agreement with the reference is
  * therefore attainable where kappa <~ 1e3 (0.4 * 2.2e-16 * kappa^2 <= 1e-10): a caller who needs to know whether a
  * result can be held to that tolerance asks here.  (bench.py reports the timed batch's largest kappa; the synthetic
- * series of SURVEY.md 8d sit at kappa ~ 10 - 40.)  Replaces nothing in the reference (which reports no conditioning);
+ * series of SURVEY.md 8d at N = 4096, J = 8 sit at kappa ~ 290 median, 380 at most: a floor of 1.3e-11.)  Replaces nothing in the reference (which reports no conditioning);
  * costs one `factor` pass on library temporaries (slices of 4096 series). */
 int c2_condition(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
                  const double *a, const double *U, const double *V, double *kappa, int32_t *flag, c2_stream_t stream);

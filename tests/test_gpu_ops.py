@@ -894,7 +894,7 @@ def test_condition_number_per_series(ops, oracle, B, N, J):
         rng = np.random.default_rng(1)
         rep = (B + 7) // 8
         t, c, U, V = (np.ascontiguousarray(np.tile(v, (rep,) + (1,) * (v.ndim - 1))[:B]) for v in (t, c, U, V))
-        a = np.ascontiguousarray(np.tile(a, (rep, 1))[:B] * rng.uniform(0.9, 1.5, (B, 1)))
+        a = np.ascontiguousarray(np.tile(a, (rep, 1))[:B] * rng.uniform(1.0, 1.5, (B, 1)))   # (lifting a keeps K positive definite)
     bad = B // 2
     a[bad, N // 3] = -1.0
     kappa, flag = ops.condition(*dev(t, c, a, U, V))

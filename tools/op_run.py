@@ -1,0 +1,28 @@
+"""One op of the device ABI a few times, for profilers: python tools/op_run.py <op> <B> <N> <J> [reps]
+op: loglik | loglik_grad | factor | factor_s | factor_rev | chain (factor_s + solve_lower F + solve_lower_rev + factor_rev)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from celerite2_amd import ops, synth
+op, B, N, J = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+dev = torch.device("cuda:0")
+t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
+Y = y[:, :, None].contiguous()
+def run():
+    if op == "loglik": return ops.loglik(t, c, a, U, V, y)
+    if op == "loglik_grad": return ops.loglik_grad(t, c, a, U, V, y)
+    if op == "factor": return ops.factor(t, c, a, U, V)
+    if op == "factor_s": return ops.factor(t, c, a, U, V, workspace=True)
+    d, W, S, fl = ops.factor(t, c, a, U, V, workspace=True)
+    if op == "factor_rev": return ops.factor_rev(t, c, a, U, V, d, W, S, torch.ones_like(d), torch.ones_like(W))
+    Z, F = ops.solve_lower(t, c, U, W, Y, workspace=True)
+    r1 = ops.solve_lower_rev(t, c, U, W, Y, Z, F, torch.ones_like(Z))
+    return ops.factor_rev(t, c, a, U, V, d, W, S, torch.ones_like(d), torch.ones_like(W))
+for _ in range(2): run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps): run()
+e1.record(); torch.cuda.synchronize()
+print("%s B=%d N=%d J=%d: %.3f ms per call (back to back)" % (op, B, N, J, e0.elapsed_time(e1) / reps))

@@ -1640,6 +1640,8 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
     if (nd > 0 && room(nd, &tmp)) {
       const unsigned long long *last = nullptr;
       int rc = c2_internal_factor_iter(B, N, J, t, t_bs, c, c_bs, a, U, V, d, W, flag, (double *)tmp, &last, stream);
+      if (rc == C2_OK && c2_internal_get_debug_sink())   // diagnostics: the iterations' / the scan's words (tools/e8_words.py)
+        (void)hipMemcpyAsync(c2_internal_get_debug_sink() + 8, tmp, 30 * sizeof(double), hipMemcpyDeviceToDevice, s);
       if (rc == C2_OK)
         rc = launch_fwd<2>(B, N, J, t, t_bs, c, c_bs, a, U, V, a, nullptr, flag, nullptr, 0, W,
                            reinterpret_cast<double2 *>(d), s, last);

@@ -929,6 +929,108 @@ __device__ __forceinline__ void e8_combine(const double *__restrict__ r1, const 
     ro[kE8ex] = (double)(ex1 + ex2 + ex);
   }
 }
+// ---- width 8: the chunk pass with the element SPREAD OVER THE EIGHT LANES OF A GROUP (round 6).  k_tp_onepass<8, 2> keeps
+// an element (155 doubles) in ONE lane: ~550 instructions per row with eight exponentials, 3.6 us per row.  Here lane j of a
+// group owns COLUMN j of A, G and Q in XOR order (slot k = row j ^ k: c2_loglik_helpers.hpp), so that u T, u A are eight
+// multiply-adds on the lane's own registers, d one butterfly sum, and the rank-one updates need the gathered w, r = u A and
+// decay vectors (three DPP gathers); every lane computes ONE exponential.  A wavefront walks eight chunks; the records it
+// writes are those of k_tp_onepass<8, 2> (ElemIO<8>), VEC = false: matrices only (g, h, q0 zero -- `factor`).
+template <bool VEC>
+__global__ __launch_bounds__(64) void k_e8_chunks(int64_t B, int64_t N, int64_t K, int R, const double *__restrict__ t,
+                                                  int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
+                                                  const double *__restrict__ a, const double *__restrict__ U,
+                                                  const double *__restrict__ V, const double *__restrict__ yv,
+                                                  double *__restrict__ elems) {
+  const int lane = threadIdx.x, j = lane & 7;
+  int64_t g = (int64_t)blockIdx.x * 8 + (lane >> 3);   // chunk of this group, all series flattened
+  const bool inr = g < B * K;
+  if (!inr) g = B * K - 1;
+  const int64_t b = g / K, k = g - b * K, s = k * R;
+  const int len = (int)((s + R < N ? s + R : N) - s);
+  const double cj = c[b * c_bs + j];
+  const double *tb = t + b * t_bs, *ab = a + b * N, *Ub = U + b * N * 8, *Vb = V + b * N * 8, *yb = VEC ? yv + b * N : nullptr;
+  double AX[8], GX[8], QX[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { AX[q] = q == 0 ? 1.0 : 0.0; GX[q] = 0.0; QX[q] = 0.0; }
+  double gj = 0.0, hj = 0.0, q0 = 0.0, prod = 1.0;
+  int eacc = 0;
+  bool failed = false;
+  // the next row's inputs, one row ahead
+  double uX[8], vj, an, yn = 0.0, tn = tb[s], tn1;
+  auto fetch = [&](int r, double (&u)[8], double &v, double &av, double &y, double &t1) {
+    const int64_t n = s + (r < len ? r : len - 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = Ub[n * 8 + (j ^ q)];
+    v = Vb[n * 8 + j];
+    av = ab[n];
+    if (VEC) y = yb[n];
+    t1 = tb[n + 1 < N ? n + 1 : n];
+  };
+  fetch(0, uX, vj, an, yn, tn1);
+#pragma unroll 1
+  for (int r = 0; r < len; ++r) {
+    double u[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) u[q] = uX[q];
+    const double v = vj, av = an, y = yn, t1 = tn1;
+    const int64_t n = s + r;
+    fetch(r + 1, uX, vj, an, yn, tn1);
+    double tau = 0.0, rr = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { tau = fma(u[q], GX[q], tau); rr = fma(u[q], AX[q], rr); }   // (u T)_j, (u A)_j
+    double dsum = tau * u[0], zsum = VEC ? u[0] * gj : 0.0;
+    if (VEC) gsum2<8>(dsum, zsum); else dsum = gsum<8>(dsum);
+    const double d = av - dsum;                              // forward.hpp:127
+    const double rd = rcp_nr(d);
+    failed = failed || (n > 0 && !(d > 0.0));                // forward.hpp:128
+    const double w = (v - tau) * rd;                         // forward.hpp:131
+    prod *= d;
+    if (r & 1) { int ex; prod = frexp(prod, &ex); eacc += ex; }
+    double rX[8];
+    xgather_dpp<8>(rr, nullptr, lane, rX);
+    const double rjd = rr * rd;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) QX[q] = fma(rX[q], rjd, QX[q]);   // Q += r^T r / d
+    double z0 = 0.0;
+    if (VEC) {
+      z0 = y - zsum;                                         // internal.hpp:144
+      const double z0d = z0 * rd;
+      q0 = fma(z0, z0d, q0);
+      hj = fma(z0d, rr, hj);
+    }
+    if (n + 1 < N) {   // on to row n + 1 (forward.hpp:115-123, internal.hpp:140-143)
+      const double p = exp_decay(cj * (tn - t1));
+      double wX[8], pX[8];
+      xgather_dpp<8>(w, nullptr, lane, wX);
+      xgather_dpp<8>(p, nullptr, lane, pX);
+      const double dw = d * w;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        GX[q] = (pX[q] * p) * fma(wX[q], dw, GX[q]);         // P (T + d w^T w) P
+        AX[q] = pX[q] * fma(-wX[q], rr, AX[q]);              // P (I - w^T u) A
+      }
+      if (VEC) gj = p * fma(w, z0, gj);
+    }
+    tn = t1;
+  }
+  if (!inr) return;
+  double *rec = elems + (size_t)g * ElemIO<8>::REC;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = j ^ q;
+    rec[kE8A + i * 8 + j] = AX[q];
+    if (i <= j) { rec[kE8G + sidx(8, i, j)] = GX[q]; rec[kE8Q + sidx(8, i, j)] = QX[q]; }
+  }
+  rec[kE8g + j] = gj; rec[kE8h + j] = hj;
+  if (j == 0) {
+    int ex;
+    const double pr = frexp(prod, &ex);
+    rec[kE8q0] = q0;
+    rec[kE8prod] = failed ? __longlong_as_double(0x7ff8000000000000ll) : pr;
+    rec[kE8ex] = (double)(eacc + ex);
+  }
+}
+
 // grid (ceil(Kin / span), B): workgroup x of series b reduces elements span x .. of `in` ([series][Kin] records) to ONE: written
 // to `out` ([series][gridDim.x] records) or -- when it is the only workgroup of its series -- turned into ll (numpy.py:84-109).
 // `scr`: e8_level_records(span) records per workgroup: the levels in between, back to back, and the workgroup's own final
@@ -973,9 +1075,11 @@ __global__ __launch_bounds__(kE8Waves * 64) void k_e8_tree(int64_t N, int64_t Ki
     if (threadIdx.x == 0) {
       const double prod = dst_final[kE8prod], q0 = dst_final[kE8q0], ex = dst_final[kE8ex];
       const double logdet = log(prod) + ex * 0.693147180559945309417;
-      ll[b] = -0.5 * (logdet + q0 + (double)N * 1.83787706640934548356);
-      flag[b] = 0;
-      if (!(logdet == logdet) || !(q0 == q0)) {   // left to the row-by-row kernel behind the gate
+      if (ll) {   // (nullptr: the chunk-start states of `factor` -- matrices only, the vectors of the records are junk)
+        ll[b] = -0.5 * (logdet + q0 + (double)N * 1.83787706640934548356);
+        flag[b] = 0;
+      }
+      if (!(logdet == logdet) || (ll && !(q0 == q0))) {   // left to the row-by-row kernel behind the gate
         atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
         atomicMax(guard + 1, (unsigned long long)__double_as_longlong(INFINITY));
       }
@@ -988,6 +1092,8 @@ __host__ inline int chunk_rows8(int64_t B, int64_t N) {
     if (B * ((N + R - 1) / R) <= 65536) return R;
   return 64;
 }
+// chunk pass at width 8 with the element spread over the lanes of a group (k_e8_chunks) or in one lane (k_tp_onepass<8, 2>)
+static bool e8_group_chunks() { return !(opt::has(opt::k_e8_group_chunks) && opt::ival(opt::k_e8_group_chunks) == 0); }
 struct E8Plan {
   int R, span;
   int64_t K, blocks;
@@ -1014,8 +1120,12 @@ inline int run8(int64_t B, int64_t N, const double *t, int64_t t_bs, const doubl
   constexpr size_t REC = ElemIO<8>::REC;
   if (hipMemsetAsync(guard, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) return C2_ERR_HIP;
   const dim3 gc((unsigned)((p.K + kThreads - 1) / kThreads), (unsigned)B);
-  hipLaunchKernelGGL((k_tp_onepass<8, 2>), gc, dim3(kThreads), 0, s, B, N, p.K, p.R, t, t_bs, c, c_bs, a, U, V, y, work + p.rec0, ll,
-                     flag, guard);
+  if (e8_group_chunks())
+    hipLaunchKernelGGL((k_e8_chunks<true>), dim3((unsigned)((B * p.K + 7) / 8)), dim3(64), 0, s, B, N, p.K, p.R, t, t_bs, c, c_bs, a, U,
+                       V, y, work + p.rec0);
+  else
+    hipLaunchKernelGGL((k_tp_onepass<8, 2>), gc, dim3(kThreads), 0, s, B, N, p.K, p.R, t, t_bs, c, c_bs, a, U, V, y, work + p.rec0, ll,
+                       flag, guard);
   const double *in = work + p.rec0;
   int64_t Kin = p.K;
   double *pong[2] = {work + p.rec1, work + p.rec1 + (size_t)B * (size_t)p.blocks * REC};
@@ -1027,6 +1137,186 @@ inline int run8(int64_t B, int64_t N, const double *t, int64_t t_bs, const doubl
     if (blocks == 1) break;
     in = pong[it & 1];
     Kin = blocks;
+  }
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// ---- width 8: the EXACT chunk-start states (what `factor`, `factor + S` and the factor stage of the time-parallel gradient
+// start their rows from -- five to eight Newton iterations on those states before round 6).  The tree above is the up-sweep
+// of a scan; its levels stay in the scratch, and a DOWN-sweep hands every node the state its span is entered with:
+//     start(left child) = start(node),     start(right child) = apply(element(left child), start(node))
+// with `apply` the element formula T' = G + A Gt A^T, Gt = T (I - Q T)^-1 = L Ks^-1 L^T (T = L L^T pivoted, Ks symmetric
+// positive definite: as well-conditioned as the factorisation, exact to rounding whatever the span).  One wavefront per
+// application, lane (i, j) <-> matrix entry, as e8_combine; states are packed upper triangles (36 doubles, sidx order).
+constexpr int kE8NS = 36;
+// To <- the state the span of record `r` leaves behind when entered with Tin (nullptr: the zero state).  false: Ks not
+// positive definite (a pivot of the span is not positive when entered with Tin).
+__device__ __forceinline__ bool e8_apply(const double *__restrict__ r, const double *__restrict__ Tin, double *__restrict__ To,
+                                         E8Lds &m, int lane) {
+  const int i = lane >> 3, j = lane & 7, sij = sym(8, i, j);
+  auto mm = [&](const double *X, int xi, int xk, const double *Y, int yk, int yj) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v = fma(X[i * xi + k * xk], Y[k * yk + j * yj], v);
+    return v;
+  };
+  lds_order();
+  m.A2[lane] = r[kE8A + lane]; m.G2[lane] = r[kE8G + sij]; m.Q2[lane] = r[kE8Q + sij];
+  m.Z[lane] = Tin ? Tin[sij] : 0.0;
+  double tol = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {   // T = L L^T, outer-product Cholesky with diagonal pivoting (see `posterior`)
+    lds_order();
+    double sp = m.Z[0];
+    int mi = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+      const double dq = m.Z[q * 9];
+      const bool gt = dq > sp;
+      sp = gt ? dq : sp;
+      mi = gt ? q : mi;
+    }
+    if (k == 0) tol = 1e-15 * sp;
+    const bool ok = sp > tol;
+    const double inv = ok ? 1.0 / sqrt(sp) : 0.0;
+    const double li = m.Z[i * 8 + mi] * inv, lj = m.Z[j * 8 + mi] * inv, own = m.Z[lane];
+    lds_order();
+    m.Z[lane] = fma(-li, lj, own);
+    if (j == k) m.L[lane] = li;
+  }
+  lds_order();
+  m.X[lane] = mm(m.Q2, 8, 1, m.L, 8, 1);                                  // X = Q L
+  lds_order();
+  m.Ks[lane] = (i == j ? 1.0 : 0.0) - mm(m.L, 1, 8, m.X, 8, 1);           // Ks = I - L^T X
+  bool good = true;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {   // Ks <- Ks^-1 (Gauss-Jordan; the pivots are positive <=> the span's pivots are)
+    lds_order();
+    const double p = m.Ks[k * 9], rkj = m.Ks[k * 8 + j], cik = m.Ks[i * 8 + k], own = m.Ks[lane];
+    good = good && p > 0.0;
+    const double ip = 1.0 / p;
+    lds_order();
+    m.Ks[lane] = (i == k && j == k) ? ip : (i == k ? rkj * ip : (j == k ? -cik * ip : fma(-cik * ip, rkj, own)));
+  }
+  lds_order();
+  m.Z[lane] = mm(m.Ks, 8, 1, m.L, 1, 8);                                  // Z = Ks^-1 L^T
+  lds_order();
+  m.Gt[lane] = mm(m.L, 8, 1, m.Z, 8, 1);                                  // Gt = L Z
+  lds_order();
+  m.X[lane] = mm(m.A2, 8, 1, m.Gt, 8, 1);                                 // A Gt
+  lds_order();
+  const double Tn = m.G2[lane] + mm(m.X, 8, 1, m.A2, 1, 8);               // T' = G + A Gt A^T
+  if (i <= j) To[sij] = good ? Tn : __longlong_as_double(0x7ff8000000000000ll);
+  return good;
+}
+// The down-sweep of ONE launch of k_e8_tree (same grid, same `in`, `span`, `scr`).  Tin: the start state of every workgroup's
+// span ([series][gridDim.x] packed states; nullptr: zero -- the launch whose single workgroup covered the series); Tout: the
+// start state of every input element ([series][Kin]); tscr: e8_level_records(span) packed states per workgroup.
+__global__ __launch_bounds__(kE8Waves * 64) void k_e8_down(int64_t Kin, int span, const double *__restrict__ in,
+                                                            const double *__restrict__ scr, const double *__restrict__ Tin,
+                                                            double *__restrict__ Tout, double *__restrict__ tscr,
+                                                            unsigned long long *__restrict__ guard) {
+  constexpr int REC = ElemIO<8>::REC;
+  __shared__ E8Lds lds[kE8Waves];
+  __shared__ int n_of[12], off_of[12];   // nodes of level l (0: the inputs), offset of level l >= 1 in the level scratch
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t b = blockIdx.y, first = (int64_t)blockIdx.x * span, wg = b * gridDim.x + blockIdx.x;
+  const int n0 = (int)((Kin - first) < span ? (Kin - first) : span);
+  const int stride = e8_level_records(span);
+  const double *src0 = in + (size_t)(b * Kin + first) * REC, *lvl = scr + (size_t)wg * (size_t)stride * REC;
+  double *st = tscr + (size_t)wg * (size_t)stride * kE8NS, *out0 = Tout + (size_t)(b * Kin + first) * kE8NS;
+  const double *tin = Tin ? Tin + (size_t)wg * kE8NS : nullptr;
+  int L = 0;
+  if (threadIdx.x == 0) {
+    int n = n0, off = 0, l = 0;
+    n_of[0] = n0; off_of[0] = 0;
+    while (n > 1) { const int nn = (n + 1) >> 1; ++l; n_of[l] = nn; off_of[l] = off; off += nn; n = nn; }
+    n_of[11] = l;
+  }
+  __syncthreads();
+  L = n_of[11];
+  bool good = true;
+  if (L == 0) {   // one element: its start state is the workgroup's
+    if (w == 0 && lane < kE8NS) out0[lane] = tin ? tin[lane] : 0.0;
+    return;
+  }
+  // level l + 1 -> level l, from the top (one node, state tin) down to the inputs
+  for (int l = L - 1; l >= 0; --l) {
+    const int nl = n_of[l], np = n_of[l + 1];
+    const double *el = l == 0 ? src0 : lvl + (size_t)off_of[l] * REC;              // elements of level l
+    double *sl = l == 0 ? out0 : st + (size_t)off_of[l] * kE8NS;                   // their start states
+    const double *sp = (l + 1 == L) ? tin : st + (size_t)off_of[l + 1] * kE8NS;    // the parents' (top: the workgroup's)
+    for (int p = w; p < np; p += kE8Waves) {
+      const double *ps = sp ? sp + (size_t)((l + 1 == L) ? 0 : p) * kE8NS : nullptr;
+      if (lane < kE8NS) sl[(size_t)(2 * p) * kE8NS + lane] = ps ? ps[lane] : 0.0;
+      if (2 * p + 1 < nl)
+        good = e8_apply(el + (size_t)(2 * p) * REC, ps, sl + (size_t)(2 * p + 1) * kE8NS, lds[w], lane) && good;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (!good && lane == 0) atomicMax(guard, (unsigned long long)__double_as_longlong(INFINITY));
+}
+struct E8Launch { int64_t Kin, blocks; int span; size_t in, out, scr, tscr, T; };   // offsets in doubles
+struct E8StatesPlan {
+  int R, n;
+  int64_t K;
+  E8Launch l[8];
+  size_t rec0, total;
+};
+// chunks of R rows (the caller's: the chunk length of the kernels that consume the states)
+inline E8StatesPlan e8_states_plan(int64_t B, int64_t N, int R) {
+  constexpr size_t REC = ElemIO<8>::REC;
+  E8StatesPlan p;
+  p.R = R; p.K = (N + R - 1) / R; p.n = 0;
+  p.rec0 = 0;
+  size_t at = (size_t)B * (size_t)p.K * REC;
+  int64_t Kin = p.K;
+  size_t in = p.rec0;
+  for (;;) {
+    E8Launch &q = p.l[p.n];
+    q.Kin = Kin;
+    q.span = B * ((Kin + 63) / 64) <= 256 ? 64 : 512;
+    if ((int64_t)q.span > Kin) q.span = Kin > 1 ? (int)Kin : 1;
+    q.blocks = (Kin + q.span - 1) / q.span;
+    const size_t lv = (size_t)B * (size_t)q.blocks * (size_t)e8_level_records(q.span);
+    q.in = in;
+    q.out = at; at += (size_t)B * (size_t)q.blocks * REC;
+    q.scr = at; at += lv * REC;
+    q.tscr = at; at += lv * kE8NS;
+    q.T = at; at += p.n == 0 ? 0 : (size_t)B * (size_t)Kin * kE8NS;   // (launch 0 writes the caller's array)
+    ++p.n;
+    if (q.blocks == 1 || p.n == 8) break;
+    in = q.out; Kin = q.blocks;
+  }
+  p.total = at;
+  return p;
+}
+// X[b][k][36] <- the state chunk k of series b is entered with (k = 0: zero).  `guard`: raised (+inf) when a pivot is not
+// positive / something is not finite -- the caller's row-by-row kernel behind it.
+inline int run8_states(int64_t B, int64_t N, int R, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                       const double *a, const double *U, const double *V, double *X, double *work, unsigned long long *guard,
+                       hipStream_t s) {
+  const E8StatesPlan p = e8_states_plan(B, N, R);
+  if (p.l[p.n - 1].blocks != 1 || B > 65535) return C2_ERR_UNSUPPORTED;
+  const dim3 gc((unsigned)((p.K + kThreads - 1) / kThreads), (unsigned)B);
+  if (e8_group_chunks())
+    hipLaunchKernelGGL((k_e8_chunks<false>), dim3((unsigned)((B * p.K + 7) / 8)), dim3(64), 0, s, B, N, p.K, R, t, t_bs, c, c_bs, a,
+                       U, V, (const double *)nullptr, work + p.rec0);
+  else   // (the records' vectors are computed from `a` in place of y: finite junk nobody reads)
+    hipLaunchKernelGGL((k_tp_onepass<8, 2>), gc, dim3(kThreads), 0, s, B, N, p.K, R, t, t_bs, c, c_bs, a, U, V, a, work + p.rec0,
+                       (double *)nullptr, (int32_t *)nullptr, guard);
+  for (int i = 0; i < p.n; ++i) {
+    const E8Launch &q = p.l[i];
+    hipLaunchKernelGGL(k_e8_tree, dim3((unsigned)q.blocks, (unsigned)B), dim3(kE8Waves * 64), 0, s, N, q.Kin, q.span,
+                       (const double *)(work + q.in), work + q.out, work + q.scr, (double *)nullptr, (int32_t *)nullptr, guard);
+  }
+  for (int i = p.n - 1; i >= 0; --i) {
+    const E8Launch &q = p.l[i];
+    const double *Tin = i == p.n - 1 ? nullptr : work + p.l[i + 1].T;
+    hipLaunchKernelGGL(k_e8_down, dim3((unsigned)q.blocks, (unsigned)B), dim3(kE8Waves * 64), 0, s, q.Kin, q.span,
+                       (const double *)(work + q.in), (const double *)(work + q.scr), Tin, i == 0 ? X : work + q.T,
+                       work + q.tscr, guard);
   }
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
@@ -1688,6 +1978,16 @@ size_t c2_internal_loglik_timepar_doubles(int64_t B, int64_t N, int64_t J) {
   if (J != 4 && J != 2) return 0;
   const size_t R = (size_t)c2tp::chunk_rows(N), K = ((size_t)N + R - 1) / R, gx = (K + c2tp::kThreads - 1) / c2tp::kThreads;
   return gx <= 1 ? 2 : (size_t)(J == 4 ? c2tp::ElemIO<4>::N_ : c2tp::ElemIO<2>::N_) * (size_t)B * gx;
+}
+// Width 8: exact chunk-start states for chunks of R rows (run8_states); scratch in doubles; X: (B, K, 36) packed upper triangles.
+size_t c2_internal_e8_states_doubles(int64_t B, int64_t N, int64_t R) {
+  return c2tp::e8_states_plan(B, N, (int)R).total;
+}
+int c2_internal_e8_states(int64_t B, int64_t N, int64_t R, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                          const double *a, const double *U, const double *V, double *X, double *work,
+                          unsigned long long *guard, c2_stream_t stream) {
+  if (R != 16 && R != 32 && R != 64) return C2_ERR_UNSUPPORTED;
+  return c2tp::run8_states(B, N, (int)R, t, t_bs, c, c_bs, a, U, V, X, work, guard, (hipStream_t)stream);
 }
 // Forward log-likelihood, time-parallel.  `guard` (two device words, zeroed here): a failed factorisation (or a NaN) raises
 // both; the caller launches the ordinary kernel behind it with `guard + 1` as its gate.

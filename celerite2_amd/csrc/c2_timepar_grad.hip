@@ -1232,7 +1232,12 @@ __device__ __forceinline__ double newton_half_tol(const unsigned long long *gate
   }
   return 0.5 * tol;
 }
-template <int J>
+// SCAN (width 8, round 6): X holds the EXACT start states (run8_states): no propagator, no end states stored -- the end state
+// of the chunk is compared here with the start state its successor was given, the mismatch (relative to sqrt(S_ii S_jj), S_ii
+// the largest of the chunk's start state, its end state and the successor's start state: behind a gap in time the state
+// itself is ~0) goes to `word` in units of half of kE8CheckTol.
+constexpr double kE8CheckTol = 1e-12;   // rounding leaves 1e-15 .. 3e-14 (tools/e8_words.py); anything beyond is not rounding
+template <int J, bool SCAN = false>
 __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int64_t K, const double *__restrict__ t,
                                                        int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                        const double *__restrict__ a, const double *__restrict__ U,
@@ -1304,17 +1309,37 @@ __global__ __launch_bounds__(kWave) void k_newton_pass(int64_t B, int64_t N, int
           S[sidx(J, i, j)] = fma(dwp, w[j] * p[j], S[sidx(J, i, j)] * (p[i] * p[j]));   // (S + d w_i w_j) p_i p_j
       }
       // M <- P (I - w u^T) M
+      if constexpr (!SCAN) {
 #pragma unroll
-      for (int j = 0; j < J; ++j) {
-        double um = 0.0;
+        for (int j = 0; j < J; ++j) {
+          double um = 0.0;
 #pragma unroll
-        for (int l = 0; l < J; ++l) um = fma(u[l], M[l][j], um);
+          for (int l = 0; l < J; ++l) um = fma(u[l], M[l][j], um);
 #pragma unroll
-        for (int i = 0; i < J; ++i) M[i][j] = fma(-w[i], um, M[i][j]) * p[i];
+          for (int i = 0; i < J; ++i) M[i][j] = fma(-w[i], um, M[i][j]) * p[i];
+        }
       }
     }
   }
-  if (G.len > 0) {
+  if constexpr (SCAN) {
+    double worst = 0.0;
+    if (G.len > 0 && G.k + 1 < K) {
+      const double *x0 = X + G.g * NS, *x1 = X + (G.g + 1) * NS;
+      double dg[J];
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+        dg[i] = fmax(fmax(fabs(x1[sidx(J, i, i)]), fabs(S[sidx(J, i, i)])), fabs(x0[sidx(J, i, i)]));
+#pragma unroll
+      for (int i = 0; i < J; ++i)
+#pragma unroll
+        for (int j = i; j < J; ++j) {
+          const double r = fabs(S[sidx(J, i, j)] - x1[sidx(J, i, j)]) / fmax(sqrt(dg[i] * dg[j]), 1e-300);
+          worst = (r == r) ? fmax(worst, r) : __builtin_huge_val();
+        }
+    }
+    if (G.len > 0 && G.k == 0) flag[G.b] = 0;
+    publish_max(word, worst * (2.0 / kE8CheckTol));
+  } else if (G.len > 0) {
 #pragma unroll
     for (int e = 0; e < NS; ++e) E[G.g * NS + e] = S[e];
 #pragma unroll
@@ -1812,12 +1837,31 @@ extern "C" int C2TG_NAME(c2_internal_loglik_grad_timepar)(int64_t B, int64_t N, 
 // factor (d, W) by Newton iterations on the chunk start states (widths 1 .. 8).  work: c2_internal_factor_iter_doubles;
 // its first kNewtonHdr words are the iterations' words (updates, then conditioning) -- the caller launches its row-by-row
 // kernel behind `*last_word`.
+extern "C" size_t c2_internal_e8_states_doubles(int64_t B, int64_t N, int64_t R);
+extern "C" int c2_internal_e8_states(int64_t B, int64_t N, int64_t R, const double *t, int64_t t_bs, const double *c,
+                                     int64_t c_bs, const double *a, const double *U, const double *V, double *X, double *work,
+                                     unsigned long long *guard, c2_stream_t stream);
 extern "C" size_t C2TG_NAME(c2_internal_factor_iter_doubles)(int64_t B, int64_t N, int64_t J) {
   if (J < 1 || J > 8) return 0;
   const size_t K = (size_t)((N + kRows - 1) / kRows);
   size_t n = (size_t)kNewtonHdr + (size_t)B * K * (size_t)(2 * (J * (J + 1) / 2) + J * J);
-  if ((int64_t)K >= kTwoLevelMin) n += (size_t)B * K * (size_t)(2 * J * J) + (size_t)B * ((K + kBlock - 1) / kBlock + 1) * (size_t)(J * J);
-  return n;
+  size_t extra = 0;
+  if ((int64_t)K >= kTwoLevelMin) extra = (size_t)B * K * (size_t)(2 * J * J) + (size_t)B * ((K + kBlock - 1) / kBlock + 1) * (size_t)(J * J);
+  if (J == 8) {   // the scan of the chunk elements overlays the two-level chains' arrays (one or the other runs)
+    const size_t sc = c2_internal_e8_states_doubles(B, N, kRows);
+    extra = sc > extra ? sc : extra;
+  }
+  return n + extra;
+}
+// Width 8 (round 6): the chunk start states EXACT from the scanned chunk elements (c2_timepar.hip: run8_states -- the
+// elements' tree as an up-sweep, a down-sweep of `apply`s), then ONE pass for d, W.  The pass's end state of every chunk is
+// compared with the start state its successor was given (k_newton_pass<J, true>: the residual a Newton iteration would start from) and
+// the mismatch, in units of half of kE8CheckTol, goes into the word the caller's row-by-row kernel is gated on.
+// mismatch of a chunk boundary relative to sqrt(X_ii X_jj): rounding leaves 1e-15 .. 3e-14 (kappa up to 5e3, see the floor of
+// the Newton updates above); anything beyond 1e-12 is not rounding
+static bool use_e8_states(int64_t B, int64_t N) {
+  if (opt::has(opt::k_factor_scan8)) return opt::ival(opt::k_factor_scan8) != 0;
+  return B <= 65535;
 }
 template <int J>
 static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
@@ -1831,6 +1875,19 @@ static int run_factor_iter(int64_t B, int64_t N, const double *t, int64_t t_bs, 
   double *X = work + kNewtonHdr, *E = X + BK * NS, *Phi = E + BK * NS;
   if (hipMemsetAsync(work, 0, ((size_t)kNewtonHdr + BK * NS) * sizeof(double), s) != hipSuccess) return C2_ERR_HIP;
   const dim3 grid((unsigned)((B * K + kWave - 1) / kWave));
+  if constexpr (J == 8) {
+    if (K >= 2 && use_e8_states(B, N)) {
+      double *scan = Phi + BK * J * J;   // behind the pass's arrays (c2_internal_factor_iter_doubles)
+      const int e = c2_internal_e8_states(B, N, kRows, t, t_bs, c, c_bs, a, U, V, X, scan, words + 1, (c2_stream_t)s);
+      if (e == C2_OK) {
+        hipLaunchKernelGGL((k_newton_pass<J, true>), grid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, d, W, flag,
+                           (const double *)X, E, Phi, (const unsigned long long *)nullptr, words + 1, words + (kNewtonMax + 2) + 1);
+        *last_word = words + 1;
+        return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+      }
+      if (e != C2_ERR_UNSUPPORTED) return e;
+    }
+  }
   for (int p = 1; p <= P; ++p) {
     const unsigned long long *gate = p >= 2 ? words + p - 1 : nullptr;
     hipLaunchKernelGGL((k_newton_pass<J>), grid, dim3(kWave), 0, s, B, N, K, t, t_bs, c, c_bs, a, U, V, d, W, flag,

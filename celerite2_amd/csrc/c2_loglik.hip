@@ -1308,10 +1308,13 @@ static bool use_timepar(int64_t B, int64_t N, int64_t J, bool loglik = false) {
     // tools/onepass_grid.py 8): 0.10 + 4.7e-6 per combination (B x chunks) + 9e-8 per row against 0.29e-3 per row of the
     // longest series row by row (at least 0.085): 1 x 4096 0.29 vs 1.19 (Newton iterations: 0.56), 1024 x 4096 0.78 vs 1.21,
     // 2048 x 4096 1.52 vs 1.21, 256 x 1000 0.18 vs 0.30, 1024 x 1000 0.49 vs 0.30, 1 x 256 0.097 vs 0.089
+    // round 6 (chunk pass with the element spread over a group's lanes, tools/scan8_grid.py): 0.05 + 4.5e-6 per chunk + 5e-8 per
+    // row: 1 x 256 0.056 vs 0.078, 256 x 512 0.088 vs 0.150, 512 x 1024 0.225 vs 0.293, 1024 x 1024 0.441 vs 0.295,
+    // 1024 x 2048 0.510 vs 0.887, 1024 x 4096 0.649 vs 1.162, 2048 x 4096 1.26 vs 1.17
     int R = 16;
     while (R < 64 && B * ((N + R - 1) / R) > 65536) R *= 2;   // (chunk_rows8 of c2_timepar.hip)
-    const double el = 0.10 + 4.7e-6 * (double)(B * ((N + R - 1) / R)) + 9e-8 * (double)B * (double)N;
-    const double rows8 = 0.29e-3 * (double)N > 0.085 ? 0.29e-3 * (double)N : 0.085;
+    const double el = 0.05 + 4.5e-6 * (double)(B * ((N + R - 1) / R)) + 5e-8 * (double)B * (double)N;
+    const double rows8 = 0.29e-3 * (double)N > 0.078 ? 0.29e-3 * (double)N : 0.078;
     return el * (double)opt::ival(opt::k_timepar_elements_bias) < rows8 * 100.0;
   }
   // Chunk elements (c2_timepar.hip): a wavefront per 4096 rows of a series, 64 chunks of R = 16 / 32 / 64 rows in lock step
@@ -1440,7 +1443,14 @@ static bool use_timepar_grad(int64_t B, int64_t N, int64_t J) {
                                    : (J <= 2 ? 512 : (J >= 7 ? opt::ival(opt::k_timepar_grad_min_rows) : 768));
   // (widths up to 4 would keep winning a little further -- 768 x 4096 at J = 4 2.97 -> 1.46 ms, 1024 x 4096 2.98 -> 2.44 ms
   // -- but not by enough to move the limit)
-  return N >= min_rows && B * ((N + 63) / 64) <= opt::ival(opt::k_timepar_grad_max_chunks);
+  if (!(N >= min_rows && B * ((N + 63) / 64) <= opt::ival(opt::k_timepar_grad_max_chunks))) return false;
+  if (J >= 7 && !handful) {
+    // widths 7, 8 beyond a handful of series (tools/scan8_grid.py, round 6; ms parallel along time / row by row): 256 x 1024
+    // 0.64 / 0.81, 512 x 1024 1.04 / 0.81, 512 x 2048 1.28 / 1.61, 1024 x 2048 2.58 / 1.62, 512 x 4096 2.53 / 3.21,
+    // 1024 x 4096 6.0 / 3.23: 0.40 ms + 6.5e-5 per 64-row chunk against 0.78 us per row
+    return 0.40 + 6.5e-5 * (double)(B * ((N + 63) / 64)) < 0.78e-3 * (double)N;
+  }
+  return true;
 }
 // widths 1 .. 8: `factor` by Newton iterations on the chunk start states (c2_timepar_grad.hip), the row-by-row kernel
 // gated behind; the forward-only log-likelihood composed from it
@@ -1629,11 +1639,21 @@ int c2_internal_factor_fused_ws(int64_t B, int64_t N, int64_t J, const double *t
   const bool forced_iter = opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) != 0;
   const bool scan_widths = (J == 2 || J == 4) && !forced_iter;   // chunk-start states by scanned elements (c2_timepar.hip)
   const bool long_enough = N >= 2048 && B * ((N + 63) / 64) <= 32768;
-  const bool newton = scan_widths ? false
-                      : allow_timepar == 2
-                          ? (J >= 1 && J <= 8 && N >= 2 && (forced_iter || long_enough) &&
-                             !(opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) == 0))
-                          : use_factor_iter(B, N, J);
+  bool newton = scan_widths ? false
+                : allow_timepar == 2
+                    ? (J >= 1 && J <= 8 && N >= 2 && (forced_iter || long_enough) &&
+                       !(opt::has(opt::k_factor_iter) && opt::ival(opt::k_factor_iter) == 0))
+                    : use_factor_iter(B, N, J);
+  if (J == 8 && !opt::has(opt::k_factor_iter) && !(opt::has(opt::k_lanes) && opt::ival(opt::k_lanes) != 0) &&
+      !(opt::has(opt::k_factor_scan8) && opt::ival(opt::k_factor_scan8) == 0) && B <= 65535) {
+    // width 8, round 6: the chunk start states come from the scanned chunk elements, not from Newton iterations -- 0.10 ms +
+    // 1.7e-5 per 64 rows against 0.30 us per row walked one by one (tools/scan8_grid.py, ms scan / rows: 1 x 384 0.115 /
+    // 0.119, 1 x 1024 0.164 / 0.308, 1 x 4096 0.192 / 1.213, 256 x 512 0.140 / 0.158, 512 x 1024 0.252 / 0.309, 512 x 4096
+    // 0.590 / 1.216, 1024 x 1024 0.403 / 0.310, 1024 x 2048 0.652 / 0.618, 1024 x 4096 1.198 / 1.223)
+    const double scan_ms = 0.10 + 1.7e-5 * (double)(B * ((N + 63) / 64));
+    const double rows_ms = 0.30e-3 * (double)N > 0.08 ? 0.30e-3 * (double)N : 0.08;
+    newton = scan_ms < rows_ms;
+  }
   if (allow_timepar && d != a && W != V && newton) {
     const size_t nd = c2_internal_factor_iter_doubles(B, N, J);
     void *tmp = nullptr;

@@ -25,7 +25,7 @@ SYMBOLS = [
     "c2h_factor", "c2h_solve_lower", "c2h_solve_upper", "c2h_matmul_lower", "c2h_matmul_upper",
     "c2h_general_matmul_lower", "c2h_general_matmul_upper", "c2h_factor_rev",
     "c2h_solve_lower_rev", "c2h_solve_upper_rev", "c2h_matmul_lower_rev", "c2h_matmul_upper_rev",
-    "c2h_get_celerite_matrices",
+    "c2h_get_celerite_matrices", "c2h_release_thread_cache",
     "c2_set_option", "c2_get_option", "c2_option_count", "c2_option_info", "c2_options_reload_env",
 ]
 

@@ -337,6 +337,11 @@ int c2h_get_celerite_matrices(int64_t N, int64_t Jr, int64_t Jc, const double *a
                               const double *bc, const double *dc, const double *x, const double *diag, double *a,
                               double *U, double *V);
 
+/* The c2h_* entry points stage their arguments through a per-thread device arena + pinned bounce buffer that is kept
+ * between calls (memory beyond 256 MiB is given back when the call returns).  This releases everything the CALLING
+ * thread holds; its next c2h_* call allocates again.  (The reference is stateless: nothing to replace.) */
+void c2h_release_thread_cache(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ SYMBOLS = [
     "c2_factor", "c2_solve_lower", "c2_solve_upper", "c2_matmul_lower", "c2_matmul_upper",
     "c2_general_matmul_lower", "c2_general_matmul_upper", "c2_factor_rev",
     "c2_solve_lower_rev", "c2_solve_upper_rev", "c2_matmul_lower_rev", "c2_matmul_upper_rev",
-    "c2_get_celerite_matrices", "c2_kernel_values", "c2_loglik", "c2_loglik_grad_workspace_bytes", "c2_loglik_grad", "c2_condition", "c2_dot_tril",
+    "c2_get_celerite_matrices", "c2_kernel_values", "c2_colsumsq_over_d", "c2_loglik", "c2_loglik_grad_workspace_bytes", "c2_loglik_grad", "c2_condition", "c2_dot_tril",
     "c2_kron_loglik_workspace_bytes", "c2_kron_loglik", "c2_kron_loglik_grad",
     "c2_loglik_terms_workspace_bytes", "c2_loglik_terms", "c2_loglik_terms_grad",
     "c2h_factor", "c2h_solve_lower", "c2h_solve_upper", "c2h_matmul_lower", "c2h_matmul_upper",

@@ -1156,6 +1156,106 @@ __global__ __launch_bounds__(256) void k_kernel_values(int64_t B, int64_t N, int
   K[g] = k;
 }
 
+// The same on TILES (round 6): a workgroup fills 32 rows x 64 columns.  cos / sin of a complex term's phase is taken once per
+// tile ROW and once per COLUMN relative to the tile's first row time t0 -- phi_n = dc (t1[n] - t0), psi_m = dc (t2[m] - t0) --
+// and combined per entry by the angle-addition formulas: cos(dc tau) = cos phi cos psi + sin phi sin psi, sin(dc |tau|) =
+// sgn(tau) (sin phi cos psi - cos phi sin psi), tau = t1[n] - t2[m].  Per entry and term that leaves ONE exponential (the
+// 16-instruction decay kernel) and a handful of multiply-adds instead of an exponential and a sincos (~100 instructions):
+// 64 x 4096 x 256, four terms: 1.04 -> ~0.3 ms.  Phases are differences against t0, so their rounding is that of dc tau itself.
+constexpr int kKvRows = 32, kKvCols = 64;
+__global__ __launch_bounds__(256) void k_kernel_values_tile(int64_t N, int64_t M, int Jr, int Jc, const double *__restrict__ ar,
+                                                            const double *__restrict__ cr, const double *__restrict__ ac,
+                                                            const double *__restrict__ bc, const double *__restrict__ cc,
+                                                            const double *__restrict__ dc, int coef_batched,
+                                                            const double *__restrict__ t1, int64_t t1_bs,
+                                                            const double *__restrict__ t2, int64_t t2_bs, double *__restrict__ K) {
+  extern __shared__ double kv_lds[];   // [Jc][32] cos phi, [Jc][32] sin phi, [32] t1 rows
+  double *cs_n = kv_lds, *sn_n = cs_n + (size_t)Jc * kKvRows, *tn_s = sn_n + (size_t)Jc * kKvRows;
+  const int64_t b = blockIdx.z, n0 = (int64_t)blockIdx.y * kKvRows, m = (int64_t)blockIdx.x * kKvCols + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;   // rows rg * 8 .. rg * 8 + 7 of the tile
+  const int64_t orr = coef_batched ? b * Jr : 0, oc = coef_batched ? b * Jc : 0;
+  const double *t1b = t1 + b * t1_bs, *t2b = t2 + b * t2_bs;
+  const double t0 = t1b[n0];
+  if (threadIdx.x < kKvRows) tn_s[threadIdx.x] = t1b[n0 + threadIdx.x < N ? n0 + threadIdx.x : N - 1];
+  for (int q = threadIdx.x; q < Jc * kKvRows; q += 256) {
+    const int i = q / kKvRows, r = q - i * kKvRows;
+    const double ph = dc[oc + i] * (t1b[n0 + r < N ? n0 + r : N - 1] - t0);
+    double sn, cs;
+    sincos_cw(ph, sn, cs);
+    cs_n[q] = cs; sn_n[q] = sn;
+  }
+  __syncthreads();
+  const bool live = m < M;
+  const double xm = t2b[live ? m : M - 1], dx = xm - t0;
+  double k[8], tau[8], sg[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const double d = tn_s[rg * 8 + r] - xm;
+    tau[r] = fabs(d); sg[r] = d < 0.0 ? -1.0 : 1.0; k[r] = 0.0;
+  }
+  for (int i = 0; i < Jr; ++i) {
+    const double a_ = ar[orr + i], c_ = cr[orr + i];
+    if (c_ >= 0.0) {   // (uniform: a decaying term -- the 16-instruction kernel; a growing one takes the library's exp)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) k[r] = fma(a_, exp_decay(-c_ * tau[r]), k[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) k[r] = fma(a_, exp(-c_ * tau[r]), k[r]);
+    }
+  }
+  for (int i = 0; i < Jc; ++i) {
+    const double a_ = ac[oc + i], b_ = bc[oc + i], c_ = cc[oc + i];
+    double sm, cm;
+    sincos_cw(dc[oc + i] * dx, sm, cm);
+    const double *cr_ = cs_n + (size_t)i * kKvRows + rg * 8, *sr_ = sn_n + (size_t)i * kKvRows + rg * 8;
+    const bool decays = c_ >= 0.0;   // (uniform)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const double cn = cr_[r], sn = sr_[r];
+      const double cosv = fma(cn, cm, sn * sm), sinv = sg[r] * fma(sn, cm, -cn * sm);
+      const double x = -c_ * tau[r];
+      double e;
+      if (decays) e = exp_decay(x); else e = exp(x);
+      k[r] = fma(e, fma(a_, cosv, b_ * sinv), k[r]);
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int64_t n = n0 + rg * 8 + r;
+      if (n < N) K[(b * N + n) * M + m] = k[r];
+    }
+  }
+}
+
+// out[b, m] = sum_n Z[b, n, m]^2 / d[b, n]: the quadratic form of the predictive variance from the LOWER solve alone,
+// diag(Kxs K^-1 Kxs^T)_m = sum_n (L^-1 Kxs^T)_nm^2 / d_n (K = L D L^T; core.py:134-140 reaches the same number through
+// apply_inverse = both solves and a second pass over the two N x M arrays).  One pass over Z: grid (ceil(M / 64), B), the sixteen
+// wavefronts of a workgroup take interleaved rows.
+__global__ __launch_bounds__(1024) void k_colsumsq_over_d(int64_t N, int64_t M, const double *__restrict__ Z,
+                                                          const double *__restrict__ d, double *__restrict__ out) {
+  __shared__ double part[16][64];
+  const int64_t b = blockIdx.y, m = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const double *zb = Z + b * N * M + (m < M ? m : M - 1), *db = d + b * N;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // (four rows in flight per wavefront: the loop is bound by load latency)
+  int64_t n = w;
+  for (; n + 48 < N; n += 64) {
+    const double z0 = zb[n * M], z1 = zb[(n + 16) * M], z2 = zb[(n + 32) * M], z3 = zb[(n + 48) * M];
+    const double d0 = db[n], d1 = db[n + 16], d2 = db[n + 32], d3 = db[n + 48];
+    a0 = fma(z0, z0 / d0, a0); a1 = fma(z1, z1 / d1, a1); a2 = fma(z2, z2 / d2, a2); a3 = fma(z3, z3 / d3, a3);
+  }
+  for (; n < N; n += 16) { const double z = zb[n * M]; a0 = fma(z, z / db[n], a0); }
+  part[w][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (w == 0 && m < M) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += part[q][threadIdx.x];
+    out[b * M + m] = s;
+  }
+}
+
 // Z = Y * sqrt(d)[:, None]   (numpy.py:101)
 __global__ void k_scale_sqrt(int64_t total, int64_t nrhs, const double *d, const double *Y, double *Z) {
   const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1844,9 +1944,27 @@ int c2_kernel_values(int64_t B, int64_t N, int64_t M, int64_t Jr, int64_t Jc, co
   if (B < 1 || N < 1 || M < 1 || Jr < 0 || Jc < 0 || Jr + Jc < 1) return C2_ERR_INVALID;
   if (!t1 || !t2 || !K || (Jr && (!ar || !cr)) || (Jc && (!ac || !bc || !cc || !dc))) return C2_ERR_INVALID;
   const int64_t total = B * N * M;
+  const size_t lds = sizeof(double) * ((size_t)2 * Jc * kKvRows + kKvRows);
+  // tiles of 32 x 64 entries (one sincos per tile row and column instead of one per entry) when there is enough of a grid
+  // to amortise them and the row phases fit LDS; C2_KERNEL_VALUES_TILE=0: the thread-per-entry kernel
+  if (N >= 8 && M >= 8 && B <= 65535 && (N + kKvRows - 1) / kKvRows <= 65535 && lds <= 48 * 1024 &&
+      !(opt::has(opt::k_kernel_values_tile) && opt::ival(opt::k_kernel_values_tile) == 0)) {
+    const dim3 grid((unsigned)((M + kKvCols - 1) / kKvCols), (unsigned)((N + kKvRows - 1) / kKvRows), (unsigned)B);
+    hipLaunchKernelGGL(k_kernel_values_tile, grid, dim3(256), lds, (hipStream_t)stream, N, M, (int)Jr, (int)Jc, ar, cr, ac, bc, cc,
+                       dc, coef_batched, t1, t1_bs, t2, t2_bs, K);
+    return check_launch();
+  }
   if ((total + 255) / 256 > 0x7fffffffLL) return C2_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_kernel_values, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N, M,
                      (int)Jr, (int)Jc, ar, cr, ac, bc, cc, dc, coef_batched, t1, t1_bs, t2, t2_bs, K);
+  return check_launch();
+}
+
+int c2_colsumsq_over_d(int64_t B, int64_t N, int64_t M, const double *Z, const double *d, double *out, c2_stream_t stream) {
+  if (B < 1 || N < 1 || M < 1 || !Z || !d || !out) return C2_ERR_INVALID;
+  if (B > 65535) return C2_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_colsumsq_over_d, dim3((unsigned)((M + 63) / 64), (unsigned)B), dim3(1024), 0, (hipStream_t)stream, N, M, Z, d,
+                     out);
   return check_launch();
 }
 

@@ -145,7 +145,7 @@ class ConditionalDistribution:
 
     def __init__(self, gp, y, t=None, *, include_mean=True, kernel=None):
         self.gp, self.y, self.t, self.include_mean, self.kernel = gp, y, t, include_mean, kernel
-        self._KxsT = self._Kinv_KxsT = self._mean = None
+        self._KxsT = self._Kinv_KxsT = self._Linv_KxsT = self._mean = None
         self._mats2 = self._mats1 = None
         if t is None:
             self._xs = gp._t
@@ -168,9 +168,18 @@ class ConditionalDistribution:
         return self._KxsT
 
     @property
+    def Linv_KxsT(self):  # L^-1 KxsT (K = L D L^T): the lower solve with M right-hand sides, shared by variance and Kinv_KxsT
+        if self._Linv_KxsT is None:
+            gp = self.gp
+            self._Linv_KxsT = ops.solve_lower(gp._t, gp._c, gp._U, gp._W, self.KxsT.contiguous())
+        return self._Linv_KxsT
+
+    @property
     def Kinv_KxsT(self):  # core.py:56-60: apply_inverse on the N x M matrix -- solves with M right-hand sides
         if self._Kinv_KxsT is None:
-            self._Kinv_KxsT = self.gp.apply_inverse(self.KxsT)
+            gp = self.gp
+            z = self.Linv_KxsT / gp._d[..., None]
+            self._Kinv_KxsT = ops.solve_upper(gp._t, gp._c, gp._U, gp._W, z, Z=z)
         return self._Kinv_KxsT
 
     def _do_dot(self, inp, target):
@@ -212,9 +221,18 @@ class ConditionalDistribution:
 
     @property
     def variance(self):  # core.py:134-140 + numpy.py:24-25: k(0) - diag(KxsT' K^-1 KxsT), (B, M)
-        B = self.gp._diag.shape[0]
-        k0 = self._kernel().get_value_device(torch.zeros((B, 1), dtype=torch.float64, device=self.gp._diag.device))
-        return k0 - torch.linalg.vecdot(self.KxsT, self.Kinv_KxsT, dim=1)   # (one pass over the two N x M arrays)
+        # diag(Kxs K^-1 KxsT)_m = sum_n (L^-1 KxsT)_nm^2 / d_n: the lower solve and ONE pass over its result
+        # (ops.colsumsq_over_d) -- the reference's apply_inverse + diagdot (numpy.py:24-25) is both solves and a pass over
+        # two N x M arrays for the same number
+        return self._k0() - ops.colsumsq_over_d(self.Linv_KxsT, self.gp._d)
+
+    def _k0(self):
+        """k(0) = sum ar + sum ac (terms.py:58-79 at tau = 0): a python float, or (B, 1) on the device for per-series coefficients."""
+        co = self._kernel().get_coefficients()
+        if all(v.ndim == 1 for v in co):
+            return float(co[0].sum() + co[2].sum())
+        dev, _ = self._kernel()._dev_coefs(self.gp._diag.device, self.gp._diag.shape[0])
+        return (dev[0].sum(dim=-1) + dev[2].sum(dim=-1))[:, None]
 
     @property
     def covariance(self):  # core.py:142-150: k(xs - xs') - K(xs, t) K^-1 K(t, xs), (B, M, M)

@@ -17,7 +17,7 @@ from . import _lib
 __all__ = [
     "factor", "solve_lower", "solve_upper", "matmul_lower", "matmul_upper", "general_matmul_lower",
     "general_matmul_upper", "factor_rev", "solve_lower_rev", "solve_upper_rev", "matmul_lower_rev",
-    "matmul_upper_rev", "get_celerite_matrices", "kernel_values", "loglik", "loglik_grad", "loglik_grad_workspace", "condition", "dot_tril",
+    "matmul_upper_rev", "get_celerite_matrices", "kernel_values", "colsumsq_over_d", "loglik", "loglik_grad", "loglik_grad_workspace", "condition", "dot_tril",
     "kron_loglik", "kron_loglik_grad", "loglik_terms", "loglik_terms_grad",
 ]
 
@@ -261,6 +261,20 @@ def kernel_values(ar, cr, ac, bc, cc, dc, t1, t2, B=None):
         _i64(_bs(t1, N)), _p(t2), _i64(_bs(t2, M)), _p(K), _stream())
     _lib.check(rc, "kernel_values")
     return K
+
+
+def colsumsq_over_d(Z, d):
+    """out[b, m] = sum_n Z[b, n, m]^2 / d[b, n]  (Z (B, N, M), d (B, N)): the quadratic form of the predictive variance from the
+    lower solve alone (c2_colsumsq_over_d; core.py:134-140)."""
+    if Z.dim() != 3:
+        raise ValueError("Invalid shape: Z (must be (B, N, M))")
+    B, N, M = Z.shape
+    _chk(Z, d)
+    _shape("d", d, (B, N))
+    out = torch.empty((B, M), dtype=torch.float64, device=Z.device)
+    rc = _lib.load().c2_colsumsq_over_d(_i64(B), _i64(N), _i64(M), _p(Z), _p(d), _p(out), _stream())
+    _lib.check(rc, "colsumsq_over_d")
+    return out
 
 
 def _loglik_shapes(B, N, J, t, c, a, V, y):

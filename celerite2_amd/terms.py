@@ -37,25 +37,54 @@ class Term:
         k = np.sum(ar * np.exp(-cr * tau), axis=-1)
         return k + np.sum(np.exp(-cc * tau) * (ac * np.cos(dc * tau) + bc * np.sin(dc * tau)), axis=-1)
 
+    def _dev_coefs(self, device, nb=None):
+        """The six coefficient arrays (+ the interleaved c of terms.py:171-173 as a seventh) as device tensors, ONE upload,
+        cached on the term while the coefficient VALUES stay what they were (parameters are plain attributes a caller may
+        change): a pageable host-to-device copy is a synchronisation, and predict() used to make ten of them per call.
+        Per-series coefficients keep their (B, .) shape; with any of them per-series the shared ones are broadcast to
+        (nb or their own B, .).  Returns (tensors, batched)."""
+        import torch
+
+        coefs = [np.asarray(v, dtype=np.float64) for v in self.get_coefficients()]
+        batched = any(v.ndim == 2 for v in coefs)
+        if batched:
+            B = max([v.shape[0] for v in coefs if v.ndim == 2] + [nb or 0])
+            coefs = [np.broadcast_to(v, (B, v.shape[-1])) if v.ndim == 1 else v for v in coefs]
+        ar, cr, ac, bc, cc, dc = coefs
+        Jr, Jc = ar.shape[-1], ac.shape[-1]
+        c = np.empty(cr.shape[:-1] + (Jr + 2 * Jc,))
+        c[..., :Jr] = cr       # c = [cr, cc0, cc0, cc1, cc1, ...]  (terms.py:171-173)
+        c[..., Jr::2] = cc
+        c[..., Jr + 1::2] = cc
+        host = [np.ascontiguousarray(v) for v in coefs + [c]]
+        key = (str(device), batched)
+        cache = self.__dict__.get("_dev_cache")
+        if cache is not None and cache[0] == key and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(cache[1], host)):
+            return cache[2], batched
+        flat = torch.from_numpy(np.concatenate([h.ravel() for h in host] + [np.zeros(1)])).to(device)
+        out, at = [], 0
+        for h in host:
+            out.append(flat[at:at + h.size].view(h.shape))
+            at += h.size
+        self.__dict__["_dev_cache"] = (key, host, out)
+        return out, batched
+
     def get_value_device(self, tau):
         """k(tau) (terms.py:58-79) on the device: `tau` a float64 tensor whose LEADING axis is the batch (B, ...);
         coefficients shared by the batch or one row per series.  What the conditional distribution needs for its
         cross-covariances `KxsT`, `k(0)` and `k(xs - xs')` (core.py:57-66, 134-150)."""
         import torch
 
-        ar, cr, ac, bc, cc, dc = self.get_coefficients()
+        host = self.get_coefficients()
+        batched = any(np.ndim(v) == 2 for v in host)
+        (ar, cr, ac, bc, cc, dc) = self._dev_coefs(tau.device, tau.shape[0])[0][:6] if batched else host
         tau = tau.abs()
         extra = (1,) * (tau.dim() - 1)
 
-        dev_arrays = {}   # one upload per coefficient ARRAY (not per coefficient and term)
-
-        def co(v, j):   # coefficient j as a tensor broadcastable against tau: () or (B, 1, ..)
-            v = np.asarray(v, dtype=np.float64)
-            if v.ndim == 1:
+        def co(v, j):   # coefficient j broadcastable against tau: a python float (shared) or a (B, 1, ..) device view
+            if not batched:
                 return float(v[j])
-            if id(v) not in dev_arrays:
-                dev_arrays[id(v)] = (v, torch.from_numpy(np.ascontiguousarray(v)).to(tau.device))
-            return dev_arrays[id(v)][1][:, j].reshape((-1,) + extra)
+            return v[:, j].reshape((-1,) + extra)
 
         k = torch.zeros_like(tau)
         for j in range(ar.shape[-1]):
@@ -72,17 +101,8 @@ class Term:
 
         from . import ops
 
-        coefs = self.get_coefficients()
-        batched = any(v.ndim == 2 for v in coefs)
-        nb = max([v.shape[0] for v in coefs if v.ndim == 2] + [0])
-
-        def prep(v):
-            v = np.asarray(v, dtype=np.float64)
-            if batched and v.ndim == 1:
-                v = np.broadcast_to(v, (nb, v.shape[0]))
-            return torch.from_numpy(np.ascontiguousarray(v)).to(t1.device)
-
-        return ops.kernel_values(*[prep(v) for v in coefs], t1.contiguous(), t2.contiguous(), B=B)
+        dev, _ = self._dev_coefs(t1.device, B)
+        return ops.kernel_values(*dev[:6], t1.contiguous(), t2.contiguous(), B=B)
 
     def get_celerite_matrices(self, x, diag):
         """x (N,)|(B,N), diag (B,N) torch float64 device tensors -> (c, a, U, V) device tensors."""
@@ -90,27 +110,9 @@ class Term:
 
         from . import ops
 
-        ar, cr, ac, bc, cc, dc = self.get_coefficients()
-        dev = diag.device
-        batched = any(v.ndim == 2 for v in (ar, cr, ac, bc, cc, dc))
-        B = diag.shape[0]
-
-        def prep(v):
-            v = np.asarray(v, dtype=np.float64)
-            if batched and v.ndim == 1:
-                v = np.broadcast_to(v, (B, v.shape[0]))
-            return torch.from_numpy(np.ascontiguousarray(v)).to(dev)
-
-        Jr, Jc = ar.shape[-1], ac.shape[-1]
-        if batched:
-            cr = np.broadcast_to(cr, (B, Jr)) if cr.ndim == 1 else cr
-            cc = np.broadcast_to(cc, (B, Jc)) if cc.ndim == 1 else cc
-        c = np.empty(cr.shape[:-1] + (Jr + 2 * Jc,))
-        c[..., :Jr] = cr       # c = [cr, cc0, cc0, cc1, cc1, ...]  (terms.py:171-173)
-        c[..., Jr::2] = cc
-        c[..., Jr + 1::2] = cc
-        a, U, V = ops.get_celerite_matrices(prep(ar), prep(ac), prep(bc), prep(dc), x, diag)
-        return prep(c), a, U, V
+        (ar, cr, ac, bc, cc, dc, c), _ = self._dev_coefs(diag.device, diag.shape[0])
+        a, U, V = ops.get_celerite_matrices(ar, ac, bc, dc, x, diag)
+        return c, a, U, V
 
 
 class TermSum(Term):

@@ -188,6 +188,12 @@ int c2_kernel_values(int64_t B, int64_t N, int64_t M, int64_t Jr, int64_t Jc, co
                      const double *ac, const double *bc, const double *cc, const double *dc, int coef_batched,
                      const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, double *K, c2_stream_t stream);
 
+/* out[b, m] = sum_n Z[b, n, m]^2 / d[b, n]  (Z (B,N,M), d (B,N), out (B,M)): the quadratic form of the PREDICTIVE VARIANCE,
+ * core.py:134-140 `kernel.get_value(0) - diagdot(KxsT, Kinv_KxsT)` (numpy.py:24-25), evaluated from the lower solve alone:
+ * with K = L D L^T, diag(Kxs K^-1 Kxs^T)_m = sum_n (L^-1 KxsT)_nm^2 / d_n -- Z = c2_solve_lower(KxsT); the reference reaches
+ * the same number through apply_inverse (both solves) and a second pass over the two N x M arrays. */
+int c2_colsumsq_over_d(int64_t B, int64_t N, int64_t M, const double *Z, const double *d, double *out, c2_stream_t stream);
+
 /* Fused log-likelihood -- the assembly the reference's callers perform around
  * factor + solve_lower (python/celerite2/numpy.py:66-87,104-109, core.py:407-428):
  *   ll[b] = -1/2 (sum log d + N log 2pi) - 1/2 sum z^2/d,  z = L^-1 y.

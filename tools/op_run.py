@@ -9,7 +9,25 @@ reps = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 dev = torch.device("cuda:0")
 t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
 Y = y[:, :, None].contiguous()
+gp = ts = None
+if op.startswith("predict"):
+    from celerite2_amd import gp as gpmod, terms
+    import numpy as np
+    M = 256
+    xi = np.zeros(B)
+    k = np.arange(J // 2, dtype=np.float64)
+    kernel = None
+    for kk in range(J // 2):
+        term = terms.SHOTerm(S0=5.0 * 0.7**kk, w0=0.1 * 3.0**kk, Q=3.45 + kk)
+        kernel = term if kernel is None else kernel + term
+    gp = gpmod.GaussianProcess(kernel, mean=0.0)
+    diag = torch.rand((B, N), dtype=torch.float64, device=dev) * 0.2 + 0.1
+    gp.compute(t, diag=diag)
+    ts = torch.sort(torch.rand((B, M), dtype=torch.float64, device=dev) * (N / 10.0), dim=1).values
 def run():
+    if op == "predict_var": return gp.predict(y, ts, return_var=True)
+    if op == "predict_cov": return gp.predict(y, ts, return_cov=True)
+    if op == "predict": return gp.predict(y, ts)
     if op == "loglik": return ops.loglik(t, c, a, U, V, y)
     if op == "loglik_grad": return ops.loglik_grad(t, c, a, U, V, y)
     if op == "factor": return ops.factor(t, c, a, U, V)

@@ -12,9 +12,9 @@ import glob, sqlite3, sys
 for path in glob.glob("/tmp/kb/*_results.db") + glob.glob("/tmp/kb/*/*_results.db"):
     cur = sqlite3.connect(path).cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')").fetchall()]
-    rows = cur.execute("select name, count(*), avg(duration)/1e3, sum(duration)/1e3 from kernels group by name order by sum(duration) desc").fetchall()
+    rows = cur.execute("select name, count(*), avg(duration)/1e3, sum(duration)/1e3, min(duration)/1e3, max(duration)/1e3 from kernels group by name order by sum(duration) desc").fetchall()
     tot = sum(r[3] for r in rows)
     print("## %s  (7 calls; total kernel time per call %.1f us)" % (sys.argv[1], tot / 7))
-    for n, c, a, s in rows[:24]:
-        print("  %-90s x%-4.1f avg %8.1f us   per call %8.1f us" % (n.split("(")[0].replace("void ", "")[:90], c / 7.0, a, s / 7))
+    for n, c, a, s, mn, mx in rows[:24]:
+        print("  %-90s x%-4.1f avg %8.1f us (min %.1f, max %.1f)   per call %8.1f us" % (n.split("(")[0].replace("void ", "")[:90], c / 7.0, a, mn, mx, s / 7))
 PY

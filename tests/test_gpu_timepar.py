@@ -494,6 +494,52 @@ def test_newton_factor_matches_oracle(ops, oracle, monkeypatch, B, N, J):
     close(d2, d.cpu().numpy()); np.testing.assert_allclose(W2.cpu().numpy(), W.cpu().numpy(), rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize("scan8,group", [("1", "1"), ("1", "0"), ("0", "1")])
+@pytest.mark.parametrize("B,N", [(1, 4096), (3, 390), (70, 1000), (2, 8200), (1, 100001), (5, 64), (2, 33)])
+def test_width8_scanned_states_both_sides_of_the_switches(ops, oracle, monkeypatch, B, N, scan8, group):
+    """Width 8, round 6: `factor`, the forward log-likelihood and the log-likelihood + gradient on the time-parallel forms with
+    the chunk-start states from the scanned chunk elements (C2_FACTOR_SCAN8: up-sweep + k_e8_down) or from Newton iterations
+    (= 0), and the chunk pass with the element spread over a group's lanes (C2_E8_GROUP_CHUNKS: k_e8_chunks) or in one lane
+    (= 0, k_tp_onepass<8, 2>) -- every row of d, W, the log-likelihood and all six gradients against the oracle; a failed
+    series hands the batch to the row-by-row kernel, which reports the reference's flag."""
+    t, c, a, U, V, y = dense.synthetic_batch(min(B, 4), N, 8)
+    if B > 4:
+        rng = np.random.default_rng(B)
+        rep = (B + 3) // 4
+        t, c, U, V = (np.ascontiguousarray(np.tile(v, (rep,) + (1,) * (v.ndim - 1))[:B]) for v in (t, c, U, V))
+        a = np.ascontiguousarray(np.tile(a, (rep, 1))[:B] * rng.uniform(1.0, 1.3, (B, 1)))
+        y = np.ascontiguousarray(np.tile(y, (rep, 1))[:B] + 0.05 * rng.standard_normal((B, N)))
+    monkeypatch.setenv("C2_FACTOR_SCAN8", scan8)
+    monkeypatch.setenv("C2_E8_GROUP_CHUNKS", group)
+    monkeypatch.setenv("C2_FACTOR_ITER", "1")
+    args = dev(t, c, a, U, V)
+    d, W, flag = ops.factor(*args)
+    assert int(flag.abs().sum()) == 0
+    for b in range(min(B, 5)):
+        do = np.empty(N); Wo = np.empty((N, 8))
+        assert oracle.factor_flag(t[b], c[b], a[b], U[b], V[b], do, Wo) == 0
+        close(d[b], do); np.testing.assert_allclose(W[b].cpu().numpy(), Wo, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(Wo).max()))
+    llo, go, flo = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=4)
+    assert not np.asarray(flo).any()
+    monkeypatch.setenv("C2_TIMEPAR", "1")
+    ll, fl = ops.loglik(*args, dev(y)[0])
+    assert int(fl.abs().sum()) == 0
+    close(ll, llo)
+    monkeypatch.setenv("C2_TIMEPAR_GRAD", "1")
+    ll2, grads, fl2 = ops.loglik_grad(*args, dev(y)[0])
+    assert int(fl2.abs().sum()) == 0
+    close(ll2, llo)
+    for g, e in zip(grads, go):
+        for b in range(B):
+            np.testing.assert_allclose(g[b].cpu().numpy(), e[b], rtol=0.0, atol=1e-10 * max(np.abs(e[b]).max(), 1e-300))
+    if N > 40 and B > 1:
+        a1 = a.copy(); a1[1, N // 2] = -2.0
+        d1, W1, flag1 = ops.factor(*dev(t, c, a1, U, V))
+        f = flag1.cpu().numpy()
+        assert int(f[1]) == N // 2 and int(np.abs(np.delete(f, 1)).sum()) == 0
+        close(d1[0], d[0].cpu().numpy(), 1e-12)
+
+
 def test_newton_factor_on_hard_series(ops, oracle, monkeypatch):
     """Series the Newton iteration has to work for: a long gap (the states decouple), repeated times, a nearly singular
     stretch (tiny white noise), very slow and very fast rates side by side -- every row against the oracle, whether the

@@ -149,10 +149,14 @@ def _dev(*xs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tile", ["1", "0"])
 @pytest.mark.parametrize("name", sorted(COEF_CASES))
-def test_device_matrices_and_kernel_values_vs_reference_classes(golden, name):
-    """Row M + (f)2 on the device: (c, a, U, V) of every reference term class and k(t1 - t2) on a grid."""
+def test_device_matrices_and_kernel_values_vs_reference_classes(golden, monkeypatch, name, tile):
+    """Row M + (f)2 on the device: (c, a, U, V) of every reference term class and k(t1 - t2) on a grid -- by 32 x 64 tiles
+    with angle addition (C2_KERNEL_VALUES_TILE, the default) and with a thread per entry (= 0); plus a 150 x 130 grid of the
+    fixture's own times against the reference's get_value formula evaluated in numpy on the reference's coefficients."""
     from celerite2_amd import terms
+    monkeypatch.setenv("C2_KERNEL_VALUES_TILE", tile)
 
     term = COEF_CASES[name](terms)
     x, diag = golden["coef_x"], golden["coef_diag"]
@@ -167,6 +171,13 @@ def test_device_matrices_and_kernel_values_vs_reference_classes(golden, name):
     order = np.argsort(tau)
     k = term.get_value_grid(t1, t2, B=1)
     _close(k[0, :, 0], golden["coef_%s_value" % name][order], 1e-12, 1e-14)
+    rng = np.random.default_rng(5)
+    g1, g2 = np.sort(rng.uniform(0, 40, 150)), rng.uniform(-3, 43, 130)     # (an unsorted second grid: nothing assumes order)
+    kk = term.get_value_grid(*_dev(g1[None], g2[None]), B=1)
+    ar, cr, ac, bc, cc, dc = (golden["coef_%s_%s" % (name, cn)] for cn in COEF_NAMES)
+    tau = np.abs(g1[:, None] - g2[None, :])[..., None]                       # terms.py:58-79 on the reference's coefficients
+    want = np.sum(ar * np.exp(-cr * tau), axis=-1) + np.sum(np.exp(-cc * tau) * (ac * np.cos(dc * tau) + bc * np.sin(dc * tau)), axis=-1)
+    _close(kk[0], want, 1e-12, 1e-14)
 
 
 @pytest.mark.gpu

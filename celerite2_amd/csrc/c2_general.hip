@@ -11,7 +11,9 @@
 // row or emits its next t1 row, so series whose grids interleave differently do not serialise each other; the decay
 // vector is computed by lanes 0..J-1 and broadcast through LDS.  Eight rows of BOTH streams are resident in an LDS ring per
 // series; the row eight positions down the moving stream is requested at the top of every event and written into the
-// ring three events later (the merge decides only at run time which stream advances).
+// ring five events later (the merge decides only at run time which stream advances).  The loop is software-pipelined
+// (round 6): the front half of event e + 1 (decision, request, decay vector) is issued with the back half of event e
+// (the multiply-adds on the state, the stores) -- profiles/r06_general.md.
 //
 // Workspace semantics as the reference: F[m, j * nrhs + k] (row-major), row m written when row m is absorbed, rows the
 // merge never reaches left untouched, row 0 = V_0^T Y_0 (lower) / 0 (upper), row M-1 never written by the upper variant.
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   // decay vector, event row; two doubles of padding per vector: a series' pair is 16 (KL + 2) bytes from the next one's, so
   // the b128 broadcasts of the SPW series of a wavefront fall into distinct banks (unpadded, KL = 8: 128-byte stride, four
   // series per bank group -- 13 % of the kernel's cycles were LDS bank conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT)
-  __shared__ __attribute__((aligned(16))) double rowbuf[SPW][2][KL + 2];   // [0]: the decay vector of the event, [1]: prologue
+  __shared__ __attribute__((aligned(16))) double rowbuf[SPW][2][KL + 2];   // the decay vectors of two consecutive events (double buffer); [1]: also the prologue's row
   const int lane = threadIdx.x, sl = lane / KL, k = lane % KL;
   int64_t b = (int64_t)blockIdx.x * SPW + sl;
   const bool vb = b < B;
@@ -107,86 +109,147 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
     rg[sn] = t1b[rn]; rgR[sn * KL + k] = actj ? Ub[rn * J] : 0.0; rgX[sn * KL + k] = Zb[rn * nrhs];
   }
   lds_order();
-  double tm = rg[(int)(m & (RD - 1))], tn = rg[RD + (int)(n & (RD - 1))];
+  // The event loop is SOFTWARE-PIPELINED (round 6): what a series does next depends on its two grids only, so the FRONT half
+  // of event e + 1 -- decide, request the row RD positions down, take the event's row (x, the width-J row) out of the ring,
+  // the decay vector into rowbuf[q ^ 1] -- is issued together with the BACK half of event e -- the multiply-adds on the
+  // state with the decay vector of rowbuf[q], the stores.  Neither half waits for the other inside an iteration (one fence
+  // per iteration), so the exponential's chain of sixteen dependent operations runs under the state update of the event
+  // before it instead of in front of its own: with ONE wavefront per SIMD (8192 series) nothing else hides it.  The only
+  // chain left from event to event is compare -> select on the current and next times of both grids, which are kept in
+  // registers one position ahead (tm1, tn1: positions m + 1, n + 1 are always in the ring -- a slot is refilled five
+  // iterations after its row was taken, eight positions ahead).
+  // (positions, lengths and row lengths as 32-bit integers from here on -- the launcher refuses grids of 2^31 rows: a 64-bit
+  // product per address and 64-bit compares / selects per clamp were a fifth of the loop's instructions, and the loop is
+  // bound by its instruction count: one wavefront per SIMD at 8192 series x 8 right-hand sides)
+  int mi = (int)m, ni = (int)n;
+  const int Ni = (int)N, Mi = (int)M, nr = (int)nrhs;
+  double tm = rg[mi & (RD - 1)], tn = rg[RD + (ni & (RD - 1))];
+  double tm1 = rg[(mi + 1) & (RD - 1)], tn1 = rg[RD + ((ni + 1) & (RD - 1))];
   struct Pend { double t, r, x; int slot; };
+  struct Ev { bool absorb, emit; double xe; int row; double r[JM]; };
   Pend p0{0.0, 0.0, 0.0, 2 * RD}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0;
-  auto event = [&](Pend &issue, Pend &resolve) __attribute__((always_inline)) {
-    const bool live = n < N;
+  int q = 0;   // rowbuf[sl][q]: the decay vector of the event whose back half runs in this iteration
+  auto front = [&](Pend &issue, Ev &ev) __attribute__((always_inline)) {
+    const bool live = ni < Ni;
     // lower: absorb while t2[m] <= t1[n];  upper (walking down): absorb while t2[m] > t1[n]
-    const bool absorb = live && m < M && (LOWER ? tm <= tn : tm > tn);
+    const bool absorb = live && mi < Mi && (LOWER ? tm <= tn : tm > tn);
     const bool emit = live && !absorb;
-    const int so = absorb ? (int)(m & (RD - 1)) : RD + (int)(n & (RD - 1));   // the event's row in the ring
-    {   // the request of this event: the row RD positions down the moving stream
-      const int64_t rm = clampM(m + RD), rn = clampN(n + RD);
-      const double *pt = absorb ? t2b + rm : t1b + rn;
-      const double *pr = absorb ? Vb + rm * J : Ub + rn * J;
-      const double *px = absorb ? Yb + rm * nrhs : (const double *)Zb + rn * nrhs;
-      issue.t = *pt; issue.r = actj ? *pr : 0.0; issue.x = *px;
+    const int pos = absorb ? mi : ni;                        // position of the event's row along its stream
+    const int len1 = (absorb ? Mi : Ni) - 1;
+    const int so = (pos & (RD - 1)) + (absorb ? 0 : RD);     // the event's row in the ring
+    {   // the request of this event: the row RD positions down the moving stream (clamped at the end of its grid)
+      const int sreq = pos + RD < len1 ? pos + RD : len1;
+      const int rreq = LOWER ? sreq : len1 - sreq;
+      const double *pt = (absorb ? t2b : t1b) + rreq;
+      const double *pr = (absorb ? Vb : Ub) + (int64_t)rreq * J;
+      const double *px = (absorb ? Yb : (const double *)Zb) + (int64_t)rreq * nr;
+      issue.t = *pt;
+      const double rv = *pr;          // (every lane loads: lanes beyond the width read element 0 of the row and drop it)
+      issue.r = actj ? rv : 0.0;
+      issue.x = *px;
       issue.slot = live ? so : 2 * RD;
     }
-    const double xe = rgX[so * KL + k];   // y_m / z_n
-    const double tev = absorb ? tm : tn;
-    const double p = exp_decay(cj * (LOWER ? tlast - tev : tev - tlast));
-    rowbuf[sl][0][k] = p;
-    lds_order();
-    double red = 0.0;
+    ev.absorb = absorb; ev.emit = emit;
+    ev.row = LOWER ? pos : len1 - pos;
+    ev.xe = rgX[so * KL + k];   // y_m / z_n
 #pragma unroll
     for (int j = 0; j < JM; j += 2) {
-      double2 p2, r2;
       if constexpr (JM >= 2) {
-        p2 = *reinterpret_cast<const double2 *>(&rowbuf[sl][0][j]);
-        r2 = *reinterpret_cast<const double2 *>(&rgR[so * KL + j]);
+        const double2 r2 = *reinterpret_cast<const double2 *>(&rgR[so * KL + j]);
+        ev.r[j] = r2.x; ev.r[j + 1] = r2.y;
       } else {
-        p2 = make_double2(rowbuf[sl][0][0], 0.0); r2 = make_double2(rgR[so * KL], 0.0);
+        ev.r[0] = rgR[so * KL];
       }
-      const double f0 = p2.x * Fj[j];
-      red = fma(r2.x, f0, red);                       // emit: (U_n o p) . F          (forward.hpp:329 / 389)
-      Fj[j] = absorb ? fma(r2.x, xe, f0) : Fj[j];      // absorb: F = p o F + V_m^T y_m (forward.hpp:320-323 / 380-383)
-      if (j + 1 < JM) {
-        const double f1 = p2.y * Fj[j + 1];
-        red = fma(r2.y, f1, red);
-        Fj[j + 1] = absorb ? fma(r2.y, xe, f1) : Fj[j + 1];
+    }
+    const double tev = absorb ? tm : tn;
+    rowbuf[sl][q ^ 1][k] = exp_decay(cj * (LOWER ? tlast - tev : tev - tlast));
+    tlast = absorb ? tm : tlast;
+    tm = absorb ? tm1 : tm;
+    tn = emit ? tn1 : tn;
+    mi += absorb ? 1 : 0;
+    ni += emit ? 1 : 0;
+    tm1 = rg[(mi + 1) & (RD - 1)]; tn1 = rg[RD + ((ni + 1) & (RD - 1))];
+  };
+  // The back half in two pieces: its decay vector is REQUESTED from LDS before the front half of the next event is issued
+  // (LDS answers in order: behind the front half's reads of the ring the multiply-adds would wait for those as well) and
+  // used after it.
+  auto back_load = [&](double (&pv)[JM]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < JM; j += 2) {
+      if constexpr (JM >= 2) {
+        const double2 p2 = *reinterpret_cast<const double2 *>(&rowbuf[sl][q][j]);
+        pv[j] = p2.x; pv[j + 1] = p2.y;
+      } else {
+        pv[0] = rowbuf[sl][q][0];
       }
+    }
+  };
+  auto back = [&](const Ev &ev, const double (&pv)[JM], Pend &resolve) __attribute__((always_inline)) {
+    // (a scheduling barrier here -- so that the front half's instructions stay in front and cover the LDS latency of pv -- was
+    // measured: 3.50 against 3.43 ms, the scheduler's own interleaving is the better one)
+    double f0[JM];
+#pragma unroll
+    for (int j = 0; j < JM; ++j) f0[j] = pv[j] * Fj[j];
+    // (the two kinds of event as predicated regions, not selects: a select of a double is two instructions, and there were
+    // JM of them per event)
+    if (ev.emit) {        // (U_n o p) . F   (forward.hpp:329 / 389); the state stays at the time of the last absorbed row
+      double red = 0.0;   // (one chain in the order of the columns, as every version of this kernel summed it)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) red = fma(ev.r[j], f0[j], red);
+      if (vk) Zb[(int64_t)ev.row * nr] = ev.xe + red;
+    }
+    if (ev.absorb) {      // F = p o F + V_m^T y_m   (forward.hpp:320-323 / 380-383)
+      // (written into the state's own registers: as plain C++ the compiler accumulates into f0 and copies it over, JM moves)
+#pragma unroll
+      for (int j = 0; j < JM; ++j) asm volatile("v_fma_f64 %0, %1, %2, %3" : "+v"(Fj[j]) : "v"(ev.r[j]), "v"(ev.xe), "v"(f0[j]));
     }
     if constexpr (WF) {
       if (dense_f) {   // the row (J x nrhs doubles, [j][k]) leaves as 16-byte pieces through an LDS tile
-        const int nr = (int)nrhs;
         if (k < nr) {
 #pragma unroll
           for (int j = 0; j < JM; ++j) ftile[sl * JM * KL + j * nr + k] = Fj[j];
         }
         lds_order();
-        if (absorb && vb) {
-          double *fr = F + (b * M + rowM(m)) * (int64_t)(JM * nr);
+        if (ev.absorb && vb) {
+          double *fr = F + (b * M + ev.row) * (int64_t)(JM * nr);
 #pragma unroll
-          for (int q = 0; q < JM / 2; ++q)
-            if (2 * (q * KL + k) < JM * nr)
-              *reinterpret_cast<double2 *>(fr + 2 * (q * KL + k)) = *reinterpret_cast<const double2 *>(&ftile[sl * JM * KL + 2 * (q * KL + k)]);
+          for (int qq = 0; qq < JM / 2; ++qq)
+            if (2 * (qq * KL + k) < JM * nr)
+              *reinterpret_cast<double2 *>(fr + 2 * (qq * KL + k)) = *reinterpret_cast<const double2 *>(&ftile[sl * JM * KL + 2 * (qq * KL + k)]);
         }
-      } else if (absorb && vk) {
-        const int64_t mr = rowM(m);
-        for (int j = 0; j < J; ++j) Fb[mr * J * nrhs + (int64_t)j * nrhs] = Fj[j];
+      } else if (ev.absorb && vk) {
+        for (int j = 0; j < J; ++j) Fb[(int64_t)ev.row * J * nrhs + (int64_t)j * nrhs] = Fj[j];
       }
     }
-    if (emit && vk) Zb[rowN(n) * nrhs] = xe + red;
-    // the row requested five events ago goes into its slot (the row that slot held was consumed by the event that
-    // requested it); then the stream this event came from moves up and the current times are read again
+    // the row requested five iterations ago goes into its slot (the row that slot held was taken out by the front half that
+    // requested it)
     rg[resolve.slot] = resolve.t;
     rgR[resolve.slot * KL + k] = resolve.r;
     rgX[resolve.slot * KL + k] = resolve.x;
-    tlast = absorb ? tm : tlast;
-    m += absorb ? 1 : 0;
-    n += emit ? 1 : 0;
     lds_order();
-    tm = rg[(int)(m & (RD - 1))]; tn = rg[RD + (int)(n & (RD - 1))];
+    q ^= 1;
   };
-  while (__any(n < N)) {
-    event(p0, p1);
-    event(p1, p2);   // (an event of a finished series is a no-op: nothing absorbed, nothing emitted, its request parked)
-    event(p2, p3);
-    event(p3, p4);
-    event(p4, p5);
-    event(p5, p0);
+  Ev ea, eb;
+  ea.absorb = false; ea.emit = false; ea.xe = 0.0; ea.row = 0;
+#pragma unroll
+  for (int j = 0; j < JM; ++j) ea.r[j] = 0.0;
+  rowbuf[sl][0][k] = 1.0;   // (the decay vector of the empty event in front of the first one)
+  lds_order();
+  bool more = __any(ni < Ni);
+  double pv[JM];
+  while (more) {
+    back_load(pv); front(p0, eb); back(ea, pv, p1);
+    back_load(pv); front(p1, ea); back(eb, pv, p2);   // (an event of a finished series is a no-op: nothing absorbed, nothing emitted, its request parked)
+    back_load(pv); front(p2, eb); back(ea, pv, p3);
+    back_load(pv); front(p3, ea); back(eb, pv, p4);
+    back_load(pv); front(p4, eb); back(ea, pv, p5);
+    back_load(pv); front(p5, ea); back(eb, pv, p0);
+    more = __any(ni < Ni);
+  }
+  {   // the back half of the last event
+    Pend none{0.0, 0.0, 0.0, 2 * RD};
+    back_load(pv);
+    back(ea, pv, none);
   }
 }
 
@@ -200,6 +263,7 @@ extern "C" int c2_internal_generalK(int lower, int64_t B, int64_t N, int64_t M, 
                                     const double *U, const double *V, const double *Y, double *Z, double *F, int zero_z,
                                     c2_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (N > 2147483600 || M > 2147483600 || nrhs > 2147483600) return C2_ERR_UNSUPPORTED;   // 32-bit positions in the event loop
   const int JM = J <= 8 ? 8 : (J <= 16 ? 16 : 32);
   int KL = 8;
   while (KL < 64 && KL < nrhs) KL *= 2;

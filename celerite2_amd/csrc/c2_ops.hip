@@ -1429,23 +1429,24 @@ static bool solve_chunks_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
 static bool solve_cols_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   if (opt::has(opt::k_solve_cols)) return opt::ival(opt::k_solve_cols) != 0 && J <= 16 && N >= 2 && B <= 65535;
   if (J > 16 || nrhs < 16 || N < opt::ival(opt::k_solve_cols_min_rows) || B > 65535) return false;
-  const double wide = J > 8 ? 1.3 : 1.0;
+  const double wide = J > 8 ? 1.25 : 1.0;
   int64_t KL = 16;
   while (KL < 64 && KL < nrhs) KL *= 2;
   const double tiles = (double)((nrhs + 63) / 64);
   const double waves = (double)((B + 64 / KL - 1) / (64 / KL)) * (double)((nrhs + KL - 1) / KL);
-  // row by row: one wavefront's N steps of 0.26 us while the chip holds the launch, the bytes at ~3 TB/s beyond
-  const double bytes = (double)B * (double)N * 8.0 * (double)(2 * nrhs + 2 * J + 1);
-  double rows_ms = 1e-3 * (double)N * 0.26 * wide * (waves > 2048.0 ? waves / 2048.0 : 1.0);
-  if (bytes / 3e9 > rows_ms) rows_ms = bytes / 3e9;
-  // chunk maps over the columns: 0.10 ms for the three launches and their temporary + 3.4e-5 ms per wavefront-walk of 64 rows
-  // (x 1.5 at J = 16).  Re-fitted in round 5 on 60 shapes (tools/cols_probe.py: B = 16 ... 256, 64 ... 1024 right-hand sides,
-  // J = 4, 8, 16; 64 x 4096 x 256: 0.84 against 1.14 ms row by row, 128 x 4096 x 128: 0.92 against 1.14 -- both were missed)
+  // row by row: one wavefront's N steps of 0.26 us; a launch of w x 1024 wavefronts takes (1 + 0.33 w) of that while the chip
+  // holds it (w <= 1) and 1.08 w beyond (round 6, tools/cols_probe.py on 60 shapes: 64 wavefronts 1.07 ms, 512: 1.28, 1024:
+  // 1.40 - 1.44, 2048: 2.30 - 2.38, 4096: 4.5; the first model had the chip hold 2048 at the price of one)
+  const double w = waves / 1024.0;
+  const double rows_ms = 1e-3 * (double)N * 0.26 * wide * (1.0 + 0.33 * w > 1.08 * w ? 1.0 + 0.33 * w : 1.08 * w);
+  // chunk maps over the columns: the launches and their temporary + a price per wavefront-walk of 64 rows.  Re-fitted in round 6
+  // after the first walk lost its 442 registers (c2_solve_cols.hip): 0.09 ms + 2.5e-5 per walk (round 5: 0.10 + 3.4e-5), width 16
+  // 0.20 + 3.4e-5; 64 x 4096 x 512: 1.02 against 1.28 ms row by row, 256 x 4096 x 64: 0.73 against 1.14 -- both were missed
   int64_t Lc = 64;
   while (Lc < 1024 && (double)B * (double)((N + Lc - 1) / Lc) * tiles > 8192.0) Lc *= 2;   // (the plan of c2_solve_cols.hip)
   const double K = (double)((N + Lc - 1) / Lc), cw = (double)B * K * (tiles + 1.0) * (double)Lc / 64.0;
-  const double cols_ms = 0.10 + 3.4e-5 * (J > 8 ? 1.5 : 1.0) * cw;
-  return cols_ms < 0.9 * rows_ms;
+  const double cols_ms = J > 8 ? 0.20 + 3.4e-5 * cw : 0.09 + 2.5e-5 * cw;
+  return cols_ms < rows_ms;
 }
 static bool solve_chunks_enabled() {
   return !(opt::has(opt::k_timepar) && opt::ival(opt::k_timepar) == 0);   // the switch of the time-parallel solves: 0 keeps them row by row

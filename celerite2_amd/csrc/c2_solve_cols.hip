@@ -19,6 +19,7 @@
 // result differs from the row-by-row kernel by rounding only.  Z may alias Y (pass 1 has read every row before pass 3
 // writes).  No workspace F here: calls that ask for it keep their row-by-row / column-by-column forms.
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/celerite2_amd.h"
 #include "c2_common.hpp"
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
     rt[r] = tb[nn];
     ra[r] = actj ? Ab[nn * J] : 0.0;
     rb[r] = actj ? Bb[nn * J] : 0.0;
-    ry[r] = phi_tile ? 0.0 : yb[nn * nrhs];
+    const double yv = yb[nn * nrhs];   // (loaded by the virtual columns too -- a valid, clamped column -- and dropped: no branch in the ring)
+    ry[r] = phi_tile ? 0.0 : yv;
   };
   double tprev = tb[rowof<LOWER>(s_lo > 0 ? s_lo - 1 : 0, N)];
 #pragma unroll
@@ -108,6 +110,14 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
       G[j + 1] = fma(a2.y, zn, G[j + 1]);
     }
     q ^= 1;
+    // (MODE 0 has no store in its step, and without one the optimiser lets the state's chain trail the R unrolled steps' loads,
+    // LDS reads and exponentials: 442 registers -- ONE wavefront per SIMD and v_accvgpr moves on every operand, the first walk
+    // took 2.2 x the second (tools/kernel_regs.py lists such kernels).  An empty asm that 'uses and redefines' the state pins
+    // every step where it is written: 138 registers.  Round 6 also measured the rows as precomputed records [p | A | B] read
+    // through uniform (scalar) loads -- no exponential, no LDS exchange, 28 VALU instructions per step: the second walk 261 ->
+    // 341 us, two scalar-cache round trips per step that eight wavefronts per SIMD do not cover; not taken.)
+#pragma unroll
+    for (int j = 0; j < JM; ++j) asm volatile("" : "+v"(G[j]));
   };
   int64_t s0 = s_lo;
   for (; s0 + R <= s_hi; s0 += R) {
@@ -131,9 +141,69 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
   }
 }
 
-// Gbuf[chunk] <- the state the chunk starts from (it held g of the chunk): G_{k+1} = Phi_k G_k + g_k, G_0 = 0
+// Gbuf[chunk] <- the state the chunk starts from (it held g of the chunk): G_{k+1} = Phi_k G_k + g_k, G_0 = 0.
+// A thread per (series, column) walks the K chunks one after the other, so what an iteration costs is what it WAITS for.
+// Round 6: the chunk maps of the series are staged in LDS KP chunks at a time (they are the same for every column: the first
+// version read them through the scalar cache, three round trips per chunk: ~1.3 us a chunk, 43 - 66 us for the 32 - 64
+// chunks of a 4096-row series) and g is requested PF chunks ahead into a register ring.
 template <int JM>
-__global__ __launch_bounds__(kWave) void k_cols_chain(int64_t K, const double *__restrict__ Phi, double *__restrict__ Gbuf,
+__global__ __launch_bounds__(kWave) void k_cols_chain(int64_t K, const double *__restrict__ Phi, double *Gbuf, int64_t ncolp) {
+  constexpr int KP = JM <= 8 ? 64 : 16;   // 32 KB of maps per piece
+  constexpr int PF = 4;
+  __shared__ __attribute__((aligned(16))) double ph[KP * JM * JM];
+  const int lane = threadIdx.x;
+  const int64_t b = blockIdx.y, col = (int64_t)blockIdx.x * kWave + lane;   // (ncolp is a multiple of 64)
+  double G[JM], gq[PF][JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) G[j] = 0.0;
+  auto gload = [&](auto slot_tag, int64_t k) __attribute__((always_inline)) {
+    constexpr int Q = decltype(slot_tag)::value;
+    const int64_t kc = k < K ? k : K - 1;
+#pragma unroll
+    for (int i = 0; i < JM; ++i) gq[Q][i] = Gbuf[((b * K + kc) * JM + i) * ncolp + col];
+  };
+  gload(std::integral_constant<int, 0>{}, 0); gload(std::integral_constant<int, 1>{}, 1);
+  gload(std::integral_constant<int, 2>{}, 2); gload(std::integral_constant<int, 3>{}, 3);
+  auto chunk = [&](auto slot_tag, int64_t k, int kl) __attribute__((always_inline)) {
+    constexpr int Q = decltype(slot_tag)::value;
+    double *gb = Gbuf + ((b * K + k) * JM) * ncolp + col;
+#pragma unroll
+    for (int i = 0; i < JM; ++i) gb[i * ncolp] = G[i];   // (g of this chunk was read PF chunks ago)
+    const double *pm = ph + kl * (JM * JM);
+    double gn[JM];
+#pragma unroll
+    for (int i = 0; i < JM; ++i) {
+      double v = gq[Q][i];
+#pragma unroll
+      for (int j = 0; j < JM; j += 2) {
+        const double2 p2 = *reinterpret_cast<const double2 *>(pm + i * JM + j);
+        v = fma(p2.x, G[j], v);
+        v = fma(p2.y, G[j + 1], v);
+      }
+      gn[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < JM; ++i) G[i] = gn[i];
+    gload(slot_tag, k + PF);
+  };
+  for (int64_t k0 = 0; k0 < K; k0 += KP) {
+    const int kn = (int)((K - k0) < KP ? (K - k0) : KP);
+    lds_order();
+    for (int idx = lane; idx < kn * JM * JM; idx += kWave) ph[idx] = Phi[(b * K + k0) * (JM * JM) + idx];
+    lds_order();
+    for (int kl = 0; kl < kn; kl += PF) {   // (K, KP multiples of nothing in particular: the tail is guarded)
+      chunk(std::integral_constant<int, 0>{}, k0 + kl, kl);
+      if (kl + 1 < kn) chunk(std::integral_constant<int, 1>{}, k0 + kl + 1, kl + 1);
+      if (kl + 2 < kn) chunk(std::integral_constant<int, 2>{}, k0 + kl + 2, kl + 2);
+      if (kl + 3 < kn) chunk(std::integral_constant<int, 3>{}, k0 + kl + 3, kl + 3);
+    }
+  }
+}
+
+// The first version of the chain: the maps through the scalar cache, g one chunk ahead.  Kept for width 16, where a chunk's map
+// is 2 KB and the LDS version (16 chunks a piece, 128 b128 reads per chunk) measured 2.5 x slower (336 against ~130 us at 64 x 4096 x 64).
+template <int JM>
+__global__ __launch_bounds__(kWave) void k_cols_chain_s(int64_t K, const double *__restrict__ Phi, double *__restrict__ Gbuf,
                                                       int64_t ncolp) {
   const int64_t b = blockIdx.y, col = (int64_t)blockIdx.x * kWave + threadIdx.x;   // (ncolp is a multiple of 64)
   double G[JM], g[JM], gn[JM];
@@ -208,7 +278,8 @@ int c2_internal_solve_cols(int lower, int64_t B, int64_t N, int64_t J, int64_t n
   do {                                                                                                                \
     hipLaunchKernelGGL((k_cols_walk<JM_, LO, 0>), g0, dim3(kWave), 0, s, N, (int)J, nrhs, p.Lc, p.K, p.ntile, t, t_bs, c, \
                        c_bs, U, W, Y, Z, Phi, Gbuf, p.ncolp);                                                          \
-    hipLaunchKernelGGL((k_cols_chain<JM_>), gc, dim3(kWave), 0, s, p.K, (const double *)Phi, Gbuf, p.ncolp);           \
+    if (JM_ <= 8) hipLaunchKernelGGL((k_cols_chain<JM_>), gc, dim3(kWave), 0, s, p.K, (const double *)Phi, Gbuf, p.ncolp); \
+    else hipLaunchKernelGGL((k_cols_chain_s<JM_>), gc, dim3(kWave), 0, s, p.K, (const double *)Phi, Gbuf, p.ncolp);      \
     hipLaunchKernelGGL((k_cols_walk<JM_, LO, 1>), g1, dim3(kWave), 0, s, N, (int)J, nrhs, p.Lc, p.K, p.ntile, t, t_bs, c, \
                        c_bs, U, W, Y, Z, Phi, Gbuf, p.ncolp);                                                          \
   } while (0)

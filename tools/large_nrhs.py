@@ -11,8 +11,10 @@ def timed(fn, reps=5):
     return synth.timed_steady(fn, reps=reps)   # (steady clock: profiles/r05_clock_ramp.md)
 print("| J | B | nrhs | solve_lower ms | GB/s | frac | solve_upper ms | GB/s | frac |")
 print("|---|---|---|---|---|---|---|---|---|")
-for J in (8, 16):
-    for B in (1, 64, 2048):
+Bs = [int(x) for x in os.environ.get("LARGE_NRHS_B", "1,64,2048").split(",")]
+Js = [int(x) for x in os.environ.get("LARGE_NRHS_J", "8,16").split(",")]
+for J in Js:
+    for B in Bs:
         t, c, a, U, V, y = synth.device_batch_fast(0, B, N, J, dev)
         d, W, flag = ops.factor(t, c, a, U, V)
         for nrhs in (64, 256, 1024):
@@ -25,6 +27,7 @@ for J in (8, 16):
             del Y
         del t, c, a, U, V, y, d, W
         torch.cuda.empty_cache()
+if os.environ.get("LARGE_NRHS_B"): sys.exit(0)
 # the frontend: predictive variance of 64 light curves of 4096 points at 256 new times (apply_inverse with 256 right-hand sides)
 from celerite2_amd import gp as gpmod, terms
 B, M = 64, 256

@@ -399,7 +399,32 @@ __global__ __launch_bounds__(kWave, 1) void k_k2_fwd(int64_t B, int64_t N, const
 #ifndef C2K2_SLDS
 #define C2K2_SLDS 0   // the forward state S of the backward recursion likewise: measured, no (16384 series: 12.2 against 10.1 ms)
 #endif
-constexpr int kRevLds = (2 * SPW * RSTR + 3 * SPW * SSTR + (C2K2_MLDS ? NL * kWave : 0) + (C2K2_SLDS ? NL * kWave : 0)) * 8;
+// The scalar gradients (ba, by, bt) leave the reverse sweep as SIXTEEN-row tiles -- whole aligned 128-byte lines per series (second
+// session of round 6).  With eight-row tiles the two 64-byte halves of a line were written eight steps (~30 us) apart: the line has left
+// L2 by then and the memory side merges each half on its own (a read-modify-write); tools/ubench/replay_traffic.hip, which reproduces
+// the one-lane pair's times from its memory operations alone, puts that at 11 - 15 % of the reverse sweep (profiles/r06_halflines.md).
+// C2K2_STR=8: the earlier tiles (A/B builds).
+#ifndef C2K2_STR
+#define C2K2_STR 16
+#endif
+constexpr int STR = C2K2_STR, SSTRR = STR + 1;   // rows / LDS stride (doubles) of a series in a scalar tile of the reverse sweep
+constexpr int kRevLds = (2 * SPW * RSTR + 3 * SPW * SSTRR + (C2K2_MLDS ? NL * kWave : 0) + (C2K2_SLDS ? NL * kWave : 0)) * 8;
+
+// STR-row scalar tile of the reverse sweep -> memory: one instruction moves (64 / STR) series x (8 STR) bytes
+template <bool FULL>
+__device__ __forceinline__ void sc_flush_r(double *__restrict__ base, int64_t N, int64_t n0, const double *tile, int lane,
+                                           int last) {
+  constexpr int SPI = kWave / STR, NI = SPW / SPI;   // series per instruction, instructions per tile
+  const int64_t r = n0 + (lane & (STR - 1));
+  double v[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) v[i] = tile[(SPI * i + lane / STR) * SSTRR + (lane & (STR - 1))];
+  if (r >= 0 && r < N) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (FULL || SPI * i + lane / STR <= last) base[(int64_t)(SPI * i + lane / STR) * N + r] = v[i];
+  }
+}
 
 template <bool PAIRED, bool FULL>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
@@ -412,7 +437,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const int last = (int)((B - b0 < SPW ? B - b0 : SPW) - 1);
   const bool real = sl <= last;
   const int64_t b = b0 + (real ? sl : last);
-  double *tU = lds, *tBV = tU + SPW * RSTR, *tBA = tBV + SPW * RSTR, *tBY = tBA + SPW * SSTR, *tBT = tBY + SPW * SSTR;
+  double *tU = lds, *tBV = tU + SPW * RSTR, *tBA = tBV + SPW * RSTR, *tBY = tBA + SPW * SSTRR, *tBT = tBY + SPW * SSTRR;
   const double *Ub = U + b0 * N * J;
   double *bUb = bU + b0 * N * J, *bVb = bV + b0 * N * J, *bab = ba + b0 * N, *byb = by + b0 * N, *btb = bt + b0 * N;
   const double2 *recW = reinterpret_cast<const double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * SPW);
@@ -429,12 +454,12 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   // or a checkpoint); bV is needed whole by the pass over the elements and is completed from the partner
   double F[4], bF[4], bVn[J];
 #if C2K2_SLDS
-  double2 *Sl = reinterpret_cast<double2 *>(tBT + SPW * SSTR + (C2K2_MLDS ? NL * kWave : 0)) + lane;
+  double2 *Sl = reinterpret_cast<double2 *>(tBT + SPW * SSTRR + (C2K2_MLDS ? NL * kWave : 0)) + lane;
 #else
   double S[NL];
 #endif
 #if C2K2_MLDS
-  double2 *Ml = reinterpret_cast<double2 *>(tBT + SPW * SSTR) + lane;   // elements 2q, 2q + 1 at Ml[q * kWave]
+  double2 *Ml = reinterpret_cast<double2 *>(tBT + SPW * SSTRR) + lane;   // elements 2q, 2q + 1 at Ml[q * kWave]
 #pragma unroll
   for (int q = 0; q < NL / 2; ++q) Ml[q * kWave] = make_double2(0.0, 0.0);
 #else
@@ -496,13 +521,13 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     // ---- prologue: bV, ba, by of the last row are pure seeds ---------------------------------------------------------------
     const int ph0 = (int)(nf & 1);
     row_write_half(tBV, sl, h, ph0, bVn);
-    tBA[sl * SSTR + (nf & (ST - 1))] = ban;
-    tBY[sl * SSTR + (nf & (ST - 1))] = bzn;
+    tBA[sl * SSTRR + (nf & (STR - 1))] = ban;
+    tBY[sl * SSTRR + (nf & (STR - 1))] = bzn;
     lds_order();
     if (ph0 == 0) row_flush<FULL>(bVb, N, nf, tBV, lane, last);   // (an even last row: its pair partner lies beyond the series: only row nf)
-    if ((nf & (ST - 1)) == 0) {                       // the last row alone at the bottom of its scalar tile
-      sc_flush<FULL>(bab, N, nf, tBA, lane, last);
-      sc_flush<FULL>(byb, N, nf, tBY, lane, last);
+    if ((nf & (STR - 1)) == 0) {                      // the last row alone at the bottom of its scalar tile
+      sc_flush_r<FULL>(bab, N, nf, tBA, lane, last);
+      sc_flush_r<FULL>(byb, N, nf, tBY, lane, last);
     }
     double su[8], wa[J];
     double2 dza;
@@ -533,7 +558,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       const double2 dzb = dz_fetch(n - 2);
       const double tb2 = t_fetch(n - 2);
       if constexpr (PH == 1) lds_order();
-      const int rs = (int)((n - 1) & (ST - 1));
+      const int rs = (int)((n - 1) & (STR - 1));
       double u[J], p[J], ip[J];
       row_read(tU, sl, h, PH, u);
       const double tm = ta, dt = tm - tcur;
@@ -629,9 +654,9 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       for (int j = 0; j < 4; ++j) bVn[4 + j] = swap_pair(bVn[j]);   // (the partner's local 0..3)
       ban = 0.5 * rdm * (zm * zr - 1.0) - 0.5 * Q - zr * Gs;
       if (h == 0) {
-        tBA[sl * SSTR + rs] = ban;
-        tBY[sl * SSTR + rs] = bzn;
-        tBT[sl * SSTR + (int)(n & (ST - 1))] = btn;
+        tBA[sl * SSTRR + rs] = ban;
+        tBY[sl * SSTRR + rs] = bzn;
+        tBT[sl * SSTRR + (int)(n & (STR - 1))] = btn;
       }
       row_write_half(tBV, sl, h, (PH + 1) & 1, bVn);   // bV_{n-1}
       lds_order();
@@ -639,10 +664,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       // step (rows n - 1, n)
       if constexpr (PH == 0) row_flush<FULL>(bUb, N, n, tU, lane, last);
       else row_flush<FULL>(bVb, N, n - 1, tBV, lane, last);
-      if ((n & (ST - 1)) == 0) sc_flush<FULL>(btb, N, n, tBT, lane, last);
+      if ((n & (STR - 1)) == 0) sc_flush_r<FULL>(btb, N, n, tBT, lane, last);
       if (rs == 0) {
-        sc_flush<FULL>(bab, N, n - 1, tBA, lane, last);
-        sc_flush<FULL>(byb, N, n - 1, tBY, lane, last);
+        sc_flush_r<FULL>(bab, N, n - 1, tBA, lane, last);
+        sc_flush_r<FULL>(byb, N, n - 1, tBY, lane, last);
       }
       if (ckm && n >= 2) load_ckpt();   // the state of row n-1 is on record: it replaces the recursed one
 #pragma unroll
@@ -661,10 +686,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       for (int j = 0; j < J; ++j) zero[j] = failed ? nan : 0.0;
       lds_order();
       row_write_half(tU, sl, h, 0, zero);   // bU_1 is waiting in row 1 of the tile
-      if (h == 0) tBT[sl * SSTR] = carry;
+      if (h == 0) tBT[sl * SSTRR] = carry;
       lds_order();
       row_flush<FULL>(bUb, N, 0, tU, lane, last);
-      sc_flush<FULL>(btb, N, 0, tBT, lane, last);
+      sc_flush_r<FULL>(btb, N, 0, tBT, lane, last);
     }
   } else if (h == 0 && real) {   // N == 1: seeds only
     bab[(int64_t)sl * N] = ban;

@@ -139,6 +139,35 @@ struct RowIOT {
 };
 using RowIO = RowIOT<false>;
 
+// Streaming hints (C2T_NT).  Every byte of this pair is touched ONCE -- inputs, records, gradients -- so nothing it streams needs to
+// stay in L2; what DOES need to stay is the half-written lines of the scalar gradients: ba, by, bt leave the reverse sweep as 64-byte
+// runs, and the other half of each 128-byte line follows eight steps (~30 us, ~20 MB of traffic through a 4 MB L2) later.  Evicted in
+// between, each half is merged on the memory side on its own (read-modify-write).  tools/ubench/replay_traffic.hip -- the pair's memory
+// operations without its arithmetic, which reproduces the kernels' times -- puts that at 11 - 15 % of the reverse sweep, and shows
+// that the non-temporal hint on every OTHER stream is as good as whole-line stores (for which this kernel has no LDS left: 16-row
+// scalar tiles need 13 KB more per wavefront): 15.8 -> 13.8 ms.  Level 1: the records and the width-J gradients (round 2's flag, then
+// measured 'no gain' -- with the inputs still displacing the half lines).  Level 2 (default since round 6): the API rows and scalars
+// the passes read as well.  Bench step, six alternating fresh processes on one box: 30.06 (28.8 - 31.1) -> 27.75 ms (27.2 - 28.9)
+// (profiles/r06_halflines.md).  0: plain accesses (A/B builds).
+#ifndef C2T_NT
+#define C2T_NT 2
+#endif
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2_in(const double2 *p) {
+#if C2T_NT >= 2
+  const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ double ld1_in(const double *p) {
+#if C2T_NT >= 2
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 // global -> registers: rows n0 .. n0+RT-1 (clamped to [0, N-1]) of every series
 // (staging registers are plain doubles: arrays of double2 end up in scratch)
 template <class IO>
@@ -150,7 +179,7 @@ __device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64
   const int64_t off = r * JS + 2 * pc;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)io.rl(i) * N * JS + off);
+    const double2 v = ld2_in(reinterpret_cast<const double2 *>(base + (int64_t)io.rl(i) * N * JS + off));
     st[2 * i] = piece_in(io.rpiece) ? v.x : 0.0; st[2 * i + 1] = piece_in(io.rpiece) ? v.y : 0.0;
   }
 }
@@ -235,7 +264,7 @@ __device__ __forceinline__ void sc_fetch16(const double *__restrict__ base, int6
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int s = 4 * i + lane / 16;
-    st[i] = base[(int64_t)(s < last ? s : last) * sN + r];
+    st[i] = ld1_in(&base[(int64_t)(s < last ? s : last) * sN + r]);
   }
 }
 __device__ __forceinline__ void sc_stage16(double *tile, int lane, int half, const double (&st)[16]) {
@@ -291,12 +320,7 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
 #ifndef C2T_MLDS
 #define C2T_MLDS 0   // half of M in LDS for the coefficient-level sweep: measured, 3 - 5 % SLOWER (20.4 against 19.8 ms at 65536 series)
 #endif
-// Streaming hints (C2T_NT): the records are written once by the forward pass and read once by the reverse sweep, the
-// gradients are written once -- none of it should displace the half-used lines of the API rows from L2.
-#ifndef C2T_NT
-#define C2T_NT 0
-#endif
-typedef double d2v __attribute__((ext_vector_type(2)));
+// the records (written once by the forward pass, read once by the reverse sweep) and the width-J gradients: C2T_NT >= 1
 __device__ __forceinline__ double2 ld2_stream(const double2 *p) {
 #if C2T_NT
   const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));

@@ -1162,15 +1162,26 @@ __global__ __launch_bounds__(256) void k_kernel_values(int64_t B, int64_t N, int
 // sgn(tau) (sin phi cos psi - cos phi sin psi), tau = t1[n] - t2[m].  Per entry and term that leaves ONE exponential (the
 // 16-instruction decay kernel) and a handful of multiply-adds instead of an exponential and a sincos (~100 instructions):
 // 64 x 4096 x 256, four terms: 1.04 -> ~0.3 ms.  Phases are differences against t0, so their rounding is that of dc tau itself.
+// Second session of round 6: the EXPONENTIAL is factored the same way.  A wavefront owns 8 rows x 64 columns; with tmin / tmax the
+// smallest / largest of its 8 row times, a column x <= tmin sees exp(-c (t_r - x)) = exp(-c (t_r - tmin)) exp(-c (tmin - x)) and a
+// column x >= tmax sees exp(-c (x - t_r)) = exp(-c (tmax - t_r)) exp(-c (x - tmax)) -- every factor an exponential of a NON-POSITIVE
+// argument (nothing overflows whatever the gap), the row factors one table per tile (LDS), the column factor one exponential per
+// lane and term instead of eight.  Columns that fall strictly inside the 8 rows' range (one row group of a tile column in ~8: a
+// wavefront-uniform test) take the exponential per entry as before, as do growing terms (c < 0).  Per entry and term: one multiply.
 constexpr int kKvRows = 32, kKvCols = 64;
+__host__ __device__ inline size_t kv_lds_doubles(int64_t Jr, int64_t Jc) {
+  return (size_t)2 * Jc * kKvRows + kKvRows + (size_t)2 * (Jr + Jc) * kKvRows + 8;
+}
 __global__ __launch_bounds__(256) void k_kernel_values_tile(int64_t N, int64_t M, int Jr, int Jc, const double *__restrict__ ar,
                                                             const double *__restrict__ cr, const double *__restrict__ ac,
                                                             const double *__restrict__ bc, const double *__restrict__ cc,
                                                             const double *__restrict__ dc, int coef_batched,
                                                             const double *__restrict__ t1, int64_t t1_bs,
                                                             const double *__restrict__ t2, int64_t t2_bs, double *__restrict__ K) {
-  extern __shared__ double kv_lds[];   // [Jc][32] cos phi, [Jc][32] sin phi, [32] t1 rows
+  extern __shared__ double kv_lds[];   // [Jc][32] cos phi, [Jc][32] sin phi, [32] t1 rows, [Jr + Jc][32] row factors up / down, tmin, tmax
+  const int JT = Jr + Jc;
   double *cs_n = kv_lds, *sn_n = cs_n + (size_t)Jc * kKvRows, *tn_s = sn_n + (size_t)Jc * kKvRows;
+  double *e_up = tn_s + kKvRows, *e_dn = e_up + (size_t)JT * kKvRows, *tmn = e_dn + (size_t)JT * kKvRows, *tmx = tmn + 4;
   const int64_t b = blockIdx.z, n0 = (int64_t)blockIdx.y * kKvRows, m = (int64_t)blockIdx.x * kKvCols + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;   // rows rg * 8 .. rg * 8 + 7 of the tile
   const int64_t orr = coef_batched ? b * Jr : 0, oc = coef_batched ? b * Jc : 0;
@@ -1185,38 +1196,66 @@ __global__ __launch_bounds__(256) void k_kernel_values_tile(int64_t N, int64_t M
     cs_n[q] = cs; sn_n[q] = sn;
   }
   __syncthreads();
+  if (threadIdx.x < 4) {   // smallest / largest time of each group of 8 rows (the rows need not be sorted)
+    double lo = tn_s[threadIdx.x * 8], hi = lo;
+    for (int r = 1; r < 8; ++r) { const double v = tn_s[threadIdx.x * 8 + r]; lo = fmin(lo, v); hi = fmax(hi, v); }
+    tmn[threadIdx.x] = lo; tmx[threadIdx.x] = hi;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < JT * kKvRows; q += 256) {
+    const int i = q / kKvRows, r = q - i * kKvRows;
+    const double c_ = i < Jr ? cr[orr + i] : cc[oc + i - Jr];
+    const double tr = tn_s[r];
+    e_up[q] = exp_decay(-c_ * (tr - tmn[r >> 3]));   // (c < 0: never read)
+    e_dn[q] = exp_decay(-c_ * (tmx[r >> 3] - tr));
+  }
+  __syncthreads();
   const bool live = m < M;
   const double xm = t2b[live ? m : M - 1], dx = xm - t0;
+  const double tlo = tmn[rg], thi = tmx[rg];
+  const bool below = xm <= tlo, above = xm >= thi;
+  const bool direct = __any(!(below || above));          // some column of this wavefront lies inside the rows' range (or is NaN)
+  const double far = below ? tlo - xm : xm - thi;        // >= 0 where it is used
+  const double *e_row = (below ? e_up : e_dn) + rg * 8;  // + term * 32 + r
   double k[8], tau[8], sg[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const double d = tn_s[rg * 8 + r] - xm;
     tau[r] = fabs(d); sg[r] = d < 0.0 ? -1.0 : 1.0; k[r] = 0.0;
   }
-  for (int i = 0; i < Jr; ++i) {
-    const double a_ = ar[orr + i], c_ = cr[orr + i];
-    if (c_ >= 0.0) {   // (uniform: a decaying term -- the 16-instruction kernel; a growing one takes the library's exp)
+  // e[r] = exp(-c tau[r]) of term ti (rate c_)
+  auto decay8 = [&](const double c_, const int ti, double (&e)[8]) __attribute__((always_inline)) {
+    if (c_ >= 0.0 && !direct) {          // (uniform) factored: row table x one exponential per lane
+      const double fm = exp_decay(-c_ * far);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) k[r] = fma(a_, exp_decay(-c_ * tau[r]), k[r]);
-    } else {
+      for (int r = 0; r < 8; ++r) e[r] = e_row[ti * kKvRows + r] * fm;
+    } else if (c_ >= 0.0) {              // a decaying term -- the 16-instruction kernel
 #pragma unroll
-      for (int r = 0; r < 8; ++r) k[r] = fma(a_, exp(-c_ * tau[r]), k[r]);
+      for (int r = 0; r < 8; ++r) e[r] = exp_decay(-c_ * tau[r]);
+    } else {                             // a growing one takes the library's exp
+#pragma unroll
+      for (int r = 0; r < 8; ++r) e[r] = exp(-c_ * tau[r]);
     }
+  };
+  for (int i = 0; i < Jr; ++i) {
+    const double a_ = ar[orr + i];
+    double e[8];
+    decay8(cr[orr + i], i, e);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) k[r] = fma(a_, e[r], k[r]);
   }
   for (int i = 0; i < Jc; ++i) {
-    const double a_ = ac[oc + i], b_ = bc[oc + i], c_ = cc[oc + i];
+    const double a_ = ac[oc + i], b_ = bc[oc + i];
     double sm, cm;
     sincos_cw(dc[oc + i] * dx, sm, cm);
     const double *cr_ = cs_n + (size_t)i * kKvRows + rg * 8, *sr_ = sn_n + (size_t)i * kKvRows + rg * 8;
-    const bool decays = c_ >= 0.0;   // (uniform)
+    double e[8];
+    decay8(cc[oc + i], Jr + i, e);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const double cn = cr_[r], sn = sr_[r];
       const double cosv = fma(cn, cm, sn * sm), sinv = sg[r] * fma(sn, cm, -cn * sm);
-      const double x = -c_ * tau[r];
-      double e;
-      if (decays) e = exp_decay(x); else e = exp(x);
-      k[r] = fma(e, fma(a_, cosv, b_ * sinv), k[r]);
+      k[r] = fma(e[r], fma(a_, cosv, b_ * sinv), k[r]);
     }
   }
   if (live) {
@@ -1945,7 +1984,7 @@ int c2_kernel_values(int64_t B, int64_t N, int64_t M, int64_t Jr, int64_t Jc, co
   if (B < 1 || N < 1 || M < 1 || Jr < 0 || Jc < 0 || Jr + Jc < 1) return C2_ERR_INVALID;
   if (!t1 || !t2 || !K || (Jr && (!ar || !cr)) || (Jc && (!ac || !bc || !cc || !dc))) return C2_ERR_INVALID;
   const int64_t total = B * N * M;
-  const size_t lds = sizeof(double) * ((size_t)2 * Jc * kKvRows + kKvRows);
+  const size_t lds = sizeof(double) * kv_lds_doubles(Jr, Jc);
   // tiles of 32 x 64 entries (one sincos per tile row and column instead of one per entry) when there is enough of a grid
   // to amortise them and the row phases fit LDS; C2_KERNEL_VALUES_TILE=0: the thread-per-entry kernel
   if (N >= 8 && M >= 8 && B <= 65535 && (N + kKvRows - 1) / kKvRows <= 65535 && lds <= 48 * 1024 &&

@@ -803,7 +803,10 @@ __global__ __launch_bounds__(kThreads) void k_tp_join(int64_t B, int64_t N, int6
 // A workgroup of 16 wavefronts reduces up to `span` (64 for a handful of series -- more workgroups, shorter levels --, else 512)
 // consecutive elements of one series level by level (the levels' results in a global scratch block); longer series take
 // another launch over the workgroups' results.
-constexpr int kE8Waves = 16;
+#ifndef C2_E8_WAVES
+#define C2_E8_WAVES 16
+#endif
+constexpr int kE8Waves = C2_E8_WAVES;
 struct E8Lds {
   double A1[64], G1[64], Q1[64], A2[64], G2[64], Q2[64], L[64], X[64], Ks[64], Z[64], Gt[64], MA[64], T1[64];
   double g1[8], h1[8], g2[8], h2[8], rho[8], Gr[8], tv[8], red[8];

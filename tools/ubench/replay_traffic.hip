@@ -49,6 +49,9 @@ __device__ __forceinline__ void rows4_store(double *X, int64_t N, int64_t b0, in
       *reinterpret_cast<double2 *>(X + (s * N + n0 + 2 * h) * J + 2 * (lane % 8)) = r[8 * h + i];
     }
 }
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ldnt2(const double *p) { const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p)); return make_double2(v.x, v.y); }
+__device__ __forceinline__ void stnt2(double *p, double2 v) { d2v w; w.x = v.x; w.y = v.y; __builtin_nontemporal_store(w, reinterpret_cast<d2v *>(p)); }
 // rows [n0, n0 + 8) of a (B, N) array: 8 instructions of 8 bytes per lane
 __device__ __forceinline__ void sc8_load(const double *x, int64_t N, int64_t b0, int64_t n0, int lane, double (&r)[8]) {
 #pragma unroll
@@ -57,6 +60,11 @@ __device__ __forceinline__ void sc8_load(const double *x, int64_t N, int64_t b0,
 __device__ __forceinline__ void sc8_store(double *x, int64_t N, int64_t b0, int64_t n0, int lane, const double (&r)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) x[(b0 + 8 * i + lane / 8) * N + n0 + lane % 8] = r[i];
+}
+// rows [n0, n0 + 16) of a (B, N) array: 16 instructions of 8 bytes per lane, 4 series x 128 bytes each
+__device__ __forceinline__ void sc16_store(double *x, int64_t N, int64_t b0, int64_t n0, int lane, const double (&r)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[(b0 + 4 * i + lane / 16) * N + n0 + lane % 16] = r[i];
 }
 __device__ __forceinline__ double fold(const double2 (&r)[16]) {
   double s = 0;
@@ -135,6 +143,129 @@ __global__ __launch_bounds__(64, 1) void k(Bufs p, int64_t B, int64_t N, int C) 
       sc8_store(p.bt, N, b0, n0, lane, st);
       sc8_store(p.ba, N, b0, n0, lane, sa);
       sc8_store(p.by, N, b0, n0, lane, sy);
+    }
+  } else if (MODE == 11) {   // A rev as today (halves 8 rows apart), every OTHER stream with the non-temporal hint: do the half lines survive in L2?
+    for (int64_t n0 = N - 8; n0 >= 0; n0 -= 8) {
+      if ((n0 + 8) % C == 0) {
+        const double *ck = CKr + (n0 / C) * NSF * 64;
+        for (int e = 0; e < NSF; ++e) acc += __builtin_nontemporal_load(&ck[e * 64 + lane]);
+      }
+#pragma unroll
+      for (int q = 1; q >= 0; --q) {
+        const int64_t n = n0 + 4 * q;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) u[8 * hh + i] = ldnt2(p.U + ((b0 + 8 * i + lane / 8) * N + n + 2 * hh) * J + 2 * (lane % 8));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int pc = 0; pc < 4; ++pc) v[4 * r + pc] = ldnt2(Wr + ((n + r) * 4 + pc) * 128 + 2 * lane);
+          const double2 dz = ldnt2(DZr + (n + r) * 128 + 2 * lane);
+          acc += dz.x + dz.y + __builtin_nontemporal_load(&Tr[(n + r) * 64 + lane]);
+        }
+        acc += fold(u) + fold(v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { u[i].x += acc; v[i].y += acc; }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            stnt2(p.bU + ((b0 + 8 * i + lane / 8) * N + n + 2 * hh) * J + 2 * (lane % 8), u[8 * hh + i]);
+            stnt2(p.bV + ((b0 + 8 * i + lane / 8) * N + n + 2 * hh) * J + 2 * (lane % 8), v[8 * hh + i]);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { st[i] = acc + i; sa[i] = acc - i; sy[i] = acc * i; }
+      sc8_store(p.bt, N, b0, n0, lane, st);
+      sc8_store(p.ba, N, b0, n0, lane, sa);
+      sc8_store(p.by, N, b0, n0, lane, sy);
+    }
+  } else if (MODE == 6 || MODE == 9 || MODE == 10) {   // A rev in blocks of 16 rows; the scalar gradients leave as 6: 16-row tiles (whole 128-byte lines), 9: the two 64-byte halves of every line back to back, 10: the halves 8 rows apart in time (today)
+    double s16a[16], s16b[16], s16c[16];
+    for (int64_t n0 = N - 16; n0 >= 0; n0 -= 16) {
+      if ((n0 + 16) % C == 0) {
+        const double *ck = CKr + (n0 / C) * NSF * 64;
+        for (int e = 0; e < NSF; ++e) acc += ck[e * 64 + lane];
+      }
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        const int64_t n = n0 + 4 * q;
+        rows4_load(p.U, N, b0, n, lane, u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int pc = 0; pc < 4; ++pc) v[4 * r + pc] = *reinterpret_cast<const double2 *>(Wr + ((n + r) * 4 + pc) * 128 + 2 * lane);
+          const double2 dz = *reinterpret_cast<const double2 *>(DZr + (n + r) * 128 + 2 * lane);
+          acc += dz.x + dz.y + Tr[(n + r) * 64 + lane];
+        }
+        acc += fold(u) + fold(v);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { u[i].x += acc; v[i].y += acc; }
+        rows4_store(p.bU, N, b0, n, lane, u);
+        rows4_store(p.bV, N, b0, n, lane, v);
+        if (MODE == 10 && (q == 2 || q == 0)) {   // rows n0 + 8 .. n0 + 15 after the upper two row tiles, rows n0 .. n0 + 7 after the lower two
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { st[i] = acc + i; sa[i] = acc - i; sy[i] = acc * i; }
+          sc8_store(p.bt, N, b0, n0 + 4 * q, lane, st);
+          sc8_store(p.ba, N, b0, n0 + 4 * q, lane, sa);
+          sc8_store(p.by, N, b0, n0 + 4 * q, lane, sy);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s16a[i] = acc + i; s16b[i] = acc - i; s16c[i] = acc * i; }
+      if (MODE == 6) {
+        sc16_store(p.bt, N, b0, n0, lane, s16a);
+        sc16_store(p.ba, N, b0, n0, lane, s16b);
+        sc16_store(p.by, N, b0, n0, lane, s16c);
+      } else if (MODE == 9) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // lower and upper half of the same lines in consecutive instructions
+          const int64_t o = (b0 + 8 * i + lane / 8) * N + n0 + lane % 8;
+          p.bt[o] = s16a[i]; p.bt[o + 8] = s16a[8 + i];
+          p.ba[o] = s16b[i]; p.ba[o + 8] = s16b[8 + i];
+          p.by[o] = s16c[i]; p.by[o + 8] = s16c[8 + i];
+        }
+      }
+    }
+  } else if (MODE == 7 || MODE == 8) {   // the same bytes as A rev (7) / A fwd (8) with EVERY stream lane-major: what the layout of the API arrays costs
+    const double *in1 = p.U + wave * N * J * 64, *in2 = p.V + wave * N * J * 64;
+    double *o1 = p.bU + wave * N * J * 64, *o2 = p.bV + wave * N * J * 64, *o3 = p.bt + wave * N * 64, *o4 = p.ba + wave * N * 64, *o5 = p.by + wave * N * 64;
+    const double *i3 = p.t + wave * N * 64, *i4 = p.a + wave * N * 64, *i5 = p.y + wave * N * 64;
+    for (int64_t n = 0; n < N; ++n) {
+      double2 x[4], w2[4];
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) x[pc] = *reinterpret_cast<const double2 *>(in1 + (n * 4 + pc) * 128 + 2 * lane);
+      if (MODE == 7) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) w2[pc] = *reinterpret_cast<const double2 *>(Wr + (n * 4 + pc) * 128 + 2 * lane);
+        const double2 dz = *reinterpret_cast<const double2 *>(DZr + n * 128 + 2 * lane);
+        acc += dz.x + dz.y + Tr[n * 64 + lane];
+      } else {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) w2[pc] = *reinterpret_cast<const double2 *>(in2 + (n * 4 + pc) * 128 + 2 * lane);
+        acc += i3[n * 64 + lane] + i4[n * 64 + lane] + i5[n * 64 + lane];
+      }
+#pragma unroll
+      for (int pc = 0; pc < 4; ++pc) acc += x[pc].x + x[pc].y + w2[pc].x + w2[pc].y;
+      if (MODE == 7) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+          *reinterpret_cast<double2 *>(o1 + (n * 4 + pc) * 128 + 2 * lane) = make_double2(acc, x[pc].x);
+          *reinterpret_cast<double2 *>(o2 + (n * 4 + pc) * 128 + 2 * lane) = make_double2(acc, w2[pc].y);
+        }
+        o3[n * 64 + lane] = acc; o4[n * 64 + lane] = acc + 1; o5[n * 64 + lane] = acc + 2;
+      } else {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) *reinterpret_cast<double2 *>(Wr + (n * 4 + pc) * 128 + 2 * lane) = make_double2(acc + pc, x[pc].x);
+        *reinterpret_cast<double2 *>(DZr + n * 128 + 2 * lane) = make_double2(acc, w2[0].y);
+        Tr[n * 64 + lane] = acc;
+      }
+      if ((n + 1) % C == 0) {
+        double *ck = CKr + (n / C) * NSF * 64;
+        if (MODE == 8) { for (int e = 0; e < NSF; ++e) ck[e * 64 + lane] = acc + e; }
+        else { for (int e = 0; e < NSF; ++e) acc += ck[e * 64 + lane]; }
+      }
     }
   } else {
     for (int64_t top = N; top > 0; top -= C) {
@@ -232,18 +363,28 @@ int main(int argc, char **argv) {
   printf("series %lld rows %lld C %d   (ring %.1f KB per wavefront, %.1f MB in all)\n", (long long)B, (long long)N, C, C * 10 * 64 * 8 / 1024.0,
          (B / 64) * (double)C * 10 * 64 * 8 / 1e6);
   const double ck = 2.0 * NSF * 8 / C / 2;  // checkpoint bytes per row, one direction
-  struct { const char *name; double hbm, cache; float ms; } r[6] = {
+  struct { const char *name; double hbm, cache; float ms; } r[12] = {
       {"A fwd (records)", 152 + 88 + ck, 0, 0},          {"A rev (records)", 152 + ck + 152, 0, 0},
       {"B fwd (checkpoints)", 152 + ck, 0, 0},           {"B rev (replay, ring)", 152 + ck + 152, 80 + 80 + 72, 0},
-      {"B rev, ring traffic removed", 152 + ck + 152, 72, 0}, {"B rev, ring, U t not re-read", 152 + ck + 152, 160, 0}};
+      {"B rev, ring traffic removed", 152 + ck + 152, 72, 0}, {"B rev, ring, U t not re-read", 152 + ck + 152, 160, 0},
+      {"A rev, scalars as 128-B runs", 152 + ck + 152, 0, 0}, {"A rev, every stream lane-major", 152 + ck + 152, 0, 0},
+      {"A fwd, every stream lane-major", 152 + 88 + ck, 0, 0},
+      {"A rev 16-row blocks, halves back to back", 152 + ck + 152, 0, 0}, {"A rev 16-row blocks, halves 8 rows apart", 152 + ck + 152, 0, 0},
+      {"A rev today, other streams non-temporal", 152 + ck + 152, 0, 0}};
   r[0].ms = run<0>(p, B, N, C, reps);
   r[1].ms = run<1>(p, B, N, C, reps);
   r[2].ms = run<2>(p, B, N, C, reps);
   r[3].ms = run<3>(p, B, N, C, reps);
   r[4].ms = run<4>(p, B, N, C, reps);
   r[5].ms = run<5>(p, B, N, C, reps);
+  r[6].ms = run<6>(p, B, N, C, reps);
+  r[7].ms = run<7>(p, B, N, C, reps);
+  r[8].ms = run<8>(p, B, N, C, reps);
+  r[9].ms = run<9>(p, B, N, C, reps);
+  r[10].ms = run<10>(p, B, N, C, reps);
+  r[11].ms = run<11>(p, B, N, C, reps);
   for (auto &x : r)
-    printf("%-32s %7.3f ms   first-touch bytes %.1f GB (%.2f TB/s)   re-touched %.1f GB   all %.2f TB/s\n", x.name, x.ms, x.hbm * rows / 1e9,
+    printf("%-42s %7.3f ms   first-touch bytes %.1f GB (%.2f TB/s)   re-touched %.1f GB   all %.2f TB/s\n", x.name, x.ms, x.hbm * rows / 1e9,
            x.hbm * rows / 1e9 / x.ms, x.cache * rows / 1e9, (x.hbm + x.cache) * rows / 1e9 / x.ms);
   printf("A pair %.3f ms   B pair %.3f ms   (B with U, t kept on chip %.3f)\n", r[0].ms + r[1].ms, r[2].ms + r[3].ms, r[2].ms + r[5].ms);
   return 0;

@@ -43,6 +43,10 @@ extern "C" void c2_internal_read_dbg(unsigned long long *out) {  // read and cle
   hipMemcpyToSymbol(HIP_SYMBOL(c2_dbg), z, sizeof(z));
 }
 #endif
+#ifndef C2_LOGLIK_PAIRLINES
+#define C2_LOGLIK_PAIRLINES 1
+#endif
+
 namespace c2 {
 
 // Checkpoint record of one lane: SX[0..G-1] (column j, XOR order), F_j, w_j, d, z  -> G+4 doubles.
@@ -715,6 +719,9 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   double tref = 0.0, gtop = 1.0, igtop = 1.0;   // (SC) reference time of the frame; g, 1 / g of the row above the current segment's last step
 #pragma unroll
   for (int i = 0; i < (BACK ? G : 1); ++i) carS[i] = 0.0;
+  constexpr bool HOLD = C2_LOGLIK_PAIRLINES && G == 8 && C == 8 && NV == 1;   // (see the flush at the end of a segment)
+  double hA = 0.0, hY = 0.0, hT = 0.0;
+  bool hAok = false, hTok = false;
   int bq = 0;   // buffer of oBT the current segment writes
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
@@ -1087,6 +1094,35 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     lds_order();
     C2_TCK(3);
     // flush the per-series scalar outputs, transposed: lane j <-> row n_lo - 1 + j of ba, by; row n_lo + C - 1 + j of bt
+    if constexpr (HOLD) {
+      // (segments of eight rows at width 8: a run is HALF a 128-byte line, and the two halves of a line written eight steps apart
+      // are merged on the memory side one by one -- profiles/r06_halflines.md.  The upper half (rows 16 i + 8 ..) waits in a register
+      // per stream and leaves with the lower half, back to back.  C2_LOGLIK_PAIRLINES=0: as they come.)
+      if (PAD ? L.valid : true) {
+        const double vA = oBA[grp][j], vT = j == 0 ? oBT[bq][grp][C - 1] : oBT[bq ^ 1][grp][j - 1];
+        double vY = 0.0;
+        if constexpr (!FR) vY = oBY[grp][j];
+        const bool tv = n_lo + C - 1 + j < N;
+        if (k & 1) {
+          hA = vA; hY = vY; hAok = j < cnt;
+        } else {
+          if (j < cnt) bab[n_lo - 1 + j] = vA;
+          if (hAok) bab[n_lo - 1 + C + j] = hA;
+          if constexpr (!FR) {
+            if (j < cnt) byb[n_lo - 1 + j] = vY;
+            if (hAok) byb[n_lo - 1 + C + j] = hY;
+          }
+          hAok = false;
+        }
+        if ((k + 1) & 1) {
+          hT = vT; hTok = tv;
+        } else {
+          if (tv) btb[n_lo + C - 1 + j] = vT;
+          if (hTok) btb[n_lo + 2 * C - 1 + j] = hT;
+          hTok = false;
+        }
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
@@ -1097,6 +1133,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
         }
         if (n_lo + C - 1 + idx < N) btb[n_lo + C - 1 + idx] = idx == 0 ? oBT[bq][grp][C - 1] : oBT[bq ^ 1][grp][idx - 1];
       }
+    }
     }
     bq ^= 1;
     lds_order();
@@ -1125,6 +1162,9 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
   for (int m = 0; m < NV; ++m) {
     const int idx = m * G + j;
     if ((G * NV == C || idx < C) && idx < N && (PAD ? L.valid : true)) btb[idx] = idx == 0 ? carry : oBT[bq ^ 1][grp][idx - 1];
+  }
+  if constexpr (HOLD) {   // the upper half of bt's first line (rows 8 .. 15) waited for these
+    if (hTok && (PAD ? L.valid : true)) btb[C + j] = hT;
   }
   if constexpr (LN) {   // row 0 completes pair 0 (row 1 is in the tile of even pairs since the last step)
     double *obu = reinterpret_cast<double *>(otile[0][0]) + lto, *obv = reinterpret_cast<double *>(otile[0][1]) + lto;

@@ -32,6 +32,9 @@
 namespace c2 {
 namespace q4 {
 
+#ifndef C2Q4_PAIRLINES
+#define C2Q4_PAIRLINES 1
+#endif
 constexpr int LG = 4, J = 8, SPW = kWave / LG, C = 8, A = 4;   // C rows per segment, A segments between two anchors
 constexpr int kCkD2 = 9;                                       // double2 per lane and checkpoint: SX[2][8] + F[2]
 
@@ -522,6 +525,10 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
 #pragma unroll
   for (int q = 0; q < J; ++q) { SX[0][q] = 0.0; SX[1][q] = 0.0; }
   double tref = 0.0, gtop[2] = {1.0, 1.0}, igtop[2] = {1.0, 1.0};
+  double hA[NV], hY[NV], hT[NV];   // the held upper halves (see the flush at the end of a segment)
+  bool hAok[NV], hTok[NV];
+#pragma unroll
+  for (int m = 0; m < NV; ++m) { hA[m] = hY[m] = hT[m] = 0.0; hAok[m] = hTok[m] = false; }
   int bq = 0;   // buffer of oBT the current segment writes
   for (int64_t k = nseg - 1; k >= 0; --k) {
     const int64_t n_lo = 1 + k * C;
@@ -677,22 +684,52 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
     }
     gtop[0] = gv[0][0]; gtop[1] = gv[0][1]; igtop[0] = igv[0][0]; igtop[1] = igv[0][1];
     lds_order();
+    // The scalar gradients of a segment are an aligned run of 8 rows = HALF a 128-byte line per series.  Written when they are ready,
+    // the two halves of a line reach memory eight steps apart -- the line has left L2 in between and each half is merged on the
+    // memory side on its own (a read-modify-write: 11 - 15 % of the one-lane reverse sweep, profiles/r06_halflines.md).  So the
+    // UPPER half (rows 16 i + 8 ..) waits in a register per lane and stream and leaves with the lower half, back to back
+    // (C2Q4_PAIRLINES=0: as they come).
 #pragma unroll
     for (int m = 0; m < NV; ++m) {   // (slots beyond the batch hold copies of its last series: same values, same addresses)
       if (ok8[m]) {
-        if (srow < cnt) {
-          bab8[m][n_lo - 1 + srow] = oBA[ssl[m]][srow];
-          byb8[m][n_lo - 1 + srow] = oBY[ssl[m]][srow];
+        const double vA = oBA[ssl[m]][srow], vY = oBY[ssl[m]][srow];
+        const double vT = srow == 0 ? oBT[bq][ssl[m]][C - 1] : oBT[bq ^ 1][ssl[m]][srow - 1];
+        const bool tv = n_lo + C - 1 + srow < N;
+#if C2Q4_PAIRLINES
+        if (k & 1) {                       // rows 8 k ..: the upper half of their lines
+          hA[m] = vA; hY[m] = vY; hAok[m] = srow < cnt;
+        } else {
+          if (srow < cnt) bab8[m][n_lo - 1 + srow] = vA;
+          if (hAok[m]) bab8[m][n_lo - 1 + C + srow] = hA[m];
+          if (srow < cnt) byb8[m][n_lo - 1 + srow] = vY;
+          if (hAok[m]) byb8[m][n_lo - 1 + C + srow] = hY[m];
+          hAok[m] = false;
         }
-        if (n_lo + C - 1 + srow < N) btb8[m][n_lo + C - 1 + srow] = srow == 0 ? oBT[bq][ssl[m]][C - 1] : oBT[bq ^ 1][ssl[m]][srow - 1];
+        if ((k + 1) & 1) {                 // bt of rows 8 (k + 1) ..
+          hT[m] = vT; hTok[m] = tv;
+        } else {
+          if (tv) btb8[m][n_lo + C - 1 + srow] = vT;
+          if (hTok[m]) btb8[m][n_lo + 2 * C - 1 + srow] = hT[m];
+          hTok[m] = false;
+        }
+#else
+        if (srow < cnt) {
+          bab8[m][n_lo - 1 + srow] = vA;
+          byb8[m][n_lo - 1 + srow] = vY;
+        }
+        if (tv) btb8[m][n_lo + C - 1 + srow] = vT;
+#endif
       }
     }
     bq ^= 1;
     lds_order();
   }
 #pragma unroll
-  for (int m = 0; m < NV; ++m) {   // the rows of bt the first segment left behind (1 .. C - 1; row 0 below)
+  for (int m = 0; m < NV; ++m) {   // the rows of bt the first segment left behind (1 .. C - 1; row 0 below) + their line's upper half
     if (ok8[m] && srow >= 1 && srow < N) btb8[m][srow] = oBT[bq ^ 1][ssl[m]][srow - 1];
+#if C2Q4_PAIRLINES
+    if (ok8[m] && hTok[m]) btb8[m][C + srow] = hT[m];
+#endif
   }
   if (nseg == 0) {   // N == 1
     const double rd0 = 1.0 / carDZ.x, cz = carDZ.y;

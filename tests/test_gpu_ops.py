@@ -559,6 +559,29 @@ def test_group_mapping_backward_recursion_and_its_fallback(ops, oracle, monkeypa
         monkeypatch.delenv("C2_LOGLIK_LINES")
 
 
+@pytest.mark.parametrize("lanes", ["8", "4", "2", "1"])
+def test_scalar_gradient_lines_every_length(ops, oracle, monkeypatch, lanes):
+    """Round 6: the reverse sweeps hand the per-series scalar gradients (ba, by, bt) over as whole 128-byte lines -- sixteen-row tiles
+    (two lanes), the upper half of a line held in a register until the lower half is ready (four and eight lanes) -- instead of
+    8-row runs as they come.  Every series length from 1 to 50 rows (every position of the last row inside a line and a half line,
+    an odd and an even number of 8-row segments, a first segment that is the upper or the lower half), ragged wavefronts, each lane
+    mapping forced, all six gradients against the oracle."""
+    monkeypatch.setenv("C2_LANES", lanes)
+    if lanes == "4":
+        monkeypatch.setenv("C2_LOGLIK_Q4_LINES", "1")
+    J, B = 8, 70
+    for N in range(1, 51):
+        t, c, a, U, V, y = dense.synthetic_batch(B, max(N, 2), J)
+        t, a, U, V, y = (np.ascontiguousarray(v[:, :N]) for v in (t, a, U, V, y))
+        llo, go, flo = oracle.loglik_grad_batched(t, c, a, U, V, y, nthreads=2)
+        assert int(np.abs(flo).sum()) == 0
+        ll, grads, flag = ops.loglik_grad(*dev(t, c, a, U, V, y))
+        assert int(flag.abs().sum()) == 0, N
+        close(ll, llo)
+        for g, e in zip(grads, go):
+            close(g, e, floor=4e-12)
+
+
 @pytest.mark.parametrize("lines", ["1", "0"])
 @pytest.mark.parametrize("N", [1, 2, 9, 32, 33, 34, 64, 65, 66, 97, 130, 300])
 def test_four_lane_pair_scaled_frame_and_its_fallback(ops, oracle, monkeypatch, N, lines):

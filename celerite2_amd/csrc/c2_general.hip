@@ -25,14 +25,25 @@
 namespace c2g {
 using namespace c2;
 
-template <int KL, int JM, bool LOWER, bool WF>
+// CH (round 6): a small batch with many right-hand sides is a handful of wavefronts on a chain of N + M events (64 series x 256
+// columns: 256 wavefronts, 2.9 ms).  The state's propagator is DIAGONAL -- pure decay -- so the t2 grid is cut into chunks of Lc
+// rows (blockIdx.z) and the same kernel runs twice: CH = 1 absorbs a chunk's rows from a zero state (no outputs) and leaves
+// the sum in Gbuf; k_general_chain turns the sums into the state every chunk starts from (F_start(k + 1) = exp(-c dt_k) o
+// F_start(k) + G_k); CH = 2 runs the event loop of chunk k from that state over the outputs whose last absorbed row lies in
+// the chunk.  Which outputs those are is decided with the SAME comparisons the merge itself makes (a binary search on the
+// absorb predicate), so ties fall where the sequential merge puts them.  No workspace F in this form.
+// Gbuf: [series][chunk][JM][ncolp] (columns fastest).
+template <int KL, int JM, bool LOWER, bool WF, int CH = 0>
 __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_t M, int J, int64_t nrhs,
                                                     const double *__restrict__ t1, int64_t t1_bs,
                                                     const double *__restrict__ t2, int64_t t2_bs,
                                                     const double *__restrict__ c, int64_t c_bs,
                                                     const double *__restrict__ U, const double *__restrict__ V,
-                                                    const double *__restrict__ Y, double *Z, double *F, int zero_z) {
+                                                    const double *__restrict__ Y, double *Z, double *F, int zero_z,
+                                                    int64_t Lc = 0, int64_t K = 1, double *__restrict__ Gbuf = nullptr,
+                                                    int64_t ncolp = 0) {
   static_assert(JM <= KL, "the lanes of a series also carry its width-J vectors");
+  static_assert(CH == 0 || !WF, "no workspace in the chunked form");
   constexpr int SPW = kWave / KL;
   // decay vector, event row; two doubles of padding per vector: a series' pair is 16 (KL + 2) bytes from the next one's, so
   // the b128 broadcasts of the SPW series of a wavefront fall into distinct banks (unpadded, KL = 8: 128-byte stride, four
@@ -57,9 +68,13 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   auto rowN = [&](int64_t s) { return LOWER ? s : N - 1 - s; };
   auto rowM = [&](int64_t s) { return LOWER ? s : M - 1 - s; };
 
+  // chunk kc absorbs the positions [a0, a1) of the t2 grid (position 0 is the state the walk starts from)
+  const int64_t kc = CH ? (int64_t)blockIdx.z : 0;
+  const int64_t a0 = CH ? 1 + kc * Lc : 1, a1 = CH ? ((a0 + Lc < M) ? a0 + Lc : M) : M;
+  double *gb = CH ? Gbuf + ((b * K + kc) * JM) * ncolp + (int64_t)blockIdx.y * KL + k : nullptr;   // element j at gb[j * ncolp]
   // state after the first t2 row (forward.hpp:297-300 / 358-361)
   double Fj[JM];
-  {
+  if (CH == 0 || kc == 0) {
     const double y0 = Yb[rowM(0) * nrhs];
     rowbuf[sl][1][k] = actj ? Vb[rowM(0) * J] : 0.0;
     lds_order();
@@ -69,13 +84,31 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
     if (WF && vk) {
       for (int j = 0; j < J; ++j) Fb[(LOWER ? 0 : 0) * J * nrhs + (int64_t)j * nrhs] = LOWER ? Fj[j] : 0.0;  // row 0
     }
+  } else if (CH == 1) {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) Fj[j] = 0.0;
+  } else {
+#pragma unroll
+    for (int j = 0; j < JM; ++j) Fj[j] = gb[j * ncolp];   // the state after position a0 - 1 (k_general_chain)
   }
-  const double tfirst = t2b[rowM(0)];
-  // outputs on the near side of the first t2 row get nothing (forward.hpp:303-306 / 364-367); the F rows stay
-  // untouched if there is no output at all beyond it
-  int64_t n = 0;
-  while (n < N && (LOWER ? t1b[rowN(n)] < tfirst : t1b[rowN(n)] >= tfirst)) ++n;
-  int64_t m = 1;
+  const double tfirst = t2b[rowM(a0 - 1)];
+  // lower: a row is absorbed in front of an output while t2[m] <= t1[n]; upper (walking down): while t2[m] > t1[n]
+  auto absorbed = [&](double tm_, double tn_) { return LOWER ? tm_ <= tn_ : tm_ > tn_; };
+  // the first output behind position pm of the t2 grid: outputs on the near side of it get nothing from it (forward.hpp:303-306 /
+  // 364-367).  The predicate is monotone along the walk: a binary search (the first version walked the outputs one by one)
+  auto first_output_behind = [&](int64_t pm) {
+    const double tp = t2b[rowM(pm)];
+    int64_t lo = 0, hi = N;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (absorbed(tp, t1b[rowN(mid)])) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  int64_t n = CH == 1 ? 0 : first_output_behind(a0 - 1);
+  // the outputs of this chunk: those whose last absorbed row lies in it (the last row of a chunk opens the next chunk's)
+  const int64_t n_end = (CH == 2 && kc + 1 < K) ? first_output_behind(a1 - 1) : N;
+  int64_t m = a0;
   double tlast = tfirst;
   // the next row of either stream (clamped at the end of its grid)
   auto clampN = [&](int64_t s) { return rowN(s < N ? s : N - 1); };
@@ -122,7 +155,7 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   // product per address and 64-bit compares / selects per clamp were a fifth of the loop's instructions, and the loop is
   // bound by its instruction count: one wavefront per SIMD at 8192 series x 8 right-hand sides)
   int mi = (int)m, ni = (int)n;
-  const int Ni = (int)N, Mi = (int)M, nr = (int)nrhs;
+  const int Ni = (int)N, Mi = (int)M, nr = (int)nrhs, a1i = (int)a1, nEnd = (int)n_end;   // (CH = 2: the chunk's outputs end at n_end; Ni, Mi also map positions to rows)
   double tm = rg[mi & (RD - 1)], tn = rg[RD + (ni & (RD - 1))];
   double tm1 = rg[(mi + 1) & (RD - 1)], tn1 = rg[RD + ((ni + 1) & (RD - 1))];
   struct Pend { double t, r, x; int slot; };
@@ -130,10 +163,10 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   Pend p0{0.0, 0.0, 0.0, 2 * RD}, p1 = p0, p2 = p0, p3 = p0, p4 = p0, p5 = p0;
   int q = 0;   // rowbuf[sl][q]: the decay vector of the event whose back half runs in this iteration
   auto front = [&](Pend &issue, Ev &ev) __attribute__((always_inline)) {
-    const bool live = ni < Ni;
-    // lower: absorb while t2[m] <= t1[n];  upper (walking down): absorb while t2[m] > t1[n]
-    const bool absorb = live && mi < Mi && (LOWER ? tm <= tn : tm > tn);
-    const bool emit = live && !absorb;
+    // lower: absorb while t2[m] <= t1[n];  upper (walking down): absorb while t2[m] > t1[n];  CH = 1: the chunk's rows, no outputs
+    const bool live = CH == 1 ? mi < a1i : ni < nEnd;
+    const bool absorb = CH == 1 ? live : (live && mi < Mi && (LOWER ? tm <= tn : tm > tn));
+    const bool emit = CH == 1 ? false : (live && !absorb);
     const int pos = absorb ? mi : ni;                        // position of the event's row along its stream
     const int len1 = (absorb ? Mi : Ni) - 1;
     const int so = (pos & (RD - 1)) + (absorb ? 0 : RD);     // the event's row in the ring
@@ -235,7 +268,7 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
   for (int j = 0; j < JM; ++j) ea.r[j] = 0.0;
   rowbuf[sl][0][k] = 1.0;   // (the decay vector of the empty event in front of the first one)
   lds_order();
-  bool more = __any(ni < Ni);
+  bool more = __any(CH == 1 ? mi < a1i : ni < nEnd);
   double pv[JM];
   while (more) {
     back_load(pv); front(p0, eb); back(ea, pv, p1);
@@ -244,18 +277,94 @@ __global__ __launch_bounds__(kWave) void k_generalK(int64_t B, int64_t N, int64_
     back_load(pv); front(p3, ea); back(eb, pv, p4);
     back_load(pv); front(p4, eb); back(ea, pv, p5);
     back_load(pv); front(p5, ea); back(eb, pv, p0);
-    more = __any(ni < Ni);
+    more = __any(CH == 1 ? mi < a1i : ni < nEnd);
   }
   {   // the back half of the last event
     Pend none{0.0, 0.0, 0.0, 2 * RD};
     back_load(pv);
     back(ea, pv, none);
   }
+  if constexpr (CH == 1) {   // the chunk's sum, at the time of its last row
+    if (vb) {
+#pragma unroll
+      for (int j = 0; j < JM; ++j) gb[j * ncolp] = Fj[j];
+    }
+  }
+}
+
+// Gbuf[chunk] <- the state the chunk starts from (it held the chunk's sum G_k): F_start(k + 1) = exp(-c |t_end(k) - t_end(k - 1)|) o
+// F_start(k) + G_k, t_end(k) the time of the chunk's last row (t_end(-1): the first row of the grid).  A thread per (series, column).
+template <int JM, bool LOWER>
+__global__ __launch_bounds__(kWave) void k_general_chain(int64_t M, int J, int64_t Lc, int64_t K, const double *__restrict__ t2,
+                                                         int64_t t2_bs, const double *__restrict__ c, int64_t c_bs,
+                                                         double *__restrict__ Gbuf, int64_t ncolp) {
+  const int64_t b = blockIdx.y, col = (int64_t)blockIdx.x * kWave + threadIdx.x;   // (ncolp is a multiple of 64)
+  const double *t2b = t2 + b * t2_bs;
+  auto rowM = [&](int64_t s) { return LOWER ? s : M - 1 - s; };
+  double S[JM], cj[JM];
+#pragma unroll
+  for (int j = 0; j < JM; ++j) { S[j] = 0.0; cj[j] = j < J ? c[b * c_bs + j] : 0.0; }
+  double tprev = t2b[rowM(0)];
+  for (int64_t kc = 0; kc < K; ++kc) {
+    const int64_t a0 = 1 + kc * Lc, a1 = (a0 + Lc < M) ? a0 + Lc : M;
+    double *gb = Gbuf + ((b * K + kc) * JM) * ncolp + col;
+    const double tend = t2b[rowM(a1 - 1)];
+    const double dt = LOWER ? tprev - tend : tend - tprev;   // (the negative difference inside, as in the event loop)
+    tprev = tend;
+#pragma unroll
+    for (int j = 0; j < JM; ++j) {
+      const double g = gb[j * ncolp];
+      if (kc > 0) gb[j * ncolp] = S[j];
+      S[j] = fma(exp_decay(cj[j] * dt), S[j], g);
+    }
+  }
 }
 
 }  // namespace c2g
 
 using namespace c2g;
+
+// Many right-hand sides on a small batch, cut along time (CH above).  scratch: c2_internal_general_chunks_doubles doubles; Lc from
+// c2_internal_general_chunks_plan.  Z accumulates as in the plain form; no workspace.
+extern "C" int64_t c2_internal_general_chunks_plan(int64_t B, int64_t M, int64_t nrhs) {
+  if (nrhs < 33 || M < 1024 || B > 65535) return 0;            // (64 lanes per series and tile)
+  const int64_t waves = B * ((nrhs + 63) / 64);
+  if (waves >= 1024) return 0;                                   // the chip is full without chunks
+  int64_t K = 4096 / waves;                                      // ~ four wavefronts per SIMD
+  if (K > (M - 1) / 128) K = (M - 1) / 128;                      // chunks of at least 128 rows
+  if (K < 2) return 0;
+  int64_t Lc = (M - 1 + K - 1) / K;
+  return (Lc + 7) & ~(int64_t)7;
+}
+extern "C" size_t c2_internal_general_chunks_doubles(int64_t B, int64_t M, int64_t J, int64_t nrhs, int64_t Lc) {
+  if (Lc < 1 || J > 32) return 0;
+  const int64_t K = (M - 1 + Lc - 1) / Lc, JM = J <= 8 ? 8 : (J <= 16 ? 16 : 32), ncolp = ((nrhs + 63) / 64) * 64;
+  return (size_t)(B * K * JM * ncolp);
+}
+extern "C" int c2_internal_general_chunks(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, int64_t Lc,
+                                          const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c,
+                                          int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
+                                          double *scratch, c2_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (N > 2147483600 || M > 2147483600 || nrhs > 2147483600 || Lc < 1 || M < 2 || J > 32 || B > 65535) return C2_ERR_UNSUPPORTED;
+  const int64_t K = (M - 1 + Lc - 1) / Lc, ntile = (nrhs + 63) / 64, ncolp = ntile * 64;
+  if (K > 65535) return C2_ERR_UNSUPPORTED;
+  const int JM = J <= 8 ? 8 : (J <= 16 ? 16 : 32);
+  const dim3 grid((unsigned)B, (unsigned)ntile, (unsigned)K), gc((unsigned)ntile, (unsigned)B);
+#define C2_GC(JM_, LO)                                                                                                         \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL((k_generalK<64, JM_, LO, false, 1>), grid, dim3(kWave), 0, s, B, N, M, (int)J, nrhs, t1, t1_bs, t2, t2_bs, c, \
+                       c_bs, U, V, Y, Z, (double *)nullptr, 0, Lc, K, scratch, ncolp);                                         \
+    hipLaunchKernelGGL((k_general_chain<JM_, LO>), gc, dim3(kWave), 0, s, M, (int)J, Lc, K, t2, t2_bs, c, c_bs, scratch, ncolp);    \
+    hipLaunchKernelGGL((k_generalK<64, JM_, LO, false, 2>), grid, dim3(kWave), 0, s, B, N, M, (int)J, nrhs, t1, t1_bs, t2, t2_bs, c, \
+                       c_bs, U, V, Y, Z, (double *)nullptr, 0, Lc, K, scratch, ncolp);                                         \
+  } while (0)
+  if (JM == 8) { if (lower) C2_GC(8, true); else C2_GC(8, false); }
+  else if (JM == 16) { if (lower) C2_GC(16, true); else C2_GC(16, false); }
+  else { if (lower) C2_GC(32, true); else C2_GC(32, false); }
+#undef C2_GC
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
 
 // lower != 0: general_matmul_lower, else upper.  Returns C2_ERR_UNSUPPORTED for shapes the mapping does not cover.
 extern "C" int c2_internal_generalK(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, const double *t1,

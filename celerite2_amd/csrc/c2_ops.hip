@@ -1621,6 +1621,12 @@ extern "C" int c2_internal_general_tile(int lower, int64_t B, int64_t N, int64_t
                                         int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
                                         double *F, double *scratch, c2_stream_t stream);
 extern "C" size_t c2_internal_general_tile_doubles(int64_t B, int64_t M, int64_t J, int64_t nrhs);
+extern "C" int64_t c2_internal_general_chunks_plan(int64_t B, int64_t M, int64_t nrhs);
+extern "C" size_t c2_internal_general_chunks_doubles(int64_t B, int64_t M, int64_t J, int64_t nrhs, int64_t Lc);
+extern "C" int c2_internal_general_chunks(int lower, int64_t B, int64_t N, int64_t M, int64_t J, int64_t nrhs, int64_t Lc,
+                                          const double *t1, int64_t t1_bs, const double *t2, int64_t t2_bs, const double *c,
+                                          int64_t c_bs, const double *U, const double *V, const double *Y, double *Z,
+                                          double *scratch, c2_stream_t stream);
 static bool use_general_tile() {
   return !(opt::has(opt::k_general_tile) && opt::ival(opt::k_general_tile) == 0);   // 0: the kernels below (A/B runs, tests of every path)
 }
@@ -1642,6 +1648,26 @@ static int launch_general(int64_t B, int64_t N, int64_t M, int64_t J, int64_t nr
   // a wavefront per series, lanes over 64 consecutive rows of either grid (c2_general_tile.hip)
   // (three right-hand sides on a large batch: lanes over the right-hand sides are ahead, 3.45 against 3.79 ms at B = 8192,
   // N = M = 4096, J = 8, in-process A/B; small batches keep the tiles, which cut long series into chunks)
+  // many right-hand sides on a small batch (the products of the predictive covariance, core.py:142-150): lanes over the right-hand
+  // sides, the t2 grid cut into chunks that run in parallel (c2_general.hip, CH).  Scratch is a stream-ordered temporary; not inside
+  // graph captures.
+  if (!F && nrhs >= 33 && M >= 2 && use_generalK()) {
+    int64_t Lc = c2_internal_general_chunks_plan(B, M, nrhs);
+    if (opt::has(opt::k_general_rhs_chunks)) Lc = opt::ival(opt::k_general_rhs_chunks) >= 8 ? opt::ival(opt::k_general_rhs_chunks) : 0;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);
+    if (Lc > 0 && capturing == hipStreamCaptureStatusNone) {
+      const size_t nd = c2_internal_general_chunks_doubles(B, M, J, nrhs, Lc);
+      void *tmp = nullptr;
+      if (nd > 0 && c2::temp_alloc(&tmp, nd * sizeof(double), s) == hipSuccess) {
+        int rc = c2_internal_general_chunks(LOWER ? 1 : 0, B, N, M, J, nrhs, Lc, t1, t1_bs, t2, t2_bs, c, c_bs, U, V, Y, Z, (double *)tmp,
+                                            stream);
+        if (hipFreeAsync(tmp, s) != hipSuccess && rc == C2_OK) rc = C2_ERR_HIP;
+        if (rc != C2_ERR_UNSUPPORTED) return rc;
+      }
+      (void)hipGetLastError();
+    }
+  }
   if (use_general_tile() && !(nrhs == 3 && B >= 512 && use_generalK())) {
     // small batches of long series are cut into chunks along time: a stream-ordered temporary for the chunk maps (not
     // inside a graph capture, and one wavefront per series if the allocation fails)

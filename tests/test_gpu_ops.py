@@ -1695,6 +1695,52 @@ def test_general_matmul_batched(ops, oracle, monkeypatch, J, nrhs, N, M, tile):
         close(Zz, Zo - Z0)
 
 
+@pytest.mark.parametrize("J,nrhs,N,M,Lc", [(8, 33, 50, 300, 64), (8, 64, 257, 1030, 128), (8, 100, 700, 701, 96), (4, 256, 64, 2100, 256),
+                                           (12, 70, 300, 520, 8), (16, 64, 129, 1500, 200), (24, 40, 90, 400, 56), (8, 65, 1, 900, 128),
+                                           (8, 64, 400, 2, 8), (8, 256, 256, 4096, None)])
+def test_general_matmul_many_rhs_chunked_along_time(ops, oracle, monkeypatch, J, nrhs, N, M, Lc):
+    """Round 6: general_matmul_* with many right-hand sides on a small batch cut into chunks of the t2 grid (c2_general.hip, CH: chunk
+    sums, a diagonal chain, the event loop per chunk from its true start state over the outputs whose last absorbed row lies in the
+    chunk).  Forced chunk lengths that do not divide the grid, chunks without any output, every output before / after the grid, ties
+    between the grids ON chunk boundaries and runs of identical times across them, a grid of two rows, one output; the last case is
+    the shape of the predictive covariance under the automatic plan -- against the sequential-merge oracle and against the unchunked
+    kernel (C2_GENERAL_RHS_CHUNKS=0)."""
+    B = 3
+    rng = np.random.default_rng(31 * J + nrhs + N + M)
+    Je = J if J % 2 == 0 else J + 1
+    t2, c, a, Ue, Ve, y = dense.synthetic_batch(B, max(M, 2), Je)
+    t2 = np.ascontiguousarray(t2[:, :M]); V = np.ascontiguousarray(Ve[:, :M, :J]); c = np.ascontiguousarray(c[:, :J])
+    lo, hi = t2[:, :1], t2[:, -1:]
+    t1 = np.sort(lo - 0.2 * (hi - lo + 1.0) + (1.4 * (hi - lo + 1.0)) * rng.random((B, N)), axis=1)
+    L = Lc or 256
+    if N > 8 and M > 2 * L + 2:
+        # outputs exactly ON the rows around the first two chunk boundaries (positions 1 + k L), repeated; a run of equal t2 across one
+        t2[0, L + 1] = t2[0, L]; t2[0, L + 2] = t2[0, L]
+        t1[0, :6] = [t2[0, L - 1], t2[0, L], t2[0, L], t2[0, L + 1], t2[0, 2 * L], t2[0, 2 * L + 1]]
+        t1[1, :] = np.sort(t2[1, 0] - 1.0 - rng.random(N))    # every output before the grid
+        t1[2, :N // 2] = np.sort(t2[2, -1] + 0.5 + rng.random(N // 2))   # half of them after it, none inside the middle chunks
+        t1[2, N // 2:] = t2[2, 0] + 1e-3 * rng.random(N - N // 2)
+        t1 = np.sort(t1, axis=1)
+    U = rng.standard_normal((B, N, J))
+    Y = rng.standard_normal((B, M, nrhs))
+    t1d, t2d, cd, Ud, Vd, Yd = dev(t1, t2, c, U, V, Y)
+    for name in ("general_matmul_lower", "general_matmul_upper"):
+        Z0 = rng.standard_normal((B, N, nrhs))
+        Zo = Z0.copy(); Fo = np.zeros((B, M, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name)(t1[b], t2[b], c[b], U[b], V[b], Y[b], Zo[b], Fo[b])
+        if Lc is None: monkeypatch.delenv("C2_GENERAL_RHS_CHUNKS", raising=False)
+        else: monkeypatch.setenv("C2_GENERAL_RHS_CHUNKS", str(Lc))
+        (Zd,) = dev(Z0)
+        Zd = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zd)
+        close(Zd, Zo)
+        monkeypatch.setenv("C2_GENERAL_RHS_CHUNKS", "0")
+        (Zu,) = dev(Z0)
+        Zu = getattr(ops, name)(t1d, t2d, cd, Ud, Vd, Yd, Z=Zu)
+        close(Zu, Zo)
+        close(Zd, Zu.cpu().numpy(), tol=1e-12, floor=1e-13)
+
+
 @pytest.mark.parametrize("J,nrhs,N,M", [(8, 1, 64, 64), (8, 1, 128, 129), (8, 1, 1000, 300), (8, 1, 70, 2000), (4, 2, 513, 511),
                                         (8, 4, 300, 257), (5, 3, 190, 640), (16, 1, 200, 200), (11, 2, 130, 65),
                                         (1, 1, 65, 1), (2, 4, 1, 200), (8, 1, 4096, 4096), (8, 1, 4500, 5000),

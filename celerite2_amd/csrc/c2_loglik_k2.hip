@@ -38,6 +38,43 @@
 namespace c2k2 {
 using namespace c2;
 
+// Streaming hints (C2K2_NT; see C2T_NT in c2_loglik_t.hip): every byte of this pair is touched once.  With the scalar gradients leaving as
+// whole lines (STR = 16 below) nothing has to SURVIVE in L2 here, so the hint is worth less than in the one-lane pair.
+#ifndef C2K2_NT
+#define C2K2_NT 0
+#endif
+typedef double k2d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld2s(const double2 *p) {
+#if C2K2_NT
+  const k2d2v v = __builtin_nontemporal_load(reinterpret_cast<const k2d2v *>(p));
+  return make_double2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ double ld1s(const double *p) {
+#if C2K2_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st2s(double2 *p, double2 v) {
+#if C2K2_NT
+  k2d2v w; w.x = v.x; w.y = v.y;
+  __builtin_nontemporal_store(w, reinterpret_cast<k2d2v *>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st1s(double *p, double v) {
+#if C2K2_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 constexpr int J = 8, NL = 20, SPW = 32, C = 32, ST = 8;
 constexpr int RSTR = 2 * J;       // LDS stride (doubles) of a series in a two-row tile: one 128-byte line, its eight 16-byte
                                   // pieces XOR-swizzled by the series (swz) -- see row_read
@@ -97,7 +134,7 @@ __device__ __forceinline__ void row_fetch(const double *__restrict__ base, int64
   const int64_t off = r * J + 2 * (lane & 3);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const double2 v = *reinterpret_cast<const double2 *>(base + (int64_t)clamp_series<FULL>(8 * i + lane / 8, last) * N * J + off);
+    const double2 v = ld2s(reinterpret_cast<const double2 *>(base + (int64_t)clamp_series<FULL>(8 * i + lane / 8, last) * N * J + off));
     st[2 * i] = v.x; st[2 * i + 1] = v.y;
   }
 }
@@ -139,7 +176,7 @@ __device__ __forceinline__ void row_flush(double *__restrict__ base, int64_t N, 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       if (FULL || 8 * i + lane / 8 <= last)
-        *reinterpret_cast<double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + r * J + 2 * (lane & 3)) = v[i];
+        st2s(reinterpret_cast<double2 *>(base + (int64_t)(8 * i + lane / 8) * N * J + r * J + 2 * (lane & 3)), v[i]);
   }
 }
 // per-series scalar streams in 16-row tiles: one instruction moves 4 series x 128 bytes
@@ -149,7 +186,7 @@ __device__ __forceinline__ void sc_fetch16(const double *__restrict__ base, int6
   int64_t r = n16 + (lane & 15);
   r = r < 0 ? 0 : (r > N - 1 ? N - 1 : r);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) st[i] = base[(int64_t)clamp_series<FULL>(4 * i + lane / 16, last) * sN + r];
+  for (int i = 0; i < 8; ++i) st[i] = ld1s(&base[(int64_t)clamp_series<FULL>(4 * i + lane / 16, last) * sN + r]);
 }
 __device__ __forceinline__ void sc_stage16(double *tile, int lane, int half, const double (&st)[8]) {
   if (((lane & 15) >> 3) == half) {
@@ -247,18 +284,18 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   auto write_ckpt = [&](int64_t row) __attribute__((always_inline)) {   // the state as it stands = state after `row`
     double *ck = recCK + (size_t)slot * CKD * kWave;
 #pragma unroll
-    for (int e = 0; e < NL; ++e) ck[e * kWave + lane] = S[e];
+    for (int e = 0; e < NL; ++e) st1s(&ck[e * kWave + lane], S[e]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ck[(NL + j) * kWave + lane] = F[j];
+    for (int j = 0; j < 4; ++j) st1s(&ck[(NL + j) * kWave + lane], F[j]);
     ++slot;
     lastck = row;
   };
   auto write_rec = [&](int64_t n, bool seg_end) __attribute__((always_inline)) {
-    recW[((size_t)n * 4 + 2 * h) * SPW + sl] = make_double2(w[0], w[1]);        // local 0..3 = global 4h .. 4h+3
-    recW[((size_t)n * 4 + 2 * h + 1) * SPW + sl] = make_double2(w[2], w[3]);
+    st2s(&recW[((size_t)n * 4 + 2 * h) * SPW + sl], make_double2(w[0], w[1]));        // local 0..3 = global 4h .. 4h+3
+    st2s(&recW[((size_t)n * 4 + 2 * h + 1) * SPW + sl], make_double2(w[2], w[3]));
     if (h == 0) {
-      recDZ[(size_t)n * SPW + sl] = make_double2(seg_end ? -fabs(d) : fabs(d), z);   // the sign of d: this row carries a checkpoint
-      recT[(size_t)n * SPW + sl] = tprev;
+      st2s(&recDZ[(size_t)n * SPW + sl], make_double2(seg_end ? -fabs(d) : fabs(d), z));   // the sign of d: this row carries a checkpoint
+      st1s(&recT[(size_t)n * SPW + sl], tprev);
     }
     if (seg_end) write_ckpt(n);   // (wavefront-uniform)
   };
@@ -493,10 +530,10 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     for (int q = 0; q < NL / 2; ++q) Sl[q * kWave] = make_double2(ck[(2 * q) * kWave + lane], ck[(2 * q + 1) * kWave + lane]);
 #else
 #pragma unroll
-    for (int e = 0; e < NL; ++e) S[e] = ck[e * kWave + lane];
+    for (int e = 0; e < NL; ++e) S[e] = ld1s(&ck[e * kWave + lane]);
 #endif
 #pragma unroll
-    for (int j = 0; j < 4; ++j) F[j] = ck[(NL + j) * kWave + lane];
+    for (int j = 0; j < 4; ++j) F[j] = ld1s(&ck[(NL + j) * kWave + lane]);
   };
   auto w_fetch = [&](int64_t row, double (&wv)[J]) {
     row = row < 0 ? 0 : row;
@@ -505,7 +542,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #endif
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double2 v = recW[((size_t)row * 4 + ((q + 2 * h) & 3)) * SPW + sl];
+      const double2 v = ld2s(&recW[((size_t)row * 4 + ((q + 2 * h) & 3)) * SPW + sl]);
       wv[2 * q] = v.x; wv[2 * q + 1] = v.y;
     }
   };
@@ -513,8 +550,8 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)((row < 0 ? 0 : row) & 3) * SPW + sl]; };
   auto t_fetch = [&](int64_t row) { return recT[(size_t)((row < 0 ? 0 : row) & 3) * SPW + sl]; };
 #else
-  auto dz_fetch = [&](int64_t row) { return recDZ[(size_t)(row < 0 ? 0 : row) * SPW + sl]; };
-  auto t_fetch = [&](int64_t row) { return recT[(size_t)(row < 0 ? 0 : row) * SPW + sl]; };
+  auto dz_fetch = [&](int64_t row) { return ld2s(&recDZ[(size_t)(row < 0 ? 0 : row) * SPW + sl]); };
+  auto t_fetch = [&](int64_t row) { return ld1s(&recT[(size_t)(row < 0 ? 0 : row) * SPW + sl]); };
 #endif
 
   if (N >= 2) {

@@ -1,3 +1,7 @@
+#!/bin/bash
+# tools/ab_fresh.sh: the bench step in FRESH processes, the current library alternating with A/B builds (tools/build_variant.sh) on one box --
+# process-to-process and box-to-box spreads are as large as a round's gains, so every change of round 6's second session was judged this way.
+#   AB_BATCH=<series per GPU, default 65536> AB_REPS=<pairs, default 3> AB_VARIANTS="<tag> ..." bash tools/ab_fresh.sh
 R=${GRAFT_REPO_ROOT:-/root/repo}
 B=${AB_BATCH:-65536}
 one() { local label=$1; shift

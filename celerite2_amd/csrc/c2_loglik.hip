@@ -1426,14 +1426,24 @@ extern "C" int c2_internal_tpg_short_chunks(int64_t B, int64_t N) {
   return N <= opt::ival(opt::k_tpg_rows16_max_rows) ? 2 : 1;   // the shortest chunks while the chains stay short
 }
 #define C2_TPG_PICK(stem) (c2_internal_tpg_short_chunks(B, N) == 2 ? stem##16 : (c2_internal_tpg_short_chunks(B, N) == 1 ? stem##32 : stem##64))
+// ... of the log-likelihood GRADIENT: between 4096 and 9216 chunks of 64 rows, chunks of 32 (round 6, tools/tpg_rows_probe.py, N = 4096, J = 8,
+// ms with chunks of 16 / 32 / 64 rows: 80 series 0.94 / 0.75 / 0.89, 128 series 1.13 / 0.89 / 1.02, 160 series 1.37 / 1.10 / 1.09, 192 series
+// 1.56 / 1.21 / 1.15 -- the sweeps' work does not depend on the chunk length, the chains over the chunks do, and 64-row chunks fill a
+// quarter of the chip at 128 series)
+static int tpg_short_chunks_grad(int64_t B, int64_t N) {
+  const int sh = c2_internal_tpg_short_chunks(B, N);
+  if (sh != 0 || opt::has(opt::k_tpg_rows)) return sh;
+  return B * ((N + 63) / 64) <= 9216 ? 1 : 0;
+}
+#define C2_TPG_PICK_G(stem) (tpg_short_chunks_grad(B, N) == 2 ? stem##16 : (tpg_short_chunks_grad(B, N) == 1 ? stem##32 : stem##64))
 static size_t c2_internal_timepar_grad_doubles(int64_t B, int64_t N, int64_t J) {
-  return C2_TPG_PICK(c2_internal_timepar_grad_doubles)(B, N, J);
+  return C2_TPG_PICK_G(c2_internal_timepar_grad_doubles)(B, N, J);
 }
 static int c2_internal_loglik_grad_timepar(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c,
                                            int64_t c_bs, const double *a, const double *U, const double *V,
                                            const double *y, double *ll, double *bt, double *bc, double *ba, double *bU,
                                            double *bV, double *by, int32_t *flag, double *work, c2_stream_t stream) {
-  return C2_TPG_PICK(c2_internal_loglik_grad_timepar)(
+  return C2_TPG_PICK_G(c2_internal_loglik_grad_timepar)(
       B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, bt, bc, ba, bU, bV, by, flag, work, stream);
 }
 static size_t c2_internal_factor_iter_doubles(int64_t B, int64_t N, int64_t J) {

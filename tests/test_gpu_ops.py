@@ -1547,6 +1547,63 @@ def test_predictive_variance_and_covariance(ops):
         gp.condition(yd, tsd[:2])
 
 
+@pytest.mark.parametrize("tile", ["1", "0"])
+def test_kernel_values_factored_exponential(ops, monkeypatch, tile):
+    """c2_kernel_values on 32 x 64 tiles (round 6: the exponential factored into a row table and one exponential per column, with tmin / tmax
+    the extreme times of a wavefront's eight rows): columns strictly inside a row group's range, exactly on its smallest / largest time,
+    far outside on either side (every factor an exponential of a non-positive argument: gaps of 1e4 time units between the rows of one
+    group), UNSORTED rows and columns, a growing real term (c < 0: the exponential per entry), ragged tile edges; per-series and shared
+    coefficients -- against numpy, and the tile kernel against the thread-per-entry kernel."""
+    import torch
+    monkeypatch.setenv("C2_KERNEL_VALUES_TILE", tile)
+    rng = np.random.default_rng(77)
+    B, N, M, Jr, Jc = 3, 77, 150, 2, 3
+    t1 = rng.uniform(0.0, 40.0, (B, N))
+    t1[0] = np.sort(t1[0]); t1[0, 40:] += 1.0e4             # a gap inside a tile (rows 32 .. 63) and inside a group of eight rows
+    t2 = rng.uniform(-5.0, 45.0, (B, M))
+    t2[0, :8] = t1[0, 8:16]                                   # columns ON the rows of a group (its tmin, its tmax, in between)
+    t2[0, 8:12] = [t1[0, 39] + 10.0, t1[0, 40] - 10.0, 0.5 * (t1[0, 39] + t1[0, 40]), 2.0e4]
+    t2[1] = np.sort(t2[1])
+    ar = rng.uniform(0.5, 2.0, (B, Jr)); cr = rng.uniform(0.05, 0.5, (B, Jr)); cr[2, 1] = -0.01   # one growing term
+    ac = rng.uniform(0.5, 2.0, (B, Jc)); bc = rng.uniform(-0.5, 0.5, (B, Jc)); cc = rng.uniform(0.02, 0.3, (B, Jc)); dc = rng.uniform(0.1, 3.0, (B, Jc))
+    dc[1, 0] = -dc[1, 0]
+    def want(b):
+        tau = np.abs(t1[b][:, None] - t2[b][None, :])
+        k = np.zeros_like(tau)
+        for i in range(Jr): k += ar[b, i] * np.exp(-cr[b, i] * tau)
+        for i in range(Jc): k += np.exp(-cc[b, i] * tau) * (ac[b, i] * np.cos(dc[b, i] * tau) + bc[b, i] * np.sin(dc[b, i] * tau))
+        return k
+    # criterion: 2e-13 of k(0) = sum ar + sum ac per entry (the terms oscillate and cancel: an entry can be 1e-5 of its largest term;
+    # measured against an extended-precision evaluation: 5.5e-14 on tiles -- phases of 3e4 rad through the angle addition -- 9e-16 per entry)
+    K = ops.kernel_values(*dev(ar, cr, ac, bc, cc, dc, t1, t2)).cpu().numpy()
+    for b in range(B):
+        np.testing.assert_allclose(K[b], want(b), rtol=0.0, atol=2e-13 * (ar[b].sum() + ac[b].sum()))
+    Ks = ops.kernel_values(*dev(ar[1], cr[1], ac[1], bc[1], cc[1], dc[1], t1[1], t2[1])).cpu().numpy()   # everything shared: B = 1
+    np.testing.assert_allclose(Ks[0], want(1), rtol=0.0, atol=2e-13 * (ar[1].sum() + ac[1].sum()))
+
+
+@pytest.mark.parametrize("J,K", [(8, 1), (8, 2), (8, 3), (8, 5), (8, 7), (8, 65), (8, 130), (4, 67), (16, 5), (16, 33)])
+def test_many_rhs_solves_over_awkward_chunk_counts(ops, oracle, monkeypatch, J, K):
+    """c2_solve_cols.hip: the chain over the chunks keeps the chunk maps of a series in LDS 64 chunks at a time and requests g four chunks
+    ahead (round 6): series of K chunks of 64 rows with K below the ring depth, not a multiple of it, and beyond one LDS piece (65, 130),
+    a last chunk that is short -- solve_lower / solve_upper with 70 right-hand sides, forced onto the chunk maps, against the oracle."""
+    monkeypatch.setenv("C2_SOLVE_COLS", "1")
+    B, nrhs = 2, 70
+    N = 64 * K - (13 if K > 1 else 20)
+    rng = np.random.default_rng(5 * J + K)
+    t, c, a, U, V, y = dense.synthetic_batch(B, N, J)
+    d_, W = np.empty_like(a), np.empty_like(V)
+    for b in range(B):
+        oracle.factor(t[b], c[b], a[b], U[b], V[b], d_[b], W[b], np.empty((N, J, J)))
+    Y = rng.standard_normal((B, N, nrhs))
+    td, cd, Ud, Wd, Yd = dev(t, c, U, W, Y)
+    for name in ("solve_lower", "solve_upper"):
+        Zo = np.empty_like(Y); Fo = np.empty((B, N, J, nrhs))
+        for b in range(B):
+            getattr(oracle, name + "_fwd")(t[b], c[b], U[b], W[b], Y[b], Zo[b], Fo[b])
+        close(getattr(ops, name)(td, cd, Ud, Wd, Yd, zero_z=True), Zo)
+
+
 @pytest.mark.parametrize("B,N", [(8, 8), (8, 10), (16, 12), (8, 14), (8, 34), (16, 64), (8, 132), (16, 200), (7, 64), (8, 33), (13, 9), (21, 65), (9, 130)])
 def test_multi_rhs_forward_sweeps_by_lines(ops, oracle, B, N):
     """nrhs = J = 8: the four forward sweeps by aligned 128-byte lines (k_sweep8_lines) on the whole wavefronts of the batch,

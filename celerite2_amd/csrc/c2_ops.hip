@@ -1478,13 +1478,14 @@ static bool solve_cols_shape(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   // 1.40 - 1.44, 2048: 2.30 - 2.38, 4096: 4.5; the first model had the chip hold 2048 at the price of one)
   const double w = waves / 1024.0;
   const double rows_ms = 1e-3 * (double)N * 0.26 * wide * (1.0 + 0.33 * w > 1.08 * w ? 1.0 + 0.33 * w : 1.08 * w);
-  // chunk maps over the columns: the launches and their temporary + a price per wavefront-walk of 64 rows.  Re-fitted in round 6
-  // after the first walk lost its 442 registers (c2_solve_cols.hip): 0.09 ms + 2.5e-5 per walk (round 5: 0.10 + 3.4e-5), width 16
-  // 0.20 + 3.4e-5; 64 x 4096 x 512: 1.02 against 1.28 ms row by row, 256 x 4096 x 64: 0.73 against 1.14 -- both were missed
+  // chunk maps over the columns: the launches and their temporary + a price per wavefront-walk of 64 rows.  Re-fitted twice in round 6
+  // (tools/cols_probe.py, 60 shapes): after the first walk lost its 442 registers 0.09 ms + 2.5e-5 per walk (round 5: 0.10 + 3.4e-5), with
+  // the walks on precomputed row records 0.08 + 2.05e-5, width 16 0.20 + 2.9e-5; 64 x 4096 x 512: 0.84 against 1.28 ms row by row,
+  // 256 x 4096 x 128: 1.01 against 1.29 -- both were missed by the first model
   int64_t Lc = 64;
   while (Lc < 1024 && (double)B * (double)((N + Lc - 1) / Lc) * tiles > 8192.0) Lc *= 2;   // (the plan of c2_solve_cols.hip)
   const double K = (double)((N + Lc - 1) / Lc), cw = (double)B * K * (tiles + 1.0) * (double)Lc / 64.0;
-  const double cols_ms = J > 8 ? 0.20 + 3.4e-5 * cw : 0.09 + 2.5e-5 * cw;
+  const double cols_ms = J > 8 ? 0.20 + 2.9e-5 * cw : 0.08 + 2.05e-5 * cw;
   return cols_ms < rows_ms;
 }
 static bool solve_chunks_enabled() {

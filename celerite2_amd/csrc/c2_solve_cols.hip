@@ -32,16 +32,40 @@ using namespace c2;
 template <bool LOWER>
 __device__ __forceinline__ int64_t rowof(int64_t s, int64_t N) { return LOWER ? s : N - 1 - s; }
 
+// Row records (round 6).  What a step needs of its row -- the decay vector p_n, the row fed into the state, the row applied to it -- is
+// the same for every column, every tile of columns and both walks, and the walks are bound by instruction issue (~75 per step, 16 of
+// them the exponential that all 64 lanes evaluate for the J that count).  k_cols_rows writes it ONCE per call as a record of 3 JM
+// doubles per row, zero-padded from J to JM: [series][row][p | A | B]; a walk's step is then ONE load by 3 JM lanes, one LDS write and
+// the broadcast reads -- no exponential, no t.  (The same records read through uniform addresses -- scalar loads straight into the
+// multiply-adds' scalar operand, no LDS at all, 28 VALU instructions per step -- measured SLOWER: two scalar-cache round trips per
+// step that eight wavefronts per SIMD do not cover, second walk 261 -> 341 us.)
+template <int JM, bool LOWER>
+__global__ __launch_bounds__(256) void k_cols_rows(int64_t N, int J, const double *__restrict__ t, int64_t t_bs,
+                                                  const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
+                                                  const double *__restrict__ W, double *__restrict__ rec) {
+  const int64_t b = blockIdx.y, idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = idx / JM;
+  const int j = (int)(idx % JM);
+  if (n >= N) return;
+  const double *tb = t + b * t_bs;
+  const double tn = tb[n];
+  // the row the walk comes from: lower n - 1, upper n + 1; the first row of a walk has dt = 0, p = 1 exactly
+  const double tp = LOWER ? (n > 0 ? tb[n - 1] : tn) : (n < N - 1 ? tb[n + 1] : tn);
+  double *r = rec + (b * N + n) * (3 * JM);
+  const bool actj = j < J;
+  // exp(-c |dt|) with the negative difference inside (internal.hpp:139, 182)
+  r[j] = actj ? exp_decay(c[b * c_bs + j] * (LOWER ? tp - tn : tn - tp)) : 0.0;
+  r[JM + j] = actj ? (LOWER ? W : U)[(b * N + n) * J + j] : 0.0;       // fed into the state
+  r[2 * JM + j] = actj ? (LOWER ? U : W)[(b * N + n) * J + j] : 0.0;   // applied to the state
+}
+
 // Gbuf: [series][chunk][JM][ncolp] (columns fastest: coalesced for the lanes of a walk and the threads of the chain)
 // Phi : [series][chunk][JM][JM]    (Phi(i, j) at i * JM + j)
 template <int JM, bool LOWER, int MODE>
-__global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t nrhs, int64_t Lc, int64_t K, int ntile,
-                                                     const double *__restrict__ t, int64_t t_bs,
-                                                     const double *__restrict__ c, int64_t c_bs,
-                                                     const double *__restrict__ U, const double *__restrict__ W,
-                                                     const double *Y, double *Z, double *__restrict__ Phi,
-                                                     double *__restrict__ Gbuf, int64_t ncolp) {
-  __shared__ __attribute__((aligned(16))) double rowbuf[2][3][JM];   // p_n, A_n, B_n of two consecutive steps
+__global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int64_t nrhs, int64_t Lc, int64_t K, int ntile,
+                                                     const double *__restrict__ rec, const double *Y, double *Z,
+                                                     double *__restrict__ Phi, double *__restrict__ Gbuf, int64_t ncolp) {
+  __shared__ __attribute__((aligned(16))) double rowbuf[2][3 * JM];   // [p | A | B] of two consecutive steps
   const int lane = threadIdx.x;
   const int64_t k = blockIdx.x, b = blockIdx.z;
   const int tile = blockIdx.y;
@@ -49,14 +73,10 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
   int64_t col = (int64_t)tile * kWave + lane;
   const bool vcol = !phi_tile && col < nrhs;
   if (col >= nrhs) col = nrhs - 1;                    // clamped copies of the last column (their results are not kept)
-  const bool actj = lane < J;                          // this lane also carries element `lane` of the width-J vectors
-  const int jl = actj ? lane : 0;
-  const double *tb = t + b * t_bs;
-  const double *Ab = (LOWER ? W : U) + b * N * J + jl;   // row fed into the state
-  const double *Bb = (LOWER ? U : W) + b * N * J + jl;   // row applied to the state
+  const bool rl = lane < 3 * JM;                      // this lane also moves element `lane` of the rows' records
+  const double *rb = rec + b * N * (3 * JM) + (rl ? lane : 0);
   const double *yb = Y + b * N * nrhs + col;
   double *zb = Z + b * N * nrhs + col;
-  const double cj = actj ? c[b * c_bs + lane] : 0.0;
   const int64_t s_lo = k * Lc, s_hi = (s_lo + Lc < N) ? s_lo + Lc : N;
   double *gb = Gbuf + ((b * K + k) * JM) * ncolp + (int64_t)tile * kWave + lane;   // element j at gb[j * ncolp]
 
@@ -68,34 +88,28 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
   }
   // A walk is short (Lc rows) and there are many of them: what a step costs is the latency of its loads, so the rows are
   // requested R steps ahead into a register ring (one step ahead: 0.75 us a step, profiles/r04_large_nrhs.md)
-  constexpr int R = JM <= 8 ? 8 : 4;   // (width 16 with a ring of eight rows spills: 64 x 4096 x 64 right-hand sides 0.6 -> 2.8 ms)
-  double rt[R], ra[R], rb[R], ry[R];
+  constexpr int R = 8;
+  double rr[R], ry[R];
   auto load_row = [&](int r, int64_t s) {
     const int64_t nn = rowof<LOWER>(s < s_hi ? s : s_hi - 1, N);
-    rt[r] = tb[nn];
-    ra[r] = actj ? Ab[nn * J] : 0.0;
-    rb[r] = actj ? Bb[nn * J] : 0.0;
+    rr[r] = rb[nn * (3 * JM)];
     const double yv = yb[nn * nrhs];   // (loaded by the virtual columns too -- a valid, clamped column -- and dropped: no branch in the ring)
     ry[r] = phi_tile ? 0.0 : yv;
   };
-  double tprev = tb[rowof<LOWER>(s_lo > 0 ? s_lo - 1 : 0, N)];
 #pragma unroll
   for (int r = 0; r < R; ++r) load_row(r, s_lo + r);
   int q = 0;
   auto step = [&](const int r, const int64_t s) __attribute__((always_inline)) {
     const int64_t n = rowof<LOWER>(s, N);
-    const double tn = rt[r], an = ra[r], bn = rb[r], yn = ry[r];
+    const double rv = rr[r], yn = ry[r];
     load_row(r, s + R);
-    // exp(-c |dt|) with the negative difference inside (internal.hpp:139, 182); step 0: dt = 0, p = 1 exactly, G = 0
-    const double p = exp_decay(cj * (LOWER ? tprev - tn : tn - tprev));
-    tprev = tn;
-    if (lane < JM) { rowbuf[q][0][lane] = actj ? p : 0.0; rowbuf[q][1][lane] = an; rowbuf[q][2][lane] = bn; }
+    if (rl) rowbuf[q][lane] = rv;
     lds_order();
     double red0 = 0.0, red1 = 0.0;   // (two partial sums: half the dependent chain)
 #pragma unroll
     for (int j = 0; j < JM; j += 2) {
-      const double2 p2 = *reinterpret_cast<const double2 *>(&rowbuf[q][0][j]);
-      const double2 b2 = *reinterpret_cast<const double2 *>(&rowbuf[q][2][j]);
+      const double2 p2 = *reinterpret_cast<const double2 *>(&rowbuf[q][j]);
+      const double2 b2 = *reinterpret_cast<const double2 *>(&rowbuf[q][2 * JM + j]);
       G[j] *= p2.x;                  // F = P G: internal.hpp:143 / 186
       G[j + 1] *= p2.y;
       red0 = fma(b2.x, G[j], red0);
@@ -105,17 +119,14 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
     if (MODE == 1 && vcol) zb[n * nrhs] = zn;
 #pragma unroll
     for (int j = 0; j < JM; j += 2) {
-      const double2 a2 = *reinterpret_cast<const double2 *>(&rowbuf[q][1][j]);
+      const double2 a2 = *reinterpret_cast<const double2 *>(&rowbuf[q][JM + j]);
       G[j] = fma(a2.x, zn, G[j]);    // internal.hpp:140 / 183 (the state the next row decays)
       G[j + 1] = fma(a2.y, zn, G[j + 1]);
     }
     q ^= 1;
-    // (MODE 0 has no store in its step, and without one the optimiser lets the state's chain trail the R unrolled steps' loads,
-    // LDS reads and exponentials: 442 registers -- ONE wavefront per SIMD and v_accvgpr moves on every operand, the first walk
-    // took 2.2 x the second (tools/kernel_regs.py lists such kernels).  An empty asm that 'uses and redefines' the state pins
-    // every step where it is written: 138 registers.  Round 6 also measured the rows as precomputed records [p | A | B] read
-    // through uniform (scalar) loads -- no exponential, no LDS exchange, 28 VALU instructions per step: the second walk 261 ->
-    // 341 us, two scalar-cache round trips per step that eight wavefronts per SIMD do not cover; not taken.)
+    // (MODE 0 has no store in its step, and without one the optimiser lets the state's chain trail the R unrolled steps' loads and LDS
+    // reads: the first version took 442 registers there -- ONE wavefront per SIMD, the first walk 2.2 x the second (tools/kernel_regs.py
+    // lists such kernels).  An empty asm that 'uses and redefines' the state pins every step where it is written.)
 #pragma unroll
     for (int j = 0; j < JM; ++j) asm volatile("" : "+v"(G[j]));
   };
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(kWave) void k_cols_walk(int64_t N, int J, int64_t n
       if (lane < JM) {
         double *ph = Phi + (b * K + k) * (JM * JM);
 #pragma unroll
-        for (int i = 0; i < JM; ++i) ph[i * JM + lane] = (lane < J && i < J) ? G[i] : 0.0;   // column `lane` of Phi
+        for (int i = 0; i < JM; ++i) ph[i * JM + lane] = G[i];   // column `lane` of Phi (rows and columns beyond J: zero)
       }
     } else {
 #pragma unroll
@@ -233,7 +244,7 @@ struct Plan {
   int JM;
   int64_t Lc, K, ncolp;
   int ntile;
-  size_t phi, gbuf, total;   // doubles
+  size_t phi, gbuf, rec, total;   // doubles
 };
 static Plan plan(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   Plan p;
@@ -247,7 +258,8 @@ static Plan plan(int64_t B, int64_t N, int64_t J, int64_t nrhs) {
   p.K = (N + p.Lc - 1) / p.Lc;
   p.phi = 0;
   p.gbuf = (size_t)B * p.K * p.JM * p.JM;
-  p.total = p.gbuf + (size_t)B * p.K * p.JM * p.ncolp;
+  p.rec = p.gbuf + (size_t)B * p.K * p.JM * p.ncolp;
+  p.total = p.rec + (size_t)B * N * 3 * p.JM;
   return p;
 }
 
@@ -274,14 +286,17 @@ int c2_internal_solve_cols(int lower, int64_t B, int64_t N, int64_t J, int64_t n
   double *Phi = scratch + p.phi, *Gbuf = scratch + p.gbuf;
   const dim3 g0((unsigned)p.K, (unsigned)(p.ntile + 1), (unsigned)B), g1((unsigned)p.K, (unsigned)p.ntile, (unsigned)B);
   const dim3 gc((unsigned)p.ntile, (unsigned)B);
+  double *rec = scratch + p.rec;
+  const dim3 gr((unsigned)((N * p.JM + 255) / 256), (unsigned)B);
 #define C2_COLS(JM_, LO)                                                                                              \
   do {                                                                                                                \
-    hipLaunchKernelGGL((k_cols_walk<JM_, LO, 0>), g0, dim3(kWave), 0, s, N, (int)J, nrhs, p.Lc, p.K, p.ntile, t, t_bs, c, \
-                       c_bs, U, W, Y, Z, Phi, Gbuf, p.ncolp);                                                          \
+    hipLaunchKernelGGL((k_cols_rows<JM_, LO>), gr, dim3(256), 0, s, N, (int)J, t, t_bs, c, c_bs, U, W, rec);          \
+    hipLaunchKernelGGL((k_cols_walk<JM_, LO, 0>), g0, dim3(kWave), 0, s, N, nrhs, p.Lc, p.K, p.ntile, (const double *)rec, \
+                       Y, Z, Phi, Gbuf, p.ncolp);                                                                      \
     if (JM_ <= 8) hipLaunchKernelGGL((k_cols_chain<JM_>), gc, dim3(kWave), 0, s, p.K, (const double *)Phi, Gbuf, p.ncolp); \
     else hipLaunchKernelGGL((k_cols_chain_s<JM_>), gc, dim3(kWave), 0, s, p.K, (const double *)Phi, Gbuf, p.ncolp);      \
-    hipLaunchKernelGGL((k_cols_walk<JM_, LO, 1>), g1, dim3(kWave), 0, s, N, (int)J, nrhs, p.Lc, p.K, p.ntile, t, t_bs, c, \
-                       c_bs, U, W, Y, Z, Phi, Gbuf, p.ncolp);                                                          \
+    hipLaunchKernelGGL((k_cols_walk<JM_, LO, 1>), g1, dim3(kWave), 0, s, N, nrhs, p.Lc, p.K, p.ntile, (const double *)rec, \
+                       Y, Z, Phi, Gbuf, p.ncolp);                                                                      \
   } while (0)
   if (p.JM == 8) { if (lower) C2_COLS(8, true); else C2_COLS(8, false); }
   else { if (lower) C2_COLS(16, true); else C2_COLS(16, false); }

@@ -1170,18 +1170,20 @@ __global__ __launch_bounds__(256) void k_kernel_values(int64_t B, int64_t N, int
 // wavefront-uniform test) take the exponential per entry as before, as do growing terms (c < 0).  Per entry and term: one multiply.
 constexpr int kKvRows = 32, kKvCols = 64;
 __host__ __device__ inline size_t kv_lds_doubles(int64_t Jr, int64_t Jc) {
-  return (size_t)2 * Jc * kKvRows + kKvRows + (size_t)2 * (Jr + Jc) * kKvRows + 8;
+  return (size_t)2 * Jc * kKvRows + kKvRows + (size_t)2 * (Jr + Jc) * kKvRows + (size_t)4 * Jc * kKvRows + 8;
 }
-__global__ __launch_bounds__(256) void k_kernel_values_tile(int64_t N, int64_t M, int Jr, int Jc, const double *__restrict__ ar,
+__global__ __launch_bounds__(256, 4) void k_kernel_values_tile(int64_t N, int64_t M, int Jr, int Jc, const double *__restrict__ ar,
                                                             const double *__restrict__ cr, const double *__restrict__ ac,
                                                             const double *__restrict__ bc, const double *__restrict__ cc,
                                                             const double *__restrict__ dc, int coef_batched,
                                                             const double *__restrict__ t1, int64_t t1_bs,
                                                             const double *__restrict__ t2, int64_t t2_bs, double *__restrict__ K) {
-  extern __shared__ double kv_lds[];   // [Jc][32] cos phi, [Jc][32] sin phi, [32] t1 rows, [Jr + Jc][32] row factors up / down, tmin, tmax
+  extern __shared__ double kv_lds[];   // [Jc][32] cos phi, [Jc][32] sin phi, [32] t1 rows, [Jr + Jc][32] row factors up / down, [Jc][32] x 4 their products with cos / sin phi, tmin, tmax
   const int JT = Jr + Jc;
   double *cs_n = kv_lds, *sn_n = cs_n + (size_t)Jc * kKvRows, *tn_s = sn_n + (size_t)Jc * kKvRows;
-  double *e_up = tn_s + kKvRows, *e_dn = e_up + (size_t)JT * kKvRows, *tmn = e_dn + (size_t)JT * kKvRows, *tmx = tmn + 4;
+  double *e_up = tn_s + kKvRows, *e_dn = e_up + (size_t)JT * kKvRows;
+  double *ec_up = e_dn + (size_t)JT * kKvRows, *es_up = ec_up + (size_t)Jc * kKvRows, *ec_dn = es_up + (size_t)Jc * kKvRows,
+         *es_dn = ec_dn + (size_t)Jc * kKvRows, *tmn = es_dn + (size_t)Jc * kKvRows, *tmx = tmn + 4;
   const int64_t b = blockIdx.z, n0 = (int64_t)blockIdx.y * kKvRows, m = (int64_t)blockIdx.x * kKvCols + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;   // rows rg * 8 .. rg * 8 + 7 of the tile
   const int64_t orr = coef_batched ? b * Jr : 0, oc = coef_batched ? b * Jc : 0;
@@ -1206,8 +1208,13 @@ __global__ __launch_bounds__(256) void k_kernel_values_tile(int64_t N, int64_t M
     const int i = q / kKvRows, r = q - i * kKvRows;
     const double c_ = i < Jr ? cr[orr + i] : cc[oc + i - Jr];
     const double tr = tn_s[r];
-    e_up[q] = exp_decay(-c_ * (tr - tmn[r >> 3]));   // (c < 0: never read)
-    e_dn[q] = exp_decay(-c_ * (tmx[r >> 3] - tr));
+    const double eu = exp_decay(-c_ * (tr - tmn[r >> 3])), ed = exp_decay(-c_ * (tmx[r >> 3] - tr));   // (c < 0: never read)
+    e_up[q] = eu; e_dn[q] = ed;
+    if (i >= Jr) {   // a complex term: the row's share of e (a cos + b sin), see the fast path below
+      const int qc = (i - Jr) * kKvRows + r;
+      ec_up[qc] = eu * cs_n[qc]; es_up[qc] = eu * sn_n[qc];
+      ec_dn[qc] = ed * cs_n[qc]; es_dn[qc] = ed * sn_n[qc];
+    }
   }
   __syncthreads();
   const bool live = m < M;
@@ -1244,10 +1251,26 @@ __global__ __launch_bounds__(256) void k_kernel_values_tile(int64_t N, int64_t M
 #pragma unroll
     for (int r = 0; r < 8; ++r) k[r] = fma(a_, e[r], k[r]);
   }
+  // Fast path of a complex term (a column outside its wavefront's rows: the sign of tau is one for all eight): with phi_r, psi the
+  // phases of row and column against t0,  a cos(dc tau) + b sin(dc |tau|) = cos phi_r (a cos psi - b s sin psi) + sin phi_r (a sin psi
+  // + b s cos psi),  s = sgn(tau) -- two per-COLUMN numbers; times the column's exponential they meet the row's E cos phi, E sin phi
+  // from the tables: TWO multiply-adds and two LDS reads per entry and term (nine and three before).  The kernel is bound by its VALU
+  // instructions (893 per wavefront, four wavefronts per SIMD 88 % VALU-active: rocprofv3 --pmc): 348 -> 298 us at 64 x 4096 x 256 with
+  // the registers capped at 128 (uncapped the two paths take 173: 412 us).  A workgroup that loops over the column tiles with ONE set of
+  // row tables (a quarter of the instructions) spills under that cap: 389 us, not taken.
+  const double sgc = below ? 1.0 : -1.0;
+  const double *ec_row = (below ? ec_up : ec_dn) + rg * 8, *es_row = (below ? es_up : es_dn) + rg * 8;
   for (int i = 0; i < Jc; ++i) {
     const double a_ = ac[oc + i], b_ = bc[oc + i];
     double sm, cm;
     sincos_cw(dc[oc + i] * dx, sm, cm);
+    if (cc[oc + i] >= 0.0 && !direct) {   // (uniform)
+      const double fm = exp_decay(-cc[oc + i] * far), bs = b_ * sgc;
+      const double Ac = fm * fma(a_, cm, -bs * sm), As = fm * fma(a_, sm, bs * cm);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) k[r] = fma(ec_row[i * kKvRows + r], Ac, fma(es_row[i * kKvRows + r], As, k[r]));
+      continue;
+    }
     const double *cr_ = cs_n + (size_t)i * kKvRows + rg * 8, *sr_ = sn_n + (size_t)i * kKvRows + rg * 8;
     double e[8];
     decay8(cc[oc + i], Jr + i, e);

@@ -27,7 +27,16 @@
 // twice the regular number per wavefront); a wavefront that runs out of them marks its group of 64 series and the replay
 // kernels take those.  Which rows carry a checkpoint is the sign of their d record; the slots are consumed in reverse order of
 // writing, so the reverse sweep needs their number and no list.
-// Not here (the dispatch keeps the other mappings for them): widths other than 8, the coefficient-level form.
+// Not here (the dispatch keeps the other mappings for them): widths other than 8.
+//
+// Coefficient-level form (TM != 0; SURVEY.md section 8f-1, driver.cpp:456-474): the rows U_n, V_n are formed in the lanes from
+// (ar, cr, ac, bc, cc, dc) and x_n and no width-8 array is read or written.  A lane's local 0..3 are the global columns
+// 4h .. 4h+3, i.e. two SLOTS of two columns each; J = Jr + 2 Jc = 8 makes Jr even, so a slot is either one complex term
+// (cos / sin columns) or a pair of real terms, and a real pair is evaluated by the SAME instructions as a complex term with
+// dc = 0 (cos = 1, sin = 0 exactly), ac = ar_0, bc = -ar_1: U = (ar_0, ar_1) bit for bit, V's second column selected to 1.
+// One sincos per slot and step; the partner's half of U arrives by the same DPP move as its half of W.  The reverse sweep
+// folds the reverse of the recipe (k_terms_rev of c2_terms.hip) into its step: per slot three running sums (bac, bbc, bdc --
+// for a real pair the first two are sum bU_0 and -sum bU_1), the sum of ba, and bx_n = bt_n + sum_k g_nk dc_k.
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -239,15 +248,88 @@ __device__ __forceinline__ void inverses(const double (&p)[J], double (&ip)[J]) 
   }
 }
 
+// ---- rows generated from the celerite coefficients (driver.cpp:456-474; c2_loglik_t.hip has the one-lane form) -------------
+struct TermsArgs {
+  const double *ar, *cr, *ac, *bc, *cc, *dc;
+  int batched;   // coefficients per series (1) or shared by the batch (0)
+  int Jc;        // complex terms; Jr = 8 - 2 Jc real ones in front of them
+};
+struct TermsGrads {
+  double *bar, *bcr, *bac, *bbc, *bcc, *bdc;
+};
+// TM: 0 rows from the caller's arrays; 1 coefficient-level, every phase of the wavefront inside the range of the branch-free
+// sincos; 2 coefficient-level with the library's sincos (raw Julian dates times a fast frequency)
+struct SlotCoef {
+  double A[2], Bq[2], D[2], A0;
+  bool re[2];   // the slot is a pair of real terms
+  int g0;       // first global column of the lane (4 h)
+  __device__ __forceinline__ void load(const TermsArgs &T, int64_t b, int h, double (&cj)[J]) {
+    const int JC = T.Jc, JR = J - 2 * JC;
+    const int64_t br = T.batched ? b * JR : 0, bk = T.batched ? b * JC : 0;
+    g0 = 4 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int g = g0 + 2 * s;
+      re[s] = g < JR;
+      if (re[s]) {
+        A[s] = T.ar[br + g]; Bq[s] = -T.ar[br + g + 1]; D[s] = 0.0;
+        cj[2 * s] = T.cr[br + g]; cj[2 * s + 1] = T.cr[br + g + 1];
+      } else {
+        const int k = (g - JR) >> 1;
+        A[s] = T.ac[bk + k]; Bq[s] = T.bc[bk + k]; D[s] = T.dc[bk + k];
+        cj[2 * s] = cj[2 * s + 1] = T.cc[bk + k];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cj[4 + j] = swap_pair(cj[j]);
+    double sum = 0.0;   // driver.cpp:456-458: the sum of ar, then of ac
+    for (int r = 0; r < JR; ++r) sum += T.ar[br + r];
+    for (int k = 0; k < JC; ++k) sum += T.ac[bk + k];
+    A0 = sum;
+  }
+  // x sorted: the largest |x| of a series sits at one of its ends
+  __device__ __forceinline__ bool phases_fast(double x_first, double x_last) const {
+    const double xm = fmax(fabs(x_first), fabs(x_last));
+    return (fabs(D[0]) * xm < kSincosFastMax) && (fabs(D[1]) * xm < kSincosFastMax);
+  }
+  template <int TM>
+  static __device__ __forceinline__ void sc(double ph, double &sn, double &cs) {
+    if constexpr (TM == 1) sincos_cw_fast(ph, sn, cs);
+    else sincos_cw(ph, sn, cs);   // (a real pair's phase 0 stays on the branch-free path: cos = 1, sin = 0 exactly)
+  }
+  // U_n whole (local order), sin / cos of the lane's two slots
+  template <int TM>
+  __device__ __forceinline__ void rows_sc(double xn, double (&u)[J], double (&sn)[2], double (&cs)[2]) const {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      sc<TM>(D[s] * xn, sn[s], cs[s]);
+      u[2 * s] = fma(A[s], cs[s], Bq[s] * sn[s]);
+      u[2 * s + 1] = fma(A[s], sn[s], -(Bq[s] * cs[s]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[4 + j] = swap_pair(u[j]);
+  }
+  // ... and the lane's half of V_n
+  template <int TM>
+  __device__ __forceinline__ void rows(double xn, double (&u)[J], double (&v)[J]) const {
+    double sn[2], cs[2];
+    rows_sc<TM>(xn, u, sn, cs);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { v[2 * s] = cs[s]; v[2 * s + 1] = re[s] ? 1.0 : sn[s]; }
+  }
+};
+
 // =====================================================================================================================
 // Forward pass.  REC: also W rows, (d, z), t, checkpoints and the stability measure of the backward recursion.
 // =====================================================================================================================
-template <bool REC, bool PAIRED, bool FULL>
+template <bool REC, bool PAIRED, bool FULL, int TM = 0>
 __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                          const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                          const double *__restrict__ U, const double *__restrict__ V,
                                          const double *__restrict__ y, double *__restrict__ ll, int32_t *__restrict__ flag,
-                                         double *__restrict__ rec, Rec R, unsigned long long *__restrict__ guard, double *lds) {
+                                         double *__restrict__ rec, Rec R, unsigned long long *__restrict__ guard, double *lds,
+                                         const TermsArgs T = TermsArgs{}) {
+  constexpr bool TERMS = TM != 0;   // `a` is then the white-noise diagonal; c, U, V are not read
   const int lane = threadIdx.x, sl = lane >> 1, h = lane & 1;
   const int64_t b0 = (int64_t)blockIdx.x * SPW;
   const int last = (int)((B - b0 < SPW ? B - b0 : SPW) - 1);   // lanes beyond the batch walk a copy of its last series
@@ -258,8 +340,14 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   const double *tb = t + (t_bs ? b0 * N : 0);
   const int64_t tN = t_bs ? N : 0;
   double cj[J], cmax = 0.0;
+  SlotCoef tc;
+  if constexpr (TERMS) tc.load(T, b, h, cj);
+  else {
 #pragma unroll
-  for (int j = 0; j < J; ++j) { cj[j] = c[b * c_bs + ((j + 4 * h) & 7)]; cmax = fmax(cmax, cj[j]); }
+    for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + ((j + 4 * h) & 7)];
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) cmax = fmax(cmax, cj[j]);
   double2 *recW = REC ? reinterpret_cast<double2 *>(rec + R.w + (size_t)blockIdx.x * N * J * SPW) : nullptr;
   double2 *recDZ = REC ? reinterpret_cast<double2 *>(rec + R.dz + (size_t)blockIdx.x * N * 2 * SPW) : nullptr;
   double *recT = REC ? rec + R.t + (size_t)blockIdx.x * N * SPW : nullptr;
@@ -270,9 +358,20 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   for (int e = 0; e < NL; ++e) S[e] = 0.0;
   double F[4], w[J];   // (F: this lane's local 0..3 only -- every use is a half of a dot product or a checkpoint)
   double tprev = t[b * t_bs];
-  double d = a[b * N], z = y[b * N], rd = 1.0 / d;
+  double d = a[b * N], z = y[b * N];
+  if constexpr (TERMS) d += tc.A0;
+  double rd = 1.0 / d;
+  if constexpr (TERMS) {
+    double u0[J], v0[J];
+    tc.template rows<TM>(tprev, u0, v0);
 #pragma unroll
-  for (int j = 0; j < J; ++j) w[j] = V[b * N * J + ((j + 4 * h) & 7)] * rd;
+    for (int j = 0; j < 4; ++j) w[j] = v0[j] * rd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[4 + j] = swap_pair(w[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < J; ++j) w[j] = V[b * N * J + ((j + 4 * h) & 7)] * rd;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) F[j] = 0.0;
   double prod = d, quad = z * z * rd;
@@ -302,7 +401,7 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
   if (REC) write_rec(0, false);
 
   double su[8], sv[8], st_[8], sa_[8], sy_[8];
-  row_fetch<FULL>(Ub, N, 0, lane, last, su); row_fetch<FULL>(Vb, N, 0, lane, last, sv);
+  if constexpr (!TERMS) { row_fetch<FULL>(Ub, N, 0, lane, last, su); row_fetch<FULL>(Vb, N, 0, lane, last, sv); }
   sc_fetch16<FULL>(tb, tN, N, 0, lane, last, st_); sc_fetch16<FULL>(ab, N, N, 0, lane, last, sa_); sc_fetch16<FULL>(yb, N, N, 0, lane, last, sy_);
   for (int64_t n0 = 0; n0 < N; n0 += ST) {
     const int half = (int)((n0 >> 3) & 1);
@@ -316,16 +415,19 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
     for (int rt = 0; rt < ST / 2; ++rt) {
       const int64_t nt = n0 + rt * 2;
       if (nt < N) {
-        lds_order();
-        row_stage(tU, lane, su); row_stage(tV, lane, sv);
-        row_fetch<FULL>(Ub, N, nt + 2, lane, last, su); row_fetch<FULL>(Vb, N, nt + 2, lane, last, sv);
-        lds_order();
+        if constexpr (!TERMS) {
+          lds_order();
+          row_stage(tU, lane, su); row_stage(tV, lane, sv);
+          row_fetch<FULL>(Ub, N, nt + 2, lane, last, su); row_fetch<FULL>(Vb, N, nt + 2, lane, last, sv);
+          lds_order();
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int64_t n = nt + r;
           if (n < N && n > 0) {
             const int rs = rt * 2 + r;
-            const double tn = tT[sl * SSTR + rs], yn = tY[sl * SSTR + rs], an = tA[sl * SSTR + rs];
+            const double tn = tT[sl * SSTR + rs], yn = tY[sl * SSTR + rs];
+            const double an = TERMS ? tA[sl * SSTR + rs] + tc.A0 : tA[sl * SSTR + rs];
             double u[J], v[J], p[J];
             const double dt = tprev - tn;
             if (REC) {
@@ -341,7 +443,8 @@ __device__ __forceinline__ void fwd_body(int64_t B, int64_t N, const double *__r
               gmax = fmax(gmax, cmax * (tn - tseg));
             }
             tprev = tn;
-            row_read(tU, sl, h, r, u); row_read(tV, sl, h, r, v);
+            if constexpr (TERMS) tc.template rows<TM>(tn, u, v);   // (v: the lane's local 0..3 only)
+            else { row_read(tU, sl, h, r, u); row_read(tV, sl, h, r, v); }
             decay<PAIRED>(cj, dt, p);
             // S = P (S + d w^T w) P (forward.hpp:115-123); tau = U_n S (forward.hpp:126): own elements, then the pair's total
             double dw[J], tau[J], taut[4];
@@ -463,12 +566,14 @@ __device__ __forceinline__ void sc_flush_r(double *__restrict__ base, int64_t N,
   }
 }
 
-template <bool PAIRED, bool FULL>
+template <bool PAIRED, bool FULL, int TM = 0>
 __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__restrict__ c, int64_t c_bs,
                                          const double *__restrict__ U, const int32_t *__restrict__ flag,
                                          const double *__restrict__ rec, Rec R, double *__restrict__ bt,
                                          double *__restrict__ bc, double *__restrict__ ba, double *__restrict__ bU,
-                                         double *__restrict__ bV, double *__restrict__ by, double *lds) {
+                                         double *__restrict__ bV, double *__restrict__ by, double *lds,
+                                         const TermsArgs T = TermsArgs{}, const TermsGrads G = TermsGrads{}) {
+  constexpr bool TERMS = TM != 0;   // bt, ba, by are then bx, bdiag, by; c, U, bc, bU, bV are not touched
   const int lane = threadIdx.x, sl = lane >> 1, h = lane & 1;
   const int64_t b0 = (int64_t)blockIdx.x * SPW;
   const int last = (int)((B - b0 < SPW ? B - b0 : SPW) - 1);
@@ -484,8 +589,15 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   const bool failed = flag[b] != 0;   // NaN gradients for a failed factorisation
   const double nan = __builtin_nan("");
   double cj[J], bcj[4];
+  SlotCoef tc;
+  if constexpr (TERMS) tc.load(T, b, h, cj);
+  else {
 #pragma unroll
-  for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + ((j + 4 * h) & 7)];
+    for (int j = 0; j < J; ++j) cj[j] = c[b * c_bs + ((j + 4 * h) & 7)];
+  }
+  // coefficient-level form: running sums of the lane's two slots -- [s][0] bac (real pair: sum bU_0), [1] bbc (-sum bU_1),
+  // [2] bdc -- and the sum of ba
+  double acc[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, sba = 0.0;
 
   // F, bF, the accumulators of bc: this lane's local 0..3 only (every use is a half of a dot product, a half row of an output
   // or a checkpoint); bV is needed whole by the pass over the elements and is completed from the partner
@@ -557,11 +669,13 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
   if (N >= 2) {
     // ---- prologue: bV, ba, by of the last row are pure seeds ---------------------------------------------------------------
     const int ph0 = (int)(nf & 1);
-    row_write_half(tBV, sl, h, ph0, bVn);
+    if constexpr (!TERMS) row_write_half(tBV, sl, h, ph0, bVn);
     tBA[sl * SSTRR + (nf & (STR - 1))] = ban;
     tBY[sl * SSTRR + (nf & (STR - 1))] = bzn;
     lds_order();
-    if (ph0 == 0) row_flush<FULL>(bVb, N, nf, tBV, lane, last);   // (an even last row: its pair partner lies beyond the series: only row nf)
+    if constexpr (!TERMS) {
+      if (ph0 == 0) row_flush<FULL>(bVb, N, nf, tBV, lane, last);   // (an even last row: its pair partner lies beyond the series: only row nf)
+    }
     if ((nf & (STR - 1)) == 0) {                      // the last row alone at the bottom of its scalar tile
       sc_flush_r<FULL>(bab, N, nf, tBA, lane, last);
       sc_flush_r<FULL>(byb, N, nf, tBY, lane, last);
@@ -569,12 +683,14 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
     double su[8], wa[J];
     double2 dza;
     double ta;
-    row_fetch<FULL>(Ub, N, nf - ph0, lane, last, su);
-    if (ph0 != 1) {   // the first step is not a staging one: its tile goes into LDS here
-      lds_order();
-      row_stage(tU, lane, su);
-      lds_order();
-      row_fetch<FULL>(Ub, N, nf - ph0 - 2, lane, last, su);
+    if constexpr (!TERMS) {
+      row_fetch<FULL>(Ub, N, nf - ph0, lane, last, su);
+      if (ph0 != 1) {   // the first step is not a staging one: its tile goes into LDS here
+        lds_order();
+        row_stage(tU, lane, su);
+        lds_order();
+        row_fetch<FULL>(Ub, N, nf - ph0 - 2, lane, last, su);
+      }
     }
     w_fetch(nf - 1, wa);
     dza = dz_fetch(nf - 1);
@@ -586,7 +702,7 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       constexpr int PH = decltype(phase_tag)::value;   // n & 1
       __builtin_amdgcn_sched_barrier(0);
       double wb[J];
-      if constexpr (PH == 1) {   // the step that puts its pair of U rows into LDS and requests the pair below
+      if constexpr (PH == 1 && !TERMS) {   // the step that puts its pair of U rows into LDS and requests the pair below
         lds_order();
         row_stage(tU, lane, su);
         row_fetch<FULL>(Ub, N, n - 3, lane, last, su);
@@ -594,10 +710,18 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       w_fetch(n - 2, wb);
       const double2 dzb = dz_fetch(n - 2);
       const double tb2 = t_fetch(n - 2);
-      if constexpr (PH == 1) lds_order();
+      if constexpr (PH == 1 && !TERMS) lds_order();
       const int rs = (int)((n - 1) & (STR - 1));
       double u[J], p[J], ip[J];
-      row_read(tU, sl, h, PH, u);
+      double sn2[2], cs2[2], gv[2];
+      const double xn = tcur, ba_in = ban;
+      if constexpr (TERMS) {
+        tc.template rows_sc<TM>(xn, u, sn2, cs2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) gv[s] = fma(bVn[2 * s + 1], cs2[s], -(bVn[2 * s] * sn2[s]));   // -bV0 sin + bV1 cos of row n
+      } else {
+        row_read(tU, sl, h, PH, u);
+      }
       const double tm = ta, dt = tm - tcur;
       tcur = tm;
       decay<PAIRED>(cj, dt, p);
@@ -669,16 +793,32 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
       pair_total4(bps, bp);
 #pragma unroll
       for (int j = 0; j < 4; ++j) bp[j] += bp0[j];
+      double gsum = 0.0;
       {
         double o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = fma(-bzn, F[j], -xst[j]);   // bU_n = -bz_n F_n - x S_n
-        row_write_half(tU, sl, h, PH, o);                               // bU_n takes the place of U_n in the tile
+        if constexpr (TERMS) {   // the reverse of the recipe for row n (c2_terms.hip: k_terms_rev), this lane's two slots
+          double gs = 0.0;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const double b0_ = o[2 * s], b1_ = o[2 * s + 1];
+            acc[s][0] = fma(b0_, cs2[s], fma(b1_, sn2[s], acc[s][0]));
+            acc[s][1] = fma(b0_, sn2[s], fma(-b1_, cs2[s], acc[s][1]));
+            const double g = fma(-b0_, u[2 * s + 1], fma(b1_, u[2 * s], gv[s]));   // cotangent of the phase dc x_n
+            acc[s][2] = fma(g, xn, acc[s][2]);
+            gs = fma(g, tc.D[s], gs);
+          }
+          gsum = gs + swap_pair(gs);
+          sba += ba_in;
+        } else {
+          row_write_half(tU, sl, h, PH, o);                             // bU_n takes the place of U_n in the tile
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) bcj[j] = fma(dt, bp[j], bcj[j]);
       const double f = dot_halves(bp, cj);
-      const double btn = carry - f;
+      const double btn = carry - f + gsum;   // coefficient-level form: bx_n
       carry = f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) F[j] = fma(-wa[j], zm, F[j] * ip[j]);   // F_{n-1} = P^-1 F_n - w_{n-1} z_{n-1}
@@ -695,12 +835,14 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
         tBY[sl * SSTRR + rs] = bzn;
         tBT[sl * SSTRR + (int)(n & (STR - 1))] = btn;
       }
-      row_write_half(tBV, sl, h, (PH + 1) & 1, bVn);   // bV_{n-1}
+      if constexpr (!TERMS) row_write_half(tBV, sl, h, (PH + 1) & 1, bVn);   // bV_{n-1}
       lds_order();
       // width-8 outputs leave as aligned pairs of rows: bU at the end of the even step (rows n, n + 1), bV at the end of the odd
       // step (rows n - 1, n)
-      if constexpr (PH == 0) row_flush<FULL>(bUb, N, n, tU, lane, last);
-      else row_flush<FULL>(bVb, N, n - 1, tBV, lane, last);
+      if constexpr (!TERMS) {
+        if constexpr (PH == 0) row_flush<FULL>(bUb, N, n, tU, lane, last);
+        else row_flush<FULL>(bVb, N, n - 1, tBV, lane, last);
+      }
       if ((n & (STR - 1)) == 0) sc_flush_r<FULL>(btb, N, n, tBT, lane, last);
       if (rs == 0) {
         sc_flush_r<FULL>(bab, N, n - 1, tBA, lane, last);
@@ -722,22 +864,66 @@ __device__ __forceinline__ void rev_body(int64_t B, int64_t N, const double *__r
 #pragma unroll
       for (int j = 0; j < J; ++j) zero[j] = failed ? nan : 0.0;
       lds_order();
-      row_write_half(tU, sl, h, 0, zero);   // bU_1 is waiting in row 1 of the tile
+      if constexpr (TERMS) {   // row 0: bU_0 = 0; bV_0 and ba_0 are complete
+        double u0[J], sn2[2], cs2[2], gs = 0.0;
+        tc.template rows_sc<TM>(tcur, u0, sn2, cs2);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const double g = fma(bVn[2 * s + 1], cs2[s], -(bVn[2 * s] * sn2[s]));
+          acc[s][2] = fma(g, tcur, acc[s][2]);
+          gs = fma(g, tc.D[s], gs);
+        }
+        carry += gs + swap_pair(gs);
+        sba += ban;
+      } else {
+        row_write_half(tU, sl, h, 0, zero);   // bU_1 is waiting in row 1 of the tile
+      }
       if (h == 0) tBT[sl * SSTRR] = carry;
       lds_order();
-      row_flush<FULL>(bUb, N, 0, tU, lane, last);
+      if constexpr (!TERMS) row_flush<FULL>(bUb, N, 0, tU, lane, last);
       sc_flush_r<FULL>(btb, N, 0, tBT, lane, last);
     }
-  } else if (h == 0 && real) {   // N == 1: seeds only
-    bab[(int64_t)sl * N] = ban;
-    byb[(int64_t)sl * N] = bzn;
-    btb[(int64_t)sl * N] = failed ? nan : 0.0;
+  } else {   // N == 1: seeds only
+    if (h == 0 && real) {
+      bab[(int64_t)sl * N] = ban;
+      byb[(int64_t)sl * N] = bzn;
+      btb[(int64_t)sl * N] = failed ? nan : 0.0;
+      if constexpr (!TERMS) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) { bUb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; }
+        for (int j = 0; j < J; ++j) { bUb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; bVb[(int64_t)sl * N * J + j] = failed ? nan : 0.0; }
+      }
+    }
+    if constexpr (TERMS) {   // the only row: sum ba = ba_0, every other sum is empty
+      sba = ban;
+      if (failed) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { acc[s][0] = acc[s][1] = acc[s][2] = nan; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bcj[j] = nan;
+      }
+    }
   }
   if (real) {
+    if constexpr (TERMS) {
+      const int JC = T.Jc, JR = J - 2 * JC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bc[b * J + 4 * h + j] = bcj[j];   // local 0..3 = global 4h .. 4h+3
+      for (int s = 0; s < 2; ++s) {
+        const int g = tc.g0 + 2 * s;
+        if (tc.re[s]) {
+          G.bar[b * JR + g] = sba + acc[s][0]; G.bar[b * JR + g + 1] = sba - acc[s][1];
+          G.bcr[b * JR + g] = bcj[2 * s]; G.bcr[b * JR + g + 1] = bcj[2 * s + 1];
+        } else {
+          const int k = (g - JR) >> 1;
+          G.bac[b * JC + k] = sba + acc[s][0];
+          G.bbc[b * JC + k] = acc[s][1];
+          G.bdc[b * JC + k] = acc[s][2];
+          G.bcc[b * JC + k] = bcj[2 * s] + bcj[2 * s + 1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bc[b * J + 4 * h + j] = bcj[j];   // local 0..3 = global 4h .. 4h+3
+    }
   }
 }
 
@@ -761,6 +947,52 @@ __global__ __launch_bounds__(kWave, 1) void k_k2_rev(int64_t B, int64_t N, const
   if (__all(paired)) { if (full) C2K2_REV(true, true); else C2K2_REV(true, false); }
   else { if (full) C2K2_REV(false, true); else C2K2_REV(false, false); }
 #undef C2K2_REV
+}
+
+// ---- coefficient-level kernels: the same bodies, rows formed in the lanes ---------------------------------------------------
+// wavefront-uniform: paired rates (every complex term is; a real pair only with equal rates) and phases inside the range of
+// the branch-free sincos
+__device__ __forceinline__ void terms_traits(int64_t B, int64_t N, const double *__restrict__ x, int64_t x_bs, const TermsArgs &T,
+                                             bool &paired, bool &fast) {
+  int64_t bb = (int64_t)blockIdx.x * SPW + (threadIdx.x >> 1);
+  bb = bb < B ? bb : B - 1;
+  SlotCoef tc;
+  double cj[J];
+  tc.load(T, bb, (int)(threadIdx.x & 1), cj);
+  paired = __all(cj[0] == cj[1] && cj[2] == cj[3]);
+  fast = __all(tc.phases_fast(x[bb * x_bs], x[bb * x_bs + N - 1]));
+}
+
+template <bool REC>
+__global__ __launch_bounds__(kWave, 1) void k_k2_tt_fwd(int64_t B, int64_t N, const double *__restrict__ x, int64_t x_bs,
+                                                        TermsArgs T, const double *__restrict__ diag,
+                                                        const double *__restrict__ y, double *__restrict__ ll,
+                                                        int32_t *__restrict__ flag, double *__restrict__ rec, Rec R,
+                                                        unsigned long long *__restrict__ guard) {
+  __shared__ __attribute__((aligned(16))) double lds[kFwdLds / 8];
+  bool paired, fast;
+  terms_traits(B, N, x, x_bs, T, paired, fast);
+#define C2K2_TFWD(P_, M_) fwd_body<REC, P_, false, M_>(B, N, x, x_bs, nullptr, 0, diag, nullptr, nullptr, y, ll, flag, rec, R, guard, lds, T)
+  if (paired) { if (fast) C2K2_TFWD(true, 1); else C2K2_TFWD(true, 2); }
+  else { if (fast) C2K2_TFWD(false, 1); else C2K2_TFWD(false, 2); }
+#undef C2K2_TFWD
+}
+
+__global__ __launch_bounds__(kWave, 1) void k_k2_tt_rev(int64_t B, int64_t N, const double *__restrict__ x, int64_t x_bs,
+                                                        TermsArgs T, const int32_t *__restrict__ flag,
+                                                        const double *__restrict__ rec, Rec R,
+                                                        const unsigned long long *__restrict__ guard, TermsGrads G,
+                                                        double *__restrict__ bx, double *__restrict__ bdiag,
+                                                        double *__restrict__ by) {
+  __shared__ __attribute__((aligned(16))) double lds[kRevLds / 8];
+  const int64_t b0 = (int64_t)blockIdx.x * SPW;
+  if (__longlong_as_double((long long)guard[kGateHeadWords + (b0 >> 6)]) > kGuard) return;   // the composed chain takes this group
+  bool paired, fast;
+  terms_traits(B, N, x, x_bs, T, paired, fast);
+#define C2K2_TREV(P_, M_) rev_body<P_, false, M_>(B, N, nullptr, 0, nullptr, flag, rec, R, bx, nullptr, bdiag, nullptr, nullptr, by, lds, T, G)
+  if (paired) { if (fast) C2K2_TREV(true, 1); else C2K2_TREV(true, 2); }
+  else { if (fast) C2K2_TREV(false, 1); else C2K2_TREV(false, 2); }
+#undef C2K2_TREV
 }
 
 }  // namespace c2k2
@@ -794,6 +1026,37 @@ int c2_internal_loglik_k2_grad(int64_t B, int64_t N, const double *t, int64_t t_
   if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
   hipLaunchKernelGGL(k_k2_rev, grid, dim3(kWave), 0, s, B, N, c, c_bs, U, (const int32_t *)flag, (const double *)rec, R,
                      (const unsigned long long *)guard, bt, bc, ba, bU, bV, by);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// Coefficient-level forms (J = Jr + 2 Jc == 8; same arguments as c2_internal_loglik_tt8 / _tt_grad8 of c2_loglik_t.hip).
+int c2_internal_loglik_k2_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                             const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                             int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag, c2_stream_t stream) {
+  if (Jc < 0 || Jc > 4) return C2_ERR_UNSUPPORTED;
+  const TermsArgs T{ar, cr, ac, bc, cc, dc, coef_batched, (int)Jc};
+  Rec R{};
+  hipLaunchKernelGGL((k_k2_tt_fwd<false>), dim3((unsigned)((B + SPW - 1) / SPW)), dim3(kWave), 0, (hipStream_t)stream, B, N, x, x_bs,
+                     T, diag, y, ll, flag, (double *)nullptr, R, (unsigned long long *)nullptr);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// `guard`: kGateHeadWords + ceil(B / 64) words, ALL zeroed by the caller on the same stream (see c2_internal_loglik_k2_grad).
+int c2_internal_loglik_k2_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                                  const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                                  int64_t x_bs, const double *diag, const double *y, double *ll, double *bar, double *bcr,
+                                  double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                                  int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream) {
+  if (Jc < 0 || Jc > 4) return C2_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((B + SPW - 1) / SPW));
+  const TermsArgs T{ar, cr, ac, bc, cc, dc, coef_batched, (int)Jc};
+  const TermsGrads G{bar, bcr, bac, bbc, bcc, bdc};
+  const Rec R = rec_layout(B, N);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((k_k2_tt_fwd<true>), grid, dim3(kWave), 0, s, B, N, x, x_bs, T, diag, y, ll, flag, rec, R, guard);
+  if (hipGetLastError() != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(k_k2_tt_rev, grid, dim3(kWave), 0, s, B, N, x, x_bs, T, (const int32_t *)flag, (const double *)rec, R,
+                     (const unsigned long long *)guard, G, bx, bdiag, by);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

@@ -198,6 +198,8 @@ using namespace c2terms;
 
 // One-lane-per-series kernels that generate U_n / V_n from the coefficients in the lane (c2_loglik_t.hip): no matrices in
 // memory.  Widths 8, 4, 2.  C2_TERMS_FUSED=1 forces them, =0 disables them; otherwise batches that fill the chip.
+// At width 8 the two-lane pair of c2_loglik_k2.hip has the same form (k_k2_tt_*) and takes the batches in between
+// (C2_TERMS_TWO_LANES, profiles/r06_terms_lanes.md).
 extern "C" {
 #define C2_DECL_TT(J_)                                                                                                 \
   int c2_internal_loglik_tt##J_(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr, \
@@ -215,6 +217,16 @@ C2_DECL_TT(8)
 C2_DECL_TT(4)
 C2_DECL_TT(2)
 #undef C2_DECL_TT
+// the same with two lanes per series (c2_loglik_k2.hip, J == 8): batches that give the one-lane mapping half a chip
+int c2_internal_loglik_k2_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                             const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                             int64_t x_bs, const double *diag, const double *y, double *ll, int32_t *flag, c2_stream_t stream);
+int c2_internal_loglik_k2_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *cr,
+                                  const double *ac, const double *bc, const double *cc, const double *dc, const double *x,
+                                  int64_t x_bs, const double *diag, const double *y, double *ll, double *bar, double *bcr,
+                                  double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                                  int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
+size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N);
 int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
                          const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
                          const double *diag, double *a, double *U, double *V, const unsigned long long *gate,
@@ -228,8 +240,20 @@ static bool fused_width(int64_t J) { return J == 8 || J == 4 || J == 2; }
 // guard words in front of the fused kernels' records: the head + one per wavefront of 64 series, rounded to 16 bytes
 static size_t fused_gate_words(int64_t B) { return (size_t)((c2::kGateHeadWords + (B + 63) / 64 + 1) & ~(int64_t)1); }
 static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
-  return J == 8 ? c2_internal_loglik_t_record_doubles8(B, N)
-                : (J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N));
+  if (J == 8) {   // either lane mapping
+    const size_t r1 = c2_internal_loglik_t_record_doubles8(B, N), r2 = c2_internal_loglik_k2_record_doubles(B, N);
+    return r1 > r2 ? r1 : r2;
+  }
+  return J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N);
+}
+// Two lanes per series (J == 8) between the composed chain and the one-lane kernels: C2_TERMS_TWO_LANES=1 forces them, =0
+// disables them; otherwise by batch size (a forced C2_TERMS_FUSED decides first)
+static bool use_two_lanes(int64_t B, int64_t J, bool grad) {
+  if (J != 8) return false;
+  if (c2::opt::has(c2::opt::k_terms_two_lanes)) return c2::opt::ival(c2::opt::k_terms_two_lanes) != 0;
+  if (c2::opt::has(c2::opt::k_terms_fused)) return false;
+  return B >= c2::opt::ival(grad ? c2::opt::k_terms_two_lanes_min_batch_grad : c2::opt::k_terms_two_lanes_min_batch_fwd) &&
+         B < c2::opt::ival(grad ? c2::opt::k_terms_two_lanes_max_batch_grad : c2::opt::k_terms_two_lanes_max_batch_fwd);
 }
 static bool use_fused(int64_t B, int64_t J, bool grad) {
   if (!fused_width(J)) return false;
@@ -273,6 +297,8 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
     return C2_ERR_INVALID;
   const int64_t J = Jr + 2 * Jc;
   if (work_bytes < c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 0)) return C2_ERR_INVALID;
+  if (use_two_lanes(B, J, false))
+    return c2_internal_loglik_k2_tt(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
   if (use_fused(B, J, false))
     return (J == 8 ? c2_internal_loglik_tt8 : (J == 4 ? c2_internal_loglik_tt4 : c2_internal_loglik_tt2))(
         B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
@@ -298,14 +324,17 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
   double *w = (double *)work;
   hipStream_t s = (hipStream_t)stream;
   const unsigned long long *gate = nullptr;
-  if (use_fused(B, J, true)) {
+  const bool two = use_two_lanes(B, J, true);
+  if (two || use_fused(B, J, true)) {
     // Forward with records + reverse sweep, both forming the rows in the lane.  As in c2_loglik_grad, the forward pass
     // leaves its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the
     // composed chain below -- every kernel of it behind the same word -- produces the gradients instead.
     unsigned long long *guard = (unsigned long long *)work;
-    if (hipMemsetAsync(guard, 0, 8 * c2::kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+    // (two lanes per series: the two wavefronts of a group of 64 series raise its word together -- every word starts at zero)
+    if (hipMemsetAsync(guard, 0, 8 * (two ? fused_gate_words(B) : (size_t)c2::kGateHeadWords), s) != hipSuccess) return C2_ERR_HIP;
     w += fused_gate_words(B);
-    auto fused = J == 8 ? c2_internal_loglik_tt_grad8 : (J == 4 ? c2_internal_loglik_tt_grad4 : c2_internal_loglik_tt_grad2);
+    auto fused = two ? c2_internal_loglik_k2_tt_grad
+                     : (J == 8 ? c2_internal_loglik_tt_grad8 : (J == 4 ? c2_internal_loglik_tt_grad4 : c2_internal_loglik_tt_grad2));
     if (int e = fused(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, bar, bcr, bac, bbc, bcc, bdc,
                       bx, bdiag, by, flag, w, guard, stream))
       return e;

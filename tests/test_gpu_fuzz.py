@@ -288,9 +288,12 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
     x = np.sort(rng.uniform(0, N / 10.0 + 0.1, (B, N)), axis=1) + rng.choice([0.0, 2.4e6])
     diag = rng.uniform(0.1, 0.3, (B, N)); y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
     args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
-    monkeypatch.setenv("C2_TERMS_FUSED", "0")
+    monkeypatch.setenv("C2_TERMS_FUSED", "0"); monkeypatch.setenv("C2_TERMS_TWO_LANES", "0")
     ll_c, g_c, fl_c = ops.loglik_terms_grad(*args)
-    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    if J == 8 and seed % 2 == 1:   # two lanes per series (c2_loglik_k2.hip) on every other width-8 draw
+        monkeypatch.setenv("C2_TERMS_TWO_LANES", "1")
+    else:
+        monkeypatch.setenv("C2_TERMS_FUSED", "1")
     ll_f, g_f, fl_f = ops.loglik_terms_grad(*args)
     ll_f0, _ = ops.loglik_terms(*args)
     assert int(fl_c.abs().sum()) == 0 and int(fl_f.abs().sum()) == 0

@@ -29,6 +29,12 @@ def close(a, b, tol=1e-10, floor=1e-12):
     np.testing.assert_allclose(a, b, rtol=tol, atol=floor * max(1.0, float(np.abs(b).max())))
 
 
+def force(monkeypatch, which):
+    """composed chain (matrices in memory) / one lane per series (c2_loglik_t.hip) / two lanes per series (c2_loglik_k2.hip)"""
+    monkeypatch.setenv("C2_TERMS_FUSED", {"composed": "0", "one": "1", "two": "0"}[which])
+    monkeypatch.setenv("C2_TERMS_TWO_LANES", "1" if which == "two" else "0")
+
+
 def coeffs(B, Jr, Jc, rng):
     ar = rng.uniform(0.5, 1.5, (B, Jr)); cr = rng.uniform(0.05, 0.5, (B, Jr))
     ac = rng.uniform(0.5, 2.0, (B, Jc))
@@ -122,11 +128,13 @@ def test_log_likelihood_terms_autograd(ops, oracle):
         ops.loglik_terms(*[v.detach() for v in leaves[:8]], leaves[8].detach()[:, :5].contiguous())
 
 
+@pytest.mark.parametrize("lanes", ["one", "two"])
 @pytest.mark.parametrize("Jr,Jc", [(0, 4), (2, 3), (4, 2), (6, 1), (8, 0)])
 @pytest.mark.parametrize("B,N", [(70, 200), (3, 1), (2, 2), (5, 9), (130, 67)])
-def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc):
-    """The one-lane-per-series kernels that form U_n, V_n in registers (c2_loglik_t.hip, width 8), forced for any batch
-    size, against the same oracle chain; and against the composed path (matrices in memory)."""
+def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc, lanes):
+    """The kernels that form U_n, V_n in registers -- one lane per series (c2_loglik_t.hip) and two lanes per series
+    (c2_loglik_k2.hip: a slot of two columns per lane is a complex term or a pair of real terms), width 8 -- forced for any
+    batch size, against the same oracle chain; and against the composed path (matrices in memory)."""
     rng = np.random.default_rng(100 * Jr + N)
     ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
     x = np.sort(rng.uniform(0, N / 10.0, (B, N)), axis=1)
@@ -135,10 +143,10 @@ def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc):
     nb = min(B, 6)
     want = [oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b]) for b in range(nb)]
     args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
-    monkeypatch.setenv("C2_TERMS_FUSED", "0")
+    force(monkeypatch, "composed")
     ll_c, flag_c = ops.loglik_terms(*args)
     ll_cg, grads_c, _ = ops.loglik_terms_grad(*args)
-    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    force(monkeypatch, lanes)
     ll, flag = ops.loglik_terms(*args)
     assert int(flag.abs().sum()) == 0
     close(ll[:nb], np.array([w[0] for w in want]))
@@ -154,7 +162,7 @@ def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc):
     # shared coefficients and grid
     args_s = dev(ar[0], cr[0], ac[0], bc[0], cc[0], dc[0], x[0], diag, y)
     ll3, grads3, _ = ops.loglik_terms_grad(*args_s)
-    monkeypatch.setenv("C2_TERMS_FUSED", "0")
+    force(monkeypatch, "composed")
     ll4, grads4, _ = ops.loglik_terms_grad(*args_s)
     close(ll3, ll4.cpu().numpy())
     for g3, g4 in zip(grads3, grads4):
@@ -162,7 +170,8 @@ def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc):
             close(g3, g4.cpu().numpy(), tol=1e-9, floor=1e-11)
 
 
-def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, monkeypatch):
+@pytest.mark.parametrize("lanes", ["one", "two"])
+def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, monkeypatch, lanes):
     """Rates x segment span beyond kBackwardGuard: the fused reverse sweep declines on the device and the gated composed
     chain delivers the gradients (same outputs); a batch inside the guard next to it takes the fused sweep."""
     rng = np.random.default_rng(8)
@@ -173,7 +182,7 @@ def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, mon
         x = np.sort(rng.uniform(0, N * scale, (B, N)), axis=1)
         y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
         want = [oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b]) for b in range(4)]
-        monkeypatch.setenv("C2_TERMS_FUSED", "1")
+        force(monkeypatch, lanes)
         ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
         assert int(flag.abs().sum()) == 0
         close(ll[:4], np.array([w[0] for w in want]))
@@ -181,7 +190,8 @@ def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, mon
             close(g[:4], np.stack([w[1][k] for w in want]))
 
 
-def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch):
+@pytest.mark.parametrize("lanes", ["one", "two"])
+def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch, lanes):
     import torch
     rng = np.random.default_rng(3)
     B, N, Jr, Jc = 70, 40, 2, 3
@@ -190,7 +200,7 @@ def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch):
     diag = rng.uniform(0.1, 0.3, (B, N))
     diag[9, 17] = -50.0      # not positive definite
     y = rng.standard_normal((B, N))
-    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    force(monkeypatch, lanes)
     ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
     assert int(flag[9]) != 0 and int(flag.abs().sum()) == int(flag[9].abs())
     for g in grads:
@@ -199,7 +209,8 @@ def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch):
         assert bool(torch.isfinite(ok).all())
 
 
-def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkeypatch):
+@pytest.mark.parametrize("lanes", ["one", "two"])
+def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkeypatch, lanes):
     """Raw Julian dates: dc * x beyond the range of the branch-free sincos -> the wavefront runs the instantiation with
     the library's large-argument reduction; a neighbouring wavefront with small phases keeps the fast one."""
     rng = np.random.default_rng(21)
@@ -215,7 +226,7 @@ def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkey
         _, a_o, U_o, V_o = dense.celerite_matrices(dense.Coeffs(ar=ar[b], cr=cr[b], ac=ac[b], bc=bc[b], cc=cc[b], dc=dc[b]),
                                                    x[b], diag[b])
         close(a_d[b], a_o); close(U_d[b], U_o); close(V_d[b], V_o)
-    monkeypatch.setenv("C2_TERMS_FUSED", "1")
+    force(monkeypatch, lanes)
     ll, grads, flag = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
     ll_f, _ = ops.loglik_terms(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
     assert int(flag.abs().sum()) == 0

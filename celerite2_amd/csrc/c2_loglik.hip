@@ -214,6 +214,91 @@ __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int 
   }
 }
 
+// ---- coefficient-level form of the eight-lane pair (TT; SURVEY.md section 8f-1, driver.cpp:456-474) ------------------------
+// Lane j forms ITS column of U_n and V_n from the celerite coefficients and x_n: a real term r = j (U = ar_r, V = 1), or the
+// cos (even) / sin (odd) column of complex term k = (j - Jr) / 2 -- J = Jr + 2 Jc = 8 makes Jr even, so the two lanes of an
+// XOR-1 pair are two real terms or the two columns of ONE complex term.  One sincos per lane and row (dc = 0 for a real term:
+// cos = 1, sin = 0 exactly).  No U / V rows are read and no bU / bV rows written: the reverse sweep folds the reverse of the
+// recipe (c2_terms.hip: k_terms_rev) into its step.  Only the branch-free sincos lives in these kernels: a group of 64 series
+// with a phase beyond its range (raw Julian dates times a fast frequency) is closed in the gate like one beyond the backward
+// guard, and the composed chain, launched behind on the same words, takes it.  The rates come as the c array (k_rates).
+struct TermsArgs8 {
+  const double *ar, *ac, *bc, *dc;
+  int batched, Jc;
+};
+struct TermsGrads8 {
+  double *bar, *bcr, *bac, *bbc, *bcc, *bdc;
+};
+struct LaneTerm {
+  double A, Bq, D, A0;
+  bool odd, re;
+  __device__ __forceinline__ void load(const TermsArgs8 &T, int64_t b, int j) {
+    const int JC = T.Jc, JR = 8 - 2 * JC;
+    const int64_t br = T.batched ? b * JR : 0, bk = T.batched ? b * JC : 0;
+    re = j < JR;
+    odd = !re && ((j - JR) & 1);
+    if (re) {
+      A = T.ar[br + j]; Bq = 0.0; D = 0.0;
+    } else {
+      const int k = (j - JR) >> 1;
+      const double bb = T.bc[bk + k];
+      A = T.ac[bk + k]; Bq = odd ? -bb : bb; D = T.dc[bk + k];
+    }
+    double sum = 0.0;   // driver.cpp:456-458: the sum of ar, then of ac
+    for (int r = 0; r < JR; ++r) sum += T.ar[br + r];
+    for (int k = 0; k < JC; ++k) sum += T.ac[bk + k];
+    A0 = sum;
+  }
+  // own column of U_n and of V_n (cos column: U = ac cos + bc sin; sin column: U = ac sin - bc cos)
+  __device__ __forceinline__ void uv(double x, double &u, double &v) const {
+    double sn, cs;
+    sincos_cw_fast(D * x, sn, cs);
+    const double p = odd ? sn : cs, q = odd ? cs : sn;
+    u = fma(A, p, Bq * q);
+    v = p;
+  }
+};
+__device__ __forceinline__ bool tt_group_open(const unsigned long long *gate, int64_t b0) {
+  return __longlong_as_double((long long)gate[b0 >> 6]) <= kBackwardGuard;   // (NaN / +inf: closed)
+}
+// One word per group of 64 series for the coefficient-level pair: the largest single-segment span word of its wavefronts
+// (k_anchor_spans, words[2 w + 1]), +inf if a phase dc x of the group leaves the range of the branch-free sincos (x sorted: the
+// largest |x| of a series sits at one of its ends).  head[0]: the largest word of the launch, head[1]: closed groups.
+__global__ __launch_bounds__(256) void k_tt8_gate(int64_t B, int64_t N, int64_t nwaves, int wpg,
+                                                  const unsigned long long *__restrict__ words, TermsArgs8 T,
+                                                  const double *__restrict__ x, int64_t x_bs,
+                                                  unsigned long long *__restrict__ head, unsigned long long *__restrict__ gate) {
+  const int64_t ngroups = (B + 63) / 64;
+  double big = 0.0;
+  unsigned long long closed = 0;
+  for (int64_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+    double m = 0.0;
+    for (int64_t w = wpg * g; words && w < wpg * (g + 1) && w < nwaves; ++w) {
+      const double v = __longlong_as_double((long long)words[2 * w + 1]);
+      m = (v > m || v != v) ? v : m;
+      if (v != v) break;
+    }
+    bool fast = true;
+    for (int64_t b = 64 * g; b < 64 * (g + 1) && b < B; ++b) {
+      const double xm = fmax(fabs(x[b * x_bs]), fabs(x[b * x_bs + N - 1]));
+      for (int k = 0; k < T.Jc; ++k) fast = fast && (fabs(T.dc[(T.batched ? b * T.Jc : 0) + k]) * xm < kSincosFastMax);
+    }
+    if (m != m || !fast) m = __builtin_inf();
+    gate[g] = (unsigned long long)__double_as_longlong(m);
+    big = fmax(big, m);
+    closed += !(m <= kBackwardGuard);
+  }
+  __shared__ double sb[256];
+  __shared__ unsigned long long scl[256];
+  sb[threadIdx.x] = big; scl[threadIdx.x] = closed;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)blockDim.x; ++i) { big = fmax(big, sb[i]); closed += scl[i]; }
+    head[0] = (unsigned long long)__double_as_longlong(big);
+    head[1] = closed;
+  }
+}
+
 // DG: the next step's p and U gathered by DPP permutes instead of through LDS.  The LDS form costs the VALU nothing but
 // makes the wavefront wait for two LDS round trips per step -- which one would expect to hurt when the grid gives every
 // wavefront a SIMD of its own; measured it does not: the DPP form is 2 - 9 % slower there too (launch_fwd).
@@ -225,7 +310,7 @@ __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int 
 // address unit gives back -- 8192 series 4.69 against 4.72 ms, 1024 - 4096 series 9 - 12 % SLOWER -- hence off.  Rows (2P, 2P+1) of a series share a line: one 16-byte piece per lane fetches the pair for all eight
 // series (a ring of four pairs in registers, eight rows ahead), a per-wave LDS tile turns pieces into the lanes' own
 // elements one pair ahead of their use.
-template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC, bool DG = false, bool LN = false>
+template <int G, int R, int C, int MODE, bool PAD, int OCC = C2_FWD_OCC, bool DG = false, bool LN = false, bool TT = false>
 __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ a,
@@ -236,10 +321,15 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
                                                          int64_t nseg, double *__restrict__ Wst,
                                                          double2 *__restrict__ DZst,
                                                          const unsigned long long *__restrict__ gate,
-                                                         const unsigned long long *__restrict__ segguard = nullptr) {
+                                                         const unsigned long long *__restrict__ segguard = nullptr,
+                                                         TermsArgs8 T8 = TermsArgs8{},
+                                                         const unsigned long long *__restrict__ tgate = nullptr) {
   // `gate` (nullable): this launch is the fallback of the one-lane-per-series path and runs only when the stability
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;   // (the series of a wavefront share a group of 64)
+  // TT: the coefficient-level form (`a` = the white-noise diagonal, U / V not read); `tgate`: one word per group of 64 series
+  static_assert(!TT || (G == 8 && !PAD && !LN && MODE != 2), "coefficient-level form: full groups of eight lanes");
+  if constexpr (TT) { if (!tt_group_open(tgate, (int64_t)blockIdx.x * (kWave / G))) return; }
   // MODE 1 with Wst and segguard (the reverse sweep by the BACKWARD recursion, k_loglik_rev<..., BACK>): W rows are
   // recorded as well, and one more checkpoint holds the state after the last row.  segguard[2 w], [2 w + 1] (k_anchor_spans)
   // say what the backward recursion of wavefront w would have to invert: largest c_j x (time spanned by kAnchor segments /
@@ -267,6 +357,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   const double *tb = t + L.b0 * t_bs + ot, *ab = a + L.b0 * N + on, *yb = y + L.b0 * N + on;
   const double *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
+  LaneTerm lt;
+  if constexpr (TT) lt.load(T8, L.b, j);
   // (with W records -- the backward-recursion form -- a wavefront owns one more checkpoint: the state after its last row)
   double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * (nseg + (segguard != nullptr ? 1 : 0)) * CkptRec<G>::DOUBLES : nullptr;
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
@@ -332,7 +424,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   double ru[LN ? 1 : RR], rv[LN ? 1 : RR];
   const double *up = Ub, *vp = Vb;  // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {  // row n = n0 + ahead
-    if constexpr (!LN) {
+    if constexpr (!LN && !TT) {
       int64_t o = ahead;
       if (clamp && n >= N) o -= n - (N - 1);
       ru[r] = act ? up[o * J] : 0.0; rv[r] = act ? vp[o * J] : 0.0;
@@ -371,6 +463,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   lds_order();
   double tnext = sin_[0][0][grp][0];
   double pc = 1.0, uc = LN ? cu[0] : ru[0];
+  double vcur = 0.0;   // (TT) own column of V of the current row
+  if constexpr (TT) lt.uv(tnext, uc, vcur);
   double pXc[G], uXc[G];
   if constexpr (DG) {
     xgather_dpp<G>(pc, xs[0], lane, pXc);
@@ -394,7 +488,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
           if (!sparse || (m % kAnchor == 0 && m > 0))   // (uniform; the backward recursion never reads the state after row 0)
             ckpt_store<G>(ckw + m * CkptRec<G>::DOUBLES, lane, soff, SX, F, w);
         }
-        const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r];
+        const double tn = tnext, yn = sin_[q][2][grp][r];
+        const double an = TT ? sin_[q][1][grp][r] + lt.A0 : sin_[q][1][grp][r];
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
         // (a) next step's p and U -> LDS -> XOR gathers (consumed by the next iteration)
         const int rn = (r + 1) % R;
@@ -409,6 +504,9 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
           } else {
             v = cv[1]; un1 = nu[0];                                 // (pair P + 1, read back during the step before)
           }
+        } else if constexpr (TT) {
+          v = vcur;
+          lt.uv(tn1, un1, vcur);   // row n + 1 (beyond the last row: the clamped time, unused)
         } else {
           v = rv[LN ? 0 : r % RR]; un1 = ru[LN ? 0 : rn % RR];
         }
@@ -546,7 +644,7 @@ __device__ __forceinline__ double afetch(int lo, int hi) {
 // rows (2P, 2P+1) of a series share one -- through per-wave LDS tiles, as in k_loglik_fwd<..., LN>: four line requests per
 // segment for U (rows 8k .. 8k+7; row 8k is handed down to the segment below), one store per completed pair for bU and bV
 // (the lane's element goes into a two-row tile; a pair is complete at its even row and leaves during the step after).
-template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC, bool SC = false, bool LN = false>
+template <int G, int C, bool PAD, bool FR, bool BACK = false, int OCC = C2_REV_OCC, bool SC = false, bool LN = false, bool TT = false>
 __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N, int Jrt, const double *__restrict__ t,
                                                          int64_t t_bs, const double *__restrict__ c, int64_t c_bs,
                                                          const double *__restrict__ U,
@@ -560,7 +658,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
                                                          const double *__restrict__ fr_bd,
                                                          const double *__restrict__ fr_bW,
                                                          const unsigned long long *__restrict__ gate,
-                                                         const unsigned long long *__restrict__ segguard = nullptr) {
+                                                         const unsigned long long *__restrict__ segguard = nullptr,
+                                                         TermsArgs8 T8 = TermsArgs8{}, TermsGrads8 G8 = TermsGrads8{},
+                                                         const unsigned long long *__restrict__ tgate = nullptr) {
+  // TT (coefficient-level form): bt, ba, by are bx, bdiag, by; U, bU, bV, bc are not touched; G8 takes the coefficient gradients
+  static_assert(!TT || (G == 8 && C == 8 && !PAD && !FR && BACK && OCC == 1 && SC && !LN && C2_REV_APARK),
+                "coefficient-level form: the scaled-frame backward sweep on full groups of eight lanes");
+  if constexpr (TT) { if (!tt_group_open(tgate, (int64_t)blockIdx.x * (kWave / G))) return; }
   static_assert(!(BACK && FR), "factor_rev replays from the caller's workspace");
   static_assert(!SC || BACK, "the scaled frame belongs to the backward-recursion sweep");
   static_assert(!LN || (SC && G == 8 && C == 8 && !PAD), "line staging: the scaled-frame sweep on full groups of eight lanes");
@@ -618,6 +722,15 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       for (int64_t n = j; n < N; n += G) {
         if (PAD ? L.valid : true) { btb[n] = nan; bab[n] = nan; byb[n] = nan; }
       }
+      if constexpr (TT) {
+        const int JC = T8.Jc, JR = 8 - 2 * JC;
+        if (j < JR) { G8.bar[L.b * JR + j] = nan; G8.bcr[L.b * JR + j] = nan; }
+        else if (((j - JR) & 1) == 0) {
+          const int64_t o = L.b * JC + ((j - JR) >> 1);
+          G8.bac[o] = nan; G8.bbc[o] = nan; G8.bcc[o] = nan; G8.bdc[o] = nan;
+        }
+        return;
+      }
       for (int64_t n = 0; n < N; ++n) {
         if (st) { bUb[n * J] = nan; bVb[n * J] = nan; }
       }
@@ -625,6 +738,13 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       return;
     }
   }
+  LaneTerm lt;
+  if constexpr (TT) lt.load(T8, L.b, j);
+  // (TT) running sums of the lane: bU_own v_own + bU_p v_p (bac; a real term: sum bU_own), bU_own v_p - bU_p v_own (+- bbc),
+  // x times the phase cotangent (+- bdc), the sum of ba; the lane's own trig column of every row of the segment parked
+  double accA = 0.0, accB = 0.0, accD = 0.0, sba = 0.0;
+  const double wD = (TT && !lt.re && !lt.odd) ? lt.D : 0.0;   // the even lane of a complex term carries g dc into bx
+  int vAlo[TT ? C : 1], vAhi[TT ? C : 1];
 
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
   soff[0] = lane;
@@ -675,7 +795,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      if constexpr (!LN) iu[r] = act ? Ub[n * J] : 0.0;
+      if constexpr (!LN && !TT) iu[r] = act ? Ub[n * J] : 0.0;
       if constexpr (BACK) iw[r] = V[((size_t)blockIdx.x * N + (n - 1)) * kWave + lane];   // the recorded W row n-1 (lane-major)
       else iw[r] = act ? Vb[(n - 1) * J] : 0.0;  // V row n-1 (-> W_{n-1} in the replay); FR: the caller's W row n-1
       if constexpr (FR) ibw[r] = act ? fbWb[(n - 1) * J] : 0.0;
@@ -777,6 +897,14 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
           if (i == 0) ucar = ut[0];
           else iu[2 * i - 1] = ut[0];
           iu[2 * i] = ut[8];
+        }
+      }
+      if constexpr (TT) {   // own columns of U_n, V_n of rows n_lo .. n_lo + C - 1 (entry r + 1 of rowT)
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+          double vown;
+          lt.uv(rowT[r + 1][grp], iu[r], vown);
+          apark(vown, vAlo[r], vAhi[r]);
         }
       }
 #pragma unroll
@@ -932,10 +1060,11 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
               bUl[P * 8] = otile[((r + 2) / 2) & 1][0][lane];
               bVl[P * 8] = otile[((r + 2) / 2) & 1][1][lane];
             }
-          } else {
+          } else if constexpr (!TT) {
             if (st) bVb[n * J] = bVn * gn;
           }
           const double bVout = bVn * gn;
+          const double ba_in = ban;   // ba_n
           // x- = bV- + 2 ba u- is the vector gathered on the chain; M^ -= u-^T x- + bV-^T u- = u-_i bV-_j + x-_i u-_j
           const double xv = fma(2.0 * ban, u, bVn);
           xgather_dpp<G>(xv, xB, lane, xX);
@@ -951,14 +1080,29 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
             if (i & 1) { xs1 = fma(xX[i], SX[i], xs1); bp1 = fma(SX[i], m, bp1); q1 = fma(wX[i], m, q1); }
             else { xs0 = fma(xX[i], SX[i], xs0); bp0 = fma(SX[i], m, bp0); q0 = fma(wX[i], m, q0); }
           }
+          double gs8 = 0.0;   // (TT) sum_k g_nk dc_k of row n: what bx_n has on top of bt_n
           if constexpr (LN) { *obu = ign * (bU1 - (xs0 + xs1)); *obv = bVout; }   // (adjacent tiles: one ds_write2_b64)
+          else if constexpr (TT) {
+            // the reverse of the recipe for row n: own values and the XOR-1 partner's (the other column of the complex term)
+            const double bUo = ign * (bU1 - (xs0 + xs1));          // bU_n, own column
+            const double uo = u * gn;                              // U_n, own column (u is u- = U_n / g_n)
+            const double vo = afetch(vAlo[r], vAhi[r]);            // V_n, own column
+            const double bUp = dpp_mov<kDppXor1>(bUo), bVp = dpp_mov<kDppXor1>(bVout), up = dpp_mov<kDppXor1>(uo);
+            const double vp = lt.re ? 0.0 : dpp_mov<kDppXor1>(vo);
+            accA = fma(bUo, vo, fma(bUp, vp, accA));
+            accB = fma(bUo, vp, fma(-bUp, vo, accB));
+            const double Y = fma(-bUo, up, fma(bUp, uo, fma(-bVout, vp, bVp * vo)));   // +- cotangent of the phase dc x_n
+            accD = fma(Y, rowT[r + 1][grp], accD);
+            gs8 = gsum<G>(Y * wD);
+            sba += ba_in;
+          }
           else if (st) bUb[n * J] = ign * (bU1 - (xs0 + xs1));     // reverse.hpp:66 + internal.hpp:232
           const double bp = bp_s + (bp0 + bp1);
           bcj = fma(dt, bp, bcj);
           const double q = q0 + q1;               // (w~ M^)_j = q_j / g_{n-1}
           double f = cj * bp, Gs = wm * bF, Q = q * wm;
           gsum3<G>(f, Gs, Q);
-          oBT[bq][grp][r] = carry - f;
+          oBT[bq][grp][r] = TT ? carry - f + gs8 : carry - f;   // (TT: bx_n)
           carry = f;
           const double zr = zm * rdm;
           bzn = Gs - zr;
@@ -1156,6 +1300,16 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
       if (st0) byb[0] = bzn;
     }
   }
+  if constexpr (TT) {   // row 0: bU_0 = 0; bV_0 and ba_0 are complete (carT = t_0)
+    double u0, v0;
+    lt.uv(carT, u0, v0);
+    const double bV0 = bVn * gtop, bVp = dpp_mov<kDppXor1>(bV0);
+    const double vp = lt.re ? 0.0 : dpp_mov<kDppXor1>(v0);
+    const double Y = fma(-bV0, vp, bVp * v0);
+    accD = fma(Y, carT, accD);
+    carry += gsum<G>(Y * wD);
+    sba += ban;
+  }
   // row 0 (reverse.hpp:83-84) and the rows of bt the first segment left behind (rows 1 .. C - 1)
   if (st0) bab[0] = ban;
 #pragma unroll
@@ -1174,6 +1328,14 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     bUl[0] = otile[0][0][lane];
     bVl[0] = otile[0][1][lane];
     bc[L.b * J + j] = bcj;
+  } else if constexpr (TT) {
+    const int JC = T8.Jc, JR = 8 - 2 * JC;
+    const double bcp = dpp_mov<kDppXor1>(bcj);
+    if (lt.re) { G8.bar[L.b * JR + j] = sba + accA; G8.bcr[L.b * JR + j] = bcj; }
+    else if (!lt.odd) {
+      const int64_t o = L.b * JC + ((j - JR) >> 1);
+      G8.bac[o] = sba + accA; G8.bbc[o] = accB; G8.bdc[o] = accD; G8.bcc[o] = bcj + bcp;
+    }
   } else if (st) { bVb[0] = SC ? bVn * gtop : bVn; bUb[0] = 0.0; bc[L.b * J + j] = bcj; }
 }
 
@@ -2042,6 +2204,73 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
   }
 #undef C2_REV
   return launch_ok();
+}
+
+// Coefficient-level log-likelihood + gradient on the eight-lane pair (J = Jr + 2 Jc = 8; k_loglik_fwd / k_loglik_rev<..., TT>):
+// batches of at most one wavefront per SIMD.  `c`: the rates (B, 8) (c2_terms.hip: k_rates); `work`: grad_ws(B, N, 8, back)
+// doubles; `guard`: kGateHeadWords + ceil(B / 64) words, written here -- a group of 64 series whose word exceeds
+// kBackwardGuard (a span the backward recursion cannot cross, unsorted times, a phase beyond the branch-free sincos) is left
+// to the caller's composed chain, gated on the same words.
+size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N) { return grad_ws(B, N, 8, true).total; }
+int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N) { return N >= 2 && B >= 1 && (B * 8 + kWave - 1) / kWave <= simd_count(); }
+int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+                                  const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
+                                  const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
+                                  double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                                  int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {
+  if (Jc < 0 || Jc > 4 || !c2_internal_loglik_g8_tt_ok(B, N)) return C2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int C_ = C2_CKPT_C;
+  const int64_t nseg = (N - 1 + C_ - 1) / C_;
+  const GradWs ws = grad_ws(B, N, 8, true);
+  double *ckpt = work, *Wrec = ckpt + ws.ck;
+  double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck + ws.w);
+  unsigned long long *segg = reinterpret_cast<unsigned long long *>(ckpt + ws.ck + ws.w + ws.dz);
+  const dim3 grid((unsigned)((B * 8 + kWave - 1) / kWave));
+  const TermsArgs8 T{ar, ac, bc, dc, coef_batched, (int)Jc};
+  const TermsGrads8 G{bar, bcr, bac, bbc, bcc, bdc};
+  unsigned long long *tgate = guard + kGateHeadWords;
+  hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, s, B, N, 8, C_, kWave / 8, x, x_bs, c, (int64_t)8, segg);
+  if (int e = launch_ok()) return e;
+  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, 8, (const unsigned long long *)segg, T, x, x_bs,
+                     guard, tgate);
+  if (int e = launch_ok()) return e;
+  hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R8, C2_CKPT_C, 1, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, 8, x, x_bs,
+                     c, (int64_t)8, diag, (const double *)nullptr, (const double *)nullptr, y, ll, flag, ckpt, nseg, Wrec, DZst,
+                     (const unsigned long long *)nullptr, (const unsigned long long *)segg, T, (const unsigned long long *)tgate);
+  if (int e = launch_ok()) return e;
+  hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 1, true, false, true>), grid, dim3(kWave), 0, s, B, N, 8, x, x_bs,
+                     c, (int64_t)8, (const double *)nullptr, (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg,
+                     (const int32_t *)flag, bx, (double *)nullptr, bdiag, (double *)nullptr, (double *)nullptr, by,
+                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const unsigned long long *)nullptr,
+                     (const unsigned long long *)segg, T, G, (const unsigned long long *)tgate);
+  return launch_ok();
+}
+
+// The forward-only form: `guard` as above (here a word is 0 or +inf: only the phases decide) ...
+int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+                             const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
+                             const double *diag, const double *y, double *ll, int32_t *flag, unsigned long long *guard,
+                             c2_stream_t stream) {
+  if (Jc < 0 || Jc > 4 || B < 1 || N < 1) return C2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((B * 8 + kWave - 1) / kWave));
+  const TermsArgs8 T{ar, ac, bc, dc, coef_batched, (int)Jc};
+  unsigned long long *tgate = guard + kGateHeadWords;
+  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, 8, (const unsigned long long *)nullptr, T, x, x_bs,
+                     guard, tgate);
+  if (int e = launch_ok()) return e;
+  hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R8, C2_CKPT_C, 0, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, 8, x, x_bs,
+                     c, (int64_t)8, diag, (const double *)nullptr, (const double *)nullptr, y, ll, flag, (double *)nullptr, (int64_t)0,
+                     (double *)nullptr, (double2 *)nullptr, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, T,
+                     (const unsigned long long *)tgate);
+  return launch_ok();
+}
+// ... and the matrix-level eight-lane forward kernel for the groups it declined (`gate`: per group of 64 series, gate_per_wave)
+int c2_internal_loglik_g8_gated(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
+                                const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+                                const unsigned long long *gate, c2_stream_t stream) {
+  return launch_fwd<0>(B, N, 8, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, gate);
 }
 
 // core::factor_rev on the segment-replay kernel (FR mode of k_loglik_rev): the caller's S workspace serves as the

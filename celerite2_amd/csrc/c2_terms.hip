@@ -227,6 +227,21 @@ int c2_internal_loglik_k2_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_bat
                                   double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
                                   int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
 size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N);
+// ... and with eight lanes per series (c2_loglik.hip: k_loglik_fwd / k_loglik_rev<..., TT>): at most one wavefront per SIMD
+size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N);
+int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N);
+int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+                             const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
+                             const double *diag, const double *y, double *ll, int32_t *flag, unsigned long long *guard,
+                             c2_stream_t stream);
+int c2_internal_loglik_g8_gated(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
+                                const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+                                const unsigned long long *gate, c2_stream_t stream);
+int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+                                  const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
+                                  const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
+                                  double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                                  int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream);
 int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,
                          const double *bc, const double *dc, int coef_batched, const double *x, int64_t x_bs,
                          const double *diag, double *a, double *U, double *V, const unsigned long long *gate,
@@ -242,7 +257,9 @@ static size_t fused_gate_words(int64_t B) { return (size_t)((c2::kGateHeadWords 
 static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
   if (J == 8) {   // either lane mapping
     const size_t r1 = c2_internal_loglik_t_record_doubles8(B, N), r2 = c2_internal_loglik_k2_record_doubles(B, N);
-    return r1 > r2 ? r1 : r2;
+    const size_t r3 = al2((size_t)B * 8) + c2_internal_loglik_g8_tt_doubles(B, N);   // (the rates in front: Plan::c)
+    const size_t r = r1 > r2 ? r1 : r2;
+    return r > r3 ? r : r3;
   }
   return J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N);
 }
@@ -259,6 +276,17 @@ static bool use_fused(int64_t B, int64_t J, bool grad) {
   if (!fused_width(J)) return false;
   if (c2::opt::has(c2::opt::k_terms_fused)) return c2::opt::ival(c2::opt::k_terms_fused) != 0;
   return B >= c2::opt::ival(grad ? c2::opt::k_terms_fused_min_batch_grad : c2::opt::k_terms_fused_min_batch_fwd);
+}
+
+// Eight lanes per series (J == 8, gradient) below the two-lane range: C2_TERMS_EIGHT_LANES=1 forces, =0 disables; otherwise
+// by batch size (a forced C2_TERMS_FUSED / C2_TERMS_TWO_LANES decides first)
+static bool use_eight_lanes(int64_t B, int64_t N, int64_t J, bool grad) {
+  if (J != 8) return false;
+  if (grad && !c2_internal_loglik_g8_tt_ok(B, N)) return false;
+  if (c2::opt::has(c2::opt::k_terms_eight_lanes)) return c2::opt::ival(c2::opt::k_terms_eight_lanes) != 0;
+  if (c2::opt::has(c2::opt::k_terms_fused) || c2::opt::has(c2::opt::k_terms_two_lanes)) return false;
+  if (grad) return B >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_grad);
+  return B >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_fwd) && B < c2::opt::ival(c2::opt::k_terms_eight_lanes_max_batch_fwd);
 }
 
 static int matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr, const double *ac,
@@ -284,6 +312,8 @@ size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t
   if (grad && fused_width(J)) {
     const size_t r = fused_record_doubles(B, N, J);
     n = fused_gate_words(B) + (r > n ? r : n);
+  } else if (!grad && J == 8) {
+    n += fused_gate_words(B);   // the eight-lane forward form: one word per group of 64 series in front of the plan
   }
   return n * sizeof(double);
 }
@@ -297,6 +327,22 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
     return C2_ERR_INVALID;
   const int64_t J = Jr + 2 * Jc;
   if (work_bytes < c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 0)) return C2_ERR_INVALID;
+  if (use_eight_lanes(B, N, J, false)) {
+    // every lane forms its column of U, V (k_loglik_fwd<..., TT>); a group of 64 series with a phase beyond the branch-free
+    // sincos is closed in the gate words and goes through matrices in memory, every kernel of that chain behind the same words
+    unsigned long long *guard = (unsigned long long *)work;
+    double *w = (double *)work + fused_gate_words(B);
+    hipStream_t s = (hipStream_t)stream;
+    const Plan p = plan(B, N, J, 0);
+    hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc, coef_batched,
+                       w + p.c, (const unsigned long long *)nullptr);
+    if (int e = launch_ok()) return e;
+    if (int e = c2_internal_loglik_g8_tt(B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, flag, guard, stream))
+      return e;
+    const unsigned long long *gate = c2::gate_per_wave(guard + c2::kGateHeadWords);
+    if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, gate, s)) return e;
+    return c2_internal_loglik_g8_gated(B, N, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, flag, gate, stream);
+  }
   if (use_two_lanes(B, J, false))
     return c2_internal_loglik_k2_tt(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
   if (use_fused(B, J, false))
@@ -324,8 +370,21 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
   double *w = (double *)work;
   hipStream_t s = (hipStream_t)stream;
   const unsigned long long *gate = nullptr;
-  const bool two = use_two_lanes(B, J, true);
-  if (two || use_fused(B, J, true)) {
+  const bool eight = use_eight_lanes(B, N, J, true);
+  const bool two = !eight && use_two_lanes(B, J, true);
+  if (eight) {
+    // the eight-lane pair with the rows formed in the lanes; its gate words (written by the launch) send a group of 64 series
+    // it declines -- a span beyond the backward guard, a phase beyond the branch-free sincos -- to the composed chain below
+    unsigned long long *guard = (unsigned long long *)work;
+    w += fused_gate_words(B);
+    hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc, coef_batched,
+                       w + p.c, (const unsigned long long *)nullptr);
+    if (int e = launch_ok()) return e;
+    if (int e = c2_internal_loglik_g8_tt_grad(B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, bar, bcr, bac,
+                                              bbc, bcc, bdc, bx, bdiag, by, flag, w + al2((size_t)B * 8), guard, stream))
+      return e;
+    gate = c2::gate_per_wave(guard + c2::kGateHeadWords);
+  } else if (two || use_fused(B, J, true)) {
     // Forward with records + reverse sweep, both forming the rows in the lane.  As in c2_loglik_grad, the forward pass
     // leaves its stability measure in `guard`; if it exceeds kBackwardGuard the reverse sweep returns at once and the
     // composed chain below -- every kernel of it behind the same word -- produces the gradients instead.

@@ -109,6 +109,88 @@ __global__ __launch_bounds__(256) void k_q4_gate(int64_t nwaves, const unsigned 
   }
 }
 
+// ---- coefficient-level form (TT; SURVEY.md section 8f-1, driver.cpp:456-474) -----------------------------------------------------
+// A lane's two columns are ONE slot: a complex term (cos / sin columns) or a pair of real terms (J = Jr + 2 Jc = 8 makes Jr
+// even), evaluated by the same instructions -- a real pair is a complex term with dc = 0 (cos = 1, sin = 0 exactly), ac = ar_0,
+// bc = -ar_1, and V's second column selected to 1.  One branch-free sincos per lane and row; no U / V rows are read, no bU / bV
+// rows written: the reverse sweep folds the reverse of the recipe (c2_terms.hip: k_terms_rev) into its step -- three running
+// sums per lane, the sum of ba, bx_n = bt_n + sum_k g_nk dc_k (one more group sum per row).  The rates come as the (B, 8) array
+// of k_rates.  A group of 64 series with a phase beyond the branch-free range is closed in the gate (k_q4_gate_tt) like one
+// beyond the guard, and the caller's composed chain takes it.
+struct TermsArgsQ {
+  const double *ar, *ac, *bc, *dc;
+  int batched, Jc;
+};
+struct TermsGradsQ {
+  double *bar, *bcr, *bac, *bbc, *bcc, *bdc;
+};
+struct SlotTerm {
+  double A, Bq, D, A0;
+  bool re;
+  __device__ __forceinline__ void load(const TermsArgsQ &T, int64_t b, int jl) {
+    const int JC = T.Jc, JR = J - 2 * JC, g = 2 * jl;
+    const int64_t br = T.batched ? b * JR : 0, bk = T.batched ? b * JC : 0;
+    re = g < JR;
+    if (re) {
+      A = T.ar[br + g]; Bq = -T.ar[br + g + 1]; D = 0.0;
+    } else {
+      const int k = (g - JR) >> 1;
+      A = T.ac[bk + k]; Bq = T.bc[bk + k]; D = T.dc[bk + k];
+    }
+    double sum = 0.0;   // driver.cpp:456-458: the sum of ar, then of ac
+    for (int r = 0; r < JR; ++r) sum += T.ar[br + r];
+    for (int k = 0; k < JC; ++k) sum += T.ac[bk + k];
+    A0 = sum;
+  }
+  // the lane's two columns of U_n (and sin, cos of the slot)
+  __device__ __forceinline__ void usc(double x, double (&u)[2], double &sn, double &cs) const {
+    sincos_cw_fast(D * x, sn, cs);
+    u[0] = fma(A, cs, Bq * sn);
+    u[1] = fma(A, sn, -(Bq * cs));
+  }
+  // ... and of V_n
+  __device__ __forceinline__ void uv(double x, double (&u)[2], double (&v)[2]) const {
+    double sn, cs;
+    usc(x, u, sn, cs);
+    v[0] = cs; v[1] = re ? 1.0 : sn;
+  }
+};
+// k_q4_gate with the phases: a group is also closed (+inf) when dc x of one of its series leaves the range of the branch-free
+// sincos (x sorted: the largest |x| of a series sits at one of its ends)
+__global__ __launch_bounds__(256) void k_q4_gate_tt(int64_t B, int64_t N, int64_t nwaves, const unsigned long long *__restrict__ words,
+                                                    TermsArgsQ T, const double *__restrict__ x, int64_t x_bs,
+                                                    unsigned long long *__restrict__ head, unsigned long long *__restrict__ gate) {
+  const int64_t ngroups = (nwaves + 3) / 4;
+  double big = 0.0;
+  unsigned long long closed = 0;
+  for (int64_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
+    double m = 0.0;
+    for (int64_t w = 4 * g; w < 4 * g + 4 && w < nwaves; ++w) {
+      const double v = __longlong_as_double((long long)words[2 * w]);
+      m = (v > m || v != v) ? v : m;
+      if (v != v) break;
+    }
+    bool fast = true;
+    for (int64_t b = 64 * g; b < 64 * (g + 1) && b < B; ++b) {
+      const double xm = fmax(fabs(x[b * x_bs]), fabs(x[b * x_bs + N - 1]));
+      for (int k = 0; k < T.Jc; ++k) fast = fast && (fabs(T.dc[(T.batched ? b * T.Jc : 0) + k]) * xm < kSincosFastMax);
+    }
+    if (m != m || !fast) m = __builtin_inf();
+    gate[g] = (unsigned long long)__double_as_longlong(m);
+    big = fmax(big, m);
+    closed += !(m <= kBackwardGuard);
+  }
+  __shared__ double sb[256];
+  __shared__ unsigned long long sc[256];
+  sb[threadIdx.x] = big; sc[threadIdx.x] = closed;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < (int)blockDim.x; ++i) { big = fmax(big, sb[i]); closed += sc[i]; }
+    head[0] = (unsigned long long)__double_as_longlong(big);
+    head[1] = closed;
+  }
+}
+
 // =============================================================================
 // Forward pass with records, scaled frame.  One step ahead of the chain: ih_{n+1} = exp(-c (t_{n+1} - t_ref)), its
 // reciprocal, u-_{n+1} = U_{n+1} ih_{n+1} and its gather through LDS (off the chain).
@@ -121,14 +203,17 @@ __global__ __launch_bounds__(256) void k_q4_gate(int64_t nwaves, const unsigned 
 // R = rows per block of the transposed scalar streams (and of the row ring without LN): 8, or 16 with LN -- then a scalar
 // request is one whole 128-byte line per series (four series per instruction) instead of a 64-byte run, and t, a, y enter
 // the chip once instead of twice (the second half of a line does not survive eight rows in the cache).
-template <bool LN, int R>
+template <bool LN, int R, bool TT = false>
 __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                                      const double *__restrict__ U, const double *__restrict__ V,
                                                      const double *__restrict__ y, double *__restrict__ ll,
                                                      int32_t *__restrict__ flag, double2 *__restrict__ ckpt, int64_t nslot,
                                                      double2 *__restrict__ Wrec, double2 *__restrict__ DZst,
-                                                     const unsigned long long *__restrict__ gate) {
+                                                     const unsigned long long *__restrict__ gate,
+                                                     TermsArgsQ TQ = TermsArgsQ{}) {
+  // TT: the coefficient-level form -- `a` is the white-noise diagonal, U / V are not read
+  static_assert(!TT || !LN, "coefficient-level form: no rows to stage");
   if (!open_group(gate, (int64_t)blockIdx.x * SPW)) return;
   constexpr int NV = R / LG;
   __shared__ __attribute__((aligned(16))) double2 xs2[kWave];
@@ -144,6 +229,8 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   // complex terms come as pairs of equal rates (terms.py:171-173): when BOTH columns of every lane of the wavefront share
   // their rate, one exponential and one reciprocal per row serve the two (uniform branch; any other model takes both)
   const bool ceq = __all(cj[0] == cj[1]);
+  SlotTerm stm;
+  if constexpr (TT) stm.load(TQ, L.b, jl);
   double2 *ckw = ckpt + (size_t)blockIdx.x * nslot * (kCkD2 * kWave);
   double2 *wrp = Wrec + (size_t)blockIdx.x * N * kWave + lane;
   double2 *dzst = DZst + L.b0 * N + on;
@@ -209,7 +296,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   double2 ru[LN ? 1 : R], rv[LN ? 1 : R];
   const double2 *up = Ub, *vp = Vb;   // row n0 of the current block
   auto load_row = [&](int r, int ahead, int64_t n, bool clamp) {
-    if constexpr (!LN) {
+    if constexpr (!LN && !TT) {
       int64_t o = ahead;
       if (clamp && n >= N) o -= n - (N - 1);
       ru[r] = up[o * LG]; rv[r] = vp[o * LG];
@@ -257,7 +344,9 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
   double tnext = sin_[0][0][grp][0];
   // row n = 0, prepared: ih_n = h_n = 1 (the reference itself), u-_n (own pair) and its gather
   double ihc[2] = {1.0, 1.0}, hc[2] = {1.0, 1.0};
-  double uc[2] = {LN ? cu[0][0] : ru[0].x, LN ? cu[0][1] : ru[0].y};
+  double uc[2] = {TT ? 0.0 : (LN ? cu[0][0] : ru[0].x), TT ? 0.0 : (LN ? cu[0][1] : ru[0].y)};
+  double vcur[2] = {0.0, 0.0};   // (TT) the lane's columns of V of the current row
+  if constexpr (TT) stm.uv(tnext, uc, vcur);
   double hp[2] = {1.0, 1.0};              // h of the row the chain starts from (row 0: the reference itself)
   double uXc[J];
   xs2[lane] = make_double2(uc[0], uc[1]);
@@ -271,7 +360,8 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
     for (int r = 0; r < R; ++r) {
       const int64_t n = n0 + r;
       if (!CHECKED || n < N) {
-        const double tn = tnext, an = sin_[q][1][grp][r], yn = sin_[q][2][grp][r];
+        const double tn = tnext, yn = sin_[q][2][grp][r];
+        const double an = TT ? sin_[q][1][grp][r] + stm.A0 : sin_[q][1][grp][r];
         double vv_[2], ur[2];   // V_n and U_{n+1} of the lane
         const int rn = (r + 1) % R;
         if constexpr (LN) {
@@ -284,10 +374,14 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
           } else {
             vv_[0] = cv[1][0]; vv_[1] = cv[1][1]; ur[0] = nu[0][0]; ur[1] = nu[0][1];
           }
-        } else {
+        } else if constexpr (!TT) {
           vv_[0] = rv[LN ? 0 : r].x; vv_[1] = rv[LN ? 0 : r].y; ur[0] = ru[LN ? 0 : rn].x; ur[1] = ru[LN ? 0 : rn].y;
         }
         const double tn1 = (r + 1 < R) ? sin_[q][0][grp][r + 1] : sin_[q ^ 1][0][grp][0];
+        if constexpr (TT) {   // row n + 1 formed here (beyond the last row: the clamped time, unused)
+          vv_[0] = vcur[0]; vv_[1] = vcur[1];
+          stm.uv(tn1, ur, vcur);
+        }
         // (a) the next row's frame factors and u- -> LDS -> gather.  Behind an anchor row the next row lives in the new frame.
         const double trn = (r == 0 && anchor_block) ? tn : tref;
         double ihn[2], hn[2];
@@ -410,7 +504,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
 // LN (N even): rows of U, bU, bV as whole 128-byte lines through LDS tiles (see k_q4_fwd): four line pairs of U per segment
 // (rows 8k .. 8k+7, two instructions each; row 8k is handed down to the segment below); a lane's bU / bV columns go into a
 // two-row tile and a completed pair leaves, during the step after, as two stores of eight whole lines each.
-template <bool LN>
+template <bool LN, bool TT = false>
 __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ U,
                                                      const double2 *__restrict__ Wrec, const double2 *__restrict__ DZst,
@@ -418,7 +512,10 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
                                                      const int32_t *__restrict__ flag, double *__restrict__ bt,
                                                      double *__restrict__ bc, double *__restrict__ ba, double *__restrict__ bU,
                                                      double *__restrict__ bV, double *__restrict__ by,
-                                                     const unsigned long long *__restrict__ gate) {
+                                                     const unsigned long long *__restrict__ gate,
+                                                     TermsArgsQ TQ = TermsArgsQ{}, TermsGradsQ GQ = TermsGradsQ{}) {
+  // TT (coefficient-level form): bt, ba, by are bx, bdiag, by; U, bU, bV, bc are not touched; GQ takes the coefficient gradients
+  static_assert(!TT || !LN, "coefficient-level form: no rows to stage");
   if (!open_group(gate, (int64_t)blockIdx.x * SPW)) return;
   constexpr int NV = C / LG;
   __shared__ __attribute__((aligned(16))) double rowT[C + 1][SPW], rowD[C + 1][SPW], rowR[C + 1][SPW], rowZ[C + 1][SPW];
@@ -447,9 +544,17 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
   if (!alive) {
     const double nan = __builtin_nan("");
     for (int64_t n = jl; n < N; n += LG) { btb[n] = nan; bab[n] = nan; byb[n] = nan; }
-    for (int64_t n = 0; n < N; ++n) { bUb[n * LG] = make_double2(nan, nan); bVb[n * LG] = make_double2(nan, nan); }
-    bc[L.b * J + 2 * jl] = nan; bc[L.b * J + 2 * jl + 1] = nan;
+    if constexpr (!TT) {
+      for (int64_t n = 0; n < N; ++n) { bUb[n * LG] = make_double2(nan, nan); bVb[n * LG] = make_double2(nan, nan); }
+      bc[L.b * J + 2 * jl] = nan; bc[L.b * J + 2 * jl + 1] = nan;
+    }
   }
+  SlotTerm stm;
+  if constexpr (TT) stm.load(TQ, L.b, jl);
+  // (TT) running sums of the lane's slot: [0] bac (a real pair: sum bU_0), [1] bbc (-sum bU_1), [2] bdc; the sum of ba; sin / cos
+  // of every row of the segment parked next to u- and w~
+  double acc[3] = {0.0, 0.0, 0.0}, sba = 0.0;
+  int scAlo[TT ? C : 1][2], scAhi[TT ? C : 1][2];
 
   double MX[2][J];
 #pragma unroll
@@ -506,7 +611,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
 #pragma unroll
     for (int r = 0; r < C; ++r) {
       const int64_t n = (full || n_lo + r < N) ? n_lo + r : N - 1;
-      if constexpr (!LN) { const double2 u2 = Ub[n * LG]; iu[r][0] = u2.x; iu[r][1] = u2.y; }
+      if constexpr (!LN && !TT) { const double2 u2 = Ub[n * LG]; iu[r][0] = u2.x; iu[r][1] = u2.y; }
       const double2 w2 = wrp[(size_t)(n - 1) * kWave];
       iw[r][0] = w2.x; iw[r][1] = w2.y;
     }
@@ -582,6 +687,15 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
         iu[2 * i][0] = a1.x; iu[2 * i][1] = a1.y;
       }
     }
+    if constexpr (TT) {   // the lane's columns of U_n of rows n_lo .. n_lo + C - 1 (entry r + 1 of rowT)
+#pragma unroll
+      for (int r = 0; r < C; ++r) {
+        double sn, cs;
+        stm.usc(rowT[r + 1][grp], iu[r], sn, cs);
+        apark(sn, scAlo[r][0], scAhi[r][0]);
+        apark(cs, scAlo[r][1], scAhi[r][1]);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < C; ++r) {
 #pragma unroll
@@ -636,10 +750,11 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
               }
             }
           }
-        } else {
+        } else if constexpr (!TT) {
           if (alive) bVb[n * LG] = make_double2(bVn[0] * gn[0], bVn[1] * gn[1]);
         }
         const double bVo[2] = {bVn[0] * gn[0], bVn[1] * gn[1]};
+        const double ba_in = ban;   // ba_n
         xg2(xv[0], xv[1], xX);
         double bpt[2], qv[2], bUo[2];
 #pragma unroll
@@ -661,12 +776,23 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
           bcj[m] = fma(dt, bpt[m], bcj[m]);
           qv[m] = q0 + q1;
         }
+        double gsq = 0.0;   // (TT) sum_k g_nk dc_k of row n: what bx_n has on top of bt_n
         if constexpr (LN) { ob[0] = make_double2(bUo[0], bUo[1]); ob[2 * kWave] = make_double2(bVo[0], bVo[1]); }
+        else if constexpr (TT) {   // the reverse of the recipe for row n, the lane's slot
+          const double sn = afetch(scAlo[r][0], scAhi[r][0]), cs = afetch(scAlo[r][1], scAhi[r][1]);
+          const double u0 = u[0] * gn[0], u1 = u[1] * gn[1];   // U_n (u is u- = U_n / g_n)
+          acc[0] = fma(bUo[0], cs, fma(bUo[1], sn, acc[0]));
+          acc[1] = fma(bUo[0], sn, fma(-bUo[1], cs, acc[1]));
+          const double g = fma(-bUo[0], u1, fma(bUo[1], u0, fma(-bVo[0], sn, bVo[1] * cs)));   // cotangent of the phase dc x_n
+          acc[2] = fma(g, rowT[r + 1][grp], acc[2]);
+          gsq = gsum<LG>(g * stm.D);
+          sba += ba_in;
+        }
         else if (alive) bUb[n * LG] = make_double2(bUo[0], bUo[1]);
         double f = fma(cj[0], bpt[0], cj[1] * bpt[1]), Gs = fma(wm[0], bF[0], wm[1] * bF[1]),
                Q = fma(qv[0], wm[0], qv[1] * wm[1]);
         gsum3<LG>(f, Gs, Q);
-        oBT[bq][grp][r] = carry - f;
+        oBT[bq][grp][r] = TT ? carry - f + gsq : carry - f;   // (TT: bx_n)
         carry = f;
         const double zr = zm * rdm;
         bzn = Gs - zr;
@@ -737,9 +863,27 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
     bzn = -cz * rd0;
     if (alive) byb[0] = bzn;
   }
+  if constexpr (TT) {   // row 0: bU_0 = 0; bV_0 and ba_0 are complete (carT = t_0)
+    double u0[2], sn, cs;
+    stm.usc(carT, u0, sn, cs);
+    const double g = fma(-(bVn[0] * gtop[0]), sn, (bVn[1] * gtop[1]) * cs);
+    acc[2] = fma(g, carT, acc[2]);
+    carry += gsum<LG>(g * stm.D);
+    sba += ban;
+    const int JC = TQ.Jc, JR = J - 2 * JC, g0 = 2 * jl;
+    const double nan = __builtin_nan("");
+    if (stm.re) {
+      GQ.bar[L.b * JR + g0] = alive ? sba + acc[0] : nan; GQ.bar[L.b * JR + g0 + 1] = alive ? sba - acc[1] : nan;
+      GQ.bcr[L.b * JR + g0] = alive ? bcj[0] : nan; GQ.bcr[L.b * JR + g0 + 1] = alive ? bcj[1] : nan;
+    } else {
+      const int64_t o = L.b * JC + ((g0 - JR) >> 1);
+      GQ.bac[o] = alive ? sba + acc[0] : nan; GQ.bbc[o] = alive ? acc[1] : nan;
+      GQ.bdc[o] = alive ? acc[2] : nan; GQ.bcc[o] = alive ? bcj[0] + bcj[1] : nan;
+    }
+  }
   if (alive) {
     bab[0] = ban; btb[0] = carry;                            // row 0 (reverse.hpp:83-84)
-    reinterpret_cast<double2 *>(bc + L.b * J)[jl] = make_double2(bcj[0], bcj[1]);
+    if constexpr (!TT) reinterpret_cast<double2 *>(bc + L.b * J)[jl] = make_double2(bcj[0], bcj[1]);
   }
   if constexpr (LN) {   // row 0 completes pair 0 (row 1 is in the tile of even pairs since the last step)
     otile[0][0][grp * 8 + jl] = make_double2(0.0, 0.0);
@@ -749,6 +893,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_rev(int64_t B, int64_t N, const
     for (int m = 0; m < NV; ++m) {
       if (ok8[m]) { bUl8[m][0] = otile[0][0][m * kWave + lane]; bVl8[m][0] = otile[0][1][m * kWave + lane]; }
     }
+  } else if constexpr (TT) {
   } else if (alive) {
     bVb[0] = make_double2(bVn[0] * gtop[0], bVn[1] * gtop[1]);
     bUb[0] = make_double2(0.0, 0.0);
@@ -820,6 +965,37 @@ int c2_internal_loglik_q4_grad(int64_t B, int64_t N, const double *t, int64_t t_
   }
 #undef C2_Q4_FWD_ARGS
 #undef C2_Q4_REV_ARGS
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+
+// Coefficient-level log-likelihood + gradient (J = Jr + 2 Jc = 8) on this pair, the rows formed in the lanes.  `c`: the rates
+// (B, 8) (c2_terms.hip: k_rates); `rec`, `guard` as above -- a group of 64 series the pair declines (a span beyond the guard,
+// unsorted times, a phase beyond the branch-free sincos) is left to the caller's composed chain, gated on the same words.
+int c2_internal_loglik_q4_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+                                  const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
+                                  const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
+                                  double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                                  int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream) {
+  if (Jc < 0 || Jc > 4 || B < 1 || N < 1) return C2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const q4::Layout l = q4::layout(B, N);
+  double2 *ck = reinterpret_cast<double2 *>(rec);
+  double2 *W = reinterpret_cast<double2 *>(rec + l.ck);
+  double2 *DZ = reinterpret_cast<double2 *>(rec + l.ck + l.w);
+  unsigned long long *words = reinterpret_cast<unsigned long long *>(rec + l.ck + l.w + l.dz);
+  unsigned long long *gate = guard + kGateHeadWords;
+  const dim3 grid((unsigned)l.waves);
+  const q4::TermsArgsQ T{ar, ac, bc, dc, coef_batched, (int)Jc};
+  const q4::TermsGradsQ G{bar, bcr, bac, bbc, bcc, bdc};
+  if (int e = c2_internal_anchor_spans(B, N, q4::J, q4::C, q4::SPW, x, x_bs, c, 8, words, stream)) return e;
+  hipLaunchKernelGGL(q4::k_q4_gate_tt, dim3(1), dim3(256), 0, s, B, N, (int64_t)l.waves, (const unsigned long long *)words, T, x, x_bs,
+                     guard, gate);
+  hipLaunchKernelGGL((q4::k_q4_fwd<false, 16, true>), grid, dim3(kWave), 0, s, B, N, x, x_bs, c, (int64_t)8, diag,
+                     (const double *)nullptr, (const double *)nullptr, y, ll, flag, ck, l.nslot, W, DZ,
+                     (const unsigned long long *)gate, T);
+  hipLaunchKernelGGL((q4::k_q4_rev<false, true>), grid, dim3(kWave), 0, s, B, N, x, x_bs, c, (int64_t)8, (const double *)nullptr,
+                     (const double2 *)W, (const double2 *)DZ, (const double2 *)ck, l.nslot, l.nseg, (const int32_t *)flag, bx,
+                     (double *)nullptr, bdiag, (double *)nullptr, (double *)nullptr, by, (const unsigned long long *)gate, T, G);
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
 

@@ -230,6 +230,13 @@ size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N);
 // ... and with eight lanes per series (c2_loglik.hip: k_loglik_fwd / k_loglik_rev<..., TT>): at most one wavefront per SIMD
 size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N);
 int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N);
+// ... and with four (c2_loglik_q4.hip: k_q4_fwd / k_q4_rev<..., TT>): the batches between the eight-lane and the two-lane range
+size_t c2_internal_loglik_q4_record_doubles(int64_t B, int64_t N);
+int c2_internal_loglik_q4_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+                                  const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
+                                  const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
+                                  double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
+                                  int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
 int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
                              const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
                              const double *diag, const double *y, double *ll, int32_t *flag, unsigned long long *guard,
@@ -258,8 +265,10 @@ static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
   if (J == 8) {   // either lane mapping
     const size_t r1 = c2_internal_loglik_t_record_doubles8(B, N), r2 = c2_internal_loglik_k2_record_doubles(B, N);
     const size_t r3 = al2((size_t)B * 8) + c2_internal_loglik_g8_tt_doubles(B, N);   // (the rates in front: Plan::c)
-    const size_t r = r1 > r2 ? r1 : r2;
-    return r > r3 ? r : r3;
+    const size_t r4 = al2((size_t)B * 8) + c2_internal_loglik_q4_record_doubles(B, N);
+    size_t r = r1 > r2 ? r1 : r2;
+    r = r > r3 ? r : r3;
+    return r > r4 ? r : r4;
   }
   return J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N);
 }
@@ -287,6 +296,16 @@ static bool use_eight_lanes(int64_t B, int64_t N, int64_t J, bool grad) {
   if (c2::opt::has(c2::opt::k_terms_fused) || c2::opt::has(c2::opt::k_terms_two_lanes)) return false;
   if (grad) return B >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_grad);
   return B >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_fwd) && B < c2::opt::ival(c2::opt::k_terms_eight_lanes_max_batch_fwd);
+}
+
+// Four lanes per series (J == 8, gradient): C2_TERMS_FOUR_LANES=1 forces, =0 disables; otherwise by batch size (any other forced
+// mapping decides first)
+static bool use_four_lanes(int64_t B, int64_t J) {
+  if (J != 8) return false;
+  if (c2::opt::has(c2::opt::k_terms_four_lanes)) return c2::opt::ival(c2::opt::k_terms_four_lanes) != 0;
+  if (c2::opt::has(c2::opt::k_terms_fused) || c2::opt::has(c2::opt::k_terms_two_lanes) || c2::opt::has(c2::opt::k_terms_eight_lanes))
+    return false;
+  return B >= c2::opt::ival(c2::opt::k_terms_four_lanes_min_batch_grad) && B < c2::opt::ival(c2::opt::k_terms_four_lanes_max_batch_grad);
 }
 
 static int matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *cr, const double *ac,
@@ -370,9 +389,10 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
   double *w = (double *)work;
   hipStream_t s = (hipStream_t)stream;
   const unsigned long long *gate = nullptr;
-  const bool eight = use_eight_lanes(B, N, J, true);
-  const bool two = !eight && use_two_lanes(B, J, true);
-  if (eight) {
+  const bool four = use_four_lanes(B, J);
+  const bool eight = !four && use_eight_lanes(B, N, J, true);
+  const bool two = !four && !eight && use_two_lanes(B, J, true);
+  if (eight || four) {
     // the eight-lane pair with the rows formed in the lanes; its gate words (written by the launch) send a group of 64 series
     // it declines -- a span beyond the backward guard, a phase beyond the branch-free sincos -- to the composed chain below
     unsigned long long *guard = (unsigned long long *)work;
@@ -380,8 +400,9 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
     hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc, coef_batched,
                        w + p.c, (const unsigned long long *)nullptr);
     if (int e = launch_ok()) return e;
-    if (int e = c2_internal_loglik_g8_tt_grad(B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, bar, bcr, bac,
-                                              bbc, bcc, bdc, bx, bdiag, by, flag, w + al2((size_t)B * 8), guard, stream))
+    if (int e = (four ? c2_internal_loglik_q4_tt_grad : c2_internal_loglik_g8_tt_grad)(
+            B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, by, flag,
+            w + al2((size_t)B * 8), guard, stream))
       return e;
     gate = c2::gate_per_wave(guard + c2::kGateHeadWords);
   } else if (two || use_fused(B, J, true)) {

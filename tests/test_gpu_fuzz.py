@@ -290,11 +290,13 @@ def test_fuzz_fused_terms_kernels(ops, monkeypatch, seed):
     args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
     monkeypatch.setenv("C2_TERMS_FUSED", "0"); monkeypatch.setenv("C2_TERMS_TWO_LANES", "0")
     ll_c, g_c, fl_c = ops.loglik_terms_grad(*args)
-    monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "0")
-    if J == 8 and seed % 3 == 1:   # two lanes per series (c2_loglik_k2.hip) / eight (k_loglik_*<..., TT>) on width-8 draws
+    monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "0"); monkeypatch.setenv("C2_TERMS_FOUR_LANES", "0")
+    if J == 8 and seed % 4 == 1:   # two lanes per series (c2_loglik_k2.hip) / eight (k_loglik_*<..., TT>) / four (k_q4_*<..., TT>)
         monkeypatch.setenv("C2_TERMS_TWO_LANES", "1")
-    elif J == 8 and seed % 3 == 2:
+    elif J == 8 and seed % 4 == 2:
         monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "1")
+    elif J == 8 and seed % 4 == 3:
+        monkeypatch.setenv("C2_TERMS_FOUR_LANES", "1")
     else:
         monkeypatch.setenv("C2_TERMS_FUSED", "1")
     ll_f, g_f, fl_f = ops.loglik_terms_grad(*args)

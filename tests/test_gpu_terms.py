@@ -30,11 +30,12 @@ def close(a, b, tol=1e-10, floor=1e-12):
 
 
 def force(monkeypatch, which):
-    """composed chain (matrices in memory) / one lane per series (c2_loglik_t.hip) / two lanes (c2_loglik_k2.hip) / eight lanes
-    (c2_loglik.hip: k_loglik_*<..., TT>; the forward-only call and a series of one row stay on the composed chain)"""
+    """composed chain (matrices in memory) / one lane per series (c2_loglik_t.hip) / two lanes (c2_loglik_k2.hip) / four (c2_loglik_q4.hip:
+    k_q4_*<..., TT>, gradient only) / eight (c2_loglik.hip: k_loglik_*<..., TT>; its gradient of a one-row series stays composed)"""
     monkeypatch.setenv("C2_TERMS_FUSED", "1" if which == "one" else "0")
     monkeypatch.setenv("C2_TERMS_TWO_LANES", "1" if which == "two" else "0")
-    monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "1" if which == "eight" else "0")   # (gradient only; N >= 2)
+    monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "1" if which == "eight" else "0")   # (the gradient at N >= 2; forward any N)
+    monkeypatch.setenv("C2_TERMS_FOUR_LANES", "1" if which == "four" else "0")     # (gradient only)
 
 
 def coeffs(B, Jr, Jc, rng):
@@ -130,7 +131,7 @@ def test_log_likelihood_terms_autograd(ops, oracle):
         ops.loglik_terms(*[v.detach() for v in leaves[:8]], leaves[8].detach()[:, :5].contiguous())
 
 
-@pytest.mark.parametrize("lanes", ["one", "two", "eight"])
+@pytest.mark.parametrize("lanes", ["one", "two", "four", "eight"])
 @pytest.mark.parametrize("Jr,Jc", [(0, 4), (2, 3), (4, 2), (6, 1), (8, 0)])
 @pytest.mark.parametrize("B,N", [(70, 200), (3, 1), (2, 2), (5, 9), (130, 67)])
 def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc, lanes):
@@ -172,7 +173,7 @@ def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc, lanes):
             close(g3, g4.cpu().numpy(), tol=1e-9, floor=1e-11)
 
 
-@pytest.mark.parametrize("lanes", ["one", "two", "eight"])
+@pytest.mark.parametrize("lanes", ["one", "two", "four", "eight"])
 def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, monkeypatch, lanes):
     """Rates x segment span beyond kBackwardGuard: the fused reverse sweep declines on the device and the gated composed
     chain delivers the gradients (same outputs); a batch inside the guard next to it takes the fused sweep."""
@@ -192,7 +193,7 @@ def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, mon
             close(g[:4], np.stack([w[1][k] for w in want]))
 
 
-@pytest.mark.parametrize("lanes", ["one", "two", "eight"])
+@pytest.mark.parametrize("lanes", ["one", "two", "four", "eight"])
 def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch, lanes):
     import torch
     rng = np.random.default_rng(3)
@@ -211,7 +212,7 @@ def test_fused_terms_failed_series_gradients_are_nan(ops, monkeypatch, lanes):
         assert bool(torch.isfinite(ok).all())
 
 
-@pytest.mark.parametrize("lanes", ["one", "two", "eight"])
+@pytest.mark.parametrize("lanes", ["one", "two", "four", "eight"])
 def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkeypatch, lanes):
     """Raw Julian dates: dc * x beyond the range of the branch-free sincos -> the wavefront runs the instantiation with
     the library's large-argument reduction; a neighbouring wavefront with small phases keeps the fast one."""

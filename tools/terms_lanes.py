@@ -12,7 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from celerite2_amd import ops, synth  # noqa: E402
 from tools.terms_time import timed  # noqa: E402
 
-MODES = {"composed": ("0", "0", "0"), "one": ("1", "0", "0"), "two": ("0", "1", "0"), "eight": ("0", "0", "1")}
+MODES = {"composed": ("0", "0", "0", "0"), "one": ("1", "0", "0", "0"), "two": ("0", "1", "0", "0"), "eight": ("0", "0", "1", "0"),
+         "four": ("0", "0", "0", "1")}
 
 
 def main():
@@ -27,9 +28,10 @@ def main():
         e = torch.zeros((B, 0), dtype=torch.float64, device="cuda")
         row = {"B": B, "N": N}
         ref = None
-        for name, (fu, two, eight) in MODES.items():
-            if name == "eight" and B > 8192:
+        for name, (fu, two, eight, four) in MODES.items():
+            if (name == "eight" and B > 8192) or (name == "four" and B > 24576):
                 continue
+            os.environ["C2_TERMS_FOUR_LANES"] = four
             os.environ["C2_TERMS_FUSED"] = fu
             os.environ["C2_TERMS_TWO_LANES"] = two
             os.environ["C2_TERMS_EIGHT_LANES"] = eight

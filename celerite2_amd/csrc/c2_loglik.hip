@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void k_anchor_spans(int64_t B, int64_t N, int 
 
 // ---- coefficient-level form of the eight-lane pair (TT; SURVEY.md section 8f-1, driver.cpp:456-474) ------------------------
 // Lane j forms ITS column of U_n and V_n from the celerite coefficients and x_n: a real term r = j (U = ar_r, V = 1), or the
-// cos (even) / sin (odd) column of complex term k = (j - Jr) / 2 -- J = Jr + 2 Jc = 8 makes Jr even, so the two lanes of an
-// XOR-1 pair are two real terms or the two columns of ONE complex term.  One sincos per lane and row (dc = 0 for a real term:
+// cos (even) / sin (odd) column of complex term k = (j - Jr) / 2 -- J = Jr + 2 Jc = 8, 4 or 2 makes Jr even, so the two lanes of
+// an XOR-1 pair are two real terms or the two columns of ONE complex term.  One sincos per lane and row (dc = 0 for a real term:
 // cos = 1, sin = 0 exactly).  No U / V rows are read and no bU / bV rows written: the reverse sweep folds the reverse of the
 // recipe (c2_terms.hip: k_terms_rev) into its step.  Only the branch-free sincos lives in these kernels: a group of 64 series
 // with a phase beyond its range (raw Julian dates times a fast frequency) is closed in the gate like one beyond the backward
@@ -232,8 +232,8 @@ struct TermsGrads8 {
 struct LaneTerm {
   double A, Bq, D, A0;
   bool odd, re;
-  __device__ __forceinline__ void load(const TermsArgs8 &T, int64_t b, int j) {
-    const int JC = T.Jc, JR = 8 - 2 * JC;
+  __device__ __forceinline__ void load(const TermsArgs8 &T, int64_t b, int j, int J) {
+    const int JC = T.Jc, JR = J - 2 * JC;
     const int64_t br = T.batched ? b * JR : 0, bk = T.batched ? b * JC : 0;
     re = j < JR;
     odd = !re && ((j - JR) & 1);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   // guard that path measured exceeds kBackwardGuard (stream-ordered device decision, no host round trip).
   if (gate_closed(gate, (int64_t)blockIdx.x * (kWave / G))) return;   // (the series of a wavefront share a group of 64)
   // TT: the coefficient-level form (`a` = the white-noise diagonal, U / V not read); `tgate`: one word per group of 64 series
-  static_assert(!TT || (G == 8 && !PAD && !LN && MODE != 2), "coefficient-level form: full groups of eight lanes");
+  static_assert(!TT || (G >= 2 && G <= 8 && !PAD && !LN && MODE != 2), "coefficient-level form: full groups of two to eight lanes");
   if constexpr (TT) { if (!tt_group_open(tgate, (int64_t)blockIdx.x * (kWave / G))) return; }
   // MODE 1 with Wst and segguard (the reverse sweep by the BACKWARD recursion, k_loglik_rev<..., BACK>): W rows are
   // recorded as well, and one more checkpoint holds the state after the last row.  segguard[2 w], [2 w + 1] (k_anchor_spans)
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_fwd(int64_t B, int64_t N,
   const double *Ub = U + L.b0 * N * J + oj, *Vb = V + L.b0 * N * J + oj;
   const double cj = act ? c[L.b * c_bs + j] : 0.0;
   LaneTerm lt;
-  if constexpr (TT) lt.load(T8, L.b, j);
+  if constexpr (TT) lt.load(T8, L.b, j, G);
   // (with W records -- the backward-recursion form -- a wavefront owns one more checkpoint: the state after its last row)
   double *ckw = CKPT ? ckpt + (size_t)blockIdx.x * (nseg + (segguard != nullptr ? 1 : 0)) * CkptRec<G>::DOUBLES : nullptr;
   int soff[G];  // packed-S offsets of this lane (slot 0 lives at [lane])
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
                                                          TermsArgs8 T8 = TermsArgs8{}, TermsGrads8 G8 = TermsGrads8{},
                                                          const unsigned long long *__restrict__ tgate = nullptr) {
   // TT (coefficient-level form): bt, ba, by are bx, bdiag, by; U, bU, bV, bc are not touched; G8 takes the coefficient gradients
-  static_assert(!TT || (G == 8 && C == 8 && !PAD && !FR && BACK && OCC == 1 && SC && !LN && C2_REV_APARK),
-                "coefficient-level form: the scaled-frame backward sweep on full groups of eight lanes");
+  static_assert(!TT || (G >= 2 && G <= 8 && C == 8 && !PAD && !FR && BACK && OCC == 1 && SC && !LN && C2_REV_APARK),
+                "coefficient-level form: the scaled-frame backward sweep on full groups of two to eight lanes");
   if constexpr (TT) { if (!tt_group_open(tgate, (int64_t)blockIdx.x * (kWave / G))) return; }
   static_assert(!(BACK && FR), "factor_rev replays from the caller's workspace");
   static_assert(!SC || BACK, "the scaled frame belongs to the backward-recursion sweep");
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
         if (PAD ? L.valid : true) { btb[n] = nan; bab[n] = nan; byb[n] = nan; }
       }
       if constexpr (TT) {
-        const int JC = T8.Jc, JR = 8 - 2 * JC;
+        const int JC = T8.Jc, JR = G - 2 * JC;
         if (j < JR) { G8.bar[L.b * JR + j] = nan; G8.bcr[L.b * JR + j] = nan; }
         else if (((j - JR) & 1) == 0) {
           const int64_t o = L.b * JC + ((j - JR) >> 1);
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     }
   }
   LaneTerm lt;
-  if constexpr (TT) lt.load(T8, L.b, j);
+  if constexpr (TT) lt.load(T8, L.b, j, G);
   // (TT) running sums of the lane: bU_own v_own + bU_p v_p (bac; a real term: sum bU_own), bU_own v_p - bU_p v_own (+- bbc),
   // x times the phase cotangent (+- bdc), the sum of ba; the lane's own trig column of every row of the segment parked
   double accA = 0.0, accB = 0.0, accD = 0.0, sba = 0.0;
@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(kWave, OCC) void k_loglik_rev(int64_t B, int64_t N,
     bVl[0] = otile[0][1][lane];
     bc[L.b * J + j] = bcj;
   } else if constexpr (TT) {
-    const int JC = T8.Jc, JR = 8 - 2 * JC;
+    const int JC = T8.Jc, JR = G - 2 * JC;
     const double bcp = dpp_mov<kDppXor1>(bcj);
     if (lt.re) { G8.bar[L.b * JR + j] = sba + accA; G8.bcr[L.b * JR + j] = bcj; }
     else if (!lt.odd) {
@@ -2206,71 +2206,84 @@ static int loglik_grad_group(int64_t B, int64_t N, int64_t J, const double *t, i
   return launch_ok();
 }
 
-// Coefficient-level log-likelihood + gradient on the eight-lane pair (J = Jr + 2 Jc = 8; k_loglik_fwd / k_loglik_rev<..., TT>):
-// batches of at most one wavefront per SIMD.  `c`: the rates (B, 8) (c2_terms.hip: k_rates); `work`: grad_ws(B, N, 8, back)
-// doubles; `guard`: kGateHeadWords + ceil(B / 64) words, written here -- a group of 64 series whose word exceeds
-// kBackwardGuard (a span the backward recursion cannot cross, unsorted times, a phase beyond the branch-free sincos) is left
-// to the caller's composed chain, gated on the same words.
-size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N) { return grad_ws(B, N, 8, true).total; }
-int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N) { return N >= 2 && B >= 1 && (B * 8 + kWave - 1) / kWave <= simd_count(); }
-int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+// Coefficient-level log-likelihood + gradient on the group mappings (J = Jr + 2 Jc = 8, 4 or 2 lanes per series;
+// k_loglik_fwd / k_loglik_rev<..., TT>): batches of at most one wavefront per SIMD.  `c`: the rates (B, J) (c2_terms.hip:
+// k_rates); `work`: grad_ws(B, N, J, back) doubles; `guard`: kGateHeadWords + ceil(B / 64) words, written here -- a group of 64
+// series whose word exceeds kBackwardGuard (a span the backward recursion cannot cross, unsorted times, a phase beyond the
+// branch-free sincos) is left to the caller's composed chain, gated on the same words.
+size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N, int64_t J) { return grad_ws(B, N, J, true).total; }
+int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N, int64_t J) {
+  return (J == 8 || J == 4 || J == 2) && N >= 2 && B >= 1 && (B * J + kWave - 1) / kWave <= simd_count();
+}
+int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t J, int64_t Jc, int coef_batched, const double *ar, const double *ac,
                                   const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
                                   const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
                                   double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
                                   int32_t *flag, double *work, unsigned long long *guard, c2_stream_t stream) {
-  if (Jc < 0 || Jc > 4 || !c2_internal_loglik_g8_tt_ok(B, N)) return C2_ERR_UNSUPPORTED;
+  if (Jc < 0 || 2 * Jc > J || !c2_internal_loglik_g8_tt_ok(B, N, J)) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   constexpr int C_ = C2_CKPT_C;
   const int64_t nseg = (N - 1 + C_ - 1) / C_;
-  const GradWs ws = grad_ws(B, N, 8, true);
+  const GradWs ws = grad_ws(B, N, J, true);
   double *ckpt = work, *Wrec = ckpt + ws.ck;
   double2 *DZst = reinterpret_cast<double2 *>(ckpt + ws.ck + ws.w);
   unsigned long long *segg = reinterpret_cast<unsigned long long *>(ckpt + ws.ck + ws.w + ws.dz);
-  const dim3 grid((unsigned)((B * 8 + kWave - 1) / kWave));
+  const dim3 grid((unsigned)((B * J + kWave - 1) / kWave));
   const TermsArgs8 T{ar, ac, bc, dc, coef_batched, (int)Jc};
   const TermsGrads8 G{bar, bcr, bac, bbc, bcc, bdc};
   unsigned long long *tgate = guard + kGateHeadWords;
-  hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, s, B, N, 8, C_, kWave / 8, x, x_bs, c, (int64_t)8, segg);
+  hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, s, B, N, (int)J, C_, kWave / (int)J, x, x_bs, c, J, segg);
   if (int e = launch_ok()) return e;
-  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, 8, (const unsigned long long *)segg, T, x, x_bs,
+  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, (int)J, (const unsigned long long *)segg, T, x, x_bs,
                      guard, tgate);
   if (int e = launch_ok()) return e;
-  hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R8, C2_CKPT_C, 1, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, 8, x, x_bs,
-                     c, (int64_t)8, diag, (const double *)nullptr, (const double *)nullptr, y, ll, flag, ckpt, nseg, Wrec, DZst,
-                     (const unsigned long long *)nullptr, (const unsigned long long *)segg, T, (const unsigned long long *)tgate);
-  if (int e = launch_ok()) return e;
-  hipLaunchKernelGGL((k_loglik_rev<8, C2_CKPT_C, false, false, true, 1, true, false, true>), grid, dim3(kWave), 0, s, B, N, 8, x, x_bs,
-                     c, (int64_t)8, (const double *)nullptr, (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg,
-                     (const int32_t *)flag, bx, (double *)nullptr, bdiag, (double *)nullptr, (double *)nullptr, by,
-                     (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, (const unsigned long long *)nullptr,
-                     (const unsigned long long *)segg, T, G, (const unsigned long long *)tgate);
+#define C2_TTG(G_, R_)                                                                                                                \
+  do {                                                                                                                                \
+    hipLaunchKernelGGL((k_loglik_fwd<G_, R_, C2_CKPT_C, 1, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, G_, x, x_bs, \
+                       c, J, diag, (const double *)nullptr, (const double *)nullptr, y, ll, flag, ckpt, nseg, Wrec, DZst,             \
+                       (const unsigned long long *)nullptr, (const unsigned long long *)segg, T, (const unsigned long long *)tgate);  \
+    if (int e = launch_ok()) return e;                                                                                                \
+    hipLaunchKernelGGL((k_loglik_rev<G_, C2_CKPT_C, false, false, true, 1, true, false, true>), grid, dim3(kWave), 0, s, B, N, G_, x,  \
+                       x_bs, c, J, (const double *)nullptr, (const double *)Wrec, (const double2 *)DZst, (const double *)ckpt, nseg,  \
+                       (const int32_t *)flag, bx, (double *)nullptr, bdiag, (double *)nullptr, (double *)nullptr, by,                 \
+                       (const double *)nullptr, (const double *)nullptr, (const double *)nullptr,                                     \
+                       (const unsigned long long *)nullptr, (const unsigned long long *)segg, T, G, (const unsigned long long *)tgate); \
+  } while (0)
+  if (J == 8) C2_TTG(8, C2_FWD_R8);
+  else if (J == 4) C2_TTG(4, C2_FWD_R);
+  else C2_TTG(2, C2_FWD_R);
+#undef C2_TTG
   return launch_ok();
 }
-
 // The forward-only form: `guard` as above (here a word is 0 or +inf: only the phases decide) ...
-int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t J, int64_t Jc, int coef_batched, const double *ar, const double *ac,
                              const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
                              const double *diag, const double *y, double *ll, int32_t *flag, unsigned long long *guard,
                              c2_stream_t stream) {
-  if (Jc < 0 || Jc > 4 || B < 1 || N < 1) return C2_ERR_UNSUPPORTED;
+  if (!(J == 8 || J == 4 || J == 2) || Jc < 0 || 2 * Jc > J || B < 1 || N < 1) return C2_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((unsigned)((B * 8 + kWave - 1) / kWave));
+  const dim3 grid((unsigned)((B * J + kWave - 1) / kWave));
   const TermsArgs8 T{ar, ac, bc, dc, coef_batched, (int)Jc};
   unsigned long long *tgate = guard + kGateHeadWords;
-  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, 8, (const unsigned long long *)nullptr, T, x, x_bs,
+  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, (int)J, (const unsigned long long *)nullptr, T, x, x_bs,
                      guard, tgate);
   if (int e = launch_ok()) return e;
-  hipLaunchKernelGGL((k_loglik_fwd<8, C2_FWD_R8, C2_CKPT_C, 0, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, 8, x, x_bs,
-                     c, (int64_t)8, diag, (const double *)nullptr, (const double *)nullptr, y, ll, flag, (double *)nullptr, (int64_t)0,
-                     (double *)nullptr, (double2 *)nullptr, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, T,
-                     (const unsigned long long *)tgate);
+#define C2_TTF(G_, R_)                                                                                                                \
+  hipLaunchKernelGGL((k_loglik_fwd<G_, R_, C2_CKPT_C, 0, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, G_, x, x_bs, c, \
+                     J, diag, (const double *)nullptr, (const double *)nullptr, y, ll, flag, (double *)nullptr, (int64_t)0,           \
+                     (double *)nullptr, (double2 *)nullptr, (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, \
+                     T, (const unsigned long long *)tgate)
+  if (J == 8) C2_TTF(8, C2_FWD_R8);
+  else if (J == 4) C2_TTF(4, C2_FWD_R);
+  else C2_TTF(2, C2_FWD_R);
+#undef C2_TTF
   return launch_ok();
 }
-// ... and the matrix-level eight-lane forward kernel for the groups it declined (`gate`: per group of 64 series, gate_per_wave)
-int c2_internal_loglik_g8_gated(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
-                                const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+// ... and the matrix-level forward kernel of the same mapping for the groups it declined (`gate`: per group of 64 series, gate_per_wave)
+int c2_internal_loglik_g8_gated(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                 const unsigned long long *gate, c2_stream_t stream) {
-  return launch_fwd<0>(B, N, 8, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, gate);
+  return launch_fwd<0>(B, N, J, t, t_bs, c, c_bs, a, U, V, y, ll, flag, nullptr, 0, nullptr, nullptr, (hipStream_t)stream, gate);
 }
 
 // core::factor_rev on the segment-replay kernel (FR mode of k_loglik_rev): the caller's S workspace serves as the

@@ -227,9 +227,10 @@ int c2_internal_loglik_k2_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_bat
                                   double *bac, double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
                                   int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
 size_t c2_internal_loglik_k2_record_doubles(int64_t B, int64_t N);
-// ... and with eight lanes per series (c2_loglik.hip: k_loglik_fwd / k_loglik_rev<..., TT>): at most one wavefront per SIMD
-size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N);
-int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N);
+// ... and with a group of J = 8, 4 or 2 lanes per series (c2_loglik.hip: k_loglik_fwd / k_loglik_rev<..., TT>): at most one
+// wavefront per SIMD
+size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N, int64_t J);
+int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N, int64_t J);
 // ... and with four (c2_loglik_q4.hip: k_q4_fwd / k_q4_rev<..., TT>): the batches between the eight-lane and the two-lane range
 size_t c2_internal_loglik_q4_record_doubles(int64_t B, int64_t N);
 int c2_internal_loglik_q4_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
@@ -237,14 +238,14 @@ int c2_internal_loglik_q4_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_bat
                                   const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
                                   double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
                                   int32_t *flag, double *rec, unsigned long long *guard, c2_stream_t stream);
-int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t J, int64_t Jc, int coef_batched, const double *ar, const double *ac,
                              const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
                              const double *diag, const double *y, double *ll, int32_t *flag, unsigned long long *guard,
                              c2_stream_t stream);
-int c2_internal_loglik_g8_gated(int64_t B, int64_t N, const double *t, int64_t t_bs, const double *c, int64_t c_bs, const double *a,
-                                const double *U, const double *V, const double *y, double *ll, int32_t *flag,
+int c2_internal_loglik_g8_gated(int64_t B, int64_t N, int64_t J, const double *t, int64_t t_bs, const double *c, int64_t c_bs,
+                                const double *a, const double *U, const double *V, const double *y, double *ll, int32_t *flag,
                                 const unsigned long long *gate, c2_stream_t stream);
-int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
+int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t J, int64_t Jc, int coef_batched, const double *ar, const double *ac,
                                   const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
                                   const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
                                   double *bbc, double *bcc, double *bdc, double *bx, double *bdiag, double *by,
@@ -262,15 +263,16 @@ static bool fused_width(int64_t J) { return J == 8 || J == 4 || J == 2; }
 // guard words in front of the fused kernels' records: the head + one per wavefront of 64 series, rounded to 16 bytes
 static size_t fused_gate_words(int64_t B) { return (size_t)((c2::kGateHeadWords + (B + 63) / 64 + 1) & ~(int64_t)1); }
 static size_t fused_record_doubles(int64_t B, int64_t N, int64_t J) {
-  if (J == 8) {   // either lane mapping
+  const size_t r3 = al2((size_t)B * J) + c2_internal_loglik_g8_tt_doubles(B, N, J);   // (the rates in front: Plan::c)
+  if (J == 8) {   // any lane mapping
     const size_t r1 = c2_internal_loglik_t_record_doubles8(B, N), r2 = c2_internal_loglik_k2_record_doubles(B, N);
-    const size_t r3 = al2((size_t)B * 8) + c2_internal_loglik_g8_tt_doubles(B, N);   // (the rates in front: Plan::c)
     const size_t r4 = al2((size_t)B * 8) + c2_internal_loglik_q4_record_doubles(B, N);
     size_t r = r1 > r2 ? r1 : r2;
     r = r > r3 ? r : r3;
     return r > r4 ? r : r4;
   }
-  return J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N);
+  const size_t r1 = J == 4 ? c2_internal_loglik_t_record_doubles4(B, N) : c2_internal_loglik_t_record_doubles2(B, N);
+  return r1 > r3 ? r1 : r3;
 }
 // Two lanes per series (J == 8) between the composed chain and the one-lane kernels: C2_TERMS_TWO_LANES=1 forces them, =0
 // disables them; otherwise by batch size (a forced C2_TERMS_FUSED decides first)
@@ -289,13 +291,21 @@ static bool use_fused(int64_t B, int64_t J, bool grad) {
 
 // Eight lanes per series (J == 8, gradient) below the two-lane range: C2_TERMS_EIGHT_LANES=1 forces, =0 disables; otherwise
 // by batch size (a forced C2_TERMS_FUSED / C2_TERMS_TWO_LANES decides first)
+// (the gradient's threshold is quoted in series at J = 8 -- eight series per wavefront -- and scales with the series per wavefront:
+// the crossovers against the composed chain measured at widths 4 and 2 sit at the same number of wavefronts)
 static bool use_eight_lanes(int64_t B, int64_t N, int64_t J, bool grad) {
-  if (J != 8) return false;
-  if (grad && !c2_internal_loglik_g8_tt_ok(B, N)) return false;
+  if (!fused_width(J)) return false;
+  if (grad && !c2_internal_loglik_g8_tt_ok(B, N, J)) return false;
   if (c2::opt::has(c2::opt::k_terms_eight_lanes)) return c2::opt::ival(c2::opt::k_terms_eight_lanes) != 0;
   if (c2::opt::has(c2::opt::k_terms_fused) || c2::opt::has(c2::opt::k_terms_two_lanes)) return false;
-  if (grad) return B >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_grad);
-  return B >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_fwd) && B < c2::opt::ival(c2::opt::k_terms_eight_lanes_max_batch_fwd);
+  const int64_t B8 = B * J / 8;
+  if (grad) {
+    if (J == 2 && B >= c2::opt::ival(c2::opt::k_terms_group_max_batch_grad_j2)) return false;   // (one lane per series from there)
+    return B8 >= c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_grad);
+  }
+  if (J == 2) return false;   // width 2 forward: the composed chain, then one lane per series (the group form never leads)
+  const int64_t lo = J == 8 ? c2::opt::ival(c2::opt::k_terms_eight_lanes_min_batch_fwd) : c2::opt::ival(c2::opt::k_terms_group_min_batch_fwd_j4);
+  return B >= lo && B8 < c2::opt::ival(c2::opt::k_terms_eight_lanes_max_batch_fwd);
 }
 
 // Four lanes per series (J == 8, gradient): C2_TERMS_FOUR_LANES=1 forces, =0 disables; otherwise by batch size (any other forced
@@ -331,8 +341,8 @@ size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t
   if (grad && fused_width(J)) {
     const size_t r = fused_record_doubles(B, N, J);
     n = fused_gate_words(B) + (r > n ? r : n);
-  } else if (!grad && J == 8) {
-    n += fused_gate_words(B);   // the eight-lane forward form: one word per group of 64 series in front of the plan
+  } else if (!grad && fused_width(J)) {
+    n += fused_gate_words(B);   // the group-mapping forward form: one word per group of 64 series in front of the plan
   }
   return n * sizeof(double);
 }
@@ -356,11 +366,11 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
     hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc, coef_batched,
                        w + p.c, (const unsigned long long *)nullptr);
     if (int e = launch_ok()) return e;
-    if (int e = c2_internal_loglik_g8_tt(B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, flag, guard, stream))
+    if (int e = c2_internal_loglik_g8_tt(B, N, J, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, flag, guard, stream))
       return e;
     const unsigned long long *gate = c2::gate_per_wave(guard + c2::kGateHeadWords);
     if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, gate, s)) return e;
-    return c2_internal_loglik_g8_gated(B, N, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, flag, gate, stream);
+    return c2_internal_loglik_g8_gated(B, N, J, x, x_bs, w + p.c, J, w + p.a, w + p.U, w + p.V, y, ll, flag, gate, stream);
   }
   if (use_two_lanes(B, J, false))
     return c2_internal_loglik_k2_tt(B, N, Jc, coef_batched, ar, cr, ac, bc, cc, dc, x, x_bs, diag, y, ll, flag, stream);
@@ -400,9 +410,11 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
     hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc, coef_batched,
                        w + p.c, (const unsigned long long *)nullptr);
     if (int e = launch_ok()) return e;
-    if (int e = (four ? c2_internal_loglik_q4_tt_grad : c2_internal_loglik_g8_tt_grad)(
-            B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, by, flag,
-            w + al2((size_t)B * 8), guard, stream))
+    if (int e = four ? c2_internal_loglik_q4_tt_grad(B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, bar, bcr,
+                                                     bac, bbc, bcc, bdc, bx, bdiag, by, flag, w + al2((size_t)B * 8), guard, stream)
+                     : c2_internal_loglik_g8_tt_grad(B, N, J, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, bar,
+                                                     bcr, bac, bbc, bcc, bdc, bx, bdiag, by, flag, w + al2((size_t)B * J), guard,
+                                                     stream))
       return e;
     gate = c2::gate_per_wave(guard + c2::kGateHeadWords);
   } else if (two || use_fused(B, J, true)) {

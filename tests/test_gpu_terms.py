@@ -173,6 +173,36 @@ def test_fused_terms_kernels(ops, oracle, monkeypatch, B, N, Jr, Jc, lanes):
             close(g3, g4.cpu().numpy(), tol=1e-9, floor=1e-11)
 
 
+@pytest.mark.parametrize("lanes", ["one", "eight"])
+@pytest.mark.parametrize("Jr,Jc", [(0, 2), (2, 1), (4, 0), (0, 1), (2, 0)])
+@pytest.mark.parametrize("B,N", [(70, 200), (3, 1), (5, 9), (130, 67)])
+def test_fused_terms_kernels_widths_four_and_two(ops, oracle, monkeypatch, B, N, Jr, Jc, lanes):
+    """Widths 4 and 2 with the rows formed in the lanes: one lane per series (c2_loglik_t.hip) and a group of J lanes
+    ("eight": k_loglik_*<..., TT> at G = 4, 2) against the oracle chain and the composed path."""
+    rng = np.random.default_rng(7 + 10 * Jr + Jc + N)
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, N / 10.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    nb = min(B, 4)
+    want = [oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b]) for b in range(nb)]
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    force(monkeypatch, "composed")
+    ll_c, _ = ops.loglik_terms(*args)
+    _, grads_c, _ = ops.loglik_terms_grad(*args)
+    force(monkeypatch, lanes)
+    ll, flag = ops.loglik_terms(*args)
+    ll2, grads, flag2 = ops.loglik_terms_grad(*args)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    close(ll[:nb], np.array([w[0] for w in want]))
+    close(ll, ll_c.cpu().numpy()); close(ll2, ll_c.cpu().numpy())
+    for k, g in enumerate(grads):
+        e = np.stack([w[1][k] for w in want])
+        if e.size:
+            close(g[:nb], e)
+            close(g, grads_c[k].cpu().numpy(), tol=1e-9, floor=1e-11)
+
+
 @pytest.mark.parametrize("lanes", ["one", "two", "four", "eight"])
 def test_fused_terms_fallback_when_backward_recursion_is_unsafe(ops, oracle, monkeypatch, lanes):
     """Rates x segment span beyond kBackwardGuard: the fused reverse sweep declines on the device and the gated composed

@@ -1,6 +1,6 @@
 # -*- coding: utf-8 -*-
 """Coefficient-level log-likelihood (+ gradient) at J = 8: composed chain / one lane per series / two lanes per series over batch
-sizes at the bench shape.  python tools/terms_lanes.py [N] [B ...]"""
+sizes at the bench shape.  python tools/terms_lanes.py [N] [B ...]   (TERMS_J=4 / 2: the narrower widths, composed / one / group)"""
 import json
 import os
 import sys
@@ -19,17 +19,17 @@ MODES = {"composed": ("0", "0", "0", "0"), "one": ("1", "0", "0", "0"), "two": (
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     Bs = [int(v) for v in sys.argv[2:]] or [8192, 12288, 16384, 24576, 32768, 49152, 65536]
-    J = 8
+    J = int(os.environ.get("TERMS_J", "8"))
     t, diag, y, ac, bc, cc, dc = synth.host_inputs(0, 8, N, J)
     for B in Bs:
         rep = (B + 7) // 8
         f = lambda x: torch.from_numpy(np.ascontiguousarray(np.tile(x, (rep,) + (1,) * (x.ndim - 1))[:B])).cuda()
         td, dg, yd, acd, bcd, ccd, dcd = map(f, (t, diag, y, ac, bc, cc, dc))
         e = torch.zeros((B, 0), dtype=torch.float64, device="cuda")
-        row = {"B": B, "N": N}
+        row = {"B": B, "N": N, "J": J}
         ref = None
         for name, (fu, two, eight, four) in MODES.items():
-            if (name == "eight" and B > 8192) or (name == "four" and B > 24576):
+            if (name == "eight" and B * J > 65536) or (name == "four" and B > 24576) or (J != 8 and name in ("two", "four")):
                 continue
             os.environ["C2_TERMS_FOUR_LANES"] = four
             os.environ["C2_TERMS_FUSED"] = fu

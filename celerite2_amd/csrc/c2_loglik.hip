@@ -252,7 +252,11 @@ struct LaneTerm {
   // own column of U_n and of V_n (cos column: U = ac cos + bc sin; sin column: U = ac sin - bc cos)
   __device__ __forceinline__ void uv(double x, double &u, double &v) const {
     double sn, cs;
-    sincos_cw_fast(D * x, sn, cs);
+    const double ph = D * x;
+    sincos_cw_fast(ph, sn, cs);
+    // (the gate looks at the ENDS of the grid; a row of an UNSORTED grid whose phase leaves the range all the same must not
+    // pass for a result: NaN, as k_matrices marks such rows)
+    if (!(fabs(ph) < kSincosFastMax)) sn = cs = __builtin_nan("");
     const double p = odd ? sn : cs, q = odd ? cs : sn;
     u = fma(A, p, Bq * q);
     v = p;

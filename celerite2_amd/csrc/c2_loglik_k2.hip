@@ -294,8 +294,11 @@ struct SlotCoef {
   }
   template <int TM>
   static __device__ __forceinline__ void sc(double ph, double &sn, double &cs) {
-    if constexpr (TM == 1) sincos_cw_fast(ph, sn, cs);
-    else sincos_cw(ph, sn, cs);   // (a real pair's phase 0 stays on the branch-free path: cos = 1, sin = 0 exactly)
+    if constexpr (TM == 1) {
+      sincos_cw_fast(ph, sn, cs);
+      // (the range test looks at the ENDS of the grid; a row of an UNSORTED grid beyond the range must not pass for a result)
+      if (!(fabs(ph) < kSincosFastMax)) sn = cs = __builtin_nan("");
+    } else sincos_cw(ph, sn, cs);   // (a real pair's phase 0 stays on the branch-free path: cos = 1, sin = 0 exactly)
   }
   // U_n whole (local order), sin / cos of the lane's two slots
   template <int TM>

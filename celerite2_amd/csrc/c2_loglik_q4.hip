@@ -144,7 +144,9 @@ struct SlotTerm {
   }
   // the lane's two columns of U_n (and sin, cos of the slot)
   __device__ __forceinline__ void usc(double x, double (&u)[2], double &sn, double &cs) const {
-    sincos_cw_fast(D * x, sn, cs);
+    const double ph = D * x;
+    sincos_cw_fast(ph, sn, cs);
+    if (!(fabs(ph) < kSincosFastMax)) sn = cs = __builtin_nan("");   // (an unsorted grid: the gate saw only its ends -- see LaneTerm::uv)
     u[0] = fma(A, cs, Bq * sn);
     u[1] = fma(A, sn, -(Bq * cs));
   }

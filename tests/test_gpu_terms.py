@@ -272,3 +272,31 @@ def test_fused_terms_large_phases_take_the_library_reduction(ops, oracle, monkey
             # whatever the summation order (the numpy chain and the device differ there), so that is its floor
             floor = 1e-15 * N * float(np.abs(x[b]).max()) if NAMES[k] == "bdc" else 1e-10
             close(g[b], want[1][k], tol=1e-10, floor=max(floor, 1e-10))
+
+
+@pytest.mark.parametrize("lanes", ["two", "four", "eight"])
+def test_fused_terms_row_beyond_the_fast_sincos_on_an_unsorted_grid_is_loud(ops, monkeypatch, lanes):
+    """The fused kernels' range test for the branch-free sincos looks at the ENDS of a series (x sorted is a precondition of the
+    recursions).  An unsorted grid with a huge time in the middle must not come back as a finite number: that series is NaN /
+    flagged, its neighbours are untouched."""
+    import torch
+    rng = np.random.default_rng(77)
+    B, N, Jr, Jc = 70, 64, 2, 3
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, 6.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    force(monkeypatch, "composed")
+    ll_c, g_c, _ = ops.loglik_terms_grad(*dev(ar, cr, ac, bc, cc, dc, x, diag, y))
+    x[3, 5] = 1e9       # dc x = O(1e9) >> 1.6e6 between ends of O(1)
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    force(monkeypatch, lanes)
+    ll, g, flag = ops.loglik_terms_grad(*args)
+    ll_f, flag_f = ops.loglik_terms(*args)
+    for v, f in ((ll, flag), (ll_f, flag_f)):
+        assert (not bool(torch.isfinite(v[3]))) or int(f[3]) != 0
+    ok = [b for b in range(B) if b != 3]
+    close(ll[ok], ll_c.cpu().numpy()[ok]); close(ll_f[ok], ll_c.cpu().numpy()[ok])
+    for a, b in zip(g, g_c):
+        if b.numel():
+            close(a[ok], b.cpu().numpy()[ok], tol=1e-9, floor=1e-11)

@@ -266,40 +266,32 @@ __device__ __forceinline__ bool tt_group_open(const unsigned long long *gate, in
   return __longlong_as_double((long long)gate[b0 >> 6]) <= kBackwardGuard;   // (NaN / +inf: closed)
 }
 // One word per group of 64 series for the coefficient-level pair: the largest single-segment span word of its wavefronts
-// (k_anchor_spans, words[2 w + 1]), +inf if a phase dc x of the group leaves the range of the branch-free sincos (x sorted: the
-// largest |x| of a series sits at one of its ends).  head[0]: the largest word of the launch, head[1]: closed groups.
-__global__ __launch_bounds__(256) void k_tt8_gate(int64_t B, int64_t N, int64_t nwaves, int wpg,
-                                                  const unsigned long long *__restrict__ words, TermsArgs8 T,
-                                                  const double *__restrict__ x, int64_t x_bs,
-                                                  unsigned long long *__restrict__ head, unsigned long long *__restrict__ gate) {
-  const int64_t ngroups = (B + 63) / 64;
-  double big = 0.0;
-  unsigned long long closed = 0;
-  for (int64_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
-    double m = 0.0;
-    for (int64_t w = wpg * g; words && w < wpg * (g + 1) && w < nwaves; ++w) {
-      const double v = __longlong_as_double((long long)words[2 * w + 1]);
-      m = (v > m || v != v) ? v : m;
-      if (v != v) break;
-    }
-    bool fast = true;
-    for (int64_t b = 64 * g; b < 64 * (g + 1) && b < B; ++b) {
-      const double xm = fmax(fabs(x[b * x_bs]), fabs(x[b * x_bs + N - 1]));
-      for (int k = 0; k < T.Jc; ++k) fast = fast && (fabs(T.dc[(T.batched ? b * T.Jc : 0) + k]) * xm < kSincosFastMax);
-    }
-    if (m != m || !fast) m = __builtin_inf();
-    gate[g] = (unsigned long long)__double_as_longlong(m);
-    big = fmax(big, m);
-    closed += !(m <= kBackwardGuard);
+// (k_anchor_spans, words[2 w + 1]; nullptr: none), +inf if a phase dc x of the group leaves the range of the branch-free sincos
+// (x sorted: the largest |x| of a series sits at one of its ends).  One wavefront per group, a lane per series.  head[0]: the
+// largest word of the launch, head[1]: closed groups -- both zeroed by the launcher on the same stream.
+__global__ __launch_bounds__(kWave) void k_tt8_gate(int64_t B, int64_t N, int64_t nwaves, int wpg,
+                                                    const unsigned long long *__restrict__ words, TermsArgs8 T,
+                                                    const double *__restrict__ x, int64_t x_bs,
+                                                    unsigned long long *__restrict__ head, unsigned long long *__restrict__ gate) {
+  const int64_t g = blockIdx.x, b = 64 * g + threadIdx.x;
+  bool fast = true;
+  if (b < B) {
+    const double xm = fmax(fabs(x[b * x_bs]), fabs(x[b * x_bs + N - 1]));
+    for (int k = 0; k < T.Jc; ++k) fast = fast && (fabs(T.dc[(T.batched ? b * T.Jc : 0) + k]) * xm < kSincosFastMax);
   }
-  __shared__ double sb[256];
-  __shared__ unsigned long long scl[256];
-  sb[threadIdx.x] = big; scl[threadIdx.x] = closed;
-  __syncthreads();
+  double m = 0.0;
+  if (words && (int)threadIdx.x < wpg && wpg * g + threadIdx.x < nwaves) {
+    m = __longlong_as_double((long long)words[2 * (wpg * g + threadIdx.x) + 1]);
+    if (m != m) m = __builtin_inf();
+  }
+#pragma unroll
+  for (int sft = 1; sft < kWave; sft <<= 1) m = fmax(m, __shfl_xor(m, sft, kWave));
+  if (!__all(fast)) m = __builtin_inf();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < (int)blockDim.x; ++i) { big = fmax(big, sb[i]); closed += scl[i]; }
-    head[0] = (unsigned long long)__double_as_longlong(big);
-    head[1] = closed;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);   // (m >= 0: the bit patterns order like the numbers)
+    gate[g] = bits;
+    atomicMax(head, bits);
+    if (!(m <= kBackwardGuard)) atomicAdd(head + 1, 1ull);
   }
 }
 
@@ -2238,8 +2230,9 @@ int c2_internal_loglik_g8_tt_grad(int64_t B, int64_t N, int64_t J, int64_t Jc, i
   unsigned long long *tgate = guard + kGateHeadWords;
   hipLaunchKernelGGL(k_anchor_spans, grid, dim3(256), 0, s, B, N, (int)J, C_, kWave / (int)J, x, x_bs, c, J, segg);
   if (int e = launch_ok()) return e;
-  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, (int)J, (const unsigned long long *)segg, T, x, x_bs,
-                     guard, tgate);
+  if (hipMemsetAsync(guard, 0, 8 * kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(k_tt8_gate, dim3((unsigned)((B + 63) / 64)), dim3(kWave), 0, s, B, N, (int64_t)grid.x, (int)J,
+                     (const unsigned long long *)segg, T, x, x_bs, guard, tgate);
   if (int e = launch_ok()) return e;
 #define C2_TTG(G_, R_)                                                                                                                \
   do {                                                                                                                                \
@@ -2269,8 +2262,9 @@ int c2_internal_loglik_g8_tt(int64_t B, int64_t N, int64_t J, int64_t Jc, int co
   const dim3 grid((unsigned)((B * J + kWave - 1) / kWave));
   const TermsArgs8 T{ar, ac, bc, dc, coef_batched, (int)Jc};
   unsigned long long *tgate = guard + kGateHeadWords;
-  hipLaunchKernelGGL(k_tt8_gate, dim3(1), dim3(256), 0, s, B, N, (int64_t)grid.x, (int)J, (const unsigned long long *)nullptr, T, x, x_bs,
-                     guard, tgate);
+  if (hipMemsetAsync(guard, 0, 8 * kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(k_tt8_gate, dim3((unsigned)((B + 63) / 64)), dim3(kWave), 0, s, B, N, (int64_t)grid.x, (int)J,
+                     (const unsigned long long *)nullptr, T, x, x_bs, guard, tgate);
   if (int e = launch_ok()) return e;
 #define C2_TTF(G_, R_)                                                                                                                \
   hipLaunchKernelGGL((k_loglik_fwd<G_, R_, C2_CKPT_C, 0, false, 1, false, false, true>), grid, dim3(kWave), 0, s, B, N, G_, x, x_bs, c, \

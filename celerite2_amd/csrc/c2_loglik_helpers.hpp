@@ -29,6 +29,14 @@ __device__ __forceinline__ bool gate_closed(const unsigned long long *gate, int6
   return !(__longlong_as_double((long long)w) > kBackwardGuard);
 }
 
+// Per-group form only: did NO group of the launch fall back?  (head[1] -- the word right in front of the groups' words -- counts
+// them.)  Lets a fallback kernel with a large grid return before it looks at its series.
+__device__ __forceinline__ bool gate_none_closed(const unsigned long long *gate) {
+  const uintptr_t g = reinterpret_cast<uintptr_t>(gate);
+  if (!gate || !(g & 1u)) return false;
+  return reinterpret_cast<const unsigned long long *>(g & ~(uintptr_t)1)[-1] == 0ull;
+}
+
 // 1/d for a well-scaled positive d: v_rcp_f64 seed + two Newton steps (full fp64 accuracy; the
 // denormal/overflow scaling of a general IEEE division is not needed for pivots of an SPD matrix).
 __device__ __forceinline__ double rcp_nr(double d) {

@@ -158,38 +158,30 @@ struct SlotTerm {
   }
 };
 // k_q4_gate with the phases: a group is also closed (+inf) when dc x of one of its series leaves the range of the branch-free
-// sincos (x sorted: the largest |x| of a series sits at one of its ends)
-__global__ __launch_bounds__(256) void k_q4_gate_tt(int64_t B, int64_t N, int64_t nwaves, const unsigned long long *__restrict__ words,
-                                                    TermsArgsQ T, const double *__restrict__ x, int64_t x_bs,
-                                                    unsigned long long *__restrict__ head, unsigned long long *__restrict__ gate) {
-  const int64_t ngroups = (nwaves + 3) / 4;
-  double big = 0.0;
-  unsigned long long closed = 0;
-  for (int64_t g = threadIdx.x; g < ngroups; g += blockDim.x) {
-    double m = 0.0;
-    for (int64_t w = 4 * g; w < 4 * g + 4 && w < nwaves; ++w) {
-      const double v = __longlong_as_double((long long)words[2 * w]);
-      m = (v > m || v != v) ? v : m;
-      if (v != v) break;
-    }
-    bool fast = true;
-    for (int64_t b = 64 * g; b < 64 * (g + 1) && b < B; ++b) {
-      const double xm = fmax(fabs(x[b * x_bs]), fabs(x[b * x_bs + N - 1]));
-      for (int k = 0; k < T.Jc; ++k) fast = fast && (fabs(T.dc[(T.batched ? b * T.Jc : 0) + k]) * xm < kSincosFastMax);
-    }
-    if (m != m || !fast) m = __builtin_inf();
-    gate[g] = (unsigned long long)__double_as_longlong(m);
-    big = fmax(big, m);
-    closed += !(m <= kBackwardGuard);
+// sincos (x sorted: the largest |x| of a series sits at one of its ends).  One wavefront per group of 64 series (four wavefronts
+// of the pair), a lane per series; head[0], head[1] zeroed by the launcher on the same stream.
+__global__ __launch_bounds__(kWave) void k_q4_gate_tt(int64_t B, int64_t N, int64_t nwaves, const unsigned long long *__restrict__ words,
+                                                      TermsArgsQ T, const double *__restrict__ x, int64_t x_bs,
+                                                      unsigned long long *__restrict__ head, unsigned long long *__restrict__ gate) {
+  const int64_t g = blockIdx.x, b = 64 * g + threadIdx.x;
+  bool fast = true;
+  if (b < B) {
+    const double xm = fmax(fabs(x[b * x_bs]), fabs(x[b * x_bs + N - 1]));
+    for (int k = 0; k < T.Jc; ++k) fast = fast && (fabs(T.dc[(T.batched ? b * T.Jc : 0) + k]) * xm < kSincosFastMax);
   }
-  __shared__ double sb[256];
-  __shared__ unsigned long long sc[256];
-  sb[threadIdx.x] = big; sc[threadIdx.x] = closed;
-  __syncthreads();
+  double m = 0.0;
+  if (threadIdx.x < 4 && 4 * g + threadIdx.x < nwaves) {
+    m = __longlong_as_double((long long)words[2 * (4 * g + threadIdx.x)]);
+    if (m != m) m = __builtin_inf();
+  }
+#pragma unroll
+  for (int sft = 1; sft < kWave; sft <<= 1) m = fmax(m, __shfl_xor(m, sft, kWave));
+  if (!__all(fast)) m = __builtin_inf();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < (int)blockDim.x; ++i) { big = fmax(big, sb[i]); closed += sc[i]; }
-    head[0] = (unsigned long long)__double_as_longlong(big);
-    head[1] = closed;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(m);   // (m >= 0: the bit patterns order like the numbers)
+    gate[g] = bits;
+    atomicMax(head, bits);
+    if (!(m <= kBackwardGuard)) atomicAdd(head + 1, 1ull);
   }
 }
 
@@ -990,8 +982,9 @@ int c2_internal_loglik_q4_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_bat
   const q4::TermsArgsQ T{ar, ac, bc, dc, coef_batched, (int)Jc};
   const q4::TermsGradsQ G{bar, bcr, bac, bbc, bcc, bdc};
   if (int e = c2_internal_anchor_spans(B, N, q4::J, q4::C, q4::SPW, x, x_bs, c, 8, words, stream)) return e;
-  hipLaunchKernelGGL(q4::k_q4_gate_tt, dim3(1), dim3(256), 0, s, B, N, (int64_t)l.waves, (const unsigned long long *)words, T, x, x_bs,
-                     guard, gate);
+  if (hipMemsetAsync(guard, 0, 8 * kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(q4::k_q4_gate_tt, dim3((unsigned)((l.waves + 3) / 4)), dim3(kWave), 0, s, B, N, (int64_t)l.waves,
+                     (const unsigned long long *)words, T, x, x_bs, guard, gate);
   hipLaunchKernelGGL((q4::k_q4_fwd<false, 16, true>), grid, dim3(kWave), 0, s, B, N, x, x_bs, c, (int64_t)8, diag,
                      (const double *)nullptr, (const double *)nullptr, y, ll, flag, ck, l.nslot, W, DZ,
                      (const unsigned long long *)gate, T);

@@ -1047,6 +1047,7 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
   // iterations are independent, so their x loads / sincos / stores overlap (one (row, term) pair per thread spent
   // 74 % of its 7500 cycles waiting for dependent loads).  Consecutive threads hold consecutive terms of a row, so a
   // wavefront's stores are dense runs (a complex term its cos / sin column pair as one 16-byte store when aligned).
+  if (gate_none_closed(gate)) return;   // (a fallback launch with nothing to do)
   const int Q = Jr + Jc, J = Jr + 2 * Jc;
   const int rpi = 256 / Q;                      // rows per block iteration
   const int q = (int)threadIdx.x % Q, r = (int)threadIdx.x / Q;
@@ -1106,28 +1107,33 @@ __global__ __launch_bounds__(256) void k_matrices(int64_t B, int64_t N, int Jr, 
 // (the reference has no sortedness precondition here, driver.cpp:460-474).  One thread per ROW; it reads x and returns
 // in the common case, so the library's large-argument reduction (and its 160 registers) stays out of the kernel that
 // does the work: 0.27 GB of reads on top of its 2.4 GB at 8192 x 4096 x 8.
+template <bool GATED>
 __global__ __launch_bounds__(256) void k_matrices_big(int64_t B, int64_t N, int Jr, int Jc, const double *__restrict__ ac,
                                                       const double *__restrict__ bc, const double *__restrict__ dc,
                                                       int coef_batched, const double *__restrict__ x, int64_t x_bs,
                                                       double *__restrict__ U, double *__restrict__ V,
                                                       const unsigned long long *__restrict__ gate) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B * N) return;
-  const int64_t b = g / N, n = g - b * N;
-  if (gate_closed(gate, b)) return;
-  const int J = Jr + 2 * Jc;
-  const int64_t o = coef_batched ? b * Jc : 0;
-  const double *xb = x + b * x_bs;
-  const double xn = xb[n], xm = fmax(fabs(xb[0]), fabs(xb[N - 1]));
-  for (int i = 0; i < Jc; ++i) {
-    const double d_ = dc[o + i], ph = d_ * xn;
-    if ((fabs(ph) < kSincosFastMax) && (fabs(d_) * xm < kSincosFastMax)) continue;   // k_matrices wrote this pair
-    double sn, cs;
-    sincos(ph, &sn, &cs);
-    const double a_ = ac[o + i], b_ = bc[o + i];
-    double *Un = U + g * J + Jr + 2 * i, *Vn = V + g * J + Jr + 2 * i;
-    Vn[0] = cs; Vn[1] = sn;
-    Un[0] = a_ * cs + b_ * sn; Un[1] = a_ * sn - b_ * cs;
+  if (GATED && gate_none_closed(gate)) return;   // (a fallback launch with nothing to do)
+  // (GATED: grid-stride -- a gated launch comes with a small grid, most of its groups are closed to it; otherwise one row per
+  // thread and no loop: the plain form is 1.8 x slower with the loop around it)
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < B * N; g += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = g / N, n = g - b * N;
+    if (GATED && gate_closed(gate, b)) continue;
+    const int J = Jr + 2 * Jc;
+    const int64_t o = coef_batched ? b * Jc : 0;
+    const double *xb = x + b * x_bs;
+    const double xn = xb[n], xm = fmax(fabs(xb[0]), fabs(xb[N - 1]));
+    for (int i = 0; i < Jc; ++i) {
+      const double d_ = dc[o + i], ph = d_ * xn;
+      if ((fabs(ph) < kSincosFastMax) && (fabs(d_) * xm < kSincosFastMax)) continue;   // k_matrices wrote this pair
+      double sn, cs;
+      sincos(ph, &sn, &cs);
+      const double a_ = ac[o + i], b_ = bc[o + i];
+      double *Un = U + g * J + Jr + 2 * i, *Vn = V + g * J + Jr + 2 * i;
+      Vn[0] = cs; Vn[1] = sn;
+      Un[0] = a_ * cs + b_ * sn; Un[1] = a_ * sn - b_ * cs;
+    }
+    if (!GATED) break;
   }
 }
 
@@ -2014,12 +2020,25 @@ int c2_internal_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
   if (B < 1 || N < 1 || Jr < 0 || Jc < 0 || Jr + 2 * Jc < 1) return C2_ERR_INVALID;
   if (!x || !diag || !a || !U || !V || (Jr && !ar) || (Jc && (!ac || !bc || !dc))) return C2_ERR_INVALID;
   const int64_t rows_per_block = (int64_t)(256 / (Jr + Jc)) * kMatRows;
-  hipLaunchKernelGGL(k_matrices, dim3((unsigned)((N + rows_per_block - 1) / rows_per_block), (unsigned)(B < 65535 ? B : 65535)), dim3(256), 0, (hipStream_t)stream, B, N,
+  // a gated launch is the fallback of a fused path: most (normally all) of its groups of 64 series are closed to it, so it comes
+  // with a small grid whose blocks stride over the series (and return at once when no group fell back) instead of one block per
+  // series and row block that looks at the gate and leaves (65536 series: 0.44 + 0.26 ms of empty blocks per call)
+  const int64_t by = gate ? (B < 512 ? B : 512) : (B < 65535 ? B : 65535);
+  hipLaunchKernelGGL(k_matrices, dim3((unsigned)((N + rows_per_block - 1) / rows_per_block), (unsigned)by), dim3(256), 0, (hipStream_t)stream, B, N,
                      (int)Jr, (int)Jc, ar, ac, bc, dc, coef_batched, x, x_bs, diag, a, U, V, gate);
   if (int e = check_launch()) return e;
-  if (Jc > 0)
-    hipLaunchKernelGGL(k_matrices_big, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B, N,
-                       (int)Jr, (int)Jc, ac, bc, dc, coef_batched, x, x_bs, U, V, gate);
+  if (Jc > 0) {
+    int64_t nb = (B * N + 255) / 256;
+    if (gate && nb > 4096) nb = 4096;
+    bool stride = gate != nullptr;
+    if (nb > 0x7fffffffLL) { nb = 0x7fffffffLL; stride = true; }   // (more rows than a grid has threads: the striding form)
+    if (stride)
+      hipLaunchKernelGGL(k_matrices_big<true>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, N, (int)Jr, (int)Jc, ac, bc,
+                         dc, coef_batched, x, x_bs, U, V, gate);
+    else
+      hipLaunchKernelGGL(k_matrices_big<false>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, B, N, (int)Jr, (int)Jc, ac, bc,
+                         dc, coef_batched, x, x_bs, U, V, gate);
+  }
   return check_launch();
 }
 int c2_get_celerite_matrices(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *ar, const double *ac,

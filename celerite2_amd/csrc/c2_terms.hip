@@ -61,6 +61,7 @@ __global__ __launch_bounds__(kThreads) void k_terms_rev(
   // nsplit > 1 (a handful of long series): blockIdx.y takes a slice of the rows and leaves its sums in
   // part[series][slice][term][4]; k_terms_rev_finish adds the slices in order
   __shared__ double red[kThreads][4];
+  if (c2::gate_none_closed(gate)) return;   // (the fallback of a fused path with nothing to do; block-uniform)
   const int Q = Jr + Jc, J = Jr + 2 * Jc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rpw = 64 / Q;                       // rows per wavefront and iteration
@@ -449,7 +450,9 @@ int c2_loglik_terms_grad(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const dou
     if (nsplit > 256) nsplit = 256;
   }
   double *part = w + p.one_d;
-  hipLaunchKernelGGL(k_terms_rev, dim3((unsigned)(B < 0x7fffffff ? B : 0x7fffffff), (unsigned)nsplit), dim3(kThreads), 0, s,
+  // (behind a fused path -- gated -- a small grid striding over the series: most of its groups are closed to it)
+  const int64_t trb = gate ? (B < 2048 ? B : 2048) : (B < 0x7fffffff ? B : 0x7fffffff);
+  hipLaunchKernelGGL(k_terms_rev, dim3((unsigned)trb, (unsigned)nsplit), dim3(kThreads), 0, s,
                      B, N, (int)Jr, (int)Jc, ac, bc, dc, coef_batched, x, x_bs, (const double *)(w + p.V),
                      (const double *)(w + p.bt), (const double *)(w + p.bc), (const double *)(w + p.ba),
                      (const double *)(w + p.bU), (const double *)(w + p.bV), bar, bcr, bac, bbc, bcc, bdc, bx, bdiag, gate,

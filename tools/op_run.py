@@ -1,5 +1,5 @@
 """One op of the device ABI a few times, for profilers: python tools/op_run.py <op> <B> <N> <J> [reps]
-op: loglik | loglik_grad | factor | factor_s | factor_rev | solve_rhs<nrhs> | predict[_var|_cov] | chain (factor_s + solve_lower F + solve_lower_rev + factor_rev)"""
+op: loglik | loglik_grad | terms | terms_grad (coefficient-level, bench coefficients) | factor | factor_s | factor_rev | solve_rhs<nrhs> | predict[_var|_cov] | chain (factor_s + solve_lower F + solve_lower_rev + factor_rev)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -25,11 +25,20 @@ if op.startswith("predict"):
     gp.compute(t, diag=diag)
     ts = torch.sort(torch.rand((B, M), dtype=torch.float64, device=dev) * (N / 10.0), dim=1).values
 Wf = Yr = None
+targs = None
+if op.startswith("terms"):
+    import numpy as np
+    th, dgh, yh, ach, bch, cch, dch = synth.host_inputs(0, 8, N, J)
+    f = lambda x: torch.from_numpy(np.ascontiguousarray(np.tile(x, ((B + 7) // 8,) + (1,) * (x.ndim - 1))[:B])).to(dev)
+    e_ = torch.zeros((B, 0), dtype=torch.float64, device=dev)
+    targs = (e_, e_, f(ach), f(bch), f(cch), f(dch), f(th), f(dgh), f(yh))
 if op.startswith("solve_rhs"):   # solve_rhs<nrhs>: solve_lower with that many right-hand sides, in place
     d_, Wf, fl_ = ops.factor(t, c, a, U, V)
     Yr = torch.randn((B, N, int(op[9:])), dtype=torch.float64, device=dev)
 def run():
     if Yr is not None: return ops.solve_lower(t, c, U, Wf, Yr, Z=Yr)
+    if op == "terms": return ops.loglik_terms(*targs)
+    if op == "terms_grad": return ops.loglik_terms_grad(*targs)
     if op == "predict_var": return gp.predict(y, ts, return_var=True)
     if op == "predict_cov": return gp.predict(y, ts, return_cov=True)
     if op == "predict": return gp.predict(y, ts)

@@ -92,10 +92,48 @@ def solve_cost_model():
           % (max(fixed, 0.0), per, row_us, rhs_us))
 
 
+def terms():
+    """Coefficient-level log-likelihood (+ gradient): composed chain against the kernels that form the rows in the lanes, per lane
+    mapping; the first batch size at which a mapping leads is the threshold to set."""
+    import numpy as np
+    print("== coefficient-level log-likelihood (+ gradient), N = 4096: composed / group of J lanes / four / two / one lane per series (ms)")
+    modes = {"composed": dict(terms_fused=0, terms_two_lanes=0, terms_eight_lanes=0, terms_four_lanes=0),
+             "group": dict(terms_fused=0, terms_two_lanes=0, terms_eight_lanes=1, terms_four_lanes=0),
+             "four": dict(terms_fused=0, terms_two_lanes=0, terms_eight_lanes=0, terms_four_lanes=1),
+             "two": dict(terms_fused=0, terms_two_lanes=1, terms_eight_lanes=0, terms_four_lanes=0),
+             "one": dict(terms_fused=1, terms_two_lanes=0, terms_eight_lanes=0, terms_four_lanes=0)}
+    N = 4096
+    for J in ((8,) if QUICK else (8, 4, 2)):
+        th, dgh, yh, ach, bch, cch, dch = synth.host_inputs(0, 8, N, J)
+        lead = {}
+        for B in ([4096, 16384] if QUICK else [1024, 2048, 3072, 4096, 6144, 8192, 10240, 12288, 16384, 24576, 32768, 49152]):
+            f = lambda x: torch.from_numpy(np.ascontiguousarray(np.tile(x, ((B + 7) // 8,) + (1,) * (x.ndim - 1))[:B])).to(dev)
+            e = torch.zeros((B, 0), dtype=torch.float64, device=dev)
+            args = (e, e, f(ach), f(bch), f(cch), f(dch), f(th), f(dgh), f(yh))
+            row = {}
+            for name, kw in modes.items():
+                if (name in ("two", "four") and J != 8) or (name == "group" and B * J > 65536) or (name == "four" and B > 16384):
+                    continue
+                with forced(**kw):
+                    row[("fwd", name)] = timed(lambda: ops.loglik_terms(*args), reps=3)
+                    row[("grad", name)] = timed(lambda: ops.loglik_terms_grad(*args), reps=3)
+            for kind in ("fwd", "grad"):
+                best = min((v, k[1]) for k, v in row.items() if k[0] == kind)[1]
+                lead.setdefault((kind, best), B)
+            print("  J %d  B %6d  fwd: %s | fwd+grad: %s" % (J, B, "  ".join("%s %.2f" % (k[1], v) for k, v in row.items() if k[0] == "fwd"),
+                                                             "  ".join("%s %.2f" % (k[1], v) for k, v in row.items() if k[0] == "grad")))
+            del args
+            torch.cuda.empty_cache()
+        print("  -> J = %d: first batch size each mapping leads at: %s" % (J, ", ".join("%s %s from %d" % (k[0], k[1], v) for k, v in sorted(lead.items()))))
+    print("  (options: terms_eight_lanes_min_batch_grad / _fwd in series AT J = 8, terms_group_min_batch_fwd_j4, terms_four_lanes_min/max_batch_grad,")
+    print("   terms_two_lanes_min/max_batch_*, terms_fused_min_batch_*, terms_group_max_batch_grad_j2)")
+
+
 if __name__ == "__main__":
     t0 = time.time()
     print("dispatch table of the loaded library: %d options; device %s" % (len(_lib.options()), torch.cuda.get_device_name(0)))
     lanes()
     timepar_grad()
     solve_cost_model()
+    terms()
     print("(%.0f s)" % (time.time() - t0))

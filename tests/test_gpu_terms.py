@@ -300,3 +300,47 @@ def test_fused_terms_row_beyond_the_fast_sincos_on_an_unsorted_grid_is_loud(ops,
     for a, b in zip(g, g_c):
         if b.numel():
             close(a[ok], b.cpu().numpy()[ok], tol=1e-9, floor=1e-11)
+
+
+@pytest.mark.parametrize("lanes", ["one", "two", "four", "eight"])
+def test_fused_terms_mixed_groups_and_long_series(ops, oracle, monkeypatch, lanes):
+    """Groups of 64 series decide on their own: in one batch the first group stays inside the backward guard (fused kernels),
+    the second has gaps in time beyond it (composed chain behind the same gate words), the third -- a partial group -- is
+    inside again; and a forced fused path on a few LONG series (thousands of anchors)."""
+    rng = np.random.default_rng(41)
+    B, N, Jr, Jc = 150, 120, 2, 3
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    scale = np.where((np.arange(B) >= 64) & (np.arange(B) < 128), 4.0, 0.02)
+    x = np.sort(rng.uniform(0, 1.0, (B, N)), axis=1) * (N * scale)[:, None]
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    force(monkeypatch, "composed")
+    ll_c, g_c, _ = ops.loglik_terms_grad(*args)
+    force(monkeypatch, lanes)
+    ll, g, flag = ops.loglik_terms_grad(*args)
+    assert int(flag.abs().sum()) == 0
+    close(ll, ll_c.cpu().numpy())
+    for a, b in zip(g, g_c):
+        close(a, b.cpu().numpy(), tol=1e-9, floor=1e-11)
+    for b in (0, 63, 64, 100, 127, 128, 149):
+        want = oracle_chain(oracle, ar[b], cr[b], ac[b], bc[b], cc[b], dc[b], x[b], diag[b], y[b])
+        close(ll[b:b + 1], np.array([want[0]]))
+        for k, gg in enumerate(g):
+            close(gg[b], want[1][k])
+    # long series
+    B, N = 3, 5003
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, N / 10.0, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    force(monkeypatch, "composed")
+    ll_c, g_c, _ = ops.loglik_terms_grad(*args)
+    force(monkeypatch, lanes)
+    ll, g, flag = ops.loglik_terms_grad(*args)
+    ll_f, _ = ops.loglik_terms(*args)
+    assert int(flag.abs().sum()) == 0
+    close(ll, ll_c.cpu().numpy()); close(ll_f, ll_c.cpu().numpy())
+    for a, b in zip(g, g_c):
+        close(a, b.cpu().numpy(), tol=1e-9, floor=1e-11)

@@ -15,6 +15,9 @@
 #include "c2_loglik_helpers.hpp"
 #include "../../include/celerite2_amd.h"
 
+#ifndef C2_SWEEP1_PAIRLINES
+#define C2_SWEEP1_PAIRLINES 1
+#endif
 namespace c2 {
 
 // LN >= 0 (G = J = 8, U and V 16-byte aligned): the two width-8 rows of a step are requested as halves of the aligned
@@ -224,6 +227,10 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   constexpr double sgn = SOLVE ? -1.0 : 1.0;
   auto rowof = [&](int64_t q) { return LOWER ? N - 1 - q : q; };
 
+  constexpr bool HOLD = C2_SWEEP1_PAIRLINES && G == 8 && R == 8 && NV == 1 && !PAD;
+  double hT = 0.0, hY = 0.0;
+  int64_t hldrow = 0;
+  bool hTok = false, hYok = false;
   const int64_t r0 = rowof(0);
   double bz = bzb[r0];
   soutY[1][grp][R - 1] = SOLVE ? bz : 0.0;      // bY of position 0: reverse.hpp:112 (bY = bZ) / :178 (bY = 0); leaves with block 0
@@ -381,6 +388,25 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
       }
     }
     lds_order();
+    if constexpr (HOLD) {
+      // (a block's run of bt / bY is HALF a 128-byte line per series; written when ready, the two halves of a line reach memory
+      // eight steps apart and are merged on the memory side one by one -- profiles/r06_halflines.md.  The half the sweep reaches
+      // first waits in a register per stream and leaves with the other, back to back.  C2_SWEEP1_PAIRLINES=0: as they come.)
+      const int64_t row = rowof(u0 + j);
+      const bool okT = !CHECKED || u0 + j + 1 < N, okY = !CHECKED || u0 + j < N;
+      const double vT = sout[grp][j], vY = j == 0 ? soutY[s ^ 1][grp][R - 1] : soutY[s][grp][j - 1];
+      const int64_t rs = LOWER ? N - R - u0 : u0;            // lowest row of the run
+      const bool first = LOWER ? ((rs >> 3) & 1) != 0 : ((rs >> 3) & 1) == 0;   // (uniform) the first half of its line the sweep meets
+      if (first) {
+        hT = vT; hY = vY; hldrow = row; hTok = okT; hYok = okY;
+      } else {
+        if (okT) btb[row] = vT;
+        if (hTok) btb[hldrow] = hT;
+        if (okY) byb[row] = vY;
+        if (hYok) byb[hldrow] = hY;
+        hTok = hYok = false;
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
@@ -388,6 +414,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
         if (!CHECKED || u0 + idx + 1 < N) btb[rowof(u0 + idx)] = sout[grp][idx];
         if (!CHECKED || u0 + idx < N) byb[rowof(u0 + idx)] = idx == 0 ? soutY[s ^ 1][grp][R - 1] : soutY[s][grp][idx - 1];
       }
+    }
     }
     vstage(s);
     vload(u0 + 3 * R);
@@ -401,6 +428,10 @@ __global__ __launch_bounds__(kWave) void k_sweep1_rev(int64_t B, int64_t N, int 
   for (; u0 + 2 * R + 1 <= N; u0 += R, s ^= 1) block(u0, s, std::false_type{});
   for (; u0 + 1 < N; u0 += R, s ^= 1) block(u0, s, std::true_type{});
 
+  if constexpr (HOLD) {   // a half line still waiting for a partner that never came
+    if (hTok) btb[hldrow] = hT;
+    if (hYok) byb[hldrow] = hY;
+  }
   if (u0 < N) byb[rowof(u0)] = soutY[s ^ 1][grp][R - 1];   // the last block's last entry: position N - 1 = R b opens a run of its own
   const int64_t rl = rowof(N - 1);
   btb[rl] = LOWER ? carry : -carry;

@@ -11,9 +11,12 @@
 //     bac_k = sum_n (ba_n + bU0 co + bU1 s) ,   bbc_k = sum_n (bU0 s - bU1 co)
 //     g_nk  = -bU0 U1 + bU1 U0 - bV0 s + bV1 co      (cotangent of the phase dc x_n)
 //     bdc_k = sum_n g_nk x_n ,   bx_n = bt_n + sum_k g_nk dc_k ,   bdiag_n = ba_n.
-// This is the COMPOSED form: the matrices are materialised once in the caller-provided workspace (the fused kernels
-// read them as they read a caller's); folding the generation into the recursion kernels themselves is the next step
-// (DESIGN.md section 8).
+// This file holds the COMPOSED form -- the matrices materialised once in the caller-provided workspace, the fused kernels
+// reading them as they read a caller's -- and the dispatch between it and the kernels that form the rows in the lanes and
+// fold this reverse into their reverse step (one lane per series: c2_loglik_t.hip; two: c2_loglik_k2.hip; four:
+// c2_loglik_q4.hip; a group of J lanes: c2_loglik.hip).  The composed form serves small batches, widths other than 8, 4, 2 and
+// the groups of 64 series a fused pair declines (backward guard, unsorted times, phases beyond the branch-free sincos): every
+// kernel of it runs behind the gate words the fused pair left (profiles/r06_terms_lanes.md).
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -55,6 +55,10 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   // Z = Y (solve, forward.hpp:168,205) / Z = 0 (matmul called with zero_z) / Z unchanged (matmul accumulate) and the zero
   // workspace row (internal.hpp:127 / :170) like any other step -- so blocks cover positions [R b, R b + R) and the
   // transposed requests of t, y, z are whole aligned runs (profiles/r05_alignment.md).
+  constexpr bool HOLDZ = C2_SWEEP1_PAIRLINES && G == 8 && R == 8 && NV == 1 && !PAD;
+  double hZ = 0.0;
+  int64_t hZrow = 0;
+  bool hZok = false;
   const int64_t r0 = rowof(0);
   double xprev = 0.0;
   double aprev = 0.0;
@@ -161,10 +165,28 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
       }
     }
     lds_order();
+    if constexpr (HOLDZ) {
+      // (a block's run of Z is HALF a 128-byte line per series: the half the sweep reaches first waits in a register and leaves
+      // with the other, back to back -- profiles/r06_halflines.md.  In-place Z == Y stays legal: the rows a held store covers were
+      // read two blocks ago.  C2_SWEEP1_PAIRLINES=0: as they come.)
+      const int64_t row = rowof(s0 + j);
+      const bool ok = !CHECKED || s0 + j < N;
+      const double v = sout[grp][j];
+      const int64_t rs = LOWER ? s0 : N - R - s0;            // lowest row of the run
+      const bool first = LOWER ? ((rs >> 3) & 1) == 0 : ((rs >> 3) & 1) != 0;   // (uniform)
+      if (first) {
+        hZ = v; hZrow = row; hZok = ok;
+      } else {
+        if (ok) zb[row] = v;
+        if (hZok) zb[hZrow] = hZ;
+        hZok = false;
+      }
+    } else {
 #pragma unroll
     for (int m = 0; m < NV; ++m) {
       const int idx = m * G + j;
       if ((G * NV == R || idx < R) && (!CHECKED || s0 + idx < N)) zb[rowof(s0 + idx)] = sout[grp][idx];
+    }
     }
     vstage(q);
     vload(s0 + 3 * R);
@@ -174,6 +196,7 @@ __global__ __launch_bounds__(kWave) void k_sweep1(int64_t B, int64_t N, int Jrt,
   int q = 0;
   for (; s0 + 2 * R <= N; s0 += R, q ^= 1) block(s0, q, std::false_type{});
   for (; s0 < N; s0 += R, q ^= 1) block(s0, q, std::true_type{});
+  if constexpr (HOLDZ) { if (hZok) zb[hZrow] = hZ; }   // a half line whose partner never came
 }
 
 // -----------------------------------------------------------------------------------------------------------------

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kWave) void k_q4_gate_tt(int64_t B, int64_t N, int6
 // R = rows per block of the transposed scalar streams (and of the row ring without LN): 8, or 16 with LN -- then a scalar
 // request is one whole 128-byte line per series (four series per instruction) instead of a 64-byte run, and t, a, y enter
 // the chip once instead of twice (the second half of a line does not survive eight rows in the cache).
-template <bool LN, int R, bool TT = false>
+template <bool LN, int R, bool TT = false, bool REC = true>
 __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const double *__restrict__ t, int64_t t_bs,
                                                      const double *__restrict__ c, int64_t c_bs, const double *__restrict__ a,
                                                      const double *__restrict__ U, const double *__restrict__ V,
@@ -206,7 +206,8 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
                                                      double2 *__restrict__ Wrec, double2 *__restrict__ DZst,
                                                      const unsigned long long *__restrict__ gate,
                                                      TermsArgsQ TQ = TermsArgsQ{}) {
-  // TT: the coefficient-level form -- `a` is the white-noise diagonal, U / V are not read
+  // TT: the coefficient-level form -- `a` is the white-noise diagonal, U / V are not read.  REC = false: log-likelihood only (no
+  // W rows, (d, z) pairs, checkpoints)
   static_assert(!TT || !LN, "coefficient-level form: no rows to stage");
   if (!open_group(gate, (int64_t)blockIdx.x * SPW)) return;
   constexpr int NV = R / LG;
@@ -414,8 +415,10 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
         w[1] = fma(-ihc[1], th1, vv_[1]) * rd;
         d = dn;
         z = zn;
-        wrp[(size_t)n * kWave] = make_double2(w[0], w[1]);
-        sout[grp][r] = make_double2(d, z);
+        if constexpr (REC) {
+          wrp[(size_t)n * kWave] = make_double2(w[0], w[1]);
+          sout[grp][r] = make_double2(d, z);
+        }
         load_row(r, r + R, n + R, CHECKED);
         fl = ((fl == 0) & (d <= 0.0)) ? (int32_t)n : fl;     // forward.hpp:128 (no early exit: outputs are flagged)
         prod *= d;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
 #pragma unroll
           for (int qq = 0; qq < J; ++qq) { SX[0][qq] *= iX[qq] * ihc[0]; SX[1][qq] *= iX[qq] * ihc[1]; }
           F[0] *= ihc[0]; F[1] *= ihc[1];
-          ck_store(ckw + (size_t)(n / (A * C) - 1) * (kCkD2 * kWave), lane, SX, F);
+          if constexpr (REC) ck_store(ckw + (size_t)(n / (A * C) - 1) * (kCkD2 * kWave), lane, SX, F);
           tref = tn;
           hp[0] = 1.0; hp[1] = 1.0;
         } else {
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
     lds_order();
 #pragma unroll
     for (int m = 0; m < NV; ++m) {   // (slots beyond the batch hold copies of its last series: same values, same addresses)
-      if (!CHECKED || n0 + srow < N) dz8[m][n0 + srow] = sout[ssl[m]][srow];
+      if constexpr (REC) { if (!CHECKED || n0 + srow < N) dz8[m][n0 + srow] = sout[ssl[m]][srow]; }
     }
     vstage(q);
     vload(n0 + 3 * R);
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(kWave, 1) void k_q4_fwd(int64_t B, int64_t N, const
 #pragma unroll
     for (int qq = 0; qq < J; ++qq) { SX[0][qq] *= iX[qq] * il[0]; SX[1][qq] *= iX[qq] * il[1]; }
     F[0] *= il[0]; F[1] *= il[1];
-    ck_store(ckw + (size_t)(nslot - 1) * (kCkD2 * kWave), lane, SX, F);
+    if constexpr (REC) ck_store(ckw + (size_t)(nslot - 1) * (kCkD2 * kWave), lane, SX, F);
   }
   if (L.valid && jl == 0) {
     flag[L.b] = fl;
@@ -961,6 +964,29 @@ int c2_internal_loglik_q4_grad(int64_t B, int64_t N, const double *t, int64_t t_
 #undef C2_Q4_REV_ARGS
   return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
 }
+
+// Coefficient-level forward only: the forward kernel without its records.  `guard`: kGateHeadWords + ceil(B / 64) words, written
+// here (a word is 0 or +inf: the scaled frame of this kernel needs the span test as well, so `words` -- 2 per wavefront -- is
+// scratch for k_anchor_spans).
+int c2_internal_loglik_q4_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac, const double *bc,
+                             const double *dc, const double *c, const double *x, int64_t x_bs, const double *diag, const double *y,
+                             double *ll, int32_t *flag, unsigned long long *words, unsigned long long *guard, c2_stream_t stream) {
+  if (Jc < 0 || Jc > 4 || B < 1 || N < 1) return C2_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const q4::Layout l = q4::layout(B, N);
+  unsigned long long *gate = guard + kGateHeadWords;
+  const dim3 grid((unsigned)l.waves);
+  const q4::TermsArgsQ T{ar, ac, bc, dc, coef_batched, (int)Jc};
+  if (int e = c2_internal_anchor_spans(B, N, q4::J, q4::C, q4::SPW, x, x_bs, c, 8, words, stream)) return e;
+  if (hipMemsetAsync(guard, 0, 8 * kGateHeadWords, s) != hipSuccess) return C2_ERR_HIP;
+  hipLaunchKernelGGL(q4::k_q4_gate_tt, dim3((unsigned)((l.waves + 3) / 4)), dim3(kWave), 0, s, B, N, (int64_t)l.waves,
+                     (const unsigned long long *)words, T, x, x_bs, guard, gate);
+  hipLaunchKernelGGL((q4::k_q4_fwd<false, 16, true, false>), grid, dim3(kWave), 0, s, B, N, x, x_bs, c, (int64_t)8, diag,
+                     (const double *)nullptr, (const double *)nullptr, y, ll, flag, (double2 *)nullptr, l.nslot, (double2 *)nullptr,
+                     (double2 *)nullptr, (const unsigned long long *)gate, T);
+  return hipGetLastError() == hipSuccess ? C2_OK : C2_ERR_HIP;
+}
+size_t c2_internal_loglik_q4_span_words(int64_t B, int64_t N) { return q4::layout(B, N).words; }
 
 // Coefficient-level log-likelihood + gradient (J = Jr + 2 Jc = 8) on this pair, the rows formed in the lanes.  `c`: the rates
 // (B, 8) (c2_terms.hip: k_rates); `rec`, `guard` as above -- a group of 64 series the pair declines (a span beyond the guard,

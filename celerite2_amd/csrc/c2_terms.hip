@@ -237,6 +237,10 @@ size_t c2_internal_loglik_g8_tt_doubles(int64_t B, int64_t N, int64_t J);
 int c2_internal_loglik_g8_tt_ok(int64_t B, int64_t N, int64_t J);
 // ... and with four (c2_loglik_q4.hip: k_q4_fwd / k_q4_rev<..., TT>): the batches between the eight-lane and the two-lane range
 size_t c2_internal_loglik_q4_record_doubles(int64_t B, int64_t N);
+int c2_internal_loglik_q4_tt(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac, const double *bc,
+                             const double *dc, const double *c, const double *x, int64_t x_bs, const double *diag, const double *y,
+                             double *ll, int32_t *flag, unsigned long long *words, unsigned long long *guard, c2_stream_t stream);
+size_t c2_internal_loglik_q4_span_words(int64_t B, int64_t N);
 int c2_internal_loglik_q4_tt_grad(int64_t B, int64_t N, int64_t Jc, int coef_batched, const double *ar, const double *ac,
                                   const double *bc, const double *dc, const double *c, const double *x, int64_t x_bs,
                                   const double *diag, const double *y, double *ll, double *bar, double *bcr, double *bac,
@@ -314,11 +318,12 @@ static bool use_eight_lanes(int64_t B, int64_t N, int64_t J, bool grad) {
 
 // Four lanes per series (J == 8, gradient): C2_TERMS_FOUR_LANES=1 forces, =0 disables; otherwise by batch size (any other forced
 // mapping decides first)
-static bool use_four_lanes(int64_t B, int64_t J) {
+static bool use_four_lanes(int64_t B, int64_t J, bool grad = true) {
   if (J != 8) return false;
   if (c2::opt::has(c2::opt::k_terms_four_lanes)) return c2::opt::ival(c2::opt::k_terms_four_lanes) != 0;
   if (c2::opt::has(c2::opt::k_terms_fused) || c2::opt::has(c2::opt::k_terms_two_lanes) || c2::opt::has(c2::opt::k_terms_eight_lanes))
     return false;
+  if (!grad) return B >= c2::opt::ival(c2::opt::k_terms_four_lanes_min_batch_fwd) && B < c2::opt::ival(c2::opt::k_terms_four_lanes_max_batch_fwd);
   return B >= c2::opt::ival(c2::opt::k_terms_four_lanes_min_batch_grad) && B < c2::opt::ival(c2::opt::k_terms_four_lanes_max_batch_grad);
 }
 
@@ -347,6 +352,7 @@ size_t c2_loglik_terms_workspace_bytes(int64_t B, int64_t N, int64_t Jr, int64_t
     n = fused_gate_words(B) + (r > n ? r : n);
   } else if (!grad && fused_width(J)) {
     n += fused_gate_words(B);   // the group-mapping forward form: one word per group of 64 series in front of the plan
+    if (J == 8) n += al2(c2_internal_loglik_q4_span_words(B, N));   // ... and the four-lane form's span words behind it
   }
   return n * sizeof(double);
 }
@@ -360,7 +366,8 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
     return C2_ERR_INVALID;
   const int64_t J = Jr + 2 * Jc;
   if (work_bytes < c2_loglik_terms_workspace_bytes(B, N, Jr, Jc, 0)) return C2_ERR_INVALID;
-  if (use_eight_lanes(B, N, J, false)) {
+  const bool four_f = use_four_lanes(B, J, false), eight_f = !four_f && use_eight_lanes(B, N, J, false);
+  if (four_f || eight_f) {
     // every lane forms its column of U, V (k_loglik_fwd<..., TT>); a group of 64 series with a phase beyond the branch-free
     // sincos is closed in the gate words and goes through matrices in memory, every kernel of that chain behind the same words
     unsigned long long *guard = (unsigned long long *)work;
@@ -370,7 +377,12 @@ int c2_loglik_terms(int64_t B, int64_t N, int64_t Jr, int64_t Jc, const double *
     hipLaunchKernelGGL(k_rates, dim3((unsigned)((B * J + 255) / 256)), dim3(256), 0, s, B, (int)Jr, (int)Jc, cr, cc, coef_batched,
                        w + p.c, (const unsigned long long *)nullptr);
     if (int e = launch_ok()) return e;
-    if (int e = c2_internal_loglik_g8_tt(B, N, J, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, flag, guard, stream))
+    if (four_f) {
+      unsigned long long *words = (unsigned long long *)(w + p.total);   // (behind the plan: k_anchor_spans' scratch)
+      if (int e = c2_internal_loglik_q4_tt(B, N, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, flag, words, guard, stream))
+        return e;
+    } else if (int e = c2_internal_loglik_g8_tt(B, N, J, Jc, coef_batched, ar, ac, bc, dc, w + p.c, x, x_bs, diag, y, ll, flag, guard,
+                                                stream))
       return e;
     const unsigned long long *gate = c2::gate_per_wave(guard + c2::kGateHeadWords);
     if (int e = matrices(B, N, Jr, Jc, ar, cr, ac, bc, cc, dc, coef_batched, x, x_bs, diag, w, p, gate, s)) return e;

@@ -35,7 +35,7 @@ def force(monkeypatch, which):
     monkeypatch.setenv("C2_TERMS_FUSED", "1" if which == "one" else "0")
     monkeypatch.setenv("C2_TERMS_TWO_LANES", "1" if which == "two" else "0")
     monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "1" if which == "eight" else "0")   # (the gradient at N >= 2; forward any N)
-    monkeypatch.setenv("C2_TERMS_FOUR_LANES", "1" if which == "four" else "0")     # (gradient only)
+    monkeypatch.setenv("C2_TERMS_FOUR_LANES", "1" if which == "four" else "0")
 
 
 def coeffs(B, Jr, Jc, rng):

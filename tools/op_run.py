@@ -1,5 +1,5 @@
 """One op of the device ABI a few times, for profilers: python tools/op_run.py <op> <B> <N> <J> [reps]
-op: loglik | loglik_grad | terms | terms_grad (coefficient-level, bench coefficients) | factor | factor_s | factor_rev | solve_rhs<nrhs> | predict[_var|_cov] | chain (factor_s + solve_lower F + solve_lower_rev + factor_rev)"""
+op: loglik | loglik_grad | terms | terms_grad (coefficient-level, bench coefficients) | factor | factor_s | factor_rev | solve_rhs<nrhs> | rev_rhs<nrhs> (solve_lower_rev) | predict[_var|_cov] | chain (factor_s + solve_lower F + solve_lower_rev + factor_rev)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,11 +32,18 @@ if op.startswith("terms"):
     f = lambda x: torch.from_numpy(np.ascontiguousarray(np.tile(x, ((B + 7) // 8,) + (1,) * (x.ndim - 1))[:B])).to(dev)
     e_ = torch.zeros((B, 0), dtype=torch.float64, device=dev)
     targs = (e_, e_, f(ach), f(bch), f(cch), f(dch), f(th), f(dgh), f(yh))
+revargs = None
+if op.startswith("rev_rhs"):   # rev_rhs<nrhs>: solve_lower_rev with that many right-hand sides
+    d_, Wf, fl_ = ops.factor(t, c, a, U, V)
+    Yq = torch.randn((B, N, int(op[7:])), dtype=torch.float64, device=dev)
+    Zq, Fq = ops.solve_lower(t, c, U, Wf, Yq, workspace=True)
+    revargs = (t, c, U, Wf, Yq, Zq, Fq, torch.ones_like(Zq))
 if op.startswith("solve_rhs"):   # solve_rhs<nrhs>: solve_lower with that many right-hand sides, in place
     d_, Wf, fl_ = ops.factor(t, c, a, U, V)
     Yr = torch.randn((B, N, int(op[9:])), dtype=torch.float64, device=dev)
 def run():
     if Yr is not None: return ops.solve_lower(t, c, U, Wf, Yr, Z=Yr)
+    if revargs is not None: return ops.solve_lower_rev(*revargs)
     if op == "terms": return ops.loglik_terms(*targs)
     if op == "terms_grad": return ops.loglik_terms_grad(*targs)
     if op == "predict_var": return gp.predict(y, ts, return_var=True)

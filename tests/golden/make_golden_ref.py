@@ -238,6 +238,22 @@ def main():
         gp_case(ref, "gp%d_" % b, kernel, xg, dgg, np.sin(xg), ts, 0.3, comp, out)
     xg = np.sort(rng.uniform(0, 10, 120)); ts = np.sort(rng.uniform(-1, 12, 300)); dgg = rng.uniform(0.1, 0.3, 120)
     gp_case(ref, "gprot_", T.RotationTerm(sigma=1.5, period=3.45, Q0=1.3, dQ=1.05, f=0.5), xg, dgg, np.sin(xg), ts, 0.0, None, out)
+    # --- width 8 and width 4 from the COEFFICIENTS (what c2_loglik_terms serves: SURVEY.md section 8f-1): the reference's
+    # get_coefficients() next to its GaussianProcess log-likelihood -- four complex terms; two real + three complex terms;
+    # the rotation term above (two complex terms)
+    xg = np.sort(rng.uniform(0, 20, 200)); ts = np.sort(rng.uniform(-1, 22, 40)); dgg = rng.uniform(0.1, 0.3, 200)
+    k8a = (T.SHOTerm(S0=1.0, w0=0.3, Q=2.0) + T.SHOTerm(S0=0.5, w0=1.1, Q=5.0) + T.SHOTerm(S0=0.3, w0=2.3, Q=1.3)
+           + T.SHOTerm(S0=0.2, w0=3.1, Q=8.0))
+    k8b = (T.RealTerm(a=0.7, c=0.15) + T.RealTerm(a=0.4, c=0.6) + T.SHOTerm(S0=1.0, w0=0.4, Q=3.0)
+           + T.SHOTerm(S0=0.4, w0=1.7, Q=0.9) + T.SHOTerm(S0=0.25, w0=2.9, Q=6.0))
+    for nm, kern in (("gp8a_", k8a), ("gp8b_", k8b)):
+        gp_case(ref, nm, kern, xg, dgg, np.sin(xg) + 0.1 * rng.standard_normal(200), ts, 0.0, None, out)
+        for cn, v in zip(("ar", "cr", "ac", "bc", "cc", "dc"), kern.get_coefficients()):
+            out[nm + "coef_" + cn] = np.asarray(v, dtype=np.float64)
+        assert out[nm + "coef_ar"].size + 2 * out[nm + "coef_ac"].size == 8
+    for cn, v in zip(("ar", "cr", "ac", "bc", "cc", "dc"),
+                     T.RotationTerm(sigma=1.5, period=3.45, Q0=1.3, dQ=1.05, f=0.5).get_coefficients()):
+        out["gprot_coef_" + cn] = np.asarray(v, dtype=np.float64)
     # --- agreement with the round-1 fixtures (oracle/dense.py): same numbers, now produced by reference code -----------
     old = dict(np.load(os.path.join(HERE, "golden.npz")))
     worst = 0.0

@@ -241,6 +241,36 @@ def test_device_gp_vs_reference_rotation_term(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lanes", ["composed", "one", "two", "four", "eight"])
+@pytest.mark.parametrize("case", ["gp8a", "gp8b", "gprot"])
+def test_device_loglik_terms_vs_reference_gaussian_process(golden, monkeypatch, case, lanes):
+    """The coefficient-level entry point (c2_loglik_terms[_grad]) on the REFERENCE's coefficients
+    (`get_coefficients()` of sums of its SHOTerm / RealTerm / RotationTerm: four complex terms; two real + three complex; two
+    complex) against the log-likelihood the reference's numpy GaussianProcess returned for the same series -- through the composed
+    chain and through every kernel that forms the rows in the lanes (one / two / four / eight lanes per series; width 4: one lane
+    and the group of four), 70 copies of the series so that whole and partial groups of 64 are exercised.  The gradient call must
+    return the same log-likelihood; its gradients are pinned against the oracle chain in tests/test_gpu_terms.py."""
+    import torch
+    from celerite2_amd import ops
+    if case == "gprot" and lanes in ("two", "four"):
+        pytest.skip("two / four lanes per series are width-8 mappings")
+    monkeypatch.setenv("C2_TERMS_FUSED", "1" if lanes == "one" else "0")
+    monkeypatch.setenv("C2_TERMS_TWO_LANES", "1" if lanes == "two" else "0")
+    monkeypatch.setenv("C2_TERMS_FOUR_LANES", "1" if lanes == "four" else "0")
+    monkeypatch.setenv("C2_TERMS_EIGHT_LANES", "1" if lanes == "eight" else "0")
+    g = {k[len(case) + 1:]: v for k, v in golden.items() if k.startswith(case + "_")}
+    B = 70
+    rep = lambda v: np.ascontiguousarray(np.tile(np.atleast_1d(v)[None], (B,) + (1,) * np.atleast_1d(v).ndim))
+    args = _dev(*[rep(g["coef_" + cn]) for cn in COEF_NAMES], rep(g["x"]), rep(g["diag"]), rep(g["y"] - g["mean"]))
+    ll, flag = ops.loglik_terms(*args)
+    ll2, grads, flag2 = ops.loglik_terms_grad(*args)
+    assert int(flag.abs().sum()) == 0 and int(flag2.abs().sum()) == 0
+    want = np.full(B, float(g["loglik"]))
+    _close(ll, want); _close(ll2, want)
+    assert all(bool(torch.isfinite(v).all()) for v in grads)
+
+
+@pytest.mark.gpu
 def test_device_general_matmul_vs_reference_k_star(golden):
     """test_driver.py:96-135 on the device: K_star @ Y with K_star = reference kernel.get_value(t - x), and the
     no-diagonal fallback (both grids the data grid, ties everywhere)."""

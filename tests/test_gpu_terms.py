@@ -344,3 +344,41 @@ def test_fused_terms_mixed_groups_and_long_series(ops, oracle, monkeypatch, lane
     close(ll, ll_c.cpu().numpy()); close(ll_f, ll_c.cpu().numpy())
     for a, b in zip(g, g_c):
         close(a, b.cpu().numpy(), tol=1e-9, floor=1e-11)
+
+
+@pytest.mark.parametrize("lanes", ["composed", "one", "two", "four", "eight"])
+def test_loglik_terms_grad_is_graph_capturable(ops, oracle, monkeypatch, lanes):
+    """The coefficient-level gradient is stream-ordered end to end on every mapping -- caller-provided workspace and outputs, the
+    choice between the fused kernels and the composed chain made per group of 64 series on the device -- so one HIP graph captured
+    once replays on new data: new observations, new coefficients, and times whose gaps close the gates of the fused kernels."""
+    import torch
+    rng = np.random.default_rng(91)
+    B, N, Jr, Jc = 70, 150, 2, 3
+    ar, cr, ac, bc, cc, dc = coeffs(B, Jr, Jc, rng)
+    x = np.sort(rng.uniform(0, N * 0.02, (B, N)), axis=1)
+    diag = rng.uniform(0.1, 0.3, (B, N))
+    y = np.sin(x) + 0.1 * rng.standard_normal((B, N))
+    force(monkeypatch, lanes)
+    args = dev(ar, cr, ac, bc, cc, dc, x, diag, y)
+    work = ops.loglik_terms_workspace(B, N, Jr, Jc, args[0].device)
+    ll, out, flag = ops.loglik_terms_grad(*args, work=work)          # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ll_g, out_g, flag_g = ops.loglik_terms_grad(*args, work=work, out=out)
+    for variant in range(3):
+        y2 = y + 0.01 * variant
+        ac2 = ac * (1.0 + 0.05 * variant)
+        x2 = x.copy()
+        if variant == 2:
+            x2[:64, N // 2:] += 500.0      # beyond the backward guard for the first group: the composed chain answers there
+        args[8].copy_(torch.from_numpy(y2)); args[2].copy_(torch.from_numpy(ac2)); args[6].copy_(torch.from_numpy(x2))
+        g.replay()
+        torch.cuda.synchronize()
+        assert int(flag_g.abs().sum()) == 0
+        for b in (0, 5, 63, 64, 69):
+            want = oracle_chain(oracle, ar[b], cr[b], ac2[b], bc[b], cc[b], dc[b], x2[b], diag[b], y2[b])
+            close(ll_g[b:b + 1], np.array([want[0]]))
+            for k, gg in enumerate(out_g):
+                floor = 1e-15 * N * float(np.abs(x2[b]).max()) if NAMES[k] == "bdc" else 1e-10
+                close(gg[b], want[1][k], tol=1e-10, floor=max(floor, 1e-10))
